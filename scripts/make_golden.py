@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own modules.
+
+Runs only in the build container (needs /root/reference); the fixtures it
+writes are plain data (inputs + expected outputs) and travel to the GPU box,
+the reference does not.  Harness-side shims, none of which touch reference files:
+  * ``np.float = float; np.int = int``  (aliases removed in numpy >= 1.24, used at
+    deep_sort/detection.py:30, deep_sort/preprocessing.py:40)
+  * an empty stub ``cv2`` module (deep_sort/preprocessing.py:3 imports it, never uses it)
+
+The per-frame driver below (NMS -> Detection -> predict/update -> count-line) is
+this repo's own restatement of deepdish.py:993-1114; deepdish.py itself cannot
+be imported here (cv2, cameratransform, uvloop, quart, gmqtt, aiofiles absent).
+"""
+import os
+import sys
+import types
+import hashlib
+import numpy as np
+
+REF = os.environ.get('DEEPDISH_REFERENCE', '/root/reference')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+np.float = float
+np.int = int
+sys.modules.setdefault('cv2', types.ModuleType('cv2'))
+sys.path.insert(0, REF)
+
+from deep_sort import kalman_filter, nn_matching, iou_matching, preprocessing, linear_assignment  # noqa: E402
+from deep_sort.tracker import Tracker  # noqa: E402
+from deep_sort.detection import Detection  # noqa: E402
+from tools.intersection import intersection, any_intersection  # noqa: E402
+
+from deepdish_amd.synth import Scene, tracker_scene  # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+os.makedirs(OUT, exist_ok=True)
+
+
+def digest(*arrays):
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return np.frombuffer(h.digest()[:8], dtype=np.uint64)[0]
+
+
+# ----------------------------------------------------------------------------- per-function
+def golden_kalman(n=96, seed=11):
+    rng = np.random.default_rng(seed)
+    kf = kalman_filter.KalmanFilter()
+    rec = {k: [] for k in ('z0', 'init_mean', 'init_cov', 'mean', 'cov', 'pred_mean', 'pred_cov',
+                           'proj_mean', 'proj_cov', 'z', 'upd_mean', 'upd_cov', 'zs', 'd2', 'd2_pos')}
+    for _ in range(n):
+        z0 = np.array([rng.uniform(0, 640), rng.uniform(0, 480), rng.uniform(0.2, 0.9), rng.uniform(40, 200)])
+        m, c = kf.initiate(z0)
+        rec['z0'].append(z0); rec['init_mean'].append(m); rec['init_cov'].append(c)
+        for _ in range(int(rng.integers(0, 6))):       # age the state a little
+            m, c = kf.predict(m, c)
+            if rng.random() < 0.7:
+                m, c = kf.update(m, c, m[:4] + rng.normal(0, [2, 2, 0.01, 2]))
+        rec['mean'].append(m); rec['cov'].append(c)
+        pm, pc = kf.predict(m, c)
+        rec['pred_mean'].append(pm); rec['pred_cov'].append(pc)
+        jm, jc = kf.project(pm, pc)
+        rec['proj_mean'].append(jm); rec['proj_cov'].append(jc)
+        z = pm[:4] + rng.normal(0, [3, 3, 0.02, 3])
+        um, uc = kf.update(pm, pc, z)
+        rec['z'].append(z); rec['upd_mean'].append(um); rec['upd_cov'].append(uc)
+        zs = pm[:4] + rng.normal(0, [8, 8, 0.05, 8], size=(16, 4))
+        rec['zs'].append(zs)
+        rec['d2'].append(kf.gating_distance(pm, pc, zs))
+        rec['d2_pos'].append(kf.gating_distance(pm, pc, zs, only_position=True))
+    np.savez_compressed(os.path.join(OUT, 'kalman.npz'), **{k: np.array(v) for k, v in rec.items()})
+
+
+def golden_iou_nms(seed=12):
+    rng = np.random.default_rng(seed)
+    out = {}
+    a = np.c_[rng.uniform(0, 500, (40, 2)), rng.uniform(10, 120, (40, 2))]
+    b = np.c_[rng.uniform(0, 500, (56, 2)), rng.uniform(10, 120, (56, 2))]
+    b[:20, :2] = a[:20, :2] + rng.uniform(-15, 15, (20, 2))     # some real overlaps
+    out['iou_a'], out['iou_b'] = a, b
+    out['iou'] = np.array([iou_matching.iou(x, b) for x in a])
+    for k in (1, 7, 20, 64, 256, 1000):
+        span = 600 if k <= 64 else (1500 if k == 256 else 2500)
+        boxes = np.c_[rng.integers(0, span, (k, 2)), rng.integers(15, 90, (k, 2))].astype(np.int64)
+        nd = k // 3
+        if nd:
+            src = rng.integers(0, k, nd)
+            boxes[:nd] = boxes[src] + rng.integers(-4, 5, (nd, 4))
+            boxes[:nd, 2:] = np.maximum(boxes[:nd, 2:], 5)
+        scores = rng.permutation(k) / (k + 1.0) * 0.5 + 0.5     # tie-free
+        out[f'nms{k}_boxes'], out[f'nms{k}_scores'] = boxes, scores
+        for thr in (0.6, 0.3, 1.0):
+            out[f'nms{k}_keep_{thr}'] = np.array(
+                preprocessing.non_max_suppression(boxes, thr, scores), dtype=np.int64)
+        out[f'nms{k}_keep_noscore'] = np.array(
+            preprocessing.non_max_suppression(boxes, 0.6, None), dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, 'iou_nms.npz'), **out)
+
+
+def golden_cosine(seed=13):
+    rng = np.random.default_rng(seed)
+    out = {}
+    a = rng.standard_normal((24, 128)).astype(np.float32)
+    b = rng.standard_normal((17, 128)).astype(np.float32)
+    b[:8] = a[:8] + 0.1 * rng.standard_normal((8, 128)).astype(np.float32)
+    out['a'], out['b'] = a, b
+    out['cos'] = nn_matching._cosine_distance(a, b)
+    assert out['cos'].dtype == np.float32
+    metric = nn_matching.NearestNeighborDistanceMetric('cosine', 0.2, None)
+    sizes = rng.integers(1, 40, 12)
+    feats, targets = [], []
+    ident = rng.standard_normal((12, 128)).astype(np.float32)
+    for t, g in enumerate(sizes):
+        f = ident[t] + 0.05 * rng.standard_normal((g, 128)).astype(np.float32)
+        f /= np.linalg.norm(f, axis=1, keepdims=True)
+        feats.append(f.astype(np.float32)); targets += [t + 1] * g
+    gal = np.concatenate(feats)
+    metric.partial_fit(gal, np.array(targets), list(range(1, 13)))
+    q = ident[rng.integers(0, 12, 20)] + 0.05 * rng.standard_normal((20, 128)).astype(np.float32)
+    q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+    out['gallery'], out['gallery_sizes'], out['query'] = gal, sizes, q
+    out['nn_cost'] = metric.distance(q, list(range(1, 13)))
+    np.savez_compressed(os.path.join(OUT, 'cosine.npz'), **out)
+
+
+def golden_intersection(seed=14):
+    rng = np.random.default_rng(seed)
+    f = lambda x: np.array(x, dtype=float)
+    # the six in-tree cases, tools/intersection.py:35-57
+    p1, q1 = f([0, 0]), f([1, 0])
+    fixed = [(p1, q1, f([1, -1]), f([0, 1]), True), (p1, q1, f([1, 2]), f([1, 1]), False),
+             (p1, q1, f([1.01, 0]), f([2, 0]), False), (f([1, 2]), f([1, 1]), f([1, 2]), f([1, 3]), True)]
+    for a, b, c, d, want in fixed:
+        assert intersection(a, b, c, d) == want
+    pts1 = f([[1, 2], [1, 1], [1, -1], [1, -2]]); pts2 = f([[1, 2], [1, 1], [3, 1], [3, -2]])
+    assert any_intersection(p1, q1, pts1) is True and any_intersection(p1, q1, pts2) is False
+    segs = rng.integers(-5, 6, (400, 4, 2)).astype(float)      # many degenerate/collinear cases
+    segs[200:] += rng.uniform(-0.5, 0.5, (200, 4, 2))
+    res = np.array([intersection(*s) for s in segs])
+    np.savez_compressed(os.path.join(OUT, 'intersection.npz'),
+                        fixed=np.array([np.stack(x[:4]) for x in fixed]),
+                        fixed_res=np.array([x[4] for x in fixed]),
+                        pts1=pts1, pts2=pts2, segs=segs, res=res)
+
+
+# ----------------------------------------------------------------------------- sequence level
+class RefCounter:
+    """deepdish.py:1035-1114 + 1303-1312 driven with the reference's intersection()."""
+
+    def __init__(self, line):
+        self.line = line
+        self.db = {}
+        self.pos = self.neg = self.int_ = self.del_ = 0
+
+    def check_deleted(self, track):
+        out = {}
+        i = track.track_id
+        if i in self.db and len(self.db[i]) > 1:
+            if any_intersection(self.line[0], self.line[1], np.array(self.db[i])):
+                l = track.get_label()
+                out[l] = out.get(l, 0) + 1
+            self.db[i] = []
+        return out
+
+    def step(self, tracker):
+        delcounts = {}
+        for t in tracker.deleted_tracks:
+            if t.is_deleted():
+                delcounts = self.check_deleted(t)
+        ev = []
+        for t in tracker.tracks:
+            if not t.is_confirmed() or t.time_since_update > 1:
+                continue
+            self.db.setdefault(t.track_id, [])
+            bb = t.to_tlbr()
+            self.db[t.track_id].append(np.array([(bb[0] + bb[2]) / 2.0, bb[3]]))
+            if len(self.db[t.track_id]) > 1:
+                p1, q1 = self.line
+                p2, q2 = np.array(self.db[t.track_id][-1]), np.array(self.db[t.track_id][-2])
+                cp = np.cross(q1 - p1, q2 - p2)
+                if intersection(p1, q1, p2, q2):
+                    ev.append(cp)
+        for cp in ev:
+            if cp >= 0:
+                self.pos += 1
+            else:
+                self.neg += 1
+            self.int_ += 1
+        for _, d in delcounts.items():
+            self.del_ += d
+
+
+def golden_scene(name, scene, n_frames, max_age=60, keep_inputs=False):
+    metric = nn_matching.NearestNeighborDistanceMetric('cosine', 0.2, None)   # deepdish.py:515-516
+    tracker = Tracker(metric, max_iou_distance=0.7, max_age=max_age)          # deepdish.py:517
+    counter = RefCounter(scene.countline())
+    rows, frame_ptr, keeps, keep_ptr, sums = [], [0], [], [0], []
+    inputs = {}
+    for f in range(n_frames):
+        boxes, scores, who, feats = scene.detections(f)
+        sums.append(digest(boxes, scores, feats))
+        if keep_inputs:
+            inputs[f'boxes_{f}'], inputs[f'scores_{f}'], inputs[f'feats_{f}'] = boxes, scores, feats
+        keep = preprocessing.non_max_suppression(boxes, 0.6, scores)          # deepdish.py:995
+        keeps += list(keep); keep_ptr.append(len(keeps))
+        dets = [Detection(boxes[i], 'person', scores[i], feats[i]) for i in keep]   # deepdish.py:1014
+        tracker.predict(); tracker.update(dets)                               # deepdish.py:1028-1029
+        counter.step(tracker)
+        for t in tracker.tracks:
+            rows.append([t.track_id, t.state, t.time_since_update, t.hits, t.age] + list(t.mean))
+        frame_ptr.append(len(rows))
+    rows = np.array(rows, dtype=np.float64).reshape(-1, 13)
+    np.savez_compressed(
+        os.path.join(OUT, f'scene_{name}.npz'),
+        seed=scene.seed, n_obj=scene.n_obj, W=scene.W, H=scene.H, n_frames=n_frames, max_age=max_age,
+        track_int=rows[:, :5].astype(np.int64), track_mean=rows[:, 5:], frame_ptr=np.array(frame_ptr),
+        nms_keep=np.array(keeps, dtype=np.int64), keep_ptr=np.array(keep_ptr),
+        input_digest=np.array(sums, dtype=np.uint64),
+        counts=np.array([counter.pos, counter.neg, counter.int_, counter.del_], dtype=np.int64),
+        next_id=tracker._next_id, **inputs)
+    print(f'scene_{name}: frames={n_frames} rows={len(rows)} next_id={tracker._next_id} '
+          f'counts(pos,neg,int,del)={counter.pos},{counter.neg},{counter.int_},{counter.del_}')
+
+
+if __name__ == '__main__':
+    golden_kalman()
+    golden_iou_nms()
+    golden_cosine()
+    golden_intersection()
+    golden_scene('n5', Scene(seed=1, n_obj=5, n_frames=100), 100, keep_inputs=True)
+    golden_scene('n20', Scene(seed=0, n_obj=20, n_frames=100), 100)
+    golden_scene('n20_age5', Scene(seed=3, n_obj=20, n_frames=100, p_miss=0.1), 100, max_age=5)
+    golden_scene('n256', tracker_scene(seed=0, n_obj=256, n_frames=40), 40)
+    for fn in sorted(os.listdir(OUT)):
+        print(fn, os.path.getsize(os.path.join(OUT, fn)))
