@@ -1,0 +1,89 @@
+"""ctypes binding of libdeepdish_hip.so (the C ABI declared in include/deepdish_hip.h).
+
+There is deliberately no fallback: if the library is missing or a call fails, this raises.
+"""
+import ctypes
+import os
+from ctypes import c_int, c_int64, c_double, c_float, c_void_p, c_char_p, POINTER
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libdeepdish_hip.so')
+
+P = c_void_p
+
+
+class DeepDishHipError(RuntimeError):
+    pass
+
+
+# name -> argtypes (every function returns int unless listed in _RESTYPE)
+SIGNATURES = {
+    'dd_last_error': [],
+    'dd_version': [],
+    'dd_ctx_create': [c_int, POINTER(P)],
+    'dd_ctx_destroy': [P],
+    'dd_ctx_stream': [P, POINTER(P)],
+    'dd_ctx_sync': [P],
+    'dd_kf_initiate': [P, P, P, P, P, c_int, P],
+    'dd_kf_predict': [P, P, P, P, c_int, P],
+    'dd_kf_project': [P, P, P, P, c_int, P, P, P],
+    'dd_kf_update': [P, P, P, P, P, c_int, P],
+    'dd_kf_gate': [P, P, P, P, c_int, P, c_int, c_int, P, P],
+    'dd_iou_cost': [P, P, P, c_int, P, c_int, P, P],
+    'dd_cosine_nn_cost': [P, P, P, c_int, P, c_int, P, P],
+    'dd_nms': [P, P, P, c_int, c_double, P, P, P],
+    'dd_nms_ssd': [P, P, P, c_int, c_double, P, P, P],
+    'dd_lsap_host': [P, c_int, c_int, P, P],
+    'dd_tracker_create': [P, c_double, c_double, c_int, c_int, c_int, c_int, c_int, POINTER(P)],
+    'dd_tracker_destroy': [P],
+    'dd_tracker_predict': [P],
+    'dd_tracker_update': [P, P, P, c_int, c_int],
+    'dd_tracker_count': [P, c_int, POINTER(c_int)],
+    'dd_tracker_read': [P, c_int, P, P, P],
+    'dd_tracker_next_id': [P, POINTER(c_int64)],
+    'dd_tracker_last_matches': [P, P, c_int, POINTER(c_int)],
+    'dd_crop_resize': [P, P, c_int, c_int, P, c_int, c_int, c_int, P, P, P],
+    'dd_resize_lanczos': [P, P, c_int, c_int, c_int, c_int, P, c_int, c_int, P],
+    'dd_resize_bilinear': [P, P, c_int, c_int, c_int, P, c_int, c_int, P],
+    'dd_net_create': [P, c_char_p, c_int, c_int, c_int, P, c_int64, POINTER(P)],
+    'dd_net_destroy': [P],
+    'dd_net_weight_count': [c_char_p, c_int, c_int, POINTER(c_int64)],
+    'dd_net_forward': [P, P, c_int, P, P],
+    'dd_net_output_shape': [P, POINTER(c_int), POINTER(c_int)],
+    'dd_ssd_postprocess': [P, P, P, c_int, c_int, c_int, c_float, c_float, P, P, P, P, P],
+    'dd_yolov5_decode': [P, P, c_int, c_int, c_float, c_float, c_float, P, P, P, c_int, P, P],
+    'dd_counts_accumulate': [P, P, P, c_int, P],
+}
+_RESTYPE = {'dd_last_error': c_char_p}
+
+_lib = None
+MISSING = []
+
+
+def lib():
+    """Load the shared library once; raise (never fall back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DeepDishHipError(
+            'libdeepdish_hip.so is missing (%s): build it with `python -m deepdish_amd.build`; '
+            'there is no CPU fallback' % LIB_PATH)
+    l = ctypes.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        try:
+            fn = getattr(l, name)
+        except AttributeError:         # header and library out of sync; tests/test_abi.py fails on this
+            MISSING.append(name)
+            continue
+        fn.argtypes = args
+        fn.restype = _RESTYPE.get(name, c_int)
+    _lib = l
+    return l
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = lib().dd_last_error()
+        raise DeepDishHipError('%s failed (%d): %s' % (what or 'libdeepdish_hip call', rc,
+                                                      msg.decode() if msg else '?'))

@@ -1,0 +1,113 @@
+"""Tracker with the reference's surface (deep_sort/tracker.py:10-138 upstream) over the C++/HIP
+tracker of csrc/tracker.hip: `predict()`, `update(detections)`, `.tracks`, `.deleted_tracks`,
+`.kf`, `._next_id`, `.metric`."""
+import ctypes
+import numpy as np
+
+from .._lib import lib, check, P
+from ..runtime import default_context, ptr
+from . import kalman_filter
+from .track import Track
+
+
+class Tracker:
+    def __init__(self, metric, max_iou_distance=0.7, max_age=30, n_init=3, context=None,
+                 track_capacity=1024, gallery_capacity=256):
+        self.metric = metric
+        self.max_iou_distance = max_iou_distance
+        self.max_age = max_age
+        self.n_init = n_init
+        self.ctx = context or default_context()
+        self.kf = kalman_filter.KalmanFilter(self.ctx)
+        self.tracks = []
+        self.deleted_tracks = []
+        self._by_id = {}
+        budget = metric.budget if getattr(metric, 'budget', None) else 0
+        h = P()
+        check(lib().dd_tracker_create(self.ctx.handle, float(metric.matching_threshold), float(max_iou_distance),
+                                      int(max_age), int(n_init), int(budget), int(track_capacity),
+                                      int(gallery_capacity), ctypes.byref(h)), 'dd_tracker_create')
+        self._h = h
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().dd_tracker_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    @property
+    def _next_id(self):
+        v = ctypes.c_int64()
+        check(lib().dd_tracker_next_id(self._h, ctypes.byref(v)), 'dd_tracker_next_id')
+        return v.value
+
+    def predict(self):
+        check(lib().dd_tracker_predict(self._h), 'dd_tracker_predict')
+        for t in self.tracks:                       # host mirror of track.py:124-125
+            t.age += 1
+            t.time_since_update += 1
+            t._covariance = None
+
+    def update(self, detections):
+        n = len(detections)
+        tlwh = np.ascontiguousarray([d.tlwh for d in detections], dtype=np.float64).reshape(n, 4)
+        feats = np.ascontiguousarray([d.feature for d in detections], dtype=np.float32).reshape(n, 128)
+        check(lib().dd_tracker_update(self._h, ptr(tlwh), ptr(feats), 0, n), 'dd_tracker_update')
+        self._refresh(detections)
+
+    def update_arrays(self, tlwh, feats_device, detections=None):
+        """Hot-path variant: tlwh f64 [n,4] on the host, features f32 [n,128] already in HBM."""
+        tlwh = np.ascontiguousarray(tlwh, dtype=np.float64).reshape(-1, 4)
+        n = len(tlwh)
+        check(lib().dd_tracker_update(self._h, ptr(tlwh), ptr(feats_device) if n else None, 1, n),
+              'dd_tracker_update')
+        self._refresh(detections)
+
+    def _read(self, which):
+        n = ctypes.c_int()
+        check(lib().dd_tracker_count(self._h, which, ctypes.byref(n)), 'dd_tracker_count')
+        ints = np.zeros((n.value, 6), dtype=np.int64)
+        means = np.zeros((n.value, 8), dtype=np.float64)
+        if n.value:
+            check(lib().dd_tracker_read(self._h, which, ptr(ints), ptr(means), None), 'dd_tracker_read')
+        return ints, means
+
+    def _refresh(self, detections):
+        live_i, live_m = self._read(0)
+        dead_i, dead_m = self._read(1)
+        by_id = {}
+        out = [[], []]
+        for which, (ints, means) in enumerate(((live_i, live_m), (dead_i, dead_m))):
+            for row, m in zip(ints, means):
+                tid, state, tsu, hits, age, last = (int(v) for v in row)
+                trk = self._by_id.get(tid)
+                det = detections[last] if (detections is not None and last >= 0) else None
+                if trk is None:
+                    trk = Track(m.copy(), None, tid, self.n_init, self.max_age, det or _NO_DET, _owner=self)
+                elif det is not None:
+                    trk._note_update(det)
+                trk.mean, trk._covariance = m.copy(), None
+                trk.state, trk.time_since_update, trk.hits, trk.age = state, tsu, hits, age
+                if which == 0:
+                    by_id[tid] = trk
+                out[which].append(trk)
+        self._by_id = by_id
+        self.tracks, self.deleted_tracks = out
+
+    def _fill_covariances(self):
+        n = len(self.tracks)
+        if n == 0:
+            return
+        covs = np.zeros((n, 64), dtype=np.float64)
+        check(lib().dd_tracker_read(self._h, 0, None, None, ptr(covs)), 'dd_tracker_read')
+        for t, c in zip(self.tracks, covs):
+            t._covariance = c.reshape(8, 8).copy()
+
+
+class _NoDetection:
+    feature, label, confidence = None, None, 0.0
+
+
+_NO_DET = _NoDetection()

@@ -1,0 +1,187 @@
+/* deepdish_hip.h -- C ABI of libdeepdish_hip.so (MI355X / gfx950 only).
+ *
+ * The upstream project (AdaptiveCity/deepdish) is pure Python and has NO FFI: its
+ * hot path is a set of duck-typed Python plugin objects.  This header is therefore
+ * the boundary a maintainer would bind with ctypes; every entry
+ * point cites the reference interface (file:line, relative to the upstream tree)
+ * whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error (DD_E_*); the message of the
+ *     last error on the calling thread is dd_last_error().  Nothing throws.
+ *   - pointers are DEVICE pointers unless the parameter name ends in _host.
+ *   - matrices are dense row-major; f64 = double, f32 = float, boxes are tlwh
+ *     (top-left x, top-left y, width, height) unless stated.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the context's own stream).
+ *     Calls only enqueue work; the caller synchronises, except for *_host outputs,
+ *     which are complete on return.
+ *   - the library never takes ownership of caller memory.
+ */
+#ifndef DEEPDISH_HIP_H
+#define DEEPDISH_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DD_OK            0
+#define DD_E_ARG        -1   /* bad argument (NULL, negative size, capacity exceeded) */
+#define DD_E_HIP        -2   /* a HIP runtime call failed */
+#define DD_E_STATE      -3   /* call order / handle state */
+#define DD_E_CAPACITY   -4   /* a fixed capacity (tracks, boxes, batch) would be exceeded */
+
+#define DD_FEATURE_DIM 128   /* re-ID feature length, tools/freeze_model.py:139-147 */
+
+typedef struct dd_ctx dd_ctx;
+typedef struct dd_tracker dd_tracker;
+typedef struct dd_net dd_net;
+typedef struct dd_pipeline dd_pipeline;
+
+const char *dd_last_error(void);
+int dd_version(void);
+
+/* One context per (thread, device): owns a stream and scratch memory.  The reference
+ * runs the detector and the encoder on different pool threads (deepdish.py:935,1008);
+ * give each its own context. */
+int dd_ctx_create(int device, dd_ctx **out);
+int dd_ctx_destroy(dd_ctx *ctx);
+int dd_ctx_stream(dd_ctx *ctx, void **out_stream);
+int dd_ctx_sync(dd_ctx *ctx);
+
+/* ---------------------------------------------------------------- Kalman filter (f64)
+ * State layout: means[slot][8] = (cx, cy, a, h, vx, vy, va, vh), covs[slot][8][8].
+ * `slots` selects rows of the state arrays (NULL = rows 0..n-1). */
+
+/* deep_sort/kalman_filter.py:55-86  KalmanFilter.initiate */
+int dd_kf_initiate(dd_ctx *ctx, double *means, double *covs, const int *slots,
+                   const double *xyah, int n, void *stream);
+/* deep_sort/kalman_filter.py:88-123  KalmanFilter.predict (Track.predict, track.py:113-125) */
+int dd_kf_predict(dd_ctx *ctx, double *means, double *covs, const int *slots, int n, void *stream);
+/* deep_sort/kalman_filter.py:125-152  KalmanFilter.project -> proj_mean[n][4], proj_cov[n][4][4] */
+int dd_kf_project(dd_ctx *ctx, const double *means, const double *covs, const int *slots, int n,
+                  double *proj_mean, double *proj_cov, void *stream);
+/* deep_sort/kalman_filter.py:154-186  KalmanFilter.update; pair i updates slots[i] with xyah[i] */
+int dd_kf_update(dd_ctx *ctx, double *means, double *covs, const int *slots,
+                 const double *xyah, int n, void *stream);
+/* deep_sort/kalman_filter.py:188-229  KalmanFilter.gating_distance for every (track, detection):
+ * out_d2[n][n_det] squared Mahalanobis distance; only_position != 0 uses (cx, cy) only. */
+int dd_kf_gate(dd_ctx *ctx, const double *means, const double *covs, const int *slots, int n,
+               const double *xyah, int n_det, int only_position, double *out_d2, void *stream);
+
+/* ---------------------------------------------------------------- cost matrices */
+
+/* deep_sort/iou_matching.py:7-39 iou + :42-81 iou_cost: out[n_t][n_d] = 1 - IoU (no +1 pixel).
+ * rows with tsu[i] > 1 are filled with 1e5 (tsu may be NULL). */
+int dd_iou_cost(dd_ctx *ctx, const double *tlwh_t, const int *tsu, int n_t,
+                const double *tlwh_d, int n_d, double *out, void *stream);
+
+/* deep_sort/nn_matching.py:31-54,78-96,156-177: per target t, min over its gallery rows of
+ * (1 - a.b) with a, b L2-normalised in f32; result widened to f64 as nn_matching.py:174-176.
+ * Target t owns gallery rows [offsets[t], offsets[t+1]).  out[n_t][n_d]. */
+int dd_cosine_nn_cost(dd_ctx *ctx, const float *gallery, const int *offsets_host, int n_t,
+                      const float *feats, int n_d, double *out, void *stream);
+
+/* deep_sort/preprocessing.py:6-73 non_max_suppression (greedy, +1 pixel, inter/area_other > thr).
+ * `keys` is the sort key (scores, or y2 when the reference is called with scores=None).
+ * out_idx[k] receives the surviving indices in pick order, *out_n their number (both device). */
+int dd_nms(dd_ctx *ctx, const double *tlwh, const double *keys, int k, double max_overlap,
+           int *out_idx, int *out_n, void *stream);
+
+/* tools/ssd_mobilenet.py:59-98 nms_boxes for ONE class: xyxy boxes, IoU with +1 on the
+ * intersection only, keep while IoU <= thr. Same outputs as dd_nms. */
+int dd_nms_ssd(dd_ctx *ctx, const double *xyxy, const double *scores, int k, double iou_thr,
+               int *out_idx, int *out_n, void *stream);
+
+/* scipy.optimize.linear_sum_assignment as called at deep_sort/linear_assignment.py:58
+ * (scipy is a third-party dependency of the reference; rectangular shortest-augmenting-path,
+ * Crouse 2016).  Host code.  row_ind/col_ind get min(nr,nc) pairs sorted by row. */
+int dd_lsap_host(const double *cost_host, int nr, int nc, int *row_ind_host, int *col_ind_host);
+
+/* ---------------------------------------------------------------- tracker (state in HBM)
+ * deep_sort/tracker.py:40-138 Tracker + track.py:67-196 Track state machine +
+ * linear_assignment.py:11-190 (threshold, LSAP, cascade, gating) + nn_matching.py:137-154
+ * partial_fit.  Kalman state and the appearance gallery live in device memory; the integer
+ * book-keeping (ids, states, hits, age, time_since_update) lives on the host. */
+int dd_tracker_create(dd_ctx *ctx, double max_cosine_distance, double max_iou_distance,
+                      int max_age, int n_init, int nn_budget /* <=0: None */,
+                      int track_capacity, int gallery_capacity, dd_tracker **out);
+int dd_tracker_destroy(dd_tracker *trk);
+/* tracker.py:51-57 */
+int dd_tracker_predict(dd_tracker *trk);
+/* tracker.py:59-93.  tlwh_host[n][4] f64; feats[n][128] f32 on device when feats_on_device,
+ * else on the host. */
+int dd_tracker_update(dd_tracker *trk, const double *tlwh_host, const float *feats,
+                      int feats_on_device, int n);
+/* which: 0 = tracker.tracks, 1 = tracker.deleted_tracks (tracker.py:80-81) */
+int dd_tracker_count(dd_tracker *trk, int which, int *out_n_host);
+/* Any output pointer may be NULL.  ints6[n][6] = (track_id, state, time_since_update, hits, age,
+ * index of the detection that updated or founded the track in the last update, else -1);
+ * means[n][8], covs[n][64]. */
+int dd_tracker_read(dd_tracker *trk, int which, int64_t *ints6_host, double *means_host,
+                    double *covs_host);
+int dd_tracker_next_id(dd_tracker *trk, int64_t *out_host);
+/* Rows of tracker.tracks reassigned by the host (deepdish.py:1047) are not supported: the
+ * identity pass-through of framerecords.py:183 is the only behaviour reproduced. */
+
+/* last association, for parity tests: matches[m][2] = (track row, detection), in update order */
+int dd_tracker_last_matches(dd_tracker *trk, int *pairs_host, int cap, int *out_m_host);
+
+/* ---------------------------------------------------------------- crops
+ * tools/generate_detections.py:40-84 extract_image_patch for every box (integer box math on the
+ * host side of the call, bilinear u8 resample as cv2.resize INTER_LINEAR on the device).
+ * frame: u8 [H][W][3] BGR.  boxes_host: int64 tlwh [n][4] exactly as the reference receives them.
+ * out: u8 [n][ph][pw][3].  valid_host[i] = 0 where the reference would return None. */
+int dd_crop_resize(dd_ctx *ctx, const uint8_t *frame, int H, int W, const int64_t *boxes_host,
+                   int n, int ph, int pw, uint8_t *out, int *valid_host, void *stream);
+
+/* PIL Image.resize(LANCZOS) of an RGB(A) u8 image as tools/ssd_mobilenet.py:54-57 and
+ * tools/yolov5.py:99 call it (stretch, no letterbox).  src u8 [H][W][src_c] (first 3 channels
+ * used, optionally swapped BGR->RGB), dst u8 [h][w][3]. */
+int dd_resize_lanczos(dd_ctx *ctx, const uint8_t *src, int H, int W, int src_c, int swap_rb,
+                      uint8_t *dst, int h, int w, void *stream);
+/* cv2.resize INTER_LINEAR stretch as tools/tflite_object_detector.py:211 */
+int dd_resize_bilinear(dd_ctx *ctx, const uint8_t *src, int H, int W, int c,
+                       uint8_t *dst, int h, int w, void *stream);
+
+/* ---------------------------------------------------------------- networks
+ * Weights come as one f32 blob in the order documented in deepdish_amd/nets.py (BN folded by the
+ * loader).  kind: "mars" (tools/freeze_model.py:88-157 + generate_detections.py:151-177),
+ * "ssd_mobilenet_v1" (tools/ssd_mobilenet.py:31-52,100-109), "yolov5s"
+ * (detectors/yolov5/yolov5s.yaml + tools/yolov5.py:71-109). */
+int dd_net_create(dd_ctx *ctx, const char *kind, int in_h, int in_w, int max_batch,
+                  const float *weights_host, int64_t n_weights, dd_net **out);
+int dd_net_destroy(dd_net *net);
+int dd_net_weight_count(const char *kind, int in_h, int in_w, int64_t *out_host);
+/* input u8 [n][in_h][in_w][3] (BGR for "mars" as generate_detections.py:168, RGB otherwise).
+ * "mars": out f32 [n][128] unit-norm features.
+ * "ssd_mobilenet_v1": out f32 [n][n_anchors][4 + n_classes] raw box encodings + class logits.
+ * "yolov5s": out f32 [n][n_rows][85] as tools/yolov5.py:109 reads it. */
+int dd_net_forward(dd_net *net, const uint8_t *input, int n, float *out, void *stream);
+int dd_net_output_shape(dd_net *net, int *rows_host, int *cols_host);
+
+/* TFLite_Detection_PostProcess (inside the reference's .tflite graph, tools/ssd_mobilenet.py:103-109):
+ * anchor decode, sigmoid, per-class NMS, top max_det.  raw f32 [n_anchors][4+n_classes] ->
+ * boxes f32 [max_det][4] (ymin,xmin,ymax,xmax normalised), classes f32, scores f32, count. */
+int dd_ssd_postprocess(dd_ctx *ctx, const float *raw, const float *anchors, int n_anchors,
+                       int n_classes, int max_det, float score_thr, float iou_thr,
+                       float *boxes, float *classes, float *scores, int *count, void *stream);
+
+/* tools/yolov5.py:120-131: xywh->xyxy, cls*=obj, argmax, conf >= thr, scale to image.
+ * raw f32 [n_rows][5+n_cls] -> out_boxes f32 [cap][4] xyxy pixels, out_scores, out_cls, *out_n
+ * (rows in ascending row order, like np.where). */
+int dd_yolov5_decode(dd_ctx *ctx, const float *raw, int n_rows, int n_cls, float thr,
+                     float img_w, float img_h, float *out_boxes, float *out_scores,
+                     int *out_cls, int cap, int *out_n, void *stream);
+
+/* ---------------------------------------------------------------- multi-GPU
+ * Sum of the per-stream count vectors (pos, neg, int, del per label; deepdish.py:1141-1145).
+ * The collective itself is issued by the host through torch.distributed (RCCL); this entry
+ * only packs/accumulates the int64 vector on the device. */
+int dd_counts_accumulate(dd_ctx *ctx, int64_t *acc, const int64_t *counts_host, int n, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEEPDISH_HIP_H */
