@@ -45,11 +45,12 @@ SIGNATURES = {
     'dd_crop_resize': [P, P, c_int, c_int, P, c_int, c_int, c_int, P, P, P],
     'dd_resize_lanczos': [P, P, c_int, c_int, c_int, c_int, P, c_int, c_int, P],
     'dd_resize_bilinear': [P, P, c_int, c_int, c_int, P, c_int, c_int, P],
-    'dd_net_create': [P, c_char_p, c_int, c_int, c_int, P, c_int64, POINTER(P)],
+    'dd_net_create': [P, P, c_int, P, c_int64, c_int, POINTER(P)],
     'dd_net_destroy': [P],
-    'dd_net_weight_count': [c_char_p, c_int, c_int, POINTER(c_int64)],
-    'dd_net_forward': [P, P, c_int, P, P],
-    'dd_net_output_shape': [P, POINTER(c_int), POINTER(c_int)],
+    'dd_net_forward': [P, P, c_int, P],
+    'dd_net_output': [P, c_int, POINTER(P), POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int),
+                      POINTER(c_int)],
+    'dd_net_read': [P, c_int, c_int, P, c_int, P],
     'dd_ssd_postprocess': [P, P, P, c_int, c_int, c_int, c_float, c_float, P, P, P, P, P],
     'dd_yolov5_decode': [P, P, c_int, c_int, c_float, c_float, c_float, P, P, P, c_int, P, P],
     'dd_counts_accumulate': [P, P, P, c_int, P],

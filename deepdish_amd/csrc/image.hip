@@ -1,0 +1,291 @@
+// Image front-end kernels (u8, integer arithmetic, HBM/L2-bound):
+//   * crop + bilinear resize of detection boxes   tools/generate_detections.py:40-84 (cv2.resize)
+//   * Lanczos stretch resize                      tools/ssd_mobilenet.py:54-57, tools/yolov5.py:99 (PIL)
+//   * bilinear stretch resize                     tools/tflite_object_detector.py:207-211 (cv2.resize)
+// Frames are BGR u8 [H][W][3]; adjacent lanes walk adjacent output pixels of one row, so loads of a
+// source row are contiguous and the 9..15 taps of neighbouring outputs hit in L1/L2.
+#include <cmath>
+#include <map>
+#include <mutex>
+#include "common.h"
+
+namespace {
+
+constexpr int PRECISION_BITS = 32 - 8 - 2;       // Pillow Resample.c
+
+// ------------------------------------------------------------------ cv2 INTER_LINEAR on u8
+// OpenCV resize.cpp: coordinates in float, coefficients rounded to 11-bit shorts.
+__device__ __forceinline__ void lin_coeff(int d, int dst, int src, int &s, int &a0, int &a1) {
+    const double scale = 1.0 / ((double)dst / (double)src);
+    float f = (float)((d + 0.5) * scale - 0.5);
+    int si = (int)floorf(f);
+    f -= (float)si;
+    if (si < 0) { f = 0.f; si = 0; }
+    if (si >= src - 1) { f = 0.f; si = src - 1; }
+    s = si;
+    a0 = (int)rintf((1.f - f) * 2048.f);
+    a1 = (int)rintf(f * 2048.f);
+}
+
+struct CropBox { int sx, sy, cw, ch; };           // cw <= 0 marks a box the reference rejects
+
+// grid (ceil(oh*ow/256), n); one thread per output pixel (3 channels).
+__global__ __launch_bounds__(256) void crop_resize_k(const uint8_t *__restrict__ frame, int W,
+                                                     const CropBox *__restrict__ boxes, int oh, int ow,
+                                                     uint8_t *__restrict__ out) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= oh * ow) return;
+    const CropBox b = boxes[blockIdx.y];
+    uint8_t *o = out + ((size_t)blockIdx.y * oh * ow + p) * 3;
+    if (b.cw <= 0) { o[0] = o[1] = o[2] = 0; return; }
+    const int dy = p / ow, dx = p - dy * ow;
+    const uint8_t *base = frame + ((size_t)b.sy * W + b.sx) * 3;
+    const size_t rs = (size_t)W * 3;
+    if (b.cw == 2 * ow && b.ch == 2 * oh) {       // exact 2x decimation: INTER_AREA shortcut
+        const uint8_t *r0 = base + (size_t)(2 * dy) * rs + (size_t)(2 * dx) * 3, *r1 = r0 + rs;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[c] = (uint8_t)((r0[c] + r0[c + 3] + r1[c] + r1[c + 3] + 2) >> 2);
+        return;
+    }
+    int sx, xa0, xa1, sy, ya0, ya1;
+    lin_coeff(dx, ow, b.cw, sx, xa0, xa1);
+    lin_coeff(dy, oh, b.ch, sy, ya0, ya1);
+    const int sx1 = min(sx + 1, b.cw - 1), sy1 = min(sy + 1, b.ch - 1);
+    const uint8_t *r0 = base + (size_t)sy * rs, *r1 = base + (size_t)sy1 * rs;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int h0 = r0[sx * 3 + c] * xa0 + r0[sx1 * 3 + c] * xa1;      // scale 2^11
+        const int h1 = r1[sx * 3 + c] * xa0 + r1[sx1 * 3 + c] * xa1;
+        const int v = (((ya0 * (h0 >> 4)) >> 16) + ((ya1 * (h1 >> 4)) >> 16) + 2) >> 2;
+        o[c] = (uint8_t)min(max(v, 0), 255);
+    }
+}
+
+// ------------------------------------------------------------------ Pillow Lanczos, 2 passes
+// Horizontal: src [H][W][src_c] -> tmp [H][w][3]; one thread per (y, xx).
+__global__ __launch_bounds__(256) void lanczos_h_k(const uint8_t *__restrict__ src, int H, int W, int src_c,
+                                                   int swap_rb, const int *__restrict__ bounds,
+                                                   const int *__restrict__ kk, int ksize, int w,
+                                                   uint8_t *__restrict__ tmp) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= H * w) return;
+    const int y = idx / w, xx = idx - y * w;
+    const int xmin = bounds[2 * xx], n = bounds[2 * xx + 1];
+    const int *k = kk + (size_t)xx * ksize;
+    const uint8_t *row = src + ((size_t)y * W + xmin) * src_c;
+    int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0;
+    for (int x = 0; x < n; ++x) {
+        const int kv = k[x];
+        a0 += row[x * src_c + 0] * kv;
+        a1 += row[x * src_c + 1] * kv;
+        a2 += row[x * src_c + 2] * kv;
+    }
+    if (swap_rb) { const int t = a0; a0 = a2; a2 = t; }
+    uint8_t *o = tmp + (size_t)idx * 3;
+    o[0] = (uint8_t)min(max(a0 >> PRECISION_BITS, 0), 255);
+    o[1] = (uint8_t)min(max(a1 >> PRECISION_BITS, 0), 255);
+    o[2] = (uint8_t)min(max(a2 >> PRECISION_BITS, 0), 255);
+}
+
+// Vertical: tmp [H][w*3] -> dst [h][w*3]; one thread per output byte, coalesced along the row.
+__global__ __launch_bounds__(256) void lanczos_v_k(const uint8_t *__restrict__ tmp, int rowbytes,
+                                                   const int *__restrict__ bounds, const int *__restrict__ kk,
+                                                   int ksize, int h, uint8_t *__restrict__ dst) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= h * rowbytes) return;
+    const int yy = idx / rowbytes, xb = idx - yy * rowbytes;
+    const int ymin = bounds[2 * yy], n = bounds[2 * yy + 1];
+    const int *k = kk + (size_t)yy * ksize;
+    int acc = 1 << (PRECISION_BITS - 1);
+    const uint8_t *col = tmp + (size_t)ymin * rowbytes + xb;
+    for (int y = 0; y < n; ++y) acc += col[(size_t)y * rowbytes] * k[y];
+    dst[idx] = (uint8_t)min(max(acc >> PRECISION_BITS, 0), 255);
+}
+
+__global__ __launch_bounds__(256) void copy_rgb_k(const uint8_t *__restrict__ src, int n_px, int src_c, int swap_rb,
+                                                  uint8_t *__restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_px) return;
+    const uint8_t *s = src + (size_t)i * src_c;
+    uint8_t *d = dst + (size_t)i * 3;
+    d[0] = s[swap_rb ? 2 : 0]; d[1] = s[1]; d[2] = s[swap_rb ? 0 : 2];
+}
+
+// Host: Pillow precompute_coeffs + normalize_coeffs_8bpc (double math on the host so that sin()
+// is the same libm the reference's Pillow uses; the device only sees integers).
+struct LanczosTable {
+    int ksize = 0;
+    std::vector<int> bounds, kk;
+};
+
+double sinc_(double x) { if (x == 0.0) return 1.0; x *= M_PI; return sin(x) / x; }
+double lanczos_(double x) { return (-3.0 <= x && x < 3.0) ? sinc_(x) * sinc_(x / 3) : 0.0; }
+
+LanczosTable make_table(int in_size, int out_size) {
+    LanczosTable t;
+    double scale = (double)in_size / out_size, filterscale = scale;
+    if (filterscale < 1.0) filterscale = 1.0;
+    const double support = 3.0 * filterscale;
+    t.ksize = (int)ceil(support) * 2 + 1;
+    t.bounds.assign((size_t)out_size * 2, 0);
+    t.kk.assign((size_t)out_size * t.ksize, 0);
+    const double ss = 1.0 / filterscale;
+    std::vector<double> w(t.ksize);
+    for (int xx = 0; xx < out_size; ++xx) {
+        const double center = (xx + 0.5) * scale;
+        int xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > in_size) xmax = in_size;
+        xmax -= xmin;
+        double ww = 0.0;
+        for (int x = 0; x < xmax; ++x) { w[x] = lanczos_((x + xmin - center + 0.5) * ss); ww += w[x]; }
+        for (int x = 0; x < xmax; ++x) {
+            const double v = ww != 0.0 ? w[x] / ww : w[x];
+            t.kk[(size_t)xx * t.ksize + x] = v < 0 ? (int)(-0.5 + v * (1 << PRECISION_BITS))
+                                                   : (int)(0.5 + v * (1 << PRECISION_BITS));
+        }
+        t.bounds[2 * xx] = xmin;
+        t.bounds[2 * xx + 1] = xmax;
+    }
+    return t;
+}
+
+struct DevTable { int ksize; int *bounds; int *kk; };
+std::mutex g_tab_mu;
+std::map<std::tuple<int, int, int>, DevTable> g_tabs;     // (device, in, out) -> device-resident table
+
+int get_table(int device, int in_size, int out_size, DevTable *out) {
+    std::lock_guard<std::mutex> lk(g_tab_mu);
+    auto key = std::make_tuple(device, in_size, out_size);
+    auto it = g_tabs.find(key);
+    if (it == g_tabs.end()) {
+        LanczosTable t = make_table(in_size, out_size);
+        DevTable d;
+        d.ksize = t.ksize;
+        DD_HIP(hipMalloc(&d.bounds, t.bounds.size() * sizeof(int)));
+        DD_HIP(hipMalloc(&d.kk, t.kk.size() * sizeof(int)));
+        DD_HIP(hipMemcpy(d.bounds, t.bounds.data(), t.bounds.size() * sizeof(int), hipMemcpyHostToDevice));
+        DD_HIP(hipMemcpy(d.kk, t.kk.data(), t.kk.size() * sizeof(int), hipMemcpyHostToDevice));
+        it = g_tabs.emplace(key, d).first;
+    }
+    *out = it->second;
+    return DD_OK;
+}
+
+}  // namespace
+
+namespace ddk {
+
+// tools/generate_detections.py:63-80 on the host: int64 tlwh -> clipped crop rectangle.
+// Returns 1 when the reference would extract a patch, 0 when it returns None.
+int crop_box_host(const int64_t *b, int ph, int pw, int H, int W, int *sx, int *sy, int *cw, int *ch) {
+    int64_t x = b[0], y = b[1], w = b[2], h = b[3];
+    const double aspect = (double)pw / ph;
+    const double new_width = aspect * (double)h;
+    x = (int64_t)((double)x - (new_width - (double)w) / 2);     // in-place int64 store truncates
+    w = (int64_t)new_width;
+    int64_t x2 = x + w, y2 = y + h;
+    if (x < 0) x = 0;
+    if (y < 0) y = 0;
+    if (x2 > W - 1) x2 = W - 1;
+    if (y2 > H - 1) y2 = H - 1;
+    if (x >= x2 || y >= y2) { *sx = *sy = 0; *cw = *ch = 0; return 0; }
+    *sx = (int)x; *sy = (int)y; *cw = (int)(x2 - x); *ch = (int)(y2 - y);
+    return 1;
+}
+
+int crop_resize(hipStream_t s, const uint8_t *frame, int W, const void *d_boxes, int n, int oh, int ow,
+                uint8_t *out) {
+    if (n <= 0) return DD_OK;
+    hipLaunchKernelGGL(crop_resize_k, dim3(dd_ceil_div(oh * ow, 256), n), dim3(256), 0, s, frame, W,
+                       static_cast<const CropBox *>(d_boxes), oh, ow, out);
+    DD_LAUNCH_CHECK();
+    return DD_OK;
+}
+
+// tmp must hold H*w*3 bytes.
+int resize_lanczos(hipStream_t s, int device, const uint8_t *src, int H, int W, int src_c, int swap_rb,
+                   uint8_t *dst, int h, int w, uint8_t *tmp) {
+    const uint8_t *mid = src;
+    int mid_c = src_c;
+    if (w != W) {
+        DevTable th;
+        int rc = get_table(device, W, w, &th);
+        if (rc != DD_OK) return rc;
+        uint8_t *o = (h != H) ? tmp : dst;
+        hipLaunchKernelGGL(lanczos_h_k, dim3(dd_ceil_div(H * w, 256)), dim3(256), 0, s, src, H, W, src_c, swap_rb,
+                           th.bounds, th.kk, th.ksize, w, o);
+        DD_LAUNCH_CHECK();
+        mid = o;
+        mid_c = 3;
+    } else if (src_c != 3 || swap_rb) {
+        uint8_t *o = (h != H) ? tmp : dst;
+        hipLaunchKernelGGL(copy_rgb_k, dim3(dd_ceil_div(H * W, 256)), dim3(256), 0, s, src, H * W, src_c, swap_rb, o);
+        DD_LAUNCH_CHECK();
+        mid = o;
+        mid_c = 3;
+    }
+    if (h != H) {
+        DevTable tv;
+        int rc = get_table(device, H, h, &tv);
+        if (rc != DD_OK) return rc;
+        hipLaunchKernelGGL(lanczos_v_k, dim3(dd_ceil_div(h * w * 3, 256)), dim3(256), 0, s, mid, w * 3, tv.bounds,
+                           tv.kk, tv.ksize, h, dst);
+        DD_LAUNCH_CHECK();
+    } else if (mid != dst) {
+        DD_HIP(hipMemcpyAsync(dst, mid, (size_t)H * w * mid_c, hipMemcpyDeviceToDevice, s));
+    }
+    return DD_OK;
+}
+
+}  // namespace ddk
+
+extern "C" {
+
+int dd_crop_resize(dd_ctx *ctx, const uint8_t *frame, int H, int W, const int64_t *boxes_host, int n, int ph,
+                   int pw, uint8_t *out, int *valid_host, void *stream) {
+    DD_REQUIRE(ctx && n >= 0 && H > 0 && W > 0 && ph > 0 && pw > 0, DD_E_ARG, "dd_crop_resize: bad argument");
+    if (n == 0) return DD_OK;
+    DD_REQUIRE(frame && boxes_host && out, DD_E_ARG, "dd_crop_resize: NULL argument");
+    hipStream_t s = dd_pick_stream(ctx, stream);
+    int rc;
+    if ((rc = ctx->pin[1].reserve((size_t)n * 16)) != DD_OK) return rc;
+    if ((rc = ctx->scratch[3].reserve((size_t)n * 16)) != DD_OK) return rc;
+    int *hb = ctx->pin[1].as<int>();
+    for (int i = 0; i < n; ++i) {
+        const int ok = ddk::crop_box_host(boxes_host + (size_t)i * 4, ph, pw, H, W, hb + 4 * i, hb + 4 * i + 1,
+                                          hb + 4 * i + 2, hb + 4 * i + 3);
+        if (valid_host) valid_host[i] = ok;
+    }
+    DD_HIP(hipMemcpyAsync(ctx->scratch[3].p, hb, (size_t)n * 16, hipMemcpyHostToDevice, s));
+    DD_HIP(hipStreamSynchronize(s));                        // the pinned block is reused by the next call
+    return ddk::crop_resize(s, frame, W, ctx->scratch[3].p, n, ph, pw, out);
+}
+
+int dd_resize_lanczos(dd_ctx *ctx, const uint8_t *src, int H, int W, int src_c, int swap_rb, uint8_t *dst, int h,
+                      int w, void *stream) {
+    DD_REQUIRE(ctx && src && dst && H > 0 && W > 0 && h > 0 && w > 0, DD_E_ARG, "dd_resize_lanczos: bad argument");
+    DD_REQUIRE(src_c == 3 || src_c == 4, DD_E_ARG, "dd_resize_lanczos: src_c must be 3 or 4");
+    int rc;
+    if ((rc = ctx->scratch[3].reserve((size_t)H * w * 3 + 64)) != DD_OK) return rc;
+    return ddk::resize_lanczos(dd_pick_stream(ctx, stream), ctx->device, src, H, W, src_c, swap_rb, dst, h, w,
+                               ctx->scratch[3].as<uint8_t>());
+}
+
+int dd_resize_bilinear(dd_ctx *ctx, const uint8_t *src, int H, int W, int c, uint8_t *dst, int h, int w,
+                       void *stream) {
+    DD_REQUIRE(ctx && src && dst && H > 0 && W > 0 && h > 0 && w > 0, DD_E_ARG, "dd_resize_bilinear: bad argument");
+    DD_REQUIRE(c == 3, DD_E_ARG, "dd_resize_bilinear: 3-channel images only");
+    hipStream_t s = dd_pick_stream(ctx, stream);
+    int rc;
+    if ((rc = ctx->pin[1].reserve(16)) != DD_OK) return rc;
+    if ((rc = ctx->scratch[3].reserve(16)) != DD_OK) return rc;
+    int *hb = ctx->pin[1].as<int>();
+    hb[0] = 0; hb[1] = 0; hb[2] = W; hb[3] = H;
+    DD_HIP(hipMemcpyAsync(ctx->scratch[3].p, hb, 16, hipMemcpyHostToDevice, s));
+    DD_HIP(hipStreamSynchronize(s));
+    return ddk::crop_resize(s, src, W, ctx->scratch[3].p, 1, h, w, dst);
+}
+
+}  // extern "C"

@@ -1,0 +1,646 @@
+// Convolutional network executor for the detector / re-ID encoder forward passes.
+//
+// Replaces tflite_runtime.Interpreter.invoke() at tools/ssd_mobilenet.py:102-109,
+// tools/yolov5.py:107-109 and tools/generate_detections.py:169-171 (upstream paths).  The host
+// (deepdish_amd/nets.py) compiles a model into a flat op program + one weight blob -- the analogue
+// of the reference's .tflite file -- and this file runs it:
+//   * activations NHWC f16 in HBM (channel stride padded to 8 so every tap is one 16-byte load),
+//   * dense convs as implicit GEMM on v_mfma_f32_16x16x32_f16 (f32 accumulate): weights are the A
+//     operand (rows = output channels) and pixels the B operand, so each lane ends up holding four
+//     consecutive output channels of one pixel and the fused epilogue (bias, activation, residual,
+//     second affine+ELU output, SSD / YOLO head scatter) stores 8 or 16 bytes per lane,
+//   * operand tiles staged through double-buffered LDS (80-byte padded rows, ds_read_b128),
+//   * depthwise 3x3, pooling, upsampling, input conversion as 16-byte-per-lane streaming kernels.
+#include <cmath>
+#include <string>
+#include "common.h"
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+enum { OP_INPUT = 1, OP_CONV = 2, OP_DWCONV = 3, OP_MAXPOOL = 4, OP_UPSAMPLE = 5, OP_FC = 6, OP_L2NORM = 7 };
+enum { ACT_NONE = 0, ACT_RELU6 = 1, ACT_ELU = 2, ACT_SILU = 3, ACT_RELU = 4, ACT_SIGMOID = 5 };
+enum { EPI_F16 = 0, EPI_F32 = 1, EPI_SSD_HEAD = 2, EPI_YOLO = 3 };
+enum { DT_F16 = 0, DT_F32 = 1, DT_U8 = 2 };
+
+constexpr int OP_WORDS = 48;       // int32 words per op record (see deepdish_amd/nets.py)
+constexpr int TENSOR_WORDS = 8;
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case ACT_RELU6: return fminf(fmaxf(v, 0.f), 6.f);
+        case ACT_ELU: return v > 0.f ? v : expm1f(v);
+        case ACT_SILU: return v / (1.f + __expf(-v));
+        case ACT_RELU: return fmaxf(v, 0.f);
+        case ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+        default: return v;
+    }
+}
+
+struct ConvP {
+    const _Float16 *in; int H, W, cs_in, coff_in, cin;
+    const _Float16 *w; const float *bias; int kpad;
+    int kh, kw, stride, pad_t, pad_l;
+    int ho, wo, cout, m;
+    int act;
+    void *out; int cs_out, coff_out, epi;
+    const _Float16 *res; int cs_res, coff_res;
+    _Float16 *out2; int cs_out2, coff_out2; const float *aff2; int cout_pad;
+    int p[6]; float f[8];
+};
+
+constexpr int LDS_ROW = 40;        // halves per staged row: 32 data + 8 pad (80 bytes)
+
+// Block tile: (WM*MI*16) pixels x (WN*NI*16) output channels, K step 32.
+template <int WM, int WN, int MI, int NI>
+__global__ __launch_bounds__(WM *WN * 64) void conv_mfma_k(const ConvP P) {
+    constexpr int T = WM * WN * 64;
+    constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
+    constexpr int XCH = (BM * 4 + T - 1) / T, WCH = (BN * 4 + T - 1) / T;
+    __shared__ __attribute__((aligned(16))) _Float16 lds[2 * (BM + BN) * LDS_ROW];
+    _Float16 *xs = lds, *ws = lds + 2 * BM * LDS_ROW;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int hw = P.ho * P.wo;
+
+    // per-thread staging coordinates
+    int x_row[XCH], x_kc[XCH], x_n[XCH], x_oy[XCH], x_ox[XCH];
+    bool x_ok[XCH];
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) {
+        const int c = tid + i * T;
+        x_row[i] = c >> 2;
+        x_kc[i] = c & 3;
+        const int m = m0 + x_row[i];
+        x_ok[i] = (c < BM * 4) && (m < P.m);
+        const int mm = x_ok[i] ? m : 0;
+        x_n[i] = mm / hw;
+        const int r = mm - x_n[i] * hw;
+        x_oy[i] = r / P.wo;
+        x_ox[i] = r - x_oy[i] * P.wo;
+    }
+    const int ntaps = P.kh * P.kw;
+    const int ksteps = P.kpad >> 5;
+
+    h8 xr[XCH], wr[WCH];
+    auto load_step = [&](int ks) {
+#pragma unroll
+        for (int i = 0; i < XCH; ++i) {
+            h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (x_ok[i]) {
+                const int k = (ks << 5) + (x_kc[i] << 3);
+                const int tap = k / P.cin;
+                const int c = k - tap * P.cin;
+                const int kh = tap / P.kw, kw = tap - kh * P.kw;
+                const int iy = x_oy[i] * P.stride - P.pad_t + kh, ix = x_ox[i] * P.stride - P.pad_l + kw;
+                if (tap < ntaps && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W)
+                    v = *reinterpret_cast<const h8 *>(P.in + ((size_t)(x_n[i] * P.H + iy) * P.W + ix) * P.cs_in + P.coff_in + c);
+            }
+            xr[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) {
+            const int c = tid + i * T;
+            if (c < BN * 4)
+                wr[i] = *reinterpret_cast<const h8 *>(P.w + (size_t)(n0 + (c >> 2)) * P.kpad + (ks << 5) + ((c & 3) << 3));
+        }
+    };
+    auto store_step = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < XCH; ++i) {
+            const int c = tid + i * T;
+            if (c < BM * 4) *reinterpret_cast<h8 *>(xs + (buf * BM + (c >> 2)) * LDS_ROW + ((c & 3) << 3)) = xr[i];
+        }
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) {
+            const int c = tid + i * T;
+            if (c < BN * 4) *reinterpret_cast<h8 *>(ws + (buf * BN + (c >> 2)) * LDS_ROW + ((c & 3) << 3)) = wr[i];
+        }
+    };
+
+    f4 acc[NI][MI];
+#pragma unroll
+    for (int a = 0; a < NI; ++a)
+#pragma unroll
+        for (int b = 0; b < MI; ++b) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
+
+    load_step(0);
+    store_step(0);
+    __syncthreads();
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int ks = 0; ks < ksteps; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < ksteps) load_step(ks + 1);              // global loads in flight under the MFMAs
+        h8 xf[MI], wf[NI];
+#pragma unroll
+        for (int b = 0; b < MI; ++b)
+            xf[b] = *reinterpret_cast<const h8 *>(xs + (buf * BM + (wm * MI + b) * 16 + fr) * LDS_ROW + (fq << 3));
+#pragma unroll
+        for (int a = 0; a < NI; ++a)
+            wf[a] = *reinterpret_cast<const h8 *>(ws + (buf * BN + (wn * NI + a) * 16 + fr) * LDS_ROW + (fq << 3));
+#pragma unroll
+        for (int a = 0; a < NI; ++a)
+#pragma unroll
+            for (int b = 0; b < MI; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[a], xf[b], acc[a][b], 0, 0, 0);
+        if (ks + 1 < ksteps) store_step(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- fused epilogue: lane holds channels co..co+3 of pixel m
+#pragma unroll
+    for (int b = 0; b < MI; ++b) {
+        const int m = m0 + (wm * MI + b) * 16 + fr;
+        if (m >= P.m) continue;
+#pragma unroll
+        for (int a = 0; a < NI; ++a) {
+            const int co = n0 + (wn * NI + a) * 16 + fq * 4;
+            if (co >= P.cout_pad) continue;
+            const f4 bv = *reinterpret_cast<const f4 *>(P.bias + co);
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r] + bv[r];
+            if (P.epi == EPI_YOLO) {
+                const int n = m / hw, p = m - n * hw;
+                const int py = p / P.wo, px = p - py * P.wo;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ch = co + r;
+                    if (ch >= P.cout) continue;
+                    const int no = P.p[0];                     // 5 + classes
+                    const int an = ch / no, o = ch - an * no;
+                    const float s = 1.f / (1.f + __expf(-v[r]));
+                    float val = s;
+                    if (o == 0) val = (s * 2.f - 0.5f + (float)px) * P.f[6] / P.f[7];
+                    else if (o == 1) val = (s * 2.f - 0.5f + (float)py) * P.f[6] / (float)P.p[4];
+                    else if (o == 2) val = (s * 2.f) * (s * 2.f) * P.f[2 * an] / P.f[7];
+                    else if (o == 3) val = (s * 2.f) * (s * 2.f) * P.f[2 * an + 1] / (float)P.p[4];
+                    const size_t row = (size_t)n * P.p[1] + P.p[2] + (size_t)an * hw + p;
+                    static_cast<float *>(P.out)[row * no + o] = val;
+                }
+                continue;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], P.act);
+            if (P.epi == EPI_SSD_HEAD) {
+                const int n = m / hw, p = m - n * hw;
+                const int g = P.p[0], A = P.p[5];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ch = co + r;
+                    if (ch >= P.cout) continue;
+                    const int an = ch / g, kk = ch - an * g;
+                    const size_t row = (size_t)n * P.p[1] + P.p[2] + (size_t)p * A + an;
+                    static_cast<float *>(P.out)[row * P.p[3] + P.p[4] + kk] = v[r];
+                }
+                continue;
+            }
+            if (P.res) {
+                const h4 rv = *reinterpret_cast<const h4 *>(P.res + (size_t)m * P.cs_res + P.coff_res + co);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (co + r >= P.cout) v[r] = 0.f;
+            if (P.epi == EPI_F32) {
+                *reinterpret_cast<f4 *>(static_cast<float *>(P.out) + (size_t)m * P.cs_out + P.coff_out + co) =
+                    f4{v[0], v[1], v[2], v[3]};
+            } else {
+                h4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (_Float16)v[r];
+                *reinterpret_cast<h4 *>(static_cast<_Float16 *>(P.out) + (size_t)m * P.cs_out + P.coff_out + co) = o;
+            }
+            if (P.out2) {                                   // second view: ELU(scale * raw + shift)
+                const f4 sc = *reinterpret_cast<const f4 *>(P.aff2 + co);
+                const f4 sh = *reinterpret_cast<const f4 *>(P.aff2 + P.cout_pad + co);
+                h4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float t = co + r < P.cout ? apply_act(sc[r] * v[r] + sh[r], ACT_ELU) : 0.f;
+                    o[r] = (_Float16)t;
+                }
+                *reinterpret_cast<h4 *>(P.out2 + (size_t)m * P.cs_out2 + P.coff_out2 + co) = o;
+            }
+        }
+    }
+}
+
+// Depthwise 3x3: one lane per (pixel, 8-channel group); weights [3][3][C] f16, bias f32 [C].
+struct DwP {
+    const _Float16 *in; int H, W, cs_in, coff_in;
+    const _Float16 *w; const float *bias;
+    int stride, pad_t, pad_l, ho, wo, c, m, act;
+    _Float16 *out; int cs_out, coff_out;
+};
+
+__global__ __launch_bounds__(256) void dwconv3_k(const DwP P) {
+    const int groups = P.c >> 3;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)P.m * groups) return;
+    const int g = (int)(idx % groups);
+    const int m = (int)(idx / groups);
+    const int hw = P.ho * P.wo;
+    const int n = m / hw, r = m - n * hw;
+    const int oy = r / P.wo, ox = r - oy * P.wo;
+    float acc[8];
+    {
+        const f4 b0 = *reinterpret_cast<const f4 *>(P.bias + g * 8), b1 = *reinterpret_cast<const f4 *>(P.bias + g * 8 + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { acc[i] = b0[i]; acc[4 + i] = b1[i]; }
+    }
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int iy = oy * P.stride - P.pad_t + kh;
+        if (iy < 0 || iy >= P.H) continue;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int ix = ox * P.stride - P.pad_l + kw;
+            if (ix < 0 || ix >= P.W) continue;
+            const h8 x = *reinterpret_cast<const h8 *>(P.in + ((size_t)(n * P.H + iy) * P.W + ix) * P.cs_in + P.coff_in + g * 8);
+            const h8 w = *reinterpret_cast<const h8 *>(P.w + (size_t)(kh * 3 + kw) * P.c + g * 8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += (float)x[i] * (float)w[i];
+        }
+    }
+    h8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (_Float16)apply_act(acc[i], P.act);
+    *reinterpret_cast<h8 *>(P.out + (size_t)m * P.cs_out + P.coff_out + g * 8) = o;
+}
+
+struct PoolP {
+    const _Float16 *in; int H, W, cs_in, coff_in;
+    int k, stride, pad, ho, wo, c, m;
+    _Float16 *out; int cs_out, coff_out;
+};
+
+__global__ __launch_bounds__(256) void maxpool_k(const PoolP P) {
+    const int groups = P.c >> 3;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)P.m * groups) return;
+    const int g = (int)(idx % groups);
+    const int m = (int)(idx / groups);
+    const int hw = P.ho * P.wo;
+    const int n = m / hw, r = m - n * hw;
+    const int oy = r / P.wo, ox = r - oy * P.wo;
+    float best[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) best[i] = -65504.f;
+    for (int kh = 0; kh < P.k; ++kh) {
+        const int iy = oy * P.stride - P.pad + kh;
+        if (iy < 0 || iy >= P.H) continue;
+        for (int kw = 0; kw < P.k; ++kw) {
+            const int ix = ox * P.stride - P.pad + kw;
+            if (ix < 0 || ix >= P.W) continue;
+            const h8 x = *reinterpret_cast<const h8 *>(P.in + ((size_t)(n * P.H + iy) * P.W + ix) * P.cs_in + P.coff_in + g * 8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) best[i] = fmaxf(best[i], (float)x[i]);
+        }
+    }
+    h8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (_Float16)best[i];
+    *reinterpret_cast<h8 *>(P.out + (size_t)m * P.cs_out + P.coff_out + g * 8) = o;
+}
+
+// nearest x2 upsample into a (possibly wider) destination channel slice
+__global__ __launch_bounds__(256) void upsample2_k(const _Float16 *__restrict__ in, int H, int W, int cs_in, int coff_in,
+                                                   int c, int m_out, _Float16 *__restrict__ out, int cs_out, int coff_out) {
+    const int groups = c >> 3;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)m_out * groups) return;
+    const int g = (int)(idx % groups);
+    const int m = (int)(idx / groups);
+    const int wo = W * 2, hw = H * 2 * wo;
+    const int n = m / hw, r = m - n * hw;
+    const int oy = r / wo, ox = r - oy * wo;
+    const h8 x = *reinterpret_cast<const h8 *>(in + ((size_t)(n * H + (oy >> 1)) * W + (ox >> 1)) * cs_in + coff_in + g * 8);
+    *reinterpret_cast<h8 *>(out + (size_t)m * cs_out + coff_out + g * 8) = x;
+}
+
+// u8 [N][H][W][3] -> f16 [N][Ho][Wo][cs]: optional channel swap, (x - mean) * scale, optional
+// space-to-depth 2 (YOLOv5 Focus: channel order (y0x0, y1x0, y0x1, y1x1) x rgb).
+__global__ __launch_bounds__(256) void input_k(const uint8_t *__restrict__ src, int H, int W, int swap_rb, float mean,
+                                               float scale, int s2d, int m_out, _Float16 *__restrict__ out, int cs_out) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= m_out) return;
+    const int ho = s2d ? H / 2 : H, wo = s2d ? W / 2 : W;
+    const int hw = ho * wo;
+    const int n = m / hw, r = m - n * hw;
+    const int oy = r / wo, ox = r - oy * wo;
+    _Float16 *o = out + (size_t)m * cs_out;
+    if (!s2d) {
+        const uint8_t *p = src + ((size_t)(n * H + oy) * W + ox) * 3;
+        h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        v[0] = (_Float16)(((float)p[swap_rb ? 2 : 0] - mean) * scale);
+        v[1] = (_Float16)(((float)p[1] - mean) * scale);
+        v[2] = (_Float16)(((float)p[swap_rb ? 0 : 2] - mean) * scale);
+        *reinterpret_cast<h8 *>(o) = v;
+    } else {
+        h8 v0 = {0, 0, 0, 0, 0, 0, 0, 0}, v1 = v0;
+        float t[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int dy = q & 1, dx = q >> 1;
+            const uint8_t *p = src + ((size_t)(n * H + 2 * oy + dy) * W + 2 * ox + dx) * 3;
+            t[q * 3 + 0] = ((float)p[swap_rb ? 2 : 0] - mean) * scale;
+            t[q * 3 + 1] = ((float)p[1] - mean) * scale;
+            t[q * 3 + 2] = ((float)p[swap_rb ? 0 : 2] - mean) * scale;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v0[i] = (_Float16)t[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v1[i] = (_Float16)t[8 + i];
+        *reinterpret_cast<h8 *>(o) = v0;
+        *reinterpret_cast<h8 *>(o + 8) = v1;
+    }
+}
+
+// Small-M fully connected: out[n][co] = act(bias + sum_k x[n][k] w[co][k]) then optional second
+// affine; one wave per output channel, lanes split K in 16-byte pieces, NB rows per pass.
+__global__ __launch_bounds__(256) void fc_k(const _Float16 *__restrict__ x, int n_rows, int k, const _Float16 *__restrict__ w,
+                                            const float *__restrict__ bias, int cout, int act, const float *__restrict__ aff2,
+                                            float *__restrict__ out, int ld_out) {
+    constexpr int NB = 8;
+    const int co = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (co >= cout) return;
+    const _Float16 *wrow = w + (size_t)co * k;
+    for (int n0 = 0; n0 < n_rows; n0 += NB) {
+        float acc[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) acc[i] = 0.f;
+        for (int kk = lane * 8; kk < k; kk += 64 * 8) {
+            const h8 wv = *reinterpret_cast<const h8 *>(wrow + kk);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int n = min(n0 + i, n_rows - 1);
+                const h8 xv = *reinterpret_cast<const h8 *>(x + (size_t)n * k + kk);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[i] += (float)xv[j] * (float)wv[j];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            float v = acc[i];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0 && n0 + i < n_rows) {
+                v = apply_act(v + bias[co], act);
+                if (aff2) v = aff2[co] * v + aff2[cout + co];
+                out[(size_t)(n0 + i) * ld_out + co] = v;
+            }
+        }
+    }
+}
+
+// x / sqrt(eps + sum x^2) over rows of `c` f32 (c <= 256); one wave per row.
+__global__ __launch_bounds__(256) void l2norm_k(const float *__restrict__ in, int n_rows, int c, float eps, float *__restrict__ out) {
+    const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (row >= n_rows) return;
+    float v[4], ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int j = lane + 64 * i;
+        v[i] = j < c ? in[(size_t)row * c + j] : 0.f;
+        ss += v[i] * v[i];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const float nrm = sqrtf(eps + ss);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int j = lane + 64 * i;
+        if (j < c) out[(size_t)row * c + j] = v[i] / nrm;
+    }
+}
+
+struct TensorDesc { int buf, h, w, c, cs, coff, dtype, pad; };
+
+}  // namespace
+
+struct dd_net {
+    dd_ctx *ctx = nullptr;
+    int max_batch = 0;
+    std::vector<int32_t> prog;
+    std::vector<TensorDesc> tensors;
+    std::vector<int64_t> buf_elems;          // per image
+    std::vector<void *> bufs;
+    std::vector<int> buf_dtype;
+    int n_ops = 0, ops_off = 0;
+    char *d_weights = nullptr;
+    int64_t weight_bytes = 0;
+    int in_h = 0, in_w = 0, out_tensor = -1;
+};
+
+namespace {
+
+inline size_t dtype_size(int dt) { return dt == DT_F16 ? 2 : (dt == DT_F32 ? 4 : 1); }
+
+template <int WM, int WN, int MI, int NI>
+int launch_conv(hipStream_t s, const ConvP &P) {
+    constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
+    dim3 grid(dd_ceil_div(P.m, BM), dd_ceil_div(P.cout_pad, BN));
+    hipLaunchKernelGGL((conv_mfma_k<WM, WN, MI, NI>), grid, dim3(WM * WN * 64), 0, s, P);
+    DD_LAUNCH_CHECK();
+    return DD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Program layout (int32 words): [magic 'DDN1'][n_tensors][n_bufs][n_ops][in_h][in_w][out_tensor][rsvd]
+// then n_tensors * 8 words (buf,h,w,c,cs,coff,dtype,0), n_bufs * 2 words (elements per image, dtype),
+// n_ops * 48 words.  See deepdish_amd/nets.py (Program.serialize) for the field order.
+int dd_net_create(dd_ctx *ctx, const int32_t *program_host, int n_words, const void *weights_host,
+                  int64_t n_weight_bytes, int max_batch, dd_net **out) {
+    DD_REQUIRE(ctx && program_host && weights_host && out && max_batch > 0 && n_words >= 8, DD_E_ARG,
+               "dd_net_create: bad argument");
+    DD_REQUIRE(program_host[0] == 0x314E4444, DD_E_ARG, "dd_net_create: bad program magic");
+    const int nt = program_host[1], nb = program_host[2], no = program_host[3];
+    DD_REQUIRE(n_words == 8 + nt * TENSOR_WORDS + nb * 2 + no * OP_WORDS, DD_E_ARG, "dd_net_create: program size mismatch");
+    dd_net *n = new dd_net();
+    n->ctx = ctx;
+    n->max_batch = max_batch;
+    n->prog.assign(program_host, program_host + n_words);
+    n->in_h = program_host[4];
+    n->in_w = program_host[5];
+    n->out_tensor = program_host[6];
+    const int32_t *p = program_host + 8;
+    for (int i = 0; i < nt; ++i, p += TENSOR_WORDS) n->tensors.push_back(TensorDesc{p[0], p[1], p[2], p[3], p[4], p[5], p[6], 0});
+    DD_HIP(hipSetDevice(ctx->device));
+    for (int i = 0; i < nb; ++i, p += 2) {
+        n->buf_elems.push_back(p[0]);
+        n->buf_dtype.push_back(p[1]);
+        void *d = nullptr;
+        const size_t bytes = (size_t)p[0] * max_batch * dtype_size(p[1]) + 256;
+        DD_HIP(hipMalloc(&d, bytes));
+        DD_HIP(hipMemset(d, 0, bytes));
+        n->bufs.push_back(d);
+    }
+    n->n_ops = no;
+    n->ops_off = (int)(p - program_host);
+    n->weight_bytes = n_weight_bytes;
+    DD_HIP(hipMalloc(&n->d_weights, (size_t)n_weight_bytes + 256));
+    DD_HIP(hipMemcpy(n->d_weights, weights_host, (size_t)n_weight_bytes, hipMemcpyHostToDevice));
+    *out = n;
+    return DD_OK;
+}
+
+int dd_net_destroy(dd_net *n) {
+    if (!n) return DD_OK;
+    for (void *b : n->bufs) (void)hipFree(b);
+    (void)hipFree(n->d_weights);
+    delete n;
+    return DD_OK;
+}
+
+int dd_net_output(dd_net *n, int tensor, void **dev_ptr, int *h, int *w, int *c, int *cs, int *dtype) {
+    DD_REQUIRE(n, DD_E_ARG, "dd_net_output: NULL net");
+    const int t = tensor < 0 ? n->out_tensor : tensor;
+    DD_REQUIRE(t >= 0 && t < (int)n->tensors.size(), DD_E_ARG, "dd_net_output: tensor %d out of range", t);
+    const TensorDesc &d = n->tensors[t];
+    if (dev_ptr) *dev_ptr = static_cast<char *>(n->bufs[d.buf]) + (size_t)d.coff * dtype_size(d.dtype);
+    if (h) *h = d.h;
+    if (w) *w = d.w;
+    if (c) *c = d.c;
+    if (cs) *cs = d.cs;
+    if (dtype) *dtype = d.dtype;
+    return DD_OK;
+}
+
+int dd_net_read(dd_net *n, int tensor, int n_img, void *dst, int dst_on_device, void *stream) {
+    DD_REQUIRE(n && dst && n_img >= 0 && n_img <= n->max_batch, DD_E_ARG, "dd_net_read: bad argument");
+    const int t = tensor < 0 ? n->out_tensor : tensor;
+    DD_REQUIRE(t >= 0 && t < (int)n->tensors.size(), DD_E_ARG, "dd_net_read: tensor %d out of range", t);
+    const TensorDesc &d = n->tensors[t];
+    DD_REQUIRE(d.coff == 0, DD_E_ARG, "dd_net_read: tensor %d is a channel slice", t);
+    hipStream_t s = dd_pick_stream(n->ctx, stream);
+    const size_t bytes = (size_t)n_img * d.h * d.w * d.cs * dtype_size(d.dtype);
+    if (!bytes) return DD_OK;
+    DD_HIP(hipMemcpyAsync(dst, n->bufs[d.buf], bytes, dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+    if (!dst_on_device) DD_HIP(hipStreamSynchronize(s));
+    return DD_OK;
+}
+
+int dd_net_forward(dd_net *net, const uint8_t *input, int nimg, void *stream) {
+    DD_REQUIRE(net && input && nimg >= 0, DD_E_ARG, "dd_net_forward: bad argument");
+    DD_REQUIRE(nimg <= net->max_batch, DD_E_CAPACITY, "dd_net_forward: batch %d > max_batch %d", nimg, net->max_batch);
+    if (nimg == 0) return DD_OK;
+    hipStream_t s = dd_pick_stream(net->ctx, stream);
+    auto base = [&](int t) -> char * {
+        const TensorDesc &d = net->tensors[t];
+        return static_cast<char *>(net->bufs[d.buf]);
+    };
+    for (int i = 0; i < net->n_ops; ++i) {
+        const int32_t *o = net->prog.data() + net->ops_off + (size_t)i * OP_WORDS;
+        const float *of = reinterpret_cast<const float *>(o);
+        const int kind = o[0], src = o[1], dst = o[2], res = o[3], dst2 = o[4];
+        const TensorDesc *ts = src >= 0 ? &net->tensors[src] : nullptr;
+        const TensorDesc *td = dst >= 0 ? &net->tensors[dst] : nullptr;
+        switch (kind) {
+            case OP_INPUT: {
+                const int s2d = o[5];
+                const int m = nimg * td->h * td->w;
+                hipLaunchKernelGGL(input_k, dim3(dd_ceil_div(m, 256)), dim3(256), 0, s, input, net->in_h, net->in_w, o[6],
+                                   of[32], of[33], s2d, m, reinterpret_cast<_Float16 *>(base(dst)) + td->coff, td->cs);
+                DD_LAUNCH_CHECK();
+                break;
+            }
+            case OP_CONV: {
+                ConvP P;
+                memset(&P, 0, sizeof(P));
+                P.in = reinterpret_cast<const _Float16 *>(base(src)); P.H = ts->h; P.W = ts->w; P.cs_in = ts->cs;
+                P.coff_in = ts->coff; P.cin = o[10];
+                P.kh = o[5]; P.kw = o[6]; P.stride = o[7]; P.pad_t = o[8]; P.pad_l = o[9];
+                P.cout = o[11]; P.cout_pad = o[12]; P.kpad = o[13]; P.act = o[14]; P.epi = o[15];
+                P.w = reinterpret_cast<const _Float16 *>(net->d_weights + (size_t)(uint32_t)o[16]);
+                P.bias = reinterpret_cast<const float *>(net->d_weights + (size_t)(uint32_t)o[17]);
+                P.ho = o[26]; P.wo = o[27]; P.m = nimg * P.ho * P.wo;      // conv grid (dst may be a head matrix)
+                P.out = base(dst); P.cs_out = td->cs; P.coff_out = td->coff;
+                if (res >= 0) {
+                    const TensorDesc &tr = net->tensors[res];
+                    P.res = reinterpret_cast<const _Float16 *>(base(res)); P.cs_res = tr.cs; P.coff_res = tr.coff;
+                }
+                if (dst2 >= 0) {
+                    const TensorDesc &t2 = net->tensors[dst2];
+                    P.out2 = reinterpret_cast<_Float16 *>(base(dst2)); P.cs_out2 = t2.cs; P.coff_out2 = t2.coff;
+                    P.aff2 = reinterpret_cast<const float *>(net->d_weights + (size_t)(uint32_t)o[18]);
+                }
+                for (int q = 0; q < 6; ++q) P.p[q] = o[20 + q];
+                for (int q = 0; q < 8; ++q) P.f[q] = of[32 + q];
+                int rc;
+                if (P.cout_pad <= 32) rc = launch_conv<4, 1, 1, 2>(s, P);
+                else rc = launch_conv<2, 2, 2, 2>(s, P);
+                if (rc != DD_OK) return rc;
+                break;
+            }
+            case OP_DWCONV: {
+                DwP P;
+                P.in = reinterpret_cast<const _Float16 *>(base(src)); P.H = ts->h; P.W = ts->w; P.cs_in = ts->cs; P.coff_in = ts->coff;
+                P.w = reinterpret_cast<const _Float16 *>(net->d_weights + (size_t)(uint32_t)o[16]);
+                P.bias = reinterpret_cast<const float *>(net->d_weights + (size_t)(uint32_t)o[17]);
+                P.stride = o[7]; P.pad_t = o[8]; P.pad_l = o[9]; P.ho = td->h; P.wo = td->w; P.c = o[12];
+                P.m = nimg * td->h * td->w; P.act = o[14];
+                P.out = reinterpret_cast<_Float16 *>(base(dst)); P.cs_out = td->cs; P.coff_out = td->coff;
+                const long long total = (long long)P.m * (P.c >> 3);
+                hipLaunchKernelGGL(dwconv3_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, P);
+                DD_LAUNCH_CHECK();
+                break;
+            }
+            case OP_MAXPOOL: {
+                PoolP P;
+                P.in = reinterpret_cast<const _Float16 *>(base(src)); P.H = ts->h; P.W = ts->w; P.cs_in = ts->cs; P.coff_in = ts->coff;
+                P.k = o[5]; P.stride = o[7]; P.pad = o[8]; P.ho = td->h; P.wo = td->w; P.c = o[12];
+                P.m = nimg * td->h * td->w;
+                P.out = reinterpret_cast<_Float16 *>(base(dst)); P.cs_out = td->cs; P.coff_out = td->coff;
+                const long long total = (long long)P.m * (P.c >> 3);
+                hipLaunchKernelGGL(maxpool_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, P);
+                DD_LAUNCH_CHECK();
+                break;
+            }
+            case OP_UPSAMPLE: {
+                const int m = nimg * td->h * td->w;
+                const long long total = (long long)m * (o[12] >> 3);
+                hipLaunchKernelGGL(upsample2_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                                   reinterpret_cast<const _Float16 *>(base(src)), ts->h, ts->w, ts->cs, ts->coff, o[12], m,
+                                   reinterpret_cast<_Float16 *>(base(dst)), td->cs, td->coff);
+                DD_LAUNCH_CHECK();
+                break;
+            }
+            case OP_FC: {
+                // src viewed as [n][k] f16 with k = h*w*cs (cs == c required), dst f32 [n][cout]
+                const int k = ts->h * ts->w * ts->cs;
+                const float *aff2 = o[18] >= 0 && o[19] ? reinterpret_cast<const float *>(net->d_weights + (size_t)(uint32_t)o[18]) : nullptr;
+                hipLaunchKernelGGL(fc_k, dim3(dd_ceil_div(o[11], 4)), dim3(256), 0, s,
+                                   reinterpret_cast<const _Float16 *>(base(src)) + ts->coff, nimg, k,
+                                   reinterpret_cast<const _Float16 *>(net->d_weights + (size_t)(uint32_t)o[16]),
+                                   reinterpret_cast<const float *>(net->d_weights + (size_t)(uint32_t)o[17]), o[11], o[14], aff2,
+                                   reinterpret_cast<float *>(base(dst)) + td->coff, td->cs);
+                DD_LAUNCH_CHECK();
+                break;
+            }
+            case OP_L2NORM: {
+                hipLaunchKernelGGL(l2norm_k, dim3(dd_ceil_div(nimg, 4)), dim3(256), 0, s,
+                                   reinterpret_cast<const float *>(base(src)) + ts->coff, nimg, ts->c, of[32],
+                                   reinterpret_cast<float *>(base(dst)) + td->coff);
+                DD_LAUNCH_CHECK();
+                break;
+            }
+            default:
+                DD_REQUIRE(false, DD_E_ARG, "dd_net_forward: unknown op kind %d at %d", kind, i);
+        }
+    }
+    return DD_OK;
+}
+
+}  // extern "C"

@@ -21,14 +21,15 @@ __device__ __forceinline__ bool before(double ka, int ia, double kb, int ib) {
     return ka > kb || (ka == kb && ia > ib);
 }
 
-__global__ __launch_bounds__(1024) void nms_sort_k(const double *__restrict__ boxes, const double *__restrict__ keys,
+template <typename TB>
+__global__ __launch_bounds__(1024) void nms_sort_k(const TB *__restrict__ boxes, const TB *__restrict__ keys,
                                                    int k, int mode, SBox *__restrict__ sorted, int *__restrict__ sidx) {
     __shared__ double skey[MAXK];
     __shared__ int sid[MAXK];
     int n = 1;
     while (n < k) n <<= 1;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        skey[i] = i < k ? keys[i] : -__builtin_inf();
+        skey[i] = i < k ? (double)keys[i] : -__builtin_inf();
         sid[i] = i < k ? i : -1 - i;                       // padding sorts last (lowest key, lowest id)
     }
     __syncthreads();
@@ -49,9 +50,12 @@ __global__ __launch_bounds__(1024) void nms_sort_k(const double *__restrict__ bo
     }
     for (int i = threadIdx.x; i < k; i += blockDim.x) {
         const int o = sid[i];
-        const double *b = boxes + (size_t)o * 4;
+        const TB *b = boxes + (size_t)o * 4;
         SBox s;
-        if (mode == 0) {
+        if (mode == 2) {                                    // f32 (ymin, xmin, ymax, xmax), TFLite fast NMS
+            s.a = b[0]; s.b = b[1]; s.c = b[2]; s.d = b[3];
+            s.area = (double)(((float)b[2] - (float)b[0]) * ((float)b[3] - (float)b[1]));
+        } else if (mode == 0) {
             s.a = b[0]; s.b = b[1]; s.c = b[2] + b[0]; s.d = b[3] + b[1];
             s.area = (s.c - s.a + 1) * (s.d - s.b + 1);     // preprocessing.py:43-48
         } else {
@@ -64,6 +68,14 @@ __global__ __launch_bounds__(1024) void nms_sort_k(const double *__restrict__ bo
 }
 
 __device__ __forceinline__ bool suppresses(const SBox &pi, const SBox &pj, double thr, int mode) {
+    if (mode == 2) {                                        // detection_postprocess.cc ComputeIntersectionOverUnion, f32
+        const float ai = (float)pi.area, aj = (float)pj.area;
+        if (ai <= 0.f || aj <= 0.f) return false;
+        const float y0 = fmaxf((float)pi.a, (float)pj.a), x0 = fmaxf((float)pi.b, (float)pj.b);
+        const float y1 = fminf((float)pi.c, (float)pj.c), x1 = fminf((float)pi.d, (float)pj.d);
+        const float inter = fmaxf(y1 - y0, 0.f) * fmaxf(x1 - x0, 0.f);
+        return inter / (ai + aj - inter) > (float)thr;
+    }
     if (mode == 0) {
         const double xx1 = fmax(pi.a, pj.a), yy1 = fmax(pi.b, pj.b);
         const double xx2 = fmin(pi.c, pj.c), yy2 = fmin(pi.d, pj.d);
@@ -159,13 +171,23 @@ int nms(hipStream_t s, const double *boxes, const double *keys, int k, double th
     int *sidx = reinterpret_cast<int *>(p);
     p += ((size_t)k * sizeof(int) + 63) / 64 * 64;
     u64 *mask = reinterpret_cast<u64 *>(p);
-    hipLaunchKernelGGL(nms_sort_k, dim3(1), dim3(1024), 0, s, boxes, keys, k, mode, sorted, sidx);
+    if (mode == 2)
+        hipLaunchKernelGGL(nms_sort_k<float>, dim3(1), dim3(1024), 0, s, reinterpret_cast<const float *>(boxes),
+                           reinterpret_cast<const float *>(keys), k, mode, sorted, sidx);
+    else
+        hipLaunchKernelGGL(nms_sort_k<double>, dim3(1), dim3(1024), 0, s, boxes, keys, k, mode, sorted, sidx);
     DD_LAUNCH_CHECK();
     hipLaunchKernelGGL(nms_mask_k, dim3(words, dd_ceil_div(k, 4)), dim3(256), 0, s, sorted, k, words, thr, mode, mask);
     DD_LAUNCH_CHECK();
     hipLaunchKernelGGL(nms_scan_k, dim3(1), dim3(64), 0, s, mask, sidx, k, words, out_idx, out_n);
     DD_LAUNCH_CHECK();
     return DD_OK;
+}
+
+int nms_f32(hipStream_t s, const float *boxes_yxyx, const float *keys, int k, float thr, int *out_idx, int *out_n,
+            void *scratch, size_t scratch_bytes) {
+    return nms(s, reinterpret_cast<const double *>(boxes_yxyx), reinterpret_cast<const double *>(keys), k, (double)thr, 2,
+               out_idx, out_n, scratch, scratch_bytes);
 }
 
 }  // namespace ddk

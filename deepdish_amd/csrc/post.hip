@@ -1,0 +1,193 @@
+// Detector post-processing kernels.
+//   * dd_ssd_postprocess : the TFLite_Detection_PostProcess custom op that sits inside the reference's
+//     SSD .tflite graph (invoked at tools/ssd_mobilenet.py:103, outputs read at :107-109): anchor
+//     decode (scales 10,10,5,5), sigmoid class scores, best class per anchor, class-agnostic fast NMS
+//     in f32, top max_det.  TensorFlow Lite is a third-party dependency absent from this image; the
+//     op is restated from its published behaviour -- parity unpinned.
+//   * dd_yolov5_decode   : tools/yolov5.py:120-131.
+//   * dd_counts_accumulate : int64 count vector (deepdish.py:1141-1145) kept on the device for the
+//     end-of-run RCCL reduction.
+#include "common.h"
+
+namespace ddk {
+int nms_f32(hipStream_t s, const float *boxes_yxyx, const float *keys, int k, float thr, int *out_idx, int *out_n,
+            void *scratch, size_t scratch_bytes);
+}
+
+namespace {
+
+__global__ __launch_bounds__(256) void ssd_decode_k(const float *__restrict__ raw, const float *__restrict__ anchors,
+                                                    int n_anchors, int n_classes, float score_thr,
+                                                    float *__restrict__ boxes, float *__restrict__ best_score,
+                                                    int *__restrict__ best_cls, float *__restrict__ keys) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n_anchors) return;
+    const float *r = raw + (size_t)a * (4 + n_classes);
+    const float ay = anchors[a * 4 + 0], ax = anchors[a * 4 + 1], ah = anchors[a * 4 + 2], aw = anchors[a * 4 + 3];
+    const float yc = r[0] / 10.f * ah + ay;
+    const float xc = r[1] / 10.f * aw + ax;
+    const float hh = 0.5f * expf(r[2] / 5.f) * ah;
+    const float hw = 0.5f * expf(r[3] / 5.f) * aw;
+    boxes[a * 4 + 0] = yc - hh;
+    boxes[a * 4 + 1] = xc - hw;
+    boxes[a * 4 + 2] = yc + hh;
+    boxes[a * 4 + 3] = xc + hw;
+    float best = -1.f;
+    int bi = 0;
+    for (int c = 1; c < n_classes; ++c) {                     // class 0 = background
+        const float sc = 1.f / (1.f + expf(-r[4 + c]));
+        if (sc > best) { best = sc; bi = c - 1; }
+    }
+    best_score[a] = best;
+    best_cls[a] = bi;
+    keys[a] = best >= score_thr ? best : -1.f;
+}
+
+__global__ void ssd_gather_k(const int *__restrict__ keep, const int *__restrict__ n_keep, const float *__restrict__ boxes,
+                             const float *__restrict__ best_score, const int *__restrict__ best_cls, float score_thr,
+                             int max_det, float *__restrict__ out_boxes, float *__restrict__ out_cls,
+                             float *__restrict__ out_scores, int *__restrict__ out_count) {
+    const int i = threadIdx.x;
+    const int n = min(*n_keep, max_det);
+    bool ok = false;
+    if (i < max_det) {
+        int idx = 0;
+        if (i < n) { idx = keep[i]; ok = best_score[idx] >= score_thr; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) out_boxes[i * 4 + q] = ok ? boxes[idx * 4 + q] : 0.f;
+        out_cls[i] = ok ? (float)best_cls[idx] : 0.f;
+        out_scores[i] = ok ? best_score[idx] : 0.f;
+    }
+    const unsigned long long b = __ballot(ok);
+    if (i == 0) *out_count = __popcll(b);
+}
+
+// tools/yolov5.py:120-131, first half: per-row confidence and class
+__global__ __launch_bounds__(256) void yolo_conf_k(const float *__restrict__ raw, int n_rows, int n_cls,
+                                                   float *__restrict__ conf, int *__restrict__ cls) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const float *x = raw + (size_t)r * (5 + n_cls);
+    const float obj = x[4];
+    float best = x[5] * obj;
+    int bi = 0;
+    for (int c = 1; c < n_cls; ++c) {
+        const float v = x[5 + c] * obj;
+        if (v > best) { best = v; bi = c; }                   // np.argmax keeps the first maximum
+    }
+    conf[r] = best;
+    cls[r] = bi;
+}
+
+// second half: ordered compaction of rows with conf >= thr (ascending row order, like np.where)
+__global__ __launch_bounds__(1024) void yolo_compact_k(const float *__restrict__ raw, const float *__restrict__ conf,
+                                                       const int *__restrict__ cls, int n_rows, int n_cls, float thr,
+                                                       float img_w, float img_h, float *__restrict__ out_boxes,
+                                                       float *__restrict__ out_scores, int *__restrict__ out_cls,
+                                                       int cap, int *__restrict__ out_n) {
+    __shared__ int wave_cnt[16];
+    __shared__ int base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int r0 = 0; r0 < n_rows; r0 += 1024) {
+        const int r = r0 + tid;
+        const bool ok = r < n_rows && conf[r] >= thr;
+        const unsigned long long b = __ballot(ok);
+        if (lane == 0) wave_cnt[wave] = __popcll(b);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+        const int pos = off + __popcll(b & ((1ull << lane) - 1ull));
+        if (ok && pos < cap) {
+            const float *x = raw + (size_t)r * (5 + n_cls);
+            const float x1 = x[0] - x[2] / 2, y1 = x[1] - x[3] / 2, x2 = x[0] + x[2] / 2, y2 = x[1] + x[3] / 2;
+            out_boxes[pos * 4 + 0] = (float)((double)x1 * (double)img_w);
+            out_boxes[pos * 4 + 1] = (float)((double)y1 * (double)img_h);
+            out_boxes[pos * 4 + 2] = (float)((double)x2 * (double)img_w);
+            out_boxes[pos * 4 + 3] = (float)((double)y2 * (double)img_h);
+            out_scores[pos] = conf[r];
+            out_cls[pos] = cls[r];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int t = 0;
+            for (int w = 0; w < 16; ++w) t += wave_cnt[w];
+            base += t;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *out_n = base;
+}
+
+__global__ void counts_add_k(long long *__restrict__ acc, const long long *__restrict__ add, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) acc[i] += add[i];
+}
+
+}  // namespace
+
+extern "C" {
+
+int dd_ssd_postprocess(dd_ctx *ctx, const float *raw, const float *anchors, int n_anchors, int n_classes, int max_det,
+                       float score_thr, float iou_thr, float *boxes, float *classes, float *scores, int *count,
+                       void *stream) {
+    DD_REQUIRE(ctx && raw && anchors && boxes && classes && scores && count, DD_E_ARG, "dd_ssd_postprocess: NULL argument");
+    DD_REQUIRE(n_anchors > 0 && n_anchors <= 4096 && n_classes > 1 && max_det > 0 && max_det <= 64, DD_E_ARG,
+               "dd_ssd_postprocess: bad shape (anchors %d, classes %d, max_det %d)", n_anchors, n_classes, max_det);
+    hipStream_t s = dd_pick_stream(ctx, stream);
+    int rc;
+    const size_t per = (size_t)n_anchors;
+    const size_t head = per * (4 * 4 + 4 + 4 + 4 + 4) + 256;            // boxes, score, cls, keys, keep
+    const size_t nms_bytes = (size_t)n_anchors * 64 + (size_t)n_anchors * ((n_anchors + 63) / 64) * 8 + 1024;
+    if ((rc = ctx->scratch[2].reserve(head + nms_bytes)) != DD_OK) return rc;
+    char *p = ctx->scratch[2].as<char>();
+    float *d_boxes = reinterpret_cast<float *>(p);
+    float *d_score = d_boxes + per * 4;
+    int *d_cls = reinterpret_cast<int *>(d_score + per);
+    float *d_keys = reinterpret_cast<float *>(d_cls + per);
+    int *d_keep = reinterpret_cast<int *>(d_keys + per);
+    int *d_nkeep = d_keep + per;
+    char *d_nms = p + ((head + 255) / 256) * 256;
+    hipLaunchKernelGGL(ssd_decode_k, dim3(dd_ceil_div(n_anchors, 256)), dim3(256), 0, s, raw, anchors, n_anchors, n_classes,
+                       score_thr, d_boxes, d_score, d_cls, d_keys);
+    DD_LAUNCH_CHECK();
+    if ((rc = ddk::nms_f32(s, d_boxes, d_keys, n_anchors, iou_thr, d_keep, d_nkeep, d_nms, nms_bytes)) != DD_OK) return rc;
+    hipLaunchKernelGGL(ssd_gather_k, dim3(1), dim3(64), 0, s, d_keep, d_nkeep, d_boxes, d_score, d_cls, score_thr, max_det,
+                       boxes, classes, scores, count);
+    DD_LAUNCH_CHECK();
+    return DD_OK;
+}
+
+int dd_yolov5_decode(dd_ctx *ctx, const float *raw, int n_rows, int n_cls, float thr, float img_w, float img_h,
+                     float *out_boxes, float *out_scores, int *out_cls, int cap, int *out_n, void *stream) {
+    DD_REQUIRE(ctx && raw && out_boxes && out_scores && out_cls && out_n && n_rows >= 0 && n_cls > 0 && cap >= 0,
+               DD_E_ARG, "dd_yolov5_decode: bad argument");
+    hipStream_t s = dd_pick_stream(ctx, stream);
+    if (n_rows == 0) { DD_HIP(hipMemsetAsync(out_n, 0, sizeof(int), s)); return DD_OK; }
+    int rc;
+    if ((rc = ctx->scratch[2].reserve((size_t)n_rows * 8 + 256)) != DD_OK) return rc;
+    float *conf = ctx->scratch[2].as<float>();
+    int *cls = reinterpret_cast<int *>(conf + n_rows);
+    hipLaunchKernelGGL(yolo_conf_k, dim3(dd_ceil_div(n_rows, 256)), dim3(256), 0, s, raw, n_rows, n_cls, conf, cls);
+    DD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(yolo_compact_k, dim3(1), dim3(1024), 0, s, raw, conf, cls, n_rows, n_cls, thr, img_w, img_h,
+                       out_boxes, out_scores, out_cls, cap, out_n);
+    DD_LAUNCH_CHECK();
+    return DD_OK;
+}
+
+int dd_counts_accumulate(dd_ctx *ctx, int64_t *acc, const int64_t *counts_host, int n, void *stream) {
+    DD_REQUIRE(ctx && acc && counts_host && n > 0, DD_E_ARG, "dd_counts_accumulate: bad argument");
+    hipStream_t s = dd_pick_stream(ctx, stream);
+    int rc;
+    if ((rc = ctx->scratch[1].reserve((size_t)n * 8)) != DD_OK) return rc;
+    DD_HIP(hipMemcpyAsync(ctx->scratch[1].p, counts_host, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    DD_HIP(hipStreamSynchronize(s));
+    hipLaunchKernelGGL(counts_add_k, dim3(dd_ceil_div(n, 64)), dim3(64), 0, s, reinterpret_cast<long long *>(acc),
+                       ctx->scratch[1].as<long long>(), n);
+    DD_LAUNCH_CHECK();
+    return DD_OK;
+}
+
+}  // extern "C"

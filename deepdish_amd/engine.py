@@ -1,0 +1,66 @@
+"""Thin host wrapper around dd_net_* : compile once, run batches, read the output tensor."""
+import ctypes
+import numpy as np
+import torch
+
+from ._lib import lib, check, P
+from .runtime import default_context, ptr
+from . import nets
+
+
+class Net:
+    def __init__(self, program, max_batch, context=None):
+        self.ctx = context or default_context()
+        self.program = program
+        self.max_batch = int(max_batch)
+        words, blob = program.serialize()
+        self._words = words
+        blob_arr = np.frombuffer(blob, dtype=np.uint8)
+        h = P()
+        check(lib().dd_net_create(self.ctx.handle, ptr(words), len(words), ptr(blob_arr), len(blob),
+                                  self.max_batch, ctypes.byref(h)), 'dd_net_create')
+        self._h = h
+        t = program.tensors[program.out_tensor]
+        self.out_shape = (t['h'], t['w'], t['cs'])
+        self.out_dtype = {nets.DT_F16: torch.float16, nets.DT_F32: torch.float32}[t['dtype']]
+        self.weight_bytes = len(blob)
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().dd_net_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def forward(self, images, stream=None):
+        """images: u8 [n, in_h, in_w, 3] torch cuda tensor (or numpy, uploaded).  Enqueues only."""
+        if isinstance(images, np.ndarray):
+            images = self.ctx.to_device(images, np.uint8)
+        n = int(images.shape[0])
+        assert images.dtype == torch.uint8 and tuple(images.shape[1:]) == (self.program.in_h, self.program.in_w, 3)
+        check(lib().dd_net_forward(self._h, ptr(images), n, stream), 'dd_net_forward')
+        self._last_n = n
+        return n
+
+    def read(self, n=None, tensor=-1, to_host=True):
+        """Output rows of the last forward: [n, h*w, cs] (host numpy or a fresh device tensor)."""
+        n = self._last_n if n is None else n
+        if tensor < 0:
+            shape, dt = self.out_shape, self.out_dtype
+        else:
+            t = self.program.tensors[tensor]
+            shape = (t['h'], t['w'], t['cs'])
+            dt = {nets.DT_F16: torch.float16, nets.DT_F32: torch.float32}[t['dtype']]
+        if to_host:
+            out = np.zeros((n,) + shape, dtype=np.float16 if dt == torch.float16 else np.float32)
+            check(lib().dd_net_read(self._h, tensor, n, ptr(out), 0, None), 'dd_net_read')
+            return out
+        out = self.ctx.empty((n,) + shape, dt)
+        check(lib().dd_net_read(self._h, tensor, n, ptr(out), 1, None), 'dd_net_read')
+        return out
+
+    def output_ptr(self, tensor=-1):
+        p = P()
+        check(lib().dd_net_output(self._h, tensor, ctypes.byref(p), None, None, None, None, None), 'dd_net_output')
+        return p.value

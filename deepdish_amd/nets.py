@@ -1,0 +1,524 @@
+"""Model compiler: named f32 weights -> (op program, weight blob) for csrc/nets.hip.
+
+This is the build's analogue of the reference's model files (.tflite / .pb): the host describes the
+network as a flat list of ops over NHWC f16 tensors, folds batch-norms into the conv weights, packs
+the weights as f16 [Cout][KH*KW*Cin] rows (bias f32) and hands both to dd_net_create().
+
+Architectures (upstream paths):
+  * MARS re-ID encoder  -- tools/freeze_model.py:88-157 (+ BGR->RGB :175-177, call contract
+    tools/generate_detections.py:151-177); 64x32x3 input per the file name mars-64x32x3.
+  * SSD-MobileNet-v1    -- no in-tree description (blob absent): public TF-OD-API definition
+    (MobileNet-v1 backbone, 4 extra feature layers, 1x1 box/class predictors, 1917 anchors).
+  * YOLOv5s             -- detectors/yolov5/yolov5s.yaml (Focus / Conv / C3 / SPP / Detect, SiLU).
+
+No weight blobs ship with the reference (.MISSING_LARGE_BLOBS); `synthetic_*` below create seeded
+random weights of the right shapes so the HIP path and the oracle can be compared on equal terms.
+"""
+import math
+import numpy as np
+
+OP_INPUT, OP_CONV, OP_DWCONV, OP_MAXPOOL, OP_UPSAMPLE, OP_FC, OP_L2NORM = 1, 2, 3, 4, 5, 6, 7
+ACT_NONE, ACT_RELU6, ACT_ELU, ACT_SILU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3, 4, 5
+EPI_F16, EPI_F32, EPI_SSD_HEAD, EPI_YOLO = 0, 1, 2, 3
+DT_F16, DT_F32, DT_U8 = 0, 1, 2
+OP_WORDS, TENSOR_WORDS = 48, 8
+MAGIC = 0x314E4444
+BN_EPS = 1e-3
+
+
+def rup(x, m):
+    return (x + m - 1) // m * m
+
+
+def same_pad(size, k, stride):
+    """TensorFlow 'SAME': (output size, pad before)."""
+    out = -(-size // stride)
+    total = max((out - 1) * stride + k - size, 0)
+    return out, total // 2
+
+
+class Program:
+    def __init__(self, in_h, in_w):
+        self.in_h, self.in_w = in_h, in_w
+        self.tensors, self.bufs, self.ops = [], [], []
+        self.blob = bytearray()
+        self.out_tensor = -1
+        self.meta = {}
+
+    # ---- storage
+    def buffer(self, elems, dtype=DT_F16):
+        self.bufs.append((int(elems), dtype))
+        return len(self.bufs) - 1
+
+    def tensor(self, h, w, c, cs=None, coff=0, buf=None, dtype=DT_F16):
+        cs = rup(c, 8) if cs is None else cs
+        if buf is None:
+            buf = self.buffer(h * w * cs, dtype)
+        self.tensors.append(dict(buf=buf, h=h, w=w, c=c, cs=cs, coff=coff, dtype=dtype))
+        return len(self.tensors) - 1
+
+    def view(self, t, coff, c):
+        """Channel slice of an existing tensor (concat without copies)."""
+        d = self.tensors[t]
+        assert coff % 8 == 0 and c % 8 == 0
+        return self.tensor(d['h'], d['w'], c, cs=d['cs'], coff=d['coff'] + coff, buf=d['buf'], dtype=d['dtype'])
+
+    def T(self, t):
+        return self.tensors[t]
+
+    def add_blob(self, arr):
+        while len(self.blob) % 256:
+            self.blob.append(0)
+        off = len(self.blob)
+        self.blob += np.ascontiguousarray(arr).tobytes()
+        return off
+
+    def _op(self, kind, src=-1, dst=-1, res=-1, dst2=-1, **kw):
+        w = np.zeros(OP_WORDS, dtype=np.int32)
+        f = w.view(np.float32)
+        w[0:5] = (kind, src, dst, res, dst2)
+        names = dict(kh=5, kw=6, stride=7, pad_t=8, pad_l=9, cin=10, cout=11, cout_pad=12, kpad=13, act=14, epi=15,
+                     w_off=16, b_off=17, aff_off=18, has_aff=19, ho=26, wo=27)
+        for k, v in kw.items():
+            if k == 'p':
+                w[20:20 + len(v)] = v
+            elif k == 'f':
+                f[32:32 + len(v)] = v
+            else:
+                w[names[k]] = v
+        self.ops.append(w)
+
+    # ---- ops
+    def input(self, swap_rb, mean=0.0, scale=1.0, s2d=False):
+        h, w = (self.in_h // 2, self.in_w // 2) if s2d else (self.in_h, self.in_w)
+        t = self.tensor(h, w, 12 if s2d else 3, cs=16 if s2d else 8)
+        self._op(OP_INPUT, dst=t, kh=int(s2d), kw=int(swap_rb), f=[mean, scale])
+        return t
+
+    def conv(self, src, w_hwio, bias, stride=1, pad=None, act=ACT_NONE, dst=None, res=-1, dst2=-1, aff2=None,
+             epi=EPI_F16, p=(), f=(), out_hw=None):
+        """w_hwio f32 [KH,KW,Cin,Cout] (already BN-folded), bias f32 [Cout]."""
+        s = self.T(src)
+        kh, kw, cin, cout = w_hwio.shape
+        assert cin == s['c'], (cin, s['c'])
+        cin_pad = rup(cin, 8)
+        if pad is None:                       # TF SAME
+            ho, pt = same_pad(s['h'], kh, stride)
+            wo, pl = same_pad(s['w'], kw, stride)
+        else:                                 # explicit symmetric padding (PyTorch style)
+            pt = pl = pad
+            ho = (s['h'] + 2 * pad - kh) // stride + 1
+            wo = (s['w'] + 2 * pad - kw) // stride + 1
+        if out_hw is not None:
+            assert (ho, wo) == tuple(out_hw), ((ho, wo), out_hw)
+        cout_pad = rup(cout, 8)
+        rows = 32 if cout_pad <= 32 else rup(cout_pad, 64)
+        kpad = rup(kh * kw * cin_pad, 32)
+        wp = np.zeros((rows, kh * kw, cin_pad), dtype=np.float16)
+        wp[:cout, :, :cin] = np.transpose(w_hwio, (3, 0, 1, 2)).reshape(cout, kh * kw, cin).astype(np.float16)
+        wflat = np.zeros((rows, kpad), dtype=np.float16)
+        wflat[:, :kh * kw * cin_pad] = wp.reshape(rows, -1)
+        bp = np.zeros(rows, dtype=np.float32)
+        bp[:cout] = bias
+        if dst is None:
+            dst = self.tensor(ho, wo, cout, dtype=DT_F32 if epi == EPI_F32 else DT_F16)
+        if epi in (EPI_F16, EPI_F32):
+            d = self.T(dst)
+            assert (d['h'], d['w']) == (ho, wo) and d['c'] == cout, (d, ho, wo, cout)
+        kw_ = dict(kh=kh, kw=kw, stride=stride, pad_t=pt, pad_l=pl, cin=cin_pad, cout=cout, cout_pad=cout_pad,
+                   kpad=kpad, act=act, epi=epi, w_off=self.add_blob(wflat), b_off=self.add_blob(bp), p=list(p), f=list(f),
+                   ho=ho, wo=wo)
+        if dst2 >= 0:
+            a = np.zeros((2, cout_pad), dtype=np.float32)
+            a[0, :cout], a[1, :cout] = aff2
+            kw_['aff_off'] = self.add_blob(a)
+            kw_['has_aff'] = 1
+        self._op(OP_CONV, src=src, dst=dst, res=res, dst2=dst2, **kw_)
+        return dst
+
+    def dwconv(self, src, w_hwc, bias, stride, act, pad=None):
+        s = self.T(src)
+        c = s['c']
+        assert w_hwc.shape == (3, 3, c)
+        if pad is None:
+            ho, pt = same_pad(s['h'], 3, stride)
+            wo, pl = same_pad(s['w'], 3, stride)
+        else:
+            pt = pl = pad
+            ho = (s['h'] + 2 * pad - 3) // stride + 1
+            wo = (s['w'] + 2 * pad - 3) // stride + 1
+        cp = rup(c, 8)
+        wp = np.zeros((9, cp), dtype=np.float16)
+        wp[:, :c] = w_hwc.reshape(9, c).astype(np.float16)
+        bp = np.zeros(cp, dtype=np.float32)
+        bp[:c] = bias
+        dst = self.tensor(ho, wo, c)
+        self._op(OP_DWCONV, src=src, dst=dst, stride=stride, pad_t=pt, pad_l=pl, cout_pad=cp, act=act,
+                 w_off=self.add_blob(wp), b_off=self.add_blob(bp))
+        return dst
+
+    def maxpool(self, src, k, stride, pad, dst=None):
+        s = self.T(src)
+        ho = (s['h'] + 2 * pad - k) // stride + 1
+        wo = (s['w'] + 2 * pad - k) // stride + 1
+        if dst is None:
+            dst = self.tensor(ho, wo, s['c'])
+        self._op(OP_MAXPOOL, src=src, dst=dst, kh=k, stride=stride, pad_t=pad, cout_pad=rup(s['c'], 8))
+        return dst
+
+    def upsample2(self, src, dst):
+        s = self.T(src)
+        self._op(OP_UPSAMPLE, src=src, dst=dst, cout_pad=rup(s['c'], 8))
+        return dst
+
+    def fc(self, src, w_io, bias, act, aff2=None):
+        """src f16 [h,w,c] flattened in NHWC order; w_io [K, Cout]; out f32 [Cout]."""
+        s = self.T(src)
+        assert s['cs'] == s['c'] and s['coff'] == 0
+        k, cout = w_io.shape
+        assert k == s['h'] * s['w'] * s['c'] and k % 8 == 0
+        dst = self.tensor(1, 1, cout, cs=cout, dtype=DT_F32)
+        kw_ = dict(cout=cout, act=act, w_off=self.add_blob(np.ascontiguousarray(w_io.T).astype(np.float16)),
+                   b_off=self.add_blob(bias.astype(np.float32)))
+        if aff2 is not None:
+            kw_['aff_off'] = self.add_blob(np.stack(aff2).astype(np.float32))
+            kw_['has_aff'] = 1
+        self._op(OP_FC, src=src, dst=dst, **kw_)
+        return dst
+
+    def l2norm(self, src, eps):
+        s = self.T(src)
+        dst = self.tensor(1, 1, s['c'], cs=s['cs'], dtype=DT_F32)
+        self._op(OP_L2NORM, src=src, dst=dst, f=[eps])
+        return dst
+
+    def serialize(self):
+        head = np.array([MAGIC, len(self.tensors), len(self.bufs), len(self.ops), self.in_h, self.in_w,
+                         self.out_tensor, 0], dtype=np.int32)
+        tw = np.array([[t['buf'], t['h'], t['w'], t['c'], t['cs'], t['coff'], t['dtype'], 0] for t in self.tensors],
+                      dtype=np.int32).reshape(-1)
+        bw = np.array(self.bufs, dtype=np.int32).reshape(-1)
+        words = np.concatenate([head, tw, bw] + self.ops).astype(np.int32)
+        return np.ascontiguousarray(words), bytes(self.blob)
+
+
+# ------------------------------------------------------------------------------------------- folding
+def bn_affine(wd, scope):
+    """(scale, shift) of an inference batch-norm; gamma optional (slim default scale=False)."""
+    var, mean, beta = wd[scope + '/moving_variance'], wd[scope + '/moving_mean'], wd[scope + '/beta']
+    gamma = wd.get(scope + '/gamma', np.ones_like(var))
+    s = gamma / np.sqrt(var + BN_EPS)
+    return s.astype(np.float32), (beta - mean * s).astype(np.float32)
+
+
+def fold_conv_bn(wd, scope, bn_scope=None):
+    """conv (no bias) followed by BN -> (w * s, shift)."""
+    w = wd[scope + '/weights']
+    s, t = bn_affine(wd, bn_scope or scope + '/bn')
+    return (w * s).astype(np.float32), t
+
+
+# ------------------------------------------------------------------------------------------- MARS
+MARS_BLOCKS = [('conv2_1', 32, False, True), ('conv2_3', 32, False, False), ('conv3_1', 64, True, False),
+               ('conv3_3', 64, False, False), ('conv4_1', 128, True, False), ('conv4_3', 128, False, False)]
+
+
+def synthetic_mars_weights(seed=1234):
+    """Seeded weights with the variable names/shapes of tools/freeze_model.py:88-157."""
+    rng = np.random.default_rng(seed)
+    wd = {}
+
+    def conv(scope, kh, cin, cout, gain=1.0, bias=False, bn=True):
+        wd[scope + '/weights'] = (rng.standard_normal((kh, kh, cin, cout)) * gain * math.sqrt(2.0 / (kh * kh * cin))).astype(np.float32)
+        if bias:
+            wd[scope + '/biases'] = (0.05 * rng.standard_normal(cout)).astype(np.float32)
+        if bn:
+            bnp(scope + '/bn', cout)
+
+    def bnp(scope, c):
+        wd[scope + '/beta'] = (0.1 * rng.standard_normal(c)).astype(np.float32)
+        wd[scope + '/moving_mean'] = (0.1 * rng.standard_normal(c)).astype(np.float32)
+        wd[scope + '/moving_variance'] = rng.uniform(0.5, 1.5, c).astype(np.float32)
+
+    conv('conv1_1', 3, 3, 32, gain=1.0 / 128)           # raw 0..255 pixels in
+    conv('conv1_2', 3, 32, 32)
+    cin = 32
+    for name, c, inc, first in MARS_BLOCKS:
+        if not first:
+            bnp(name + '/bn', cin)
+        conv(name + '/1', 3, cin, c)
+        conv(name + '/2', 3, c, c, gain=0.5, bias=True, bn=False)
+        if inc:
+            wd[name + '/projection/weights'] = (rng.standard_normal((1, 1, cin, c)) * math.sqrt(1.0 / cin)).astype(np.float32)
+        cin = c
+    wd['fc1/weights'] = (rng.standard_normal((4096, 128)) * math.sqrt(2.0 / 4096)).astype(np.float32)
+    bnp('fc1/bn', 128)
+    bnp('ball', 128)
+    return wd
+
+
+def compile_mars(wd, in_h=64, in_w=32):
+    """tools/freeze_model.py:88-157 as an op program; input u8 BGR [n,64,32,3] -> f32 [n,128]."""
+    P = Program(in_h, in_w)
+    x = P.input(swap_rb=True)                                                  # :175-177 BGR -> RGB
+    w, b = fold_conv_bn(wd, 'conv1_1'); x = P.conv(x, w, b, act=ACT_ELU)        # :101-105
+    w, b = fold_conv_bn(wd, 'conv1_2'); x = P.conv(x, w, b, act=ACT_ELU)        # :106-110
+    x = P.maxpool(x, 3, 2, 0)                                                  # :116 VALID
+    raw, pre = x, x                  # raw = block input (skip path), pre = what conv "1" reads
+    for i, (name, c, inc, first) in enumerate(MARS_BLOCKS):
+        stride = 2 if inc else 1
+        w, b = fold_conv_bn(wd, name + '/1')
+        h1 = P.conv(pre, w, b, stride=stride, act=ACT_ELU)                      # :58-62
+        if inc:
+            skip = P.conv(raw, wd[name + '/projection/weights'], np.zeros(c, np.float32), stride=2)   # :30-36
+        else:
+            skip = raw
+        nxt = MARS_BLOCKS[i + 1][0] if i + 1 < len(MARS_BLOCKS) else None
+        s = P.T(h1)
+        out = P.tensor(s['h'], s['w'], c)
+        if nxt is not None:          # the next block's BN+ELU pre-activation is a second epilogue output (:17-21)
+            out2 = P.tensor(s['h'], s['w'], c)
+            P.conv(h1, wd[name + '/2/weights'], wd[name + '/2/biases'], dst=out, res=skip, dst2=out2,
+                   aff2=bn_affine(wd, nxt + '/bn'))                             # :68-72 + :37/:39 skip add
+            raw, pre = out, out2
+        else:
+            P.conv(h1, wd[name + '/2/weights'], wd[name + '/2/biases'], dst=out, res=skip)
+            raw = pre = out
+    w, b = fold_conv_bn(wd, 'fc1', 'fc1/bn')                                    # :143-147 (w is [4096,128])
+    f = P.fc(raw, w, b, ACT_ELU, aff2=bn_affine(wd, 'ball'))                    # :152 "ball" BN
+    P.out_tensor = P.l2norm(f, 1e-8)                                           # :153-156
+    P.meta = dict(kind='mars', out_dim=128)
+    return P
+
+
+# ------------------------------------------------------------------------------------------- SSD-MobileNet-v1
+MOBILENET_V1 = [(64, 1), (128, 2), (128, 1), (256, 2), (256, 1), (512, 2), (512, 1), (512, 1), (512, 1), (512, 1),
+                (512, 1), (1024, 2), (1024, 1)]
+SSD_EXTRAS = [(256, 512), (128, 256), (128, 256), (64, 128)]
+SSD_ANCHORS_PER_MAP = [3, 6, 6, 6, 6, 6]
+SSD_CLASSES = 91
+
+
+def ssd_anchors(in_size=300):
+    """TF-OD-API multiple-grid anchor generator for ssd_mobilenet_v1 (min 0.2, max 0.95, 6 maps,
+    aspect ratios 1,2,1/2,3,1/3, reduced boxes in the lowest map) -> f32 [1917,4] (yc, xc, h, w)."""
+    maps, s = [], in_size
+    s = same_pad(s, 3, 2)[0]
+    for c, st in MOBILENET_V1:
+        s = same_pad(s, 3, st)[0]
+        if (c, st) == (512, 1):
+            f0 = s
+    maps = [f0, s]
+    for _ in SSD_EXTRAS:
+        s = same_pad(s, 3, 2)[0]
+        maps.append(s)
+    scales = [0.2 + (0.95 - 0.2) * i / 5 for i in range(6)] + [1.0]
+    out = []
+    for k, fm in enumerate(maps):
+        if k == 0:
+            specs = [(0.1, 1.0), (scales[0], 2.0), (scales[0], 0.5)]
+        else:
+            specs = [(scales[k], ar) for ar in (1.0, 2.0, 0.5, 3.0, 1.0 / 3)] + [(math.sqrt(scales[k] * scales[k + 1]), 1.0)]
+        for y in range(fm):
+            for x in range(fm):
+                for sc, ar in specs:
+                    out.append(((y + 0.5) / fm, (x + 0.5) / fm, sc / math.sqrt(ar), sc * math.sqrt(ar)))
+    return np.array(out, dtype=np.float32), maps
+
+
+def synthetic_ssd_weights(seed=1234):
+    rng = np.random.default_rng(seed)
+    wd = {}
+
+    def bnp(scope, c):
+        wd[scope + '/gamma'] = rng.uniform(0.8, 1.2, c).astype(np.float32)
+        wd[scope + '/beta'] = (0.1 * rng.standard_normal(c)).astype(np.float32)
+        wd[scope + '/moving_mean'] = (0.1 * rng.standard_normal(c)).astype(np.float32)
+        wd[scope + '/moving_variance'] = rng.uniform(0.5, 1.5, c).astype(np.float32)
+
+    def conv(scope, k, cin, cout):
+        wd[scope + '/weights'] = (rng.standard_normal((k, k, cin, cout)) * math.sqrt(2.0 / (k * k * cin))).astype(np.float32)
+        bnp(scope + '/bn', cout)
+
+    conv('conv0', 3, 3, 32)
+    cin = 32
+    for i, (c, st) in enumerate(MOBILENET_V1, 1):
+        wd[f'dw{i}/weights'] = (rng.standard_normal((3, 3, cin, 1)) * math.sqrt(2.0 / 9)).astype(np.float32)
+        bnp(f'dw{i}/bn', cin)
+        conv(f'pw{i}', 1, cin, c)
+        cin = c
+    feats = [512, 1024]
+    for j, (c1, c2) in enumerate(SSD_EXTRAS, 1):
+        conv(f'extra{j}_1', 1, cin, c1)
+        conv(f'extra{j}_2', 3, c1, c2)
+        cin = c2
+        feats.append(c2)
+    for k, (c, a) in enumerate(zip(feats, SSD_ANCHORS_PER_MAP)):
+        wd[f'box{k}/weights'] = (rng.standard_normal((1, 1, c, a * 4)) * math.sqrt(1.0 / c)).astype(np.float32)
+        wd[f'box{k}/biases'] = (0.1 * rng.standard_normal(a * 4)).astype(np.float32)
+        wd[f'cls{k}/weights'] = (rng.standard_normal((1, 1, c, a * SSD_CLASSES)) * math.sqrt(1.0 / c)).astype(np.float32)
+        wd[f'cls{k}/biases'] = (rng.standard_normal(a * SSD_CLASSES) - 3.0).astype(np.float32)
+    return wd
+
+
+def compile_ssd_mobilenet(wd, in_size=300):
+    """u8 RGB [n,300,300,3] -> f32 [n,1917,4+91] raw box encodings + class logits."""
+    P = Program(in_size, in_size)
+    anchors, maps = ssd_anchors(in_size)
+    n_anchors = len(anchors)
+    ld = 4 + SSD_CLASSES
+    x = P.input(swap_rb=False, mean=127.5, scale=1.0 / 127.5)
+    w, b = fold_conv_bn(wd, 'conv0'); x = P.conv(x, w, b, stride=2, act=ACT_RELU6)
+    feats = []
+    for i, (c, st) in enumerate(MOBILENET_V1, 1):
+        s, t = bn_affine(wd, f'dw{i}/bn')
+        x = P.dwconv(x, wd[f'dw{i}/weights'][:, :, :, 0] * s, t, st, ACT_RELU6)
+        w, b = fold_conv_bn(wd, f'pw{i}'); x = P.conv(x, w, b, act=ACT_RELU6)
+        if i in (11, 13):
+            feats.append(x)
+    for j in range(1, 5):
+        w, b = fold_conv_bn(wd, f'extra{j}_1'); x = P.conv(x, w, b, act=ACT_RELU6)
+        w, b = fold_conv_bn(wd, f'extra{j}_2'); x = P.conv(x, w, b, stride=2, act=ACT_RELU6)
+        feats.append(x)
+    out = P.tensor(n_anchors, 1, ld, cs=ld, dtype=DT_F32)
+    base = 0
+    for k, (ft, a) in enumerate(zip(feats, SSD_ANCHORS_PER_MAP)):
+        fm = P.T(ft)['h']
+        assert fm == maps[k]
+        P.conv(ft, wd[f'box{k}/weights'], wd[f'box{k}/biases'], dst=out, epi=EPI_SSD_HEAD, p=[4, n_anchors, base, ld, 0, a])
+        P.conv(ft, wd[f'cls{k}/weights'], wd[f'cls{k}/biases'], dst=out, epi=EPI_SSD_HEAD,
+               p=[SSD_CLASSES, n_anchors, base, ld, 4, a])
+        base += fm * fm * a
+    assert base == n_anchors
+    P.out_tensor = out
+    P.meta = dict(kind='ssd_mobilenet_v1', anchors=anchors, n_classes=SSD_CLASSES)
+    return P
+
+
+# ------------------------------------------------------------------------------------------- YOLOv5s
+YOLO_ANCHORS = [[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]]   # yolov5s.yaml:6-10
+YOLO_NC = 80
+
+
+class _YoloNames:
+    """Walks detectors/yolov5/yolov5s.yaml:12-48 (depth 0.33, width 0.50) and yields conv specs."""
+
+    def __init__(self):
+        self.convs = []          # (name, k, cin, cout)
+
+    def conv(self, name, k, cin, cout):
+        self.convs.append((name, k, cin, cout))
+
+    def c3(self, name, c1, c2, n):
+        c_ = c2 // 2
+        self.conv(name + '.cv1', 1, c1, c_)
+        self.conv(name + '.cv2', 1, c1, c_)
+        self.conv(name + '.cv3', 1, 2 * c_, c2)
+        for i in range(n):
+            self.conv(f'{name}.m{i}.cv1', 1, c_, c_)
+            self.conv(f'{name}.m{i}.cv2', 3, c_, c_)
+
+
+def yolov5s_convs():
+    y = _YoloNames()
+    y.conv('m0.focus', 3, 12, 32)
+    y.conv('m1', 3, 32, 64); y.c3('m2', 64, 64, 1)
+    y.conv('m3', 3, 64, 128); y.c3('m4', 128, 128, 3)
+    y.conv('m5', 3, 128, 256); y.c3('m6', 256, 256, 3)
+    y.conv('m7', 3, 256, 512)
+    y.conv('m8.cv1', 1, 512, 256); y.conv('m8.cv2', 1, 1024, 512)          # SPP
+    y.c3('m9', 512, 512, 1)
+    y.conv('m10', 1, 512, 256); y.c3('m13', 512, 256, 1)
+    y.conv('m14', 1, 256, 128); y.c3('m17', 256, 128, 1)
+    y.conv('m18', 3, 128, 128); y.c3('m20', 256, 256, 1)
+    y.conv('m21', 3, 256, 256); y.c3('m23', 512, 512, 1)
+    return y.convs
+
+
+def synthetic_yolov5s_weights(seed=1234):
+    rng = np.random.default_rng(seed)
+    wd = {}
+    for name, k, cin, cout in yolov5s_convs():
+        gain = 1.0 / 255 if name == 'm0.focus' else 1.0         # raw 0..255 pixels in (tools/yolov5.py:100)
+        wd[name + '/weights'] = (rng.standard_normal((k, k, cin, cout)) * gain * math.sqrt(2.0 / (k * k * cin))).astype(np.float32)
+        wd[name + '/bn/gamma'] = rng.uniform(0.8, 1.2, cout).astype(np.float32)
+        wd[name + '/bn/beta'] = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+        wd[name + '/bn/moving_mean'] = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+        wd[name + '/bn/moving_variance'] = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    for i, c in enumerate((128, 256, 512)):
+        wd[f'detect{i}/weights'] = (rng.standard_normal((1, 1, c, 3 * (5 + YOLO_NC))) * math.sqrt(1.0 / c)).astype(np.float32)
+        b = (0.5 * rng.standard_normal(3 * (5 + YOLO_NC))).astype(np.float32).reshape(3, -1)
+        b[:, 4] -= 3.0                                              # most cells are background
+        b[:, 5:] -= 1.0
+        wd[f'detect{i}/biases'] = b.reshape(-1)
+    return wd
+
+
+def compile_yolov5s(wd, in_size=640):
+    """u8 RGB [n,640,640,3] -> f32 [n,25200,85] decoded rows (xywh normalised, obj, cls) as the
+    reference reads them at tools/yolov5.py:109."""
+    P = Program(in_size, in_size)
+
+    def cv(name, src, k=1, s=1, dst=None):
+        w, b = fold_conv_bn(wd, name)
+        return P.conv(src, w, b, stride=s, pad=k // 2, act=ACT_SILU, dst=dst)
+
+    def c3(name, src, c2, n, shortcut, dst=None):
+        c_ = c2 // 2
+        s = P.T(src)
+        cat = P.tensor(s['h'], s['w'], 2 * c_)
+        left, right = P.view(cat, 0, c_), P.view(cat, c_, c_)
+        y = cv(name + '.cv1', src, dst=left if n == 0 else None)
+        for i in range(n):
+            h = cv(f'{name}.m{i}.cv1', y)
+            w, b = fold_conv_bn(wd, f'{name}.m{i}.cv2')
+            y = P.conv(h, w, b, pad=1, act=ACT_SILU, res=y if shortcut else -1,
+                       dst=left if i == n - 1 else None)
+        cv(name + '.cv2', src, dst=right)
+        return cv(name + '.cv3', cat, dst=dst)
+
+    x = P.input(swap_rb=False, s2d=True)                                    # Focus slicing
+    x = cv('m0.focus', x, 3)
+    x = cv('m1', x, 3, 2); x = c3('m2', x, 64, 1, True)
+    x = cv('m3', x, 3, 2)
+    s = P.T(x)
+    cat17 = P.tensor(s['h'] // 2 * 2, s['w'] // 2 * 2, 256)                 # [up(m14) | m4]
+    x4 = c3('m4', x, 128, 3, True, dst=P.view(cat17, 128, 128))
+    x = cv('m5', x4, 3, 2)
+    s = P.T(x)
+    cat13 = P.tensor(s['h'], s['w'], 512)                                   # [up(m10) | m6]
+    x6 = c3('m6', x, 256, 3, True, dst=P.view(cat13, 256, 256))
+    x = cv('m7', x6, 3, 2)
+    s = P.T(x)
+    spp = P.tensor(s['h'], s['w'], 1024)                                    # [x | mp5 | mp9 | mp13]
+    x = cv('m8.cv1', x, dst=P.view(spp, 0, 256))
+    for i, k in enumerate((5, 9, 13)):
+        P.maxpool(x, k, 1, k // 2, dst=P.view(spp, 256 * (i + 1), 256))
+    x = cv('m8.cv2', spp)
+    x = c3('m9', x, 512, 1, False)
+    cat23 = P.tensor(s['h'], s['w'], 512)                                   # [m21 | m10]
+    x10 = cv('m10', x, dst=P.view(cat23, 256, 256))
+    P.upsample2(x10, P.view(cat13, 0, 256))
+    x = c3('m13', cat13, 256, 1, False)
+    s = P.T(x)
+    cat20 = P.tensor(s['h'], s['w'], 256)                                   # [m18 | m14]
+    x14 = cv('m14', x, dst=P.view(cat20, 128, 128))
+    P.upsample2(x14, P.view(cat17, 0, 128))
+    p3 = c3('m17', cat17, 128, 1, False)
+    cv('m18', p3, 3, 2, dst=P.view(cat20, 0, 128))
+    p4 = c3('m20', cat20, 256, 1, False)
+    cv('m21', p4, 3, 2, dst=P.view(cat23, 0, 256))
+    p5 = c3('m23', cat23, 512, 1, False)
+    no = 5 + YOLO_NC
+    rows = sum(3 * P.T(t)['h'] * P.T(t)['w'] for t in (p3, p4, p5))
+    out = P.tensor(rows, 1, no, cs=no, dtype=DT_F32)
+    base = 0
+    for i, t in enumerate((p3, p4, p5)):
+        d = P.T(t)
+        stride = in_size // d['h']
+        P.conv(t, wd[f'detect{i}/weights'], wd[f'detect{i}/biases'], dst=out, epi=EPI_YOLO,
+               p=[no, rows, base, 0, in_size, 0], f=[float(v) for v in YOLO_ANCHORS[i]] + [float(stride), float(in_size)])
+        base += 3 * d['h'] * d['w']
+    P.out_tensor = out
+    P.meta = dict(kind='yolov5s', rows=rows, n_classes=YOLO_NC)
+    return P

@@ -1,0 +1,111 @@
+"""Re-ID box encoder with the reference's surface (tools/generate_detections.py:26-216 upstream):
+`create_box_encoder(model_filename, batch_size=..., num_threads=...)` -> `encoder(image, boxes, timing)`.
+
+Crop arithmetic + bilinear resample run in csrc/image.hip (one launch for all boxes), the MARS
+forward pass in csrc/nets.hip (f16 MFMA).  `encoder.encode_device` keeps features in HBM for the
+tracker; the reference-shaped call returns a host ndarray.
+"""
+from time import time
+import numpy as np
+import torch
+
+from .._lib import lib, check
+from ..runtime import default_context, ptr
+from .. import nets
+from ..engine import Net
+from .weights_io import load_named_weights
+
+
+def crop_patches_device(ctx, frame_dev, H, W, boxes_int64, ph, pw):
+    """-> (patches u8 [n, ph, pw, 3] on device, valid int32 [n] on host)."""
+    n = len(boxes_int64)
+    out = ctx.empty((n, ph, pw, 3), torch.uint8)
+    valid = np.ones(n, dtype=np.int32)
+    b = np.ascontiguousarray(boxes_int64, dtype=np.int64).reshape(n, 4)
+    check(lib().dd_crop_resize(ctx.handle, ptr(frame_dev), H, W, ptr(b), n, ph, pw, ptr(out), ptr(valid), None),
+          'dd_crop_resize')
+    return out, valid
+
+
+def extract_image_patch(image, bbox, patch_shape, context=None):
+    """tools/generate_detections.py:40-84; returns None where the reference does."""
+    ctx = context or default_context()
+    img = np.ascontiguousarray(image, dtype=np.uint8)
+    H, W = img.shape[:2]
+    bb = np.array(bbox)
+    if bb.dtype.kind == 'f':         # float boxes: replay the reference's float arithmetic, then truncate
+        if patch_shape is not None:
+            new_width = float(patch_shape[1]) / patch_shape[0] * bb[3]
+            bb[0] -= (new_width - bb[2]) / 2
+            bb[2] = new_width
+        bb[2:] += bb[:2]
+        bb = bb.astype(np.int64)
+        bb[2:] -= bb[:2]
+        raise NotImplementedError('float boxes are not on the hot path (deepdish.py:950-951 makes them ints)')
+    dev = ctx.to_device(img)
+    out, valid = crop_patches_device(ctx, dev, H, W, bb.reshape(1, 4), patch_shape[0], patch_shape[1])
+    if not valid[0]:
+        return None
+    return ctx.to_host(out)[0]
+
+
+class MarsImageEncoder(object):
+    """Counterpart of TFLiteImageEncoder / ImageEncoder (generate_detections.py:118-177)."""
+
+    def __init__(self, model_filename, num_threads=1, max_batch=256, context=None):
+        self.ctx = context or default_context()
+        wd = load_named_weights(model_filename, nets.synthetic_mars_weights)
+        self.weights = wd
+        self.net = Net(nets.compile_mars(wd), max_batch=max_batch, context=self.ctx)
+        self.image_shape = (64, 32, 3)
+        self.height, self.width = 64, 32
+        self.feature_dim = 128
+        self.max_batch_size = max_batch
+
+    def encode_device(self, patches_dev):
+        """u8 [n,64,32,3] on device -> f32 [n,128] on device."""
+        n = int(patches_dev.shape[0])
+        out = self.ctx.empty((n, 128), torch.float32)
+        for s in range(0, n, self.max_batch_size):
+            e = min(n, s + self.max_batch_size)
+            self.net.forward(patches_dev[s:e])
+            check(lib().dd_net_read(self.net._h, -1, e - s, ptr(out[s:e]), 1, None), 'dd_net_read')
+        return out
+
+    def __call__(self, data_in, batch_size=32):
+        patches = self.ctx.to_device(np.asarray(data_in, dtype=np.uint8))
+        return self.ctx.to_host(self.encode_device(patches))
+
+
+def create_box_encoder(model_filename, input_name="images", output_name="features", batch_size=32,
+                       num_threads=1, context=None):
+    if 'dummy' in model_filename or 'constant' in model_filename:
+        raise NotImplementedError('the dummy/constant test encoders of the reference are not built yet')
+    image_encoder = MarsImageEncoder(model_filename, num_threads=num_threads, context=context)
+    ctx = image_encoder.ctx
+    ph, pw = image_encoder.image_shape[:2]
+
+    def encode_device(frame_dev, H, W, boxes):
+        """Hot path: frame already in HBM; returns (features f32 [n,128] on device, valid)."""
+        patches, valid = crop_patches_device(ctx, frame_dev, H, W, boxes, ph, pw)
+        return image_encoder.encode_device(patches), valid
+
+    def encoder(image, boxes, timing=False):
+        if len(boxes) == 0:                                       # generate_detections.py:193-197
+            return (np.array([]), 0) if timing else np.array([])
+        img = np.ascontiguousarray(image, dtype=np.uint8)
+        frame_dev = ctx.to_device(img)
+        t1 = time()
+        feats, valid = encode_device(frame_dev, img.shape[0], img.shape[1],
+                                     np.asarray([np.asarray(b) for b in boxes], dtype=np.int64))
+        result = ctx.to_host(feats)
+        t2 = time()
+        for box, ok in zip(boxes, valid):
+            if not ok:                                            # :201-204 (the reference substitutes noise)
+                print("WARNING: Failed to extract image patch: %s." % str(box))
+        return (result, t2 - t1) if timing else result
+
+    encoder.image_encoder = image_encoder
+    encoder.encode_device = encode_device
+    encoder.width, encoder.height = image_encoder.width, image_encoder.height
+    return encoder

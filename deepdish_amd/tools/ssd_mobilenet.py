@@ -1,0 +1,154 @@
+"""SSD-MobileNet detector plugin with the reference's surface (tools/ssd_mobilenet.py:30-213 upstream):
+`SSD_MOBILENET(wanted_labels, model_file, label_file, num_threads, edgetpu)` and
+`detect_image(img) -> (boxes tlwh, labels, scores)`.
+
+Device side: Lanczos stretch resize (csrc/image.hip) -> MobileNet-v1 SSD forward (csrc/nets.hip, f16
+MFMA) -> anchor decode / sigmoid / fast NMS / top-10 (csrc/post.hip) -> per-class NMS
+(csrc/nms.hip mode 1).  Host side: the dozen-element list handling of predict / detect_image.
+"""
+import os
+import numpy as np
+import torch
+
+from .._lib import lib, check
+from ..runtime import default_context, ptr
+from .. import nets
+from ..engine import Net
+from .weights_io import load_named_weights
+
+COCO_LABELS_FALLBACK = None
+
+
+class SSDMobileNet:
+    MAX_DET = 10
+
+    def __init__(self, model_path, label_path, num_threads=None, edgetpu=False, libedgetpu=None,
+                 score_threshold=0.5, context=None, max_batch=1):
+        if edgetpu:
+            raise ValueError('EdgeTPU delegates do not exist on MI355X')
+        self.ctx = context or default_context()
+        self.use_edgetpu = False
+        self.num_threads = num_threads
+        wd = load_named_weights(model_path, nets.synthetic_ssd_weights)
+        self.weights = wd
+        prog = nets.compile_ssd_mobilenet(wd)
+        self.net = Net(prog, max_batch=max_batch, context=self.ctx)
+        self.height = self.width = prog.in_h
+        self.anchors = prog.meta['anchors']
+        self.n_classes = prog.meta['n_classes']
+        self._anchors_dev = self.ctx.to_device(self.anchors)
+        self.labels = self.load_labels(label_path)
+        c = self.ctx
+        self._resized = c.empty((1, self.height, self.width, 3), torch.uint8)
+        self._boxes = c.empty((self.MAX_DET, 4), torch.float32)
+        self._classes = c.empty((self.MAX_DET,), torch.float32)
+        self._scores = c.empty((self.MAX_DET,), torch.float32)
+        self._count = c.empty((1,), torch.int32)
+
+    def load_labels(self, path):
+        with open(path, 'r') as f:
+            return {i: line.strip() for i, line in enumerate(f.readlines())}
+
+    # ---- device stages
+    def prepare_image_device(self, img_dev, H, W, src_c, swap_rb=False):
+        """ssd_mobilenet.py:54-57: img.convert('RGB').resize((w,h), ANTIALIAS) -> u8 [1,h,w,3] in HBM."""
+        check(lib().dd_resize_lanczos(self.ctx.handle, ptr(img_dev), H, W, src_c, int(swap_rb),
+                                      ptr(self._resized), self.height, self.width, None), 'dd_resize_lanczos')
+        return self._resized
+
+    def invoke_device(self, resized_dev):
+        """ssd_mobilenet.py:102-109: interpreter.invoke() and its four output tensors."""
+        self.net.forward(resized_dev)
+        raw = self.net.output_ptr()
+        check(lib().dd_ssd_postprocess(self.ctx.handle, raw, ptr(self._anchors_dev), len(self.anchors), self.n_classes,
+                                       self.MAX_DET, 1e-8, 0.6, ptr(self._boxes), ptr(self._classes),
+                                       ptr(self._scores), ptr(self._count), None), 'dd_ssd_postprocess')
+        self.ctx.sync()
+        return [self._boxes.cpu().numpy(), self._classes.cpu().numpy(), self._scores.cpu().numpy(),
+                float(self._count.cpu().numpy()[0])]
+
+    def nms_boxes(self, boxes, labels, scores, iou_threshold):
+        """ssd_mobilenet.py:59-98 (one dd_nms_ssd launch per class present)."""
+        nboxes, nlabels, nscores = [], [], []
+        for c in set(labels):
+            inds = np.where(labels == c)
+            b, cl, s = boxes[inds], labels[inds], scores[inds]
+            k = len(b)
+            db, dsc = self.ctx.to_device(b.astype(np.float64)), self.ctx.to_device(s.astype(np.float64))
+            out, cnt = self.ctx.empty((k,), torch.int32), self.ctx.empty((1,), torch.int32)
+            check(lib().dd_nms_ssd(self.ctx.handle, ptr(db), ptr(dsc), k, float(iou_threshold), ptr(out), ptr(cnt), None),
+                  'dd_nms_ssd')
+            keep = self.ctx.to_host(out)[:int(self.ctx.to_host(cnt)[0])]
+            nboxes.append(b[keep]); nlabels.append(cl[keep]); nscores.append(s[keep])
+        return nboxes, nlabels, nscores
+
+    def postprocess(self, output, confidence=0.5, iou_threshold=0.5, original_image_size=None):
+        """ssd_mobilenet.py:111-150."""
+        idx = np.where(np.isnan(output[0]))
+        output[2][np.reshape(idx, -1)] = 0
+        output[2][np.where(np.isnan(output[2]))] = 0
+        indices = np.where(output[2] >= confidence)
+        w, h = original_image_size if original_image_size is not None else (self.width, self.height)
+        boxes = output[0][indices][:, [1, 0, 3, 2]] * [w, h, w, h]
+        labels = output[1][indices]
+        scores = output[2][indices]
+        n_boxes, n_labels, n_scores = self.nms_boxes(boxes, labels, scores, iou_threshold)
+        if n_boxes:
+            boxes = np.concatenate(n_boxes)
+            labels = np.concatenate(n_labels).astype(np.uint)
+            scores = np.concatenate(n_scores)
+            names = []
+            for li in labels:
+                if 0 <= li < len(self.labels) - 1:
+                    names.append(self.labels[li + 1])
+                else:
+                    print("Invalid label index: {} in {}".format(li, labels))
+            return boxes, names, scores
+        return [], [], []
+
+    def predict_array(self, rgb, confidence=0.5, iou_threshold=0.5):
+        """rgb: u8 ndarray [H,W,3 or 4] in RGB(A) order, original resolution."""
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        H, W, C = rgb.shape
+        dev = self.ctx.to_device(rgb)
+        out = self.invoke_device(self.prepare_image_device(dev, H, W, C))
+        return self.postprocess(out, confidence, iou_threshold, (W, H))
+
+
+class SSD_MOBILENET():
+    def __init__(self, wanted_labels=None, model_file=None, label_file=None, num_threads=None, edgetpu=False,
+                 libedgetpu=None, score_threshold=0.5, context=None):
+        if model_file is None:
+            model_file = 'ssd_mobilenet.tflite'
+        if label_file is None:
+            label_file = 'coco_labelmap.txt'
+        self.ssdm = SSDMobileNet(model_file, label_file, num_threads=num_threads, edgetpu=edgetpu,
+                                 libedgetpu=libedgetpu, score_threshold=score_threshold, context=context)
+        self.wanted_labels = ['person'] if wanted_labels is None else wanted_labels
+        self.score_threshold = score_threshold
+        self.labels = self.ssdm.labels
+        self.width, self.height = self.ssdm.width, self.ssdm.height
+        self.use_edgetpu = self.ssdm.use_edgetpu
+        self.num_threads = self.ssdm.num_threads
+
+    def _filter(self, boxes, labels, scores):
+        rb, rl, rs = [], [], []
+        for i in range(len(boxes)):                                # ssd_mobilenet.py:204-212
+            if labels[i] in self.wanted_labels and scores[i] >= self.score_threshold:
+                box = boxes[i]
+                rb.append([box[0], box[1], box[2] - box[0], box[3] - box[1]])
+                rl.append(labels[i])
+                rs.append(scores[i])
+        return rb, rl, rs
+
+    def detect_image(self, img):
+        """img: PIL image (RGB/RGBA, as deepdish.py:882 builds it) or an RGB(A) ndarray."""
+        arr = np.asarray(img)
+        return self._filter(*self.ssdm.predict_array(arr))
+
+    def detect_frame_device(self, frame_dev, H, W):
+        """Hot path: BGR u8 frame already in HBM (the BGR->RGB swap of deepdish.py:882 is fused into
+        the resize kernel)."""
+        s = self.ssdm
+        out = s.invoke_device(s.prepare_image_device(frame_dev, H, W, 3, swap_rb=True))
+        return self._filter(*s.postprocess(out, original_image_size=(W, H)))

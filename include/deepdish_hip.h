@@ -146,20 +146,23 @@ int dd_resize_bilinear(dd_ctx *ctx, const uint8_t *src, int H, int W, int c,
                        uint8_t *dst, int h, int w, void *stream);
 
 /* ---------------------------------------------------------------- networks
- * Weights come as one f32 blob in the order documented in deepdish_amd/nets.py (BN folded by the
- * loader).  kind: "mars" (tools/freeze_model.py:88-157 + generate_detections.py:151-177),
- * "ssd_mobilenet_v1" (tools/ssd_mobilenet.py:31-52,100-109), "yolov5s"
- * (detectors/yolov5/yolov5s.yaml + tools/yolov5.py:71-109). */
-int dd_net_create(dd_ctx *ctx, const char *kind, int in_h, int in_w, int max_batch,
-                  const float *weights_host, int64_t n_weights, dd_net **out);
+ * Replaces tflite_runtime.Interpreter(model_path).invoke() at tools/ssd_mobilenet.py:35-38,102-109,
+ * tools/yolov5.py:71-79,107-109 and tools/generate_detections.py:153-154,169-171.  A model is an op
+ * program + one weight blob compiled on the host (deepdish_amd/nets.py: MARS per
+ * tools/freeze_model.py:88-157, SSD-MobileNet-v1, YOLOv5s per detectors/yolov5/yolov5s.yaml) -- the
+ * analogue of the reference's .tflite file; the word layout is documented in csrc/nets.hip. */
+int dd_net_create(dd_ctx *ctx, const int32_t *program_host, int n_words, const void *weights_host,
+                  int64_t n_weight_bytes, int max_batch, dd_net **out);
 int dd_net_destroy(dd_net *net);
-int dd_net_weight_count(const char *kind, int in_h, int in_w, int64_t *out_host);
-/* input u8 [n][in_h][in_w][3] (BGR for "mars" as generate_detections.py:168, RGB otherwise).
- * "mars": out f32 [n][128] unit-norm features.
- * "ssd_mobilenet_v1": out f32 [n][n_anchors][4 + n_classes] raw box encodings + class logits.
- * "yolov5s": out f32 [n][n_rows][85] as tools/yolov5.py:109 reads it. */
-int dd_net_forward(dd_net *net, const uint8_t *input, int n, float *out, void *stream);
-int dd_net_output_shape(dd_net *net, int *rows_host, int *cols_host);
+/* input u8 [n][in_h][in_w][3]; results stay in the net's own device tensors (dd_net_output). */
+int dd_net_forward(dd_net *net, const uint8_t *input, int n, void *stream);
+/* tensor < 0 selects the program's declared output.  dtype: 0 f16, 1 f32, 2 u8.  Row n of the
+ * tensor starts at dev_ptr + n * h * w * cs elements. */
+int dd_net_output(dd_net *net, int tensor, void **dev_ptr_host, int *h_host, int *w_host, int *c_host,
+                  int *cs_host, int *dtype_host);
+
+/* Copy the first n images of a (whole, un-sliced) tensor to caller memory: n*h*w*cs elements. */
+int dd_net_read(dd_net *net, int tensor, int n, void *dst, int dst_on_device, void *stream);
 
 /* TFLite_Detection_PostProcess (inside the reference's .tflite graph, tools/ssd_mobilenet.py:103-109):
  * anchor decode, sigmoid, per-class NMS, top max_det.  raw f32 [n_anchors][4+n_classes] ->

@@ -1,0 +1,69 @@
+"""GPU: image front-end kernels (crop + bilinear, Lanczos stretch, bilinear stretch) -- integer
+arithmetic, so the bar is bit-exact against the oracle (and against Pillow itself for Lanczos)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    from deepdish_amd.runtime import default_context
+    return default_context()
+
+
+def test_crop_resize_vs_oracle(ctx):
+    from deepdish_amd.tools.generate_detections import crop_patches_device
+    from oracle import image_np
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    boxes = np.c_[rng.integers(-20, 630, 60), rng.integers(-20, 470, 60), rng.integers(2, 120, 60), rng.integers(2, 200, 60)]
+    extra = np.array([[100, 50, 41, 90], [100, 50, 40, 91], [10, 10, 64, 128], [0, 0, 640, 480], [639, 479, 5, 5],
+                      [700, 10, 20, 40], [-50, -50, 20, 40], [5, 5, 1, 2], [300, 200, 16, 32]])
+    boxes = np.concatenate([boxes, extra]).astype(np.int64)
+    dev = ctx.to_device(img)
+    out, valid = crop_patches_device(ctx, dev, 480, 640, boxes, 64, 32)
+    out = ctx.to_host(out)
+    n_valid = 0
+    for i, b in enumerate(boxes):
+        want = image_np.extract_image_patch(img, b, (64, 32))
+        assert bool(valid[i]) == (want is not None), (i, b)
+        if want is not None:
+            n_valid += 1
+            np.testing.assert_array_equal(out[i], want, err_msg=str(b))
+        else:
+            assert not out[i].any()
+    assert n_valid > 40 and n_valid < len(boxes)
+    # the exact-2x path (64x128 crop) must have been exercised
+    assert image_np.crop_box(np.array([10, 10, 64, 128]), (64, 32), (480, 640)) == (10, 10, 74, 138)
+
+
+@pytest.mark.parametrize('shape', [(480, 640, 300, 300), (480, 640, 640, 640), (720, 1280, 300, 300), (97, 131, 300, 300)])
+def test_lanczos_vs_pillow(ctx, shape):
+    from PIL import Image
+    from deepdish_amd._lib import lib, check
+    from deepdish_amd.runtime import ptr
+    H, W, h, w = shape
+    rng = np.random.default_rng(1)
+    bgr = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    # what the reference does: BGR frame -> RGBA PIL image (deepdish.py:882) -> convert('RGB').resize(ANTIALIAS)
+    rgba = np.dstack([bgr[..., ::-1], np.full((H, W, 1), 255, np.uint8)])
+    want = np.asarray(Image.fromarray(rgba, 'RGBA').convert('RGB').resize((w, h), Image.LANCZOS))
+    dst = ctx.empty((h, w, 3), torch.uint8)
+    check(lib().dd_resize_lanczos(ctx.handle, ptr(ctx.to_device(bgr)), H, W, 3, 1, ptr(dst), h, w, None))
+    np.testing.assert_array_equal(ctx.to_host(dst), want)
+    check(lib().dd_resize_lanczos(ctx.handle, ptr(ctx.to_device(rgba)), H, W, 4, 0, ptr(dst), h, w, None))
+    np.testing.assert_array_equal(ctx.to_host(dst), want)
+
+
+def test_bilinear_stretch_vs_oracle(ctx):
+    from deepdish_amd._lib import lib, check
+    from deepdish_amd.runtime import ptr
+    from oracle import image_np
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    for (h, w) in ((320, 320), (300, 300), (240, 320), (960, 1280)):
+        dst = ctx.empty((h, w, 3), torch.uint8)
+        check(lib().dd_resize_bilinear(ctx.handle, ptr(ctx.to_device(img)), 480, 640, 3, ptr(dst), h, w, None))
+        np.testing.assert_array_equal(ctx.to_host(dst), image_np.resize_linear_u8(img, w, h))

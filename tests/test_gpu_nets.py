@@ -1,0 +1,93 @@
+"""GPU: the MFMA conv engine against the independent f32 torch-CPU restatement of each network,
+on seeded synthetic weights (forward parity against the real TFLite models is unpinned: no
+weights, no tflite_runtime -- see oracle/nets_torch.py)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+@pytest.fixture(scope='module')
+def mars():
+    from deepdish_amd import nets
+    from deepdish_amd.engine import Net
+    wd = nets.synthetic_mars_weights(1234)
+    return wd, Net(nets.compile_mars(wd), max_batch=64)
+
+
+def test_mars_forward_vs_oracle(mars):
+    from oracle import nets_torch
+    wd, net = mars
+    rng = np.random.default_rng(0)
+    x = rng.integers(0, 256, (37, 64, 32, 3), dtype=np.uint8)
+    x[0] = 0; x[1] = 255
+    net.forward(x)
+    got = net.read()[:, 0, 0, :]
+    assert got.shape == (37, 128)
+    want16 = nets_torch.mars_forward(wd, x, w16=True)
+    want32 = nets_torch.mars_forward(wd, x, w16=False)
+    np.testing.assert_allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-5)
+    # stated tolerance: f16 activations + f16 weights vs the f32 reference arithmetic
+    cos16 = 1.0 - np.sum(got * want16, axis=1)
+    cos32 = 1.0 - np.sum(got * want32, axis=1)
+    assert np.abs(got - want16).max() < 5e-3, np.abs(got - want16).max()
+    assert cos16.max() < 2e-4 and cos32.max() < 5e-4, (cos16.max(), cos32.max())
+    # batch independence + determinism
+    net.forward(x[5:6])
+    np.testing.assert_array_equal(net.read()[:, 0, 0, :], got[5:6])
+
+
+def test_mars_intermediate_layers(mars):
+    """First conv / pool activations, layer by layer, to localise any engine bug."""
+    import torch
+    import torch.nn.functional as F
+    from oracle import nets_torch as nt
+    wd, net = mars
+    rng = np.random.default_rng(1)
+    x = rng.integers(0, 256, (3, 64, 32, 3), dtype=np.uint8)
+    net.forward(x)
+    xt = nt._t(x[..., ::-1].astype(np.float32)).permute(0, 3, 1, 2)
+    a1 = F.elu(nt._conv_bn(xt, wd, 'conv1_1', w16=True))
+    a2 = F.elu(nt._conv_bn(a1, wd, 'conv1_2', w16=True))
+    a3 = F.max_pool2d(a2, 3, 2)
+    for tid, want in ((1, a1), (2, a2), (3, a3)):
+        got = net.read(tensor=tid).astype(np.float32)[..., :32]
+        w = want.permute(0, 2, 3, 1).numpy()
+        assert got.shape == w.shape, (got.shape, w.shape)
+        assert _rel(got, w) < 4e-3, (tid, _rel(got, w))
+
+
+def test_ssd_forward_vs_oracle():
+    from deepdish_amd import nets
+    from deepdish_amd.engine import Net
+    from oracle import nets_torch
+    wd = nets.synthetic_ssd_weights(1234)
+    net = Net(nets.compile_ssd_mobilenet(wd), max_batch=2)
+    rng = np.random.default_rng(2)
+    x = rng.integers(0, 256, (2, 300, 300, 3), dtype=np.uint8)
+    net.forward(x)
+    got = net.read()[:, :, 0, :]
+    want = nets_torch.ssd_forward(wd, x, w16=True)
+    assert got.shape == want.shape == (2, 1917, 95)
+    assert _rel(got, want) < 2e-2, _rel(got, want)
+    want32 = nets_torch.ssd_forward(wd, x, w16=False)
+    assert _rel(got, want32) < 4e-2, _rel(got, want32)
+
+
+def test_yolov5s_forward_vs_oracle():
+    from deepdish_amd import nets
+    from deepdish_amd.engine import Net
+    from oracle import nets_torch
+    wd = nets.synthetic_yolov5s_weights(1234)
+    net = Net(nets.compile_yolov5s(wd), max_batch=1)
+    rng = np.random.default_rng(3)
+    x = rng.integers(0, 256, (1, 640, 640, 3), dtype=np.uint8)
+    net.forward(x)
+    got = net.read()[:, :, 0, :]
+    want = nets_torch.yolov5s_forward(wd, x, w16=True)
+    assert got.shape == want.shape == (1, 25200, 85)
+    assert np.abs(got - want).max() < 3e-2, np.abs(got - want).max()
