@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""bench.py -- end-to-end frames/s of the detect -> encode -> track hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--streams S]
+
+A "step" is one pass of the hot path over one batch of synthetic input: one 640x480 BGR frame from
+each of the S independent video streams this rank owns (SSD-MobileNet-v1 forward + post-process on
+the frame, NMS + MARS encoder over ~20 synthetic detections per frame, deep_sort predict/update,
+count-line logic).  Frames and detections are generated before the timed region and the frames are
+resident in HBM when it starts.  With N > 1 (one rank per GPU under torch.distributed.run) every
+rank runs its own streams -- there is no data-path collective; the only exchange is one RCCL
+all-reduce of the (pos, neg, int, del) count vector after the timed region.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for the roofline/cpu_baseline fields).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+W, H = 640, 480
+N_OBJ = 20
+PEAK_F16_TFLOPS = 2500.0      # dense f16 MFMA, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--streams', type=int, default=int(os.environ.get('DD_BENCH_STREAMS', '1')),
+                    help='independent video streams per GPU (one frame of each per step)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-frames', type=int, default=40)
+    return ap.parse_args()
+
+
+def make_inputs(rank, streams, n_frames):
+    """Per stream: frames u8 [F,H,W,3] (host) and per-frame injected detections."""
+    from deepdish_amd.synth import Scene
+    out = []
+    for s in range(streams):
+        sc = Scene(seed=1000 * rank + s, n_obj=N_OBJ, width=W, height=H, n_frames=n_frames)
+        frames = np.stack([sc.frame(f) for f in range(n_frames)])
+        dets = []
+        for f in range(n_frames):
+            boxes, scores, who, _ = sc.detections(f)
+            dets.append(([tuple(int(v) for v in b) for b in boxes], ['person'] * len(boxes), [float(x) for x in scores]))
+        out.append((sc, frames, dets))
+    return out
+
+
+def cpu_baseline(n_frames):
+    """The oracle's CPU path on the same workload (kind "port"), bounded sample, rank 0 only."""
+    import torch
+    from PIL import Image
+    from deepdish_amd import nets
+    from deepdish_amd.synth import Scene
+    from oracle import deepsort_np as ds, countline_np as cl, image_np, nets_torch
+    threads = min(4, os.cpu_count() or 1)              # reference default --num-threads 4 (deepdish.py:1422)
+    torch.set_num_threads(threads)
+    sc = Scene(seed=0, n_obj=N_OBJ, width=W, height=H, n_frames=n_frames + 2)
+    wd_ssd, wd_mars = nets.synthetic_ssd_weights(1234), nets.synthetic_mars_weights(1234)
+    anchors, _ = nets.ssd_anchors(300)
+    trk = ds.Tracker(ds.Metric(0.2), max_iou_distance=0.7, max_age=60)
+    counter = cl.CountLine(sc.countline())
+
+    def one(f):
+        frame = sc.frame(f)
+        rgba = np.dstack([frame[..., ::-1], np.full((H, W, 1), 255, np.uint8)])
+        img = Image.fromarray(rgba, 'RGBA').convert('RGB').resize((300, 300), Image.LANCZOS)
+        raw = nets_torch.ssd_forward(wd_ssd, np.asarray(img)[None])
+        nets_torch.ssd_postprocess(raw[0], anchors)
+        boxes, scores, _, _ = sc.detections(f)
+        keep = ds.non_max_suppression(boxes, 0.6, scores)
+        patches = np.stack([image_np.extract_image_patch(frame, boxes[i], (64, 32)) for i in keep])
+        feats = nets_torch.mars_forward(wd_mars, patches)
+        dets = [ds.Det(boxes[i], 'person', scores[i], feats[j]) for j, i in enumerate(keep)]
+        trk.predict(); trk.update(dets); counter.step(trk)
+
+    one(0); one(1)                                       # warm-up, as the reference does (deepdish.py:895-898)
+    t0 = time.perf_counter()
+    for f in range(2, n_frames + 2):
+        one(f)
+    dt = time.perf_counter() - t0
+    return dict(value=n_frames / dt, unit='frames/s', cores=threads, kind='port',
+                sample='%d frames of the same 640x480 / ~20-detection workload, oracle path (Pillow Lanczos + '
+                       'torch-CPU f32 SSD-MobileNet-v1 and MARS + numpy deep_sort), %d torch threads' % (n_frames, threads))
+
+
+def main():
+    args = parse()
+    import torch
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    dist_on = world > 1
+    torch.cuda.set_device(local_rank)
+    if dist_on:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    from deepdish_amd.pipeline import HotPath
+    from deepdish_amd.runtime import default_context
+    ctx = default_context()
+    n_frames = args.warmup + args.steps
+    streams = make_inputs(rank, args.streams, n_frames)
+    paths = [HotPath(context=ctx) for _ in range(args.streams)]
+    dev_frames = [torch.from_numpy(fr).to(f'cuda:{local_rank}') for _, fr, _ in streams]
+    torch.cuda.synchronize()
+
+    def step(f):
+        for s in range(args.streams):
+            paths[s].step(dev_frames[s][f], injected=streams[s][2][f])
+
+    for f in range(args.warmup):
+        step(f)
+    ctx.sync(); torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for f in range(args.warmup, n_frames):
+        step(f)
+    ctx.sync(); torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=f'cuda:{local_rank}')
+    counts = torch.from_numpy(sum(p.counts() for p in paths)).to(f'cuda:{local_rank}')
+    if dist_on:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)      # RCCL: the only exchange step of the path
+    dt = float(tmax.item())
+    total_frames = args.steps * args.streams * world
+
+    if rank == 0:
+        out = {
+            'metric': 'end-to-end frames/sec (detect+encode+track) at 640x480',
+            'value': total_frames / dt, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
+            'config': {'workload': 'SSD-MobileNet-v1 (300x300) + MARS-64x32x3 + deep_sort on synthetic 640x480 BGR '
+                                   'frames, ~20 synthetic detections/frame (BASELINE.json configs[1])',
+                       'streams_per_gpu': args.streams, 'frames_per_step': args.streams * world,
+                       'parallelism': 'independent streams, %d per GPU' % args.streams,
+                       'weights': 'seeded synthetic (seed 1234)'},
+            'counts_pos_neg_int_del': [int(v) for v in counts.cpu().numpy().reshape(-1)],
+        }
+        try:
+            from deepdish_amd.profile import dominant_kernel_roofline
+            out['roofline'] = dominant_kernel_roofline(paths, dev_frames, streams, args)
+        except Exception as e:                            # never let the extra pass hide the headline number
+            out['roofline'] = None
+            out['roofline_error'] = repr(e)
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args.cpu_frames)
+        print(json.dumps(out))
+    if dist_on:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

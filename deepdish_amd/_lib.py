@@ -51,6 +51,8 @@ SIGNATURES = {
     'dd_net_output': [P, c_int, POINTER(P), POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int),
                       POINTER(c_int)],
     'dd_net_read': [P, c_int, c_int, P, c_int, P],
+    'dd_net_profile': [P, c_int],
+    'dd_net_profile_read': [P, P, c_int, POINTER(c_int)],
     'dd_ssd_postprocess': [P, P, P, c_int, c_int, c_int, c_float, c_float, P, P, P, P, P],
     'dd_yolov5_decode': [P, P, c_int, c_int, c_float, c_float, c_float, P, P, P, c_int, P, P],
     'dd_counts_accumulate': [P, P, P, c_int, P],

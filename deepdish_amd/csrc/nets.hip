@@ -439,6 +439,8 @@ struct dd_net {
     char *d_weights = nullptr;
     int64_t weight_bytes = 0;
     int in_h = 0, in_w = 0, out_tensor = -1;
+    bool profile = false;
+    std::vector<hipEvent_t> events;           // n_ops + 1 when profiling
 };
 
 namespace {
@@ -499,6 +501,7 @@ int dd_net_create(dd_ctx *ctx, const int32_t *program_host, int n_words, const v
 int dd_net_destroy(dd_net *n) {
     if (!n) return DD_OK;
     for (void *b : n->bufs) (void)hipFree(b);
+    for (hipEvent_t e : n->events) (void)hipEventDestroy(e);
     (void)hipFree(n->d_weights);
     delete n;
     return DD_OK;
@@ -515,6 +518,27 @@ int dd_net_output(dd_net *n, int tensor, void **dev_ptr, int *h, int *w, int *c,
     if (c) *c = d.c;
     if (cs) *cs = d.cs;
     if (dtype) *dtype = d.dtype;
+    return DD_OK;
+}
+
+// Per-op device timing (HIP events on the launch stream) for bench.py's roofline line.
+int dd_net_profile(dd_net *n, int enable) {
+    DD_REQUIRE(n, DD_E_ARG, "dd_net_profile: NULL net");
+    if (enable && n->events.empty()) {
+        n->events.resize(n->n_ops + 1);
+        for (auto &e : n->events) DD_HIP(hipEventCreate(&e));
+    }
+    n->profile = enable != 0;
+    return DD_OK;
+}
+
+int dd_net_profile_read(dd_net *n, float *ms_host, int cap, int *n_ops_host) {
+    DD_REQUIRE(n && ms_host && n_ops_host, DD_E_ARG, "dd_net_profile_read: NULL argument");
+    DD_REQUIRE(n->profile && !n->events.empty(), DD_E_STATE, "dd_net_profile_read: profiling is off");
+    DD_REQUIRE(cap >= n->n_ops, DD_E_ARG, "dd_net_profile_read: cap %d < %d ops", cap, n->n_ops);
+    DD_HIP(hipEventSynchronize(n->events[n->n_ops]));
+    for (int i = 0; i < n->n_ops; ++i) DD_HIP(hipEventElapsedTime(&ms_host[i], n->events[i], n->events[i + 1]));
+    *n_ops_host = n->n_ops;
     return DD_OK;
 }
 
@@ -542,6 +566,7 @@ int dd_net_forward(dd_net *net, const uint8_t *input, int nimg, void *stream) {
         return static_cast<char *>(net->bufs[d.buf]);
     };
     for (int i = 0; i < net->n_ops; ++i) {
+        if (net->profile) DD_HIP(hipEventRecord(net->events[i], s));
         const int32_t *o = net->prog.data() + net->ops_off + (size_t)i * OP_WORDS;
         const float *of = reinterpret_cast<const float *>(o);
         const int kind = o[0], src = o[1], dst = o[2], res = o[3], dst2 = o[4];
@@ -640,6 +665,7 @@ int dd_net_forward(dd_net *net, const uint8_t *input, int nimg, void *stream) {
                 DD_REQUIRE(false, DD_E_ARG, "dd_net_forward: unknown op kind %d at %d", kind, i);
         }
     }
+    if (net->profile) DD_HIP(hipEventRecord(net->events[net->n_ops], s));
     return DD_OK;
 }
 

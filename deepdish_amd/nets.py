@@ -44,6 +44,7 @@ class Program:
         self.blob = bytearray()
         self.out_tensor = -1
         self.meta = {}
+        self.info = []          # per op: kernel symbol + algorithmic flops / bytes per image
 
     # ---- storage
     def buffer(self, elems, dtype=DT_F16):
@@ -87,6 +88,7 @@ class Program:
             else:
                 w[names[k]] = v
         self.ops.append(w)
+        self.info.append(dict(kernel='?', flops=0, bytes=0))
 
     # ---- ops
     def input(self, swap_rb, mean=0.0, scale=1.0, s2d=False):
@@ -134,6 +136,10 @@ class Program:
             kw_['aff_off'] = self.add_blob(a)
             kw_['has_aff'] = 1
         self._op(OP_CONV, src=src, dst=dst, res=res, dst2=dst2, **kw_)
+        self.info[-1] = dict(kernel='conv_mfma_k<4,1,1,2>' if cout_pad <= 32 else 'conv_mfma_k<2,2,2,2>',
+                             flops=2 * ho * wo * kh * kw * cin * cout,
+                             bytes=2 * (s['h'] * s['w'] * cin + kh * kw * cin * cout) + (4 if epi != EPI_F16 else 2) * ho * wo * cout
+                             + (2 * ho * wo * cout if res >= 0 else 0) + (2 * ho * wo * cout if dst2 >= 0 else 0))
         return dst
 
     def dwconv(self, src, w_hwc, bias, stride, act, pad=None):
@@ -155,6 +161,7 @@ class Program:
         dst = self.tensor(ho, wo, c)
         self._op(OP_DWCONV, src=src, dst=dst, stride=stride, pad_t=pt, pad_l=pl, cout_pad=cp, act=act,
                  w_off=self.add_blob(wp), b_off=self.add_blob(bp))
+        self.info[-1] = dict(kernel='dwconv3_k', flops=2 * ho * wo * 9 * c, bytes=2 * (s['h'] * s['w'] * c + ho * wo * c + 9 * c))
         return dst
 
     def maxpool(self, src, k, stride, pad, dst=None):
@@ -164,6 +171,7 @@ class Program:
         if dst is None:
             dst = self.tensor(ho, wo, s['c'])
         self._op(OP_MAXPOOL, src=src, dst=dst, kh=k, stride=stride, pad_t=pad, cout_pad=rup(s['c'], 8))
+        self.info[-1] = dict(kernel='maxpool_k', flops=0, bytes=2 * s['c'] * (s['h'] * s['w'] + ho * wo))
         return dst
 
     def upsample2(self, src, dst):
@@ -184,6 +192,7 @@ class Program:
             kw_['aff_off'] = self.add_blob(np.stack(aff2).astype(np.float32))
             kw_['has_aff'] = 1
         self._op(OP_FC, src=src, dst=dst, **kw_)
+        self.info[-1] = dict(kernel='fc_k', flops=2 * k * cout, bytes=2 * k + 2 * k * cout + 4 * cout)
         return dst
 
     def l2norm(self, src, eps):

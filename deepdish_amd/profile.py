@@ -1,0 +1,74 @@
+"""Measurement helpers for bench.py: per-kernel device time from HIP events on the launch stream
+and the roofline line of the dominant kernel (algorithmic FLOPs / bytes come from the op program)."""
+import ctypes
+import numpy as np
+
+from ._lib import lib, check
+from .runtime import ptr
+
+PEAK_F16_TFLOPS = 2500.0       # MI355X_MICROARCH.md: Peak BF16/FP16 MFMA ~2.5 PF dense
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak BW 8.0 TB/s spec
+
+
+def net_op_times(net):
+    n = len(net.program.ops)
+    ms = np.zeros(n, dtype=np.float32)
+    cnt = ctypes.c_int()
+    check(lib().dd_net_profile_read(net._h, ptr(ms), n, ctypes.byref(cnt)), 'dd_net_profile_read')
+    return ms
+
+
+def profile_nets(run_once, nets_with_batch, reps=20):
+    """run_once() runs one bench step; nets_with_batch: [(name, Net, images per forward)].
+    Returns {kernel: dict(ms, flops, bytes, launches)} averaged per step."""
+    for _, net, _ in nets_with_batch:
+        check(lib().dd_net_profile(net._h, 1), 'dd_net_profile')
+    acc = {}
+    try:
+        for _ in range(reps):
+            run_once()
+            for name, net, batch in nets_with_batch:
+                ms = net_op_times(net)
+                b = batch() if callable(batch) else batch
+                for t, info in zip(ms, net.program.info):
+                    k = acc.setdefault(info['kernel'], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+                    k['ms'] += float(t); k['flops'] += info['flops'] * b; k['bytes'] += info['bytes'] * b; k['launches'] += 1
+    finally:
+        for _, net, _ in nets_with_batch:
+            check(lib().dd_net_profile(net._h, 0), 'dd_net_profile')
+    for k in acc.values():
+        for f in ('ms', 'flops', 'bytes'):
+            k[f] /= reps
+        k['launches'] /= reps
+    return acc
+
+
+def dominant_kernel_roofline(paths, dev_frames, streams, args):
+    """Extra instrumented pass after the timed region (events add a record per op, so it is kept out
+    of `value`)."""
+    f0 = args.warmup
+    state = dict(f=f0)
+
+    def run_once():
+        f = state['f']
+        for s in range(len(paths)):
+            paths[s].step(dev_frames[s][f], injected=streams[s][2][f])
+        state['f'] = f0 + (f + 1 - f0) % max(1, args.steps)
+
+    p = paths[-1]            # per-op events record the LAST forward of each net in a step
+    nets = [('ssd', p.object_detector.ssdm.net, 1),
+            ('mars', p.encoder.image_encoder.net, lambda: p.encoder.image_encoder.net._last_n)]
+    acc = profile_nets(run_once, nets)
+    name, k = max(acc.items(), key=lambda kv: kv[1]['ms'])
+    sec = k['ms'] * 1e-3
+    if 'mfma' in name or name == 'fc_k':
+        achieved = k['flops'] / sec / 1e12
+        out = dict(bound='mfma', achieved=achieved, peak=PEAK_F16_TFLOPS, unit='TFLOP/s', frac=achieved / PEAK_F16_TFLOPS)
+    else:
+        achieved = k['bytes'] / sec / 1e9
+        out = dict(bound='hbm', achieved=achieved, peak=PEAK_HBM_GBS, unit='GB/s', frac=achieved / PEAK_HBM_GBS)
+    out.update(kernel=name, traffic=None, launches_per_step=k['launches'],
+               avg_launch_us=1e3 * k['ms'] / max(k['launches'], 1e-9),
+               algorithmic_per_step=dict(flops=k['flops'], bytes=k['bytes']),
+               per_kernel_ms_per_step={n: round(v['ms'], 5) for n, v in sorted(acc.items(), key=lambda kv: -kv[1]['ms'])})
+    return out

@@ -164,6 +164,11 @@ int dd_net_output(dd_net *net, int tensor, void **dev_ptr_host, int *h_host, int
 /* Copy the first n images of a (whole, un-sliced) tensor to caller memory: n*h*w*cs elements. */
 int dd_net_read(dd_net *net, int tensor, int n, void *dst, int dst_on_device, void *stream);
 
+/* Measurement aid (not on the product path): bracket every op of the next forwards with HIP events
+ * on the launch stream; read back the per-op milliseconds of the last forward. */
+int dd_net_profile(dd_net *net, int enable);
+int dd_net_profile_read(dd_net *net, float *ms_host, int cap, int *n_ops_host);
+
 /* TFLite_Detection_PostProcess (inside the reference's .tflite graph, tools/ssd_mobilenet.py:103-109):
  * anchor decode, sigmoid, per-class NMS, top max_det.  raw f32 [n_anchors][4+n_classes] ->
  * boxes f32 [max_det][4] (ymin,xmin,ymax,xmax normalised), classes f32, scores f32, count. */
