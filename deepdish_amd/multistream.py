@@ -13,7 +13,7 @@ def shard_streams(n_streams, rank, world):
 
 def reduce_counts(counts, device=None):
     """counts: int64 array [n_labels, 4] of this rank -> the sum over all ranks (every rank gets it)."""
-    t = torch.as_tensor(np.ascontiguousarray(counts, dtype=np.int64))
+    t = torch.tensor(np.asarray(counts, dtype=np.int64))          # a copy: the caller keeps its local counts
     if device is not None:
         t = t.to(device)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
