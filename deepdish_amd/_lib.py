@@ -50,11 +50,19 @@ SIGNATURES = {
     'dd_net_forward': [P, P, c_int, P],
     'dd_net_output': [P, c_int, POINTER(P), POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int),
                       POINTER(c_int)],
+    'dd_net_max_batch': [P, POINTER(c_int)],
     'dd_net_read': [P, c_int, c_int, P, c_int, P],
     'dd_net_profile': [P, c_int],
     'dd_net_profile_read': [P, P, c_int, POINTER(c_int)],
     'dd_ssd_postprocess': [P, P, P, c_int, c_int, c_int, c_float, c_float, P, P, P, P, P],
     'dd_yolov5_decode': [P, P, c_int, c_int, c_float, c_float, c_float, P, P, P, c_int, P, P],
+    'dd_pipeline_create': [P, c_int, c_int, c_int, P, P, c_int, c_int, P, c_char_p, c_char_p, c_double, c_double,
+                           c_double, c_int, c_int, P, c_int, c_int, POINTER(P)],
+    'dd_pipeline_destroy': [P],
+    'dd_pipeline_step': [P, P, P, P, P, P],
+    'dd_pipeline_counts': [P, P],
+    'dd_pipeline_tracker': [P, c_int, POINTER(P)],
+    'dd_pipeline_stage_seconds': [P, P, POINTER(ctypes.c_longlong)],
     'dd_counts_accumulate': [P, P, P, c_int, P],
 }
 _RESTYPE = {'dd_last_error': c_char_p}

@@ -92,7 +92,20 @@ int cosine_nn_cost(hipStream_t s, const float *gallery_n, const long long *row_s
 int nms(hipStream_t s, const double *boxes, const double *keys, int k, double thr, int mode,
         int *out_idx, int *out_n, void *scratch, size_t scratch_bytes);
 size_t nms_scratch_bytes(int k);
+int nms_ex(hipStream_t s, const void *boxes, const void *keys, int k, double thr, int mode, int max_keep, int *out_idx,
+           int *out_n, void *scratch, size_t scratch_bytes);
+int nms_batched_small(hipStream_t s, const double *boxes, const double *keys, const int *d_offsets, int n_problems,
+                      double thr, int mode, int *out_idx, int *out_n);
 // tracker fused kernels
+int crop_box_host(const int64_t *b, int ph, int pw, int H, int W, int *sx, int *sy, int *cw, int *ch);
+// d_boxes: device array of {sx, sy, cw, ch, frame, 0, 0, 0} int32 records
+int crop_resize(hipStream_t s, const uint8_t *frames, int H, int W, const void *d_boxes, int n, int oh, int ow, uint8_t *out);
+int resize_lanczos(hipStream_t s, int device, const uint8_t *src, int H, int W, int src_c, int swap_rb, uint8_t *dst,
+                   int h, int w, uint8_t *tmp, int batch);
+size_t ssd_post_scratch_bytes(int n_anchors, int batch);
+int ssd_postprocess(hipStream_t s, const float *raw, const float *anchors, int n_anchors, int n_classes, int max_det,
+                    float score_thr, float iou_thr, float *boxes, float *classes, float *scores, int *count, int batch,
+                    void *scratch, size_t scratch_bytes);
 int lsap(const double *cost, int nr, int nc, int *rows, int *cols);   // host; returns pair count or -1
 int gather_state(hipStream_t s, const double *means, const double *covs, const int *slots, int n,
                  double *out_means, double *out_covs);

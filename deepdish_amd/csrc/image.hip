@@ -27,10 +27,10 @@ __device__ __forceinline__ void lin_coeff(int d, int dst, int src, int &s, int &
     a1 = (int)rintf(f * 2048.f);
 }
 
-struct CropBox { int sx, sy, cw, ch; };           // cw <= 0 marks a box the reference rejects
+struct CropBox { int sx, sy, cw, ch, frame, r0, r1, r2; };   // cw <= 0 marks a box the reference rejects
 
 // grid (ceil(oh*ow/256), n); one thread per output pixel (3 channels).
-__global__ __launch_bounds__(256) void crop_resize_k(const uint8_t *__restrict__ frame, int W,
+__global__ __launch_bounds__(256) void crop_resize_k(const uint8_t *__restrict__ frames, int H, int W,
                                                      const CropBox *__restrict__ boxes, int oh, int ow,
                                                      uint8_t *__restrict__ out) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void crop_resize_k(const uint8_t *__restrict__
     uint8_t *o = out + ((size_t)blockIdx.y * oh * ow + p) * 3;
     if (b.cw <= 0) { o[0] = o[1] = o[2] = 0; return; }
     const int dy = p / ow, dx = p - dy * ow;
-    const uint8_t *base = frame + ((size_t)b.sy * W + b.sx) * 3;
+    const uint8_t *base = frames + ((size_t)b.frame * H * W + (size_t)b.sy * W + b.sx) * 3;
     const size_t rs = (size_t)W * 3;
     if (b.cw == 2 * ow && b.ch == 2 * oh) {       // exact 2x decimation: INTER_AREA shortcut
         const uint8_t *r0 = base + (size_t)(2 * dy) * rs + (size_t)(2 * dx) * 3, *r1 = r0 + rs;
@@ -69,6 +69,8 @@ __global__ __launch_bounds__(256) void lanczos_h_k(const uint8_t *__restrict__ s
                                                    uint8_t *__restrict__ tmp) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= H * w) return;
+    src += (size_t)blockIdx.y * H * W * src_c;
+    tmp += (size_t)blockIdx.y * H * w * 3;
     const int y = idx / w, xx = idx - y * w;
     const int xmin = bounds[2 * xx], n = bounds[2 * xx + 1];
     const int *k = kk + (size_t)xx * ksize;
@@ -88,11 +90,13 @@ __global__ __launch_bounds__(256) void lanczos_h_k(const uint8_t *__restrict__ s
 }
 
 // Vertical: tmp [H][w*3] -> dst [h][w*3]; one thread per output byte, coalesced along the row.
-__global__ __launch_bounds__(256) void lanczos_v_k(const uint8_t *__restrict__ tmp, int rowbytes,
+__global__ __launch_bounds__(256) void lanczos_v_k(const uint8_t *__restrict__ tmp, int H, int rowbytes,
                                                    const int *__restrict__ bounds, const int *__restrict__ kk,
                                                    int ksize, int h, uint8_t *__restrict__ dst) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= h * rowbytes) return;
+    tmp += (size_t)blockIdx.y * H * rowbytes;
+    dst += (size_t)blockIdx.y * h * rowbytes;
     const int yy = idx / rowbytes, xb = idx - yy * rowbytes;
     const int ymin = bounds[2 * yy], n = bounds[2 * yy + 1];
     const int *k = kk + (size_t)yy * ksize;
@@ -106,8 +110,8 @@ __global__ __launch_bounds__(256) void copy_rgb_k(const uint8_t *__restrict__ sr
                                                   uint8_t *__restrict__ dst) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_px) return;
-    const uint8_t *s = src + (size_t)i * src_c;
-    uint8_t *d = dst + (size_t)i * 3;
+    const uint8_t *s = src + ((size_t)blockIdx.y * n_px + i) * src_c;
+    uint8_t *d = dst + ((size_t)blockIdx.y * n_px + i) * 3;
     d[0] = s[swap_rb ? 2 : 0]; d[1] = s[1]; d[2] = s[swap_rb ? 0 : 2];
 }
 
@@ -195,18 +199,18 @@ int crop_box_host(const int64_t *b, int ph, int pw, int H, int W, int *sx, int *
     return 1;
 }
 
-int crop_resize(hipStream_t s, const uint8_t *frame, int W, const void *d_boxes, int n, int oh, int ow,
+int crop_resize(hipStream_t s, const uint8_t *frames, int H, int W, const void *d_boxes, int n, int oh, int ow,
                 uint8_t *out) {
     if (n <= 0) return DD_OK;
-    hipLaunchKernelGGL(crop_resize_k, dim3(dd_ceil_div(oh * ow, 256), n), dim3(256), 0, s, frame, W,
+    hipLaunchKernelGGL(crop_resize_k, dim3(dd_ceil_div(oh * ow, 256), n), dim3(256), 0, s, frames, H, W,
                        static_cast<const CropBox *>(d_boxes), oh, ow, out);
     DD_LAUNCH_CHECK();
     return DD_OK;
 }
 
-// tmp must hold H*w*3 bytes.
+// `batch` images of identical geometry, densely packed; tmp must hold batch*H*w*3 bytes.
 int resize_lanczos(hipStream_t s, int device, const uint8_t *src, int H, int W, int src_c, int swap_rb,
-                   uint8_t *dst, int h, int w, uint8_t *tmp) {
+                   uint8_t *dst, int h, int w, uint8_t *tmp, int batch) {
     const uint8_t *mid = src;
     int mid_c = src_c;
     if (w != W) {
@@ -214,14 +218,14 @@ int resize_lanczos(hipStream_t s, int device, const uint8_t *src, int H, int W, 
         int rc = get_table(device, W, w, &th);
         if (rc != DD_OK) return rc;
         uint8_t *o = (h != H) ? tmp : dst;
-        hipLaunchKernelGGL(lanczos_h_k, dim3(dd_ceil_div(H * w, 256)), dim3(256), 0, s, src, H, W, src_c, swap_rb,
+        hipLaunchKernelGGL(lanczos_h_k, dim3(dd_ceil_div(H * w, 256), batch), dim3(256), 0, s, src, H, W, src_c, swap_rb,
                            th.bounds, th.kk, th.ksize, w, o);
         DD_LAUNCH_CHECK();
         mid = o;
         mid_c = 3;
     } else if (src_c != 3 || swap_rb) {
         uint8_t *o = (h != H) ? tmp : dst;
-        hipLaunchKernelGGL(copy_rgb_k, dim3(dd_ceil_div(H * W, 256)), dim3(256), 0, s, src, H * W, src_c, swap_rb, o);
+        hipLaunchKernelGGL(copy_rgb_k, dim3(dd_ceil_div(H * W, 256), batch), dim3(256), 0, s, src, H * W, src_c, swap_rb, o);
         DD_LAUNCH_CHECK();
         mid = o;
         mid_c = 3;
@@ -230,11 +234,11 @@ int resize_lanczos(hipStream_t s, int device, const uint8_t *src, int H, int W, 
         DevTable tv;
         int rc = get_table(device, H, h, &tv);
         if (rc != DD_OK) return rc;
-        hipLaunchKernelGGL(lanczos_v_k, dim3(dd_ceil_div(h * w * 3, 256)), dim3(256), 0, s, mid, w * 3, tv.bounds,
+        hipLaunchKernelGGL(lanczos_v_k, dim3(dd_ceil_div(h * w * 3, 256), batch), dim3(256), 0, s, mid, H, w * 3, tv.bounds,
                            tv.kk, tv.ksize, h, dst);
         DD_LAUNCH_CHECK();
     } else if (mid != dst) {
-        DD_HIP(hipMemcpyAsync(dst, mid, (size_t)H * w * mid_c, hipMemcpyDeviceToDevice, s));
+        DD_HIP(hipMemcpyAsync(dst, mid, (size_t)batch * H * w * mid_c, hipMemcpyDeviceToDevice, s));
     }
     return DD_OK;
 }
@@ -250,17 +254,18 @@ int dd_crop_resize(dd_ctx *ctx, const uint8_t *frame, int H, int W, const int64_
     DD_REQUIRE(frame && boxes_host && out, DD_E_ARG, "dd_crop_resize: NULL argument");
     hipStream_t s = dd_pick_stream(ctx, stream);
     int rc;
-    if ((rc = ctx->pin[1].reserve((size_t)n * 16)) != DD_OK) return rc;
-    if ((rc = ctx->scratch[3].reserve((size_t)n * 16)) != DD_OK) return rc;
+    if ((rc = ctx->pin[1].reserve((size_t)n * 32)) != DD_OK) return rc;
+    if ((rc = ctx->scratch[3].reserve((size_t)n * 32)) != DD_OK) return rc;
     int *hb = ctx->pin[1].as<int>();
     for (int i = 0; i < n; ++i) {
-        const int ok = ddk::crop_box_host(boxes_host + (size_t)i * 4, ph, pw, H, W, hb + 4 * i, hb + 4 * i + 1,
-                                          hb + 4 * i + 2, hb + 4 * i + 3);
+        const int ok = ddk::crop_box_host(boxes_host + (size_t)i * 4, ph, pw, H, W, hb + 8 * i, hb + 8 * i + 1,
+                                          hb + 8 * i + 2, hb + 8 * i + 3);
+        hb[8 * i + 4] = 0;
         if (valid_host) valid_host[i] = ok;
     }
-    DD_HIP(hipMemcpyAsync(ctx->scratch[3].p, hb, (size_t)n * 16, hipMemcpyHostToDevice, s));
+    DD_HIP(hipMemcpyAsync(ctx->scratch[3].p, hb, (size_t)n * 32, hipMemcpyHostToDevice, s));
     DD_HIP(hipStreamSynchronize(s));                        // the pinned block is reused by the next call
-    return ddk::crop_resize(s, frame, W, ctx->scratch[3].p, n, ph, pw, out);
+    return ddk::crop_resize(s, frame, H, W, ctx->scratch[3].p, n, ph, pw, out);
 }
 
 int dd_resize_lanczos(dd_ctx *ctx, const uint8_t *src, int H, int W, int src_c, int swap_rb, uint8_t *dst, int h,
@@ -270,7 +275,7 @@ int dd_resize_lanczos(dd_ctx *ctx, const uint8_t *src, int H, int W, int src_c, 
     int rc;
     if ((rc = ctx->scratch[3].reserve((size_t)H * w * 3 + 64)) != DD_OK) return rc;
     return ddk::resize_lanczos(dd_pick_stream(ctx, stream), ctx->device, src, H, W, src_c, swap_rb, dst, h, w,
-                               ctx->scratch[3].as<uint8_t>());
+                               ctx->scratch[3].as<uint8_t>(), 1);
 }
 
 int dd_resize_bilinear(dd_ctx *ctx, const uint8_t *src, int H, int W, int c, uint8_t *dst, int h, int w,
@@ -279,13 +284,13 @@ int dd_resize_bilinear(dd_ctx *ctx, const uint8_t *src, int H, int W, int c, uin
     DD_REQUIRE(c == 3, DD_E_ARG, "dd_resize_bilinear: 3-channel images only");
     hipStream_t s = dd_pick_stream(ctx, stream);
     int rc;
-    if ((rc = ctx->pin[1].reserve(16)) != DD_OK) return rc;
-    if ((rc = ctx->scratch[3].reserve(16)) != DD_OK) return rc;
+    if ((rc = ctx->pin[1].reserve(32)) != DD_OK) return rc;
+    if ((rc = ctx->scratch[3].reserve(32)) != DD_OK) return rc;
     int *hb = ctx->pin[1].as<int>();
-    hb[0] = 0; hb[1] = 0; hb[2] = W; hb[3] = H;
-    DD_HIP(hipMemcpyAsync(ctx->scratch[3].p, hb, 16, hipMemcpyHostToDevice, s));
+    hb[0] = 0; hb[1] = 0; hb[2] = W; hb[3] = H; hb[4] = 0;
+    DD_HIP(hipMemcpyAsync(ctx->scratch[3].p, hb, 32, hipMemcpyHostToDevice, s));
     DD_HIP(hipStreamSynchronize(s));
-    return ddk::crop_resize(s, src, W, ctx->scratch[3].p, 1, h, w, dst);
+    return ddk::crop_resize(s, src, H, W, ctx->scratch[3].p, 1, h, w, dst);
 }
 
 }  // extern "C"

@@ -507,6 +507,12 @@ int dd_net_destroy(dd_net *n) {
     return DD_OK;
 }
 
+int dd_net_max_batch(dd_net *n, int *out_host) {
+    DD_REQUIRE(n && out_host, DD_E_ARG, "dd_net_max_batch: NULL argument");
+    *out_host = n->max_batch;
+    return DD_OK;
+}
+
 int dd_net_output(dd_net *n, int tensor, void **dev_ptr, int *h, int *w, int *c, int *cs, int *dtype) {
     DD_REQUIRE(n, DD_E_ARG, "dd_net_output: NULL net");
     const int t = tensor < 0 ? n->out_tensor : tensor;

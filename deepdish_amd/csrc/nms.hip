@@ -1,13 +1,18 @@
-// Greedy score-ordered non-maximum suppression in f64, bit-exact with the reference on the same
-// boxes: (A) one workgroup bitonic-sorts (key, index) in LDS and writes the boxes in pick order,
-// (B) a 2-D grid builds the K x K/64 suppression bit-matrix with one wave ballot per 64 pairs,
-// (C) a single wave replays the greedy scan 64 rows at a time (diagonal word resolved in registers,
-// off-diagonal words OR-ed in with independent, pipelined loads).
+// Greedy score-ordered non-maximum suppression, bit-exact with the reference on the same boxes.
 //
-// mode 0: deep_sort/preprocessing.py:6-73  (tlwh, +1 pixel, inter / area_other > thr suppresses)
-// mode 1: tools/ssd_mobilenet.py:59-98     (xyxy, +1 on the intersection only, IoU <= thr keeps)
-// Ties in the key are resolved "higher original index first" (what a stable ascending argsort
-// read from the back gives); the reference's own order under ties is unspecified (unstable sort).
+// mode 0: deep_sort/preprocessing.py:6-73  (tlwh f64, +1 pixel, inter / area_other > thr suppresses)
+// mode 1: tools/ssd_mobilenet.py:59-98     (xyxy f64, +1 on the intersection only, IoU <= thr keeps)
+// mode 2: TFLite detection_postprocess fast NMS (ymin,xmin,ymax,xmax f32, plain IoU > thr suppresses)
+//
+// k <= 64 (the per-frame case, ~25 boxes): ONE wave does everything in one launch -- rank by key,
+// permute through LDS, then replay the greedy chain with the pivot box broadcast from LDS.
+// k <= 4096: (A) rank sort (each candidate counts the candidates ahead of it, keys staged in LDS),
+// (B) a 2-D grid builds the K x K/64 suppression bit-matrix with one wave ballot per 64 pairs,
+// (C) a single wave replays the greedy scan 64 rows at a time: the chunk's rows of the bit-matrix
+// are staged in LDS with fully pipelined loads, the diagonal word is resolved in registers, and the
+// scan stops early once `max_keep` survivors exist (greedy prefix property).
+// Ties in the key are resolved "higher original index first" (what a stable ascending argsort read
+// from the back gives); the reference's own order under ties is unspecified (unstable sort).
 #include "common.h"
 
 namespace {
@@ -15,56 +20,26 @@ namespace {
 constexpr int MAXK = 4096;
 typedef unsigned long long u64;
 
-struct SBox { double a, b, c, d, area; };   // mode 0: x1,y1,x2,y2,area ; mode 1: x,y,w,h,area
+struct SBox { double a, b, c, d, area; };   // mode 0: x1,y1,x2,y2,area ; mode 1: x,y,w,h,area ; mode 2: ymin,xmin,ymax,xmax,area
 
 __device__ __forceinline__ bool before(double ka, int ia, double kb, int ib) {
     return ka > kb || (ka == kb && ia > ib);
 }
 
 template <typename TB>
-__global__ __launch_bounds__(1024) void nms_sort_k(const TB *__restrict__ boxes, const TB *__restrict__ keys,
-                                                   int k, int mode, SBox *__restrict__ sorted, int *__restrict__ sidx) {
-    __shared__ double skey[MAXK];
-    __shared__ int sid[MAXK];
-    int n = 1;
-    while (n < k) n <<= 1;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        skey[i] = i < k ? (double)keys[i] : -__builtin_inf();
-        sid[i] = i < k ? i : -1 - i;                       // padding sorts last (lowest key, lowest id)
+__device__ __forceinline__ SBox make_sbox(const TB *b, int mode) {
+    SBox s;
+    if (mode == 2) {
+        s.a = b[0]; s.b = b[1]; s.c = b[2]; s.d = b[3];
+        s.area = (double)(((float)b[2] - (float)b[0]) * ((float)b[3] - (float)b[1]));
+    } else if (mode == 0) {
+        s.a = b[0]; s.b = b[1]; s.c = b[2] + b[0]; s.d = b[3] + b[1];
+        s.area = (s.c - s.a + 1) * (s.d - s.b + 1);         // preprocessing.py:43-48
+    } else {
+        s.a = b[0]; s.b = b[1]; s.c = b[2] - b[0]; s.d = b[3] - b[1];
+        s.area = s.c * s.d;                                 // ssd_mobilenet.py:67-72
     }
-    __syncthreads();
-    for (int sz = 2; sz <= n; sz <<= 1) {
-        for (int j = sz >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < n; i += blockDim.x) {
-                const int p = i ^ j;
-                if (p > i) {
-                    const double ka = skey[i], kb = skey[p];
-                    const int ia = sid[i], ib = sid[p];
-                    const bool up = (i & sz) == 0;          // "up" = pick order (best first)
-                    const bool swap = up ? before(kb, ib, ka, ia) : before(ka, ia, kb, ib);
-                    if (swap) { skey[i] = kb; skey[p] = ka; sid[i] = ib; sid[p] = ia; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-    for (int i = threadIdx.x; i < k; i += blockDim.x) {
-        const int o = sid[i];
-        const TB *b = boxes + (size_t)o * 4;
-        SBox s;
-        if (mode == 2) {                                    // f32 (ymin, xmin, ymax, xmax), TFLite fast NMS
-            s.a = b[0]; s.b = b[1]; s.c = b[2]; s.d = b[3];
-            s.area = (double)(((float)b[2] - (float)b[0]) * ((float)b[3] - (float)b[1]));
-        } else if (mode == 0) {
-            s.a = b[0]; s.b = b[1]; s.c = b[2] + b[0]; s.d = b[3] + b[1];
-            s.area = (s.c - s.a + 1) * (s.d - s.b + 1);     // preprocessing.py:43-48
-        } else {
-            s.a = b[0]; s.b = b[1]; s.c = b[2] - b[0]; s.d = b[3] - b[1];
-            s.area = s.c * s.d;                             // ssd_mobilenet.py:67-72
-        }
-        sorted[i] = s;
-        sidx[i] = o;
-    }
+    return s;
 }
 
 __device__ __forceinline__ bool suppresses(const SBox &pi, const SBox &pj, double thr, int mode) {
@@ -90,13 +65,79 @@ __device__ __forceinline__ bool suppresses(const SBox &pi, const SBox &pj, doubl
     return !(ovr <= thr);                                   // ssd_mobilenet.py:85-91
 }
 
-// grid (words, ceil(k/4)); block = 4 waves; wave handles row i, lanes cover the 64 columns of word w.
+// ---------------------------------------------------------------- k <= 64: one wave, one launch
+// blockIdx.x selects an independent problem (batched form: offsets[p] .. offsets[p+1]).
+template <typename TB>
+__global__ __launch_bounds__(64) void nms_small_k(const TB *__restrict__ boxes, const TB *__restrict__ keys,
+                                                  const int *__restrict__ offsets, int k_single, double thr, int mode,
+                                                  int max_keep, int *__restrict__ out_idx, int *__restrict__ out_n) {
+    __shared__ SBox sb[64];
+    __shared__ int sid[64];
+    const int lane = threadIdx.x;
+    const int p = blockIdx.x;
+    const int o0 = offsets ? offsets[p] : 0;
+    const int k = offsets ? offsets[p + 1] - o0 : k_single;
+    double key = -__builtin_inf();
+    SBox mine = {0, 0, 0, 0, 0};
+    if (lane < k) {
+        key = (double)keys[o0 + lane];
+        mine = make_sbox(boxes + (size_t)(o0 + lane) * 4, mode);
+    }
+    int rank = 0;
+    for (int j = 0; j < k; ++j) {
+        const double kj = __shfl(key, j, 64);
+        rank += (lane < k && j != lane && before(kj, j, key, lane)) ? 1 : 0;
+    }
+    if (lane < k) { sb[rank] = mine; sid[rank] = lane; }
+    __syncthreads();
+    SBox me = {0, 0, 0, 0, 0};
+    if (lane < k) me = sb[lane];                             // lane now owns sorted position `lane`
+    u64 removed = 0, keep = 0;
+    int n_keep = 0;
+    for (int i = 0; i < k; ++i) {
+        if ((removed >> i) & 1ull) continue;                // wave-uniform
+        keep |= 1ull << i;
+        if (++n_keep == max_keep) break;
+        const SBox pi = sb[i];                              // LDS broadcast
+        const bool s = lane > i && lane < k && suppresses(pi, me, thr, mode);
+        removed |= __ballot(s);
+    }
+    if (lane < k && ((keep >> lane) & 1ull))
+        out_idx[o0 + __popcll(keep & ((1ull << lane) - 1ull))] = sid[lane];
+    if (lane == 0) out_n[p] = __popcll(keep);
+}
+
+// ---------------------------------------------------------------- general path
+// (A) rank sort: block b ranks candidates [256 b, 256 b + 256) against all k keys staged in LDS.
+template <typename TB>
+__global__ __launch_bounds__(256) void nms_rank_k(const TB *__restrict__ boxes, const TB *__restrict__ keys, int k, int mode,
+                                                  SBox *__restrict__ sorted, int *__restrict__ sidx) {
+    __shared__ double skey[MAXK];
+    boxes += (size_t)blockIdx.z * k * 4; keys += (size_t)blockIdx.z * k;     // blockIdx.z = image of a batch
+    sorted += (size_t)blockIdx.z * k; sidx += (size_t)blockIdx.z * k;
+    for (int i = threadIdx.x; i < k; i += blockDim.x) skey[i] = (double)keys[i];
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    const double ki = skey[i];
+    int rank = 0;
+    for (int j = 0; j < k; ++j) rank += (j != i && before(skey[j], j, ki, i)) ? 1 : 0;
+    sorted[rank] = make_sbox(boxes + (size_t)i * 4, mode);
+    sidx[rank] = i;
+}
+
+// (B) grid (words, ceil(k/4)); block = 4 waves; wave handles row i, lanes cover the 64 columns of word w.
 __global__ __launch_bounds__(256) void nms_mask_k(const SBox *__restrict__ sorted, int k, int words, double thr,
                                                   int mode, u64 *__restrict__ mask) {
     const int w = blockIdx.x;
     const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (i >= k) return;
+    sorted += (size_t)blockIdx.z * k; mask += (size_t)blockIdx.z * k * words;
+    if (w * 64 + 63 <= i) {                                 // whole word lies on or below the diagonal
+        if (lane == 0) mask[(size_t)i * words + w] = 0ull;
+        return;
+    }
     const int j = w * 64 + lane;
     bool s = false;
     if (j > i && j < k) s = suppresses(sorted[i], sorted[j], thr, mode);
@@ -104,45 +145,50 @@ __global__ __launch_bounds__(256) void nms_mask_k(const SBox *__restrict__ sorte
     if (lane == 0) mask[(size_t)i * words + w] = bits;
 }
 
+// (C) one wave; lane l owns word l of the running "removed" set (words <= 64).
 __global__ __launch_bounds__(64) void nms_scan_k(const u64 *__restrict__ mask, const int *__restrict__ sidx, int k,
-                                                 int words, int *__restrict__ out_idx, int *__restrict__ out_n) {
+                                                 int words, int max_keep, int *__restrict__ out_idx, int *__restrict__ out_n) {
+    __shared__ u64 rows[64 * 64];                           // this chunk's 64 rows x `words` words
     const int lane = threadIdx.x;
-    u64 removed = 0;                                        // lane l owns word l (words <= 64)
+    mask += (size_t)blockIdx.x * k * words; sidx += (size_t)blockIdx.x * k;   // blockIdx.x = image of a batch
+    out_idx += (size_t)blockIdx.x * k; out_n += blockIdx.x;
+    u64 removed = 0;
     int n_keep = 0;
     for (int c = 0; c < words; ++c) {
         const int row0 = c * 64;
-        const int rows = min(64, k - row0);
-        const u64 diag = lane < rows ? mask[(size_t)(row0 + lane) * words + c] : 0ull;
+        const int nrows = min(64, k - row0);
+        // stage rows [row0, row0+nrows) x words [c, words): independent coalesced loads, one wait
+        const int span = words - c;
+        for (int t = lane; t < nrows * span; t += 64) {
+            const int r = t / span, w = c + (t - r * span);
+            rows[r * 64 + w] = mask[(size_t)(row0 + r) * words + w];
+        }
+        __syncthreads();
+        const u64 diag = lane < nrows ? rows[lane * 64 + c] : 0ull;
         u64 rc = __shfl(removed, c, 64);
         u64 keep = 0;
-        for (int b = 0; b < rows; ++b) {
+        bool full = false;
+        for (int b = 0; b < nrows; ++b) {
             if (!((rc >> b) & 1ull)) {
                 keep |= 1ull << b;
                 rc |= __shfl(diag, b, 64);
+                if (max_keep > 0 && n_keep + __popcll(keep) >= max_keep) { full = true; break; }
             }
         }
-        // emit the kept rows of this chunk in pick order
-        if (lane < rows && ((keep >> lane) & 1ull)) {
-            const int pos = n_keep + __popcll(keep & ((1ull << lane) - 1ull));
-            out_idx[pos] = sidx[row0 + lane];
-        }
+        if (lane < nrows && ((keep >> lane) & 1ull))
+            out_idx[n_keep + __popcll(keep & ((1ull << lane) - 1ull))] = sidx[row0 + lane];
         n_keep += __popcll(keep);
-        // fold the kept rows into the later words (lane l > c only needs word l)
-        if (c + 1 < words) {
-            u64 kk = keep;
+        if (full) break;                                    // wave-uniform
+        if (lane > c && lane < words) {                     // fold the kept rows into my word
+            u64 acc = 0, kk = keep;
             while (kk) {
-                u64 acc = 0;
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if (kk) {
-                        const int b = __ffsll((long long)kk) - 1;
-                        kk &= kk - 1;
-                        if (lane < words) acc |= mask[(size_t)(row0 + b) * words + lane];
-                    }
-                }
-                removed |= acc;
+                const int b = __ffsll((long long)kk) - 1;
+                kk &= kk - 1;
+                acc |= rows[b * 64 + lane];
             }
+            removed |= acc;
         }
+        __syncthreads();
     }
     if (lane == 0) *out_n = n_keep;
 }
@@ -156,14 +202,26 @@ size_t nms_scratch_bytes(int k) {
     return (size_t)k * sizeof(SBox) + (size_t)k * sizeof(int) + 64 + (size_t)k * words * sizeof(u64);
 }
 
-int nms(hipStream_t s, const double *boxes, const double *keys, int k, double thr, int mode, int *out_idx,
-        int *out_n, void *scratch, size_t scratch_bytes) {
+// max_keep <= 0: keep every survivor.
+int nms_ex(hipStream_t s, const void *boxes, const void *keys, int k, double thr, int mode, int max_keep, int *out_idx,
+           int *out_n, void *scratch, size_t scratch_bytes) {
     if (k <= 0) {
         DD_HIP(hipMemsetAsync(out_n, 0, sizeof(int), s));
         return DD_OK;
     }
     DD_REQUIRE(k <= MAXK, DD_E_CAPACITY, "dd_nms: k=%d exceeds the single-pass capacity %d", k, MAXK);
-    DD_REQUIRE(scratch_bytes >= nms_scratch_bytes(k), DD_E_ARG, "dd_nms: scratch too small");
+    const bool f32 = mode == 2;
+    if (k <= 64) {
+        if (f32)
+            hipLaunchKernelGGL(nms_small_k<float>, dim3(1), dim3(64), 0, s, static_cast<const float *>(boxes),
+                               static_cast<const float *>(keys), (const int *)nullptr, k, thr, mode, max_keep, out_idx, out_n);
+        else
+            hipLaunchKernelGGL(nms_small_k<double>, dim3(1), dim3(64), 0, s, static_cast<const double *>(boxes),
+                               static_cast<const double *>(keys), (const int *)nullptr, k, thr, mode, max_keep, out_idx, out_n);
+        DD_LAUNCH_CHECK();
+        return DD_OK;
+    }
+    DD_REQUIRE(scratch && scratch_bytes >= nms_scratch_bytes(k), DD_E_ARG, "dd_nms: scratch too small");
     const int words = (k + 63) / 64;
     char *p = static_cast<char *>(scratch);
     SBox *sorted = reinterpret_cast<SBox *>(p);
@@ -171,23 +229,61 @@ int nms(hipStream_t s, const double *boxes, const double *keys, int k, double th
     int *sidx = reinterpret_cast<int *>(p);
     p += ((size_t)k * sizeof(int) + 63) / 64 * 64;
     u64 *mask = reinterpret_cast<u64 *>(p);
-    if (mode == 2)
-        hipLaunchKernelGGL(nms_sort_k<float>, dim3(1), dim3(1024), 0, s, reinterpret_cast<const float *>(boxes),
-                           reinterpret_cast<const float *>(keys), k, mode, sorted, sidx);
+    if (f32)
+        hipLaunchKernelGGL(nms_rank_k<float>, dim3(dd_ceil_div(k, 256)), dim3(256), 0, s, static_cast<const float *>(boxes),
+                           static_cast<const float *>(keys), k, mode, sorted, sidx);
     else
-        hipLaunchKernelGGL(nms_sort_k<double>, dim3(1), dim3(1024), 0, s, boxes, keys, k, mode, sorted, sidx);
+        hipLaunchKernelGGL(nms_rank_k<double>, dim3(dd_ceil_div(k, 256)), dim3(256), 0, s, static_cast<const double *>(boxes),
+                           static_cast<const double *>(keys), k, mode, sorted, sidx);
     DD_LAUNCH_CHECK();
     hipLaunchKernelGGL(nms_mask_k, dim3(words, dd_ceil_div(k, 4)), dim3(256), 0, s, sorted, k, words, thr, mode, mask);
     DD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(nms_scan_k, dim3(1), dim3(64), 0, s, mask, sidx, k, words, out_idx, out_n);
+    hipLaunchKernelGGL(nms_scan_k, dim3(1), dim3(64), 0, s, mask, sidx, k, words, max_keep, out_idx, out_n);
     DD_LAUNCH_CHECK();
     return DD_OK;
 }
 
-int nms_f32(hipStream_t s, const float *boxes_yxyx, const float *keys, int k, float thr, int *out_idx, int *out_n,
-            void *scratch, size_t scratch_bytes) {
-    return nms(s, reinterpret_cast<const double *>(boxes_yxyx), reinterpret_cast<const double *>(keys), k, (double)thr, 2,
-               out_idx, out_n, scratch, scratch_bytes);
+// `batch` independent f32 problems of the same size k (64 < k <= 4096): boxes [batch][k][4], keys
+// [batch][k], out_idx [batch][k], out_n [batch]; scratch >= batch * nms_scratch_bytes(k).
+int nms_f32_batched(hipStream_t s, const float *boxes, const float *keys, int k, float thr, int max_keep, int *out_idx,
+                    int *out_n, void *scratch, size_t scratch_bytes, int batch) {
+    DD_REQUIRE(k > 64 && k <= MAXK && batch > 0, DD_E_ARG, "nms_f32_batched: k=%d batch=%d", k, batch);
+    DD_REQUIRE(scratch && scratch_bytes >= (size_t)batch * nms_scratch_bytes(k), DD_E_ARG, "nms_f32_batched: scratch too small");
+    const int words = (k + 63) / 64;
+    char *p = static_cast<char *>(scratch);
+    SBox *sorted = reinterpret_cast<SBox *>(p);
+    p += (size_t)batch * k * sizeof(SBox);
+    int *sidx = reinterpret_cast<int *>(p);
+    p += ((size_t)batch * k * sizeof(int) + 63) / 64 * 64;
+    u64 *mask = reinterpret_cast<u64 *>(p);
+    hipLaunchKernelGGL(nms_rank_k<float>, dim3(dd_ceil_div(k, 256), 1, batch), dim3(256), 0, s, boxes, keys, k, 2, sorted, sidx);
+    DD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(nms_mask_k, dim3(words, dd_ceil_div(k, 4), batch), dim3(256), 0, s, sorted, k, words, (double)thr, 2, mask);
+    DD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(nms_scan_k, dim3(batch), dim3(64), 0, s, mask, sidx, k, words, max_keep, out_idx, out_n);
+    DD_LAUNCH_CHECK();
+    return DD_OK;
+}
+
+int nms(hipStream_t s, const double *boxes, const double *keys, int k, double thr, int mode, int *out_idx,
+        int *out_n, void *scratch, size_t scratch_bytes) {
+    return nms_ex(s, boxes, keys, k, thr, mode, 0, out_idx, out_n, scratch, scratch_bytes);
+}
+
+int nms_f32(hipStream_t s, const float *boxes_yxyx, const float *keys, int k, float thr, int max_keep, int *out_idx,
+            int *out_n, void *scratch, size_t scratch_bytes) {
+    return nms_ex(s, boxes_yxyx, keys, k, (double)thr, 2, max_keep, out_idx, out_n, scratch, scratch_bytes);
+}
+
+// P independent small problems (each <= 64 boxes) in one launch: problem p owns rows
+// [offsets[p], offsets[p+1]) of boxes/keys/out_idx; out_n[p] survivors.
+int nms_batched_small(hipStream_t s, const double *boxes, const double *keys, const int *d_offsets, int n_problems,
+                      double thr, int mode, int *out_idx, int *out_n) {
+    if (n_problems <= 0) return DD_OK;
+    hipLaunchKernelGGL(nms_small_k<double>, dim3(n_problems), dim3(64), 0, s, boxes, keys, d_offsets, 0, thr, mode, 0,
+                       out_idx, out_n);
+    DD_LAUNCH_CHECK();
+    return DD_OK;
 }
 
 }  // namespace ddk

@@ -1,0 +1,508 @@
+// Multi-stream hot path: S independent video streams advanced one frame each per step, on one GPU.
+//
+// One step = the four calls the reference's Pipeline makes per frame (deepdish.py upstream):
+// run_object_detector :880-885 -> box hygiene :940-960 -> non_max_suppression :995 -> encoder :1008 ->
+// tracker.predict/update :1028-1029 -> count-line logic :1035-1114, for every stream, with the
+// device work batched ACROSS streams (one detector forward for S frames, one crop launch and one MARS
+// forward for all boxes of all streams, one batched NMS launch) and four host<->device round trips
+// per STEP instead of ~10 per frame.  Streams share nothing (own tracker, ids, counters), exactly as
+// independent DeepDish processes would.
+#include <algorithm>
+#include <cmath>
+#include <map>
+#include <string>
+#include "common.h"
+
+struct dd_tracker;
+namespace ddk {
+int tracker_predict_async(dd_tracker *t);
+int tracker_update_begin(dd_tracker *t, const double *tlwh_host, const float *feats, int feats_on_device, int n);
+int tracker_update_match(dd_tracker *t);
+int tracker_update_end(dd_tracker *t);
+}
+extern "C" int dd_net_max_batch(dd_net *net, int *out_host);
+
+namespace {
+
+constexpr int MAX_DET = 10;              // N_max of the stock SSD post-process op
+enum { CONFIRMED = 2, DELETED = 3 };
+
+// tools/ssd_mobilenet.py:111-150 on the <= 10 rows the post-process op returns, one wave per image
+// (lane 0 does the O(100) work): NaN scrub, score >= confidence, reorder + scale to pixels (f64),
+// per-class NMS with the +1-on-intersection-only IoU (:59-98).  Classes are visited in ascending
+// id (the reference walks a Python set); the order is irrelevant downstream (NMS re-sorts by score).
+__global__ void ssd_finish_k(const float *__restrict__ boxes, const float *__restrict__ cls, const float *__restrict__ scores,
+                             double conf, double iou_thr, double img_w, double img_h, double *__restrict__ out_boxes,
+                             int *__restrict__ out_cls, double *__restrict__ out_scores, int *__restrict__ out_n) {
+    if (threadIdx.x != 0) return;
+    const int z = blockIdx.x;
+    boxes += (size_t)z * MAX_DET * 4; cls += (size_t)z * MAX_DET; scores += (size_t)z * MAX_DET;
+    out_boxes += (size_t)z * MAX_DET * 4; out_cls += (size_t)z * MAX_DET; out_scores += (size_t)z * MAX_DET;
+    float sc[MAX_DET];
+    for (int i = 0; i < MAX_DET; ++i) sc[i] = scores[i];
+    for (int i = 0; i < MAX_DET; ++i)
+        for (int c = 0; c < 4; ++c)
+            if (isnan(boxes[i * 4 + c])) { sc[i] = 0.f; sc[c] = 0.f; }     // :111-113 (np.where rows AND cols)
+    for (int i = 0; i < MAX_DET; ++i) if (isnan(sc[i])) sc[i] = 0.f;      // :115-116
+    double bx[MAX_DET][4];
+    bool live[MAX_DET];
+    for (int i = 0; i < MAX_DET; ++i) {
+        live[i] = sc[i] >= (float)conf;
+        bx[i][0] = (double)boxes[i * 4 + 1] * img_w;                      // :121-127 reorder [1,0,3,2] * [w,h,w,h]
+        bx[i][1] = (double)boxes[i * 4 + 0] * img_h;
+        bx[i][2] = (double)boxes[i * 4 + 3] * img_w;
+        bx[i][3] = (double)boxes[i * 4 + 2] * img_h;
+    }
+    int n = 0;
+    bool done[MAX_DET] = {false};
+    for (;;) {
+        int cmin = 1 << 30;
+        for (int i = 0; i < MAX_DET; ++i) if (live[i] && !done[i]) cmin = min(cmin, (int)cls[i]);
+        if (cmin == (1 << 30)) break;
+        bool dead[MAX_DET] = {false};
+        for (;;) {                                                        // greedy by descending score within the class
+            int best = -1;
+            for (int i = 0; i < MAX_DET; ++i)
+                if (live[i] && !done[i] && (int)cls[i] == cmin && !dead[i] && (best < 0 || sc[i] > sc[best])) best = i;
+            if (best < 0) break;
+            done[best] = true;
+            for (int q = 0; q < 4; ++q) out_boxes[n * 4 + q] = bx[best][q];
+            out_cls[n] = cmin;
+            out_scores[n] = (double)sc[best];
+            ++n;
+            const double x = bx[best][0], y = bx[best][1], w = bx[best][2] - bx[best][0], h = bx[best][3] - bx[best][1];
+            for (int j = 0; j < MAX_DET; ++j) {
+                if (!live[j] || done[j] || (int)cls[j] != cmin || dead[j]) continue;
+                const double xj = bx[j][0], yj = bx[j][1], wj = bx[j][2] - bx[j][0], hj = bx[j][3] - bx[j][1];
+                const double xx1 = fmax(x, xj), yy1 = fmax(y, yj);
+                const double xx2 = fmin(x + w, xj + wj), yy2 = fmin(y + h, yj + hj);
+                const double w1 = fmax(0.0, xx2 - xx1 + 1), h1 = fmax(0.0, yy2 - yy1 + 1);
+                const double inter = w1 * h1;
+                const double ovr = inter / (w * h + wj * hj - inter);
+                if (!(ovr <= iou_thr)) { dead[j] = true; done[j] = true; }
+            }
+        }
+    }
+    out_n[z] = n;
+}
+
+struct Votes {                         // track.py:78-81,147-151: label -> confidences, in first-seen order
+    std::vector<int> cls;
+    std::vector<int> cnt;
+    std::vector<double> sum;
+    void add(int c, double conf) {
+        for (size_t i = 0; i < cls.size(); ++i) if (cls[i] == c) { cnt[i]++; sum[i] += conf; return; }
+        cls.push_back(c); cnt.push_back(1); sum.push_back(conf);
+    }
+};
+
+struct StreamState {
+    dd_tracker *trk = nullptr;
+    std::map<int64_t, std::vector<std::pair<double, double>>> db;    // deepdish.py:519 self.db
+    std::map<int64_t, Votes> votes;
+    std::vector<int64_t> counts;                                     // [n_wanted][4] pos, neg, int, del
+    std::vector<int> det_cls;                                        // class of every detection of this step
+    std::vector<double> det_conf;
+};
+
+double cross2(double ax, double ay, double bx, double by) { return ax * by - ay * bx; }
+
+// tools/intersection.py:4-24
+bool seg_intersect(const double p[2], const double pr[2], const double q[2], const double qs[2]) {
+    const double eps = 2.220446049250313e-16;
+    const double rx = pr[0] - p[0], ry = pr[1] - p[1], sx = qs[0] - q[0], sy = qs[1] - q[1];
+    const double rxs = cross2(rx, ry, sx, sy);
+    const double mx = q[0] - p[0], my = q[1] - p[1];
+    const double qpxr = cross2(mx, my, rx, ry);
+    if (fabs(rxs) < eps) {
+        if (fabs(qpxr) >= eps) return false;
+        const double rr = rx * rx + ry * ry;
+        const double ex = rx / rr, ey = ry / rr;
+        double t0 = mx * ex + my * ey;
+        double t1 = t0 + sx * ex + sy * ey;
+        if (t0 > t1) std::swap(t0, t1);
+        return !(t1 < 0 || t0 > 1);
+    }
+    const double t = cross2(mx, my, sx, sy) / rxs, u = qpxr / rxs;
+    return 0.0 <= t && t <= 1.0 && 0.0 <= u && u <= 1.0;
+}
+
+}  // namespace
+
+struct dd_pipeline {
+    dd_ctx *ctx = nullptr;
+    int S = 0, H = 0, W = 0;
+    dd_net *det = nullptr, *enc = nullptr;
+    int det_in = 300, n_anchors = 0, n_classes = 0, enc_batch = 0;
+    float *d_anchors = nullptr;
+    double nms_overlap = 0.6, det_conf = 0.5;
+    double line[4] = {0, 0, 0, 0};
+    std::vector<std::string> labels;           // label file lines (index = class id + 1, ssd_mobilenet.py:142-147)
+    std::vector<std::string> wanted;
+    std::vector<StreamState> st;
+    DevBuf d_resized, d_tmp, d_post, d_det, d_fin, d_nms, d_crop, d_patches, d_feats;
+    PinBuf h_fin, h_nms, h_crop;
+    int crop_cap = 0;
+    double t_det = 0, t_nms = 0, t_enc = 0, t_trk = 0;    // host wall seconds per stage, accumulated
+    long long steps = 0;
+};
+
+namespace {
+
+int wanted_index(const dd_pipeline *p, const std::string &name) {
+    for (size_t i = 0; i < p->wanted.size(); ++i) if (p->wanted[i] == name) return (int)i;
+    return -1;
+}
+
+std::string class_name(const dd_pipeline *p, int c) {
+    if (c >= 0 && c + 1 < (int)p->labels.size()) return p->labels[c + 1];
+    return std::string();
+}
+
+// track.py:154-188 get_label (Dirichlet-multinomial expectation + the motorbike/bicycle rule)
+std::string vote_label(const dd_pipeline *p, const Votes &v) {
+    if (v.cls.empty()) return std::string();
+    double csum = 0, asum = 0;
+    std::vector<double> avg(v.cls.size());
+    for (size_t i = 0; i < v.cls.size(); ++i) { avg[i] = v.sum[i] / v.cnt[i]; csum += v.cnt[i]; asum += avg[i]; }
+    std::vector<std::pair<double, std::string>> e;
+    for (size_t i = 0; i < v.cls.size(); ++i) e.emplace_back((avg[i] + v.cnt[i]) / (csum + asum), class_name(p, v.cls[i]));
+    std::sort(e.begin(), e.end());
+    std::reverse(e.begin(), e.end());
+    if (e.size() > 1 && e[0].second == "motorbike" && e[1].second == "bicycle")
+        return e[0].first > e[1].first * 4 ? "motorbike" : "bicycle";
+    return e[0].second;
+}
+
+double now_s() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dd_tracker_create(dd_ctx *, double, double, int, int, int, int, int, dd_tracker **);
+int dd_tracker_destroy(dd_tracker *);
+int dd_tracker_count(dd_tracker *, int, int *);
+int dd_tracker_read(dd_tracker *, int, int64_t *, double *, double *);
+int dd_net_forward(dd_net *, const uint8_t *, int, void *);
+int dd_net_output(dd_net *, int, void **, int *, int *, int *, int *, int *);
+int dd_net_read(dd_net *, int, int, void *, int, void *);
+
+int dd_pipeline_create(dd_ctx *ctx, int n_streams, int frame_h, int frame_w, dd_net *detector,
+                       const float *anchors_host, int n_anchors, int n_classes, dd_net *encoder,
+                       const char *labels_nl, const char *wanted_nl, double max_cosine_distance, double nms_max_overlap,
+                       double max_iou_distance, int max_age, int n_init, const double *line_host, int track_capacity,
+                       int gallery_capacity, dd_pipeline **out) {
+    DD_REQUIRE(ctx && encoder && out && n_streams > 0 && frame_h > 0 && frame_w > 0 && labels_nl && wanted_nl && line_host,
+               DD_E_ARG, "dd_pipeline_create: bad argument");
+    DD_REQUIRE(!detector || (anchors_host && n_anchors > 64 && n_classes > 1), DD_E_ARG, "dd_pipeline_create: detector needs anchors");
+    dd_pipeline *p = new dd_pipeline();
+    p->ctx = ctx; p->S = n_streams; p->H = frame_h; p->W = frame_w;
+    p->det = detector; p->enc = encoder; p->n_anchors = n_anchors; p->n_classes = n_classes;
+    p->nms_overlap = nms_max_overlap;
+    for (int i = 0; i < 4; ++i) p->line[i] = line_host[i];
+    auto split = [](const char *s, std::vector<std::string> &out) {
+        std::string cur;
+        for (const char *c = s; *c; ++c) { if (*c == '\n') { out.push_back(cur); cur.clear(); } else cur.push_back(*c); }
+        if (!cur.empty()) out.push_back(cur);
+    };
+    split(labels_nl, p->labels);
+    split(wanted_nl, p->wanted);
+    DD_HIP(hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = dd_net_max_batch(encoder, &p->enc_batch)) != DD_OK) return rc;
+    if (detector) {
+        int db = 0;
+        if ((rc = dd_net_max_batch(detector, &db)) != DD_OK) return rc;
+        DD_REQUIRE(db >= n_streams, DD_E_CAPACITY, "dd_pipeline_create: detector max_batch %d < %d streams", db, n_streams);
+        DD_HIP(hipMalloc(&p->d_anchors, (size_t)n_anchors * 4 * sizeof(float)));
+        DD_HIP(hipMemcpy(p->d_anchors, anchors_host, (size_t)n_anchors * 4 * sizeof(float), hipMemcpyHostToDevice));
+        const size_t S = n_streams;
+        if ((rc = p->d_resized.reserve(S * p->det_in * p->det_in * 3)) != DD_OK) return rc;
+        if ((rc = p->d_tmp.reserve(S * frame_h * p->det_in * 3 + 64)) != DD_OK) return rc;
+        if ((rc = p->d_post.reserve(ddk::ssd_post_scratch_bytes(n_anchors, n_streams))) != DD_OK) return rc;
+        if ((rc = p->d_det.reserve(S * MAX_DET * 6 * sizeof(float) + S * sizeof(int) + 256)) != DD_OK) return rc;
+        if ((rc = p->d_fin.reserve(S * (MAX_DET * (4 * 8 + 4 + 8) + 4) + 256)) != DD_OK) return rc;
+        if ((rc = p->h_fin.reserve(S * (MAX_DET * (4 * 8 + 4 + 8) + 4) + 256)) != DD_OK) return rc;
+    }
+    p->st.resize(n_streams);
+    for (auto &s : p->st) {
+        if ((rc = dd_tracker_create(ctx, max_cosine_distance, max_iou_distance, max_age, n_init, 0, track_capacity,
+                                    gallery_capacity, &s.trk)) != DD_OK) return rc;
+        s.counts.assign(p->wanted.size() * 4, 0);
+    }
+    *out = p;
+    return DD_OK;
+}
+
+int dd_pipeline_destroy(dd_pipeline *p) {
+    if (!p) return DD_OK;
+    for (auto &s : p->st) dd_tracker_destroy(s.trk);
+    (void)hipFree(p->d_anchors);
+    for (DevBuf *b : {&p->d_resized, &p->d_tmp, &p->d_post, &p->d_det, &p->d_fin, &p->d_nms, &p->d_crop, &p->d_patches, &p->d_feats}) b->release();
+    for (PinBuf *b : {&p->h_fin, &p->h_nms, &p->h_crop}) b->release();
+    delete p;
+    return DD_OK;
+}
+
+int dd_pipeline_tracker(dd_pipeline *p, int stream, dd_tracker **out) {
+    DD_REQUIRE(p && out && stream >= 0 && stream < p->S, DD_E_ARG, "dd_pipeline_tracker: bad argument");
+    *out = p->st[stream].trk;
+    return DD_OK;
+}
+
+int dd_pipeline_counts(dd_pipeline *p, int64_t *counts_host) {
+    DD_REQUIRE(p && counts_host, DD_E_ARG, "dd_pipeline_counts: NULL argument");
+    const size_t n = p->wanted.size() * 4;
+    for (int s = 0; s < p->S; ++s) memcpy(counts_host + (size_t)s * n, p->st[s].counts.data(), n * sizeof(int64_t));
+    return DD_OK;
+}
+
+int dd_pipeline_stage_seconds(dd_pipeline *p, double *out4_host, long long *steps_host) {
+    DD_REQUIRE(p && out4_host, DD_E_ARG, "dd_pipeline_stage_seconds: NULL argument");
+    out4_host[0] = p->t_det; out4_host[1] = p->t_nms; out4_host[2] = p->t_enc; out4_host[3] = p->t_trk;
+    if (steps_host) *steps_host = p->steps;
+    return DD_OK;
+}
+
+// frames: device u8 [S][H][W][3] BGR.  inj_*: optional injected detections that REPLACE the detector's
+// output (the detector still runs): boxes tlwh as the detector adaptor would return them (f64),
+// scores, class ids, stream s owns rows [inj_offsets[s], inj_offsets[s+1]).
+int dd_pipeline_step(dd_pipeline *p, const uint8_t *frames, const double *inj_boxes_host, const double *inj_scores_host,
+                     const int *inj_cls_host, const int *inj_offsets_host) {
+    DD_REQUIRE(p && frames, DD_E_ARG, "dd_pipeline_step: NULL argument");
+    hipStream_t s = p->ctx->stream;
+    const int S = p->S;
+    int rc;
+    const double t0 = now_s();
+    for (auto &st : p->st)
+        if ((rc = ddk::tracker_predict_async(st.trk)) != DD_OK) return rc;              // deepdish.py:1028
+
+    // ---------------- detector: resize -> forward -> post-process -> adaptor tail, all streams at once
+    std::vector<std::vector<double>> boxes0(S);      // per stream: tlwh f64 rows
+    std::vector<std::vector<double>> scores0(S);
+    std::vector<std::vector<int>> cls0(S);
+    if (p->det) {
+        if ((rc = ddk::resize_lanczos(s, p->ctx->device, frames, p->H, p->W, 3, 1, p->d_resized.as<uint8_t>(), p->det_in,
+                                      p->det_in, p->d_tmp.as<uint8_t>(), S)) != DD_OK) return rc;      // ssd_mobilenet.py:54-57
+        if ((rc = dd_net_forward(p->det, p->d_resized.as<uint8_t>(), S, s)) != DD_OK) return rc;       // :102-103
+        void *raw = nullptr;
+        if ((rc = dd_net_output(p->det, -1, &raw, nullptr, nullptr, nullptr, nullptr, nullptr)) != DD_OK) return rc;
+        float *db = p->d_det.as<float>(), *dc = db + (size_t)S * MAX_DET * 4, *ds = dc + (size_t)S * MAX_DET;
+        int *dn = reinterpret_cast<int *>(ds + (size_t)S * MAX_DET);
+        if ((rc = ddk::ssd_postprocess(s, static_cast<const float *>(raw), p->d_anchors, p->n_anchors, p->n_classes, MAX_DET,
+                                       1e-8f, 0.6f, db, dc, ds, dn, S, p->d_post.p, p->d_post.cap)) != DD_OK) return rc;
+        double *fb = p->d_fin.as<double>(), *fs = fb + (size_t)S * MAX_DET * 4;
+        int *fc = reinterpret_cast<int *>(fs + (size_t)S * MAX_DET), *fn = fc + (size_t)S * MAX_DET;
+        hipLaunchKernelGGL(ssd_finish_k, dim3(S), dim3(64), 0, s, db, dc, ds, p->det_conf, 0.5, (double)p->W, (double)p->H, fb,
+                           fc, fs, fn);
+        DD_LAUNCH_CHECK();
+        const size_t fbytes = (size_t)S * (MAX_DET * (4 * 8 + 8 + 4) + 4);
+        DD_HIP(hipMemcpyAsync(p->h_fin.p, p->d_fin.p, fbytes, hipMemcpyDeviceToHost, s));
+        DD_HIP(hipStreamSynchronize(s));                                                               // round trip 1
+        const double *hb = p->h_fin.as<double>(), *hs = hb + (size_t)S * MAX_DET * 4;
+        const int *hc = reinterpret_cast<const int *>(hs + (size_t)S * MAX_DET), *hn = hc + (size_t)S * MAX_DET;
+        for (int z = 0; z < S; ++z)
+            for (int i = 0; i < hn[z]; ++i) {                                                          // :204-212
+                const std::string name = class_name(p, hc[z * MAX_DET + i]);
+                const double sc = hs[z * MAX_DET + i];
+                if (wanted_index(p, name) < 0 || !(sc >= p->det_conf)) continue;
+                const double *b = hb + ((size_t)z * MAX_DET + i) * 4;
+                boxes0[z].insert(boxes0[z].end(), {b[0], b[1], b[2] - b[0], b[3] - b[1]});
+                scores0[z].push_back(sc);
+                cls0[z].push_back(hc[z * MAX_DET + i]);
+            }
+    }
+    if (inj_offsets_host) {
+        DD_REQUIRE(inj_boxes_host && inj_scores_host && inj_cls_host, DD_E_ARG, "dd_pipeline_step: injected arrays missing");
+        for (int z = 0; z < S; ++z) {
+            const int a = inj_offsets_host[z], b = inj_offsets_host[z + 1];
+            boxes0[z].assign(inj_boxes_host + (size_t)a * 4, inj_boxes_host + (size_t)b * 4);
+            scores0[z].assign(inj_scores_host + a, inj_scores_host + b);
+            cls0[z].assign(inj_cls_host + a, inj_cls_host + b);
+        }
+    }
+    const double t1 = now_s();
+
+    // ---------------- box hygiene (deepdish.py:940-960, background subtraction off) + batched NMS (:995)
+    std::vector<int> off(S + 1, 0);
+    std::vector<std::vector<int64_t>> ib(S);          // int boxes per stream
+    std::vector<std::vector<double>> is(S);
+    std::vector<std::vector<int>> ic(S);
+    for (int z = 0; z < S; ++z) {
+        const int k0 = (int)scores0[z].size();
+        bool any_nan = false;
+        for (double v : boxes0[z]) if (v != v) any_nan = true;
+        if (!any_nan)
+            for (int i = 0; i < k0; ++i) {
+                const double *b = boxes0[z].data() + (size_t)i * 4;
+                auto clipi = [](double v, double lo, double hi) { return (int64_t)(v < lo ? lo : (v > hi ? hi : v)); };
+                const int64_t x = clipi(b[0], 0, p->W), y = clipi(b[1], 0, p->H);
+                const int64_t w = clipi(b[2], 0, (double)(p->W - x)), h = clipi(b[3], 0, (double)(p->H - y));
+                if ((double)(w * h) > 0.9 * p->W * p->H) continue;
+                ib[z].insert(ib[z].end(), {x, y, w, h});
+                is[z].push_back(scores0[z][i]);
+                ic[z].push_back(cls0[z][i]);
+            }
+        off[z + 1] = off[z] + (int)is[z].size();
+    }
+    const int K = off[S];
+    std::vector<std::vector<int>> keep(S);
+    if (K > 0) {
+        bool small = true;
+        for (int z = 0; z < S; ++z) if (off[z + 1] - off[z] > 64) small = false;
+        const size_t in_bytes = (size_t)K * 5 * sizeof(double) + (size_t)(S + 1) * sizeof(int);
+        const size_t out_bytes = (size_t)(K + S) * sizeof(int);
+        if ((rc = p->h_nms.reserve(in_bytes + out_bytes + 256)) != DD_OK) return rc;
+        if ((rc = p->d_nms.reserve(in_bytes + out_bytes + 256 + (small ? 0 : ddk::nms_scratch_bytes(4096)))) != DD_OK) return rc;
+        double *hb = p->h_nms.as<double>(), *hk = hb + (size_t)K * 4;
+        int *ho = reinterpret_cast<int *>(hk + K);
+        for (int z = 0; z < S; ++z) {
+            for (size_t i = 0; i < ib[z].size(); ++i) hb[(size_t)off[z] * 4 + i] = (double)ib[z][i];   // astype(np.float)
+            for (size_t i = 0; i < is[z].size(); ++i) hk[off[z] + i] = is[z][i];
+        }
+        memcpy(ho, off.data(), (size_t)(S + 1) * sizeof(int));
+        char *d = p->d_nms.as<char>();
+        DD_HIP(hipMemcpyAsync(d, hb, in_bytes, hipMemcpyHostToDevice, s));
+        const double *dbx = reinterpret_cast<const double *>(d), *dk = dbx + (size_t)K * 4;
+        const int *doff = reinterpret_cast<const int *>(dk + K);
+        int *didx = reinterpret_cast<int *>(d + ((in_bytes + 63) / 64) * 64), *dnk = didx + K;
+        if (small) {
+            if ((rc = ddk::nms_batched_small(s, dbx, dk, doff, S, p->nms_overlap, 0, didx, dnk)) != DD_OK) return rc;
+        } else {
+            void *scr = d + ((in_bytes + 63) / 64) * 64 + ((out_bytes + 63) / 64) * 64;
+            for (int z = 0; z < S; ++z) {
+                const int k = off[z + 1] - off[z];
+                if ((rc = ddk::nms_ex(s, dbx + (size_t)off[z] * 4, dk + off[z], k, p->nms_overlap, 0, 0, didx + off[z], dnk + z,
+                                      scr, ddk::nms_scratch_bytes(4096))) != DD_OK) return rc;
+            }
+        }
+        int *hidx = reinterpret_cast<int *>(p->h_nms.as<char>() + ((in_bytes + 63) / 64) * 64);
+        DD_HIP(hipMemcpyAsync(hidx, didx, out_bytes, hipMemcpyDeviceToHost, s));
+        DD_HIP(hipStreamSynchronize(s));                                                               // round trip 2
+        const int *hnk = hidx + K;
+        for (int z = 0; z < S; ++z) keep[z].assign(hidx + off[z], hidx + off[z] + hnk[z]);
+    }
+    const double t2 = now_s();
+
+    // ---------------- crops + MARS for every kept box of every stream (deepdish.py:1008)
+    std::vector<int> doff(S + 1, 0);
+    for (int z = 0; z < S; ++z) doff[z + 1] = doff[z] + (int)keep[z].size();
+    const int D = doff[S];
+    std::vector<double> tlwh((size_t)D * 4);
+    if (D > 0) {
+        if ((rc = p->h_crop.reserve((size_t)D * 32)) != DD_OK) return rc;
+        if ((rc = p->d_crop.reserve((size_t)D * 32)) != DD_OK) return rc;
+        if ((rc = p->d_patches.reserve((size_t)D * 64 * 32 * 3)) != DD_OK) return rc;
+        if ((rc = p->d_feats.reserve((size_t)D * 128 * sizeof(float))) != DD_OK) return rc;
+        int *hc = p->h_crop.as<int>();
+        for (int z = 0; z < S; ++z) {
+            p->st[z].det_cls.clear(); p->st[z].det_conf.clear();
+            for (size_t j = 0; j < keep[z].size(); ++j) {
+                const int i = keep[z][j];
+                const int64_t *b = ib[z].data() + (size_t)i * 4;
+                int *c = hc + (size_t)(doff[z] + j) * 8;
+                ddk::crop_box_host(b, 64, 32, p->H, p->W, c, c + 1, c + 2, c + 3);     // generate_detections.py:63-80
+                c[4] = z; c[5] = c[6] = c[7] = 0;
+                for (int q = 0; q < 4; ++q) tlwh[(size_t)(doff[z] + j) * 4 + q] = (double)b[q];
+                p->st[z].det_cls.push_back(ic[z][i]);
+                p->st[z].det_conf.push_back(is[z][i]);
+            }
+        }
+        DD_HIP(hipMemcpyAsync(p->d_crop.p, hc, (size_t)D * 32, hipMemcpyHostToDevice, s));
+        if ((rc = ddk::crop_resize(s, frames, p->H, p->W, p->d_crop.p, D, 64, 32, p->d_patches.as<uint8_t>())) != DD_OK) return rc;
+        for (int a = 0; a < D; a += p->enc_batch) {
+            const int n = std::min(p->enc_batch, D - a);
+            if ((rc = dd_net_forward(p->enc, p->d_patches.as<uint8_t>() + (size_t)a * 64 * 32 * 3, n, s)) != DD_OK) return rc;
+            if ((rc = dd_net_read(p->enc, -1, n, p->d_feats.as<float>() + (size_t)a * 128, 1, s)) != DD_OK) return rc;
+        }
+    } else {
+        for (auto &st : p->st) { st.det_cls.clear(); st.det_conf.clear(); }
+    }
+    const double t3 = now_s();
+
+    // ---------------- deep_sort update, phase-split so all streams share two round trips (:1029)
+    for (int z = 0; z < S; ++z)
+        if ((rc = ddk::tracker_update_begin(p->st[z].trk, tlwh.data() + (size_t)doff[z] * 4,
+                                            D ? p->d_feats.as<float>() + (size_t)doff[z] * 128 : nullptr, 1,
+                                            doff[z + 1] - doff[z])) != DD_OK) return rc;
+    DD_HIP(hipStreamSynchronize(s));                                                                   // round trip 3
+    for (int z = 0; z < S; ++z)
+        if ((rc = ddk::tracker_update_match(p->st[z].trk)) != DD_OK) return rc;
+    DD_HIP(hipStreamSynchronize(s));                                                                   // round trip 4
+    std::vector<int64_t> ints;
+    std::vector<double> means;
+    for (int z = 0; z < S; ++z) {
+        StreamState &st = p->st[z];
+        if ((rc = ddk::tracker_update_end(st.trk)) != DD_OK) return rc;
+        // ---------------- count line (deepdish.py:1035-1114, 1303-1312)
+        int nd = 0, nl = 0;
+        dd_tracker_count(st.trk, 1, &nd);
+        dd_tracker_count(st.trk, 0, &nl);
+        std::map<std::string, int> delcounts;
+        if (nd) {
+            ints.resize((size_t)nd * 6);
+            dd_tracker_read(st.trk, 1, ints.data(), nullptr, nullptr);
+            for (int i = 0; i < nd; ++i) {
+                const int64_t id = ints[(size_t)i * 6];
+                delcounts.clear();                                  // overwritten per deleted track (:1040-1044)
+                auto it = st.db.find(id);
+                if (it != st.db.end() && it->second.size() > 1) {
+                    bool hit = false;
+                    for (size_t q = 0; q + 1 < it->second.size() && !hit; ++q) {
+                        const double a[2] = {it->second[q].first, it->second[q].second};
+                        const double b[2] = {it->second[q + 1].first, it->second[q + 1].second};
+                        hit = seg_intersect(p->line, p->line + 2, a, b);
+                    }
+                    if (hit) delcounts[vote_label(p, st.votes[id])] += 1;
+                    it->second.clear();
+                }
+                st.votes.erase(id);
+            }
+        }
+        if (nl) {
+            ints.resize((size_t)nl * 6);
+            means.resize((size_t)nl * 8);
+            dd_tracker_read(st.trk, 0, ints.data(), means.data(), nullptr);
+        }
+        std::vector<std::pair<std::string, double>> events;
+        for (int i = 0; i < nl; ++i) {
+            const int64_t *r = ints.data() + (size_t)i * 6;
+            const int64_t id = r[0];
+            if (r[5] >= 0) st.votes[id].add(st.det_cls[r[5]], st.det_conf[r[5]]);
+            if (r[1] != CONFIRMED || r[2] > 1) continue;
+            const double *m = means.data() + (size_t)i * 8;
+            const double w = m[2] * m[3];                            // track.py:84-111 to_tlbr
+            const double x1 = m[0] - w / 2, y1 = m[1] - m[3] / 2;
+            const double x2 = x1 + w, y2 = y1 + m[3];
+            auto &pts = st.db[id];
+            pts.emplace_back((x1 + x2) / 2.0, y2);
+            if (pts.size() > 1) {
+                const double p2[2] = {pts.back().first, pts.back().second};
+                const double q2[2] = {pts[pts.size() - 2].first, pts[pts.size() - 2].second};
+                const double cp = cross2(p->line[2] - p->line[0], p->line[3] - p->line[1], q2[0] - p2[0], q2[1] - p2[1]);
+                if (seg_intersect(p->line, p->line + 2, p2, q2)) events.emplace_back(vote_label(p, st.votes[id]), cp);
+            }
+        }
+        for (auto &e : events) {
+            const int wi = wanted_index(p, e.first);
+            if (wi < 0) continue;
+            st.counts[wi * 4 + (e.second >= 0 ? 0 : 1)] += 1;
+            st.counts[wi * 4 + 2] += 1;
+        }
+        for (auto &d : delcounts) {
+            const int wi = wanted_index(p, d.first);
+            if (wi >= 0) st.counts[wi * 4 + 3] += d.second;
+        }
+    }
+    const double t4 = now_s();
+    p->t_det += t1 - t0; p->t_nms += t2 - t1; p->t_enc += t3 - t2; p->t_trk += t4 - t3;
+    p->steps += 1;
+    return DD_OK;
+}
+
+}  // extern "C"

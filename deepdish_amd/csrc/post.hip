@@ -10,44 +10,68 @@
 #include "common.h"
 
 namespace ddk {
-int nms_f32(hipStream_t s, const float *boxes_yxyx, const float *keys, int k, float thr, int *out_idx, int *out_n,
-            void *scratch, size_t scratch_bytes);
+int nms_f32(hipStream_t s, const float *boxes_yxyx, const float *keys, int k, float thr, int max_keep, int *out_idx,
+            int *out_n, void *scratch, size_t scratch_bytes);
+int nms_f32_batched(hipStream_t s, const float *boxes, const float *keys, int k, float thr, int max_keep, int *out_idx,
+                    int *out_n, void *scratch, size_t scratch_bytes, int batch);
 }
 
 namespace {
 
+// One wave per anchor: lanes sweep the class logits (coalesced), wave-max picks the best class
+// (lowest class index on ties, like a sequential `>` scan); the sigmoid is applied once.
 __global__ __launch_bounds__(256) void ssd_decode_k(const float *__restrict__ raw, const float *__restrict__ anchors,
                                                     int n_anchors, int n_classes, float score_thr,
                                                     float *__restrict__ boxes, float *__restrict__ best_score,
                                                     int *__restrict__ best_cls, float *__restrict__ keys) {
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    const int a = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
     if (a >= n_anchors) return;
-    const float *r = raw + (size_t)a * (4 + n_classes);
-    const float ay = anchors[a * 4 + 0], ax = anchors[a * 4 + 1], ah = anchors[a * 4 + 2], aw = anchors[a * 4 + 3];
-    const float yc = r[0] / 10.f * ah + ay;
-    const float xc = r[1] / 10.f * aw + ax;
-    const float hh = 0.5f * expf(r[2] / 5.f) * ah;
-    const float hw = 0.5f * expf(r[3] / 5.f) * aw;
-    boxes[a * 4 + 0] = yc - hh;
-    boxes[a * 4 + 1] = xc - hw;
-    boxes[a * 4 + 2] = yc + hh;
-    boxes[a * 4 + 3] = xc + hw;
-    float best = -1.f;
-    int bi = 0;
-    for (int c = 1; c < n_classes; ++c) {                     // class 0 = background
-        const float sc = 1.f / (1.f + expf(-r[4 + c]));
-        if (sc > best) { best = sc; bi = c - 1; }
+    {   // blockIdx.y = image of a batch
+        const size_t z = blockIdx.y;
+        raw += z * n_anchors * (4 + n_classes);
+        boxes += z * n_anchors * 4; best_score += z * n_anchors; best_cls += z * n_anchors; keys += z * n_anchors;
     }
-    best_score[a] = best;
-    best_cls[a] = bi;
-    keys[a] = best >= score_thr ? best : -1.f;
+    const float *r = raw + (size_t)a * (4 + n_classes);
+    float best = -__builtin_inff();
+    int bi = 0x7fffffff;
+    for (int c = 1 + lane; c < n_classes; c += 64) {          // class 0 = background
+        const float v = r[4 + c];
+        if (v > best) { best = v; bi = c - 1; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) {
+        const float ay = anchors[a * 4 + 0], ax = anchors[a * 4 + 1], ah = anchors[a * 4 + 2], aw = anchors[a * 4 + 3];
+        const float yc = r[0] / 10.f * ah + ay;
+        const float xc = r[1] / 10.f * aw + ax;
+        const float hh = 0.5f * expf(r[2] / 5.f) * ah;
+        const float hw = 0.5f * expf(r[3] / 5.f) * aw;
+        boxes[a * 4 + 0] = yc - hh;
+        boxes[a * 4 + 1] = xc - hw;
+        boxes[a * 4 + 2] = yc + hh;
+        boxes[a * 4 + 3] = xc + hw;
+        const float sc = 1.f / (1.f + expf(-best));
+        best_score[a] = sc;
+        best_cls[a] = bi;
+        keys[a] = sc >= score_thr ? sc : -1.f;
+    }
 }
 
 __global__ void ssd_gather_k(const int *__restrict__ keep, const int *__restrict__ n_keep, const float *__restrict__ boxes,
                              const float *__restrict__ best_score, const int *__restrict__ best_cls, float score_thr,
-                             int max_det, float *__restrict__ out_boxes, float *__restrict__ out_cls,
+                             int max_det, int k_stride, float *__restrict__ out_boxes, float *__restrict__ out_cls,
                              float *__restrict__ out_scores, int *__restrict__ out_count) {
     const int i = threadIdx.x;
+    {   // blockIdx.x = image of a batch; k_stride = anchors per image
+        const size_t z = blockIdx.x;
+        keep += z * k_stride; n_keep += z; boxes += z * k_stride * 4; best_score += z * k_stride; best_cls += z * k_stride;
+        out_boxes += z * max_det * 4; out_cls += z * max_det; out_scores += z * max_det; out_count += z;
+    }
     const int n = min(*n_keep, max_det);
     bool ok = false;
     if (i < max_det) {
@@ -127,36 +151,57 @@ __global__ void counts_add_k(long long *__restrict__ acc, const long long *__res
 
 }  // namespace
 
-extern "C" {
+namespace ddk {
 
-int dd_ssd_postprocess(dd_ctx *ctx, const float *raw, const float *anchors, int n_anchors, int n_classes, int max_det,
-                       float score_thr, float iou_thr, float *boxes, float *classes, float *scores, int *count,
-                       void *stream) {
-    DD_REQUIRE(ctx && raw && anchors && boxes && classes && scores && count, DD_E_ARG, "dd_ssd_postprocess: NULL argument");
-    DD_REQUIRE(n_anchors > 0 && n_anchors <= 4096 && n_classes > 1 && max_det > 0 && max_det <= 64, DD_E_ARG,
-               "dd_ssd_postprocess: bad shape (anchors %d, classes %d, max_det %d)", n_anchors, n_classes, max_det);
-    hipStream_t s = dd_pick_stream(ctx, stream);
-    int rc;
+size_t ssd_post_scratch_bytes(int n_anchors, int batch) {
     const size_t per = (size_t)n_anchors;
-    const size_t head = per * (4 * 4 + 4 + 4 + 4 + 4) + 256;            // boxes, score, cls, keys, keep
-    const size_t nms_bytes = (size_t)n_anchors * 64 + (size_t)n_anchors * ((n_anchors + 63) / 64) * 8 + 1024;
-    if ((rc = ctx->scratch[2].reserve(head + nms_bytes)) != DD_OK) return rc;
-    char *p = ctx->scratch[2].as<char>();
+    const size_t head = (size_t)batch * per * (4 * 4 + 4 + 4 + 4 + 4) + (size_t)batch * 4 + 512;
+    const size_t nms_bytes = (size_t)batch * (per * 64 + per * ((n_anchors + 63) / 64) * 8 + 1024);
+    return head + nms_bytes + 512;
+}
+
+// raw [batch][n_anchors][4+n_classes] -> boxes [batch][max_det][4], classes, scores [batch][max_det], count [batch]
+int ssd_postprocess(hipStream_t s, const float *raw, const float *anchors, int n_anchors, int n_classes, int max_det,
+                    float score_thr, float iou_thr, float *boxes, float *classes, float *scores, int *count, int batch,
+                    void *scratch, size_t scratch_bytes) {
+    DD_REQUIRE(n_anchors > 64 && n_anchors <= 4096 && n_classes > 1 && max_det > 0 && max_det <= 64 && batch > 0, DD_E_ARG,
+               "ssd_postprocess: bad shape (anchors %d, classes %d, max_det %d, batch %d)", n_anchors, n_classes, max_det, batch);
+    DD_REQUIRE(scratch_bytes >= ssd_post_scratch_bytes(n_anchors, batch), DD_E_ARG, "ssd_postprocess: scratch too small");
+    const size_t per = (size_t)n_anchors * batch;
+    char *p = static_cast<char *>(scratch);
     float *d_boxes = reinterpret_cast<float *>(p);
     float *d_score = d_boxes + per * 4;
     int *d_cls = reinterpret_cast<int *>(d_score + per);
     float *d_keys = reinterpret_cast<float *>(d_cls + per);
     int *d_keep = reinterpret_cast<int *>(d_keys + per);
     int *d_nkeep = d_keep + per;
-    char *d_nms = p + ((head + 255) / 256) * 256;
-    hipLaunchKernelGGL(ssd_decode_k, dim3(dd_ceil_div(n_anchors, 256)), dim3(256), 0, s, raw, anchors, n_anchors, n_classes,
+    const size_t head = ((per * 32 + (size_t)batch * 4) + 255) / 256 * 256;
+    char *d_nms = p + head;
+    hipLaunchKernelGGL(ssd_decode_k, dim3(dd_ceil_div(n_anchors, 4), batch), dim3(256), 0, s, raw, anchors, n_anchors, n_classes,
                        score_thr, d_boxes, d_score, d_cls, d_keys);
     DD_LAUNCH_CHECK();
-    if ((rc = ddk::nms_f32(s, d_boxes, d_keys, n_anchors, iou_thr, d_keep, d_nkeep, d_nms, nms_bytes)) != DD_OK) return rc;
-    hipLaunchKernelGGL(ssd_gather_k, dim3(1), dim3(64), 0, s, d_keep, d_nkeep, d_boxes, d_score, d_cls, score_thr, max_det,
-                       boxes, classes, scores, count);
+    int rc;
+    if ((rc = nms_f32_batched(s, d_boxes, d_keys, n_anchors, iou_thr, max_det, d_keep, d_nkeep, d_nms, scratch_bytes - head,
+                              batch)) != DD_OK) return rc;
+    hipLaunchKernelGGL(ssd_gather_k, dim3(batch), dim3(64), 0, s, d_keep, d_nkeep, d_boxes, d_score, d_cls, score_thr, max_det,
+                       n_anchors, boxes, classes, scores, count);
     DD_LAUNCH_CHECK();
     return DD_OK;
+}
+
+}  // namespace ddk
+
+extern "C" {
+
+int dd_ssd_postprocess(dd_ctx *ctx, const float *raw, const float *anchors, int n_anchors, int n_classes, int max_det,
+                       float score_thr, float iou_thr, float *boxes, float *classes, float *scores, int *count,
+                       void *stream) {
+    DD_REQUIRE(ctx && raw && anchors && boxes && classes && scores && count, DD_E_ARG, "dd_ssd_postprocess: NULL argument");
+    int rc;
+    const size_t need = ddk::ssd_post_scratch_bytes(n_anchors, 1);
+    if ((rc = ctx->scratch[2].reserve(need)) != DD_OK) return rc;
+    return ddk::ssd_postprocess(dd_pick_stream(ctx, stream), raw, anchors, n_anchors, n_classes, max_det, score_thr, iou_thr,
+                                boxes, classes, scores, count, 1, ctx->scratch[2].p, ctx->scratch[2].cap);
 }
 
 int dd_yolov5_decode(dd_ctx *ctx, const float *raw, int n_rows, int n_cls, float thr, float img_w, float img_h,

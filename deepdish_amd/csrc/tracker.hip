@@ -120,8 +120,12 @@ struct dd_tracker {
     double *d_means = nullptr, *d_covs = nullptr;
     float *d_gallery = nullptr;
     int *d_gal_count = nullptr, *d_gal_total = nullptr;
-    DevBuf d_stage, d_feats_raw, d_feats_n, d_cost, d_gather;
-    PinBuf h_stage, h_cost, h_gather;
+    DevBuf d_stage, d_pred, d_feats_raw, d_feats_n, d_cost, d_gather;
+    PinBuf h_stage, h_pred, h_cost, h_gather;
+    // state carried between the phases of one update (begin -> match -> end)
+    int ph_n = 0, ph_T = 0, ph_ng = 0, ph_nl = 0;
+    size_t ph_off_pairs = 0;
+    bool ph_have_cost = false, pred_inflight = false;
     std::vector<TrackRec> tracks, deleted;
     std::vector<int> free_slots, pending_free;
     std::vector<double> live_means, dead_means;           // host mirrors, [n][8]
@@ -204,45 +208,48 @@ int dd_tracker_destroy(dd_tracker *t) {
     (void)hipFree(t->d_gallery);
     (void)hipFree(t->d_gal_count);
     (void)hipFree(t->d_gal_total);
-    t->d_stage.release(); t->d_feats_raw.release(); t->d_feats_n.release(); t->d_cost.release(); t->d_gather.release();
+    t->d_stage.release(); t->d_pred.release(); t->h_pred.release(); t->d_feats_raw.release(); t->d_feats_n.release(); t->d_cost.release(); t->d_gather.release();
     t->h_stage.release(); t->h_cost.release(); t->h_gather.release();
     delete t;
     return DD_OK;
 }
 
-// tracker.py:51-57 + track.py:113-125
-int dd_tracker_predict(dd_tracker *t) {
-    DD_REQUIRE(t, DD_E_ARG, "dd_tracker_predict: NULL tracker");
+}  // extern "C"
+
+namespace ddk {
+
+// tracker.py:51-57 + track.py:113-125.  Enqueue only (own pinned staging block, so the copy may
+// still be in flight when update_begin stages its inputs).
+int tracker_predict_async(dd_tracker *t) {
     hipStream_t s = t->ctx->stream;
     for (int sl : t->pending_free) t->free_slots.push_back(sl);
     t->pending_free.clear();
     const int n = (int)t->tracks.size();
     if (n == 0) return DD_OK;
     int rc;
-    if ((rc = t->h_stage.reserve((size_t)n * sizeof(int))) != DD_OK) return rc;
-    if ((rc = t->d_stage.reserve((size_t)n * sizeof(int))) != DD_OK) return rc;
-    int *h = t->h_stage.as<int>();
+    if (t->pred_inflight) DD_HIP(hipStreamSynchronize(s));      // two predicts in a row: h_pred is still being read
+    t->pred_inflight = true;
+    if ((rc = t->h_pred.reserve((size_t)n * sizeof(int))) != DD_OK) return rc;
+    if ((rc = t->d_pred.reserve((size_t)n * sizeof(int))) != DD_OK) return rc;
+    int *h = t->h_pred.as<int>();
     for (int i = 0; i < n; ++i) {
         h[i] = t->tracks[i].slot;
         t->tracks[i].age += 1;
         t->tracks[i].tsu += 1;
     }
-    DD_HIP(hipMemcpyAsync(t->d_stage.p, h, (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
-    if ((rc = ddk::kf_predict(s, t->d_means, t->d_covs, t->d_stage.as<int>(), n)) != DD_OK) return rc;
-    // the pinned staging area is reused by update(): make sure the copy has left it
-    DD_HIP(hipStreamSynchronize(s));
-    return DD_OK;
+    DD_HIP(hipMemcpyAsync(t->d_pred.p, h, (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
+    return ddk::kf_predict(s, t->d_means, t->d_covs, t->d_pred.as<int>(), n);
 }
 
-// tracker.py:59-93
-int dd_tracker_update(dd_tracker *t, const double *tlwh_host, const float *feats, int feats_on_device, int n) {
-    DD_REQUIRE(t && n >= 0, DD_E_ARG, "dd_tracker_update: bad argument");
-    DD_REQUIRE(n == 0 || (tlwh_host && feats), DD_E_ARG, "dd_tracker_update: NULL detections");
+// tracker.py:59-93, phase 1: stage the detections, enqueue the association kernel and the copy of the
+// cost matrices back to pinned host memory.  No synchronisation.
+int tracker_update_begin(dd_tracker *t, const double *tlwh_host, const float *feats, int feats_on_device, int n) {
     hipStream_t s = t->ctx->stream;
     const int T = (int)t->tracks.size();
     int rc;
     t->last_pairs.clear();
     for (auto &tr : t->tracks) tr.last_det = -1;
+    t->ph_n = n; t->ph_T = T; t->ph_have_cost = false;
 
     // ---- stage inputs: [det tlwh f64 n*4][row_slot T][row_state T][row_tsu T][pairs 2*(T+n)]
     const size_t off_tlwh = 0;
@@ -260,11 +267,10 @@ int dd_tracker_update(dd_tracker *t, const double *tlwh_host, const float *feats
         h_state[i] = t->tracks[i].state;
         h_tsu[i] = t->tracks[i].tsu;
     }
+    t->ph_off_pairs = off_pairs;
     const double *d_tlwh = reinterpret_cast<const double *>(d + off_tlwh);
     const int *d_slot = reinterpret_cast<const int *>(d + off_rows), *d_state = d_slot + T, *d_tsu = d_state + T;
     const float *d_feats_n = nullptr;
-    std::vector<std::pair<int, int>> matches;
-    std::vector<int> un_rows_final, un_dets;
 
     if (n > 0) {
         DD_HIP(hipMemcpyAsync(d, h, off_pairs, hipMemcpyHostToDevice, s));
@@ -289,7 +295,26 @@ int dd_tracker_update(dd_tracker *t, const double *tlwh_host, const float *feats
                            d_app, d_iou);
         DD_LAUNCH_CHECK();
         DD_HIP(hipMemcpyAsync(t->h_cost.p, t->d_cost.p, cbytes, hipMemcpyDeviceToHost, s));
-        DD_HIP(hipStreamSynchronize(s));
+        t->ph_have_cost = true;
+    }
+    return DD_OK;
+}
+
+// phase 2 (the cost matrices have landed): matching cascade + LSAP + track management on the host,
+// then enqueue the Kalman updates / new tracks / gallery appends and the copy of the means.
+int tracker_update_match(dd_tracker *t) {
+    hipStream_t s = t->ctx->stream;
+    t->pred_inflight = false;                                   // the caller synchronised before this phase
+    const int n = t->ph_n, T = t->ph_T;
+    int rc;
+    char *h = t->h_stage.as<char>();
+    char *d = t->d_stage.as<char>();
+    const size_t off_pairs = t->ph_off_pairs;
+    const double *d_tlwh = reinterpret_cast<const double *>(d);
+    const float *d_feats_n = n > 0 ? t->d_feats_n.as<float>() : nullptr;
+    std::vector<std::pair<int, int>> matches;
+    std::vector<int> un_rows_final, un_dets;
+    if (t->ph_have_cost) {
         const double *app = t->h_cost.as<double>(), *iou = app + (size_t)T * n;
 
         // ---- tracker.py:95-133 _match
@@ -399,13 +424,40 @@ int dd_tracker_update(dd_tracker *t, const double *tlwh_host, const float *feats
         DD_HIP(hipMemcpyAsync(ds, hs, (size_t)ng * sizeof(int), hipMemcpyHostToDevice, s));
         if ((rc = ddk::gather_state(s, t->d_means, t->d_covs, ds, ng, dg, nullptr)) != DD_OK) return rc;
         DD_HIP(hipMemcpyAsync(hg, dg, (size_t)ng * 8 * sizeof(double), hipMemcpyDeviceToHost, s));
-        DD_HIP(hipStreamSynchronize(s));
+    }
+    t->ph_ng = ng; t->ph_nl = nl;
+    return DD_OK;
+}
+
+// phase 3 (the means have landed): mirror them for dd_tracker_read.
+int tracker_update_end(dd_tracker *t) {
+    const int ng = t->ph_ng, nl = t->ph_nl, nd = ng - nl;
+    if (ng > 0) {
+        const double *hg = t->h_gather.as<double>();
         memcpy(t->live_means.data(), hg, (size_t)nl * 8 * sizeof(double));
         memcpy(t->dead_means.data(), hg + (size_t)nl * 8, (size_t)nd * 8 * sizeof(double));
-    } else {
-        DD_HIP(hipStreamSynchronize(s));
     }
     return DD_OK;
+}
+
+}  // namespace ddk
+
+extern "C" {
+
+int dd_tracker_predict(dd_tracker *t) {
+    DD_REQUIRE(t, DD_E_ARG, "dd_tracker_predict: NULL tracker");
+    return ddk::tracker_predict_async(t);
+}
+
+int dd_tracker_update(dd_tracker *t, const double *tlwh_host, const float *feats, int feats_on_device, int n) {
+    DD_REQUIRE(t && n >= 0, DD_E_ARG, "dd_tracker_update: bad argument");
+    DD_REQUIRE(n == 0 || (tlwh_host && feats), DD_E_ARG, "dd_tracker_update: NULL detections");
+    int rc;
+    if ((rc = ddk::tracker_update_begin(t, tlwh_host, feats, feats_on_device, n)) != DD_OK) return rc;
+    DD_HIP(hipStreamSynchronize(t->ctx->stream));
+    if ((rc = ddk::tracker_update_match(t)) != DD_OK) return rc;
+    DD_HIP(hipStreamSynchronize(t->ctx->stream));
+    return ddk::tracker_update_end(t);
 }
 
 int dd_tracker_count(dd_tracker *t, int which, int *out_n_host) {

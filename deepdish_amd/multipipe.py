@@ -1,0 +1,118 @@
+"""Multi-stream hot path on one GPU (csrc/pipeline.hip): S independent DeepDish streams advanced one
+frame each per step, device work batched across streams.  Mirrors `pipeline.HotPath` (one stream,
+reference-shaped Python objects) but keeps the per-frame orchestration in C++."""
+import ctypes
+import numpy as np
+
+from ._lib import lib, check, P
+from .runtime import default_context, ptr
+from . import nets
+from .engine import Net
+from .pipeline import DEFAULT_LABELS
+from .tools.weights_io import load_named_weights
+
+
+class _TrackerView:
+    """Read-only view of one stream's C++ tracker (for parity tests)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    def table(self):
+        n = ctypes.c_int()
+        check(lib().dd_tracker_count(self._h, 0, ctypes.byref(n)))
+        ints = np.zeros((n.value, 6), dtype=np.int64)
+        means = np.zeros((n.value, 8), dtype=np.float64)
+        if n.value:
+            check(lib().dd_tracker_read(self._h, 0, ptr(ints), ptr(means), None))
+        return ints, means
+
+    @property
+    def next_id(self):
+        v = ctypes.c_int64()
+        check(lib().dd_tracker_next_id(self._h, ctypes.byref(v)))
+        return v.value
+
+
+class MultiStreamPipeline:
+    def __init__(self, n_streams, model='synthetic-ssd_mobilenet_v1', encoder_model='synthetic-mars-64x32x3',
+                 labels=None, wanted_labels=('person',), input_size=(640, 480), line=None, max_cosine_distance=0.2,
+                 nms_max_overlap=0.6, max_iou_distance=0.7, max_age=60, n_init=3, context=None, run_detector=True,
+                 encoder_max_batch=None, track_capacity=512, gallery_capacity=256):
+        self.ctx = context or default_context()
+        self.S = int(n_streams)
+        self.W, self.H = input_size
+        self.wanted = list(wanted_labels)
+        with open(labels or DEFAULT_LABELS) as f:
+            self.label_lines = [l.strip() for l in f.readlines()]
+        self.det = None
+        anchors, n_anchors, n_classes = None, 0, 0
+        if run_detector:
+            if 'mobilenet' not in model:
+                raise ValueError('the multi-stream pipeline batches the SSD-MobileNet detector only (got %s)' % model)
+            wd = load_named_weights(model, nets.synthetic_ssd_weights)
+            prog = nets.compile_ssd_mobilenet(wd)
+            self.det = Net(prog, max_batch=self.S, context=self.ctx)
+            anchors = np.ascontiguousarray(prog.meta['anchors'], dtype=np.float32)
+            n_anchors, n_classes = len(anchors), prog.meta['n_classes']
+        wd = load_named_weights(encoder_model, nets.synthetic_mars_weights)
+        self.enc_weights = wd
+        self.enc = Net(nets.compile_mars(wd), max_batch=encoder_max_batch or max(64, 32 * self.S), context=self.ctx)
+        if line is None:
+            line = np.array([[self.W / 2, 0], [self.W / 2, self.H]], dtype=int)        # deepdish.py:739-741
+        self.line = np.ascontiguousarray(np.asarray(line, dtype=np.float64).reshape(4))
+        h = P()
+        check(lib().dd_pipeline_create(self.ctx.handle, self.S, self.H, self.W, self.det._h if self.det else None,
+                                       ptr(anchors), n_anchors, n_classes, self.enc._h,
+                                       '\n'.join(self.label_lines).encode(), '\n'.join(self.wanted).encode(),
+                                       float(max_cosine_distance), float(nms_max_overlap), float(max_iou_distance),
+                                       int(max_age), int(n_init), ptr(self.line), int(track_capacity),
+                                       int(gallery_capacity), ctypes.byref(h)), 'dd_pipeline_create')
+        self._h = h
+        self._class_id = {name: i - 1 for i, name in enumerate(self.label_lines) if i > 0}
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().dd_pipeline_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def pack_injected(self, per_stream):
+        """per_stream: list of (boxes tlwh, labels, scores) per stream -> arrays for step()."""
+        off = np.zeros(self.S + 1, dtype=np.int32)
+        b, sc, cl = [], [], []
+        for z, (boxes, labels, scores) in enumerate(per_stream):
+            b += [tuple(float(v) for v in bb) for bb in boxes]
+            sc += [float(v) for v in scores]
+            cl += [self._class_id[l] for l in labels]
+            off[z + 1] = len(sc)
+        return (np.ascontiguousarray(np.array(b, dtype=np.float64).reshape(-1, 4)), np.array(sc, dtype=np.float64),
+                np.array(cl, dtype=np.int32), off)
+
+    def step(self, frames_dev, injected=None):
+        """frames_dev: u8 [S, H, W, 3] BGR torch tensor in HBM; injected: pack_injected(...) or None."""
+        assert tuple(frames_dev.shape) == (self.S, self.H, self.W, 3)
+        if injected is None:
+            check(lib().dd_pipeline_step(self._h, ptr(frames_dev), None, None, None, None), 'dd_pipeline_step')
+        else:
+            b, sc, cl, off = injected
+            check(lib().dd_pipeline_step(self._h, ptr(frames_dev), ptr(b), ptr(sc), ptr(cl), ptr(off)), 'dd_pipeline_step')
+
+    def counts(self):
+        out = np.zeros((self.S, len(self.wanted), 4), dtype=np.int64)
+        check(lib().dd_pipeline_counts(self._h, ptr(out)), 'dd_pipeline_counts')
+        return out
+
+    def tracker(self, stream):
+        h = P()
+        check(lib().dd_pipeline_tracker(self._h, stream, ctypes.byref(h)), 'dd_pipeline_tracker')
+        return _TrackerView(h)
+
+    def stage_ms(self):
+        t = np.zeros(4, dtype=np.float64)
+        n = ctypes.c_longlong()
+        check(lib().dd_pipeline_stage_seconds(self._h, ptr(t), ctypes.byref(n)), 'dd_pipeline_stage_seconds')
+        k = max(1, n.value)
+        return dict(objd=1e3 * t[0] / k, nms=1e3 * t[1] / k, feat=1e3 * t[2] / k, trak=1e3 * t[3] / k, steps=n.value)

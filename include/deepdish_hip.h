@@ -161,6 +161,7 @@ int dd_net_forward(dd_net *net, const uint8_t *input, int n, void *stream);
 int dd_net_output(dd_net *net, int tensor, void **dev_ptr_host, int *h_host, int *w_host, int *c_host,
                   int *cs_host, int *dtype_host);
 
+int dd_net_max_batch(dd_net *net, int *out_host);
 /* Copy the first n images of a (whole, un-sliced) tensor to caller memory: n*h*w*cs elements. */
 int dd_net_read(dd_net *net, int tensor, int n, void *dst, int dst_on_device, void *stream);
 
@@ -182,6 +183,30 @@ int dd_ssd_postprocess(dd_ctx *ctx, const float *raw, const float *anchors, int 
 int dd_yolov5_decode(dd_ctx *ctx, const float *raw, int n_rows, int n_cls, float thr,
                      float img_w, float img_h, float *out_boxes, float *out_scores,
                      int *out_cls, int cap, int *out_n, void *stream);
+
+/* ---------------------------------------------------------------- multi-stream hot path
+ * The per-frame call sequence of the reference's Pipeline (deepdish.py:880-885 run_object_detector,
+ * :940-960 box hygiene, :995 NMS, :1008 encoder, :1028-1029 tracker, :1035-1114 count line) for
+ * n_streams independent streams, one frame each per step, device work batched across streams.
+ * detector may be NULL (detections are then always injected).  labels_nl: the label file's lines
+ * joined by '\n' (line i+1 names class id i, tools/ssd_mobilenet.py:142-147); wanted_nl: --wanted-labels.
+ * line_host: count line x1,y1,x2,y2 (deepdish.py:739-744). */
+int dd_pipeline_create(dd_ctx *ctx, int n_streams, int frame_h, int frame_w, dd_net *detector,
+                       const float *anchors_host, int n_anchors, int n_classes, dd_net *encoder,
+                       const char *labels_nl, const char *wanted_nl, double max_cosine_distance,
+                       double nms_max_overlap, double max_iou_distance, int max_age, int n_init,
+                       const double *line_host, int track_capacity, int gallery_capacity, dd_pipeline **out);
+int dd_pipeline_destroy(dd_pipeline *p);
+/* frames: device u8 [n_streams][H][W][3] BGR.  inj_*: optional detections that REPLACE the detector's
+ * output (it still runs): tlwh f64 rows, scores, class ids; stream s owns rows
+ * [inj_offsets[s], inj_offsets[s+1]).  Blocks until the step is complete. */
+int dd_pipeline_step(dd_pipeline *p, const uint8_t *frames, const double *inj_boxes_host,
+                     const double *inj_scores_host, const int *inj_cls_host, const int *inj_offsets_host);
+/* counts_host: int64 [n_streams][n_wanted][4] = poscount, negcount, intcount, delcount */
+int dd_pipeline_counts(dd_pipeline *p, int64_t *counts_host);
+int dd_pipeline_tracker(dd_pipeline *p, int stream, dd_tracker **out);
+/* accumulated host wall time per stage (objd, nms, feat, trak as in deepdish.py's TimingInfo labels) */
+int dd_pipeline_stage_seconds(dd_pipeline *p, double *out4_host, long long *steps_host);
 
 /* ---------------------------------------------------------------- multi-GPU
  * Sum of the per-stream count vectors (pos, neg, int, del per label; deepdish.py:1141-1145).

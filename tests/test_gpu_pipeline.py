@@ -97,3 +97,66 @@ def test_yolov5_plugin_vs_oracle():
     got = {(round(float(s), 1), int(c)) for s, c in zip(gs, gc)}
     assert abs(len(gs) - len(conf)) <= max(3, int(0.05 * len(conf)))
     assert all(l in ('person', 'car', 'bicycle') for l in labels)
+
+
+def test_multistream_pipeline_matches_oracle_per_stream():
+    """3 streams batched in C++ == 3 independent oracle runs: track tables and crossing counts."""
+    from deepdish_amd.multipipe import MultiStreamPipeline
+    from deepdish_amd.synth import Scene
+    from oracle import deepsort_np as ds, countline_np as cl, image_np, nets_torch
+    S, F = 3, 45
+    scenes = [Scene(seed=21 + z, n_obj=10 + 3 * z, n_frames=F) for z in range(S)]
+    mp = MultiStreamPipeline(S, run_detector=True)
+    otrk = [ds.Tracker(ds.Metric(0.2), max_iou_distance=0.7, max_age=60) for _ in range(S)]
+    ocnt = [cl.CountLine(sc.countline()) for sc in scenes]
+    for f in range(F):
+        frames = np.stack([sc.frame(f) for sc in scenes])
+        per = []
+        for z, sc in enumerate(scenes):
+            boxes, scores, _, _ = sc.detections(f)
+            per.append(([tuple(int(v) for v in b) for b in boxes], ['person'] * len(boxes), [float(s) for s in scores]))
+            keep = ds.non_max_suppression(boxes, 0.6, scores)
+            patches = np.stack([image_np.extract_image_patch(frames[z], boxes[i], (64, 32)) for i in keep])
+            feats = nets_torch.mars_forward(mp.enc_weights, patches)
+            otrk[z].predict()
+            otrk[z].update([ds.Det(boxes[i], 'person', scores[i], feats[j]) for j, i in enumerate(keep)])
+            ocnt[z].step(otrk[z])
+        mp.step(torch.from_numpy(frames).cuda(), mp.pack_injected(per))
+        for z in range(S):
+            ints, means = mp.tracker(z).table()
+            want = np.array([[t.track_id, t.state, t.time_since_update, t.hits, t.age] for t in otrk[z].tracks],
+                            dtype=np.int64).reshape(-1, 5)
+            np.testing.assert_array_equal(ints[:, :5], want, err_msg=f'frame {f} stream {z}')
+            if len(want):
+                np.testing.assert_allclose(means, np.array([t.mean for t in otrk[z].tracks]), rtol=1e-6, atol=1e-6)
+    got = mp.counts()
+    for z in range(S):
+        np.testing.assert_array_equal(got[z], ocnt[z].vector())
+    assert got.sum() > 0
+    assert mp.stage_ms()['steps'] == F
+
+
+def test_multistream_detector_output_matches_plugin():
+    """Without injection the C++ pipeline consumes the detector's own output: same boxes as the
+    Python plugin produces for the same frame -> same tracks after a few frames."""
+    from deepdish_amd.multipipe import MultiStreamPipeline
+    from deepdish_amd.pipeline import HotPath
+    from deepdish_amd.synth import Scene
+    from deepdish_amd.pipeline import DEFAULT_LABELS
+    wanted = sorted({l.strip() for l in open(DEFAULT_LABELS)} - {'???'})
+    sc = Scene(seed=3, n_obj=8, n_frames=6)
+    seen = 0
+    mp = MultiStreamPipeline(1, wanted_labels=wanted)
+    hp = HotPath(wanted_labels=wanted)
+    for f in range(6):
+        fr = torch.from_numpy(sc.frame(f)).cuda()
+        mp.step(fr[None])
+        hp.step(fr)
+        ints, means = mp.tracker(0).table()
+        want = np.array([[t.track_id, t.state, t.time_since_update, t.hits, t.age] for t in hp.tracker.tracks],
+                        dtype=np.int64).reshape(-1, 5)
+        np.testing.assert_array_equal(ints[:, :5], want, err_msg=f'frame {f}')
+        if len(want):
+            np.testing.assert_allclose(means, np.array([t.mean for t in hp.tracker.tracks]), rtol=1e-9, atol=1e-9)
+        seen = max(seen, len(want))
+    assert seen > 0
