@@ -109,18 +109,19 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
-    from deepdish_amd.pipeline import HotPath
+    from deepdish_amd.multipipe import MultiStreamPipeline
     from deepdish_amd.runtime import default_context
     ctx = default_context()
     n_frames = args.warmup + args.steps
     streams = make_inputs(rank, args.streams, n_frames)
-    paths = [HotPath(context=ctx) for _ in range(args.streams)]
-    dev_frames = [torch.from_numpy(fr).to(f'cuda:{local_rank}') for _, fr, _ in streams]
+    pipe = MultiStreamPipeline(args.streams, context=ctx)
+    # frames resident in HBM before the timed region: [F][S][H][W][3]
+    dev_frames = torch.from_numpy(np.stack([fr for _, fr, _ in streams], axis=1)).to(f'cuda:{local_rank}')
+    injected = [pipe.pack_injected([streams[s][2][f] for s in range(args.streams)]) for f in range(n_frames)]
     torch.cuda.synchronize()
 
     def step(f):
-        for s in range(args.streams):
-            paths[s].step(dev_frames[s][f], injected=streams[s][2][f])
+        pipe.step(dev_frames[f], injected[f])
 
     for f in range(args.warmup):
         step(f)
@@ -134,8 +135,10 @@ def main():
     if dist_on:
         dist.barrier()
     dt = time.perf_counter() - t0
+    stage_ms = pipe.stage_ms()
+    local_counts = pipe.counts().sum(axis=0)
     tmax = torch.tensor([dt], dtype=torch.float64, device=f'cuda:{local_rank}')
-    counts = torch.from_numpy(sum(p.counts() for p in paths)).to(f'cuda:{local_rank}')
+    counts = torch.from_numpy(local_counts).to(f'cuda:{local_rank}')
     if dist_on:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)      # RCCL: the only exchange step of the path
@@ -154,10 +157,11 @@ def main():
                        'parallelism': 'independent streams, %d per GPU' % args.streams,
                        'weights': 'seeded synthetic (seed 1234)'},
             'counts_pos_neg_int_del': [int(v) for v in counts.cpu().numpy().reshape(-1)],
+            'stage_ms_per_step': {k: round(v, 4) for k, v in stage_ms.items() if k != 'steps'},
         }
         try:
             from deepdish_amd.profile import dominant_kernel_roofline
-            out['roofline'] = dominant_kernel_roofline(paths, dev_frames, streams, args)
+            out['roofline'] = dominant_kernel_roofline(pipe, lambda f: step(f), args)
         except Exception as e:                            # never let the extra pass hide the headline number
             out['roofline'] = None
             out['roofline_error'] = repr(e)

@@ -51,6 +51,7 @@ SIGNATURES = {
     'dd_net_output': [P, c_int, POINTER(P), POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int),
                       POINTER(c_int)],
     'dd_net_max_batch': [P, POINTER(c_int)],
+    'dd_net_last_batch': [P, POINTER(c_int)],
     'dd_net_read': [P, c_int, c_int, P, c_int, P],
     'dd_net_profile': [P, c_int],
     'dd_net_profile_read': [P, P, c_int, POINTER(c_int)],

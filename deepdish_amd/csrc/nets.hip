@@ -11,6 +11,7 @@
 //     second affine+ELU output, SSD / YOLO head scatter) stores 8 or 16 bytes per lane,
 //   * operand tiles staged through double-buffered LDS (80-byte padded rows, ds_read_b128),
 //   * depthwise 3x3, pooling, upsampling, input conversion as 16-byte-per-lane streaming kernels.
+#include <algorithm>
 #include <cmath>
 #include <string>
 #include "common.h"
@@ -49,17 +50,103 @@ struct ConvP {
     void *out; int cs_out, coff_out, epi;
     const _Float16 *res; int cs_res, coff_res;
     _Float16 *out2; int cs_out2, coff_out2; const float *aff2; int cout_pad;
+    int post_aff;                   // EPI_F32 only: out = aff2.scale * act(v) + aff2.shift
+    int splitk; float *slab;        // splitk > 1: raw partial sums go to slab[z][m][cout_pad]
     int p[6]; float f[8];
 };
 
-constexpr int LDS_ROW = 40;        // halves per staged row: 32 data + 8 pad (80 bytes)
 
-// Block tile: (WM*MI*16) pixels x (WN*NI*16) output channels, K step 32.
-template <int WM, int WN, int MI, int NI>
+// Everything after the K reduction for channels co..co+3 of output pixel m (v = raw sums).
+__device__ __forceinline__ void conv_epilogue(const ConvP &P, int m, int co, float v[4], int hw) {
+    const f4 bv = *reinterpret_cast<const f4 *>(P.bias + co);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] += bv[r];
+    if (P.epi == EPI_YOLO) {
+        const int n = m / hw, p = m - n * hw;
+        const int py = p / P.wo, px = p - py * P.wo;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ch = co + r;
+            if (ch >= P.cout) continue;
+            const int no = P.p[0];                     // 5 + classes
+            const int an = ch / no, o = ch - an * no;
+            const float s = 1.f / (1.f + __expf(-v[r]));
+            float val = s;
+            if (o == 0) val = (s * 2.f - 0.5f + (float)px) * P.f[6] / P.f[7];
+            else if (o == 1) val = (s * 2.f - 0.5f + (float)py) * P.f[6] / (float)P.p[4];
+            else if (o == 2) val = (s * 2.f) * (s * 2.f) * P.f[2 * an] / P.f[7];
+            else if (o == 3) val = (s * 2.f) * (s * 2.f) * P.f[2 * an + 1] / (float)P.p[4];
+            const size_t row = (size_t)n * P.p[1] + P.p[2] + (size_t)an * hw + p;
+            static_cast<float *>(P.out)[row * no + o] = val;
+        }
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], P.act);
+    if (P.epi == EPI_SSD_HEAD) {                        // fused box + class predictor of one feature map:
+        const int n = m / hw, p = m - n * hw;           // channels [0, 4A) box encodings, [4A, 4A + A*C) class logits
+        const int C = P.p[0], split = P.p[4], A = P.p[5];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ch = co + r;
+            if (ch >= P.cout) continue;
+            int an, col;
+            if (ch < split) { an = ch >> 2; col = ch & 3; }
+            else { const int c2 = ch - split; an = c2 / C; col = 4 + (c2 - an * C); }
+            const size_t row = (size_t)n * P.p[1] + P.p[2] + (size_t)p * A + an;
+            static_cast<float *>(P.out)[row * P.p[3] + col] = v[r];
+        }
+        return;
+    }
+    if (P.res) {
+        const h4 rv = *reinterpret_cast<const h4 *>(P.res + (size_t)m * P.cs_res + P.coff_res + co);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+    }
+    if (P.epi == EPI_F32) {
+        if (P.post_aff) {
+            const f4 sc = *reinterpret_cast<const f4 *>(P.aff2 + co);
+            const f4 sh = *reinterpret_cast<const f4 *>(P.aff2 + P.cout_pad + co);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = sc[r] * v[r] + sh[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (co + r >= P.cout) v[r] = 0.f;
+        *reinterpret_cast<f4 *>(static_cast<float *>(P.out) + (size_t)m * P.cs_out + P.coff_out + co) = f4{v[0], v[1], v[2], v[3]};
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (co + r >= P.cout) v[r] = 0.f;
+    {
+        h4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (_Float16)v[r];
+        *reinterpret_cast<h4 *>(static_cast<_Float16 *>(P.out) + (size_t)m * P.cs_out + P.coff_out + co) = o;
+    }
+    if (P.out2) {                                   // second view: ELU(scale * raw + shift)
+        const f4 sc = *reinterpret_cast<const f4 *>(P.aff2 + co);
+        const f4 sh = *reinterpret_cast<const f4 *>(P.aff2 + P.cout_pad + co);
+        h4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float t = co + r < P.cout ? apply_act(sc[r] * v[r] + sh[r], ACT_ELU) : 0.f;
+            o[r] = (_Float16)t;
+        }
+        *reinterpret_cast<h4 *>(P.out2 + (size_t)m * P.cs_out2 + P.coff_out2 + co) = o;
+    }
+}
+
+// Block tile: (WM*MI*16) pixels x (WN*NI*16) output channels, K step BK (32 for shallow K, else 64:
+// two MFMA k-slices per barrier); blockIdx.z = K split.  Staged rows carry 8 halves of padding.
+template <int WM, int WN, int MI, int NI, int BK>
 __global__ __launch_bounds__(WM *WN * 64) void conv_mfma_k(const ConvP P) {
+    constexpr int LDS_ROW = BK + 8;
     constexpr int T = WM * WN * 64;
     constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
-    constexpr int XCH = (BM * 4 + T - 1) / T, WCH = (BN * 4 + T - 1) / T;
+    constexpr int CPR = BK / 8;                               // 16-byte chunks per staged row
+    constexpr int XCH = (BM * CPR + T - 1) / T, WCH = (BN * CPR + T - 1) / T;
     __shared__ __attribute__((aligned(16))) _Float16 lds[2 * (BM + BN) * LDS_ROW];
     _Float16 *xs = lds, *ws = lds + 2 * BM * LDS_ROW;
 
@@ -67,59 +154,63 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_mfma_k(const ConvP P) {
     const int wm = wave / WN, wn = wave % WN;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int hw = P.ho * P.wo;
+    const int ksteps = P.kpad / BK;
+    const int per = (ksteps + P.splitk - 1) / P.splitk;
+    const int ks0 = blockIdx.z * per, ks1 = min(ksteps, ks0 + per);
 
-    // per-thread staging coordinates
-    int x_row[XCH], x_kc[XCH], x_n[XCH], x_oy[XCH], x_ox[XCH];
+    // per-thread staging coordinates; (x_kh, x_kw, x_c) walk the K axis incrementally
+    int x_n[XCH], x_iy0[XCH], x_ix0[XCH], x_kh[XCH], x_kw[XCH], x_c[XCH];
     bool x_ok[XCH];
 #pragma unroll
     for (int i = 0; i < XCH; ++i) {
         const int c = tid + i * T;
-        x_row[i] = c >> 2;
-        x_kc[i] = c & 3;
-        const int m = m0 + x_row[i];
-        x_ok[i] = (c < BM * 4) && (m < P.m);
+        const int m = m0 + c / CPR;
+        x_ok[i] = (c < BM * CPR) && (m < P.m);
         const int mm = x_ok[i] ? m : 0;
         x_n[i] = mm / hw;
         const int r = mm - x_n[i] * hw;
-        x_oy[i] = r / P.wo;
-        x_ox[i] = r - x_oy[i] * P.wo;
+        const int oy = r / P.wo, ox = r - oy * P.wo;
+        x_iy0[i] = oy * P.stride - P.pad_t;
+        x_ix0[i] = ox * P.stride - P.pad_l;
+        const int k = ks0 * BK + (c % CPR) * 8;
+        const int tap = k / P.cin;
+        x_c[i] = k - tap * P.cin;
+        x_kh[i] = tap / P.kw;
+        x_kw[i] = tap - x_kh[i] * P.kw;
     }
-    const int ntaps = P.kh * P.kw;
-    const int ksteps = P.kpad >> 5;
 
     h8 xr[XCH], wr[WCH];
     auto load_step = [&](int ks) {
 #pragma unroll
         for (int i = 0; i < XCH; ++i) {
             h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (x_ok[i]) {
-                const int k = (ks << 5) + (x_kc[i] << 3);
-                const int tap = k / P.cin;
-                const int c = k - tap * P.cin;
-                const int kh = tap / P.kw, kw = tap - kh * P.kw;
-                const int iy = x_oy[i] * P.stride - P.pad_t + kh, ix = x_ox[i] * P.stride - P.pad_l + kw;
-                if (tap < ntaps && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W)
-                    v = *reinterpret_cast<const h8 *>(P.in + ((size_t)(x_n[i] * P.H + iy) * P.W + ix) * P.cs_in + P.coff_in + c);
-            }
+            const int iy = x_iy0[i] + x_kh[i], ix = x_ix0[i] + x_kw[i];
+            if (x_ok[i] && x_kh[i] < P.kh && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W)
+                v = *reinterpret_cast<const h8 *>(P.in + ((size_t)(x_n[i] * P.H + iy) * P.W + ix) * P.cs_in + P.coff_in + x_c[i]);
             xr[i] = v;
+            x_c[i] += BK;                                     // advance to the next K step
+            while (x_c[i] >= P.cin) {
+                x_c[i] -= P.cin;
+                if (++x_kw[i] == P.kw) { x_kw[i] = 0; ++x_kh[i]; }
+            }
         }
 #pragma unroll
         for (int i = 0; i < WCH; ++i) {
             const int c = tid + i * T;
-            if (c < BN * 4)
-                wr[i] = *reinterpret_cast<const h8 *>(P.w + (size_t)(n0 + (c >> 2)) * P.kpad + (ks << 5) + ((c & 3) << 3));
+            if (c < BN * CPR)
+                wr[i] = *reinterpret_cast<const h8 *>(P.w + (size_t)(n0 + c / CPR) * P.kpad + ks * BK + (c % CPR) * 8);
         }
     };
     auto store_step = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < XCH; ++i) {
             const int c = tid + i * T;
-            if (c < BM * 4) *reinterpret_cast<h8 *>(xs + (buf * BM + (c >> 2)) * LDS_ROW + ((c & 3) << 3)) = xr[i];
+            if (c < BM * CPR) *reinterpret_cast<h8 *>(xs + (buf * BM + c / CPR) * LDS_ROW + (c % CPR) * 8) = xr[i];
         }
 #pragma unroll
         for (int i = 0; i < WCH; ++i) {
             const int c = tid + i * T;
-            if (c < BN * 4) *reinterpret_cast<h8 *>(ws + (buf * BN + (c >> 2)) * LDS_ROW + ((c & 3) << 3)) = wr[i];
+            if (c < BN * CPR) *reinterpret_cast<h8 *>(ws + (buf * BN + c / CPR) * LDS_ROW + (c % CPR) * 8) = wr[i];
         }
     };
 
@@ -129,30 +220,35 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_mfma_k(const ConvP P) {
 #pragma unroll
         for (int b = 0; b < MI; ++b) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
 
-    load_step(0);
-    store_step(0);
-    __syncthreads();
     const int fr = lane & 15, fq = lane >> 4;
-    for (int ks = 0; ks < ksteps; ++ks) {
-        const int buf = ks & 1;
-        if (ks + 1 < ksteps) load_step(ks + 1);              // global loads in flight under the MFMAs
-        h8 xf[MI], wf[NI];
-#pragma unroll
-        for (int b = 0; b < MI; ++b)
-            xf[b] = *reinterpret_cast<const h8 *>(xs + (buf * BM + (wm * MI + b) * 16 + fr) * LDS_ROW + (fq << 3));
-#pragma unroll
-        for (int a = 0; a < NI; ++a)
-            wf[a] = *reinterpret_cast<const h8 *>(ws + (buf * BN + (wn * NI + a) * 16 + fr) * LDS_ROW + (fq << 3));
-#pragma unroll
-        for (int a = 0; a < NI; ++a)
-#pragma unroll
-            for (int b = 0; b < MI; ++b)
-                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[a], xf[b], acc[a][b], 0, 0, 0);
-        if (ks + 1 < ksteps) store_step(buf ^ 1);
+    if (ks0 < ks1) {
+        load_step(ks0);
+        store_step(0);
         __syncthreads();
+        for (int ks = ks0; ks < ks1; ++ks) {
+            const int buf = (ks - ks0) & 1;
+            if (ks + 1 < ks1) load_step(ks + 1);              // global loads in flight under the MFMAs
+#pragma unroll
+            for (int kk = 0; kk < BK / 32; ++kk) {
+                h8 xf[MI], wf[NI];
+#pragma unroll
+                for (int b = 0; b < MI; ++b)
+                    xf[b] = *reinterpret_cast<const h8 *>(xs + (buf * BM + (wm * MI + b) * 16 + fr) * LDS_ROW + kk * 32 + (fq << 3));
+#pragma unroll
+                for (int a = 0; a < NI; ++a)
+                    wf[a] = *reinterpret_cast<const h8 *>(ws + (buf * BN + (wn * NI + a) * 16 + fr) * LDS_ROW + kk * 32 + (fq << 3));
+#pragma unroll
+                for (int a = 0; a < NI; ++a)
+#pragma unroll
+                    for (int b = 0; b < MI; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[a], xf[b], acc[a][b], 0, 0, 0);
+            }
+            if (ks + 1 < ks1) store_step(buf ^ 1);
+            __syncthreads();
+        }
     }
 
-    // ---- fused epilogue: lane holds channels co..co+3 of pixel m
+    // ---- lane holds channels co..co+3 of pixel m
 #pragma unroll
     for (int b = 0; b < MI; ++b) {
         const int m = m0 + (wm * MI + b) * 16 + fr;
@@ -161,75 +257,29 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_mfma_k(const ConvP P) {
         for (int a = 0; a < NI; ++a) {
             const int co = n0 + (wn * NI + a) * 16 + fq * 4;
             if (co >= P.cout_pad) continue;
-            const f4 bv = *reinterpret_cast<const f4 *>(P.bias + co);
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r] + bv[r];
-            if (P.epi == EPI_YOLO) {
-                const int n = m / hw, p = m - n * hw;
-                const int py = p / P.wo, px = p - py * P.wo;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int ch = co + r;
-                    if (ch >= P.cout) continue;
-                    const int no = P.p[0];                     // 5 + classes
-                    const int an = ch / no, o = ch - an * no;
-                    const float s = 1.f / (1.f + __expf(-v[r]));
-                    float val = s;
-                    if (o == 0) val = (s * 2.f - 0.5f + (float)px) * P.f[6] / P.f[7];
-                    else if (o == 1) val = (s * 2.f - 0.5f + (float)py) * P.f[6] / (float)P.p[4];
-                    else if (o == 2) val = (s * 2.f) * (s * 2.f) * P.f[2 * an] / P.f[7];
-                    else if (o == 3) val = (s * 2.f) * (s * 2.f) * P.f[2 * an + 1] / (float)P.p[4];
-                    const size_t row = (size_t)n * P.p[1] + P.p[2] + (size_t)an * hw + p;
-                    static_cast<float *>(P.out)[row * no + o] = val;
-                }
-                continue;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], P.act);
-            if (P.epi == EPI_SSD_HEAD) {
-                const int n = m / hw, p = m - n * hw;
-                const int g = P.p[0], A = P.p[5];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int ch = co + r;
-                    if (ch >= P.cout) continue;
-                    const int an = ch / g, kk = ch - an * g;
-                    const size_t row = (size_t)n * P.p[1] + P.p[2] + (size_t)p * A + an;
-                    static_cast<float *>(P.out)[row * P.p[3] + P.p[4] + kk] = v[r];
-                }
-                continue;
-            }
-            if (P.res) {
-                const h4 rv = *reinterpret_cast<const h4 *>(P.res + (size_t)m * P.cs_res + P.coff_res + co);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (co + r >= P.cout) v[r] = 0.f;
-            if (P.epi == EPI_F32) {
-                *reinterpret_cast<f4 *>(static_cast<float *>(P.out) + (size_t)m * P.cs_out + P.coff_out + co) =
-                    f4{v[0], v[1], v[2], v[3]};
+            if (P.splitk > 1) {
+                *reinterpret_cast<f4 *>(P.slab + ((size_t)blockIdx.z * P.m + m) * P.cout_pad + co) = acc[a][b];
             } else {
-                h4 o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (_Float16)v[r];
-                *reinterpret_cast<h4 *>(static_cast<_Float16 *>(P.out) + (size_t)m * P.cs_out + P.coff_out + co) = o;
-            }
-            if (P.out2) {                                   // second view: ELU(scale * raw + shift)
-                const f4 sc = *reinterpret_cast<const f4 *>(P.aff2 + co);
-                const f4 sh = *reinterpret_cast<const f4 *>(P.aff2 + P.cout_pad + co);
-                h4 o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float t = co + r < P.cout ? apply_act(sc[r] * v[r] + sh[r], ACT_ELU) : 0.f;
-                    o[r] = (_Float16)t;
-                }
-                *reinterpret_cast<h4 *>(P.out2 + (size_t)m * P.cs_out2 + P.coff_out2 + co) = o;
+                float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
+                conv_epilogue(P, m, co, v, hw);
             }
         }
     }
+}
+
+// Split-K tail: sum the partial slabs in a fixed order (bitwise reproducible) and run the epilogue.
+__global__ __launch_bounds__(256) void conv_splitk_finish_k(const ConvP P) {
+    const int groups = P.cout_pad >> 2;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)P.m * groups) return;
+    const int m = (int)(idx / groups), co = (int)(idx % groups) * 4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < P.splitk; ++z) {
+        const f4 s = *reinterpret_cast<const f4 *>(P.slab + ((size_t)z * P.m + m) * P.cout_pad + co);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += s[r];
+    }
+    conv_epilogue(P, m, co, v, P.ho * P.wo);
 }
 
 // Depthwise 3x3: one lane per (pixel, 8-channel group); weights [3][3][C] f16, bias f32 [C].
@@ -440,6 +490,8 @@ struct dd_net {
     int64_t weight_bytes = 0;
     int in_h = 0, in_w = 0, out_tensor = -1;
     bool profile = false;
+    int last_batch = 0;
+    DevBuf slab;                             // split-K partial sums
     std::vector<hipEvent_t> events;           // n_ops + 1 when profiling
 };
 
@@ -447,12 +499,36 @@ namespace {
 
 inline size_t dtype_size(int dt) { return dt == DT_F16 ? 2 : (dt == DT_F32 ? 4 : 1); }
 
-template <int WM, int WN, int MI, int NI>
-int launch_conv(hipStream_t s, const ConvP &P) {
+// Few blocks and a long K axis: split K over blockIdx.z so the chip is busy and each block's serial
+// chain of (load -> barrier -> MFMA) steps is short; partial sums go through an f32 slab.
+template <int WM, int WN, int MI, int NI, int BK>
+int launch_conv(hipStream_t s, ConvP &P, DevBuf &slab) {
     constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
-    dim3 grid(dd_ceil_div(P.m, BM), dd_ceil_div(P.cout_pad, BN));
-    hipLaunchKernelGGL((conv_mfma_k<WM, WN, MI, NI>), grid, dim3(WM * WN * 64), 0, s, P);
+    const int gx = dd_ceil_div(P.m, BM), gy = dd_ceil_div(P.cout_pad, BN);
+    const int ksteps = P.kpad / BK;
+    // The split depends on the layer shape only, never on the batch: every output element is then
+    // summed in the same order whatever else shares the launch (streams stay independent).
+    int splitk = 1;
+    const int blocks_per_image = dd_ceil_div(P.ho * P.wo, BM) * gy;
+    if (blocks_per_image <= 8 && ksteps >= 8) {
+        splitk = std::min(16, ksteps / 4);
+        const int per = dd_ceil_div(ksteps, splitk);
+        splitk = dd_ceil_div(ksteps, per);                    // no empty split
+    }
+    P.splitk = splitk;
+    P.slab = nullptr;
+    if (splitk > 1) {
+        int rc = slab.reserve((size_t)splitk * P.m * P.cout_pad * sizeof(float));
+        if (rc != DD_OK) return rc;
+        P.slab = slab.as<float>();
+    }
+    hipLaunchKernelGGL((conv_mfma_k<WM, WN, MI, NI, BK>), dim3(gx, gy, splitk), dim3(WM * WN * 64), 0, s, P);
     DD_LAUNCH_CHECK();
+    if (splitk > 1) {
+        const long long total = (long long)P.m * (P.cout_pad >> 2);
+        hipLaunchKernelGGL(conv_splitk_finish_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, P);
+        DD_LAUNCH_CHECK();
+    }
     return DD_OK;
 }
 
@@ -502,8 +578,15 @@ int dd_net_destroy(dd_net *n) {
     if (!n) return DD_OK;
     for (void *b : n->bufs) (void)hipFree(b);
     for (hipEvent_t e : n->events) (void)hipEventDestroy(e);
+    n->slab.release();
     (void)hipFree(n->d_weights);
     delete n;
+    return DD_OK;
+}
+
+int dd_net_last_batch(dd_net *n, int *out_host) {
+    DD_REQUIRE(n && out_host, DD_E_ARG, "dd_net_last_batch: NULL argument");
+    *out_host = n->last_batch;
     return DD_OK;
 }
 
@@ -566,6 +649,7 @@ int dd_net_forward(dd_net *net, const uint8_t *input, int nimg, void *stream) {
     DD_REQUIRE(net && input && nimg >= 0, DD_E_ARG, "dd_net_forward: bad argument");
     DD_REQUIRE(nimg <= net->max_batch, DD_E_CAPACITY, "dd_net_forward: batch %d > max_batch %d", nimg, net->max_batch);
     if (nimg == 0) return DD_OK;
+    net->last_batch = nimg;
     hipStream_t s = dd_pick_stream(net->ctx, stream);
     auto base = [&](int t) -> char * {
         const TensorDesc &d = net->tensors[t];
@@ -607,11 +691,16 @@ int dd_net_forward(dd_net *net, const uint8_t *input, int nimg, void *stream) {
                     P.out2 = reinterpret_cast<_Float16 *>(base(dst2)); P.cs_out2 = t2.cs; P.coff_out2 = t2.coff;
                     P.aff2 = reinterpret_cast<const float *>(net->d_weights + (size_t)(uint32_t)o[18]);
                 }
+                if (dst2 < 0 && o[19]) {                       // EPI_F32 with a post-activation affine (MARS fc1 + "ball")
+                    P.aff2 = reinterpret_cast<const float *>(net->d_weights + (size_t)(uint32_t)o[18]);
+                    P.post_aff = 1;
+                }
                 for (int q = 0; q < 6; ++q) P.p[q] = o[20 + q];
                 for (int q = 0; q < 8; ++q) P.f[q] = of[32 + q];
                 int rc;
-                if (P.cout_pad <= 32) rc = launch_conv<4, 1, 1, 2>(s, P);
-                else rc = launch_conv<2, 2, 2, 2>(s, P);
+                const bool bk32 = o[28] == 32;                 // shallow K (<= 96): one or few 32-wide steps
+                if (P.cout_pad <= 32) rc = bk32 ? launch_conv<4, 1, 1, 2, 32>(s, P, net->slab) : launch_conv<4, 1, 1, 2, 64>(s, P, net->slab);
+                else rc = bk32 ? launch_conv<2, 2, 2, 2, 32>(s, P, net->slab) : launch_conv<2, 2, 2, 2, 64>(s, P, net->slab);
                 if (rc != DD_OK) return rc;
                 break;
             }

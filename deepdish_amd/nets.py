@@ -79,7 +79,7 @@ class Program:
         f = w.view(np.float32)
         w[0:5] = (kind, src, dst, res, dst2)
         names = dict(kh=5, kw=6, stride=7, pad_t=8, pad_l=9, cin=10, cout=11, cout_pad=12, kpad=13, act=14, epi=15,
-                     w_off=16, b_off=17, aff_off=18, has_aff=19, ho=26, wo=27)
+                     w_off=16, b_off=17, aff_off=18, has_aff=19, ho=26, wo=27, bk=28)
         for k, v in kw.items():
             if k == 'p':
                 w[20:20 + len(v)] = v
@@ -115,7 +115,8 @@ class Program:
             assert (ho, wo) == tuple(out_hw), ((ho, wo), out_hw)
         cout_pad = rup(cout, 8)
         rows = 32 if cout_pad <= 32 else rup(cout_pad, 64)
-        kpad = rup(kh * kw * cin_pad, 32)
+        bk = 32 if kh * kw * cin_pad <= 96 else 64
+        kpad = rup(kh * kw * cin_pad, bk)
         wp = np.zeros((rows, kh * kw, cin_pad), dtype=np.float16)
         wp[:cout, :, :cin] = np.transpose(w_hwio, (3, 0, 1, 2)).reshape(cout, kh * kw, cin).astype(np.float16)
         wflat = np.zeros((rows, kpad), dtype=np.float16)
@@ -129,14 +130,14 @@ class Program:
             assert (d['h'], d['w']) == (ho, wo) and d['c'] == cout, (d, ho, wo, cout)
         kw_ = dict(kh=kh, kw=kw, stride=stride, pad_t=pt, pad_l=pl, cin=cin_pad, cout=cout, cout_pad=cout_pad,
                    kpad=kpad, act=act, epi=epi, w_off=self.add_blob(wflat), b_off=self.add_blob(bp), p=list(p), f=list(f),
-                   ho=ho, wo=wo)
+                   ho=ho, wo=wo, bk=bk)
         if dst2 >= 0:
             a = np.zeros((2, cout_pad), dtype=np.float32)
             a[0, :cout], a[1, :cout] = aff2
             kw_['aff_off'] = self.add_blob(a)
             kw_['has_aff'] = 1
         self._op(OP_CONV, src=src, dst=dst, res=res, dst2=dst2, **kw_)
-        self.info[-1] = dict(kernel='conv_mfma_k<4,1,1,2>' if cout_pad <= 32 else 'conv_mfma_k<2,2,2,2>',
+        self.info[-1] = dict(kernel=('conv_mfma_k<4,1,1,2,%d>' if cout_pad <= 32 else 'conv_mfma_k<2,2,2,2,%d>') % bk,
                              flops=2 * ho * wo * kh * kw * cin * cout,
                              bytes=2 * (s['h'] * s['w'] * cin + kh * kw * cin * cout) + (4 if epi != EPI_F16 else 2) * ho * wo * cout
                              + (2 * ho * wo * cout if res >= 0 else 0) + (2 * ho * wo * cout if dst2 >= 0 else 0))
@@ -180,19 +181,21 @@ class Program:
         return dst
 
     def fc(self, src, w_io, bias, act, aff2=None):
-        """src f16 [h,w,c] flattened in NHWC order; w_io [K, Cout]; out f32 [Cout]."""
+        """Fully connected layer on the NHWC-flattened source, run as a 1x1 conv over a [1,1,K] view
+        (M = images, split-K in the launcher): out f32 [Cout] = aff2(act(x.w + b))."""
         s = self.T(src)
         assert s['cs'] == s['c'] and s['coff'] == 0
         k, cout = w_io.shape
         assert k == s['h'] * s['w'] * s['c'] and k % 8 == 0
-        dst = self.tensor(1, 1, cout, cs=cout, dtype=DT_F32)
-        kw_ = dict(cout=cout, act=act, w_off=self.add_blob(np.ascontiguousarray(w_io.T).astype(np.float16)),
-                   b_off=self.add_blob(bias.astype(np.float32)))
+        flat = self.tensor(1, 1, k, cs=k, buf=s['buf'])
+        dst = self.tensor(1, 1, cout, cs=rup(cout, 8), dtype=DT_F32)
+        self.conv(flat, w_io.reshape(1, 1, k, cout), bias, act=act, dst=dst, epi=EPI_F32)
         if aff2 is not None:
-            kw_['aff_off'] = self.add_blob(np.stack(aff2).astype(np.float32))
-            kw_['has_aff'] = 1
-        self._op(OP_FC, src=src, dst=dst, **kw_)
-        self.info[-1] = dict(kernel='fc_k', flops=2 * k * cout, bytes=2 * k + 2 * k * cout + 4 * cout)
+            op = self.ops[-1]
+            a = np.zeros((2, rup(cout, 8)), dtype=np.float32)
+            a[0, :cout], a[1, :cout] = aff2
+            op[18] = self.add_blob(a)
+            op[19] = 1
         return dst
 
     def l2norm(self, src, eps):
@@ -394,9 +397,9 @@ def compile_ssd_mobilenet(wd, in_size=300):
     for k, (ft, a) in enumerate(zip(feats, SSD_ANCHORS_PER_MAP)):
         fm = P.T(ft)['h']
         assert fm == maps[k]
-        P.conv(ft, wd[f'box{k}/weights'], wd[f'box{k}/biases'], dst=out, epi=EPI_SSD_HEAD, p=[4, n_anchors, base, ld, 0, a])
-        P.conv(ft, wd[f'cls{k}/weights'], wd[f'cls{k}/biases'], dst=out, epi=EPI_SSD_HEAD,
-               p=[SSD_CLASSES, n_anchors, base, ld, 4, a])
+        w = np.concatenate([wd[f'box{k}/weights'], wd[f'cls{k}/weights']], axis=3)      # one launch per feature map
+        b = np.concatenate([wd[f'box{k}/biases'], wd[f'cls{k}/biases']])
+        P.conv(ft, w, b, dst=out, epi=EPI_SSD_HEAD, p=[SSD_CLASSES, n_anchors, base, ld, 4 * a, a])
         base += fm * fm * a
     assert base == n_anchors
     P.out_tensor = out

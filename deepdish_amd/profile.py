@@ -10,6 +10,12 @@ PEAK_F16_TFLOPS = 2500.0       # MI355X_MICROARCH.md: Peak BF16/FP16 MFMA ~2.5 P
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak BW 8.0 TB/s spec
 
 
+def last_batch(net):
+    n = ctypes.c_int()
+    check(lib().dd_net_last_batch(net._h, ctypes.byref(n)), 'dd_net_last_batch')
+    return n.value
+
+
 def net_op_times(net):
     n = len(net.program.ops)
     ms = np.zeros(n, dtype=np.float32)
@@ -43,21 +49,19 @@ def profile_nets(run_once, nets_with_batch, reps=20):
     return acc
 
 
-def dominant_kernel_roofline(paths, dev_frames, streams, args):
-    """Extra instrumented pass after the timed region (events add a record per op, so it is kept out
-    of `value`)."""
+def dominant_kernel_roofline(pipe, step, args):
+    """Extra instrumented pass after the timed region (an event pair per op, so it is kept out of
+    `value`): per-op HIP events on the launch stream for the detector and encoder programs."""
     f0 = args.warmup
     state = dict(f=f0)
 
     def run_once():
-        f = state['f']
-        for s in range(len(paths)):
-            paths[s].step(dev_frames[s][f], injected=streams[s][2][f])
-        state['f'] = f0 + (f + 1 - f0) % max(1, args.steps)
+        step(state['f'])
+        state['f'] = f0 + (state['f'] + 1 - f0) % max(1, args.steps)
 
-    p = paths[-1]            # per-op events record the LAST forward of each net in a step
-    nets = [('ssd', p.object_detector.ssdm.net, 1),
-            ('mars', p.encoder.image_encoder.net, lambda: p.encoder.image_encoder.net._last_n)]
+    nets = [('mars', pipe.enc, lambda: last_batch(pipe.enc))]
+    if pipe.det is not None:
+        nets.append(('ssd', pipe.det, pipe.S))
     acc = profile_nets(run_once, nets)
     name, k = max(acc.items(), key=lambda kv: kv[1]['ms'])
     sec = k['ms'] * 1e-3

@@ -162,6 +162,7 @@ int dd_net_output(dd_net *net, int tensor, void **dev_ptr_host, int *h_host, int
                   int *cs_host, int *dtype_host);
 
 int dd_net_max_batch(dd_net *net, int *out_host);
+int dd_net_last_batch(dd_net *net, int *out_host);   /* images in the most recent forward */
 /* Copy the first n images of a (whole, un-sliced) tensor to caller memory: n*h*w*cs elements. */
 int dd_net_read(dd_net *net, int tensor, int n, void *dst, int dst_on_device, void *stream);
 

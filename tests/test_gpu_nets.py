@@ -36,9 +36,11 @@ def test_mars_forward_vs_oracle(mars):
     cos32 = 1.0 - np.sum(got * want32, axis=1)
     assert np.abs(got - want16).max() < 5e-3, np.abs(got - want16).max()
     assert cos16.max() < 2e-4 and cos32.max() < 5e-4, (cos16.max(), cos32.max())
-    # batch independence + determinism
+    # batch independence (split-K is chosen per layer shape, never per batch) + determinism
     net.forward(x[5:6])
     np.testing.assert_array_equal(net.read()[:, 0, 0, :], got[5:6])
+    net.forward(x)
+    np.testing.assert_array_equal(net.read()[:, 0, 0, :], got)
 
 
 def test_mars_intermediate_layers(mars):
