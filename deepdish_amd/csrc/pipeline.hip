@@ -15,10 +15,13 @@
 
 struct dd_tracker;
 namespace ddk {
-int tracker_predict_async(dd_tracker *t);
-int tracker_update_begin(dd_tracker *t, const double *tlwh_host, const float *feats, int feats_on_device, int n);
-int tracker_update_match(dd_tracker *t);
-int tracker_update_end(dd_tracker *t);
+int tracker_group_create(dd_ctx *ctx, int n, double max_cos, double max_iou, int max_age, int n_init, int budget, int tcap,
+                         int gcap, dd_tracker **out);
+int trackers_predict(dd_tracker **ts, int S);
+int trackers_update_begin(dd_tracker **ts, int S, const double *tlwh_host, const float *feats, int feats_on_device,
+                          const int *det_off);
+int trackers_update_match(dd_tracker **ts, int S);
+int trackers_update_end(dd_tracker **ts, int S);
 }
 extern "C" int dd_net_max_batch(dd_net *net, int *out_host);
 
@@ -140,6 +143,7 @@ struct dd_pipeline {
     std::vector<std::string> labels;           // label file lines (index = class id + 1, ssd_mobilenet.py:142-147)
     std::vector<std::string> wanted;
     std::vector<StreamState> st;
+    std::vector<dd_tracker *> trks;
     DevBuf d_resized, d_tmp, d_post, d_det, d_fin, d_nms, d_crop, d_patches, d_feats;
     PinBuf h_fin, h_nms, h_crop;
     int crop_cap = 0;
@@ -230,10 +234,12 @@ int dd_pipeline_create(dd_ctx *ctx, int n_streams, int frame_h, int frame_w, dd_
         if ((rc = p->h_fin.reserve(S * (MAX_DET * (4 * 8 + 4 + 8) + 4) + 256)) != DD_OK) return rc;
     }
     p->st.resize(n_streams);
-    for (auto &s : p->st) {
-        if ((rc = dd_tracker_create(ctx, max_cosine_distance, max_iou_distance, max_age, n_init, 0, track_capacity,
-                                    gallery_capacity, &s.trk)) != DD_OK) return rc;
-        s.counts.assign(p->wanted.size() * 4, 0);
+    p->trks.resize(n_streams);
+    if ((rc = ddk::tracker_group_create(ctx, n_streams, max_cosine_distance, max_iou_distance, max_age, n_init, 0,
+                                        track_capacity, gallery_capacity, p->trks.data())) != DD_OK) return rc;
+    for (int z = 0; z < n_streams; ++z) {
+        p->st[z].trk = p->trks[z];
+        p->st[z].counts.assign(p->wanted.size() * 4, 0);
     }
     *out = p;
     return DD_OK;
@@ -279,8 +285,7 @@ int dd_pipeline_step(dd_pipeline *p, const uint8_t *frames, const double *inj_bo
     const int S = p->S;
     int rc;
     const double t0 = now_s();
-    for (auto &st : p->st)
-        if ((rc = ddk::tracker_predict_async(st.trk)) != DD_OK) return rc;              // deepdish.py:1028
+    if ((rc = ddk::trackers_predict(p->trks.data(), S)) != DD_OK) return rc;            // deepdish.py:1028
 
     // ---------------- detector: resize -> forward -> post-process -> adaptor tail, all streams at once
     std::vector<std::vector<double>> boxes0(S);      // per stream: tlwh f64 rows
@@ -426,19 +431,16 @@ int dd_pipeline_step(dd_pipeline *p, const uint8_t *frames, const double *inj_bo
     const double t3 = now_s();
 
     // ---------------- deep_sort update, phase-split so all streams share two round trips (:1029)
-    for (int z = 0; z < S; ++z)
-        if ((rc = ddk::tracker_update_begin(p->st[z].trk, tlwh.data() + (size_t)doff[z] * 4,
-                                            D ? p->d_feats.as<float>() + (size_t)doff[z] * 128 : nullptr, 1,
-                                            doff[z + 1] - doff[z])) != DD_OK) return rc;
+    if ((rc = ddk::trackers_update_begin(p->trks.data(), S, tlwh.data(), D ? p->d_feats.as<float>() : nullptr, 1,
+                                         doff.data())) != DD_OK) return rc;
     DD_HIP(hipStreamSynchronize(s));                                                                   // round trip 3
-    for (int z = 0; z < S; ++z)
-        if ((rc = ddk::tracker_update_match(p->st[z].trk)) != DD_OK) return rc;
+    if ((rc = ddk::trackers_update_match(p->trks.data(), S)) != DD_OK) return rc;
     DD_HIP(hipStreamSynchronize(s));                                                                   // round trip 4
+    if ((rc = ddk::trackers_update_end(p->trks.data(), S)) != DD_OK) return rc;
     std::vector<int64_t> ints;
     std::vector<double> means;
     for (int z = 0; z < S; ++z) {
         StreamState &st = p->st[z];
-        if ((rc = ddk::tracker_update_end(st.trk)) != DD_OK) return rc;
         // ---------------- count line (deepdish.py:1035-1114, 1303-1312)
         int nd = 0, nl = 0;
         dd_tracker_count(st.trk, 1, &nd);

@@ -4,15 +4,20 @@
 // deep_sort/linear_assignment.py:11-190, deep_sort/nn_matching.py:137-177,
 // deep_sort/iou_matching.py:42-81.
 //
-// Per frame the device does two launches and the host two small round trips:
-//   predict : 1 kernel over all live tracks
-//   update  : K1 "assoc"  -- for every (track row, detection): gated cosine NN cost (exact-f32
-//                            MFMA + f64 Mahalanobis gate) and the IoU cost, ALL cascade levels at
-//                            once (the cost of a pair does not depend on the level);
-//             host        -- matching cascade + LSAP on the tiny cost matrices (integer outputs);
-//             K2 "apply"  -- Kalman update / initiate + gallery append for the decided pairs.
+// Trackers are driven in GROUPS (one tracker per video stream; a stand-alone dd_tracker is a group
+// of one): per step the device does a handful of launches for ALL streams together and the host
+// two round trips:
+//   predict : 1 kernel over every live track of every stream
+//   update  : normalise all detection features (1 launch);
+//             K1 "assoc"  -- for every (track row, detection of the SAME stream): gated cosine NN cost
+//                            (exact-f32 MFMA + f64 Mahalanobis gate) and the IoU cost, ALL cascade
+//                            levels at once (the cost of a pair does not depend on the level);
+//             host        -- per stream: matching cascade + LSAP on the small cost matrices;
+//             K2 "apply"  -- Kalman update / initiate + gallery append for the decided pairs;
+//             gather      -- means of all live / just-deleted tracks back to the host.
 // Layout: means[slot][8] f64, covs[slot][64] f64, gallery[slot][gcap][128] f32 (rows already
-// L2-normalised, ring buffer), one slot per track, slots recycled through a free list.
+// L2-normalised, ring buffer); a stream owns the slot range [slot_base, slot_base + tcap) of a pool,
+// slots recycled through a per-stream free list.
 #include <algorithm>
 #include <numeric>
 #include "common.h"
@@ -35,26 +40,31 @@ __device__ __forceinline__ void tlwh_to_xyah(const double *b, double z[4]) {
     z[3] = b[3];
 }
 
-// grid (n_rows, ceil(n_det/64)); 4 waves, 16 detections per wave.
+// grid (R rows of all streams, ceil(max n_det / 64)); 4 waves, 16 detections per wave.  Row r belongs to
+// one stream and sees only that stream's detections [det_off, det_off + n_det).
 __global__ __launch_bounds__(256) void tracker_assoc_k(
     const double *__restrict__ means, const double *__restrict__ covs, const float *__restrict__ gallery,
     int gcap, const int *__restrict__ row_slot, const int *__restrict__ row_state, const int *__restrict__ row_tsu,
-    const int *__restrict__ gal_count, const double *__restrict__ det_tlwh, const float *__restrict__ feats_n,
-    int n_det, double *__restrict__ cost_app, double *__restrict__ cost_iou) {
+    const int *__restrict__ row_det_off, const int *__restrict__ row_ndet, const int *__restrict__ row_cost_off,
+    const int *__restrict__ row_iou_delta, const int *__restrict__ gal_count, const double *__restrict__ det_tlwh,
+    const float *__restrict__ feats_n, double *__restrict__ cost) {
     const int row = blockIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n_det = row_ndet[row];
     const int d0 = blockIdx.y * 64 + wave * 16;
     if (d0 >= n_det) return;                                  // wave-uniform
     const int slot = row_slot[row];
+    const int det_off = row_det_off[row];
     const bool confirmed = row_state[row] == CONFIRMED;
     float best = 0.f;
     if (confirmed)                                            // wave-uniform branch around the MFMAs
-        best = nn_max_dot(gallery + (size_t)slot * gcap * 128, gal_count[slot], feats_n, d0, n_det, lane);
+        best = nn_max_dot(gallery + (size_t)slot * gcap * 128, gal_count[slot], feats_n + (size_t)det_off * 128, d0,
+                          n_det, lane);
     const int d = d0 + (lane & 15);
     if ((lane >> 4) != 0 || d >= n_det) return;
     const double *m = means + (size_t)slot * 8;
-    const double *b = det_tlwh + (size_t)d * 4;
-    const size_t o = (size_t)row * n_det + d;
+    const double *b = det_tlwh + (size_t)(det_off + d) * 4;
+    const size_t o = (size_t)row_cost_off[row] + d;
     if (confirmed) {
         double S[16], z[4];
         innovation_cov(covs + (size_t)slot * 64, m[3], S);
@@ -62,7 +72,7 @@ __global__ __launch_bounds__(256) void tracker_assoc_k(
         tlwh_to_xyah(b, z);
         const double mm[4] = {m[0], m[1], m[2], m[3]};
         const double d2 = maha2(c, mm, z, 0);
-        cost_app[o] = d2 > GATE_4DOF ? INFTY_COST : (double)(1.0f - best);   // linear_assignment.py:181-189
+        cost[o] = d2 > GATE_4DOF ? INFTY_COST : (double)(1.0f - best);   // linear_assignment.py:181-189
     }
     double ci = INFTY_COST;                                   // iou_matching.py:74-76
     if (row_tsu[row] <= 1) {
@@ -73,19 +83,19 @@ __global__ __launch_bounds__(256) void tracker_assoc_k(
         t[1] = m[1] - t[3] / 2;
         ci = 1.0 - iou_tlwh(t, b);
     }
-    cost_iou[o] = ci;
+    cost[o + row_iou_delta[row]] = ci;
 }
 
 // One wave per decided pair: [0, n_upd) Kalman update + gallery append; [n_upd, n_upd+n_new) new track.
 __global__ __launch_bounds__(256) void tracker_apply_k(
-    double *__restrict__ means, double *__restrict__ covs, float *__restrict__ gallery, int gcap, int cap_eff,
+    double *__restrict__ means, double *__restrict__ covs, float *__restrict__ gallery, int gcap,
     int *__restrict__ gal_count, int *__restrict__ gal_total, const int *__restrict__ pair_slot,
-    const int *__restrict__ pair_det, int n_upd, int n_new, const double *__restrict__ det_tlwh,
-    const float *__restrict__ feats_n) {
+    const int *__restrict__ pair_det, const int *__restrict__ pair_cap, int n_upd, int n_new,
+    const double *__restrict__ det_tlwh, const float *__restrict__ feats_n) {
     const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (w >= n_upd + n_new) return;
-    const int slot = pair_slot[w], det = pair_det[w];
+    const int slot = pair_slot[w], det = pair_det[w], cap_eff = pair_cap[w];
     double z[4];
     tlwh_to_xyah(det_tlwh + (size_t)det * 4, z);
     double *P = covs + (size_t)slot * 64, *m = means + (size_t)slot * 8;
@@ -108,29 +118,39 @@ __global__ __launch_bounds__(256) void tracker_apply_k(
 
 struct TrackRec {
     int64_t id;
-    int state, tsu, hits, age, slot, last_det;
+    int state, tsu, hits, age, slot, last_det;           // slot is pool-global
 };
 
 }  // namespace
 
-struct dd_tracker {
+// Device state shared by the trackers of one group + the group's staging buffers.
+struct TrackerPool {
     dd_ctx *ctx = nullptr;
-    double max_cos = 0.2, max_iou = 0.7;
-    int max_age = 30, n_init = 3, budget = 0, tcap = 0, gcap = 0;
+    int slots = 0, gcap = 0, refs = 0;
     double *d_means = nullptr, *d_covs = nullptr;
     float *d_gallery = nullptr;
     int *d_gal_count = nullptr, *d_gal_total = nullptr;
-    DevBuf d_stage, d_pred, d_feats_raw, d_feats_n, d_cost, d_gather;
-    PinBuf h_stage, h_pred, h_cost, h_gather;
-    // state carried between the phases of one update (begin -> match -> end)
-    int ph_n = 0, ph_T = 0, ph_ng = 0, ph_nl = 0;
-    size_t ph_off_pairs = 0;
-    bool ph_have_cost = false, pred_inflight = false;
+    DevBuf d_pred, d_in, d_feats_raw, d_feats_n, d_cost, d_pairs, d_gather;
+    PinBuf h_pred, h_in, h_cost, h_pairs, h_gather;
+    bool pred_inflight = false;
+    // phase state of the current group update
+    std::vector<dd_tracker *> cur;
+    std::vector<int> det_off, cost_base;
+    int D = 0, R = 0, ng = 0;
+    bool have_cost = false;
+};
+
+struct dd_tracker {
+    TrackerPool *pool = nullptr;
+    int slot_base = 0;
+    double max_cos = 0.2, max_iou = 0.7;
+    int max_age = 30, n_init = 3, budget = 0, tcap = 0;
     std::vector<TrackRec> tracks, deleted;
     std::vector<int> free_slots, pending_free;
     std::vector<double> live_means, dead_means;           // host mirrors, [n][8]
     std::vector<int> last_pairs;                          // (track row before update, detection)
     int64_t next_id = 1;
+    int ph_n = 0, ph_T = 0;
 };
 
 namespace {
@@ -169,273 +189,297 @@ void min_cost_matching(const double *full, int n_det, double max_distance, const
     }
 }
 
-}  // namespace
-
-extern "C" {
-
-int dd_tracker_create(dd_ctx *ctx, double max_cosine_distance, double max_iou_distance, int max_age, int n_init,
-                      int nn_budget, int track_capacity, int gallery_capacity, dd_tracker **out) {
-    DD_REQUIRE(ctx && out, DD_E_ARG, "dd_tracker_create: NULL argument");
-    DD_REQUIRE(track_capacity > 0 && gallery_capacity > 0, DD_E_ARG, "dd_tracker_create: capacities must be > 0");
-    dd_tracker *t = new dd_tracker();
-    t->ctx = ctx;
-    t->max_cos = max_cosine_distance;
-    t->max_iou = max_iou_distance;
-    t->max_age = max_age;
-    t->n_init = n_init;
-    t->budget = nn_budget > 0 ? nn_budget : 0;
-    t->tcap = track_capacity;
-    t->gcap = gallery_capacity;
+int pool_create(dd_ctx *ctx, int slots, int gcap, TrackerPool **out) {
+    TrackerPool *p = new TrackerPool();
+    p->ctx = ctx; p->slots = slots; p->gcap = gcap;
     DD_HIP(hipSetDevice(ctx->device));
-    DD_HIP(hipMalloc(&t->d_means, (size_t)t->tcap * 8 * sizeof(double)));
-    DD_HIP(hipMalloc(&t->d_covs, (size_t)t->tcap * 64 * sizeof(double)));
-    DD_HIP(hipMalloc(&t->d_gallery, (size_t)t->tcap * t->gcap * 128 * sizeof(float)));
-    DD_HIP(hipMalloc(&t->d_gal_count, (size_t)t->tcap * sizeof(int)));
-    DD_HIP(hipMalloc(&t->d_gal_total, (size_t)t->tcap * sizeof(int)));
-    DD_HIP(hipMemsetAsync(t->d_gal_count, 0, (size_t)t->tcap * sizeof(int), ctx->stream));
-    DD_HIP(hipMemsetAsync(t->d_gal_total, 0, (size_t)t->tcap * sizeof(int), ctx->stream));
+    DD_HIP(hipMalloc(&p->d_means, (size_t)slots * 8 * sizeof(double)));
+    DD_HIP(hipMalloc(&p->d_covs, (size_t)slots * 64 * sizeof(double)));
+    DD_HIP(hipMalloc(&p->d_gallery, (size_t)slots * gcap * 128 * sizeof(float)));
+    DD_HIP(hipMalloc(&p->d_gal_count, (size_t)slots * sizeof(int)));
+    DD_HIP(hipMalloc(&p->d_gal_total, (size_t)slots * sizeof(int)));
+    DD_HIP(hipMemsetAsync(p->d_gal_count, 0, (size_t)slots * sizeof(int), ctx->stream));
+    DD_HIP(hipMemsetAsync(p->d_gal_total, 0, (size_t)slots * sizeof(int), ctx->stream));
     DD_HIP(hipStreamSynchronize(ctx->stream));
-    t->free_slots.resize(t->tcap);
-    for (int i = 0; i < t->tcap; ++i) t->free_slots[i] = t->tcap - 1 - i;     // pop_back hands out 0,1,2,...
-    *out = t;
+    *out = p;
     return DD_OK;
 }
 
-int dd_tracker_destroy(dd_tracker *t) {
-    if (!t) return DD_OK;
-    (void)hipFree(t->d_means);
-    (void)hipFree(t->d_covs);
-    (void)hipFree(t->d_gallery);
-    (void)hipFree(t->d_gal_count);
-    (void)hipFree(t->d_gal_total);
-    t->d_stage.release(); t->d_pred.release(); t->h_pred.release(); t->d_feats_raw.release(); t->d_feats_n.release(); t->d_cost.release(); t->d_gather.release();
-    t->h_stage.release(); t->h_cost.release(); t->h_gather.release();
-    delete t;
-    return DD_OK;
+void pool_release(TrackerPool *p) {
+    if (!p || --p->refs > 0) return;
+    (void)hipFree(p->d_means); (void)hipFree(p->d_covs); (void)hipFree(p->d_gallery);
+    (void)hipFree(p->d_gal_count); (void)hipFree(p->d_gal_total);
+    for (DevBuf *b : {&p->d_pred, &p->d_in, &p->d_feats_raw, &p->d_feats_n, &p->d_cost, &p->d_pairs, &p->d_gather}) b->release();
+    for (PinBuf *b : {&p->h_pred, &p->h_in, &p->h_cost, &p->h_pairs, &p->h_gather}) b->release();
+    delete p;
 }
 
-}  // extern "C"
+dd_tracker *tracker_new(TrackerPool *pool, int slot_base, int tcap, double max_cos, double max_iou, int max_age, int n_init,
+                        int budget) {
+    dd_tracker *t = new dd_tracker();
+    t->pool = pool; pool->refs += 1;
+    t->slot_base = slot_base; t->tcap = tcap;
+    t->max_cos = max_cos; t->max_iou = max_iou; t->max_age = max_age; t->n_init = n_init;
+    t->budget = budget > 0 ? budget : 0;
+    t->free_slots.resize(tcap);
+    for (int i = 0; i < tcap; ++i) t->free_slots[i] = slot_base + tcap - 1 - i;      // pop_back hands out base+0,1,2,...
+    return t;
+}
+
+}  // namespace
 
 namespace ddk {
 
-// tracker.py:51-57 + track.py:113-125.  Enqueue only (own pinned staging block, so the copy may
-// still be in flight when update_begin stages its inputs).
-int tracker_predict_async(dd_tracker *t) {
-    hipStream_t s = t->ctx->stream;
-    for (int sl : t->pending_free) t->free_slots.push_back(sl);
-    t->pending_free.clear();
-    const int n = (int)t->tracks.size();
-    if (n == 0) return DD_OK;
-    int rc;
-    if (t->pred_inflight) DD_HIP(hipStreamSynchronize(s));      // two predicts in a row: h_pred is still being read
-    t->pred_inflight = true;
-    if ((rc = t->h_pred.reserve((size_t)n * sizeof(int))) != DD_OK) return rc;
-    if ((rc = t->d_pred.reserve((size_t)n * sizeof(int))) != DD_OK) return rc;
-    int *h = t->h_pred.as<int>();
-    for (int i = 0; i < n; ++i) {
-        h[i] = t->tracks[i].slot;
-        t->tracks[i].age += 1;
-        t->tracks[i].tsu += 1;
-    }
-    DD_HIP(hipMemcpyAsync(t->d_pred.p, h, (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
-    return ddk::kf_predict(s, t->d_means, t->d_covs, t->d_pred.as<int>(), n);
+// n trackers sharing one pool (slots [i*tcap, (i+1)*tcap) each)
+int tracker_group_create(dd_ctx *ctx, int n, double max_cos, double max_iou, int max_age, int n_init, int budget, int tcap,
+                         int gcap, dd_tracker **out) {
+    TrackerPool *pool = nullptr;
+    int rc = pool_create(ctx, n * tcap, gcap, &pool);
+    if (rc != DD_OK) return rc;
+    for (int i = 0; i < n; ++i) out[i] = tracker_new(pool, i * tcap, tcap, max_cos, max_iou, max_age, n_init, budget);
+    return DD_OK;
 }
 
-// tracker.py:59-93, phase 1: stage the detections, enqueue the association kernel and the copy of the
-// cost matrices back to pinned host memory.  No synchronisation.
-int tracker_update_begin(dd_tracker *t, const double *tlwh_host, const float *feats, int feats_on_device, int n) {
-    hipStream_t s = t->ctx->stream;
-    const int T = (int)t->tracks.size();
+// tracker.py:51-57 + track.py:113-125 for every tracker of the group: one copy, one launch, no sync.
+int trackers_predict(dd_tracker **ts, int S) {
+    if (S <= 0) return DD_OK;
+    TrackerPool *p = ts[0]->pool;
+    hipStream_t s = p->ctx->stream;
+    int n = 0;
+    for (int z = 0; z < S; ++z) {
+        dd_tracker *t = ts[z];
+        for (int sl : t->pending_free) t->free_slots.push_back(sl);
+        t->pending_free.clear();
+        n += (int)t->tracks.size();
+    }
+    if (n == 0) return DD_OK;
     int rc;
-    t->last_pairs.clear();
-    for (auto &tr : t->tracks) tr.last_det = -1;
-    t->ph_n = n; t->ph_T = T; t->ph_have_cost = false;
-
-    // ---- stage inputs: [det tlwh f64 n*4][row_slot T][row_state T][row_tsu T][pairs 2*(T+n)]
-    const size_t off_tlwh = 0;
-    const size_t off_rows = (size_t)n * 4 * sizeof(double);
-    const size_t off_pairs = off_rows + (size_t)3 * T * sizeof(int);
-    const size_t stage_bytes = off_pairs + (size_t)2 * (T + n) * sizeof(int) + 64;
-    if ((rc = t->h_stage.reserve(stage_bytes)) != DD_OK) return rc;
-    if ((rc = t->d_stage.reserve(stage_bytes)) != DD_OK) return rc;
-    char *h = t->h_stage.as<char>();
-    char *d = t->d_stage.as<char>();
-    if (n) memcpy(h + off_tlwh, tlwh_host, (size_t)n * 4 * sizeof(double));
-    int *h_slot = reinterpret_cast<int *>(h + off_rows), *h_state = h_slot + T, *h_tsu = h_state + T;
-    for (int i = 0; i < T; ++i) {
-        h_slot[i] = t->tracks[i].slot;
-        h_state[i] = t->tracks[i].state;
-        h_tsu[i] = t->tracks[i].tsu;
-    }
-    t->ph_off_pairs = off_pairs;
-    const double *d_tlwh = reinterpret_cast<const double *>(d + off_tlwh);
-    const int *d_slot = reinterpret_cast<const int *>(d + off_rows), *d_state = d_slot + T, *d_tsu = d_state + T;
-    const float *d_feats_n = nullptr;
-
-    if (n > 0) {
-        DD_HIP(hipMemcpyAsync(d, h, off_pairs, hipMemcpyHostToDevice, s));
-        const float *raw = feats;
-        if (!feats_on_device) {
-            if ((rc = t->d_feats_raw.reserve((size_t)n * 128 * sizeof(float))) != DD_OK) return rc;
-            DD_HIP(hipMemcpyAsync(t->d_feats_raw.p, feats, (size_t)n * 128 * sizeof(float), hipMemcpyHostToDevice, s));
-            raw = t->d_feats_raw.as<float>();
+    if (p->pred_inflight) DD_HIP(hipStreamSynchronize(s));      // two predicts in a row: h_pred is still being read
+    p->pred_inflight = true;
+    if ((rc = p->h_pred.reserve((size_t)n * sizeof(int))) != DD_OK) return rc;
+    if ((rc = p->d_pred.reserve((size_t)n * sizeof(int))) != DD_OK) return rc;
+    int *h = p->h_pred.as<int>();
+    int k = 0;
+    for (int z = 0; z < S; ++z)
+        for (auto &tr : ts[z]->tracks) {
+            h[k++] = tr.slot;
+            tr.age += 1;
+            tr.tsu += 1;
         }
-        if ((rc = t->d_feats_n.reserve((size_t)n * 128 * sizeof(float))) != DD_OK) return rc;
-        if ((rc = ddk::normalize_rows(s, raw, t->d_feats_n.as<float>(), n)) != DD_OK) return rc;
-        d_feats_n = t->d_feats_n.as<float>();
-    }
+    DD_HIP(hipMemcpyAsync(p->d_pred.p, h, (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
+    return ddk::kf_predict(s, p->d_means, p->d_covs, p->d_pred.as<int>(), n);
+}
 
-    if (n > 0 && T > 0) {
-        const size_t cbytes = (size_t)2 * T * n * sizeof(double);
-        if ((rc = t->d_cost.reserve(cbytes)) != DD_OK) return rc;
-        if ((rc = t->h_cost.reserve(cbytes)) != DD_OK) return rc;
-        double *d_app = t->d_cost.as<double>(), *d_iou = d_app + (size_t)T * n;
-        hipLaunchKernelGGL(tracker_assoc_k, dim3(T, dd_ceil_div(n, 64)), dim3(256), 0, s, t->d_means, t->d_covs,
-                           t->d_gallery, t->gcap, d_slot, d_state, d_tsu, t->d_gal_count, d_tlwh, d_feats_n, n,
-                           d_app, d_iou);
+// tracker.py:59-93, phase 1 for the whole group.  tlwh_host: [D][4] f64 for all streams, stream z owns
+// detections [det_off[z], det_off[z+1]); feats likewise [D][128] f32 (device or host).  Enqueue only.
+int trackers_update_begin(dd_tracker **ts, int S, const double *tlwh_host, const float *feats, int feats_on_device,
+                          const int *det_off) {
+    TrackerPool *p = ts[0]->pool;
+    hipStream_t s = p->ctx->stream;
+    int rc;
+    p->cur.assign(ts, ts + S);
+    p->det_off.assign(det_off, det_off + S + 1);
+    p->cost_base.assign(S, 0);
+    const int D = det_off[S];
+    int R = 0, maxn = 0;
+    size_t cost_total = 0;
+    for (int z = 0; z < S; ++z) {
+        dd_tracker *t = ts[z];
+        t->last_pairs.clear();
+        for (auto &tr : t->tracks) tr.last_det = -1;
+        t->ph_n = det_off[z + 1] - det_off[z];
+        t->ph_T = (int)t->tracks.size();
+        p->cost_base[z] = (int)cost_total;
+        cost_total += (size_t)2 * t->ph_T * t->ph_n;
+        R += t->ph_T;
+        maxn = std::max(maxn, t->ph_n);
+    }
+    p->D = D; p->R = R; p->have_cost = false;
+    if (D == 0) return DD_OK;
+    // ---- stage inputs: [det tlwh f64 D*4][7 int arrays of R rows]
+    const size_t off_rows = (size_t)D * 4 * sizeof(double);
+    const size_t in_bytes = off_rows + (size_t)7 * R * sizeof(int);
+    if ((rc = p->h_in.reserve(in_bytes + 64)) != DD_OK) return rc;
+    if ((rc = p->d_in.reserve(in_bytes + 64)) != DD_OK) return rc;
+    char *h = p->h_in.as<char>();
+    memcpy(h, tlwh_host, (size_t)D * 4 * sizeof(double));
+    int *hr = reinterpret_cast<int *>(h + off_rows);
+    int *h_slot = hr, *h_state = hr + R, *h_tsu = hr + 2 * R, *h_doff = hr + 3 * R, *h_nd = hr + 4 * R, *h_coff = hr + 5 * R,
+        *h_idel = hr + 6 * R;
+    int r = 0;
+    for (int z = 0; z < S; ++z) {
+        dd_tracker *t = ts[z];
+        for (int i = 0; i < t->ph_T; ++i, ++r) {
+            h_slot[r] = t->tracks[i].slot;
+            h_state[r] = t->tracks[i].state;
+            h_tsu[r] = t->tracks[i].tsu;
+            h_doff[r] = det_off[z];
+            h_nd[r] = t->ph_n;
+            h_coff[r] = p->cost_base[z] + i * t->ph_n;
+            h_idel[r] = t->ph_T * t->ph_n;
+        }
+    }
+    char *d = p->d_in.as<char>();
+    DD_HIP(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, s));
+    const float *raw = feats;
+    if (!feats_on_device) {
+        if ((rc = p->d_feats_raw.reserve((size_t)D * 128 * sizeof(float))) != DD_OK) return rc;
+        DD_HIP(hipMemcpyAsync(p->d_feats_raw.p, feats, (size_t)D * 128 * sizeof(float), hipMemcpyHostToDevice, s));
+        raw = p->d_feats_raw.as<float>();
+    }
+    if ((rc = p->d_feats_n.reserve((size_t)D * 128 * sizeof(float))) != DD_OK) return rc;
+    if ((rc = ddk::normalize_rows(s, raw, p->d_feats_n.as<float>(), D)) != DD_OK) return rc;
+    if (R > 0 && cost_total > 0) {
+        if ((rc = p->d_cost.reserve(cost_total * sizeof(double))) != DD_OK) return rc;
+        if ((rc = p->h_cost.reserve(cost_total * sizeof(double))) != DD_OK) return rc;
+        const int *dr = reinterpret_cast<const int *>(d + off_rows);
+        hipLaunchKernelGGL(tracker_assoc_k, dim3(R, dd_ceil_div(maxn, 64)), dim3(256), 0, s, p->d_means, p->d_covs,
+                           p->d_gallery, p->gcap, dr, dr + R, dr + 2 * R, dr + 3 * R, dr + 4 * R, dr + 5 * R, dr + 6 * R,
+                           p->d_gal_count, reinterpret_cast<const double *>(d), p->d_feats_n.as<float>(),
+                           p->d_cost.as<double>());
         DD_LAUNCH_CHECK();
-        DD_HIP(hipMemcpyAsync(t->h_cost.p, t->d_cost.p, cbytes, hipMemcpyDeviceToHost, s));
-        t->ph_have_cost = true;
+        DD_HIP(hipMemcpyAsync(p->h_cost.p, p->d_cost.p, cost_total * sizeof(double), hipMemcpyDeviceToHost, s));
+        p->have_cost = true;
     }
     return DD_OK;
 }
 
-// phase 2 (the cost matrices have landed): matching cascade + LSAP + track management on the host,
-// then enqueue the Kalman updates / new tracks / gallery appends and the copy of the means.
-int tracker_update_match(dd_tracker *t) {
-    hipStream_t s = t->ctx->stream;
-    t->pred_inflight = false;                                   // the caller synchronised before this phase
-    const int n = t->ph_n, T = t->ph_T;
+// phase 2 (the cost matrices have landed): per stream matching cascade + LSAP + track management on
+// the host, then ONE launch for all Kalman updates / new tracks / gallery appends of the group and
+// ONE gather of the means.
+int trackers_update_match(dd_tracker **ts, int S) {
+    TrackerPool *p = ts[0]->pool;
+    hipStream_t s = p->ctx->stream;
+    p->pred_inflight = false;                                   // the caller synchronised before this phase
     int rc;
-    char *h = t->h_stage.as<char>();
-    char *d = t->d_stage.as<char>();
-    const size_t off_pairs = t->ph_off_pairs;
-    const double *d_tlwh = reinterpret_cast<const double *>(d);
-    const float *d_feats_n = n > 0 ? t->d_feats_n.as<float>() : nullptr;
+    const int D = p->D;
+    size_t max_pairs = (size_t)p->R + D;
+    if ((rc = p->h_pairs.reserve(max_pairs * 3 * sizeof(int) + 64)) != DD_OK) return rc;
+    if ((rc = p->d_pairs.reserve(max_pairs * 3 * sizeof(int) + 64)) != DD_OK) return rc;
+    std::vector<int> upd_slot, upd_det, upd_cap, new_slot, new_det, new_cap;
     std::vector<std::pair<int, int>> matches;
-    std::vector<int> un_rows_final, un_dets;
-    if (t->ph_have_cost) {
-        const double *app = t->h_cost.as<double>(), *iou = app + (size_t)T * n;
-
-        // ---- tracker.py:95-133 _match
-        std::vector<int> confirmed, unconfirmed;
-        for (int i = 0; i < T; ++i) (t->tracks[i].state == CONFIRMED ? confirmed : unconfirmed).push_back(i);
-        un_dets.resize(n);
-        std::iota(un_dets.begin(), un_dets.end(), 0);
-        // linear_assignment.py:78-141 matching_cascade
-        std::vector<int> lvl_rows, tmp_rows, tmp_dets;
-        for (int level = 0; level < t->max_age; ++level) {
-            if (un_dets.empty()) break;
-            lvl_rows.clear();
-            for (int k : confirmed) if (t->tracks[k].tsu == 1 + level) lvl_rows.push_back(k);
-            if (lvl_rows.empty()) continue;
-            min_cost_matching(app, n, t->max_cos, lvl_rows, un_dets, matches, tmp_rows, tmp_dets);
+    std::vector<int> un_rows_final, un_dets, lvl_rows, tmp_rows, tmp_dets, confirmed, unconfirmed;
+    for (int z = 0; z < S; ++z) {
+        dd_tracker *t = ts[z];
+        const int n = t->ph_n, T = t->ph_T, doff = p->det_off[z];
+        const int cap_eff = t->budget > 0 ? std::min(t->budget, p->gcap) : p->gcap;
+        matches.clear(); un_rows_final.clear(); un_dets.clear();
+        if (n > 0 && T > 0) {
+            const double *app = p->h_cost.as<double>() + p->cost_base[z], *iou = app + (size_t)T * n;
+            // ---- tracker.py:95-133 _match
+            confirmed.clear(); unconfirmed.clear();
+            for (int i = 0; i < T; ++i) (t->tracks[i].state == CONFIRMED ? confirmed : unconfirmed).push_back(i);
+            un_dets.resize(n);
+            std::iota(un_dets.begin(), un_dets.end(), 0);
+            for (int level = 0; level < t->max_age; ++level) {            // linear_assignment.py:78-141
+                if (un_dets.empty()) break;
+                lvl_rows.clear();
+                for (int k : confirmed) if (t->tracks[k].tsu == 1 + level) lvl_rows.push_back(k);
+                if (lvl_rows.empty()) continue;
+                min_cost_matching(app, n, t->max_cos, lvl_rows, un_dets, matches, tmp_rows, tmp_dets);
+                un_dets = tmp_dets;
+            }
+            std::vector<char> matched_row(T, 0);
+            for (auto &m : matches) matched_row[m.first] = 1;
+            // set(track_indices) - matched: ascending row order here (the reference's order is CPython's
+            // set iteration order; it only permutes LSAP rows, see DESIGN.md "known order dependence")
+            std::vector<int> iou_rows = unconfirmed, un_rows_a;
+            for (int k : confirmed) {
+                if (matched_row[k]) continue;
+                if (t->tracks[k].tsu == 1) iou_rows.push_back(k); else un_rows_a.push_back(k);
+            }
+            std::vector<int> un_rows_b;
+            min_cost_matching(iou, n, t->max_iou, iou_rows, un_dets, matches, un_rows_b, tmp_dets);
             un_dets = tmp_dets;
+            un_rows_final = un_rows_a;
+            un_rows_final.insert(un_rows_final.end(), un_rows_b.begin(), un_rows_b.end());
+        } else {
+            un_dets.resize(n);
+            std::iota(un_dets.begin(), un_dets.end(), 0);
+            for (int i = 0; i < T; ++i) un_rows_final.push_back(i);
         }
-        std::vector<char> matched_row(T, 0);
-        for (auto &m : matches) matched_row[m.first] = 1;
-        // set(track_indices) - matched: ascending row order here (the reference's order is CPython's
-        // set iteration order; it only permutes LSAP rows, see DESIGN.md "known order dependence")
-        std::vector<int> iou_rows = unconfirmed, un_rows_a;
-        for (int k : confirmed) {
-            if (matched_row[k]) continue;
-            if (t->tracks[k].tsu == 1) iou_rows.push_back(k); else un_rows_a.push_back(k);
+        // ---- tracker.py:70-79 apply to the integer book-keeping
+        for (auto &m : matches) {                                  // track.py:127-152
+            TrackRec &tr = t->tracks[m.first];
+            tr.hits += 1;
+            tr.tsu = 0;
+            tr.last_det = m.second;
+            if (tr.state == TENTATIVE && tr.hits >= t->n_init) tr.state = CONFIRMED;
+            upd_slot.push_back(tr.slot); upd_det.push_back(doff + m.second); upd_cap.push_back(cap_eff);
+            t->last_pairs.push_back(m.first);
+            t->last_pairs.push_back(m.second);
         }
-        std::vector<int> un_rows_b;
-        min_cost_matching(iou, n, t->max_iou, iou_rows, un_dets, matches, un_rows_b, tmp_dets);
-        un_dets = tmp_dets;
-        un_rows_final = un_rows_a;
-        un_rows_final.insert(un_rows_final.end(), un_rows_b.begin(), un_rows_b.end());
-    } else {
-        un_dets.resize(n);
-        std::iota(un_dets.begin(), un_dets.end(), 0);
-        for (int i = 0; i < T; ++i) un_rows_final.push_back(i);
+        for (int r : un_rows_final) {                              // track.py:190-196
+            TrackRec &tr = t->tracks[r];
+            if (tr.state == TENTATIVE) tr.state = DELETED;
+            else if (tr.tsu > t->max_age) tr.state = DELETED;
+        }
+        DD_REQUIRE((int)t->free_slots.size() >= (int)un_dets.size(), DD_E_CAPACITY,
+                   "dd_tracker_update: track capacity %d exhausted", t->tcap);
+        for (int dd : un_dets) {                                   // tracker.py:135-138
+            TrackRec tr;
+            tr.id = t->next_id++;
+            tr.state = TENTATIVE; tr.tsu = 0; tr.hits = 1; tr.age = 1;
+            tr.slot = t->free_slots.back();
+            t->free_slots.pop_back();
+            tr.last_det = dd;
+            t->tracks.push_back(tr);
+            new_slot.push_back(tr.slot); new_det.push_back(doff + dd); new_cap.push_back(cap_eff);
+        }
+        // ---- tracker.py:80-81 split live / deleted
+        std::vector<TrackRec> live;
+        t->deleted.clear();
+        for (auto &tr : t->tracks) (tr.state == DELETED ? t->deleted : live).push_back(tr);
+        t->tracks.swap(live);
+        for (auto &tr : t->deleted) t->pending_free.push_back(tr.slot);
     }
-
-    // ---- tracker.py:70-79 apply to the integer book-keeping
-    int *h_pair_slot = reinterpret_cast<int *>(h + off_pairs), *h_pair_det = h_pair_slot + (T + n);
-    int np = 0;
-    for (auto &m : matches) {                                  // track.py:127-152
-        TrackRec &tr = t->tracks[m.first];
-        tr.hits += 1;
-        tr.tsu = 0;
-        tr.last_det = m.second;
-        if (tr.state == TENTATIVE && tr.hits >= t->n_init) tr.state = CONFIRMED;
-        h_pair_slot[np] = tr.slot;
-        h_pair_det[np] = m.second;
-        ++np;
-        t->last_pairs.push_back(m.first);
-        t->last_pairs.push_back(m.second);
-    }
-    const int n_upd = np;
-    for (int r : un_rows_final) {                              // track.py:190-196
-        TrackRec &tr = t->tracks[r];
-        if (tr.state == TENTATIVE) tr.state = DELETED;
-        else if (tr.tsu > t->max_age) tr.state = DELETED;
-    }
-    DD_REQUIRE((int)t->free_slots.size() >= (int)un_dets.size(), DD_E_CAPACITY,
-               "dd_tracker_update: track capacity %d exhausted", t->tcap);
-    for (int dd : un_dets) {                                   // tracker.py:135-138
-        TrackRec tr;
-        tr.id = t->next_id++;
-        tr.state = TENTATIVE;
-        tr.tsu = 0;
-        tr.hits = 1;
-        tr.age = 1;
-        tr.slot = t->free_slots.back();
-        t->free_slots.pop_back();
-        tr.last_det = dd;
-        t->tracks.push_back(tr);
-        h_pair_slot[np] = tr.slot;
-        h_pair_det[np] = dd;
-        ++np;
-    }
-    const int n_new = np - n_upd;
+    const int n_upd = (int)upd_slot.size(), n_new = (int)new_slot.size(), np = n_upd + n_new;
     if (np > 0) {
-        // ship both index lists as one block: [slot 0..np)[det 0..np)]
-        memmove(h_pair_slot + np, h_pair_det, (size_t)np * sizeof(int));
-        int *d_pair = reinterpret_cast<int *>(d + off_pairs);
-        DD_HIP(hipMemcpyAsync(d_pair, h_pair_slot, (size_t)2 * np * sizeof(int), hipMemcpyHostToDevice, s));
-        const int cap_eff = t->budget > 0 ? std::min(t->budget, t->gcap) : t->gcap;
-        hipLaunchKernelGGL(tracker_apply_k, dim3(dd_ceil_div(np, 4)), dim3(256), 0, s, t->d_means, t->d_covs,
-                           t->d_gallery, t->gcap, cap_eff, t->d_gal_count, t->d_gal_total, d_pair, d_pair + np,
-                           n_upd, n_new, d_tlwh, d_feats_n);
+        int *hp = p->h_pairs.as<int>();
+        for (int i = 0; i < n_upd; ++i) { hp[i] = upd_slot[i]; hp[np + i] = upd_det[i]; hp[2 * np + i] = upd_cap[i]; }
+        for (int i = 0; i < n_new; ++i) { hp[n_upd + i] = new_slot[i]; hp[np + n_upd + i] = new_det[i]; hp[2 * np + n_upd + i] = new_cap[i]; }
+        int *dp = p->d_pairs.as<int>();
+        DD_HIP(hipMemcpyAsync(dp, hp, (size_t)3 * np * sizeof(int), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(tracker_apply_k, dim3(dd_ceil_div(np, 4)), dim3(256), 0, s, p->d_means, p->d_covs, p->d_gallery,
+                           p->gcap, p->d_gal_count, p->d_gal_total, dp, dp + np, dp + 2 * np, n_upd, n_new,
+                           p->d_in.as<double>(), p->d_feats_n.as<float>());
         DD_LAUNCH_CHECK();
     }
-
-    // ---- tracker.py:80-81 split live / deleted, then mirror the means of both on the host
-    std::vector<TrackRec> live;
-    t->deleted.clear();
-    for (auto &tr : t->tracks) (tr.state == DELETED ? t->deleted : live).push_back(tr);
-    t->tracks.swap(live);
-    for (auto &tr : t->deleted) t->pending_free.push_back(tr.slot);
-    const int nl = (int)t->tracks.size(), nd = (int)t->deleted.size(), ng = nl + nd;
-    t->live_means.assign((size_t)nl * 8, 0.0);
-    t->dead_means.assign((size_t)nd * 8, 0.0);
+    // ---- mirror the means of live + just-deleted tracks of every stream
+    int ng = 0;
+    for (int z = 0; z < S; ++z) ng += (int)(ts[z]->tracks.size() + ts[z]->deleted.size());
+    p->ng = ng;
     if (ng > 0) {
-        if ((rc = t->h_gather.reserve((size_t)ng * (sizeof(int) + 8 * sizeof(double)))) != DD_OK) return rc;
-        if ((rc = t->d_gather.reserve((size_t)ng * (sizeof(int) + 8 * sizeof(double)))) != DD_OK) return rc;
-        double *hg = t->h_gather.as<double>();
+        if ((rc = p->h_gather.reserve((size_t)ng * (sizeof(int) + 8 * sizeof(double)))) != DD_OK) return rc;
+        if ((rc = p->d_gather.reserve((size_t)ng * (sizeof(int) + 8 * sizeof(double)))) != DD_OK) return rc;
+        double *hg = p->h_gather.as<double>();
         int *hs = reinterpret_cast<int *>(hg + (size_t)ng * 8);
-        for (int i = 0; i < nl; ++i) hs[i] = t->tracks[i].slot;
-        for (int i = 0; i < nd; ++i) hs[nl + i] = t->deleted[i].slot;
-        double *dg = t->d_gather.as<double>();
+        int k = 0;
+        for (int z = 0; z < S; ++z) {
+            for (auto &tr : ts[z]->tracks) hs[k++] = tr.slot;
+            for (auto &tr : ts[z]->deleted) hs[k++] = tr.slot;
+        }
+        double *dg = p->d_gather.as<double>();
         int *ds = reinterpret_cast<int *>(dg + (size_t)ng * 8);
         DD_HIP(hipMemcpyAsync(ds, hs, (size_t)ng * sizeof(int), hipMemcpyHostToDevice, s));
-        if ((rc = ddk::gather_state(s, t->d_means, t->d_covs, ds, ng, dg, nullptr)) != DD_OK) return rc;
+        if ((rc = ddk::gather_state(s, p->d_means, p->d_covs, ds, ng, dg, nullptr)) != DD_OK) return rc;
         DD_HIP(hipMemcpyAsync(hg, dg, (size_t)ng * 8 * sizeof(double), hipMemcpyDeviceToHost, s));
     }
-    t->ph_ng = ng; t->ph_nl = nl;
     return DD_OK;
 }
 
 // phase 3 (the means have landed): mirror them for dd_tracker_read.
-int tracker_update_end(dd_tracker *t) {
-    const int ng = t->ph_ng, nl = t->ph_nl, nd = ng - nl;
-    if (ng > 0) {
-        const double *hg = t->h_gather.as<double>();
-        memcpy(t->live_means.data(), hg, (size_t)nl * 8 * sizeof(double));
-        memcpy(t->dead_means.data(), hg + (size_t)nl * 8, (size_t)nd * 8 * sizeof(double));
+int trackers_update_end(dd_tracker **ts, int S) {
+    TrackerPool *p = ts[0]->pool;
+    const double *hg = p->h_gather.as<double>();
+    size_t k = 0;
+    for (int z = 0; z < S; ++z) {
+        dd_tracker *t = ts[z];
+        const size_t nl = t->tracks.size(), nd = t->deleted.size();
+        t->live_means.assign(hg + k * 8, hg + (k + nl) * 8);
+        k += nl;
+        t->dead_means.assign(hg + k * 8, hg + (k + nd) * 8);
+        k += nd;
     }
     return DD_OK;
 }
@@ -444,20 +488,37 @@ int tracker_update_end(dd_tracker *t) {
 
 extern "C" {
 
+int dd_tracker_create(dd_ctx *ctx, double max_cosine_distance, double max_iou_distance, int max_age, int n_init,
+                      int nn_budget, int track_capacity, int gallery_capacity, dd_tracker **out) {
+    DD_REQUIRE(ctx && out, DD_E_ARG, "dd_tracker_create: NULL argument");
+    DD_REQUIRE(track_capacity > 0 && gallery_capacity > 0, DD_E_ARG, "dd_tracker_create: capacities must be > 0");
+    return ddk::tracker_group_create(ctx, 1, max_cosine_distance, max_iou_distance, max_age, n_init, nn_budget,
+                                     track_capacity, gallery_capacity, out);
+}
+
+int dd_tracker_destroy(dd_tracker *t) {
+    if (!t) return DD_OK;
+    pool_release(t->pool);
+    delete t;
+    return DD_OK;
+}
+
 int dd_tracker_predict(dd_tracker *t) {
     DD_REQUIRE(t, DD_E_ARG, "dd_tracker_predict: NULL tracker");
-    return ddk::tracker_predict_async(t);
+    return ddk::trackers_predict(&t, 1);
 }
 
 int dd_tracker_update(dd_tracker *t, const double *tlwh_host, const float *feats, int feats_on_device, int n) {
     DD_REQUIRE(t && n >= 0, DD_E_ARG, "dd_tracker_update: bad argument");
     DD_REQUIRE(n == 0 || (tlwh_host && feats), DD_E_ARG, "dd_tracker_update: NULL detections");
     int rc;
-    if ((rc = ddk::tracker_update_begin(t, tlwh_host, feats, feats_on_device, n)) != DD_OK) return rc;
-    DD_HIP(hipStreamSynchronize(t->ctx->stream));
-    if ((rc = ddk::tracker_update_match(t)) != DD_OK) return rc;
-    DD_HIP(hipStreamSynchronize(t->ctx->stream));
-    return ddk::tracker_update_end(t);
+    const int off[2] = {0, n};
+    hipStream_t s = t->pool->ctx->stream;
+    if ((rc = ddk::trackers_update_begin(&t, 1, tlwh_host, feats, feats_on_device, off)) != DD_OK) return rc;
+    DD_HIP(hipStreamSynchronize(s));
+    if ((rc = ddk::trackers_update_match(&t, 1)) != DD_OK) return rc;
+    DD_HIP(hipStreamSynchronize(s));
+    return ddk::trackers_update_end(&t, 1);
 }
 
 int dd_tracker_count(dd_tracker *t, int which, int *out_n_host) {
@@ -481,18 +542,19 @@ int dd_tracker_read(dd_tracker *t, int which, int64_t *ints6_host, double *means
         memcpy(means_host, mm.data(), (size_t)n * 8 * sizeof(double));
     }
     if (covs_host && n) {
-        hipStream_t s = t->ctx->stream;
+        TrackerPool *p = t->pool;
+        hipStream_t s = p->ctx->stream;
         int rc;
         const size_t bytes = (size_t)n * (sizeof(int) + 72 * sizeof(double));
-        if ((rc = t->h_gather.reserve(bytes)) != DD_OK) return rc;
-        if ((rc = t->d_gather.reserve(bytes)) != DD_OK) return rc;
-        double *hg = t->h_gather.as<double>();
+        if ((rc = p->h_gather.reserve(bytes)) != DD_OK) return rc;
+        if ((rc = p->d_gather.reserve(bytes)) != DD_OK) return rc;
+        double *hg = p->h_gather.as<double>();
         int *hs = reinterpret_cast<int *>(hg + (size_t)n * 72);
         for (int i = 0; i < n; ++i) hs[i] = v[i].slot;
-        double *dg = t->d_gather.as<double>();
+        double *dg = p->d_gather.as<double>();
         int *ds = reinterpret_cast<int *>(dg + (size_t)n * 72);
         DD_HIP(hipMemcpyAsync(ds, hs, (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
-        if ((rc = ddk::gather_state(s, t->d_means, t->d_covs, ds, n, dg, dg + (size_t)n * 8)) != DD_OK) return rc;
+        if ((rc = ddk::gather_state(s, p->d_means, p->d_covs, ds, n, dg, dg + (size_t)n * 8)) != DD_OK) return rc;
         DD_HIP(hipMemcpyAsync(hg, dg, (size_t)n * 72 * sizeof(double), hipMemcpyDeviceToHost, s));
         DD_HIP(hipStreamSynchronize(s));
         memcpy(covs_host, hg + (size_t)n * 8, (size_t)n * 64 * sizeof(double));
