@@ -5,6 +5,7 @@
 // Frames are BGR u8 [H][W][3]; adjacent lanes walk adjacent output pixels of one row, so loads of a
 // source row are contiguous and the 9..15 taps of neighbouring outputs hit in L1/L2.
 #include <cmath>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include "common.h"
@@ -104,6 +105,80 @@ __global__ __launch_bounds__(256) void lanczos_v_k(const uint8_t *__restrict__ t
     const uint8_t *col = tmp + (size_t)ymin * rowbytes + xb;
     for (int y = 0; y < n; ++y) acc += col[(size_t)y * rowbytes] * k[y];
     dst[idx] = (uint8_t)min(max(acc >> PRECISION_BITS, 0), 255);
+}
+
+// Fast variants used when the row geometry allows 16-byte / 4-byte accesses (640x480 -> 300x300 does):
+// horizontal: one block per source row, the row staged in LDS with 16-byte loads, taps read from LDS;
+// vertical: four consecutive output bytes per lane, one 32-bit load per tap.
+constexpr int HROWS = 8;            // source rows per block in the fast horizontal pass
+constexpr int HTAPS = 24;           // register-resident taps per output (falls back when ksize is larger)
+
+__global__ __launch_bounds__(320) void lanczos_h_row_k(const uint8_t *__restrict__ src, int H, int W, int src_c,
+                                                       int swap_rb, const int *__restrict__ bounds,
+                                                       const int *__restrict__ kk, int ksize, int w,
+                                                       uint8_t *__restrict__ tmp) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t srow[];            // HROWS rows of W*src_c bytes
+    const int y0 = blockIdx.x * HROWS;
+    const int nr = min(HROWS, H - y0);
+    const size_t img = blockIdx.y;
+    const int rowbytes = W * src_c;                           // multiple of 16 (checked by the launcher)
+    const uint4 *g = reinterpret_cast<const uint4 *>(src + (img * H + y0) * (size_t)rowbytes);
+    for (int i = threadIdx.x; i < nr * (rowbytes / 16); i += blockDim.x) reinterpret_cast<uint4 *>(srow)[i] = g[i];
+    __syncthreads();
+    for (int xx = threadIdx.x; xx < w; xx += blockDim.x) {
+        const int xmin = bounds[2 * xx], n = bounds[2 * xx + 1];
+        int kv[HTAPS];
+#pragma unroll
+        for (int x = 0; x < HTAPS; ++x) kv[x] = x < n ? kk[(size_t)xx * ksize + x] : 0;   // taps once, reused for all rows
+        for (int r = 0; r < nr; ++r) {
+            const uint8_t *row = srow + (size_t)r * rowbytes + xmin * src_c;
+            int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0;
+#pragma unroll
+            for (int x = 0; x < HTAPS; ++x) {
+                if (x < n) {
+                    a0 += row[x * src_c + 0] * kv[x];
+                    a1 += row[x * src_c + 1] * kv[x];
+                    a2 += row[x * src_c + 2] * kv[x];
+                }
+            }
+            if (swap_rb) { const int t = a0; a0 = a2; a2 = t; }
+            uint8_t *o = tmp + ((img * H + y0 + r) * (size_t)w + xx) * 3;
+            o[0] = (uint8_t)min(max(a0 >> PRECISION_BITS, 0), 255);
+            o[1] = (uint8_t)min(max(a1 >> PRECISION_BITS, 0), 255);
+            o[2] = (uint8_t)min(max(a2 >> PRECISION_BITS, 0), 255);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void lanczos_v4_k(const uint8_t *__restrict__ tmp, int H, int rowbytes,
+                                                    const int *__restrict__ bounds, const int *__restrict__ kk,
+                                                    int ksize, int h, uint8_t *__restrict__ dst) {
+    const int q = rowbytes >> 2;                              // rowbytes is a multiple of 4
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= h * q) return;
+    tmp += (size_t)blockIdx.y * H * rowbytes;
+    dst += (size_t)blockIdx.y * h * rowbytes;
+    const int yy = idx / q, xb = (idx - yy * q) * 4;
+    const int ymin = bounds[2 * yy], n = bounds[2 * yy + 1];
+    const int *k = kk + (size_t)yy * ksize;
+    int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0, a3 = a0;
+    const uint8_t *col = tmp + (size_t)ymin * rowbytes + xb;
+    for (int y = 0; y < n; ++y) {
+        const uint32_t v = *reinterpret_cast<const uint32_t *>(col + (size_t)y * rowbytes);
+        const int kv = k[y];
+        a0 += (int)(v & 255u) * kv;
+        a1 += (int)((v >> 8) & 255u) * kv;
+        a2 += (int)((v >> 16) & 255u) * kv;
+        a3 += (int)(v >> 24) * kv;
+    }
+    // hipcc (ROCm 7.2) lowers clamp(a >> 22) | clamp(b >> 22) << 8 to v_ashr_pk_u8_i32, whose upper 16 result
+    // bits are not zero on gfx950; the following v_or3 then corrupts bytes 2-3.  Keep the four clamped
+    // bytes opaque to the pattern matcher.
+    uint32_t b0 = (uint32_t)min(max(a0 >> PRECISION_BITS, 0), 255), b1 = (uint32_t)min(max(a1 >> PRECISION_BITS, 0), 255);
+    uint32_t b2 = (uint32_t)min(max(a2 >> PRECISION_BITS, 0), 255), b3 = (uint32_t)min(max(a3 >> PRECISION_BITS, 0), 255);
+    asm volatile("" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
+    const uint32_t o = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+    *reinterpret_cast<uint32_t *>(dst + (size_t)yy * rowbytes + xb) = o;
 }
 
 __global__ __launch_bounds__(256) void copy_rgb_k(const uint8_t *__restrict__ src, int n_px, int src_c, int swap_rb,
@@ -218,8 +293,14 @@ int resize_lanczos(hipStream_t s, int device, const uint8_t *src, int H, int W, 
         int rc = get_table(device, W, w, &th);
         if (rc != DD_OK) return rc;
         uint8_t *o = (h != H) ? tmp : dst;
-        hipLaunchKernelGGL(lanczos_h_k, dim3(dd_ceil_div(H * w, 256), batch), dim3(256), 0, s, src, H, W, src_c, swap_rb,
-                           th.bounds, th.kk, th.ksize, w, o);
+        static const int dbg = getenv("DD_LANCZOS_DEBUG") ? atoi(getenv("DD_LANCZOS_DEBUG")) : 0;
+        if (!(dbg & 1) && (W * src_c) % 16 == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 && W * src_c <= 6144 &&
+            th.ksize <= HTAPS)
+            hipLaunchKernelGGL(lanczos_h_row_k, dim3(dd_ceil_div(H, HROWS), batch), dim3(320), (size_t)HROWS * W * src_c, s, src,
+                               H, W, src_c, swap_rb, th.bounds, th.kk, th.ksize, w, o);
+        else
+            hipLaunchKernelGGL(lanczos_h_k, dim3(dd_ceil_div(H * w, 256), batch), dim3(256), 0, s, src, H, W, src_c, swap_rb,
+                               th.bounds, th.kk, th.ksize, w, o);
         DD_LAUNCH_CHECK();
         mid = o;
         mid_c = 3;
@@ -234,8 +315,13 @@ int resize_lanczos(hipStream_t s, int device, const uint8_t *src, int H, int W, 
         DevTable tv;
         int rc = get_table(device, H, h, &tv);
         if (rc != DD_OK) return rc;
-        hipLaunchKernelGGL(lanczos_v_k, dim3(dd_ceil_div(h * w * 3, 256), batch), dim3(256), 0, s, mid, H, w * 3, tv.bounds,
-                           tv.kk, tv.ksize, h, dst);
+        static const int dbg2 = getenv("DD_LANCZOS_DEBUG") ? atoi(getenv("DD_LANCZOS_DEBUG")) : 0;
+        if (!(dbg2 & 2) && (w * 3) % 4 == 0 && (reinterpret_cast<uintptr_t>(mid) & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 3) == 0)
+            hipLaunchKernelGGL(lanczos_v4_k, dim3(dd_ceil_div(h * (w * 3 / 4), 256), batch), dim3(256), 0, s, mid, H, w * 3,
+                               tv.bounds, tv.kk, tv.ksize, h, dst);
+        else
+            hipLaunchKernelGGL(lanczos_v_k, dim3(dd_ceil_div(h * w * 3, 256), batch), dim3(256), 0, s, mid, H, w * 3, tv.bounds,
+                               tv.kk, tv.ksize, h, dst);
         DD_LAUNCH_CHECK();
     } else if (mid != dst) {
         DD_HIP(hipMemcpyAsync(dst, mid, (size_t)batch * H * w * mid_c, hipMemcpyDeviceToDevice, s));
