@@ -108,20 +108,28 @@ __global__ __launch_bounds__(64) void nms_small_k(const TB *__restrict__ boxes, 
 }
 
 // ---------------------------------------------------------------- general path
-// (A) rank sort: block b ranks candidates [256 b, 256 b + 256) against all k keys staged in LDS.
+// (A) rank sort: block b ranks candidates [256 b, 256 b + 256) against all k keys staged in LDS
+// (keys kept in their own precision; four f32 / two f64 keys per LDS read).
 template <typename TB>
 __global__ __launch_bounds__(256) void nms_rank_k(const TB *__restrict__ boxes, const TB *__restrict__ keys, int k, int mode,
                                                   SBox *__restrict__ sorted, int *__restrict__ sidx) {
-    __shared__ double skey[MAXK];
+    constexpr int V = 16 / sizeof(TB);                       // keys per 16-byte LDS read
+    __shared__ __attribute__((aligned(16))) TB skey[MAXK + 4];
     boxes += (size_t)blockIdx.z * k * 4; keys += (size_t)blockIdx.z * k;     // blockIdx.z = image of a batch
     sorted += (size_t)blockIdx.z * k; sidx += (size_t)blockIdx.z * k;
-    for (int i = threadIdx.x; i < k; i += blockDim.x) skey[i] = (double)keys[i];
+    const int kp = (k + V - 1) / V * V;
+    for (int i = threadIdx.x; i < kp; i += blockDim.x) skey[i] = i < k ? keys[i] : (TB)(-__builtin_inf());
     __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= k) return;
-    const double ki = skey[i];
+    const TB ki = skey[i];
     int rank = 0;
-    for (int j = 0; j < k; ++j) rank += (j != i && before(skey[j], j, ki, i)) ? 1 : 0;
+    for (int j = 0; j < kp; j += V) {
+        TB kj[V];
+        *reinterpret_cast<uint4 *>(kj) = *reinterpret_cast<const uint4 *>(skey + j);
+#pragma unroll
+        for (int u = 0; u < V; ++u) rank += (kj[u] > ki || (kj[u] == ki && j + u > i && j + u < k)) ? 1 : 0;
+    }
     sorted[rank] = make_sbox(boxes + (size_t)i * 4, mode);
     sidx[rank] = i;
 }
@@ -193,6 +201,76 @@ __global__ __launch_bounds__(64) void nms_scan_k(const u64 *__restrict__ mask, c
     if (lane == 0) *out_n = n_keep;
 }
 
+// (B+C fused) one workgroup per problem: for each chunk of 64 sorted rows, 16 waves build that
+// chunk's rows of the suppression bit-matrix on the fly (skipping rows that are already suppressed;
+// a wave owns whole 64-column words so its column box stays in registers and the pivot boxes are
+// broadcast from LDS), then wave 0 resolves the chunk and folds the survivors into the running
+// "removed" set.  With max_keep the loop usually ends after the first chunk, so only ~64 x k pairs
+// are ever evaluated instead of k^2 / 2 (the SSD post-process needs 10 survivors of 1917 candidates).
+__global__ __launch_bounds__(1024) void nms_lazy_k(const SBox *__restrict__ sorted, const int *__restrict__ sidx, int k,
+                                                   int words, double thr, int mode, int max_keep,
+                                                   int *__restrict__ out_idx, int *__restrict__ out_n) {
+    __shared__ u64 rows[64 * 64];
+    __shared__ u64 s_removed[64];
+    __shared__ SBox srowbox[64];
+    __shared__ int s_nkeep, s_done;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    sorted += (size_t)blockIdx.x * k; sidx += (size_t)blockIdx.x * k;
+    out_idx += (size_t)blockIdx.x * k; out_n += blockIdx.x;
+    if (tid < 64) s_removed[tid] = 0ull;
+    if (tid == 0) { s_nkeep = 0; s_done = 0; }
+    __syncthreads();
+    for (int c = 0; c < words; ++c) {
+        const int row0 = c * 64;
+        const int nrows = min(64, k - row0);
+        const u64 gone = s_removed[c];
+        if (tid < nrows) srowbox[tid] = sorted[row0 + tid];
+        __syncthreads();
+        for (int w = c + wave; w < words; w += 16) {
+            const int j = w * 64 + lane;
+            SBox cj = {0, 0, 0, 0, 0};
+            if (j < k) cj = sorted[j];
+            for (int r = 0; r < nrows; ++r) {
+                u64 bits = 0ull;
+                if (!((gone >> r) & 1ull)) {                   // wave-uniform: suppressed rows never suppress
+                    const bool s = j > row0 + r && j < k && suppresses(srowbox[r], cj, thr, mode);
+                    bits = __ballot(s);
+                }
+                if (lane == 0) rows[r * 64 + w] = bits;
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const u64 diag = lane < nrows ? rows[lane * 64 + c] : 0ull;
+            u64 rc = gone, keep = 0;
+            const int n_keep = s_nkeep;
+            bool full = false;
+            for (int b = 0; b < nrows; ++b) {
+                if (!((rc >> b) & 1ull)) {
+                    keep |= 1ull << b;
+                    rc |= __shfl(diag, b, 64);
+                    if (max_keep > 0 && n_keep + __popcll(keep) >= max_keep) { full = true; break; }
+                }
+            }
+            if (lane < nrows && ((keep >> lane) & 1ull))
+                out_idx[n_keep + __popcll(keep & ((1ull << lane) - 1ull))] = sidx[row0 + lane];
+            if (lane > c && lane < words) {
+                u64 acc = 0, kk = keep;
+                while (kk) {
+                    const int b = __ffsll((long long)kk) - 1;
+                    kk &= kk - 1;
+                    acc |= rows[b * 64 + lane];
+                }
+                s_removed[lane] |= acc;
+            }
+            if (lane == 0) { s_nkeep = n_keep + __popcll(keep); s_done = full ? 1 : 0; }
+        }
+        __syncthreads();
+        if (s_done) break;
+    }
+    if (tid == 0) *out_n = s_nkeep;
+}
+
 }  // namespace
 
 namespace ddk {
@@ -236,6 +314,11 @@ int nms_ex(hipStream_t s, const void *boxes, const void *keys, int k, double thr
         hipLaunchKernelGGL(nms_rank_k<double>, dim3(dd_ceil_div(k, 256)), dim3(256), 0, s, static_cast<const double *>(boxes),
                            static_cast<const double *>(keys), k, mode, sorted, sidx);
     DD_LAUNCH_CHECK();
+    if (max_keep > 0 || k <= 1024) {
+        hipLaunchKernelGGL(nms_lazy_k, dim3(1), dim3(1024), 0, s, sorted, sidx, k, words, thr, mode, max_keep, out_idx, out_n);
+        DD_LAUNCH_CHECK();
+        return DD_OK;
+    }
     hipLaunchKernelGGL(nms_mask_k, dim3(words, dd_ceil_div(k, 4)), dim3(256), 0, s, sorted, k, words, thr, mode, mask);
     DD_LAUNCH_CHECK();
     hipLaunchKernelGGL(nms_scan_k, dim3(1), dim3(64), 0, s, mask, sidx, k, words, max_keep, out_idx, out_n);
@@ -258,6 +341,11 @@ int nms_f32_batched(hipStream_t s, const float *boxes, const float *keys, int k,
     u64 *mask = reinterpret_cast<u64 *>(p);
     hipLaunchKernelGGL(nms_rank_k<float>, dim3(dd_ceil_div(k, 256), 1, batch), dim3(256), 0, s, boxes, keys, k, 2, sorted, sidx);
     DD_LAUNCH_CHECK();
+    if (max_keep > 0 || k <= 1024) {
+        hipLaunchKernelGGL(nms_lazy_k, dim3(batch), dim3(1024), 0, s, sorted, sidx, k, words, (double)thr, 2, max_keep, out_idx, out_n);
+        DD_LAUNCH_CHECK();
+        return DD_OK;
+    }
     hipLaunchKernelGGL(nms_mask_k, dim3(words, dd_ceil_div(k, 4), batch), dim3(256), 0, s, sorted, k, words, (double)thr, 2, mask);
     DD_LAUNCH_CHECK();
     hipLaunchKernelGGL(nms_scan_k, dim3(batch), dim3(64), 0, s, mask, sidx, k, words, max_keep, out_idx, out_n);
