@@ -34,28 +34,29 @@ PEAK_HBM_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--streams', type=int, default=int(os.environ.get('DD_BENCH_STREAMS', '1')),
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--streams', type=int, default=int(os.environ.get('DD_BENCH_STREAMS', '64')),
                     help='independent video streams per GPU (one frame of each per step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-frames', type=int, default=40)
+    ap.add_argument('--cpu-frames', type=int, default=300)
     return ap.parse_args()
 
 
 def make_inputs(rank, streams, n_frames):
-    """Per stream: frames u8 [F,H,W,3] (host) and per-frame injected detections."""
+    """-> frames u8 [F, S, H, W, 3] (host, filled in place) and per-stream per-frame injected detections."""
     from deepdish_amd.synth import Scene
-    out = []
+    frames = np.empty((n_frames, streams, H, W, 3), dtype=np.uint8)
+    dets = []
     for s in range(streams):
         sc = Scene(seed=1000 * rank + s, n_obj=N_OBJ, width=W, height=H, n_frames=n_frames)
-        frames = np.stack([sc.frame(f) for f in range(n_frames)])
-        dets = []
+        per = []
         for f in range(n_frames):
+            frames[f, s] = sc.frame(f)
             boxes, scores, who, _ = sc.detections(f)
-            dets.append(([tuple(int(v) for v in b) for b in boxes], ['person'] * len(boxes), [float(x) for x in scores]))
-        out.append((sc, frames, dets))
-    return out
+            per.append(([tuple(int(v) for v in b) for b in boxes], ['person'] * len(boxes), [float(x) for x in scores]))
+        dets.append(per)
+    return frames, dets
 
 
 def cpu_baseline(n_frames):
@@ -113,11 +114,12 @@ def main():
     from deepdish_amd.runtime import default_context
     ctx = default_context()
     n_frames = args.warmup + args.steps
-    streams = make_inputs(rank, args.streams, n_frames)
+    frames, dets = make_inputs(rank, args.streams, n_frames)
     pipe = MultiStreamPipeline(args.streams, context=ctx)
     # frames resident in HBM before the timed region: [F][S][H][W][3]
-    dev_frames = torch.from_numpy(np.stack([fr for _, fr, _ in streams], axis=1)).to(f'cuda:{local_rank}')
-    injected = [pipe.pack_injected([streams[s][2][f] for s in range(args.streams)]) for f in range(n_frames)]
+    dev_frames = torch.from_numpy(frames).to(f'cuda:{local_rank}')
+    del frames
+    injected = [pipe.pack_injected([dets[s][f] for s in range(args.streams)]) for f in range(n_frames)]
     torch.cuda.synchronize()
 
     def step(f):
