@@ -138,6 +138,37 @@ __device__ __forceinline__ void conv_epilogue(const ConvP &P, int m, int co, flo
     }
 }
 
+// Plain NHWC f16 output, 8 consecutive channels of one pixel (v = raw sums): one 16-byte store, so
+// eight neighbouring lanes write a full 128-byte line.
+__device__ __forceinline__ void conv_epilogue_f16x8(const ConvP &P, int m, int co, float v[8]) {
+    const f4 b0 = *reinterpret_cast<const f4 *>(P.bias + co), b1 = *reinterpret_cast<const f4 *>(P.bias + co + 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { v[r] = apply_act(v[r] + b0[r], P.act); v[4 + r] = apply_act(v[4 + r] + b1[r], P.act); }
+    if (P.res) {
+        const h8 rv = *reinterpret_cast<const h8 *>(P.res + (size_t)m * P.cs_res + P.coff_res + co);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += (float)rv[r];
+    }
+    h8 o;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        if (co + r >= P.cout) v[r] = 0.f;
+        o[r] = (_Float16)v[r];
+    }
+    *reinterpret_cast<h8 *>(static_cast<_Float16 *>(P.out) + (size_t)m * P.cs_out + P.coff_out + co) = o;
+    if (P.out2) {                                   // second view: ELU(scale * raw + shift)
+        const f4 s0 = *reinterpret_cast<const f4 *>(P.aff2 + co), s1 = *reinterpret_cast<const f4 *>(P.aff2 + co + 4);
+        const f4 t0 = *reinterpret_cast<const f4 *>(P.aff2 + P.cout_pad + co), t1 = *reinterpret_cast<const f4 *>(P.aff2 + P.cout_pad + co + 4);
+        h8 o2;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const float sc = r < 4 ? s0[r] : s1[r - 4], sh = r < 4 ? t0[r] : t1[r - 4];
+            o2[r] = (_Float16)(co + r < P.cout ? apply_act(sc * v[r] + sh, ACT_ELU) : 0.f);
+        }
+        *reinterpret_cast<h8 *>(P.out2 + (size_t)m * P.cs_out2 + P.coff_out2 + co) = o2;
+    }
+}
+
 // Block tile: (WM*MI*16) pixels x (WN*NI*16) output channels, K step BK (32 for shallow K, else 64:
 // two MFMA k-slices per barrier); blockIdx.z = K split.  Staged rows carry 8 halves of padding.
 template <int WM, int WN, int MI, int NI, int BK>
@@ -147,7 +178,7 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_mfma_k(const ConvP P) {
     constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
     constexpr int CPR = BK / 8;                               // 16-byte chunks per staged row
     constexpr int XCH = (BM * CPR + T - 1) / T, WCH = (BN * CPR + T - 1) / T;
-    __shared__ __attribute__((aligned(16))) _Float16 lds[2 * (BM + BN) * LDS_ROW];
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];         // 2 * (BM + BN) * LDS_ROW halves
     _Float16 *xs = lds, *ws = lds + 2 * BM * LDS_ROW;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -248,6 +279,29 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_mfma_k(const ConvP P) {
         }
     }
 
+    if (P.epi == EPI_F16 && P.splitk == 1) {
+        // ---- transpose the accumulators through LDS (f32) so that stores are 16 bytes per lane and whole
+        // 128-byte lines per pixel; the staging buffers are free after the loop's last barrier.
+        constexpr int OROW = BN + 4;                              // floats per staged pixel row
+        float *ot = reinterpret_cast<float *>(lds);
+#pragma unroll
+        for (int b = 0; b < MI; ++b)
+#pragma unroll
+            for (int a = 0; a < NI; ++a)
+                *reinterpret_cast<f4 *>(ot + ((wm * MI + b) * 16 + fr) * OROW + (wn * NI + a) * 16 + fq * 4) = acc[a][b];
+        __syncthreads();
+        constexpr int G = BN / 8;                                 // 8-channel groups per pixel row
+        for (int t = tid; t < BM * G; t += T) {
+            const int pl = t / G, g = t - pl * G;
+            const int m = m0 + pl, co = n0 + g * 8;
+            if (m >= P.m || co >= P.cout_pad) continue;
+            const f4 lo = *reinterpret_cast<const f4 *>(ot + pl * OROW + g * 8);
+            const f4 hi = *reinterpret_cast<const f4 *>(ot + pl * OROW + g * 8 + 4);
+            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            conv_epilogue_f16x8(P, m, co, v);
+        }
+        return;
+    }
     // ---- lane holds channels co..co+3 of pixel m
 #pragma unroll
     for (int b = 0; b < MI; ++b) {
@@ -522,7 +576,16 @@ int launch_conv(hipStream_t s, ConvP &P, DevBuf &slab) {
         if (rc != DD_OK) return rc;
         P.slab = slab.as<float>();
     }
-    hipLaunchKernelGGL((conv_mfma_k<WM, WN, MI, NI, BK>), dim3(gx, gy, splitk), dim3(WM * WN * 64), 0, s, P);
+    constexpr size_t stage_bytes = (size_t)2 * (BM + BN) * (BK + 8) * sizeof(_Float16);
+    constexpr size_t out_bytes = (size_t)BM * (BN + 4) * sizeof(float);
+    constexpr size_t lds_bytes = stage_bytes > out_bytes ? stage_bytes : out_bytes;
+    static bool attr_done = false;                            // > 64 KiB of LDS needs the opt-in attribute
+    if (!attr_done && lds_bytes > 65536) {
+        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_k<WM, WN, MI, NI, BK>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv_mfma_k<WM, WN, MI, NI, BK>), dim3(gx, gy, splitk), dim3(WM * WN * 64), lds_bytes, s, P);
     DD_LAUNCH_CHECK();
     if (splitk > 1) {
         const long long total = (long long)P.m * (P.cout_pad >> 2);
@@ -699,7 +762,12 @@ int dd_net_forward(dd_net *net, const uint8_t *input, int nimg, void *stream) {
                 for (int q = 0; q < 8; ++q) P.f[q] = of[32 + q];
                 int rc;
                 const bool bk32 = o[28] == 32;                 // shallow K (<= 96): one or few 32-wide steps
+                // A 128 x 128 tile (4 x 4 MFMA tiles per wave) was measured at HALF the speed of the 64 x 64 tile
+                // here (19x19x512 -> 512 at 64 frames: 110 us vs 51 us): 74 KiB of LDS leaves two blocks per CU and
+                // this loop has only one K step of prefetch.  Kept compiled for the next round's pipelined version.
+                const bool big = false && !bk32 && P.epi == EPI_F16 && P.cout_pad >= 128 && P.m >= 16384;
                 if (P.cout_pad <= 32) rc = bk32 ? launch_conv<4, 1, 1, 2, 32>(s, P, net->slab) : launch_conv<4, 1, 1, 2, 64>(s, P, net->slab);
+                else if (big) rc = launch_conv<2, 2, 4, 4, 64>(s, P, net->slab);
                 else rc = bk32 ? launch_conv<2, 2, 2, 2, 32>(s, P, net->slab) : launch_conv<2, 2, 2, 2, 64>(s, P, net->slab);
                 if (rc != DD_OK) return rc;
                 break;

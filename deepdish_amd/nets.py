@@ -114,7 +114,7 @@ class Program:
         if out_hw is not None:
             assert (ho, wo) == tuple(out_hw), ((ho, wo), out_hw)
         cout_pad = rup(cout, 8)
-        rows = 32 if cout_pad <= 32 else rup(cout_pad, 64)
+        rows = 32 if cout_pad <= 32 else rup(cout_pad, 128 if cout_pad >= 128 else 64)
         bk = 32 if kh * kw * cin_pad <= 96 else 64
         kpad = rup(kh * kw * cin_pad, bk)
         wp = np.zeros((rows, kh * kw, cin_pad), dtype=np.float16)
