@@ -190,6 +190,38 @@ __global__ __launch_bounds__(256) void copy_rgb_k(const uint8_t *__restrict__ sr
     d[0] = s[swap_rb ? 2 : 0]; d[1] = s[1]; d[2] = s[swap_rb ? 0 : 2];
 }
 
+// tools/generate_detections.py:86-116 -- the reference's model-free test encoders.
+// mode 0 (DummyImageEncoder): patches u8 [n][16][8][3] -> mean over the 3 channels -> 128 values - 128
+// -> L2-normalised (e0 when the norm is 0).  mode 1 (ConstantImageEncoder): e0.  One wave per patch.
+__global__ __launch_bounds__(256) void fake_encode_k(const uint8_t *__restrict__ patches, int n, int mode,
+                                                     float *__restrict__ out) {
+    const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (w >= n) return;
+    float v[2] = {0.f, 0.f};
+    float ss = 0.f;
+    if (mode == 0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const uint8_t *p = patches + ((size_t)w * 128 + lane + 64 * q) * 3;
+            // np.average over the channel axis of a float32 array: sum in f32, divide by 3
+            v[q] = ((float)p[0] + (float)p[1] + (float)p[2]) / 3.0f - 128.0f;
+            ss += v[q] * v[q];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const float l = sqrtf(ss);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int j = lane + 64 * q;
+        float r;
+        if (mode == 1 || l == 0.f) r = (mode == 1) ? (j == 0 ? 1.f : 0.f) : (j == 0 ? 1.f : v[q]);
+        else r = v[q] / l;
+        out[(size_t)w * 128 + j] = r;
+    }
+}
+
 // Host: Pillow precompute_coeffs + normalize_coeffs_8bpc (double math on the host so that sin()
 // is the same libm the reference's Pillow uses; the device only sees integers).
 struct LanczosTable {
@@ -352,6 +384,15 @@ int dd_crop_resize(dd_ctx *ctx, const uint8_t *frame, int H, int W, const int64_
     DD_HIP(hipMemcpyAsync(ctx->scratch[3].p, hb, (size_t)n * 32, hipMemcpyHostToDevice, s));
     DD_HIP(hipStreamSynchronize(s));                        // the pinned block is reused by the next call
     return ddk::crop_resize(s, frame, H, W, ctx->scratch[3].p, n, ph, pw, out);
+}
+
+int dd_fake_encode(dd_ctx *ctx, const uint8_t *patches, int n, int mode, float *out, void *stream) {
+    DD_REQUIRE(ctx && n >= 0 && (mode == 0 || mode == 1), DD_E_ARG, "dd_fake_encode: bad argument");
+    if (n == 0) return DD_OK;
+    DD_REQUIRE(out && (mode == 1 || patches), DD_E_ARG, "dd_fake_encode: NULL argument");
+    hipLaunchKernelGGL(fake_encode_k, dim3(dd_ceil_div(n, 4)), dim3(256), 0, dd_pick_stream(ctx, stream), patches, n, mode, out);
+    DD_LAUNCH_CHECK();
+    return DD_OK;
 }
 
 int dd_resize_lanczos(dd_ctx *ctx, const uint8_t *src, int H, int W, int src_c, int swap_rb, uint8_t *dst, int h,

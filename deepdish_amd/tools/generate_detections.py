@@ -77,11 +77,43 @@ class MarsImageEncoder(object):
         return self.ctx.to_host(self.encode_device(patches))
 
 
+class _FakeImageEncoder(object):
+    """DummyImageEncoder / ConstantImageEncoder (generate_detections.py:86-116) on csrc/image.hip."""
+    mode = 0
+
+    def __init__(self, context=None):
+        self.ctx = context or default_context()
+        self.height, self.width = 16, 8
+        self.image_shape = 16, 8, 3
+        self.feature_dim = 128
+
+    def encode_device(self, patches_dev):
+        n = int(patches_dev.shape[0])
+        out = self.ctx.empty((n, 128), torch.float32)
+        check(lib().dd_fake_encode(self.ctx.handle, ptr(patches_dev), n, self.mode, ptr(out), None), 'dd_fake_encode')
+        return out
+
+    def __call__(self, data_in, batch_size=32):
+        patches = self.ctx.to_device(np.asarray(data_in, dtype=np.uint8))
+        return self.ctx.to_host(self.encode_device(patches))
+
+
+class DummyImageEncoder(_FakeImageEncoder):
+    mode = 0
+
+
+class ConstantImageEncoder(_FakeImageEncoder):
+    mode = 1
+
+
 def create_box_encoder(model_filename, input_name="images", output_name="features", batch_size=32,
                        num_threads=1, context=None):
-    if 'dummy' in model_filename or 'constant' in model_filename:
-        raise NotImplementedError('the dummy/constant test encoders of the reference are not built yet')
-    image_encoder = MarsImageEncoder(model_filename, num_threads=num_threads, context=context)
+    if 'dummy' in model_filename:                                 # generate_detections.py:182-189
+        image_encoder = DummyImageEncoder(context)
+    elif 'constant' in model_filename:
+        image_encoder = ConstantImageEncoder(context)
+    else:
+        image_encoder = MarsImageEncoder(model_filename, num_threads=num_threads, context=context)
     ctx = image_encoder.ctx
     ph, pw = image_encoder.image_shape[:2]
 

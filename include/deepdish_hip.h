@@ -136,6 +136,11 @@ int dd_tracker_last_matches(dd_tracker *trk, int *pairs_host, int cap, int *out_
 int dd_crop_resize(dd_ctx *ctx, const uint8_t *frame, int H, int W, const int64_t *boxes_host,
                    int n, int ph, int pw, uint8_t *out, int *valid_host, void *stream);
 
+/* tools/generate_detections.py:86-116 DummyImageEncoder (mode 0: channel-mean of 16x8 patches, -128,
+ * L2-normalised) and ConstantImageEncoder (mode 1: e0): the reference's model-free test encoders.
+ * patches u8 [n][16][8][3] -> out f32 [n][128]. */
+int dd_fake_encode(dd_ctx *ctx, const uint8_t *patches, int n, int mode, float *out, void *stream);
+
 /* PIL Image.resize(LANCZOS) of an RGB(A) u8 image as tools/ssd_mobilenet.py:54-57 and
  * tools/yolov5.py:99 call it (stretch, no letterbox).  src u8 [H][W][src_c] (first 3 channels
  * used, optionally swapped BGR->RGB), dst u8 [h][w][3]. */

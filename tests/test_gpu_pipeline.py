@@ -160,3 +160,115 @@ def test_multistream_detector_output_matches_plugin():
             np.testing.assert_allclose(means, np.array([t.mean for t in hp.tracker.tracks]), rtol=1e-9, atol=1e-9)
         seen = max(seen, len(want))
     assert seen > 0
+
+
+def test_tflite_plugin_vs_oracle():
+    """a13: generic TFLite-Task adaptor = cv2 bilinear stretch + SSD forward + post-process + int() boxes."""
+    from deepdish_amd.pipeline import make_detector, DEFAULT_LABELS
+    from deepdish_amd.synth import Scene
+    from oracle import nets_torch, image_np
+    names = [l.strip() for l in open(DEFAULT_LABELS)]
+    wanted = sorted(set(names) - {'???'})
+    det = make_detector('synthetic-efficientdet_lite0.tflite', wanted_labels=wanted)
+    assert type(det).__name__ == 'TFLITE' and det.labels[1] == 'person' and (det.width, det.height) == (300, 300)
+    rgb = np.ascontiguousarray(Scene(seed=9, n_obj=8).frame(0)[..., ::-1])
+    boxes, labels, scores = det.detect_image(rgb)
+    resized = image_np.resize_linear_u8(rgb, 300, 300)
+    raw = nets_torch.ssd_forward(det.detector.weights, resized[None], w16=True)[0]
+    ob, oc, osc, n = nets_torch.ssd_postprocess(raw, det.detector._anchors)
+    want = []
+    for i in range(n):
+        if osc[i] >= 0.5:
+            y0, x0, y1, x1 = ob[i]
+            want.append(([int(x0 * 640), int(y0 * 480), int(x1 * 640) - int(x0 * 640), int(y1 * 480) - int(y0 * 480)],
+                         names[int(oc[i]) + 1], float(osc[i])))
+    want.sort(key=lambda t: -t[2])
+    assert len(boxes) == len(want) > 0
+    hits = 0
+    for b, l, s in zip(boxes, labels, scores):
+        for wb, wl, ws in want:
+            if l == wl and abs(s - ws) < 5e-3 and max(abs(np.array(b) - np.array(wb))) <= 2:
+                hits += 1
+                break
+    assert hits >= len(want) - 2, (hits, len(want))
+    assert all(isinstance(v, int) for v in boxes[0])
+    assert list(scores) == sorted(scores, reverse=True)
+
+
+def test_fake_encoders_vs_reference_statements():
+    """DummyImageEncoder / ConstantImageEncoder (generate_detections.py:86-116), restated inline."""
+    from deepdish_amd.tools.generate_detections import create_box_encoder
+    from oracle import image_np
+    rng = np.random.default_rng(0)
+    frame = rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    frame[100:200, 100:150] = 128                                   # a zero-norm patch after the -128 shift
+    boxes = [np.array(b) for b in ([30, 40, 25, 60], [300, 200, 40, 90], [110, 110, 20, 40])]
+    enc = create_box_encoder('dummy-encoder')
+    assert (enc.width, enc.height) == (8, 16)
+    got = enc(frame, boxes)
+    patches = np.stack([image_np.extract_image_patch(frame, b, (16, 8)) for b in boxes])
+    mat = np.average(np.array(patches, dtype=np.float32), axis=3).reshape((-1, 128)) - 128
+    want = np.zeros_like(mat)
+    for i in range(len(mat)):
+        l = np.sqrt(np.sum(mat[i] ** 2, axis=0))
+        if l == 0:
+            want[i] = mat[i]; want[i, 0] = 1
+        else:
+            want[i] = mat[i] / l
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-6)
+    assert got[2, 0] == 1.0 and not got[2, 1:].any()
+    const = create_box_encoder('constant-encoder')(frame, boxes)
+    assert const.shape == (3, 128) and np.all(const[:, 0] == 1) and not const[:, 1:].any()
+    assert create_box_encoder('dummy')(frame, []).shape == (0,)
+
+
+def test_yolo_candidates_through_nms_and_tracker():
+    """Config 3 shape: YOLOv5 rows (no NMS in the adaptor) -> deep_sort NMS over a few hundred
+    candidates (general NMS path) == oracle NMS on the same boxes -> encoder -> tracker step."""
+    from deepdish_amd.pipeline import HotPath, clean_boxes, DEFAULT_YOLO_LABELS
+    from deepdish_amd.deep_sort import preprocessing
+    from deepdish_amd.synth import Scene
+    from oracle import deepsort_np as ds
+    wanted = [l.strip() for l in open(DEFAULT_YOLO_LABELS)]
+    hp = HotPath(model='synthetic-yolov5s-fp16.tflite', wanted_labels=wanted)
+    sc = Scene(seed=4, n_obj=8)
+    frame = torch.from_numpy(sc.frame(0)).cuda()
+    b0, l0, s0 = hp.object_detector.detect_frame_device(frame, 480, 640)
+    assert len(b0) > 64                                              # exercises the rank + lazy NMS kernels
+    boxes, labels, scores = clean_boxes(b0, l0, s0, 640, 480)
+    keep = preprocessing.non_max_suppression(np.array(boxes), 0.6, np.array(scores))
+    assert keep == ds.non_max_suppression(np.array(boxes), 0.6, np.array(scores))
+    assert 0 < len(keep) < len(boxes)
+    for f in range(3):
+        hp.step(torch.from_numpy(sc.frame(f)).cuda())
+    assert len(hp.tracker.tracks) > 0
+
+
+def test_multistream_720p_streams():
+    """Config 5 shape: 1280x720 streams, one tracker each, counts vector per stream."""
+    from deepdish_amd.multipipe import MultiStreamPipeline
+    from deepdish_amd.synth import Scene
+    from oracle import deepsort_np as ds, countline_np as cl, image_np, nets_torch
+    S, F = 2, 12
+    scenes = [Scene(seed=40 + z, n_obj=12, width=1280, height=720, n_frames=F, vmax=6.0) for z in range(S)]
+    mp = MultiStreamPipeline(S, input_size=(1280, 720))
+    otrk = [ds.Tracker(ds.Metric(0.2), max_iou_distance=0.7, max_age=60) for _ in range(S)]
+    ocnt = [cl.CountLine(sc.countline()) for sc in scenes]
+    for f in range(F):
+        frames = np.stack([sc.frame(f) for sc in scenes])
+        per = []
+        for z, sc in enumerate(scenes):
+            boxes, scores, _, _ = sc.detections(f)
+            per.append(([tuple(int(v) for v in b) for b in boxes], ['person'] * len(boxes), [float(s) for s in scores]))
+            keep = ds.non_max_suppression(boxes, 0.6, scores)
+            patches = np.stack([image_np.extract_image_patch(frames[z], boxes[i], (64, 32)) for i in keep])
+            feats = nets_torch.mars_forward(mp.enc_weights, patches)
+            otrk[z].predict()
+            otrk[z].update([ds.Det(boxes[i], 'person', scores[i], feats[j]) for j, i in enumerate(keep)])
+            ocnt[z].step(otrk[z])
+        mp.step(torch.from_numpy(frames).cuda(), mp.pack_injected(per))
+    for z in range(S):
+        ints, _ = mp.tracker(z).table()
+        want = np.array([[t.track_id, t.state, t.time_since_update, t.hits, t.age] for t in otrk[z].tracks], dtype=np.int64)
+        np.testing.assert_array_equal(ints[:, :5], want.reshape(-1, 5))
+        np.testing.assert_array_equal(mp.counts()[z], ocnt[z].vector())
