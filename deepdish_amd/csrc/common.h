@@ -74,6 +74,15 @@ static inline hipStream_t dd_pick_stream(dd_ctx *ctx, void *stream) {
 
 static inline int dd_ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// XCD-aware block order (MI355X: 8 XCDs, each with a private 4 MiB L2; workgroups are dealt round-robin
+// over them).  Maps the hardware's linear workgroup id to a logical id such that every XCD works on one
+// contiguous 1/8 of the logical range: neighbouring tiles (shared halo rows, shared weight panels) then
+// hit in the same L2 instead of being fetched by up to 8 of them.  Bijective for any count.
+__device__ __forceinline__ unsigned dd_xcd_remap(unsigned id, unsigned n) {
+    const unsigned q = n >> 3, r = n & 7u, xcd = id & 7u, slot = id >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
 // ---- kernel launchers shared between the flat C ABI and the tracker / pipeline handles ----
 namespace ddk {
 int kf_initiate(hipStream_t s, double *means, double *covs, const int *slots, const double *xyah, int n);

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void lanczos_v4_k(const uint8_t *__restrict__ 
                                                     const int *__restrict__ bounds, const int *__restrict__ kk,
                                                     int ksize, int h, uint8_t *__restrict__ dst) {
     const int q = rowbytes >> 2;                              // rowbytes is a multiple of 4
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int idx = dd_xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     if (idx >= h * q) return;
     tmp += (size_t)blockIdx.y * H * rowbytes;
     dst += (size_t)blockIdx.y * h * rowbytes;

@@ -183,7 +183,9 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_mfma_k(const ConvP P) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    // logical tile order: pixel tiles fastest within one channel tile, one contiguous slice per XCD
+    const unsigned lin = dd_xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+    const int m0 = (int)(lin % gridDim.x) * BM, n0 = (int)(lin / gridDim.x) * BN;
     const int hw = P.ho * P.wo;
     const int ksteps = P.kpad / BK;
     const int per = (ksteps + P.splitk - 1) / P.splitk;
@@ -346,7 +348,7 @@ struct DwP {
 
 __global__ __launch_bounds__(256) void dwconv3_k(const DwP P) {
     const int groups = P.c >> 3;
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long idx = (long long)dd_xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     if (idx >= (long long)P.m * groups) return;
     const int g = (int)(idx % groups);
     const int m = (int)(idx / groups);
@@ -387,7 +389,7 @@ struct PoolP {
 
 __global__ __launch_bounds__(256) void maxpool_k(const PoolP P) {
     const int groups = P.c >> 3;
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long idx = (long long)dd_xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     if (idx >= (long long)P.m * groups) return;
     const int g = (int)(idx % groups);
     const int m = (int)(idx / groups);

@@ -88,7 +88,7 @@ class Program:
             else:
                 w[names[k]] = v
         self.ops.append(w)
-        self.info.append(dict(kernel='?', flops=0, bytes=0))
+        self.info.append(dict(kernel='?', flops=0, bytes=0, wbytes=0))
 
     # ---- ops
     def input(self, swap_rb, mean=0.0, scale=1.0, s2d=False):
@@ -139,8 +139,9 @@ class Program:
         self._op(OP_CONV, src=src, dst=dst, res=res, dst2=dst2, **kw_)
         self.info[-1] = dict(kernel=('conv_mfma_k<4,1,1,2,%d>' if cout_pad <= 32 else 'conv_mfma_k<2,2,2,2,%d>') % bk,
                              flops=2 * ho * wo * kh * kw * cin * cout,
-                             bytes=2 * (s['h'] * s['w'] * cin + kh * kw * cin * cout) + (4 if epi != EPI_F16 else 2) * ho * wo * cout
-                             + (2 * ho * wo * cout if res >= 0 else 0) + (2 * ho * wo * cout if dst2 >= 0 else 0))
+                             bytes=2 * s['h'] * s['w'] * cin + (4 if epi != EPI_F16 else 2) * ho * wo * cout
+                             + (2 * ho * wo * cout if res >= 0 else 0) + (2 * ho * wo * cout if dst2 >= 0 else 0),
+                             wbytes=2 * kh * kw * cin * cout + 4 * cout)
         return dst
 
     def dwconv(self, src, w_hwc, bias, stride, act, pad=None):
@@ -162,7 +163,7 @@ class Program:
         dst = self.tensor(ho, wo, c)
         self._op(OP_DWCONV, src=src, dst=dst, stride=stride, pad_t=pt, pad_l=pl, cout_pad=cp, act=act,
                  w_off=self.add_blob(wp), b_off=self.add_blob(bp))
-        self.info[-1] = dict(kernel='dwconv3_k', flops=2 * ho * wo * 9 * c, bytes=2 * (s['h'] * s['w'] * c + ho * wo * c + 9 * c))
+        self.info[-1] = dict(kernel='dwconv3_k', flops=2 * ho * wo * 9 * c, bytes=2 * (s['h'] * s['w'] * c + ho * wo * c), wbytes=2 * 9 * c + 4 * c)
         return dst
 
     def maxpool(self, src, k, stride, pad, dst=None):
@@ -172,7 +173,7 @@ class Program:
         if dst is None:
             dst = self.tensor(ho, wo, s['c'])
         self._op(OP_MAXPOOL, src=src, dst=dst, kh=k, stride=stride, pad_t=pad, cout_pad=rup(s['c'], 8))
-        self.info[-1] = dict(kernel='maxpool_k', flops=0, bytes=2 * s['c'] * (s['h'] * s['w'] + ho * wo))
+        self.info[-1] = dict(kernel='maxpool_k', flops=0, bytes=2 * s['c'] * (s['h'] * s['w'] + ho * wo), wbytes=0)
         return dst
 
     def upsample2(self, src, dst):

@@ -38,7 +38,7 @@ def profile_nets(run_once, nets_with_batch, reps=20):
                 b = batch() if callable(batch) else batch
                 for t, info in zip(ms, net.program.info):
                     k = acc.setdefault(info['kernel'], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
-                    k['ms'] += float(t); k['flops'] += info['flops'] * b; k['bytes'] += info['bytes'] * b; k['launches'] += 1
+                    k['ms'] += float(t); k['flops'] += info['flops'] * b; k['bytes'] += info['bytes'] * b + info.get('wbytes', 0); k['launches'] += 1
     finally:
         for _, net, _ in nets_with_batch:
             check(lib().dd_net_profile(net._h, 0), 'dd_net_profile')

@@ -29,7 +29,7 @@ acc /= reps
 tot = 0
 print(f'{kind} batch {batch}: op  kernel  ms  GFLOP  MB  TFLOP/s  GB/s')
 for i, (ms, info, op) in enumerate(zip(acc, prog.info, prog.ops)):
-    fl, by = info['flops'] * batch, info['bytes'] * batch
+    fl, by = info['flops'] * batch, info['bytes'] * batch + info.get('wbytes', 0)
     tot += ms
     print(f'{i:3d} {info["kernel"]:22s} {ms*1e3:8.1f}us {fl/1e9:8.3f} {by/1e6:8.2f} {fl/ms/1e9 if ms else 0:8.1f} {by/ms/1e6 if ms else 0:8.1f}  k={op[5]}x{op[6]} s={op[7]} cin={op[10]} cout={op[11]} hw={op[26]}x{op[27]}')
 print('total ms', tot, 'GFLOP', sum(i['flops'] for i in prog.info) * batch / 1e9)
