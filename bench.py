@@ -36,26 +36,45 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--streams', type=int, default=int(os.environ.get('DD_BENCH_STREAMS', '64')),
+    ap.add_argument('--streams', type=int, default=int(os.environ.get('DD_BENCH_STREAMS', '128')),
                     help='independent video streams per GPU (one frame of each per step)')
+    ap.add_argument('--groups', type=int, default=int(os.environ.get('DD_BENCH_GROUPS', '4')),
+                    help='worker threads per GPU: the streams are split into this many pipelines, each with its own '
+                         'HIP stream, so one group\'s host phases (LSAP, count line) overlap the other\'s kernels')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-frames', type=int, default=300)
     return ap.parse_args()
 
 
-def make_inputs(rank, streams, n_frames):
-    """-> frames u8 [F, S, H, W, 3] (host, filled in place) and per-stream per-frame injected detections."""
+def _gen_stream(args):
+    seed, n_frames = args
     from deepdish_amd.synth import Scene
+    sc = Scene(seed=seed, n_obj=N_OBJ, width=W, height=H, n_frames=n_frames)
+    frames = np.stack([sc.frame(f) for f in range(n_frames)])
+    per = []
+    for f in range(n_frames):
+        boxes, scores, who, _ = sc.detections(f)
+        per.append(([tuple(int(v) for v in b) for b in boxes], ['person'] * len(boxes), [float(x) for x in scores]))
+    return frames, per
+
+
+def make_inputs(rank, streams, n_frames):
+    """-> frames u8 [F, S, H, W, 3] (host) and per-stream per-frame injected detections (seeded, untimed)."""
+    import multiprocessing as mp
     frames = np.empty((n_frames, streams, H, W, 3), dtype=np.uint8)
-    dets = []
-    for s in range(streams):
-        sc = Scene(seed=1000 * rank + s, n_obj=N_OBJ, width=W, height=H, n_frames=n_frames)
-        per = []
-        for f in range(n_frames):
-            frames[f, s] = sc.frame(f)
-            boxes, scores, who, _ = sc.detections(f)
-            per.append(([tuple(int(v) for v in b) for b in boxes], ['person'] * len(boxes), [float(x) for x in scores]))
-        dets.append(per)
+    dets = [None] * streams
+    jobs = [(1000 * rank + s, n_frames) for s in range(streams)]
+    workers = max(1, min(16, (os.cpu_count() or 2) // 2, streams))
+    if workers > 1:
+        with mp.get_context('spawn').Pool(workers) as pool:
+            for s, (fr, per) in enumerate(pool.imap(_gen_stream, jobs)):
+                frames[:, s] = fr
+                dets[s] = per
+    else:
+        for s, job in enumerate(jobs):
+            fr, per = _gen_stream(job)
+            frames[:, s] = fr
+            dets[s] = per
     return frames, dets
 
 
@@ -110,35 +129,48 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
+    import threading
     from deepdish_amd.multipipe import MultiStreamPipeline
-    from deepdish_amd.runtime import default_context
-    ctx = default_context()
+    from deepdish_amd.runtime import Context
     n_frames = args.warmup + args.steps
+    G = max(1, min(args.groups, args.streams))
+    bounds = [round(g * args.streams / G) for g in range(G + 1)]
     frames, dets = make_inputs(rank, args.streams, n_frames)
-    pipe = MultiStreamPipeline(args.streams, context=ctx)
-    # frames resident in HBM before the timed region: [F][S][H][W][3]
-    dev_frames = torch.from_numpy(frames).to(f'cuda:{local_rank}')
+    ctxs = [Context(local_rank) for _ in range(G)]
+    pipes = [MultiStreamPipeline(bounds[g + 1] - bounds[g], context=ctxs[g]) for g in range(G)]
+    # frames resident in HBM before the timed region: per group [F][S_g][H][W][3]
+    dev_frames = [torch.from_numpy(np.ascontiguousarray(frames[:, bounds[g]:bounds[g + 1]])).to(f'cuda:{local_rank}')
+                  for g in range(G)]
     del frames
-    injected = [pipe.pack_injected([dets[s][f] for s in range(args.streams)]) for f in range(n_frames)]
+    injected = [[pipes[g].pack_injected([dets[s][f] for s in range(bounds[g], bounds[g + 1])]) for f in range(n_frames)]
+                for g in range(G)]
     torch.cuda.synchronize()
 
-    def step(f):
-        pipe.step(dev_frames[f], injected[f])
+    def run(g, f0, f1):
+        for f in range(f0, f1):
+            pipes[g].step(dev_frames[g][f], injected[g][f])       # blocking C call, releases the GIL
 
-    for f in range(args.warmup):
-        step(f)
-    ctx.sync(); torch.cuda.synchronize()
+    def run_all(f0, f1):
+        if G == 1:
+            return run(0, f0, f1)
+        th = [threading.Thread(target=run, args=(g, f0, f1)) for g in range(G)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+
+    run_all(0, args.warmup)
+    torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
     t0 = time.perf_counter()
-    for f in range(args.warmup, n_frames):
-        step(f)
-    ctx.sync(); torch.cuda.synchronize()
+    run_all(args.warmup, n_frames)
+    torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
     dt = time.perf_counter() - t0
-    stage_ms = pipe.stage_ms()
-    local_counts = pipe.counts().sum(axis=0)
+    stage_ms = pipes[0].stage_ms()
+    local_counts = sum(p.counts().sum(axis=0) for p in pipes)
     tmax = torch.tensor([dt], dtype=torch.float64, device=f'cuda:{local_rank}')
     counts = torch.from_numpy(local_counts).to(f'cuda:{local_rank}')
     if dist_on:
@@ -156,14 +188,15 @@ def main():
             'config': {'workload': 'SSD-MobileNet-v1 (300x300) + MARS-64x32x3 + deep_sort on synthetic 640x480 BGR '
                                    'frames, ~20 synthetic detections/frame (BASELINE.json configs[1])',
                        'streams_per_gpu': args.streams, 'frames_per_step': args.streams * world,
-                       'parallelism': 'independent streams, %d per GPU' % args.streams,
+                       'worker_threads_per_gpu': G,
+                       'parallelism': 'independent streams, %d per GPU in %d worker groups' % (args.streams, G),
                        'weights': 'seeded synthetic (seed 1234)'},
             'counts_pos_neg_int_del': [int(v) for v in counts.cpu().numpy().reshape(-1)],
             'stage_ms_per_step': {k: round(v, 4) for k, v in stage_ms.items() if k != 'steps'},
         }
         try:
             from deepdish_amd.profile import dominant_kernel_roofline
-            out['roofline'] = dominant_kernel_roofline(pipe, lambda f: step(f), args)
+            out['roofline'] = dominant_kernel_roofline(pipes[0], lambda f: pipes[0].step(dev_frames[0][f], injected[0][f]), args)
         except Exception as e:                            # never let the extra pass hide the headline number
             out['roofline'] = None
             out['roofline_error'] = repr(e)

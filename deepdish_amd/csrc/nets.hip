@@ -679,7 +679,7 @@ int dd_net_output(dd_net *n, int tensor, void **dev_ptr, int *h, int *w, int *c,
 int dd_net_profile(dd_net *n, int enable) {
     DD_REQUIRE(n, DD_E_ARG, "dd_net_profile: NULL net");
     if (enable && n->events.empty()) {
-        n->events.resize(n->n_ops + 1);
+        n->events.resize(n->n_ops + 2);                 // + an empty bracket to price the event record itself
         for (auto &e : n->events) DD_HIP(hipEventCreate(&e));
     }
     n->profile = enable != 0;
@@ -690,8 +690,13 @@ int dd_net_profile_read(dd_net *n, float *ms_host, int cap, int *n_ops_host) {
     DD_REQUIRE(n && ms_host && n_ops_host, DD_E_ARG, "dd_net_profile_read: NULL argument");
     DD_REQUIRE(n->profile && !n->events.empty(), DD_E_STATE, "dd_net_profile_read: profiling is off");
     DD_REQUIRE(cap >= n->n_ops, DD_E_ARG, "dd_net_profile_read: cap %d < %d ops", cap, n->n_ops);
-    DD_HIP(hipEventSynchronize(n->events[n->n_ops]));
-    for (int i = 0; i < n->n_ops; ++i) DD_HIP(hipEventElapsedTime(&ms_host[i], n->events[i], n->events[i + 1]));
+    DD_HIP(hipEventSynchronize(n->events[n->n_ops + 1]));
+    float empty = 0.f;                                        // two back-to-back records: what a bracket costs by itself
+    DD_HIP(hipEventElapsedTime(&empty, n->events[n->n_ops], n->events[n->n_ops + 1]));
+    for (int i = 0; i < n->n_ops; ++i) {
+        DD_HIP(hipEventElapsedTime(&ms_host[i], n->events[i], n->events[i + 1]));
+        ms_host[i] = ms_host[i] > empty ? ms_host[i] - empty : 0.f;
+    }
     *n_ops_host = n->n_ops;
     return DD_OK;
 }
@@ -830,7 +835,10 @@ int dd_net_forward(dd_net *net, const uint8_t *input, int nimg, void *stream) {
                 DD_REQUIRE(false, DD_E_ARG, "dd_net_forward: unknown op kind %d at %d", kind, i);
         }
     }
-    if (net->profile) DD_HIP(hipEventRecord(net->events[net->n_ops], s));
+    if (net->profile) {
+        DD_HIP(hipEventRecord(net->events[net->n_ops], s));
+        DD_HIP(hipEventRecord(net->events[net->n_ops + 1], s));
+    }
     return DD_OK;
 }
 

@@ -26,7 +26,11 @@ def net_op_times(net):
 
 def profile_nets(run_once, nets_with_batch, reps=20):
     """run_once() runs one bench step; nets_with_batch: [(name, Net, images per forward)].
-    Returns {kernel: dict(ms, flops, bytes, launches)} averaged per step."""
+    Returns {kernel: dict(ms, flops, bytes, launches)} averaged per step.
+
+    Every op is bracketed by two HIP events on the launch stream.  An event record costs a few
+    microseconds of stream time itself, so each op's interval is corrected by the interval measured
+    for an empty bracket (two back-to-back records) on the same stream."""
     for _, net, _ in nets_with_batch:
         check(lib().dd_net_profile(net._h, 1), 'dd_net_profile')
     acc = {}
@@ -47,6 +51,21 @@ def profile_nets(run_once, nets_with_batch, reps=20):
             k[f] /= reps
         k['launches'] /= reps
     return acc
+
+
+def pmc_traffic(kernel, streams):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (separate --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE passes of this same bench; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
+    None when no summary exists for this stream count -- bench.py cannot run the profiler on itself."""
+    import json, os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'r01_pmc_traffic_s%d.json' % streams)
+    if not os.path.exists(path):
+        return None
+    key = kernel.replace(',', ', ')
+    for k, v in json.load(open(path)).items():
+        if key in k:
+            return v['hbm_read_bytes_corrected'] + v['hbm_write_bytes']
+    return None
 
 
 def dominant_kernel_roofline(pipe, step, args):
@@ -71,7 +90,7 @@ def dominant_kernel_roofline(pipe, step, args):
     else:
         achieved = k['bytes'] / sec / 1e9
         out = dict(bound='hbm', achieved=achieved, peak=PEAK_HBM_GBS, unit='GB/s', frac=achieved / PEAK_HBM_GBS)
-    out.update(kernel=name, traffic=None, launches_per_step=k['launches'],
+    out.update(kernel=name, traffic=pmc_traffic(name, pipe.S), launches_per_step=k['launches'],
                avg_launch_us=1e3 * k['ms'] / max(k['launches'], 1e-9),
                algorithmic_per_step=dict(flops=k['flops'], bytes=k['bytes']),
                per_kernel_ms_per_step={n: round(v['ms'], 5) for n, v in sorted(acc.items(), key=lambda kv: -kv[1]['ms'])})
