@@ -13,6 +13,7 @@
 //   * depthwise 3x3, pooling, upsampling, input conversion as 16-byte-per-lane streaming kernels.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <string>
 #include "common.h"
 
@@ -52,6 +53,7 @@ struct ConvP {
     _Float16 *out2; int cs_out2, coff_out2; const float *aff2; int cout_pad;
     int post_aff;                   // EPI_F32 only: out = aff2.scale * act(v) + aff2.shift
     int splitk; float *slab;        // splitk > 1: raw partial sums go to slab[z][m][cout_pad]
+    const _Float16 *zero;           // >= 16 bytes of zeros: source of out-of-image taps for direct-to-LDS fills
     int p[6]; float f[8];
 };
 
@@ -169,6 +171,56 @@ __device__ __forceinline__ void conv_epilogue_f16x8(const ConvP &P, int m, int c
     }
 }
 
+// Everything after the K loop, shared by the register-staged and the direct-to-LDS kernels.
+template <int WM, int WN, int MI, int NI>
+__device__ __forceinline__ void conv_finish(const ConvP &P, f4 (&acc)[NI][MI], _Float16 *lds, int m0, int n0, int hw) {
+    constexpr int T = WM * WN * 64;
+    constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int fr = lane & 15, fq = lane >> 4;
+    if (P.epi == EPI_F16 && P.splitk == 1) {
+        // ---- transpose the accumulators through LDS (f32) so that stores are 16 bytes per lane and whole
+        // 128-byte lines per pixel; the staging buffers are free after the loop's last barrier.
+        constexpr int OROW = BN + 4;                              // floats per staged pixel row
+        float *ot = reinterpret_cast<float *>(lds);
+#pragma unroll
+        for (int b = 0; b < MI; ++b)
+#pragma unroll
+            for (int a = 0; a < NI; ++a)
+                *reinterpret_cast<f4 *>(ot + ((wm * MI + b) * 16 + fr) * OROW + (wn * NI + a) * 16 + fq * 4) = acc[a][b];
+        __syncthreads();
+        constexpr int G = BN / 8;                                 // 8-channel groups per pixel row
+        for (int t = tid; t < BM * G; t += T) {
+            const int pl = t / G, g = t - pl * G;
+            const int m = m0 + pl, co = n0 + g * 8;
+            if (m >= P.m || co >= P.cout_pad) continue;
+            const f4 lo = *reinterpret_cast<const f4 *>(ot + pl * OROW + g * 8);
+            const f4 hi = *reinterpret_cast<const f4 *>(ot + pl * OROW + g * 8 + 4);
+            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            conv_epilogue_f16x8(P, m, co, v);
+        }
+        return;
+    }
+    // ---- lane holds channels co..co+3 of pixel m
+#pragma unroll
+    for (int b = 0; b < MI; ++b) {
+        const int m = m0 + (wm * MI + b) * 16 + fr;
+        if (m >= P.m) continue;
+#pragma unroll
+        for (int a = 0; a < NI; ++a) {
+            const int co = n0 + (wn * NI + a) * 16 + fq * 4;
+            if (co >= P.cout_pad) continue;
+            if (P.splitk > 1) {
+                *reinterpret_cast<f4 *>(P.slab + ((size_t)blockIdx.z * P.m + m) * P.cout_pad + co) = acc[a][b];
+            } else {
+                float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
+                conv_epilogue(P, m, co, v, hw);
+            }
+        }
+    }
+}
+
 // Block tile: (WM*MI*16) pixels x (WN*NI*16) output channels, K step BK (32 for shallow K, else 64:
 // two MFMA k-slices per barrier); blockIdx.z = K split.  Staged rows carry 8 halves of padding.
 template <int WM, int WN, int MI, int NI, int BK>
@@ -281,46 +333,108 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_mfma_k(const ConvP P) {
         }
     }
 
-    if (P.epi == EPI_F16 && P.splitk == 1) {
-        // ---- transpose the accumulators through LDS (f32) so that stores are 16 bytes per lane and whole
-        // 128-byte lines per pixel; the staging buffers are free after the loop's last barrier.
-        constexpr int OROW = BN + 4;                              // floats per staged pixel row
-        float *ot = reinterpret_cast<float *>(lds);
+    conv_finish<WM, WN, MI, NI>(P, acc, lds, m0, n0, hw);
+}
+
+// global_load_lds_dwordx4: each lane moves 16 bytes from its own global address to
+// (wave-uniform LDS base) + lane * 16.  The builtin only exists in the device pass of hipcc.
+__device__ __forceinline__ void lds_fill16(const _Float16 *g, _Float16 *lds_wave_base) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_global_load_lds(g, lds_wave_base, 16, 0, 0);
+#endif
+}
+
+// Direct-to-LDS variant for layers whose padded Cin is a multiple of 64 (every K step of 64 then lies
+// inside one filter tap and is one 128-byte line per pixel / per output channel).  Operand tiles go
+// HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR staging, no ds_write); one wave instruction fills
+// eight consecutive 128-byte rows.  Rows are unpadded, so the 16-byte chunks of a row are XOR-swizzled
+// with (row & 7) -- on the SOURCE address for the fill and on the ds_read_b128 address for the
+// fragments -- which makes every 16-lane read group hit 16 distinct 4-bank groups.
+template <int WM, int WN, int MI, int NI>
+__global__ __launch_bounds__(WM *WN * 64) void conv_glds_k(const ConvP P) {
+    constexpr int NW = WM * WN;
+    constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
+    constexpr int XG = BM / 8 / NW, WG = BN / 8 / NW;           // 8-row groups per wave
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split into 8-row groups per wave");
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];         // [2][BM + BN][64] halves
+    _Float16 *xs = lds, *ws = lds + 2 * BM * 64;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const unsigned lin = dd_xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+    const int m0 = (int)(lin % gridDim.x) * BM, n0 = (int)(lin / gridDim.x) * BN;
+    const int hw = P.ho * P.wo;
+    const int ksteps = P.kpad >> 6;
+    const int per = (ksteps + P.splitk - 1) / P.splitk;
+    const int ks0 = blockIdx.z * per, ks1 = min(ksteps, ks0 + per);
+
+    const int rr = lane >> 3, pp = lane & 7;                    // row inside the 8-row group, LDS chunk position
+    const int gchunk = (pp ^ rr) * 8;                           // which 8 halves of the global row land there
+    int x_n[XG], x_iy0[XG], x_ix0[XG];
+    bool x_ok[XG];
 #pragma unroll
-        for (int b = 0; b < MI; ++b)
-#pragma unroll
-            for (int a = 0; a < NI; ++a)
-                *reinterpret_cast<f4 *>(ot + ((wm * MI + b) * 16 + fr) * OROW + (wn * NI + a) * 16 + fq * 4) = acc[a][b];
-        __syncthreads();
-        constexpr int G = BN / 8;                                 // 8-channel groups per pixel row
-        for (int t = tid; t < BM * G; t += T) {
-            const int pl = t / G, g = t - pl * G;
-            const int m = m0 + pl, co = n0 + g * 8;
-            if (m >= P.m || co >= P.cout_pad) continue;
-            const f4 lo = *reinterpret_cast<const f4 *>(ot + pl * OROW + g * 8);
-            const f4 hi = *reinterpret_cast<const f4 *>(ot + pl * OROW + g * 8 + 4);
-            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            conv_epilogue_f16x8(P, m, co, v);
-        }
-        return;
+    for (int i = 0; i < XG; ++i) {
+        const int m = m0 + (wave * XG + i) * 8 + rr;
+        x_ok[i] = m < P.m;
+        const int mm = x_ok[i] ? m : 0;
+        x_n[i] = mm / hw;
+        const int r = mm - x_n[i] * hw;
+        const int oy = r / P.wo, ox = r - oy * P.wo;
+        x_iy0[i] = oy * P.stride - P.pad_t;
+        x_ix0[i] = ox * P.stride - P.pad_l;
     }
-    // ---- lane holds channels co..co+3 of pixel m
+    const _Float16 *wbase[WG];
 #pragma unroll
-    for (int b = 0; b < MI; ++b) {
-        const int m = m0 + (wm * MI + b) * 16 + fr;
-        if (m >= P.m) continue;
+    for (int i = 0; i < WG; ++i) wbase[i] = P.w + (size_t)(n0 + (wave * WG + i) * 8 + rr) * P.kpad + gchunk;
+
+    auto fill = [&](int ks, int buf) {
+        const int k = ks << 6;
+        const int tap = k / P.cin, c0 = k - tap * P.cin;        // uniform: cin % 64 == 0
+        const int kh = tap / P.kw, kw = tap - kh * P.kw;
 #pragma unroll
-        for (int a = 0; a < NI; ++a) {
-            const int co = n0 + (wn * NI + a) * 16 + fq * 4;
-            if (co >= P.cout_pad) continue;
-            if (P.splitk > 1) {
-                *reinterpret_cast<f4 *>(P.slab + ((size_t)blockIdx.z * P.m + m) * P.cout_pad + co) = acc[a][b];
-            } else {
-                float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
-                conv_epilogue(P, m, co, v, hw);
+        for (int i = 0; i < XG; ++i) {
+            const int iy = x_iy0[i] + kh, ix = x_ix0[i] + kw;
+            const bool ok = x_ok[i] && kh < P.kh && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
+            const _Float16 *g = ok ? P.in + ((size_t)(x_n[i] * P.H + iy) * P.W + ix) * P.cs_in + P.coff_in + c0 + gchunk
+                                   : P.zero;
+            lds_fill16(g, xs + (size_t)(buf * BM + (wave * XG + i) * 8) * 64);
+        }
+#pragma unroll
+        for (int i = 0; i < WG; ++i) lds_fill16(wbase[i] + k, ws + (size_t)(buf * BN + (wave * WG + i) * 8) * 64);
+    };
+
+    f4 acc[NI][MI];
+#pragma unroll
+    for (int a = 0; a < NI; ++a)
+#pragma unroll
+        for (int b = 0; b < MI; ++b) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fq = lane >> 4, sw = fr & 7;
+    if (ks0 < ks1) {
+        fill(ks0, 0);
+        __syncthreads();                                          // waits for the fills (vmcnt(0) before s_barrier)
+        for (int ks = ks0; ks < ks1; ++ks) {
+            const int buf = (ks - ks0) & 1;
+            if (ks + 1 < ks1) fill(ks + 1, buf ^ 1);              // lands while this step's MFMAs run
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                h8 xf[MI], wf[NI];
+#pragma unroll
+                for (int b = 0; b < MI; ++b)
+                    xf[b] = *reinterpret_cast<const h8 *>(xs + (size_t)(buf * BM + (wm * MI + b) * 16 + fr) * 64 + (((kk << 2) + fq) ^ sw) * 8);
+#pragma unroll
+                for (int a = 0; a < NI; ++a)
+                    wf[a] = *reinterpret_cast<const h8 *>(ws + (size_t)(buf * BN + (wn * NI + a) * 16 + fr) * 64 + (((kk << 2) + fq) ^ sw) * 8);
+#pragma unroll
+                for (int a = 0; a < NI; ++a)
+#pragma unroll
+                    for (int b = 0; b < MI; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[a], xf[b], acc[a][b], 0, 0, 0);
             }
+            __syncthreads();
         }
     }
+    conv_finish<WM, WN, MI, NI>(P, acc, lds, m0, n0, hw);
 }
 
 // Split-K tail: sum the partial slabs in a fixed order (bitwise reproducible) and run the epilogue.
@@ -548,6 +662,8 @@ struct dd_net {
     bool profile = false;
     int last_batch = 0;
     DevBuf slab;                             // split-K partial sums
+    _Float16 *d_zero = nullptr;              // 256 bytes of zeros (padding taps of the direct-to-LDS fills)
+    bool use_glds = true;
     std::vector<hipEvent_t> events;           // n_ops + 1 when profiling
 };
 
@@ -557,7 +673,8 @@ inline size_t dtype_size(int dt) { return dt == DT_F16 ? 2 : (dt == DT_F32 ? 4 :
 
 // Few blocks and a long K axis: split K over blockIdx.z so the chip is busy and each block's serial
 // chain of (load -> barrier -> MFMA) steps is short; partial sums go through an f32 slab.
-template <int WM, int WN, int MI, int NI, int BK>
+// GLDS selects the direct-to-LDS kernel (needs padded Cin % 64 == 0 and BK == 64).
+template <int WM, int WN, int MI, int NI, int BK, bool GLDS>
 int launch_conv(hipStream_t s, ConvP &P, DevBuf &slab) {
     constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
     const int gx = dd_ceil_div(P.m, BM), gy = dd_ceil_div(P.cout_pad, BN);
@@ -578,16 +695,23 @@ int launch_conv(hipStream_t s, ConvP &P, DevBuf &slab) {
         if (rc != DD_OK) return rc;
         P.slab = slab.as<float>();
     }
-    constexpr size_t stage_bytes = (size_t)2 * (BM + BN) * (BK + 8) * sizeof(_Float16);
+    constexpr size_t stage_bytes = (size_t)2 * (BM + BN) * (GLDS ? 64 : BK + 8) * sizeof(_Float16);
     constexpr size_t out_bytes = (size_t)BM * (BN + 4) * sizeof(float);
     constexpr size_t lds_bytes = stage_bytes > out_bytes ? stage_bytes : out_bytes;
     static bool attr_done = false;                            // > 64 KiB of LDS needs the opt-in attribute
     if (!attr_done && lds_bytes > 65536) {
-        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_k<WM, WN, MI, NI, BK>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        if constexpr (GLDS)
+            DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_glds_k<WM, WN, MI, NI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        else
+            DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_k<WM, WN, MI, NI, BK>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_mfma_k<WM, WN, MI, NI, BK>), dim3(gx, gy, splitk), dim3(WM * WN * 64), lds_bytes, s, P);
+    if constexpr (GLDS)
+        hipLaunchKernelGGL((conv_glds_k<WM, WN, MI, NI>), dim3(gx, gy, splitk), dim3(WM * WN * 64), lds_bytes, s, P);
+    else
+        hipLaunchKernelGGL((conv_mfma_k<WM, WN, MI, NI, BK>), dim3(gx, gy, splitk), dim3(WM * WN * 64), lds_bytes, s, P);
     DD_LAUNCH_CHECK();
     if (splitk > 1) {
         const long long total = (long long)P.m * (P.cout_pad >> 2);
@@ -633,6 +757,9 @@ int dd_net_create(dd_ctx *ctx, const int32_t *program_host, int n_words, const v
     n->n_ops = no;
     n->ops_off = (int)(p - program_host);
     n->weight_bytes = n_weight_bytes;
+    DD_HIP(hipMalloc(&n->d_zero, 256));
+    DD_HIP(hipMemset(n->d_zero, 0, 256));
+    n->use_glds = getenv("DD_NO_GLDS") == nullptr;
     DD_HIP(hipMalloc(&n->d_weights, (size_t)n_weight_bytes + 256));
     DD_HIP(hipMemcpy(n->d_weights, weights_host, (size_t)n_weight_bytes, hipMemcpyHostToDevice));
     *out = n;
@@ -644,6 +771,7 @@ int dd_net_destroy(dd_net *n) {
     for (void *b : n->bufs) (void)hipFree(b);
     for (hipEvent_t e : n->events) (void)hipEventDestroy(e);
     n->slab.release();
+    (void)hipFree(n->d_zero);
     (void)hipFree(n->d_weights);
     delete n;
     return DD_OK;
@@ -769,13 +897,17 @@ int dd_net_forward(dd_net *net, const uint8_t *input, int nimg, void *stream) {
                 for (int q = 0; q < 8; ++q) P.f[q] = of[32 + q];
                 int rc;
                 const bool bk32 = o[28] == 32;                 // shallow K (<= 96): one or few 32-wide steps
-                // A 128 x 128 tile (4 x 4 MFMA tiles per wave) was measured at HALF the speed of the 64 x 64 tile
-                // here (19x19x512 -> 512 at 64 frames: 110 us vs 51 us): 74 KiB of LDS leaves two blocks per CU and
-                // this loop has only one K step of prefetch.  Kept compiled for the next round's pipelined version.
-                const bool big = false && !bk32 && P.epi == EPI_F16 && P.cout_pad >= 128 && P.m >= 16384;
-                if (P.cout_pad <= 32) rc = bk32 ? launch_conv<4, 1, 1, 2, 32>(s, P, net->slab) : launch_conv<4, 1, 1, 2, 64>(s, P, net->slab);
-                else if (big) rc = launch_conv<2, 2, 4, 4, 64>(s, P, net->slab);
-                else rc = bk32 ? launch_conv<2, 2, 2, 2, 32>(s, P, net->slab) : launch_conv<2, 2, 2, 2, 64>(s, P, net->slab);
+                const bool glds = !bk32 && P.cin % 64 == 0 && net->use_glds;   // every 64-wide K step inside one tap
+                P.zero = net->d_zero;
+                if (P.cout_pad <= 32) {
+                    rc = bk32 ? launch_conv<4, 1, 1, 2, 32, false>(s, P, net->slab)
+                       : glds ? launch_conv<4, 1, 1, 2, 64, true>(s, P, net->slab)
+                              : launch_conv<4, 1, 1, 2, 64, false>(s, P, net->slab);
+                } else {
+                    rc = bk32 ? launch_conv<2, 2, 2, 2, 32, false>(s, P, net->slab)
+                       : glds ? launch_conv<2, 2, 2, 2, 64, true>(s, P, net->slab)
+                              : launch_conv<2, 2, 2, 2, 64, false>(s, P, net->slab);
+                }
                 if (rc != DD_OK) return rc;
                 break;
             }
