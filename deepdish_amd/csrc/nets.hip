@@ -235,9 +235,11 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_mfma_k(const ConvP P) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    // logical tile order: pixel tiles fastest within one channel tile, one contiguous slice per XCD
+    // logical tile order: one contiguous slice per XCD, and inside it all channel tiles of a pixel tile
+    // back to back -- the pixel tile is then fetched from HBM once and re-read by the other channel
+    // tiles from that XCD's L2 (the weights, a few hundred KiB, stay L2-resident anyway)
     const unsigned lin = dd_xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
-    const int m0 = (int)(lin % gridDim.x) * BM, n0 = (int)(lin / gridDim.x) * BN;
+    const int m0 = (int)(lin / gridDim.y) * BM, n0 = (int)(lin % gridDim.y) * BN;
     const int hw = P.ho * P.wo;
     const int ksteps = P.kpad / BK;
     const int per = (ksteps + P.splitk - 1) / P.splitk;
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_glds_k(const ConvP P) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const unsigned lin = dd_xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
-    const int m0 = (int)(lin % gridDim.x) * BM, n0 = (int)(lin / gridDim.x) * BN;
+    const int m0 = (int)(lin / gridDim.y) * BM, n0 = (int)(lin % gridDim.y) * BN;      // channel tiles fastest (see conv_mfma_k)
     const int hw = P.ho * P.wo;
     const int ksteps = P.kpad >> 6;
     const int per = (ksteps + P.splitk - 1) / P.splitk;
