@@ -196,7 +196,7 @@ def main():
         }
         try:
             from deepdish_amd.profile import dominant_kernel_roofline
-            out['roofline'] = dominant_kernel_roofline(pipes[0], lambda f: pipes[0].step(dev_frames[0][f], injected[0][f]), args)
+            out['roofline'] = dominant_kernel_roofline(pipes, lambda g, f: pipes[g].step(dev_frames[g][f], injected[g][f]), args)
         except Exception as e:                            # never let the extra pass hide the headline number
             out['roofline'] = None
             out['roofline_error'] = repr(e)
