@@ -34,6 +34,7 @@ SIGNATURES = {
     'dd_nms': [P, P, P, c_int, c_double, P, P, P],
     'dd_nms_ssd': [P, P, P, c_int, c_double, P, P, P],
     'dd_lsap_host': [P, c_int, c_int, P, P],
+    'dd_pyset_difference_order_host': [P, c_int, P, c_int, P, POINTER(c_int)],
     'dd_tracker_create': [P, c_double, c_double, c_int, c_int, c_int, c_int, c_int, POINTER(P)],
     'dd_tracker_destroy': [P],
     'dd_tracker_predict': [P],

@@ -115,6 +115,7 @@ size_t ssd_post_scratch_bytes(int n_anchors, int batch);
 int ssd_postprocess(hipStream_t s, const float *raw, const float *anchors, int n_anchors, int n_classes, int max_det,
                     float score_thr, float iou_thr, float *boxes, float *classes, float *scores, int *count, int batch,
                     void *scratch, size_t scratch_bytes);
+void pyset_difference_order(const std::vector<int> &a, const std::vector<int> &b, std::vector<int> &out);
 int lsap(const double *cost, int nr, int nc, int *rows, int *cols);   // host; returns pair count or -1
 int gather_state(hipStream_t s, const double *means, const double *covs, const int *slots, int n,
                  double *out_means, double *out_covs);

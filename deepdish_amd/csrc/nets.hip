@@ -585,44 +585,6 @@ __global__ __launch_bounds__(256) void input_k(const uint8_t *__restrict__ src, 
     }
 }
 
-// Small-M fully connected: out[n][co] = act(bias + sum_k x[n][k] w[co][k]) then optional second
-// affine; one wave per output channel, lanes split K in 16-byte pieces, NB rows per pass.
-__global__ __launch_bounds__(256) void fc_k(const _Float16 *__restrict__ x, int n_rows, int k, const _Float16 *__restrict__ w,
-                                            const float *__restrict__ bias, int cout, int act, const float *__restrict__ aff2,
-                                            float *__restrict__ out, int ld_out) {
-    constexpr int NB = 8;
-    const int co = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
-    if (co >= cout) return;
-    const _Float16 *wrow = w + (size_t)co * k;
-    for (int n0 = 0; n0 < n_rows; n0 += NB) {
-        float acc[NB];
-#pragma unroll
-        for (int i = 0; i < NB; ++i) acc[i] = 0.f;
-        for (int kk = lane * 8; kk < k; kk += 64 * 8) {
-            const h8 wv = *reinterpret_cast<const h8 *>(wrow + kk);
-#pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const int n = min(n0 + i, n_rows - 1);
-                const h8 xv = *reinterpret_cast<const h8 *>(x + (size_t)n * k + kk);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[i] += (float)xv[j] * (float)wv[j];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            float v = acc[i];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-            if (lane == 0 && n0 + i < n_rows) {
-                v = apply_act(v + bias[co], act);
-                if (aff2) v = aff2[co] * v + aff2[cout + co];
-                out[(size_t)(n0 + i) * ld_out + co] = v;
-            }
-        }
-    }
-}
-
 // x / sqrt(eps + sum x^2) over rows of `c` f32 (c <= 256); one wave per row.
 __global__ __launch_bounds__(256) void l2norm_k(const float *__restrict__ in, int n_rows, int c, float eps, float *__restrict__ out) {
     const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -943,18 +905,6 @@ int dd_net_forward(dd_net *net, const uint8_t *input, int nimg, void *stream) {
                 hipLaunchKernelGGL(upsample2_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
                                    reinterpret_cast<const _Float16 *>(base(src)), ts->h, ts->w, ts->cs, ts->coff, o[12], m,
                                    reinterpret_cast<_Float16 *>(base(dst)), td->cs, td->coff);
-                DD_LAUNCH_CHECK();
-                break;
-            }
-            case OP_FC: {
-                // src viewed as [n][k] f16 with k = h*w*cs (cs == c required), dst f32 [n][cout]
-                const int k = ts->h * ts->w * ts->cs;
-                const float *aff2 = o[18] >= 0 && o[19] ? reinterpret_cast<const float *>(net->d_weights + (size_t)(uint32_t)o[18]) : nullptr;
-                hipLaunchKernelGGL(fc_k, dim3(dd_ceil_div(o[11], 4)), dim3(256), 0, s,
-                                   reinterpret_cast<const _Float16 *>(base(src)) + ts->coff, nimg, k,
-                                   reinterpret_cast<const _Float16 *>(net->d_weights + (size_t)(uint32_t)o[16]),
-                                   reinterpret_cast<const float *>(net->d_weights + (size_t)(uint32_t)o[17]), o[11], o[14], aff2,
-                                   reinterpret_cast<float *>(base(dst)) + td->coff, td->cs);
                 DD_LAUNCH_CHECK();
                 break;
             }

@@ -379,13 +379,14 @@ int trackers_update_match(dd_tracker **ts, int S) {
                 min_cost_matching(app, n, t->max_cos, lvl_rows, un_dets, matches, tmp_rows, tmp_dets);
                 un_dets = tmp_dets;
             }
-            std::vector<char> matched_row(T, 0);
-            for (auto &m : matches) matched_row[m.first] = 1;
-            // set(track_indices) - matched: ascending row order here (the reference's order is CPython's
-            // set iteration order; it only permutes LSAP rows, see DESIGN.md "known order dependence")
+            // unmatched_tracks_a = list(set(track_indices) - set(k for k, _ in matches)) (linear_assignment.py:140):
+            // the reference's order is CPython's set iteration order, reproduced by csrc/pyset.cpp, because it
+            // becomes the row order of the IoU assignment below (tracker.py:120-123).
+            std::vector<int> matched_rows, un_a_all;
+            for (auto &m : matches) matched_rows.push_back(m.first);
+            ddk::pyset_difference_order(confirmed, matched_rows, un_a_all);
             std::vector<int> iou_rows = unconfirmed, un_rows_a;
-            for (int k : confirmed) {
-                if (matched_row[k]) continue;
+            for (int k : un_a_all) {
                 if (t->tracks[k].tsu == 1) iou_rows.push_back(k); else un_rows_a.push_back(k);
             }
             std::vector<int> un_rows_b;

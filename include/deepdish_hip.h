@@ -99,6 +99,12 @@ int dd_nms_ssd(dd_ctx *ctx, const double *xyxy, const double *scores, int k, dou
  * Crouse 2016).  Host code.  row_ind/col_ind get min(nr,nc) pairs sorted by row. */
 int dd_lsap_host(const double *cost_host, int nr, int nc, int *row_ind_host, int *col_ind_host);
 
+/* Iteration order of Python's list(set(a) - set(b)) for small non-negative ints (CPython 3.10 set
+ * layout): deep_sort/linear_assignment.py:140 feeds that order into the IoU stage (tracker.py:120-123),
+ * where it decides new-track-id order under cost ties.  Host code; exported for tests. */
+int dd_pyset_difference_order_host(const int *a_host, int na, const int *b_host, int nb, int *out_host,
+                                   int *out_n_host);
+
 /* ---------------------------------------------------------------- tracker (state in HBM)
  * deep_sort/tracker.py:40-138 Tracker + track.py:67-196 Track state machine +
  * linear_assignment.py:11-190 (threshold, LSAP, cascade, gating) + nn_matching.py:137-154

@@ -272,3 +272,65 @@ def test_multistream_720p_streams():
         want = np.array([[t.track_id, t.state, t.time_since_update, t.hits, t.age] for t in otrk[z].tracks], dtype=np.int64)
         np.testing.assert_array_equal(ints[:, :5], want.reshape(-1, 5))
         np.testing.assert_array_equal(mp.counts()[z], ocnt[z].vector())
+
+
+def test_multistream_ragged_and_empty_inputs():
+    """Streams with no detections, one detection, and detections that vanish mid-run; a frame with no
+    detections anywhere; NaN boxes (the whole frame's boxes are dropped, deepdish.py:947)."""
+    from deepdish_amd.multipipe import MultiStreamPipeline
+    from deepdish_amd.synth import Scene
+    from oracle import deepsort_np as ds, countline_np as cl, image_np, nets_torch
+    S, F = 3, 14
+    sc = Scene(seed=77, n_obj=6, n_frames=F, p_miss=0.0, churn=False)
+    mp = MultiStreamPipeline(S, run_detector=False)
+    otrk = [ds.Tracker(ds.Metric(0.2), max_iou_distance=0.7, max_age=60) for _ in range(S)]
+    for f in range(F):
+        frame = sc.frame(f)
+        boxes, scores, _, _ = sc.detections(f)
+        full = ([tuple(int(v) for v in b) for b in boxes], ['person'] * len(boxes), [float(s) for s in scores])
+        per = [full if f not in (5, 6) else ([], [], []),              # stream 0: nothing on frames 5-6
+               ([], [], []),                                            # stream 1: never anything
+               (full[0][:1], full[1][:1], full[2][:1]) if f < 9 else ([], [], [])]   # stream 2: one box, then gone
+        if f == 3:                                                      # NaN anywhere -> every box of that stream dropped
+            per[0] = ([(float('nan'), 1.0, 2.0, 3.0)] + full[0], ['person'] + full[1], [0.9] + full[2])
+        frames = np.stack([frame] * S)
+        mp.step(torch.from_numpy(frames).cuda(), mp.pack_injected(per))
+        for z in range(S):
+            b, l, s = per[z]
+            if f == 3 and z == 0:
+                b, l, s = [], [], []
+            bb = np.array(b, dtype=np.int64).reshape(-1, 4)
+            keep = ds.non_max_suppression(bb, 0.6, np.array(s)) if len(b) else []
+            dets = []
+            if keep:
+                patches = np.stack([image_np.extract_image_patch(frame, bb[i], (64, 32)) for i in keep])
+                feats = nets_torch.mars_forward(mp.enc_weights, patches)
+                dets = [ds.Det(bb[i], 'person', s[i], feats[j]) for j, i in enumerate(keep)]
+            otrk[z].predict(); otrk[z].update(dets)
+            ints, _ = mp.tracker(z).table()
+            want = np.array([[t.track_id, t.state, t.time_since_update, t.hits, t.age] for t in otrk[z].tracks],
+                            dtype=np.int64).reshape(-1, 5)
+            np.testing.assert_array_equal(ints[:, :5], want, err_msg=f'frame {f} stream {z}')
+    assert len(otrk[1].tracks) == 0 and len(otrk[0].tracks) > 0
+
+
+def test_clean_boxes_and_hygiene_in_cpp_match():
+    """Oversized / out-of-frame / fractional boxes go through the same int(clip()) path in the Python
+    harness and in the C++ pipeline: both feed the tracker identical integer boxes."""
+    from deepdish_amd.multipipe import MultiStreamPipeline
+    from deepdish_amd.pipeline import HotPath
+    from deepdish_amd.synth import Scene
+    frame = Scene(seed=8, n_obj=5).frame(0)
+    weird = ([(-10.5, 20.7, 60.2, 130.9), (600.0, 400.0, 100.0, 200.0), (0.0, 0.0, 639.0, 479.0), (100.2, 100.9, 40.5, 90.5)],
+             ['person'] * 4, [0.9, 0.8, 0.7, 0.6])
+    mp = MultiStreamPipeline(1, run_detector=False)
+    hp = HotPath(run_detector=False)
+    fr = torch.from_numpy(frame).cuda()
+    for _ in range(4):
+        mp.step(fr[None], mp.pack_injected([weird]))
+        hp.step(fr, injected=weird)
+    ints, means = mp.tracker(0).table()
+    want = np.array([[t.track_id, t.state, t.time_since_update, t.hits, t.age] for t in hp.tracker.tracks], dtype=np.int64)
+    np.testing.assert_array_equal(ints[:, :5], want)
+    np.testing.assert_allclose(means, np.array([t.mean for t in hp.tracker.tracks]), rtol=1e-12, atol=1e-12)
+    assert len(want) == 3                                               # the 639x479 box exceeds 90 % of the frame
