@@ -462,39 +462,62 @@ struct DwP {
     _Float16 *out; int cs_out, coff_out;
 };
 
+// Each lane produces TX = 4 consecutive output pixels of one row for one 8-channel group: the
+// 3 x (3 + 3*stride) input window is loaded once (18 or 27 sixteen-byte loads instead of 36) and the
+// nine filter taps stay in registers.
+template <int STRIDE>
 __global__ __launch_bounds__(256) void dwconv3_k(const DwP P) {
+    constexpr int TX = 4, NCOL = (TX - 1) * STRIDE + 3;
     const int groups = P.c >> 3;
+    const int wo4 = (P.wo + TX - 1) / TX;
+    const long long total = (long long)(P.m / P.wo) * wo4 * groups;       // m / wo = images * rows
     const long long idx = (long long)dd_xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
-    if (idx >= (long long)P.m * groups) return;
+    if (idx >= total) return;
     const int g = (int)(idx % groups);
-    const int m = (int)(idx / groups);
-    const int hw = P.ho * P.wo;
-    const int n = m / hw, r = m - n * hw;
-    const int oy = r / P.wo, ox = r - oy * P.wo;
-    float acc[8];
+    long long t = idx / groups;
+    const int ox0 = (int)(t % wo4) * TX;
+    t /= wo4;
+    const int oy = (int)(t % P.ho), n = (int)(t / P.ho);
+    float acc[TX][8];
     {
         const f4 b0 = *reinterpret_cast<const f4 *>(P.bias + g * 8), b1 = *reinterpret_cast<const f4 *>(P.bias + g * 8 + 4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { acc[i] = b0[i]; acc[4 + i] = b1[i]; }
+        for (int j = 0; j < TX; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { acc[j][i] = b0[i]; acc[j][4 + i] = b1[i]; }
     }
+    const int ix0 = ox0 * STRIDE - P.pad_l;
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
-        const int iy = oy * P.stride - P.pad_t + kh;
+        const int iy = oy * STRIDE - P.pad_t + kh;
         if (iy < 0 || iy >= P.H) continue;
+        const _Float16 *row = P.in + ((size_t)(n * P.H + iy) * P.W) * P.cs_in + P.coff_in + g * 8;
+        h8 x[NCOL];
+#pragma unroll
+        for (int cx = 0; cx < NCOL; ++cx) {
+            const int ix = ix0 + cx;
+            h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (ix >= 0 && ix < P.W) v = *reinterpret_cast<const h8 *>(row + (size_t)ix * P.cs_in);
+            x[cx] = v;
+        }
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
-            const int ix = ox * P.stride - P.pad_l + kw;
-            if (ix < 0 || ix >= P.W) continue;
-            const h8 x = *reinterpret_cast<const h8 *>(P.in + ((size_t)(n * P.H + iy) * P.W + ix) * P.cs_in + P.coff_in + g * 8);
             const h8 w = *reinterpret_cast<const h8 *>(P.w + (size_t)(kh * 3 + kw) * P.c + g * 8);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] += (float)x[i] * (float)w[i];
+            for (int j = 0; j < TX; ++j)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[j][i] += (float)x[j * STRIDE + kw][i] * (float)w[i];
         }
     }
-    h8 o;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = (_Float16)apply_act(acc[i], P.act);
-    *reinterpret_cast<h8 *>(P.out + (size_t)m * P.cs_out + P.coff_out + g * 8) = o;
+    for (int j = 0; j < TX; ++j) {
+        if (ox0 + j >= P.wo) break;
+        h8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (_Float16)apply_act(acc[j][i], P.act);
+        const size_t m = ((size_t)n * P.ho + oy) * P.wo + ox0 + j;
+        *reinterpret_cast<h8 *>(P.out + m * P.cs_out + P.coff_out + g * 8) = o;
+    }
 }
 
 struct PoolP {
@@ -628,6 +651,7 @@ struct dd_net {
     DevBuf slab;                             // split-K partial sums
     _Float16 *d_zero = nullptr;              // 256 bytes of zeros (padding taps of the direct-to-LDS fills)
     bool use_glds = true;
+    int tile_mode = 0;                       // DD_TILE_MODE=1 forces the 64 x 64 tile everywhere (A/B measurements)
     std::vector<hipEvent_t> events;           // n_ops + 1 when profiling
 };
 
@@ -724,6 +748,7 @@ int dd_net_create(dd_ctx *ctx, const int32_t *program_host, int n_words, const v
     DD_HIP(hipMalloc(&n->d_zero, 256));
     DD_HIP(hipMemset(n->d_zero, 0, 256));
     n->use_glds = getenv("DD_NO_GLDS") == nullptr;
+    n->tile_mode = getenv("DD_TILE_MODE") ? atoi(getenv("DD_TILE_MODE")) : 0;
     DD_HIP(hipMalloc(&n->d_weights, (size_t)n_weight_bytes + 256));
     DD_HIP(hipMemcpy(n->d_weights, weights_host, (size_t)n_weight_bytes, hipMemcpyHostToDevice));
     *out = n;
@@ -867,6 +892,10 @@ int dd_net_forward(dd_net *net, const uint8_t *input, int nimg, void *stream) {
                     rc = bk32 ? launch_conv<4, 1, 1, 2, 32, false>(s, P, net->slab)
                        : glds ? launch_conv<4, 1, 1, 2, 64, true>(s, P, net->slab)
                               : launch_conv<4, 1, 1, 2, 64, false>(s, P, net->slab);
+                } else if (glds && net->tile_mode == 0 && P.m >= 4096 && P.cout_pad >= 128) {
+                    // 64 pixels x 128 channels: each staged pixel row feeds twice the MFMAs; measured 31 us vs 38 us
+                    // for 19x19x512 -> 512 at 64 frames (128 x 64 gave nothing, 128 x 128 was 2.5x slower: 2 blocks/CU)
+                    rc = launch_conv<2, 2, 2, 4, 64, true>(s, P, net->slab);
                 } else {
                     rc = bk32 ? launch_conv<2, 2, 2, 2, 32, false>(s, P, net->slab)
                        : glds ? launch_conv<2, 2, 2, 2, 64, true>(s, P, net->slab)
@@ -883,8 +912,12 @@ int dd_net_forward(dd_net *net, const uint8_t *input, int nimg, void *stream) {
                 P.stride = o[7]; P.pad_t = o[8]; P.pad_l = o[9]; P.ho = td->h; P.wo = td->w; P.c = o[12];
                 P.m = nimg * td->h * td->w; P.act = o[14];
                 P.out = reinterpret_cast<_Float16 *>(base(dst)); P.cs_out = td->cs; P.coff_out = td->coff;
-                const long long total = (long long)P.m * (P.c >> 3);
-                hipLaunchKernelGGL(dwconv3_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, P);
+                const long long total = (long long)(P.m / P.wo) * ((P.wo + 3) / 4) * (P.c >> 3);
+                DD_REQUIRE(P.stride == 1 || P.stride == 2, DD_E_ARG, "dd_net_forward: depthwise stride %d", P.stride);
+                if (P.stride == 1)
+                    hipLaunchKernelGGL(dwconv3_k<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, P);
+                else
+                    hipLaunchKernelGGL(dwconv3_k<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, P);
                 DD_LAUNCH_CHECK();
                 break;
             }

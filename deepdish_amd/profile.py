@@ -64,10 +64,12 @@ def pmc_traffic(kernel, streams):
     if not os.path.exists(path):
         return None
     key = kernel.replace(',', ', ')
-    for k, v in json.load(open(path)).items():
+    tot_b = tot_n = 0.0
+    for k, v in json.load(open(path)).items():          # a kernel family (all tile shapes of conv_glds_k) is summed
         if key in k:
-            return v['hbm_read_bytes_corrected'] + v['hbm_write_bytes']
-    return None
+            tot_b += (v['hbm_read_bytes_corrected'] + v['hbm_write_bytes']) * v['launches']
+            tot_n += v['launches']
+    return tot_b / tot_n if tot_n else None
 
 
 def dominant_kernel_roofline(pipes, step_group, args, reps=20):
