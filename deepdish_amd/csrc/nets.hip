@@ -346,8 +346,8 @@ __device__ __forceinline__ void lds_fill16(const _Float16 *g, _Float16 *lds_wave
 #endif
 }
 
-// Direct-to-LDS variant for layers whose padded Cin is a multiple of 64 (every K step of 64 then lies
-// inside one filter tap and is one 128-byte line per pixel / per output channel).  Operand tiles go
+// Direct-to-LDS variant (K step 64, any padded Cin: each lane moves one 16-byte chunk = 8 channels of one
+// filter tap, so a staged 128-byte row may be gathered from several taps).  Operand tiles go
 // HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR staging, no ds_write); one wave instruction fills
 // eight consecutive 128-byte rows.  Rows are unpadded, so the 16-byte chunks of a row are XOR-swizzled
 // with (row & 7) -- on the SOURCE address for the fill and on the ds_read_b128 address for the
@@ -389,18 +389,31 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_glds_k(const ConvP P) {
 #pragma unroll
     for (int i = 0; i < WG; ++i) wbase[i] = P.w + (size_t)(n0 + (wave * WG + i) * 8 + rr) * P.kpad + gchunk;
 
-    auto fill = [&](int ks, int buf) {
-        const int k = ks << 6;
-        const int tap = k / P.cin, c0 = k - tap * P.cin;        // uniform: cin % 64 == 0
-        const int kh = tap / P.kw, kw = tap - kh * P.kw;
+    // This lane always moves the same logical 16-byte chunk (8 channels) of a K step; (l_kh, l_kw, l_c)
+    // walk the (tap, channel) position of that chunk along K, so any Cin that is a multiple of 8 works
+    // (Cin = 32: a 64-wide step covers two taps, Cin = 8: eight taps).
+    int l_kh, l_kw, l_c;
+    {
+        const int k = (ks0 << 6) + gchunk;
+        const int tap = k / P.cin;
+        l_c = k - tap * P.cin;
+        l_kh = tap / P.kw;
+        l_kw = tap - l_kh * P.kw;
+    }
+    auto fill = [&](int ks, int buf) {                          // called with consecutive ks
 #pragma unroll
         for (int i = 0; i < XG; ++i) {
-            const int iy = x_iy0[i] + kh, ix = x_ix0[i] + kw;
-            const bool ok = x_ok[i] && kh < P.kh && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
-            const _Float16 *g = ok ? P.in + ((size_t)(x_n[i] * P.H + iy) * P.W + ix) * P.cs_in + P.coff_in + c0 + gchunk
-                                   : P.zero;
+            const int iy = x_iy0[i] + l_kh, ix = x_ix0[i] + l_kw;
+            const bool ok = x_ok[i] && l_kh < P.kh && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
+            const _Float16 *g = ok ? P.in + ((size_t)(x_n[i] * P.H + iy) * P.W + ix) * P.cs_in + P.coff_in + l_c : P.zero;
             lds_fill16(g, xs + (size_t)(buf * BM + (wave * XG + i) * 8) * 64);
         }
+        l_c += 64;
+        while (l_c >= P.cin) {
+            l_c -= P.cin;
+            if (++l_kw == P.kw) { l_kw = 0; ++l_kh; }
+        }
+        const int k = ks << 6;
 #pragma unroll
         for (int i = 0; i < WG; ++i) lds_fill16(wbase[i] + k, ws + (size_t)(buf * BN + (wave * WG + i) * 8) * 64);
     };
@@ -886,10 +899,12 @@ int dd_net_forward(dd_net *net, const uint8_t *input, int nimg, void *stream) {
                 for (int q = 0; q < 8; ++q) P.f[q] = of[32 + q];
                 int rc;
                 const bool bk32 = o[28] == 32;                 // shallow K (<= 96): one or few 32-wide steps
-                const bool glds = !bk32 && P.cin % 64 == 0 && net->use_glds;   // every 64-wide K step inside one tap
+                const bool glds = !bk32 && net->use_glds;          // K >= 97: direct-to-LDS fills, any Cin % 8 == 0
                 P.zero = net->d_zero;
                 if (P.cout_pad <= 32) {
+                    // 32 output channels: 128 pixels per block (each wave 32 px x 32 ch) once there are enough pixels
                     rc = bk32 ? launch_conv<4, 1, 1, 2, 32, false>(s, P, net->slab)
+                       : (glds && P.m >= 16384) ? launch_conv<4, 1, 2, 2, 64, true>(s, P, net->slab)
                        : glds ? launch_conv<4, 1, 1, 2, 64, true>(s, P, net->slab)
                               : launch_conv<4, 1, 1, 2, 64, false>(s, P, net->slab);
                 } else if (glds && net->tile_mode == 0 && P.m >= 4096 && P.cout_pad >= 128) {

@@ -138,7 +138,7 @@ class Program:
             kw_['has_aff'] = 1
         self._op(OP_CONV, src=src, dst=dst, res=res, dst2=dst2, **kw_)
         tile = '4,1,1,2' if cout_pad <= 32 else '2,2,2,2'
-        self.info[-1] = dict(kernel='conv_glds_k' if (bk == 64 and cin_pad % 64 == 0) else 'conv_mfma_k<%s,%d>' % (tile, bk),
+        self.info[-1] = dict(kernel='conv_glds_k' if bk == 64 else 'conv_mfma_k<%s,%d>' % (tile, bk),
                              flops=2 * ho * wo * kh * kw * cin * cout,
                              bytes=2 * s['h'] * s['w'] * cin + (4 if epi != EPI_F16 else 2) * ho * wo * cout
                              + (2 * ho * wo * cout if res >= 0 else 0) + (2 * ho * wo * cout if dst2 >= 0 else 0),
