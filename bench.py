@@ -118,11 +118,16 @@ def cpu_baseline(n_frames):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE JSON line: keep the real stdout aside and point fd 1 at stderr while
+    # libraries (RCCL prints a version banner on stdout) are at work.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    dist_on = world > 1
+    dist_on = world > 1 or ('RANK' in os.environ and 'MASTER_PORT' in os.environ)    # launched by torch.distributed.run
     torch.cuda.set_device(local_rank)
     if dist_on:
         import torch.distributed as dist
@@ -202,7 +207,7 @@ def main():
             out['roofline_error'] = repr(e)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.cpu_frames)
-        print(json.dumps(out))
+        os.write(real_stdout, (json.dumps(out) + '\n').encode())
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
