@@ -23,7 +23,7 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-enum { OP_INPUT = 1, OP_CONV = 2, OP_DWCONV = 3, OP_MAXPOOL = 4, OP_UPSAMPLE = 5, OP_FC = 6, OP_L2NORM = 7 };
+enum { OP_INPUT = 1, OP_CONV = 2, OP_DWCONV = 3, OP_MAXPOOL = 4, OP_UPSAMPLE = 5, OP_FC = 6, OP_L2NORM = 7, OP_STEM = 8 };
 enum { ACT_NONE = 0, ACT_RELU6 = 1, ACT_ELU = 2, ACT_SILU = 3, ACT_RELU = 4, ACT_SIGMOID = 5 };
 enum { EPI_F16 = 0, EPI_F32 = 1, EPI_SSD_HEAD = 2, EPI_YOLO = 3 };
 enum { DT_F16 = 0, DT_F32 = 1, DT_U8 = 2 };
@@ -34,7 +34,8 @@ constexpr int TENSOR_WORDS = 8;
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
         case ACT_RELU6: return fminf(fmaxf(v, 0.f), 6.f);
-        case ACT_ELU: return v > 0.f ? v : expm1f(v);
+        case ACT_ELU:                                   // expm1 to well below half an f16 ulp: cubic Taylor near 0, exp - 1 beyond
+            return v > 0.f ? v : (v > -0.03125f ? v * (1.f + 0.5f * v * (1.f + v * (1.f / 3.f))) : __expf(v) - 1.f);
         case ACT_SILU: return v / (1.f + __expf(-v));
         case ACT_RELU: return fmaxf(v, 0.f);
         case ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
@@ -55,6 +56,9 @@ struct ConvP {
     int splitk; float *slab;        // splitk > 1: raw partial sums go to slab[z][m][cout_pad]
     const _Float16 *zero;           // >= 16 bytes of zeros: source of out-of-image taps for direct-to-LDS fills
     int p[6]; float f[8];
+    // spatially tiled kernels (conv3x3_rw_k, stem_conv3_k): th x tw output pixels of one image per block
+    int th, tw, tiles_x, tiles_y;
+    const uint8_t *src8; float in_mean, in_scale;      // stem: u8 [N][H][W][3] source, (x - mean) * scale
 };
 
 
@@ -141,11 +145,31 @@ __device__ __forceinline__ void conv_epilogue(const ConvP &P, int m, int co, flo
 }
 
 // Plain NHWC f16 output, 8 consecutive channels of one pixel (v = raw sums): one 16-byte store, so
-// eight neighbouring lanes write a full 128-byte line.
-__device__ __forceinline__ void conv_epilogue_f16x8(const ConvP &P, int m, int co, float v[8]) {
-    const f4 b0 = *reinterpret_cast<const f4 *>(P.bias + co), b1 = *reinterpret_cast<const f4 *>(P.bias + co + 4);
+// eight neighbouring lanes write a full 128-byte line.  Epi8 = the per-channel constants of those
+// eight channels (kernels whose lanes keep the same channels for every pixel load them once).
+struct Epi8 { f4 b0, b1, s0, s1, t0, t1; };
+
+__device__ __forceinline__ Epi8 epi8_load(const ConvP &P, int co) {
+    Epi8 E;
+    E.b0 = *reinterpret_cast<const f4 *>(P.bias + co);
+    E.b1 = *reinterpret_cast<const f4 *>(P.bias + co + 4);
+    E.s0 = E.s1 = E.t0 = E.t1 = f4{0.f, 0.f, 0.f, 0.f};
+    if (P.out2) {
+        E.s0 = *reinterpret_cast<const f4 *>(P.aff2 + co);
+        E.s1 = *reinterpret_cast<const f4 *>(P.aff2 + co + 4);
+        E.t0 = *reinterpret_cast<const f4 *>(P.aff2 + P.cout_pad + co);
+        E.t1 = *reinterpret_cast<const f4 *>(P.aff2 + P.cout_pad + co + 4);
+    }
+    return E;
+}
+
+// ACT >= 0: the activation is known at compile time (the per-element switch on P.act would otherwise be
+// compiled into a chain of branches around every value).
+template <int ACT = -1>
+__device__ __forceinline__ void conv_epilogue_f16x8(const ConvP &P, const Epi8 &E, int m, int co, float v[8]) {
+    const int act = ACT < 0 ? P.act : ACT;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { v[r] = apply_act(v[r] + b0[r], P.act); v[4 + r] = apply_act(v[4 + r] + b1[r], P.act); }
+    for (int r = 0; r < 4; ++r) { v[r] = apply_act(v[r] + E.b0[r], act); v[4 + r] = apply_act(v[4 + r] + E.b1[r], act); }
     if (P.res) {
         const h8 rv = *reinterpret_cast<const h8 *>(P.res + (size_t)m * P.cs_res + P.coff_res + co);
 #pragma unroll
@@ -159,15 +183,34 @@ __device__ __forceinline__ void conv_epilogue_f16x8(const ConvP &P, int m, int c
     }
     *reinterpret_cast<h8 *>(static_cast<_Float16 *>(P.out) + (size_t)m * P.cs_out + P.coff_out + co) = o;
     if (P.out2) {                                   // second view: ELU(scale * raw + shift)
-        const f4 s0 = *reinterpret_cast<const f4 *>(P.aff2 + co), s1 = *reinterpret_cast<const f4 *>(P.aff2 + co + 4);
-        const f4 t0 = *reinterpret_cast<const f4 *>(P.aff2 + P.cout_pad + co), t1 = *reinterpret_cast<const f4 *>(P.aff2 + P.cout_pad + co + 4);
         h8 o2;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            const float sc = r < 4 ? s0[r] : s1[r - 4], sh = r < 4 ? t0[r] : t1[r - 4];
+            const float sc = r < 4 ? E.s0[r] : E.s1[r - 4], sh = r < 4 ? E.t0[r] : E.t1[r - 4];
             o2[r] = (_Float16)(co + r < P.cout ? apply_act(sc * v[r] + sh, ACT_ELU) : 0.f);
         }
         *reinterpret_cast<h8 *>(P.out2 + (size_t)m * P.cs_out2 + P.coff_out2 + co) = o2;
+    }
+}
+
+template <int ACT = -1>
+__device__ __forceinline__ void conv_epilogue_f16x8(const ConvP &P, int m, int co, float v[8]) {
+    const Epi8 E = epi8_load(P, co);
+    conv_epilogue_f16x8<ACT>(P, E, m, co, v);
+}
+
+// Rows of a block's f32 output tile staged in LDS -> activation etc. -> 16-byte stores.
+template <int ACT, int BM, int BN, int T>
+__device__ __forceinline__ void conv_finish_rows(const ConvP &P, const float *ot, int m0, int n0) {
+    constexpr int OROW = BN + 4, G = BN / 8;                      // floats per staged pixel row, 8-channel groups per row
+    for (int t = threadIdx.x; t < BM * G; t += T) {
+        const int pl = t / G, g = t - pl * G;
+        const int m = m0 + pl, co = n0 + g * 8;
+        if (m >= P.m || co >= P.cout_pad) continue;
+        const f4 lo = *reinterpret_cast<const f4 *>(ot + pl * OROW + g * 8);
+        const f4 hi = *reinterpret_cast<const f4 *>(ot + pl * OROW + g * 8 + 4);
+        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        conv_epilogue_f16x8<ACT>(P, m, co, v);
     }
 }
 
@@ -190,15 +233,12 @@ __device__ __forceinline__ void conv_finish(const ConvP &P, f4 (&acc)[NI][MI], _
             for (int a = 0; a < NI; ++a)
                 *reinterpret_cast<f4 *>(ot + ((wm * MI + b) * 16 + fr) * OROW + (wn * NI + a) * 16 + fq * 4) = acc[a][b];
         __syncthreads();
-        constexpr int G = BN / 8;                                 // 8-channel groups per pixel row
-        for (int t = tid; t < BM * G; t += T) {
-            const int pl = t / G, g = t - pl * G;
-            const int m = m0 + pl, co = n0 + g * 8;
-            if (m >= P.m || co >= P.cout_pad) continue;
-            const f4 lo = *reinterpret_cast<const f4 *>(ot + pl * OROW + g * 8);
-            const f4 hi = *reinterpret_cast<const f4 *>(ot + pl * OROW + g * 8 + 4);
-            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            conv_epilogue_f16x8(P, m, co, v);
+        switch (P.act) {                                          // one straight-line copy of the row loop per activation
+            case ACT_NONE: conv_finish_rows<ACT_NONE, BM, BN, T>(P, ot, m0, n0); break;
+            case ACT_RELU6: conv_finish_rows<ACT_RELU6, BM, BN, T>(P, ot, m0, n0); break;
+            case ACT_ELU: conv_finish_rows<ACT_ELU, BM, BN, T>(P, ot, m0, n0); break;
+            case ACT_SILU: conv_finish_rows<ACT_SILU, BM, BN, T>(P, ot, m0, n0); break;
+            default: conv_finish_rows<-1, BM, BN, T>(P, ot, m0, n0);
         }
         return;
     }
@@ -452,6 +492,218 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_glds_k(const ConvP P) {
     conv_finish<WM, WN, MI, NI>(P, acc, lds, m0, n0, hw);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Spatially tiled 3x3 kernels with register-resident weights.
+//
+// For 32 input channels one filter tap is exactly one MFMA k-slice, and 32 output channels are two
+// 16-row weight fragments, so the whole 3x3x32x32 filter is 18 fragments = 72 VGPRs per lane: it is
+// loaded once per wave and never staged.  The block copies its input patch (tile + halo) into LDS
+// once -- every input byte crosses L2->LDS one time instead of nine -- and each pixel fragment is a
+// single ds_read_b128 per tap.  LDS image: four 8-channel planes [chunk][patch pixel] x 16 bytes with
+// a plane pitch that is a multiple of 256 bytes: the 16 lanes of every ds_read_b128 lane group then
+// fall on 16 different 16-byte slots of the 256-byte bank row, whatever the tap offset.
+//
+// Weight rows are taken in the order (fr>>2)*8 + a*4 + (fr&3) for fragment a, so the lane that owns
+// accumulator rows fq*4..fq*4+3 of fragments 2g and 2g+1 holds output channels g*32 + fq*8 .. +7:
+// one 16-byte store per pixel and lane, 64 contiguous bytes per pixel, 1 KiB per fragment.
+__device__ __forceinline__ int rw_weight_row(int a, int fr) { return (a >> 1) * 32 + (fr >> 2) * 8 + (a & 1) * 4 + (fr & 3); }
+
+constexpr int RW_FILL = 10;                                    // 16 patch pixels x 4 chunks per wave pass: <= 640 patch pixels
+constexpr int RW_MAX_PATCH = RW_FILL * 64;
+constexpr int RW_MB = 4;                                       // pixel fragments in flight per wave
+
+template <int NCO, int TW, int ACT>                            // TW: tile width when known at compile time (tap offsets
+__global__ __launch_bounds__(256, 2) void conv3x3_rw_k(const ConvP P, const int total_tiles) {   // become ds_read immediates), else 0
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int tw = TW ? TW : P.tw;
+    const int PW = tw + 2, npix = (P.th + 2) * PW;
+    const int plane = (npix * 8 + 127) & ~127;                  // halves per 8-channel plane (256-byte multiple)
+    // exact x / d for x < 1024, d <= 34 without an integer division per lane
+    const unsigned rcp_pw = (65536u + PW - 1) / PW, rcp_tw = (65536u + tw - 1) / tw;
+    const int tiles_per_image = P.tiles_x * P.tiles_y;
+
+    h8 wf[9][NCO];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int a = 0; a < NCO; ++a)
+            wf[t][a] = *reinterpret_cast<const h8 *>(P.w + (size_t)rw_weight_row(a, fr) * P.kpad + t * 32 + fq * 8);
+    Epi8 E[NCO / 2];
+#pragma unroll
+    for (int g = 0; g < NCO / 2; ++g) E[g] = epi8_load(P, g * 32 + fq * 8);
+
+    // Persistent blocks: tile t of this block is logical tile dd_xcd_remap(t) (each XCD walks one contiguous
+    // range of images, so halo rows shared by neighbouring tiles meet in one L2).  The next tile's patch
+    // is fetched into registers while the current one is multiplied.
+    // Patch fill: a wave pass covers 16 consecutive patch pixels x 4 chunks; inside it each 8-lane group
+    // takes 8 consecutive pixels of one chunk (the ds_write_b128 lane groups are 8 contiguous lanes).
+    const int fc = (lane >> 3) & 3, fpl = (lane & 7) + ((lane >> 5) << 3);
+    h8 v[RW_FILL];
+    auto fetch = [&](int t) {
+        const int lt = (int)dd_xcd_remap((unsigned)t, (unsigned)total_tiles);
+        const int n = lt / tiles_per_image, r = lt - n * tiles_per_image;
+        const int ty = r / P.tiles_x, tx = r - ty * P.tiles_x;
+        const int ys = ty * P.th - P.pad_t, xs = tx * tw - P.pad_l;
+        const _Float16 *img = P.in + (size_t)n * P.H * P.W * P.cs_in + P.coff_in + fc * 8;
+#pragma unroll
+        for (int i = 0; i < RW_FILL; ++i) {
+            const int pix = (wave + 4 * i) * 16 + fpl;
+            const int py = (int)((pix * rcp_pw) >> 16);
+            const int y = ys + py, x = xs + pix - py * PW;
+            h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (pix < npix && y >= 0 && y < P.H && x >= 0 && x < P.W) z = *reinterpret_cast<const h8 *>(img + ((size_t)y * P.W + x) * P.cs_in);
+            v[i] = z;
+        }
+    };
+
+    const int tile_px = P.th * tw;
+    const int nfrag = (tile_px + 15) >> 4;
+    int t = blockIdx.x;
+    fetch(t);
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < RW_FILL; ++i) {
+            const int pix = (wave + 4 * i) * 16 + fpl;
+            if (pix < npix) *reinterpret_cast<h8 *>(lds + fc * plane + pix * 8) = v[i];
+        }
+        __syncthreads();
+        const int lt = (int)dd_xcd_remap((unsigned)t, (unsigned)total_tiles);
+        const int n = lt / tiles_per_image, rt = lt - n * tiles_per_image;
+        const int tile_y = rt / P.tiles_x;
+        const int y0 = tile_y * P.th, x0 = (rt - tile_y * P.tiles_x) * tw;
+        const int tn = t + gridDim.x;
+        if (tn < total_tiles) fetch(tn);
+
+        for (int f0 = wave * RW_MB; f0 < nfrag; f0 += 4 * RW_MB) {
+            int base[RW_MB], mrow[RW_MB];
+            bool ok[RW_MB];
+#pragma unroll
+            for (int b = 0; b < RW_MB; ++b) {
+                const int p = (f0 + b) * 16 + fr;
+                const int ty = (int)((p * rcp_tw) >> 16), tx = p - ty * tw;
+                ok[b] = p < tile_px && y0 + ty < P.ho && x0 + tx < P.wo;
+                base[b] = fq * plane + (ok[b] ? ty * PW + tx : 0) * 8;     // top-left tap of the pixel, in halves
+                mrow[b] = (n * P.ho + y0 + ty) * P.wo + x0 + tx;
+            }
+            f4 acc[NCO][RW_MB];
+#pragma unroll
+            for (int a = 0; a < NCO; ++a)
+#pragma unroll
+                for (int b = 0; b < RW_MB; ++b) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int off = (dy * PW + dx) * 8;
+                    h8 xf[RW_MB];
+#pragma unroll
+                    for (int b = 0; b < RW_MB; ++b) xf[b] = *reinterpret_cast<const h8 *>(lds + base[b] + off);
+#pragma unroll
+                    for (int a = 0; a < NCO; ++a)
+#pragma unroll
+                        for (int b = 0; b < RW_MB; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[dy * 3 + dx][a], xf[b], acc[a][b], 0, 0, 0);
+                }
+#pragma unroll
+            for (int b = 0; b < RW_MB; ++b) {
+                if (!ok[b]) continue;
+#pragma unroll
+                for (int g = 0; g < NCO / 2; ++g) {
+                    float o[8];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { o[r] = acc[2 * g][b][r]; o[4 + r] = acc[2 * g + 1][b][r]; }
+                    conv_epilogue_f16x8<ACT>(P, E[g], mrow[b], g * 32 + fq * 8, o);
+                }
+            }
+        }
+        if (tn >= total_tiles) break;
+        __syncthreads();                                          // every wave is done reading this patch
+        t = tn;
+    }
+}
+
+// First layer of a network straight from the u8 image: (x - mean) * scale, 3x3 conv over 3 channels
+// (K = 27, one MFMA k-slice padded to 32; k = dy*9 + dx*3 + ch, so one filter row of a pixel is nine
+// consecutive halves of the LDS patch), bias, activation -> NHWC f16 with 32 channels.  Replaces the
+// separate input-conversion pass and its 8-channel f16 tensor.  Weights [32][32] f16, channel swap
+// (BGR -> RGB) already folded into them by the host.
+template <int STRIDE, int ACT>
+__global__ __launch_bounds__(256) void stem_conv3_k(const ConvP P) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    int bi = blockIdx.x;
+    const int tile_x = bi % P.tiles_x; bi /= P.tiles_x;
+    const int tile_y = bi % P.tiles_y;
+    const int n = bi / P.tiles_y;
+    const int y0 = tile_y * P.th, x0 = tile_x * P.tw;
+    const int PW3 = ((P.tw - 1) * STRIDE + 3) * 3, PH = (P.th - 1) * STRIDE + 3;
+    const unsigned rcp_tw = (65536u + P.tw - 1) / P.tw;         // exact x / tw for x < 1024, tw <= 32
+
+    h8 wf[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) wf[a] = *reinterpret_cast<const h8 *>(P.w + rw_weight_row(a, fr) * 32 + fq * 8);
+
+    {   // patch fill, eight independent byte loads in flight per lane (a dependent load per element would
+        // leave the block waiting on one HBM round trip after another)
+        const int xs3 = (x0 * STRIDE - P.pad_l) * 3, w3 = P.W * 3, total = PH * PW3;
+        const unsigned rcp = 0xFFFFFFFFu / (unsigned)PW3 + 1u;     // __umulhi(i, rcp) == i / PW3 for i < 2^16
+        const uint8_t *img = P.src8 + (size_t)n * P.H * w3;
+        for (int i0 = tid; i0 < total; i0 += 8 * 256) {
+            int raw[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int idx = i0 + j * 256;
+                const int py = (int)__umulhi((unsigned)idx, rcp), r = idx - py * PW3;
+                const int y = y0 * STRIDE - P.pad_t + py, x3 = xs3 + r;
+                raw[j] = (idx < total && y >= 0 && y < P.H && x3 >= 0 && x3 < w3) ? (int)img[(size_t)y * w3 + x3] : -1;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int idx = i0 + j * 256;                     // zero padding is applied after normalisation
+                if (idx < total) lds[idx] = (_Float16)(raw[j] < 0 ? 0.f : ((float)raw[j] - P.in_mean) * P.in_scale);
+            }
+        }
+    }
+    int koff[8];                                                  // this lane's eight k positions inside a pixel's window
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = fq * 8 + j;
+        koff[j] = k < 27 ? (k / 9) * PW3 + (k % 9) : 0;             // k >= 27: weight is zero, any finite value will do
+    }
+    __syncthreads();
+
+    const Epi8 E = epi8_load(P, fq * 8);
+    const int tile_px = P.th * P.tw;
+    const int nfrag = (tile_px + 15) >> 4;
+    for (int f0 = wave * RW_MB; f0 < nfrag; f0 += 4 * RW_MB) {
+        h8 xf[RW_MB];
+        int mrow[RW_MB];
+        bool ok[RW_MB];
+#pragma unroll
+        for (int b = 0; b < RW_MB; ++b) {
+            const int p = (f0 + b) * 16 + fr;
+            const int ty = (int)((p * rcp_tw) >> 16), tx = p - ty * P.tw;
+            ok[b] = p < tile_px && y0 + ty < P.ho && x0 + tx < P.wo;
+            const int e0 = ok[b] ? ty * STRIDE * PW3 + tx * STRIDE * 3 : 0;
+            mrow[b] = (n * P.ho + y0 + ty) * P.wo + x0 + tx;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xf[b][j] = lds[e0 + koff[j]];
+        }
+#pragma unroll
+        for (int b = 0; b < RW_MB; ++b) {
+            const f4 z = f4{0.f, 0.f, 0.f, 0.f};
+            const f4 a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0], xf[b], z, 0, 0, 0);
+            const f4 a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[1], xf[b], z, 0, 0, 0);
+            if (!ok[b]) continue;
+            float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            conv_epilogue_f16x8<ACT>(P, E, mrow[b], fq * 8, v);
+        }
+    }
+}
+
 // Split-K tail: sum the partial slabs in a fixed order (bitwise reproducible) and run the epilogue.
 __global__ __launch_bounds__(256) void conv_splitk_finish_k(const ConvP P) {
     const int groups = P.cout_pad >> 2;
@@ -664,6 +916,7 @@ struct dd_net {
     DevBuf slab;                             // split-K partial sums
     _Float16 *d_zero = nullptr;              // 256 bytes of zeros (padding taps of the direct-to-LDS fills)
     bool use_glds = true;
+    bool use_rw = true;                      // DD_NO_RW=1: 3x3x32x32 layers fall back to the implicit-GEMM kernels (A/B measurements)
     int tile_mode = 0;                       // DD_TILE_MODE=1 forces the 64 x 64 tile everywhere (A/B measurements)
     std::vector<hipEvent_t> events;           // n_ops + 1 when profiling
 };
@@ -722,6 +975,48 @@ int launch_conv(hipStream_t s, ConvP &P, DevBuf &slab) {
     return DD_OK;
 }
 
+// Tile of th x tw output pixels (<= 512, i.e. 32 pixel fragments) whose input patch fits `max_patch`
+// pixels (0 = no limit); tiles are balanced so the last row / column of tiles is not a sliver.
+void spatial_tile(int ho, int wo, int stride, int max_patch, ConvP &P) {
+    int tiles_x = dd_ceil_div(wo, 32);
+    int tw = dd_ceil_div(wo, tiles_x);
+    int th = std::max(1, std::min(ho, 512 / tw));
+    while (max_patch && th > 1 && ((th - 1) * stride + 3) * ((tw - 1) * stride + 3) > max_patch) --th;
+    int tiles_y = dd_ceil_div(ho, th);
+    th = dd_ceil_div(ho, tiles_y);
+    P.th = th; P.tw = tw; P.tiles_x = tiles_x; P.tiles_y = tiles_y;
+}
+
+int launch_conv3x3_rw(hipStream_t s, ConvP &P, int nimg) {
+    spatial_tile(P.ho, P.wo, 1, RW_MAX_PATCH, P);
+    const int npix = (P.th + 2) * (P.tw + 2);
+    DD_REQUIRE(npix <= RW_MAX_PATCH, DD_E_ARG, "conv3x3_rw: patch of %d pixels", npix);
+    const size_t lds_bytes = (size_t)4 * ((npix * 16 + 255) & ~255);
+    const int total = nimg * P.tiles_x * P.tiles_y;
+    const int grid = std::min(total, 2 * 256);                   // persistent: 2 blocks per CU (register-bound), multiple of 8
+#define DD_RW(TW_, ACT_) hipLaunchKernelGGL((conv3x3_rw_k<2, TW_, ACT_>), dim3((unsigned)grid), dim3(256), lds_bytes, s, P, total)
+    if (P.tw == 32 && P.act == ACT_ELU) DD_RW(32, ACT_ELU);
+    else if (P.tw == 32 && P.act == ACT_SILU) DD_RW(32, ACT_SILU);
+    else if (P.tw == 15 && P.act == ACT_ELU) DD_RW(15, ACT_ELU);
+    else if (P.tw == 15 && P.act == ACT_NONE) DD_RW(15, ACT_NONE);
+    else DD_RW(0, -1);
+#undef DD_RW
+    DD_LAUNCH_CHECK();
+    return DD_OK;
+}
+
+int launch_stem(hipStream_t s, ConvP &P, int nimg) {
+    spatial_tile(P.ho, P.wo, P.stride, 0, P);
+    const size_t lds_bytes = (size_t)((P.th - 1) * P.stride + 3) * ((P.tw - 1) * P.stride + 3) * 3 * sizeof(_Float16);
+    const dim3 grid((unsigned)(nimg * P.tiles_x * P.tiles_y));
+    if (P.stride == 1 && P.act == ACT_ELU) hipLaunchKernelGGL((stem_conv3_k<1, ACT_ELU>), grid, dim3(256), lds_bytes, s, P);
+    else if (P.stride == 2 && P.act == ACT_RELU6) hipLaunchKernelGGL((stem_conv3_k<2, ACT_RELU6>), grid, dim3(256), lds_bytes, s, P);
+    else if (P.stride == 1) hipLaunchKernelGGL((stem_conv3_k<1, -1>), grid, dim3(256), lds_bytes, s, P);
+    else hipLaunchKernelGGL((stem_conv3_k<2, -1>), grid, dim3(256), lds_bytes, s, P);
+    DD_LAUNCH_CHECK();
+    return DD_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -761,6 +1056,7 @@ int dd_net_create(dd_ctx *ctx, const int32_t *program_host, int n_words, const v
     DD_HIP(hipMalloc(&n->d_zero, 256));
     DD_HIP(hipMemset(n->d_zero, 0, 256));
     n->use_glds = getenv("DD_NO_GLDS") == nullptr;
+    n->use_rw = getenv("DD_NO_RW") == nullptr;
     n->tile_mode = getenv("DD_TILE_MODE") ? atoi(getenv("DD_TILE_MODE")) : 0;
     DD_HIP(hipMalloc(&n->d_weights, (size_t)n_weight_bytes + 256));
     DD_HIP(hipMemcpy(n->d_weights, weights_host, (size_t)n_weight_bytes, hipMemcpyHostToDevice));
@@ -901,7 +1197,11 @@ int dd_net_forward(dd_net *net, const uint8_t *input, int nimg, void *stream) {
                 const bool bk32 = o[28] == 32;                 // shallow K (<= 96): one or few 32-wide steps
                 const bool glds = !bk32 && net->use_glds;          // K >= 97: direct-to-LDS fills, any Cin % 8 == 0
                 P.zero = net->d_zero;
-                if (P.cout_pad <= 32) {
+                if (net->use_rw && P.kh == 3 && P.kw == 3 && P.stride == 1 && P.cin == 32 && P.cout_pad == 32 &&
+                    P.epi == EPI_F16 && P.pad_t == 1 && P.pad_l == 1) {
+                    // whole filter in registers, input patch staged once (see conv3x3_rw_k)
+                    rc = launch_conv3x3_rw(s, P, nimg);
+                } else if (P.cout_pad <= 32) {
                     // 32 output channels: 128 pixels per block (each wave 32 px x 32 ch) once there are enough pixels
                     rc = bk32 ? launch_conv<4, 1, 1, 2, 32, false>(s, P, net->slab)
                        : (glds && P.m >= 16384) ? launch_conv<4, 1, 2, 2, 64, true>(s, P, net->slab)
@@ -916,6 +1216,21 @@ int dd_net_forward(dd_net *net, const uint8_t *input, int nimg, void *stream) {
                        : glds ? launch_conv<2, 2, 2, 2, 64, true>(s, P, net->slab)
                               : launch_conv<2, 2, 2, 2, 64, false>(s, P, net->slab);
                 }
+                if (rc != DD_OK) return rc;
+                break;
+            }
+            case OP_STEM: {
+                ConvP P;
+                memset(&P, 0, sizeof(P));
+                P.src8 = input; P.H = net->in_h; P.W = net->in_w; P.in_mean = of[32]; P.in_scale = of[33];
+                P.kh = P.kw = 3; P.stride = o[7]; P.pad_t = o[8]; P.pad_l = o[9];
+                P.cout = o[11]; P.cout_pad = o[12]; P.act = o[14]; P.epi = EPI_F16; P.splitk = 1;
+                DD_REQUIRE(P.cout_pad == 32 && (P.stride == 1 || P.stride == 2), DD_E_ARG, "dd_net_forward: stem needs 32 output channels, stride 1 or 2");
+                P.w = reinterpret_cast<const _Float16 *>(net->d_weights + (size_t)(uint32_t)o[16]);
+                P.bias = reinterpret_cast<const float *>(net->d_weights + (size_t)(uint32_t)o[17]);
+                P.ho = td->h; P.wo = td->w; P.m = nimg * P.ho * P.wo;
+                P.out = base(dst); P.cs_out = td->cs; P.coff_out = td->coff;
+                int rc = launch_stem(s, P, nimg);
                 if (rc != DD_OK) return rc;
                 break;
             }

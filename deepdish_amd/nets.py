@@ -17,7 +17,7 @@ random weights of the right shapes so the HIP path and the oracle can be compare
 import math
 import numpy as np
 
-OP_INPUT, OP_CONV, OP_DWCONV, OP_MAXPOOL, OP_UPSAMPLE, OP_FC, OP_L2NORM = 1, 2, 3, 4, 5, 6, 7
+OP_INPUT, OP_CONV, OP_DWCONV, OP_MAXPOOL, OP_UPSAMPLE, OP_FC, OP_L2NORM, OP_STEM = 1, 2, 3, 4, 5, 6, 7, 8
 ACT_NONE, ACT_RELU6, ACT_ELU, ACT_SILU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3, 4, 5
 EPI_F16, EPI_F32, EPI_SSD_HEAD, EPI_YOLO = 0, 1, 2, 3
 DT_F16, DT_F32, DT_U8 = 0, 1, 2
@@ -97,6 +97,26 @@ class Program:
         self._op(OP_INPUT, dst=t, kh=int(s2d), kw=int(swap_rb), f=[mean, scale])
         return t
 
+    def stem(self, w_hwio, bias, stride, act, swap_rb, mean=0.0, scale=1.0):
+        """First layer straight from the u8 image: (x - mean) * scale -> 3x3 conv over the 3 colour channels
+        (TF SAME) -> bias -> act -> NHWC f16 with 32 channels (csrc/nets.hip stem_conv3_k).  The channel swap
+        is folded into the weights; they are packed [32][32] f16 with k = dy*9 + dx*3 + ch (27 real)."""
+        kh, kw, cin, cout = w_hwio.shape
+        assert (kh, kw, cin) == (3, 3, 3) and cout <= 32
+        ho, pt = same_pad(self.in_h, 3, stride)
+        wo, pl = same_pad(self.in_w, 3, stride)
+        w = w_hwio[:, :, ::-1, :] if swap_rb else w_hwio
+        wp = np.zeros((32, 32), dtype=np.float16)
+        wp[:cout, :27] = np.transpose(w, (3, 0, 1, 2)).reshape(cout, 27).astype(np.float16)
+        bp = np.zeros(32, dtype=np.float32)
+        bp[:cout] = bias
+        dst = self.tensor(ho, wo, cout)
+        self._op(OP_STEM, dst=dst, stride=stride, pad_t=pt, pad_l=pl, cout=cout, cout_pad=32, act=act,
+                 w_off=self.add_blob(wp), b_off=self.add_blob(bp), ho=ho, wo=wo, f=[mean, scale])
+        self.info[-1] = dict(kernel='stem_conv3_k', flops=2 * ho * wo * 27 * cout,
+                             bytes=3 * self.in_h * self.in_w + 2 * ho * wo * cout, wbytes=2 * 27 * cout + 4 * cout)
+        return dst
+
     def conv(self, src, w_hwio, bias, stride=1, pad=None, act=ACT_NONE, dst=None, res=-1, dst2=-1, aff2=None,
              epi=EPI_F16, p=(), f=(), out_hw=None):
         """w_hwio f32 [KH,KW,Cin,Cout] (already BN-folded), bias f32 [Cout]."""
@@ -138,7 +158,8 @@ class Program:
             kw_['has_aff'] = 1
         self._op(OP_CONV, src=src, dst=dst, res=res, dst2=dst2, **kw_)
         tile = '4,1,1,2' if cout_pad <= 32 else '2,2,2,2'
-        self.info[-1] = dict(kernel='conv_glds_k' if bk == 64 else 'conv_mfma_k<%s,%d>' % (tile, bk),
+        rw = (kh, kw, stride, cin_pad, cout_pad, epi, pt, pl) == (3, 3, 1, 32, 32, EPI_F16, 1, 1)
+        self.info[-1] = dict(kernel='conv3x3_rw_k' if rw else 'conv_glds_k' if bk == 64 else 'conv_mfma_k<%s,%d>' % (tile, bk),
                              flops=2 * ho * wo * kh * kw * cin * cout,
                              bytes=2 * s['h'] * s['w'] * cin + (4 if epi != EPI_F16 else 2) * ho * wo * cout
                              + (2 * ho * wo * cout if res >= 0 else 0) + (2 * ho * wo * cout if dst2 >= 0 else 0),
@@ -274,10 +295,10 @@ def synthetic_mars_weights(seed=1234):
 def compile_mars(wd, in_h=64, in_w=32):
     """tools/freeze_model.py:88-157 as an op program; input u8 BGR [n,64,32,3] -> f32 [n,128]."""
     P = Program(in_h, in_w)
-    x = P.input(swap_rb=True)                                                  # :175-177 BGR -> RGB
-    w, b = fold_conv_bn(wd, 'conv1_1'); x = P.conv(x, w, b, act=ACT_ELU)        # :101-105
-    w, b = fold_conv_bn(wd, 'conv1_2'); x = P.conv(x, w, b, act=ACT_ELU)        # :106-110
-    x = P.maxpool(x, 3, 2, 0)                                                  # :116 VALID
+    w, b = fold_conv_bn(wd, 'conv1_1')
+    x = c11 = P.stem(w, b, 1, ACT_ELU, swap_rb=True)                           # :175-177 BGR -> RGB, :101-105
+    w, b = fold_conv_bn(wd, 'conv1_2'); x = c12 = P.conv(x, w, b, act=ACT_ELU)  # :106-110
+    x = pool = P.maxpool(x, 3, 2, 0)                                           # :116 VALID
     raw, pre = x, x                  # raw = block input (skip path), pre = what conv "1" reads
     for i, (name, c, inc, first) in enumerate(MARS_BLOCKS):
         stride = 2 if inc else 1
@@ -301,7 +322,7 @@ def compile_mars(wd, in_h=64, in_w=32):
     w, b = fold_conv_bn(wd, 'fc1', 'fc1/bn')                                    # :143-147 (w is [4096,128])
     f = P.fc(raw, w, b, ACT_ELU, aff2=bn_affine(wd, 'ball'))                    # :152 "ball" BN
     P.out_tensor = P.l2norm(f, 1e-8)                                           # :153-156
-    P.meta = dict(kind='mars', out_dim=128)
+    P.meta = dict(kind='mars', out_dim=128, tensors=dict(conv1_1=c11, conv1_2=c12, pool1=pool))
     return P
 
 
@@ -381,8 +402,8 @@ def compile_ssd_mobilenet(wd, in_size=300):
     anchors, maps = ssd_anchors(in_size)
     n_anchors = len(anchors)
     ld = 4 + SSD_CLASSES
-    x = P.input(swap_rb=False, mean=127.5, scale=1.0 / 127.5)
-    w, b = fold_conv_bn(wd, 'conv0'); x = P.conv(x, w, b, stride=2, act=ACT_RELU6)
+    w, b = fold_conv_bn(wd, 'conv0')
+    x = P.stem(w, b, 2, ACT_RELU6, swap_rb=False, mean=127.5, scale=1.0 / 127.5)
     feats = []
     for i, (c, st) in enumerate(MOBILENET_V1, 1):
         s, t = bn_affine(wd, f'dw{i}/bn')

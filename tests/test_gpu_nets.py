@@ -56,7 +56,8 @@ def test_mars_intermediate_layers(mars):
     a1 = F.elu(nt._conv_bn(xt, wd, 'conv1_1', w16=True))
     a2 = F.elu(nt._conv_bn(a1, wd, 'conv1_2', w16=True))
     a3 = F.max_pool2d(a2, 3, 2)
-    for tid, want in ((1, a1), (2, a2), (3, a3)):
+    ids = net.program.meta['tensors']
+    for tid, want in ((ids['conv1_1'], a1), (ids['conv1_2'], a2), (ids['pool1'], a3)):
         got = net.read(tensor=tid).astype(np.float32)[..., :32]
         w = want.permute(0, 2, 3, 1).numpy()
         assert got.shape == w.shape, (got.shape, w.shape)
