@@ -23,7 +23,7 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-enum { OP_INPUT = 1, OP_CONV = 2, OP_DWCONV = 3, OP_MAXPOOL = 4, OP_UPSAMPLE = 5, OP_FC = 6, OP_L2NORM = 7, OP_STEM = 8 };
+enum { OP_INPUT = 1, OP_CONV = 2, OP_DWCONV = 3, OP_MAXPOOL = 4, OP_UPSAMPLE = 5, OP_FC = 6, OP_L2NORM = 7, OP_STEM = 8, OP_DWPW = 9 };
 enum { ACT_NONE = 0, ACT_RELU6 = 1, ACT_ELU = 2, ACT_SILU = 3, ACT_RELU = 4, ACT_SIGMOID = 5 };
 enum { EPI_F16 = 0, EPI_F32 = 1, EPI_SSD_HEAD = 2, EPI_YOLO = 3 };
 enum { DT_F16 = 0, DT_F32 = 1, DT_U8 = 2 };
@@ -59,6 +59,8 @@ struct ConvP {
     // spatially tiled kernels (conv3x3_rw_k, stem_conv3_k): th x tw output pixels of one image per block
     int th, tw, tiles_x, tiles_y;
     const uint8_t *src8; float in_mean, in_scale;      // stem: u8 [N][H][W][3] source, (x - mean) * scale
+    // fused depthwise 3x3 -> pointwise (dwpw_k): the depthwise half (H, W, stride, pad_* describe it; kh = kw = 1)
+    const _Float16 *dw_w; const float *dw_bias; int dw_act; int total_quads;
 };
 
 
@@ -175,11 +177,14 @@ __device__ __forceinline__ void conv_epilogue_f16x8(const ConvP &P, const Epi8 &
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] += (float)rv[r];
     }
+    const bool tail = co + 8 > P.cout;             // only the last, partly padded channel group needs masking
     h8 o;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        if (co + r >= P.cout) v[r] = 0.f;
-        o[r] = (_Float16)v[r];
+    for (int r = 0; r < 8; ++r) o[r] = (_Float16)v[r];
+    if (tail) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            if (co + r >= P.cout) o[r] = (_Float16)0.f;
     }
     *reinterpret_cast<h8 *>(static_cast<_Float16 *>(P.out) + (size_t)m * P.cs_out + P.coff_out + co) = o;
     if (P.out2) {                                   // second view: ELU(scale * raw + shift)
@@ -187,7 +192,12 @@ __device__ __forceinline__ void conv_epilogue_f16x8(const ConvP &P, const Epi8 &
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const float sc = r < 4 ? E.s0[r] : E.s1[r - 4], sh = r < 4 ? E.t0[r] : E.t1[r - 4];
-            o2[r] = (_Float16)(co + r < P.cout ? apply_act(sc * v[r] + sh, ACT_ELU) : 0.f);
+            o2[r] = (_Float16)apply_act(sc * v[r] + sh, ACT_ELU);
+        }
+        if (tail) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                if (co + r >= P.cout) o2[r] = (_Float16)0.f;
         }
         *reinterpret_cast<h8 *>(P.out2 + (size_t)m * P.cs_out2 + P.coff_out2 + co) = o2;
     }
@@ -552,9 +562,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rw_k(const ConvP P, const int 
             const int pix = (wave + 4 * i) * 16 + fpl;
             const int py = (int)((pix * rcp_pw) >> 16);
             const int y = ys + py, x = xs + pix - py * PW;
-            h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (pix < npix && y >= 0 && y < P.H && x >= 0 && x < P.W) z = *reinterpret_cast<const h8 *>(img + ((size_t)y * P.W + x) * P.cs_in);
-            v[i] = z;
+            const bool ok = pix < npix && y >= 0 && y < P.H && x >= 0 && x < P.W;      // else: a line of zeros, no branch
+            v[i] = *reinterpret_cast<const h8 *>(ok ? img + ((size_t)y * P.W + x) * P.cs_in : P.zero);
         }
     };
 
@@ -704,6 +713,159 @@ __global__ __launch_bounds__(256) void stem_conv3_k(const ConvP P) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// MobileNet block in one launch: depthwise 3x3 (+bias, activation) -> pointwise 1x1 (+bias, activation).
+// The depthwise result of a pixel tile never leaves the CU: it is rounded to f16 (exactly what the
+// two-kernel path stores) into the LDS image the MFMA fragments are read from, so the layer pair
+// costs one read of the block input and one write of the block output instead of two of each.
+//
+// Pixels are taken in "quad order": a quad is 4 consecutive output pixels of one row (the last quad of
+// a row may hang over the edge), a block owns BM/4 consecutive quads and each thread computes one
+// (quad, 8-channel group) item from a 3 x (3 + 3*stride) window of 16-byte loads, as dwconv3_k does.
+// The whole pointwise weight panel [BN][CIN] is resident in LDS (fetched while the depthwise part
+// runs); its rows are stored in fragment order of rw_weight_row, so a lane ends up with 8 consecutive
+// output channels of a pixel and stores 16 bytes without a transposition pass.
+template <int CIN>
+__device__ __forceinline__ int dwpw_swz(int c, int row) {         // position of 16-byte chunk c inside LDS row `row`
+    if (CIN == 32) return c ^ ((4 - ((row >> 2) & 3)) & 3);
+    if (CIN == 64) return c ^ (row & 7);
+    return (c & ~15) | ((c & 15) ^ (row & 15));
+}
+
+template <int WM, int WN, int MI, int CIN, int STRIDE, int DACT, int ACT>
+__global__ __launch_bounds__(256) void dwpw_k(const ConvP P) {
+    constexpr int NI = 4, BM = WM * MI * 16, BN = WN * 64, G = CIN / 8, KS = CIN / 32;
+    constexpr int TX = 4, NCOL = (TX - 1) * STRIDE + 3;
+    static_assert(WM * WN == 4 && (BM / 4) * G == 256, "one (quad, channel group) item per thread");
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    _Float16 *xs = lds, *ws = lds + BM * CIN;
+    int *mrow = reinterpret_cast<int *>(ws + BN * CIN);             // output pixel index of each tile row, -1 = none
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int q0 = (int)dd_xcd_remap(blockIdx.x, gridDim.x) * (BM / 4);
+    const int n0 = blockIdx.y * BN;
+
+    // ---- pointwise weight panel -> LDS (rows in fragment order)
+    {
+        constexpr int CH = BN * G / 256;
+        h8 wv[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int idx = tid + i * 256;
+            const int j = idx / G, c = idx % G;
+            const int co = n0 + (j & ~63) + rw_weight_row((j >> 4) & 3, j & 15);
+            wv[i] = *reinterpret_cast<const h8 *>(P.w + (size_t)co * P.kpad + c * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int idx = tid + i * 256;
+            const int j = idx / G, c = idx % G;
+            *reinterpret_cast<h8 *>(ws + j * CIN + dwpw_swz<CIN>(c, j) * 8) = wv[i];
+        }
+    }
+
+    // ---- depthwise part: this thread's quad and channel group
+    {
+        const int ql = tid / G, g = tid % G;
+        const int Q = q0 + ql;
+        const int wo4 = (P.wo + TX - 1) / TX;
+        const bool qok = Q < P.total_quads;
+        const int Qc = qok ? Q : 0;
+        const int oxq = Qc % wo4, t2 = Qc / wo4;
+        const int oy = t2 % P.ho, n = t2 / P.ho;
+        const int ox0 = oxq * TX;
+        float acc[TX][8];
+        {
+            const f4 b0 = *reinterpret_cast<const f4 *>(P.dw_bias + g * 8), b1 = *reinterpret_cast<const f4 *>(P.dw_bias + g * 8 + 4);
+#pragma unroll
+            for (int j = 0; j < TX; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { acc[j][i] = b0[i]; acc[j][4 + i] = b1[i]; }
+        }
+        const int ix0 = ox0 * STRIDE - P.pad_l;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            // out-of-image taps read a zero line instead of branching around the load: all 3 x NCOL loads
+            // of the window are then independent and in flight together
+            const int iy = oy * STRIDE - P.pad_t + kh;
+            const bool rok = qok && iy >= 0 && iy < P.H;
+            const _Float16 *row = P.in + ((size_t)(n * P.H + (rok ? iy : 0)) * P.W) * P.cs_in + P.coff_in + g * 8;
+            h8 x[NCOL];
+#pragma unroll
+            for (int cx = 0; cx < NCOL; ++cx) {
+                const int ix = ix0 + cx;
+                const _Float16 *src = (rok && ix >= 0 && ix < P.W) ? row + (size_t)ix * P.cs_in : P.zero;
+                x[cx] = *reinterpret_cast<const h8 *>(src);
+            }
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const h8 w = *reinterpret_cast<const h8 *>(P.dw_w + (size_t)(kh * 3 + kw) * CIN + g * 8);
+#pragma unroll
+                for (int j = 0; j < TX; ++j)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[j][i] += (float)x[j * STRIDE + kw][i] * (float)w[i];
+            }
+        }
+        const int dact = DACT < 0 ? P.dw_act : DACT;
+#pragma unroll
+        for (int j = 0; j < TX; ++j) {
+            const int prow = ql * TX + j;
+            const bool pok = qok && ox0 + j < P.wo;
+            h8 o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = (_Float16)apply_act(acc[j][i], dact);
+            typedef unsigned u4v __attribute__((ext_vector_type(4)));
+            u4v ou = __builtin_bit_cast(u4v, o);                   // rows past the edge are zeroed on the packed words
+            ou &= pok ? 0xFFFFFFFFu : 0u;                          // (a per-element select gets compiled into 32 branches)
+            *reinterpret_cast<u4v *>(xs + prow * CIN + dwpw_swz<CIN>(g, prow) * 8) = ou;
+            if (g == 0) mrow[prow] = pok ? (n * P.ho + oy) * P.wo + ox0 + j : -1;
+        }
+    }
+    __syncthreads();
+
+    // ---- pointwise part: [BM pixels] x [BN channels] x CIN, everything already in LDS
+    f4 acc[NI][MI];
+#pragma unroll
+    for (int a = 0; a < NI; ++a)
+#pragma unroll
+        for (int b = 0; b < MI; ++b) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+        const int c = kk * 4 + fq;
+        h8 xf[MI], wf[NI];
+#pragma unroll
+        for (int b = 0; b < MI; ++b) {
+            const int r = (wm * MI + b) * 16 + fr;
+            xf[b] = *reinterpret_cast<const h8 *>(xs + r * CIN + dwpw_swz<CIN>(c, r) * 8);
+        }
+#pragma unroll
+        for (int a = 0; a < NI; ++a) {
+            const int r = (wn * NI + a) * 16 + fr;
+            wf[a] = *reinterpret_cast<const h8 *>(ws + r * CIN + dwpw_swz<CIN>(c, r) * 8);
+        }
+#pragma unroll
+        for (int a = 0; a < NI; ++a)
+#pragma unroll
+            for (int b = 0; b < MI; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[a], xf[b], acc[a][b], 0, 0, 0);
+    }
+    Epi8 E[2];
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2) E[g2] = epi8_load(P, n0 + wn * 64 + g2 * 32 + fq * 8);
+#pragma unroll
+    for (int b = 0; b < MI; ++b) {
+        const int m = mrow[(wm * MI + b) * 16 + fr];
+        if (m < 0) continue;
+#pragma unroll
+        for (int g2 = 0; g2 < 2; ++g2) {
+            float o[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { o[r] = acc[2 * g2][b][r]; o[4 + r] = acc[2 * g2 + 1][b][r]; }
+            conv_epilogue_f16x8<ACT>(P, E[g2], m, n0 + wn * 64 + g2 * 32 + fq * 8, o);
+        }
+    }
+}
+
 // Split-K tail: sum the partial slabs in a fixed order (bitwise reproducible) and run the epilogue.
 __global__ __launch_bounds__(256) void conv_splitk_finish_k(const ConvP P) {
     const int groups = P.cout_pad >> 2;
@@ -725,6 +887,7 @@ struct DwP {
     const _Float16 *w; const float *bias;
     int stride, pad_t, pad_l, ho, wo, c, m, act;
     _Float16 *out; int cs_out, coff_out;
+    const _Float16 *zero;           // >= 16 bytes of zeros: what out-of-image taps read
 };
 
 // Each lane produces TX = 4 consecutive output pixels of one row for one 8-channel group: the
@@ -755,15 +918,13 @@ __global__ __launch_bounds__(256) void dwconv3_k(const DwP P) {
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
         const int iy = oy * STRIDE - P.pad_t + kh;
-        if (iy < 0 || iy >= P.H) continue;
-        const _Float16 *row = P.in + ((size_t)(n * P.H + iy) * P.W) * P.cs_in + P.coff_in + g * 8;
+        const bool rok = iy >= 0 && iy < P.H;                 // out-of-image taps read the zero line: no branches, all loads in flight
+        const _Float16 *row = P.in + ((size_t)(n * P.H + (rok ? iy : 0)) * P.W) * P.cs_in + P.coff_in + g * 8;
         h8 x[NCOL];
 #pragma unroll
         for (int cx = 0; cx < NCOL; ++cx) {
             const int ix = ix0 + cx;
-            h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (ix >= 0 && ix < P.W) v = *reinterpret_cast<const h8 *>(row + (size_t)ix * P.cs_in);
-            x[cx] = v;
+            x[cx] = *reinterpret_cast<const h8 *>((rok && ix >= 0 && ix < P.W) ? row + (size_t)ix * P.cs_in : P.zero);
         }
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
@@ -1017,6 +1178,26 @@ int launch_stem(hipStream_t s, ConvP &P, int nimg) {
     return DD_OK;
 }
 
+template <int WM, int WN, int MI, int CIN, int STRIDE>
+int launch_dwpw(hipStream_t s, ConvP &P) {
+    constexpr int BM = WM * MI * 16, BN = WN * 64;
+    constexpr size_t lds_bytes = (size_t)(BM + BN) * CIN * sizeof(_Float16) + BM * sizeof(int);
+    const dim3 grid((unsigned)dd_ceil_div(P.total_quads, BM / 4), (unsigned)dd_ceil_div(P.cout_pad, BN));
+    const bool relu6 = P.act == ACT_RELU6 && P.dw_act == ACT_RELU6;
+    static bool attr_done = false;
+    if (!attr_done && lds_bytes > 65536) {
+        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dwpw_k<WM, WN, MI, CIN, STRIDE, ACT_RELU6, ACT_RELU6>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dwpw_k<WM, WN, MI, CIN, STRIDE, -1, -1>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        attr_done = true;
+    }
+    if (relu6) hipLaunchKernelGGL((dwpw_k<WM, WN, MI, CIN, STRIDE, ACT_RELU6, ACT_RELU6>), grid, dim3(256), lds_bytes, s, P);
+    else hipLaunchKernelGGL((dwpw_k<WM, WN, MI, CIN, STRIDE, -1, -1>), grid, dim3(256), lds_bytes, s, P);
+    DD_LAUNCH_CHECK();
+    return DD_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1234,6 +1415,30 @@ int dd_net_forward(dd_net *net, const uint8_t *input, int nimg, void *stream) {
                 if (rc != DD_OK) return rc;
                 break;
             }
+            case OP_DWPW: {
+                ConvP P;
+                memset(&P, 0, sizeof(P));
+                P.in = reinterpret_cast<const _Float16 *>(base(src)); P.H = ts->h; P.W = ts->w; P.cs_in = ts->cs;
+                P.coff_in = ts->coff; P.cin = o[10];
+                P.kh = P.kw = 1; P.stride = o[7]; P.pad_t = o[8]; P.pad_l = o[9];
+                P.cout = o[11]; P.cout_pad = o[12]; P.kpad = o[13]; P.act = o[14]; P.epi = EPI_F16; P.splitk = 1;
+                P.w = reinterpret_cast<const _Float16 *>(net->d_weights + (size_t)(uint32_t)o[16]);
+                P.bias = reinterpret_cast<const float *>(net->d_weights + (size_t)(uint32_t)o[17]);
+                P.dw_w = reinterpret_cast<const _Float16 *>(net->d_weights + (size_t)(uint32_t)o[20]);
+                P.dw_bias = reinterpret_cast<const float *>(net->d_weights + (size_t)(uint32_t)o[21]);
+                P.dw_act = o[22]; P.zero = net->d_zero;
+                P.ho = td->h; P.wo = td->w; P.m = nimg * P.ho * P.wo;
+                P.total_quads = nimg * P.ho * ((P.wo + 3) / 4);
+                P.out = base(dst); P.cs_out = td->cs; P.coff_out = td->coff;
+                int rc;
+                if (P.cin == 32 && P.cout_pad == 64 && P.stride == 1) rc = launch_dwpw<4, 1, 4, 32, 1>(s, P);
+                else if (P.cin == 64 && P.cout_pad == 128 && P.stride == 2) rc = launch_dwpw<2, 2, 4, 64, 2>(s, P);
+                else if (P.cin == 128 && P.cout_pad == 128 && P.stride == 1) rc = launch_dwpw<2, 2, 2, 128, 1>(s, P);
+                else if (P.cin == 128 && P.cout_pad == 256 && P.stride == 2) rc = launch_dwpw<1, 4, 4, 128, 2>(s, P);
+                else DD_REQUIRE(false, DD_E_ARG, "dd_net_forward: no fused dw+pw kernel for %d -> %d stride %d", P.cin, P.cout_pad, P.stride);
+                if (rc != DD_OK) return rc;
+                break;
+            }
             case OP_DWCONV: {
                 DwP P;
                 P.in = reinterpret_cast<const _Float16 *>(base(src)); P.H = ts->h; P.W = ts->w; P.cs_in = ts->cs; P.coff_in = ts->coff;
@@ -1242,6 +1447,7 @@ int dd_net_forward(dd_net *net, const uint8_t *input, int nimg, void *stream) {
                 P.stride = o[7]; P.pad_t = o[8]; P.pad_l = o[9]; P.ho = td->h; P.wo = td->w; P.c = o[12];
                 P.m = nimg * td->h * td->w; P.act = o[14];
                 P.out = reinterpret_cast<_Float16 *>(base(dst)); P.cs_out = td->cs; P.coff_out = td->coff;
+                P.zero = net->d_zero;
                 const long long total = (long long)(P.m / P.wo) * ((P.wo + 3) / 4) * (P.c >> 3);
                 DD_REQUIRE(P.stride == 1 || P.stride == 2, DD_E_ARG, "dd_net_forward: depthwise stride %d", P.stride);
                 if (P.stride == 1)

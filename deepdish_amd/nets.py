@@ -17,7 +17,7 @@ random weights of the right shapes so the HIP path and the oracle can be compare
 import math
 import numpy as np
 
-OP_INPUT, OP_CONV, OP_DWCONV, OP_MAXPOOL, OP_UPSAMPLE, OP_FC, OP_L2NORM, OP_STEM = 1, 2, 3, 4, 5, 6, 7, 8
+OP_INPUT, OP_CONV, OP_DWCONV, OP_MAXPOOL, OP_UPSAMPLE, OP_FC, OP_L2NORM, OP_STEM, OP_DWPW = 1, 2, 3, 4, 5, 6, 7, 8, 9
 ACT_NONE, ACT_RELU6, ACT_ELU, ACT_SILU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3, 4, 5
 EPI_F16, EPI_F32, EPI_SSD_HEAD, EPI_YOLO = 0, 1, 2, 3
 DT_F16, DT_F32, DT_U8 = 0, 1, 2
@@ -186,6 +186,30 @@ class Program:
         self._op(OP_DWCONV, src=src, dst=dst, stride=stride, pad_t=pt, pad_l=pl, cout_pad=cp, act=act,
                  w_off=self.add_blob(wp), b_off=self.add_blob(bp))
         self.info[-1] = dict(kernel='dwconv3_k', flops=2 * ho * wo * 9 * c, bytes=2 * (s['h'] * s['w'] * c + ho * wo * c), wbytes=2 * 9 * c + 4 * c)
+        return dst
+
+    DWPW_SHAPES = {(32, 64, 1), (64, 128, 2), (128, 128, 1), (128, 256, 2)}     # (channels, pointwise cout, depthwise stride)
+
+    def dwpw(self, src, dw_hwc, dw_bias, stride, dw_act, pw_hwio, pw_bias, pw_act):
+        """Depthwise 3x3 (TF SAME) + pointwise 1x1 as one launch (csrc/nets.hip dwpw_k) for the block shapes
+        it is instantiated for; any other shape falls back to the two separate ops."""
+        s = self.T(src)
+        c = s['c']
+        cout = pw_hwio.shape[3]
+        if (c, cout, stride) not in self.DWPW_SHAPES or c % 8 or cout % 8:
+            x = self.dwconv(src, dw_hwc, dw_bias, stride, dw_act)
+            return self.conv(x, pw_hwio, pw_bias, act=pw_act)
+        assert dw_hwc.shape == (3, 3, c) and pw_hwio.shape[:3] == (1, 1, c)
+        ho, pt = same_pad(s['h'], 3, stride)
+        wo, pl = same_pad(s['w'], 3, stride)
+        dwp = dw_hwc.reshape(9, c).astype(np.float16)
+        wflat = np.ascontiguousarray(pw_hwio.reshape(c, cout).T.astype(np.float16))          # [cout][cin]
+        dst = self.tensor(ho, wo, cout)
+        self._op(OP_DWPW, src=src, dst=dst, kh=1, kw=1, stride=stride, pad_t=pt, pad_l=pl, cin=c, cout=cout, cout_pad=cout,
+                 kpad=c, act=pw_act, epi=EPI_F16, w_off=self.add_blob(wflat), b_off=self.add_blob(pw_bias.astype(np.float32)),
+                 p=[self.add_blob(dwp), self.add_blob(dw_bias.astype(np.float32)), dw_act], ho=ho, wo=wo)
+        self.info[-1] = dict(kernel='dwpw_k', flops=2 * ho * wo * c * (9 + cout), bytes=2 * (s['h'] * s['w'] * c + ho * wo * cout),
+                             wbytes=2 * c * (9 + cout) + 4 * (c + cout))
         return dst
 
     def maxpool(self, src, k, stride, pad, dst=None):
@@ -407,8 +431,8 @@ def compile_ssd_mobilenet(wd, in_size=300):
     feats = []
     for i, (c, st) in enumerate(MOBILENET_V1, 1):
         s, t = bn_affine(wd, f'dw{i}/bn')
-        x = P.dwconv(x, wd[f'dw{i}/weights'][:, :, :, 0] * s, t, st, ACT_RELU6)
-        w, b = fold_conv_bn(wd, f'pw{i}'); x = P.conv(x, w, b, act=ACT_RELU6)
+        w, b = fold_conv_bn(wd, f'pw{i}')
+        x = P.dwpw(x, wd[f'dw{i}/weights'][:, :, :, 0] * s, t, st, ACT_RELU6, w, b, ACT_RELU6)
         if i in (11, 13):
             feats.append(x)
     for j in range(1, 5):
