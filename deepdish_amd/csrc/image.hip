@@ -8,6 +8,10 @@
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <tuple>
+#include <vector>
+#include <algorithm>
+#include <cstdint>
 #include "common.h"
 
 namespace {
@@ -181,6 +185,65 @@ __global__ __launch_bounds__(256) void lanczos_v4_k(const uint8_t *__restrict__ 
     *reinterpret_cast<uint32_t *>(dst + (size_t)yy * rowbytes + xb) = o;
 }
 
+// ------------------------------------------------------------------ Pillow Lanczos on the i8 matrix cores
+// Either pass of the separable resample is a banded matrix product over bytes,
+//     outT[col][row] = clip8((sum_k coef[col][k] * src[row][start(col group) + k] + 2^21) >> 22),
+// (horizontal: row = image row, col = (output x, channel), k runs over the interleaved bytes of the
+// source row; vertical: row = (x, channel) of the transposed intermediate, col = output y, k = source y).
+// Both write their result transposed, so two passes end in the natural [h][w][3] layout and neither
+// needs a byte shuffle.  The 22-bit Pillow coefficients are split into three signed base-256 digits
+// (balanced, so each fits i8) and the pixels are biased by -128 (x ^ 0x80); three
+// v_mfma_i32_16x16x64_i8 per 64 source bytes give the digit sums exactly in i32 and
+// d0 + (d1 << 8) + (d2 << 16) + 128 * sum(coef) is the integer Pillow computes -- bit-exact.
+// One wave owns 16 output columns (its coefficient fragments stay in registers) and walks 16-row tiles;
+// operands come straight from global memory in MFMA fragment shape: no LDS, no barriers.
+typedef int i4v __attribute__((ext_vector_type(4)));
+
+template <int KS>
+__global__ __launch_bounds__(256) void band_resample_k(const uint8_t *__restrict__ src, size_t src_img_stride, int R,
+                                                       int pitch_s, const int *__restrict__ start,
+                                                       const i4v *__restrict__ coef, const int *__restrict__ bias,
+                                                       int n_groups, int C, uint8_t *__restrict__ outT,
+                                                       size_t out_img_stride, int pitch_o, int tiles_per_chunk) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = blockIdx.x * 4 + wave;
+    if (g >= n_groups) return;                                  // whole waves leave; the kernel has no barrier
+    const int fr = lane & 15, fq = lane >> 4;
+    i4v cf[KS][3];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) cf[ks][p] = coef[((size_t)(g * KS + ks) * 3 + p) * 64 + lane];
+    const int col = g * 16 + fr;
+    const int b = col < C ? bias[col] : 0;
+    const uint8_t *base = src + blockIdx.z * src_img_stride + start[g] + fq * 16;
+    uint8_t *obase = outT + blockIdx.z * out_img_stride + (size_t)col * pitch_o + fq * 4;
+    const int r_first = blockIdx.y * tiles_per_chunk * 16;
+    for (int t = 0; t < tiles_per_chunk; ++t) {
+        const int r0 = r_first + t * 16;
+        if (r0 >= R) break;
+        const uint8_t *p = base + (size_t)min(r0 + fr, R - 1) * pitch_s;
+        i4v a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            i4v x = *reinterpret_cast<const i4v *>(p + ks * 64);
+            x ^= (int)0x80808080;                                // u8 -> i8: p - 128
+            a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, cf[ks][0], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, cf[ks][1], a1, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, cf[ks][2], a2, 0, 0, 0);
+        }
+        uint32_t by[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int v = (int)((unsigned)a0[i] + ((unsigned)a1[i] << 8) + ((unsigned)a2[i] << 16) + (unsigned)b);
+            by[i] = (uint32_t)min(max(v >> PRECISION_BITS, 0), 255);
+        }
+        asm volatile("" : "+v"(by[0]), "+v"(by[1]), "+v"(by[2]), "+v"(by[3]));     // see lanczos_v4_k: keep v_ashr_pk_u8_i32 away
+        if (col < C && r0 + fq * 4 < R)
+            *reinterpret_cast<uint32_t *>(obase + r0) = by[0] | (by[1] << 8) | (by[2] << 16) | (by[3] << 24);
+    }
+}
+
 __global__ __launch_bounds__(256) void copy_rgb_k(const uint8_t *__restrict__ src, int n_px, int src_c, int swap_rb,
                                                   uint8_t *__restrict__ dst) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -284,6 +347,113 @@ int get_table(int device, int in_size, int out_size, DevTable *out) {
     return DD_OK;
 }
 
+// Banded-product tables for band_resample_k.  `taps(col)` yields (source byte index, coefficient)
+// pairs of output column `col`; pitch = bytes per source row (the window of a column group must fit).
+struct BandTable { int n_groups = 0, ksteps = 0, n_cols = 0; int *start = nullptr; void *coef = nullptr; int *bias = nullptr; bool ok = false; };
+std::map<std::tuple<int, int, int, int, int, int, int>, BandTable> g_bands;     // (device, in, out, mode, src_c, swap, pitch)
+
+template <class TapFn>
+bool build_band(int n_cols, int pitch, TapFn taps, std::vector<int> &start, std::vector<int8_t> &coef, std::vector<int> &bias, int &ksteps) {
+    const int n_groups = (n_cols + 15) / 16;
+    std::vector<std::vector<std::pair<int, int>>> col_taps(n_cols);
+    for (int c = 0; c < n_cols; ++c) taps(c, col_taps[c]);
+    start.assign(n_groups, 0);
+    ksteps = 1;
+    std::vector<int> kmax(n_groups, 0);
+    for (int g = 0; g < n_groups; ++g) {
+        int lo = INT32_MAX, hi = -1;
+        for (int c = g * 16; c < std::min(n_cols, g * 16 + 16); ++c)
+            for (auto &t : col_taps[c]) { lo = std::min(lo, t.first); hi = std::max(hi, t.first); }
+        if (hi < 0) { lo = hi = 0; }
+        start[g] = lo & ~15;
+        kmax[g] = hi;
+        ksteps = std::max(ksteps, (hi + 1 - start[g] + 63) / 64);
+    }
+    if (ksteps > 4 || ksteps * 64 > pitch) return false;
+    for (int g = 0; g < n_groups; ++g) {
+        if (start[g] + ksteps * 64 > pitch) start[g] = (pitch - ksteps * 64) & ~15;      // keep the window inside the row
+        if (start[g] < 0 || kmax[g] >= start[g] + ksteps * 64) return false;
+    }
+    coef.assign((size_t)n_groups * ksteps * 3 * 64 * 16, 0);
+    bias.assign((size_t)n_groups * 16, 0);
+    for (int c = 0; c < n_cols; ++c) {
+        const int g = c / 16, j = c % 16;
+        long long sum = 0;
+        for (auto &t : col_taps[c]) {
+            const int k = t.second;
+            sum += k;
+            const int d0 = ((k + 128) & 255) - 128, r1 = (k - d0) >> 8;
+            const int d1 = ((r1 + 128) & 255) - 128, d2 = (r1 - d1) >> 8;
+            if (d2 < -128 || d2 > 127) return false;
+            const int off = t.first - start[g], ks = off / 64, kg = (off % 64) / 16, i = off % 16;
+            const int dig[3] = {d0, d1, d2};
+            for (int p = 0; p < 3; ++p) {
+                int8_t &slot = coef[((((size_t)g * ksteps + ks) * 3 + p) * 64 + (kg * 16 + j)) * 16 + i];
+                slot = (int8_t)(slot + dig[p]);                    // one tap per source byte and column: plain store
+            }
+        }
+        bias[c] = (int)((1LL << (PRECISION_BITS - 1)) + 128 * sum);
+    }
+    return true;
+}
+
+// mode 0: horizontal (in = W, out = w, columns (x, c), source bytes x*src_c + channel); mode 1: vertical (in = H, out = h).
+int get_band(int device, int in_size, int out_size, int mode, int src_c, int swap_rb, int pitch, BandTable *out) {
+    std::lock_guard<std::mutex> lk(g_tab_mu);
+    auto key = std::make_tuple(device, in_size, out_size, mode, src_c, swap_rb, pitch);
+    auto it = g_bands.find(key);
+    if (it == g_bands.end()) {
+        const LanczosTable t = make_table(in_size, out_size);
+        BandTable b;
+        std::vector<int> start, bias;
+        std::vector<int8_t> coef;
+        int ksteps = 0;
+        const int n_cols = mode == 0 ? out_size * 3 : out_size;
+        auto taps = [&](int c, std::vector<std::pair<int, int>> &v) {
+            const int o = mode == 0 ? c / 3 : c, ch = mode == 0 ? c % 3 : 0;
+            const int lo = t.bounds[2 * o], n = t.bounds[2 * o + 1];
+            for (int x = 0; x < n; ++x) {
+                const int k = t.kk[(size_t)o * t.ksize + x];
+                if (k == 0) continue;
+                v.emplace_back(mode == 0 ? (lo + x) * src_c + (swap_rb ? 2 - ch : ch) : lo + x, k);
+            }
+        };
+        b.ok = build_band(n_cols, pitch, taps, start, coef, bias, ksteps);
+        if (b.ok) {
+            b.n_groups = (int)start.size(); b.ksteps = ksteps; b.n_cols = n_cols;
+            DD_HIP(hipMalloc(&b.start, start.size() * sizeof(int)));
+            DD_HIP(hipMalloc(&b.coef, coef.size()));
+            DD_HIP(hipMalloc(&b.bias, bias.size() * sizeof(int)));
+            DD_HIP(hipMemcpy(b.start, start.data(), start.size() * sizeof(int), hipMemcpyHostToDevice));
+            DD_HIP(hipMemcpy(b.coef, coef.data(), coef.size(), hipMemcpyHostToDevice));
+            DD_HIP(hipMemcpy(b.bias, bias.data(), bias.size() * sizeof(int), hipMemcpyHostToDevice));
+        }
+        it = g_bands.emplace(key, b).first;
+    }
+    *out = it->second;
+    return DD_OK;
+}
+
+int launch_band(hipStream_t s, const BandTable &b, const uint8_t *src, size_t src_img_stride, int R, int pitch_s, uint8_t *outT,
+                size_t out_img_stride, int pitch_o, int batch) {
+    const int tiles = dd_ceil_div(R, 16);
+    const int chunks = std::max(1, std::min(tiles, dd_ceil_div(8192, std::max(1, b.n_groups * batch))));
+    const int tpc = dd_ceil_div(tiles, chunks);
+    const dim3 grid((unsigned)dd_ceil_div(b.n_groups, 4), (unsigned)dd_ceil_div(tiles, tpc), (unsigned)batch);
+    const i4v *cf = static_cast<const i4v *>(b.coef);
+#define DD_BAND(KS_) hipLaunchKernelGGL(band_resample_k<KS_>, grid, dim3(256), 0, s, src, src_img_stride, R, pitch_s, b.start, cf, b.bias, \
+                                        b.n_groups, b.n_cols, outT, out_img_stride, pitch_o, tpc)
+    switch (b.ksteps) {
+        case 1: DD_BAND(1); break;
+        case 2: DD_BAND(2); break;
+        case 3: DD_BAND(3); break;
+        default: DD_BAND(4); break;
+    }
+#undef DD_BAND
+    DD_LAUNCH_CHECK();
+    return DD_OK;
+}
+
 }  // namespace
 
 namespace ddk {
@@ -318,6 +488,22 @@ int crop_resize(hipStream_t s, const uint8_t *frames, int H, int W, const void *
 // `batch` images of identical geometry, densely packed; tmp must hold batch*H*w*3 bytes.
 int resize_lanczos(hipStream_t s, int device, const uint8_t *src, int H, int W, int src_c, int swap_rb,
                    uint8_t *dst, int h, int w, uint8_t *tmp, int batch) {
+    // ---- matrix-core path: both passes as banded i8 products through a transposed intermediate [w*3][H]
+    static const int dbg_band = getenv("DD_LANCZOS_DEBUG") ? atoi(getenv("DD_LANCZOS_DEBUG")) : 0;
+    if (!(dbg_band & 4) && w != W && h != H && (src_c == 3 || src_c == 4) && (W * src_c) % 16 == 0 && H % 16 == 0 &&
+        (w * 3) % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(tmp) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(dst) & 3) == 0 && ((size_t)H * W * src_c) % 16 == 0) {
+        BandTable bh, bv;
+        int rc = get_band(device, W, w, 0, src_c, swap_rb, W * src_c, &bh);
+        if (rc != DD_OK) return rc;
+        rc = get_band(device, H, h, 1, 1, 0, H, &bv);
+        if (rc != DD_OK) return rc;
+        if (bh.ok && bv.ok) {
+            rc = launch_band(s, bh, src, (size_t)H * W * src_c, H, W * src_c, tmp, (size_t)w * 3 * H, H, batch);
+            if (rc != DD_OK) return rc;
+            return launch_band(s, bv, tmp, (size_t)w * 3 * H, w * 3, H, dst, (size_t)h * w * 3, w * 3, batch);
+        }
+    }
     const uint8_t *mid = src;
     int mid_c = src_c;
     if (w != W) {
