@@ -1090,15 +1090,18 @@ inline size_t dtype_size(int dt) { return dt == DT_F16 ? 2 : (dt == DT_F32 ? 4 :
 // chain of (load -> barrier -> MFMA) steps is short; partial sums go through an f32 slab.
 // GLDS selects the direct-to-LDS kernel (needs padded Cin % 64 == 0 and BK == 64).
 template <int WM, int WN, int MI, int NI, int BK, bool GLDS>
-int launch_conv(hipStream_t s, ConvP &P, DevBuf &slab) {
+int launch_conv(hipStream_t s, ConvP &P, DevBuf &slab, int max_batch) {
     constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
     const int gx = dd_ceil_div(P.m, BM), gy = dd_ceil_div(P.cout_pad, BN);
     const int ksteps = P.kpad / BK;
-    // The split depends on the layer shape only, never on the batch: every output element is then
-    // summed in the same order whatever else shares the launch (streams stay independent).
+    // The split depends on the layer shape and on the engine's max_batch only, never on the batch of the
+    // call: every output element is then summed in the same order whatever else shares the launch
+    // (streams stay independent).  An engine sized for many images has enough blocks without splitting,
+    // and the f32 partial-sum slabs (splitk x the layer output, written and re-read) would dominate.
     int splitk = 1;
     const int blocks_per_image = dd_ceil_div(P.ho * P.wo, BM) * gy;
-    if (blocks_per_image <= 8 && ksteps >= 8) {
+    const long long blocks_full = (long long)dd_ceil_div(max_batch * P.ho * P.wo, BM) * gy;
+    if (blocks_per_image <= 8 && ksteps >= 8 && blocks_full < 512) {
         splitk = std::min(16, ksteps / 4);
         const int per = dd_ceil_div(ksteps, splitk);
         splitk = dd_ceil_div(ksteps, per);                    // no empty split
@@ -1384,18 +1387,18 @@ int dd_net_forward(dd_net *net, const uint8_t *input, int nimg, void *stream) {
                     rc = launch_conv3x3_rw(s, P, nimg);
                 } else if (P.cout_pad <= 32) {
                     // 32 output channels: 128 pixels per block (each wave 32 px x 32 ch) once there are enough pixels
-                    rc = bk32 ? launch_conv<4, 1, 1, 2, 32, false>(s, P, net->slab)
-                       : (glds && P.m >= 16384) ? launch_conv<4, 1, 2, 2, 64, true>(s, P, net->slab)
-                       : glds ? launch_conv<4, 1, 1, 2, 64, true>(s, P, net->slab)
-                              : launch_conv<4, 1, 1, 2, 64, false>(s, P, net->slab);
+                    rc = bk32 ? launch_conv<4, 1, 1, 2, 32, false>(s, P, net->slab, net->max_batch)
+                       : (glds && P.m >= 16384) ? launch_conv<4, 1, 2, 2, 64, true>(s, P, net->slab, net->max_batch)
+                       : glds ? launch_conv<4, 1, 1, 2, 64, true>(s, P, net->slab, net->max_batch)
+                              : launch_conv<4, 1, 1, 2, 64, false>(s, P, net->slab, net->max_batch);
                 } else if (glds && net->tile_mode == 0 && P.m >= 4096 && P.cout_pad >= 128) {
                     // 64 pixels x 128 channels: each staged pixel row feeds twice the MFMAs; measured 31 us vs 38 us
                     // for 19x19x512 -> 512 at 64 frames (128 x 64 gave nothing, 128 x 128 was 2.5x slower: 2 blocks/CU)
-                    rc = launch_conv<2, 2, 2, 4, 64, true>(s, P, net->slab);
+                    rc = launch_conv<2, 2, 2, 4, 64, true>(s, P, net->slab, net->max_batch);
                 } else {
-                    rc = bk32 ? launch_conv<2, 2, 2, 2, 32, false>(s, P, net->slab)
-                       : glds ? launch_conv<2, 2, 2, 2, 64, true>(s, P, net->slab)
-                              : launch_conv<2, 2, 2, 2, 64, false>(s, P, net->slab);
+                    rc = bk32 ? launch_conv<2, 2, 2, 2, 32, false>(s, P, net->slab, net->max_batch)
+                       : glds ? launch_conv<2, 2, 2, 2, 64, true>(s, P, net->slab, net->max_batch)
+                              : launch_conv<2, 2, 2, 2, 64, false>(s, P, net->slab, net->max_batch);
                 }
                 if (rc != DD_OK) return rc;
                 break;
