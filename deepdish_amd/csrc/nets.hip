@@ -518,11 +518,11 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_glds_k(const ConvP P) {
 // one 16-byte store per pixel and lane, 64 contiguous bytes per pixel, 1 KiB per fragment.
 __device__ __forceinline__ int rw_weight_row(int a, int fr) { return (a >> 1) * 32 + (fr >> 2) * 8 + (a & 1) * 4 + (fr & 3); }
 
-constexpr int RW_FILL = 10;                                    // 16 patch pixels x 4 chunks per wave pass: <= 640 patch pixels
+constexpr int RW_FILL = 11;                                    // 16 patch pixels x 4 chunks per wave pass: <= 704 patch pixels
 constexpr int RW_MAX_PATCH = RW_FILL * 64;
 constexpr int RW_MB = 4;                                       // pixel fragments in flight per wave
 
-template <int NCO, int TW, int ACT>                            // TW: tile width when known at compile time (tap offsets
+template <int NCO, int TW, int ACT, bool POOL>                 // TW: tile width when known at compile time (tap offsets
 __global__ __launch_bounds__(256, 2) void conv3x3_rw_k(const ConvP P, const int total_tiles) {   // become ds_read immediates), else 0
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -530,6 +530,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rw_k(const ConvP P, const int 
     const int tw = TW ? TW : P.tw;
     const int PW = tw + 2, npix = (P.th + 2) * PW;
     const int plane = (npix * 8 + 127) & ~127;                  // halves per 8-channel plane (256-byte multiple)
+    _Float16 *stage = lds + 4 * plane;                          // POOL: the activated output tile [th*tw][NCO*16]
     // exact x / d for x < 1024, d <= 34 without an integer division per lane
     const unsigned rcp_pw = (65536u + PW - 1) / PW, rcp_tw = (65536u + tw - 1) / tw;
     const int tiles_per_image = P.tiles_x * P.tiles_y;
@@ -555,7 +556,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rw_k(const ConvP P, const int 
         const int lt = (int)dd_xcd_remap((unsigned)t, (unsigned)total_tiles);
         const int n = lt / tiles_per_image, r = lt - n * tiles_per_image;
         const int ty = r / P.tiles_x, tx = r - ty * P.tiles_x;
-        const int ys = ty * P.th - P.pad_t, xs = tx * tw - P.pad_l;
+        const int ys = ty * (POOL ? P.th - 1 : P.th) - P.pad_t, xs = tx * tw - P.pad_l;
         const _Float16 *img = P.in + (size_t)n * P.H * P.W * P.cs_in + P.coff_in + fc * 8;
 #pragma unroll
         for (int i = 0; i < RW_FILL; ++i) {
@@ -581,7 +582,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rw_k(const ConvP P, const int 
         const int lt = (int)dd_xcd_remap((unsigned)t, (unsigned)total_tiles);
         const int n = lt / tiles_per_image, rt = lt - n * tiles_per_image;
         const int tile_y = rt / P.tiles_x;
-        const int y0 = tile_y * P.th, x0 = (rt - tile_y * P.tiles_x) * tw;
+        const int y0 = tile_y * (POOL ? P.th - 1 : P.th), x0 = (rt - tile_y * P.tiles_x) * tw;
         const int tn = t + gridDim.x;
         if (tn < total_tiles) fetch(tn);
 
@@ -623,8 +624,44 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rw_k(const ConvP P, const int 
                     float o[8];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { o[r] = acc[2 * g][b][r]; o[4 + r] = acc[2 * g + 1][b][r]; }
-                    conv_epilogue_f16x8<ACT>(P, E[g], mrow[b], g * 32 + fq * 8, o);
+                    if constexpr (POOL) {                         // activated tile -> LDS, pooled below
+                        const int act = ACT < 0 ? P.act : ACT;
+                        h8 hv;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            hv[r] = (_Float16)apply_act(o[r] + E[g].b0[r], act);
+                            hv[4 + r] = (_Float16)apply_act(o[4 + r] + E[g].b1[r], act);
+                        }
+                        *reinterpret_cast<h8 *>(stage + ((f0 + b) * 16 + fr) * (NCO * 16) + g * 32 + fq * 8) = hv;
+                    } else {
+                        conv_epilogue_f16x8<ACT>(P, E[g], mrow[b], g * 32 + fq * 8, o);
+                    }
                 }
+            }
+        }
+        if constexpr (POOL) {
+            // 3x3 stride-2 VALID max pool of the tile: pooled row j of the tile covers tile rows 2j..2j+2
+            // (the last tile row is the next tile's first -- one recomputed row per tile instead of a
+            // round trip of the whole activation through HBM)
+            __syncthreads();
+            constexpr int CG = NCO * 2;                           // 8-channel groups
+            const int prows = (P.th - 1) >> 1, ph = P.p[0], pw = P.p[1];
+            for (int it = tid; it < prows * pw * CG; it += 256) {
+                const int c = it % CG, q = it / CG;
+                const int ox = q % pw, oyl = q / pw;
+                const int oy = tile_y * prows + oyl;
+                if (oy >= ph) continue;
+                h8 best = *reinterpret_cast<const h8 *>(stage + ((2 * oyl) * tw + 2 * ox) * (NCO * 16) + c * 8);
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        if (dy == 0 && dx == 0) continue;
+                        const h8 x = *reinterpret_cast<const h8 *>(stage + ((2 * oyl + dy) * tw + 2 * ox + dx) * (NCO * 16) + c * 8);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) best[i] = x[i] > best[i] ? x[i] : best[i];
+                    }
+                *reinterpret_cast<h8 *>(static_cast<_Float16 *>(P.out) + ((size_t)(n * ph + oy) * pw + ox) * P.cs_out + P.coff_out + c * 8) = best;
             }
         }
         if (tn >= total_tiles) break;
@@ -1151,14 +1188,30 @@ void spatial_tile(int ho, int wo, int stride, int max_patch, ConvP &P) {
     P.th = th; P.tw = tw; P.tiles_x = tiles_x; P.tiles_y = tiles_y;
 }
 
-int launch_conv3x3_rw(hipStream_t s, ConvP &P, int nimg) {
-    spatial_tile(P.ho, P.wo, 1, RW_MAX_PATCH, P);
+int launch_conv3x3_rw(hipStream_t s, ConvP &P, int nimg, bool pool) {
+    if (pool) {                                                  // 8 pooled rows per tile = 17 conv rows, full width
+        P.tw = P.wo; P.th = 17; P.tiles_x = 1; P.tiles_y = dd_ceil_div(P.p[0], 8);
+        DD_REQUIRE(P.wo == 32 && P.act == ACT_ELU && !P.res && !P.out2, DD_E_ARG, "conv3x3_rw: fused pooling needs a 32-wide ELU layer");
+    } else {
+        spatial_tile(P.ho, P.wo, 1, RW_MAX_PATCH, P);
+    }
     const int npix = (P.th + 2) * (P.tw + 2);
     DD_REQUIRE(npix <= RW_MAX_PATCH, DD_E_ARG, "conv3x3_rw: patch of %d pixels", npix);
-    const size_t lds_bytes = (size_t)4 * ((npix * 16 + 255) & ~255);
+    const size_t lds_bytes = (size_t)4 * ((npix * 16 + 255) & ~255) + (pool ? (size_t)P.th * P.tw * 32 * sizeof(_Float16) : 0);
     const int total = nimg * P.tiles_x * P.tiles_y;
     const int grid = std::min(total, 2 * 256);                   // persistent: 2 blocks per CU (register-bound), multiple of 8
-#define DD_RW(TW_, ACT_) hipLaunchKernelGGL((conv3x3_rw_k<2, TW_, ACT_>), dim3((unsigned)grid), dim3(256), lds_bytes, s, P, total)
+    static bool attr_done = false;
+    if (pool && !attr_done) {
+        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_rw_k<2, 32, ACT_ELU, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        attr_done = true;
+    }
+    if (pool) {
+        hipLaunchKernelGGL((conv3x3_rw_k<2, 32, ACT_ELU, true>), dim3((unsigned)grid), dim3(256), lds_bytes, s, P, total);
+        DD_LAUNCH_CHECK();
+        return DD_OK;
+    }
+#define DD_RW(TW_, ACT_) hipLaunchKernelGGL((conv3x3_rw_k<2, TW_, ACT_, false>), dim3((unsigned)grid), dim3(256), lds_bytes, s, P, total)
     if (P.tw == 32 && P.act == ACT_ELU) DD_RW(32, ACT_ELU);
     else if (P.tw == 32 && P.act == ACT_SILU) DD_RW(32, ACT_SILU);
     else if (P.tw == 15 && P.act == ACT_ELU) DD_RW(15, ACT_ELU);
@@ -1378,13 +1431,16 @@ int dd_net_forward(dd_net *net, const uint8_t *input, int nimg, void *stream) {
                 for (int q = 0; q < 6; ++q) P.p[q] = o[20 + q];
                 for (int q = 0; q < 8; ++q) P.f[q] = of[32 + q];
                 int rc;
+                DD_REQUIRE(!o[29] || (net->use_rw && P.kh == 3 && P.stride == 1 && P.cin == 32 && P.cout_pad == 32), DD_E_ARG,
+                           "dd_net_forward: fused pooling is only built for the 3x3 32->32 kernel");
                 const bool bk32 = o[28] == 32;                 // shallow K (<= 96): one or few 32-wide steps
                 const bool glds = !bk32 && net->use_glds;          // K >= 97: direct-to-LDS fills, any Cin % 8 == 0
                 P.zero = net->d_zero;
                 if (net->use_rw && P.kh == 3 && P.kw == 3 && P.stride == 1 && P.cin == 32 && P.cout_pad == 32 &&
                     P.epi == EPI_F16 && P.pad_t == 1 && P.pad_l == 1) {
                     // whole filter in registers, input patch staged once (see conv3x3_rw_k)
-                    rc = launch_conv3x3_rw(s, P, nimg);
+                    if (o[29]) { P.p[0] = td->h; P.p[1] = td->w; }      // fused 3x3/2 max pool: dst is the pooled tensor
+                    rc = launch_conv3x3_rw(s, P, nimg, o[29] != 0);
                 } else if (P.cout_pad <= 32) {
                     // 32 output channels: 128 pixels per block (each wave 32 px x 32 ch) once there are enough pixels
                     rc = bk32 ? launch_conv<4, 1, 1, 2, 32, false>(s, P, net->slab, net->max_batch)

@@ -79,7 +79,7 @@ class Program:
         f = w.view(np.float32)
         w[0:5] = (kind, src, dst, res, dst2)
         names = dict(kh=5, kw=6, stride=7, pad_t=8, pad_l=9, cin=10, cout=11, cout_pad=12, kpad=13, act=14, epi=15,
-                     w_off=16, b_off=17, aff_off=18, has_aff=19, ho=26, wo=27, bk=28)
+                     w_off=16, b_off=17, aff_off=18, has_aff=19, ho=26, wo=27, bk=28, pool=29)
         for k, v in kw.items():
             if k == 'p':
                 w[20:20 + len(v)] = v
@@ -118,8 +118,9 @@ class Program:
         return dst
 
     def conv(self, src, w_hwio, bias, stride=1, pad=None, act=ACT_NONE, dst=None, res=-1, dst2=-1, aff2=None,
-             epi=EPI_F16, p=(), f=(), out_hw=None):
-        """w_hwio f32 [KH,KW,Cin,Cout] (already BN-folded), bias f32 [Cout]."""
+             epi=EPI_F16, p=(), f=(), out_hw=None, pool=False):
+        """w_hwio f32 [KH,KW,Cin,Cout] (already BN-folded), bias f32 [Cout].  pool=True appends a 3x3 stride-2
+        VALID max pool inside the same launch (conv3x3_rw_k; 3x3 32->32 layers only): dst is the pooled tensor."""
         s = self.T(src)
         kh, kw, cin, cout = w_hwio.shape
         assert cin == s['c'], (cin, s['c'])
@@ -143,14 +144,17 @@ class Program:
         wflat[:, :kh * kw * cin_pad] = wp.reshape(rows, -1)
         bp = np.zeros(rows, dtype=np.float32)
         bp[:cout] = bias
-        if dst is None:
+        if pool:
+            assert dst is None and res < 0 and dst2 < 0 and epi == EPI_F16
+            dst = self.tensor((ho - 3) // 2 + 1, (wo - 3) // 2 + 1, cout)
+        elif dst is None:
             dst = self.tensor(ho, wo, cout, dtype=DT_F32 if epi == EPI_F32 else DT_F16)
-        if epi in (EPI_F16, EPI_F32):
+        if epi in (EPI_F16, EPI_F32) and not pool:
             d = self.T(dst)
             assert (d['h'], d['w']) == (ho, wo) and d['c'] == cout, (d, ho, wo, cout)
         kw_ = dict(kh=kh, kw=kw, stride=stride, pad_t=pt, pad_l=pl, cin=cin_pad, cout=cout, cout_pad=cout_pad,
                    kpad=kpad, act=act, epi=epi, w_off=self.add_blob(wflat), b_off=self.add_blob(bp), p=list(p), f=list(f),
-                   ho=ho, wo=wo, bk=bk)
+                   ho=ho, wo=wo, bk=bk, pool=int(pool))
         if dst2 >= 0:
             a = np.zeros((2, cout_pad), dtype=np.float32)
             a[0, :cout], a[1, :cout] = aff2
@@ -161,7 +165,7 @@ class Program:
         rw = (kh, kw, stride, cin_pad, cout_pad, epi, pt, pl) == (3, 3, 1, 32, 32, EPI_F16, 1, 1)
         self.info[-1] = dict(kernel='conv3x3_rw_k' if rw else 'conv_glds_k' if bk == 64 else 'conv_mfma_k<%s,%d>' % (tile, bk),
                              flops=2 * ho * wo * kh * kw * cin * cout,
-                             bytes=2 * s['h'] * s['w'] * cin + (4 if epi != EPI_F16 else 2) * ho * wo * cout
+                             bytes=2 * s['h'] * s['w'] * cin + (4 if epi != EPI_F16 else 2) * (self.T(dst)['h'] * self.T(dst)['w'] if pool else ho * wo) * cout
                              + (2 * ho * wo * cout if res >= 0 else 0) + (2 * ho * wo * cout if dst2 >= 0 else 0),
                              wbytes=2 * kh * kw * cin * cout + 4 * cout)
         return dst
@@ -321,8 +325,7 @@ def compile_mars(wd, in_h=64, in_w=32):
     P = Program(in_h, in_w)
     w, b = fold_conv_bn(wd, 'conv1_1')
     x = c11 = P.stem(w, b, 1, ACT_ELU, swap_rb=True)                           # :175-177 BGR -> RGB, :101-105
-    w, b = fold_conv_bn(wd, 'conv1_2'); x = c12 = P.conv(x, w, b, act=ACT_ELU)  # :106-110
-    x = pool = P.maxpool(x, 3, 2, 0)                                           # :116 VALID
+    w, b = fold_conv_bn(wd, 'conv1_2'); x = pool = P.conv(x, w, b, act=ACT_ELU, pool=True)   # :106-110 + :116 VALID pool
     raw, pre = x, x                  # raw = block input (skip path), pre = what conv "1" reads
     for i, (name, c, inc, first) in enumerate(MARS_BLOCKS):
         stride = 2 if inc else 1
@@ -346,7 +349,7 @@ def compile_mars(wd, in_h=64, in_w=32):
     w, b = fold_conv_bn(wd, 'fc1', 'fc1/bn')                                    # :143-147 (w is [4096,128])
     f = P.fc(raw, w, b, ACT_ELU, aff2=bn_affine(wd, 'ball'))                    # :152 "ball" BN
     P.out_tensor = P.l2norm(f, 1e-8)                                           # :153-156
-    P.meta = dict(kind='mars', out_dim=128, tensors=dict(conv1_1=c11, conv1_2=c12, pool1=pool))
+    P.meta = dict(kind='mars', out_dim=128, tensors=dict(conv1_1=c11, pool1=pool))
     return P
 
 

@@ -57,7 +57,7 @@ def test_mars_intermediate_layers(mars):
     a2 = F.elu(nt._conv_bn(a1, wd, 'conv1_2', w16=True))
     a3 = F.max_pool2d(a2, 3, 2)
     ids = net.program.meta['tensors']
-    for tid, want in ((ids['conv1_1'], a1), (ids['conv1_2'], a2), (ids['pool1'], a3)):
+    for tid, want in ((ids['conv1_1'], a1), (ids['pool1'], a3)):          # conv1_2 is pooled inside its own launch
         got = net.read(tensor=tid).astype(np.float32)[..., :32]
         w = want.permute(0, 2, 3, 1).numpy()
         assert got.shape == w.shape, (got.shape, w.shape)

@@ -41,7 +41,7 @@ def test_model_compiler_shapes():
     from deepdish_amd import nets
     p = nets.compile_mars(nets.synthetic_mars_weights(1))
     words, blob = p.serialize()
-    assert words[0] == nets.MAGIC and len(p.ops) == 19 and p.tensors[p.out_tensor]['c'] == 128
+    assert words[0] == nets.MAGIC and len(p.ops) == 18 and p.tensors[p.out_tensor]['c'] == 128
     assert sum(i['flops'] for i in p.info) > 1.3e8                 # ~0.144 GFLOP / crop
     a, maps = nets.ssd_anchors(300)
     assert a.shape == (1917, 4) and maps == [19, 10, 5, 3, 2, 1]
