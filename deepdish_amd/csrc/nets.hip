@@ -34,8 +34,8 @@ constexpr int TENSOR_WORDS = 8;
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
         case ACT_RELU6: return fminf(fmaxf(v, 0.f), 6.f);
-        case ACT_ELU:                                   // expm1 to well below half an f16 ulp: cubic Taylor near 0, exp - 1 beyond
-            return v > 0.f ? v : (v > -0.03125f ? v * (1.f + 0.5f * v * (1.f + v * (1.f / 3.f))) : __expf(v) - 1.f);
+        case ACT_ELU:                                   // exp(v) - 1: absolute error ~1e-7, far below the f16 the result is stored in
+            return v > 0.f ? v : __expf(v) - 1.f;
         case ACT_SILU: return v / (1.f + __expf(-v));
         case ACT_RELU: return fmaxf(v, 0.f);
         case ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
@@ -167,11 +167,14 @@ __device__ __forceinline__ Epi8 epi8_load(const ConvP &P, int co) {
 
 // ACT >= 0: the activation is known at compile time (the per-element switch on P.act would otherwise be
 // compiled into a chain of branches around every value).
-template <int ACT = -1>
+template <int ACT = -1, bool BIAS = true>           // BIAS = false: the accumulators were initialised with the bias
 __device__ __forceinline__ void conv_epilogue_f16x8(const ConvP &P, const Epi8 &E, int m, int co, float v[8]) {
     const int act = ACT < 0 ? P.act : ACT;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { v[r] = apply_act(v[r] + E.b0[r], act); v[4 + r] = apply_act(v[4 + r] + E.b1[r], act); }
+    for (int r = 0; r < 4; ++r) {
+        v[r] = apply_act(BIAS ? v[r] + E.b0[r] : v[r], act);
+        v[4 + r] = apply_act(BIAS ? v[4 + r] + E.b1[r] : v[4 + r], act);
+    }
     if (P.res) {
         const h8 rv = *reinterpret_cast<const h8 *>(P.res + (size_t)m * P.cs_res + P.coff_res + co);
 #pragma unroll
@@ -597,11 +600,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rw_k(const ConvP P, const int 
                 base[b] = fq * plane + (ok[b] ? ty * PW + tx : 0) * 8;     // top-left tap of the pixel, in halves
                 mrow[b] = (n * P.ho + y0 + ty) * P.wo + x0 + tx;
             }
-            f4 acc[NCO][RW_MB];
+            f4 acc[NCO][RW_MB];                                  // start from the bias of the lane's output channels
 #pragma unroll
             for (int a = 0; a < NCO; ++a)
 #pragma unroll
-                for (int b = 0; b < RW_MB; ++b) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
+                for (int b = 0; b < RW_MB; ++b) acc[a][b] = (a & 1) ? E[a >> 1].b1 : E[a >> 1].b0;
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
@@ -629,12 +632,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rw_k(const ConvP P, const int 
                         h8 hv;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            hv[r] = (_Float16)apply_act(o[r] + E[g].b0[r], act);
-                            hv[4 + r] = (_Float16)apply_act(o[4 + r] + E[g].b1[r], act);
+                            hv[r] = (_Float16)apply_act(o[r], act);
+                            hv[4 + r] = (_Float16)apply_act(o[4 + r], act);
                         }
                         *reinterpret_cast<h8 *>(stage + ((f0 + b) * 16 + fr) * (NCO * 16) + g * 32 + fq * 8) = hv;
                     } else {
-                        conv_epilogue_f16x8<ACT>(P, E[g], mrow[b], g * 32 + fq * 8, o);
+                        conv_epilogue_f16x8<ACT, false>(P, E[g], mrow[b], g * 32 + fq * 8, o);
                     }
                 }
             }
@@ -658,8 +661,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rw_k(const ConvP P, const int 
                     for (int dx = 0; dx < 3; ++dx) {
                         if (dy == 0 && dx == 0) continue;
                         const h8 x = *reinterpret_cast<const h8 *>(stage + ((2 * oyl + dy) * tw + 2 * ox + dx) * (NCO * 16) + c * 8);
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) best[i] = x[i] > best[i] ? x[i] : best[i];
+                        best = __builtin_elementwise_max(best, x);      // v_pk_max_f16
                     }
                 *reinterpret_cast<h8 *>(static_cast<_Float16 *>(P.out) + ((size_t)(n * ph + oy) * pw + ox) * P.cs_out + P.coff_out + c * 8) = best;
             }
@@ -740,12 +742,11 @@ __global__ __launch_bounds__(256) void stem_conv3_k(const ConvP P) {
         }
 #pragma unroll
         for (int b = 0; b < RW_MB; ++b) {
-            const f4 z = f4{0.f, 0.f, 0.f, 0.f};
-            const f4 a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0], xf[b], z, 0, 0, 0);
-            const f4 a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[1], xf[b], z, 0, 0, 0);
+            const f4 a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0], xf[b], E.b0, 0, 0, 0);     // accumulate onto the bias
+            const f4 a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[1], xf[b], E.b1, 0, 0, 0);
             if (!ok[b]) continue;
             float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-            conv_epilogue_f16x8<ACT>(P, E, mrow[b], fq * 8, v);
+            conv_epilogue_f16x8<ACT, false>(P, E, mrow[b], fq * 8, v);
         }
     }
 }
@@ -862,11 +863,14 @@ __global__ __launch_bounds__(256) void dwpw_k(const ConvP P) {
     __syncthreads();
 
     // ---- pointwise part: [BM pixels] x [BN channels] x CIN, everything already in LDS
-    f4 acc[NI][MI];
+    Epi8 E[2];
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2) E[g2] = epi8_load(P, n0 + wn * 64 + g2 * 32 + fq * 8);
+    f4 acc[NI][MI];                                             // start from the bias of the lane's output channels
 #pragma unroll
     for (int a = 0; a < NI; ++a)
 #pragma unroll
-        for (int b = 0; b < MI; ++b) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < MI; ++b) acc[a][b] = (a & 1) ? E[a >> 1].b1 : E[a >> 1].b0;
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
         const int c = kk * 4 + fq;
@@ -886,9 +890,6 @@ __global__ __launch_bounds__(256) void dwpw_k(const ConvP P) {
 #pragma unroll
             for (int b = 0; b < MI; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[a], xf[b], acc[a][b], 0, 0, 0);
     }
-    Epi8 E[2];
-#pragma unroll
-    for (int g2 = 0; g2 < 2; ++g2) E[g2] = epi8_load(P, n0 + wn * 64 + g2 * 32 + fq * 8);
 #pragma unroll
     for (int b = 0; b < MI; ++b) {
         const int m = mrow[(wm * MI + b) * 16 + fr];
@@ -898,7 +899,7 @@ __global__ __launch_bounds__(256) void dwpw_k(const ConvP P) {
             float o[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) { o[r] = acc[2 * g2][b][r]; o[4 + r] = acc[2 * g2 + 1][b][r]; }
-            conv_epilogue_f16x8<ACT>(P, E[g2], m, n0 + wn * 64 + g2 * 32 + fq * 8, o);
+            conv_epilogue_f16x8<ACT, false>(P, E[g2], m, n0 + wn * 64 + g2 * 32 + fq * 8, o);
         }
     }
 }
