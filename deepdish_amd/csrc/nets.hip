@@ -274,6 +274,42 @@ __device__ __forceinline__ void conv_finish(const ConvP &P, f4 (&acc)[NI][MI], _
     }
 }
 
+// Epilogue without the LDS transposition: used when the weight rows of the tile were staged in the
+// fragment order of rw_weight_row (conv_glds_k does that for plain f16 outputs), so the lane that owns
+// rows fq*4.. of fragments 2g and 2g+1 holds 8 consecutive output channels of its pixel.
+template <int WM, int WN, int MI, int NI, int ACT>
+__device__ __forceinline__ void conv_finish_direct_act(const ConvP &P, f4 (&acc)[NI][MI], int m0, int n0) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int g = 0; g < NI / 2; ++g) {
+        const int co = n0 + (wn * NI + 2 * g) * 16 + fq * 8;
+        if (co >= P.cout_pad) continue;
+        const Epi8 E = epi8_load(P, co);
+#pragma unroll
+        for (int b = 0; b < MI; ++b) {
+            const int m = m0 + (wm * MI + b) * 16 + fr;
+            if (m >= P.m) continue;
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] = acc[2 * g][b][r]; v[4 + r] = acc[2 * g + 1][b][r]; }
+            conv_epilogue_f16x8<ACT>(P, E, m, co, v);
+        }
+    }
+}
+
+template <int WM, int WN, int MI, int NI>
+__device__ __forceinline__ void conv_finish_direct(const ConvP &P, f4 (&acc)[NI][MI], int m0, int n0) {
+    switch (P.act) {
+        case ACT_NONE: conv_finish_direct_act<WM, WN, MI, NI, ACT_NONE>(P, acc, m0, n0); break;
+        case ACT_RELU6: conv_finish_direct_act<WM, WN, MI, NI, ACT_RELU6>(P, acc, m0, n0); break;
+        case ACT_ELU: conv_finish_direct_act<WM, WN, MI, NI, ACT_ELU>(P, acc, m0, n0); break;
+        case ACT_SILU: conv_finish_direct_act<WM, WN, MI, NI, ACT_SILU>(P, acc, m0, n0); break;
+        default: conv_finish_direct_act<WM, WN, MI, NI, -1>(P, acc, m0, n0);
+    }
+}
+
 // Block tile: (WM*MI*16) pixels x (WN*NI*16) output channels, K step BK (32 for shallow K, else 64:
 // two MFMA k-slices per barrier); blockIdx.z = K split.  Staged rows carry 8 halves of padding.
 template <int WM, int WN, int MI, int NI, int BK>
@@ -438,9 +474,14 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_glds_k(const ConvP P) {
         x_iy0[i] = oy * P.stride - P.pad_t;
         x_ix0[i] = ox * P.stride - P.pad_l;
     }
+    const bool direct = (NI % 2 == 0) && P.epi == EPI_F16 && P.splitk == 1;     // plain f16 output: no LDS transposition pass
     const _Float16 *wbase[WG];
 #pragma unroll
-    for (int i = 0; i < WG; ++i) wbase[i] = P.w + (size_t)(n0 + (wave * WG + i) * 8 + rr) * P.kpad + gchunk;
+    for (int i = 0; i < WG; ++i) {
+        const int L = (wave * WG + i) * 8 + rr;                 // LDS row of the tile; direct: fragment order (see rw_weight_row)
+        const int row = direct ? ((L & ~31) | (((L & 15) >> 2) << 3) | (((L >> 4) & 1) << 2) | (L & 3)) : L;
+        wbase[i] = P.w + (size_t)(n0 + row) * P.kpad + gchunk;
+    }
 
     // This lane always moves the same logical 16-byte chunk (8 channels) of a K step; (l_kh, l_kw, l_c)
     // walk the (tap, channel) position of that chunk along K, so any Cin that is a multiple of 8 works
@@ -502,7 +543,8 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_glds_k(const ConvP P) {
             __syncthreads();
         }
     }
-    conv_finish<WM, WN, MI, NI>(P, acc, lds, m0, n0, hw);
+    if (direct) conv_finish_direct<WM, WN, MI, NI>(P, acc, m0, n0);
+    else conv_finish<WM, WN, MI, NI>(P, acc, lds, m0, n0, hw);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1139,7 +1181,7 @@ int launch_conv(hipStream_t s, ConvP &P, DevBuf &slab, int max_batch) {
     int splitk = 1;
     const int blocks_per_image = dd_ceil_div(P.ho * P.wo, BM) * gy;
     const long long blocks_full = (long long)dd_ceil_div(max_batch * P.ho * P.wo, BM) * gy;
-    if (blocks_per_image <= 8 && ksteps >= 8 && blocks_full < 512) {
+    if (blocks_per_image <= 8 && ksteps >= 8 && blocks_full < 256) {        // fewer blocks than CUs at full batch
         splitk = std::min(16, ksteps / 4);
         const int per = dd_ceil_div(ksteps, splitk);
         splitk = dd_ceil_div(ksteps, per);                    // no empty split
@@ -1448,7 +1490,13 @@ int dd_net_forward(dd_net *net, const uint8_t *input, int nimg, void *stream) {
                        : (glds && P.m >= 16384) ? launch_conv<4, 1, 2, 2, 64, true>(s, P, net->slab, net->max_batch)
                        : glds ? launch_conv<4, 1, 1, 2, 64, true>(s, P, net->slab, net->max_batch)
                               : launch_conv<4, 1, 1, 2, 64, false>(s, P, net->slab, net->max_batch);
-                } else if (glds && net->tile_mode == 0 && P.m >= 4096 && P.cout_pad >= 128) {
+                } else if (glds && net->tile_mode != 1 && P.m >= 16384 && P.cout_pad >= 128) {
+                    // plenty of pixels: 128 x 128 with 8 waves -- a third less L2->LDS traffic per FLOP than 64 x 128
+                    // (24.3 us vs 26.6 us for 19x19x512 -> 512 at 64 frames; at 10x10 it halves the block count and loses)
+                    rc = launch_conv<4, 2, 2, 4, 64, true>(s, P, net->slab, net->max_batch);
+                } else if (glds && net->tile_mode != 1 && P.m >= 16384 && P.cout_pad == 64) {
+                    rc = launch_conv<4, 2, 2, 2, 64, true>(s, P, net->slab, net->max_batch);      // 128 x 64, 8 waves
+                } else if (glds && net->tile_mode != 1 && P.m >= 4096 && P.cout_pad >= 128) {
                     // 64 pixels x 128 channels: each staged pixel row feeds twice the MFMAs; measured 31 us vs 38 us
                     // for 19x19x512 -> 512 at 64 frames (128 x 64 gave nothing, 128 x 128 was 2.5x slower: 2 blocks/CU)
                     rc = launch_conv<2, 2, 2, 4, 64, true>(s, P, net->slab, net->max_batch);
