@@ -111,9 +111,28 @@ def cpu_baseline(n_frames):
     for f in range(2, n_frames + 2):
         one(f)
     dt = time.perf_counter() - t0
-    return dict(value=n_frames / dt, unit='frames/s', cores=threads, kind='port',
+    table = [(int(t.track_id), int(t.state), int(t.time_since_update), int(t.hits)) for t in trk.tracks]
+    base = dict(value=n_frames / dt, unit='frames/s', cores=threads, kind='port',
                 sample='%d frames of the same 640x480 / ~20-detection workload, oracle path (Pillow Lanczos + '
                        'torch-CPU f32 SSD-MobileNet-v1 and MARS + numpy deep_sort), %d torch threads' % (n_frames, threads))
+    return base, sc, [int(v) for v in np.asarray(counter.vector()).reshape(-1)], table
+
+
+def gpu_sample_check(sc, n_frames, oracle_counts, oracle_table, device):
+    """The HIP path over the very frames the CPU baseline just processed (one stream): crossing counts and the
+    final track table (id, state, time_since_update, hits) must be identical."""
+    import torch
+    from deepdish_amd.multipipe import MultiStreamPipeline
+    mp1 = MultiStreamPipeline(1)
+    for f in range(n_frames + 2):
+        boxes, scores, _, _ = sc.detections(f)
+        inj = mp1.pack_injected([([tuple(int(v) for v in b) for b in boxes], ['person'] * len(boxes), [float(x) for x in scores])])
+        mp1.step(torch.from_numpy(sc.frame(f)[None]).to(device), inj)
+    ints, _ = mp1.tracker(0).table()
+    table = [tuple(int(v) for v in r[:4]) for r in ints]
+    counts = [int(v) for v in np.asarray(mp1.counts()[0]).reshape(-1)]
+    return dict(frames=n_frames + 2, counts_hip=counts, counts_oracle=oracle_counts,
+                identical=bool(counts == oracle_counts and table == oracle_table))
 
 
 def main():
@@ -206,7 +225,11 @@ def main():
             out['roofline'] = None
             out['roofline_error'] = repr(e)
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(args.cpu_frames)
+            out['cpu_baseline'], sc0, ocounts, otable = cpu_baseline(args.cpu_frames)
+            try:
+                out['parity_sample'] = gpu_sample_check(sc0, args.cpu_frames, ocounts, otable, f'cuda:{local_rank}')
+            except Exception as e:
+                out['parity_sample'] = dict(error=repr(e))
         os.write(real_stdout, (json.dumps(out) + '\n').encode())
     if dist_on:
         dist.barrier()
