@@ -2,14 +2,14 @@
 """Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; collected separately as MI355X_MICROARCH.md
 prescribes) into per-kernel HBM bytes per launch.  FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950
 FETCH_SIZE reports half of the bytes of wide coalesced reads, so it is doubled."""
-import csv, glob, collections, json, sys
+import csv, glob, collections, json, os, sys
 
 fetch_dir, write_dir, out = sys.argv[1:4]
 
 
 def load(d):
     acc = collections.defaultdict(lambda: [0, 0.0])
-    for r in csv.DictReader(open(glob.glob(d + '/*/*counter_collection.csv')[0])):
+    for r in csv.DictReader(open(sorted(glob.glob(d + '/*/*counter_collection.csv'), key=os.path.getmtime)[-1])):
         a = acc[r['Kernel_Name']]
         a[0] += 1
         a[1] += float(r['Counter_Value'])
