@@ -91,19 +91,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvP &P, int m, int co, flo
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], P.act);
-    if (P.epi == EPI_SSD_HEAD) {                        // fused box + class predictor of one feature map:
-        const int n = m / hw, p = m - n * hw;           // channels [0, 4A) box encodings, [4A, 4A + A*C) class logits
-        const int C = P.p[0], split = P.p[4], A = P.p[5];
+    if (P.epi == EPI_SSD_HEAD) {                        // fused box + class predictor of one feature map; the host
+        const int n = m / hw, p = m - n * hw;           // ordered the output channels [anchor][4 box + C class], which is
+        const int A = P.p[5];                           // the memory order of the pixel's A rows of the head matrix
+        float *dst = static_cast<float *>(P.out) + ((size_t)n * P.p[1] + P.p[2] + (size_t)p * A) * P.p[3];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int ch = co + r;
-            if (ch >= P.cout) continue;
-            int an, col;
-            if (ch < split) { an = ch >> 2; col = ch & 3; }
-            else { const int c2 = ch - split; an = c2 / C; col = 4 + (c2 - an * C); }
-            const size_t row = (size_t)n * P.p[1] + P.p[2] + (size_t)p * A + an;
-            static_cast<float *>(P.out)[row * P.p[3] + col] = v[r];
-        }
+        for (int r = 0; r < 4; ++r)
+            if (co + r < P.cout) dst[co + r] = v[r];
         return;
     }
     if (P.res) {
@@ -252,6 +246,30 @@ __device__ __forceinline__ void conv_finish(const ConvP &P, f4 (&acc)[NI][MI], _
             case ACT_ELU: conv_finish_rows<ACT_ELU, BM, BN, T>(P, ot, m0, n0); break;
             case ACT_SILU: conv_finish_rows<ACT_SILU, BM, BN, T>(P, ot, m0, n0); break;
             default: conv_finish_rows<-1, BM, BN, T>(P, ot, m0, n0);
+        }
+        return;
+    }
+    if (P.epi == EPI_SSD_HEAD && P.splitk == 1) {
+        // ---- head matrix rows: a pixel's A x (4 + C) floats are contiguous, so stage the tile in LDS and let
+        // each wave write one pixel's run with consecutive lanes on consecutive floats (256-byte stores)
+        constexpr int OROW = BN + 4;
+        float *ot = reinterpret_cast<float *>(lds);
+#pragma unroll
+        for (int b = 0; b < MI; ++b)
+#pragma unroll
+            for (int a = 0; a < NI; ++a)
+                *reinterpret_cast<f4 *>(ot + ((wm * MI + b) * 16 + fr) * OROW + (wn * NI + a) * 16 + fq * 4) = acc[a][b];
+        __syncthreads();
+        const int A = P.p[5];
+        for (int pl = wave; pl < BM; pl += WM * WN) {
+            const int m = m0 + pl;
+            if (m >= P.m) break;
+            const int n = m / hw, p = m - n * hw;                 // wave-uniform
+            float *dst = static_cast<float *>(P.out) + ((size_t)n * P.p[1] + P.p[2] + (size_t)p * A) * P.p[3];
+            for (int c = lane; c < BN; c += 64) {
+                const int ch = n0 + c;
+                if (ch < P.cout) dst[ch] = ot[pl * OROW + c] + P.bias[ch];
+            }
         }
         return;
     }

@@ -449,6 +449,10 @@ def compile_ssd_mobilenet(wd, in_size=300):
         assert fm == maps[k]
         w = np.concatenate([wd[f'box{k}/weights'], wd[f'cls{k}/weights']], axis=3)      # one launch per feature map
         b = np.concatenate([wd[f'box{k}/biases'], wd[f'cls{k}/biases']])
+        # output channels in the memory order of the head matrix: [anchor][4 box encodings + C class logits]
+        order = np.concatenate([np.concatenate([np.arange(an * 4, an * 4 + 4),
+                                                4 * a + np.arange(an * SSD_CLASSES, (an + 1) * SSD_CLASSES)]) for an in range(a)])
+        w, b = w[..., order], b[order]
         P.conv(ft, w, b, dst=out, epi=EPI_SSD_HEAD, p=[SSD_CLASSES, n_anchors, base, ld, 4 * a, a])
         base += fm * fm * a
     assert base == n_anchors
