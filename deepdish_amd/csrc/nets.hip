@@ -1196,9 +1196,12 @@ int launch_conv(hipStream_t s, ConvP &P, DevBuf &slab, int max_batch) {
     // call: every output element is then summed in the same order whatever else shares the launch
     // (streams stay independent).  An engine sized for many images has enough blocks without splitting,
     // and the f32 partial-sum slabs (splitk x the layer output, written and re-read) would dominate.
+    // Counted in 64 x 64 tiles whatever tile this launch uses: the tile is picked from the batch of the call,
+    // the split must not be.
     int splitk = 1;
-    const int blocks_per_image = dd_ceil_div(P.ho * P.wo, BM) * gy;
-    const long long blocks_full = (long long)dd_ceil_div(max_batch * P.ho * P.wo, BM) * gy;
+    const int gy64 = dd_ceil_div(P.cout_pad, 64);
+    const int blocks_per_image = dd_ceil_div(P.ho * P.wo, 64) * gy64;
+    const long long blocks_full = (long long)dd_ceil_div(max_batch * P.ho * P.wo, 64) * gy64;
     if (blocks_per_image <= 8 && ksteps >= 8 && blocks_full < 256) {        // fewer blocks than CUs at full batch
         splitk = std::min(16, ksteps / 4);
         const int per = dd_ceil_div(ksteps, splitk);

@@ -39,7 +39,8 @@ def test_crop_resize_vs_oracle(ctx):
     assert image_np.crop_box(np.array([10, 10, 64, 128]), (64, 32), (480, 640)) == (10, 10, 74, 138)
 
 
-@pytest.mark.parametrize('shape', [(480, 640, 300, 300), (480, 640, 640, 640), (720, 1280, 300, 300), (97, 131, 300, 300)])
+@pytest.mark.parametrize('shape', [(480, 640, 300, 300), (480, 640, 640, 640), (720, 1280, 300, 300), (97, 131, 300, 300),
+                                   (200, 640, 150, 300)])     # last: rows not a multiple of 16 -> the LDS-staged scalar kernels
 def test_lanczos_vs_pillow(ctx, shape):
     from PIL import Image
     from deepdish_amd._lib import lib, check

@@ -1,0 +1,104 @@
+"""GPU: size-independent properties at the bench's full sizes, and equivalence of the specialised
+kernels with the general ones they replace (where the oracle would take minutes or does not apply)."""
+import os
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_ssd_batch_of_64_is_frame_independent():
+    """A frame gives the same bits alone and as frame 0 / 63 of a 64-frame launch (bench batch per worker group)."""
+    from deepdish_amd import nets
+    from deepdish_amd.engine import Net
+    net = Net(nets.compile_ssd_mobilenet(nets.synthetic_ssd_weights(1234)), max_batch=64)
+    rng = np.random.default_rng(0)
+    x = rng.integers(0, 256, (64, 300, 300, 3), dtype=np.uint8)
+    net.forward(x)
+    full = net.read()
+    assert np.isfinite(full).all()
+    for i in (0, 31, 63):
+        net.forward(x[i:i + 1])
+        np.testing.assert_array_equal(net.read()[0], full[i])
+
+
+def test_mars_batch_of_1280_is_crop_independent():
+    from deepdish_amd import nets
+    from deepdish_amd.engine import Net
+    net = Net(nets.compile_mars(nets.synthetic_mars_weights(1234)), max_batch=1280)
+    rng = np.random.default_rng(1)
+    x = rng.integers(0, 256, (1280, 64, 32, 3), dtype=np.uint8)
+    net.forward(x)
+    full = net.read()[:, 0, 0, :]
+    np.testing.assert_allclose(np.linalg.norm(full, axis=1), 1.0, atol=1e-5)
+    for i in (0, 640, 1279):
+        net.forward(x[i:i + 1])
+        np.testing.assert_array_equal(net.read()[0, 0, 0, :], full[i])
+
+
+def test_fused_mobilenet_blocks_match_the_two_kernel_path():
+    """dwpw_k (depthwise + pointwise in one launch) against dwconv3_k followed by the GEMM kernel: same f16
+    rounding point between the two halves, so the head outputs agree to summation-order noise."""
+    from deepdish_amd import nets
+    from deepdish_amd.engine import Net
+    wd = nets.synthetic_ssd_weights(1234)
+    fused = Net(nets.compile_ssd_mobilenet(wd), max_batch=2)
+    saved = nets.Program.DWPW_SHAPES
+    nets.Program.DWPW_SHAPES = set()
+    try:
+        prog = nets.compile_ssd_mobilenet(wd)
+    finally:
+        nets.Program.DWPW_SHAPES = saved
+    assert sum(i['kernel'] == 'dwpw_k' for i in prog.info) == 0 < sum(i['kernel'] == 'dwpw_k' for i in fused.program.info)
+    plain = Net(prog, max_batch=2)
+    x = np.random.default_rng(2).integers(0, 256, (2, 300, 300, 3), dtype=np.uint8)
+    fused.forward(x); plain.forward(x)
+    a, b = fused.read(), plain.read()
+    assert np.abs(a - b).max() <= 2e-3 * np.abs(b).max(), np.abs(a - b).max() / np.abs(b).max()
+
+
+def test_stream_order_does_not_matter():
+    """Streams are independent units: permuting which slot a stream occupies permutes the results."""
+    from deepdish_amd.multipipe import MultiStreamPipeline
+    from deepdish_amd.synth import Scene
+    S, F = 6, 25
+    scenes = [Scene(seed=70 + z, n_obj=6 + z, n_frames=F) for z in range(S)]
+    perm = [3, 0, 5, 1, 4, 2]
+    res = []
+    for order in (list(range(S)), perm):
+        mp = MultiStreamPipeline(S, run_detector=False)
+        for f in range(F):
+            frames = np.stack([scenes[z].frame(f) for z in order])
+            dets = []
+            for z in order:
+                boxes, scores, _, _ = scenes[z].detections(f)
+                dets.append(([tuple(int(v) for v in b) for b in boxes], ['person'] * len(boxes), [float(s) for s in scores]))
+            mp.step(torch.from_numpy(frames).cuda(), mp.pack_injected(dets))
+        res.append(([mp.tracker(k).table() for k in range(S)], mp.counts()))
+    (tab0, cnt0), (tab1, cnt1) = res
+    for k, z in enumerate(perm):
+        np.testing.assert_array_equal(tab1[k][0], tab0[z][0])
+        np.testing.assert_array_equal(tab1[k][1], tab0[z][1])
+        np.testing.assert_array_equal(cnt1[k], cnt0[z])
+    assert sum(len(t[0]) for t in tab0) > 0
+
+
+def test_kalman_256_tracks_stay_symmetric_and_gate_is_nonnegative():
+    from deepdish_amd.deep_sort.kalman_filter import KalmanFilter
+    kf = KalmanFilter()
+    rng = np.random.default_rng(3)
+    meas = np.c_[rng.uniform(0, 4000, 256), rng.uniform(0, 3000, 256), rng.uniform(0.3, 0.6, 256), rng.uniform(60, 120, 256)]
+    states = [kf.initiate(m) for m in meas]
+    for step in range(20):
+        nxt = []
+        for (mean, cov), m in zip(states, meas):
+            mean, cov = kf.predict(mean, cov)
+            z = m + np.array([step * 1.5, step * 0.5, 0.0, 0.1 * step])
+            d = kf.gating_distance(mean, cov, z[None])
+            assert d.shape == (1,) and d[0] >= 0.0
+            mean, cov = kf.update(mean, cov, z)
+            assert np.abs(cov - cov.T).max() <= 1e-9 * np.abs(cov).max()
+            assert np.all(np.linalg.eigvalsh((cov + cov.T) / 2) > -1e-9)
+            nxt.append((mean, cov))
+        states = nxt
