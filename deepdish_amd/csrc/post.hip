@@ -18,34 +18,36 @@ int nms_f32_batched(hipStream_t s, const float *boxes, const float *keys, int k,
 
 namespace {
 
-// One wave per anchor: lanes sweep the class logits (coalesced), wave-max picks the best class
-// (lowest class index on ties, like a sequential `>` scan); the sigmoid is applied once.
+// Sixteen lanes per anchor (four anchors per wave): the lanes sweep the class logits of their anchor in
+// 64-byte pieces, a 16-lane butterfly picks the best class (lowest class index on ties, like a
+// sequential `>` scan); the sigmoid is applied once.  (One wave per anchor left most lanes idle and made
+// the kernel a chain of 120 K tiny waves for a 64-frame batch.)
 __global__ __launch_bounds__(256) void ssd_decode_k(const float *__restrict__ raw, const float *__restrict__ anchors,
                                                     int n_anchors, int n_classes, float score_thr,
                                                     float *__restrict__ boxes, float *__restrict__ best_score,
                                                     int *__restrict__ best_cls, float *__restrict__ keys) {
-    const int a = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
-    if (a >= n_anchors) return;
+    const int a = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int sub = threadIdx.x & 15;
     {   // blockIdx.y = image of a batch
         const size_t z = blockIdx.y;
         raw += z * n_anchors * (4 + n_classes);
         boxes += z * n_anchors * 4; best_score += z * n_anchors; best_cls += z * n_anchors; keys += z * n_anchors;
     }
-    const float *r = raw + (size_t)a * (4 + n_classes);
+    const bool live = a < n_anchors;                          // whole 16-lane groups are live or not; all lanes shuffle
+    const float *r = raw + (size_t)(live ? a : 0) * (4 + n_classes);
     float best = -__builtin_inff();
     int bi = 0x7fffffff;
-    for (int c = 1 + lane; c < n_classes; c += 64) {          // class 0 = background
+    for (int c = 1 + sub; c < n_classes; c += 16) {           // class 0 = background
         const float v = r[4 + c];
         if (v > best) { best = v; bi = c - 1; }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
+    for (int o = 8; o > 0; o >>= 1) {
         const float ob = __shfl_xor(best, o, 64);
         const int oi = __shfl_xor(bi, o, 64);
         if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
     }
-    if (lane == 0) {
+    if (live && sub == 0) {
         const float ay = anchors[a * 4 + 0], ax = anchors[a * 4 + 1], ah = anchors[a * 4 + 2], aw = anchors[a * 4 + 3];
         const float yc = r[0] / 10.f * ah + ay;
         const float xc = r[1] / 10.f * aw + ax;
@@ -177,7 +179,7 @@ int ssd_postprocess(hipStream_t s, const float *raw, const float *anchors, int n
     int *d_nkeep = d_keep + per;
     const size_t head = ((per * 32 + (size_t)batch * 4) + 255) / 256 * 256;
     char *d_nms = p + head;
-    hipLaunchKernelGGL(ssd_decode_k, dim3(dd_ceil_div(n_anchors, 4), batch), dim3(256), 0, s, raw, anchors, n_anchors, n_classes,
+    hipLaunchKernelGGL(ssd_decode_k, dim3(dd_ceil_div(n_anchors, 16), batch), dim3(256), 0, s, raw, anchors, n_anchors, n_classes,
                        score_thr, d_boxes, d_score, d_cls, d_keys);
     DD_LAUNCH_CHECK();
     int rc;
