@@ -47,6 +47,13 @@ SIGNATURES = {
     'dd_fake_encode': [P, P, c_int, c_int, P, P],
     'dd_resize_lanczos': [P, P, c_int, c_int, c_int, c_int, P, c_int, c_int, P],
     'dd_resize_bilinear': [P, P, c_int, c_int, c_int, P, c_int, c_int, P],
+    'dd_ingest_create': [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    'dd_ingest_destroy': [P],
+    'dd_ingest_host_slot': [P, c_int, P, P],
+    'dd_ingest_submit': [P, c_int],
+    'dd_ingest_wait_uploaded': [P, c_int],
+    'dd_ingest_acquire': [P, c_int, P, P],
+    'dd_ingest_release': [P, c_int, P],
     'dd_net_create': [P, P, c_int, P, c_int64, c_int, POINTER(P)],
     'dd_net_destroy': [P],
     'dd_net_forward': [P, P, c_int, P],

@@ -32,7 +32,7 @@ __device__ __forceinline__ void lin_coeff(int d, int dst, int src, int &s, int &
     a1 = (int)rintf(f * 2048.f);
 }
 
-struct CropBox { int sx, sy, cw, ch, frame, r0, r1, r2; };   // cw <= 0 marks a box the reference rejects
+struct CropBox { int sx, sy, cw, ch, frame, flip, r1, r2; };   // cw <= 0 marks a box the reference rejects; flip: rows read bottom-up (cv2.flip(frame, 0))
 
 // grid (ceil(oh*ow/256), n); one thread per output pixel (3 channels).
 __global__ __launch_bounds__(256) void crop_resize_k(const uint8_t *__restrict__ frames, int H, int W,
@@ -44,10 +44,13 @@ __global__ __launch_bounds__(256) void crop_resize_k(const uint8_t *__restrict__
     uint8_t *o = out + ((size_t)blockIdx.y * oh * ow + p) * 3;
     if (b.cw <= 0) { o[0] = o[1] = o[2] = 0; return; }
     const int dy = p / ow, dx = p - dy * ow;
-    const uint8_t *base = frames + ((size_t)b.frame * H * W + (size_t)b.sy * W + b.sx) * 3;
-    const size_t rs = (size_t)W * 3;
+    // flip: row y of the (virtually) flipped frame is row H-1-y of the stored one: start at the flipped first
+    // row and walk with a negative row stride
+    const size_t row0 = b.flip ? (size_t)(H - 1 - b.sy) : (size_t)b.sy;
+    const uint8_t *base = frames + ((size_t)b.frame * H * W + row0 * W + b.sx) * 3;
+    const ptrdiff_t rs = b.flip ? -(ptrdiff_t)W * 3 : (ptrdiff_t)W * 3;
     if (b.cw == 2 * ow && b.ch == 2 * oh) {       // exact 2x decimation: INTER_AREA shortcut
-        const uint8_t *r0 = base + (size_t)(2 * dy) * rs + (size_t)(2 * dx) * 3, *r1 = r0 + rs;
+        const uint8_t *r0 = base + (ptrdiff_t)(2 * dy) * rs + (size_t)(2 * dx) * 3, *r1 = r0 + rs;
 #pragma unroll
         for (int c = 0; c < 3; ++c) o[c] = (uint8_t)((r0[c] + r0[c + 3] + r1[c] + r1[c + 3] + 2) >> 2);
         return;
@@ -56,7 +59,7 @@ __global__ __launch_bounds__(256) void crop_resize_k(const uint8_t *__restrict__
     lin_coeff(dx, ow, b.cw, sx, xa0, xa1);
     lin_coeff(dy, oh, b.ch, sy, ya0, ya1);
     const int sx1 = min(sx + 1, b.cw - 1), sy1 = min(sy + 1, b.ch - 1);
-    const uint8_t *r0 = base + (size_t)sy * rs, *r1 = base + (size_t)sy1 * rs;
+    const uint8_t *r0 = base + (ptrdiff_t)sy * rs, *r1 = base + (ptrdiff_t)sy1 * rs;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const int h0 = r0[sx * 3 + c] * xa0 + r0[sx1 * 3 + c] * xa1;      // scale 2^11
@@ -564,7 +567,7 @@ int dd_crop_resize(dd_ctx *ctx, const uint8_t *frame, int H, int W, const int64_
     for (int i = 0; i < n; ++i) {
         const int ok = ddk::crop_box_host(boxes_host + (size_t)i * 4, ph, pw, H, W, hb + 8 * i, hb + 8 * i + 1,
                                           hb + 8 * i + 2, hb + 8 * i + 3);
-        hb[8 * i + 4] = 0;
+        hb[8 * i + 4] = 0; hb[8 * i + 5] = 0; hb[8 * i + 6] = 0; hb[8 * i + 7] = 0;
         if (valid_host) valid_host[i] = ok;
     }
     DD_HIP(hipMemcpyAsync(ctx->scratch[3].p, hb, (size_t)n * 32, hipMemcpyHostToDevice, s));
@@ -600,7 +603,7 @@ int dd_resize_bilinear(dd_ctx *ctx, const uint8_t *src, int H, int W, int c, uin
     if ((rc = ctx->pin[1].reserve(32)) != DD_OK) return rc;
     if ((rc = ctx->scratch[3].reserve(32)) != DD_OK) return rc;
     int *hb = ctx->pin[1].as<int>();
-    hb[0] = 0; hb[1] = 0; hb[2] = W; hb[3] = H; hb[4] = 0;
+    hb[0] = 0; hb[1] = 0; hb[2] = W; hb[3] = H; hb[4] = 0; hb[5] = 0; hb[6] = 0; hb[7] = 0;
     DD_HIP(hipMemcpyAsync(ctx->scratch[3].p, hb, 32, hipMemcpyHostToDevice, s));
     DD_HIP(hipStreamSynchronize(s));
     return ddk::crop_resize(s, src, H, W, ctx->scratch[3].p, 1, h, w, dst);

@@ -156,6 +156,23 @@ int dd_resize_lanczos(dd_ctx *ctx, const uint8_t *src, int H, int W, int src_c, 
 int dd_resize_bilinear(dd_ctx *ctx, const uint8_t *src, int H, int W, int c,
                        uint8_t *dst, int h, int w, void *stream);
 
+/* ---------------------------------------------------------------- frame ingest
+ * The CPU side of Pipeline.capture (deepdish.py:837-878): cv2.flip(frame, 0) (:864) + cv2.resize(frame,
+ * input_size) (:867) on frames that a decoder put in host memory.  A ring of `slots` pinned host buffers,
+ * each [n_streams][src_h][src_w][3] u8 BGR, with device twins; dd_ingest_submit queues host->device copy
+ * + flip + INTER_LINEAR stretch on a private copy stream; dd_ingest_acquire makes the consumer's stream
+ * wait for that slot (no host wait) and returns the device frames [n_streams][dst_h][dst_w][3];
+ * dd_ingest_release marks the consumer's last use so the slot can be refilled. */
+typedef struct dd_ingest dd_ingest;
+int dd_ingest_create(dd_ctx *ctx, int slots, int n_streams, int src_h, int src_w, int dst_h, int dst_w, int flip,
+                     dd_ingest **out);
+int dd_ingest_destroy(dd_ingest *g);
+int dd_ingest_host_slot(dd_ingest *g, int slot, uint8_t **host_ptr, int64_t *n_bytes);
+int dd_ingest_wait_uploaded(dd_ingest *g, int slot);    /* host may overwrite the pinned slot after this returns */
+int dd_ingest_submit(dd_ingest *g, int slot);
+int dd_ingest_acquire(dd_ingest *g, int slot, void *consumer_stream, const uint8_t **frames_dev);
+int dd_ingest_release(dd_ingest *g, int slot, void *consumer_stream);
+
 /* ---------------------------------------------------------------- networks
  * Replaces tflite_runtime.Interpreter(model_path).invoke() at tools/ssd_mobilenet.py:35-38,102-109,
  * tools/yolov5.py:71-79,107-109 and tools/generate_detections.py:153-154,169-171.  A model is an op
