@@ -36,7 +36,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--streams', type=int, default=int(os.environ.get('DD_BENCH_STREAMS', '256')),
+    ap.add_argument('--streams', type=int, default=int(os.environ.get('DD_BENCH_STREAMS', '384')),
                     help='independent video streams per GPU (one frame of each per step)')
     ap.add_argument('--groups', type=int, default=int(os.environ.get('DD_BENCH_GROUPS', '4')),
                     help='worker threads per GPU: the streams are split into this many pipelines, each with its own '
@@ -61,24 +61,25 @@ def _gen_stream(args):
     return frames, per
 
 
-def make_inputs(rank, streams, n_frames):
-    """-> frames u8 [F, S, H, W, 3] (host) and per-stream per-frame injected detections (seeded, untimed)."""
+def make_inputs(rank, streams, n_frames, sink):
+    """Seeded frames and injected detections of every stream (untimed).  sink(s, frames u8 [F, H, W, 3]) places a
+    stream's frames (HBM tensor slice or pinned slot) as soon as a worker delivers them, so the host never holds
+    more than the few streams in flight; returns the per-stream per-frame detections."""
     import multiprocessing as mp
-    frames = np.empty((n_frames, streams, H, W, 3), dtype=np.uint8)
     dets = [None] * streams
     jobs = [(1000 * rank + s, n_frames) for s in range(streams)]
     workers = max(1, min(16, (os.cpu_count() or 2) // 2, streams))
     if workers > 1:
         with mp.get_context('spawn').Pool(workers) as pool:
             for s, (fr, per) in enumerate(pool.imap(_gen_stream, jobs)):
-                frames[:, s] = fr
+                sink(s, fr)
                 dets[s] = per
     else:
         for s, job in enumerate(jobs):
             fr, per = _gen_stream(job)
-            frames[:, s] = fr
+            sink(s, fr)
             dets[s] = per
-    return frames, dets
+    return dets
 
 
 def cpu_baseline(n_frames):
@@ -162,23 +163,28 @@ def main():
     n_frames = args.warmup + args.steps
     G = max(1, min(args.groups, args.streams))
     bounds = [round(g * args.streams / G) for g in range(G + 1)]
-    frames, dets = make_inputs(rank, args.streams, n_frames)
     ctxs = [Context(local_rank) for _ in range(G)]
     pipes = [MultiStreamPipeline(bounds[g + 1] - bounds[g], context=ctxs[g]) for g in range(G)]
-    ings = None
+    group_of = [g for g in range(G) for _ in range(bounds[g], bounds[g + 1])]
+    ings = dev_frames = None
     if args.ingest_host:
         # one pinned slot per step and group, filled before the timed region (a decoder would write there directly)
         from deepdish_amd.ingest import FrameIngest
         ings = [FrameIngest(bounds[g + 1] - bounds[g], (W, H), slots=n_frames, context=ctxs[g]) for g in range(G)]
-        for g in range(G):
+
+        def sink(s, fr):
+            g = group_of[s]
             for f in range(n_frames):
-                ings[g].host(f)[...] = frames[f, bounds[g]:bounds[g + 1]]
-        dev_frames = None
+                ings[g].host(f)[s - bounds[g]] = fr[f]
     else:
         # frames resident in HBM before the timed region: per group [F][S_g][H][W][3]
-        dev_frames = [torch.from_numpy(np.ascontiguousarray(frames[:, bounds[g]:bounds[g + 1]])).to(f'cuda:{local_rank}')
+        dev_frames = [torch.empty((n_frames, bounds[g + 1] - bounds[g], H, W, 3), dtype=torch.uint8, device=f'cuda:{local_rank}')
                       for g in range(G)]
-    del frames
+
+        def sink(s, fr):
+            g = group_of[s]
+            dev_frames[g][:, s - bounds[g]] = torch.from_numpy(fr).to(f'cuda:{local_rank}')
+    dets = make_inputs(rank, args.streams, n_frames, sink)
     injected = [[pipes[g].pack_injected([dets[s][f] for s in range(bounds[g], bounds[g + 1])]) for f in range(n_frames)]
                 for g in range(G)]
     torch.cuda.synchronize()
