@@ -459,7 +459,10 @@ __device__ __forceinline__ void lds_fill16(const _Float16 *g, _Float16 *lds_wave
 // eight consecutive 128-byte rows.  Rows are unpadded, so the 16-byte chunks of a row are XOR-swizzled
 // with (row & 7) -- on the SOURCE address for the fill and on the ds_read_b128 address for the
 // fragments -- which makes every 16-lane read group hit 16 distinct 4-bank groups.
-template <int WM, int WN, int MI, int NI>
+// FM (fill mode) 1: 1x1, stride 1, no padding, Cin % 64 == 0 -- the pixel operand is a plain row-major matrix: no
+// tap walk, no bounds tests.  (The general per-lane walk costs more issue slots per K step than the MFMAs:
+// 19x19x512 -> 512 went 24.9 -> 21.8 us.  A scalar-tap variant for 3x3 with Cin % 64 == 0 was measured slower.)
+template <int WM, int WN, int MI, int NI, int FM = 0>
 __global__ __launch_bounds__(WM *WN * 64) void conv_glds_k(const ConvP P) {
     constexpr int NW = WM * WN;
     constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
@@ -512,7 +515,22 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_glds_k(const ConvP P) {
         l_kh = tap / P.kw;
         l_kw = tap - l_kh * P.kw;
     }
+    const _Float16 *xbase[XG];                                  // FM 1: this lane's chunk of its pixel rows at K = 0
+#pragma unroll
+    for (int i = 0; i < XG; ++i) {
+        const int m = m0 + (wave * XG + i) * 8 + rr;
+        xbase[i] = x_ok[i] ? P.in + (size_t)m * P.cs_in + P.coff_in + gchunk : nullptr;
+    }
     auto fill = [&](int ks, int buf) {                          // called with consecutive ks
+        if constexpr (FM == 1) {                                 // one add per row group and step
+            const int k = ks << 6;
+#pragma unroll
+            for (int i = 0; i < XG; ++i)
+                lds_fill16(xbase[i] ? xbase[i] + k : P.zero, xs + (size_t)(buf * BM + (wave * XG + i) * 8) * 64);
+#pragma unroll
+            for (int i = 0; i < WG; ++i) lds_fill16(wbase[i] + k, ws + (size_t)(buf * BN + (wave * WG + i) * 8) * 64);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < XG; ++i) {
             const int iy = x_iy0[i] + l_kh, ix = x_ix0[i] + l_kw;
@@ -1220,16 +1238,23 @@ int launch_conv(hipStream_t s, ConvP &P, DevBuf &slab, int max_batch) {
     static bool attr_done = false;                            // > 64 KiB of LDS needs the opt-in attribute
     if (!attr_done && lds_bytes > 65536) {
         if constexpr (GLDS)
-            DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_glds_k<WM, WN, MI, NI>),
+        {
+            DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_glds_k<WM, WN, MI, NI, 0>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_glds_k<WM, WN, MI, NI, 1>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        }
         else
             DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_k<WM, WN, MI, NI, BK>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         attr_done = true;
     }
-    if constexpr (GLDS)
-        hipLaunchKernelGGL((conv_glds_k<WM, WN, MI, NI>), dim3(gx, gy, splitk), dim3(WM * WN * 64), lds_bytes, s, P);
-    else
+    if constexpr (GLDS) {
+        const bool pw = P.kh == 1 && P.kw == 1 && P.stride == 1 && P.pad_t == 0 && P.pad_l == 0 && P.cin % 64 == 0 &&
+                        P.ho == P.H && P.wo == P.W;
+        if (pw) hipLaunchKernelGGL((conv_glds_k<WM, WN, MI, NI, 1>), dim3(gx, gy, splitk), dim3(WM * WN * 64), lds_bytes, s, P);
+        else hipLaunchKernelGGL((conv_glds_k<WM, WN, MI, NI, 0>), dim3(gx, gy, splitk), dim3(WM * WN * 64), lds_bytes, s, P);
+    } else
         hipLaunchKernelGGL((conv_mfma_k<WM, WN, MI, NI, BK>), dim3(gx, gy, splitk), dim3(WM * WN * 64), lds_bytes, s, P);
     DD_LAUNCH_CHECK();
     if (splitk > 1) {
