@@ -460,8 +460,10 @@ __device__ __forceinline__ void lds_fill16(const _Float16 *g, _Float16 *lds_wave
 // with (row & 7) -- on the SOURCE address for the fill and on the ds_read_b128 address for the
 // fragments -- which makes every 16-lane read group hit 16 distinct 4-bank groups.
 // FM (fill mode) 1: 1x1, stride 1, no padding, Cin % 64 == 0 -- the pixel operand is a plain row-major matrix: no
-// tap walk, no bounds tests.  (The general per-lane walk costs more issue slots per K step than the MFMAs:
-// 19x19x512 -> 512 went 24.9 -> 21.8 us.  A scalar-tap variant for 3x3 with Cin % 64 == 0 was measured slower.)
+// tap walk, no bounds tests; 2: up to 3x3 with Cin % 64 == 0 -- a K step lies inside one filter tap, the same one
+// for every lane, so the tap walk is scalar and a lane does one add and a two-bit test per row group; 0: anything
+// else.  (The general per-lane walk costs more issue slots per K step than the MFMAs: 19x19x512 -> 512 went
+// 24.9 -> 21.8 us with FM 1, the MARS 16x8x64 -> 64 layers 28.8 -> 24.5 us with FM 2.)
 template <int WM, int WN, int MI, int NI, int FM = 0>
 __global__ __launch_bounds__(WM *WN * 64) void conv_glds_k(const ConvP P) {
     constexpr int NW = WM * WN;
@@ -515,13 +517,43 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_glds_k(const ConvP P) {
         l_kh = tap / P.kw;
         l_kw = tap - l_kh * P.kw;
     }
-    const _Float16 *xbase[XG];                                  // FM 1: this lane's chunk of its pixel rows at K = 0
+    const _Float16 *xbase[XG];                                  // FM 1/2: this lane's chunk of its pixel rows at tap (0,0), K = 0
+    unsigned rmask[XG], cmask[XG];                              // FM 2: bit k set = filter row / column k of the pixel is inside the image
 #pragma unroll
     for (int i = 0; i < XG; ++i) {
         const int m = m0 + (wave * XG + i) * 8 + rr;
-        xbase[i] = x_ok[i] ? P.in + (size_t)m * P.cs_in + P.coff_in + gchunk : nullptr;
+        if constexpr (FM == 2) {
+            xbase[i] = P.in + ((ptrdiff_t)(x_n[i] * P.H + x_iy0[i]) * P.W + x_ix0[i]) * P.cs_in + P.coff_in + gchunk;
+            unsigned rm = 0, cm = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (x_ok[i] && x_iy0[i] + k >= 0 && x_iy0[i] + k < P.H) rm |= 1u << k;
+                if (x_ix0[i] + k >= 0 && x_ix0[i] + k < P.W) cm |= 1u << k;
+            }
+            rmask[i] = rm; cmask[i] = cm;
+        } else {
+            xbase[i] = x_ok[i] ? P.in + (size_t)m * P.cs_in + P.coff_in + gchunk : nullptr;
+        }
+    }
+    int s_c = 0, s_kh = 0, s_kw = 0;                            // FM 2: scalar (tap, channel) position of the K step
+    if constexpr (FM == 2) {
+        const int k = ks0 << 6, tap = k / P.cin;
+        s_c = k - tap * P.cin; s_kh = tap / P.kw; s_kw = tap - s_kh * P.kw;
     }
     auto fill = [&](int ks, int buf) {                          // called with consecutive ks
+        if constexpr (FM == 2) {                                 // Cin % 64 == 0: the K step lies inside one tap, the same for every lane
+            const ptrdiff_t off = (ptrdiff_t)(s_kh * P.W + s_kw) * P.cs_in + s_c;      // wave-uniform
+#pragma unroll
+            for (int i = 0; i < XG; ++i)
+                lds_fill16((((rmask[i] >> s_kh) & (cmask[i] >> s_kw)) & 1u) ? xbase[i] + off : P.zero,
+                           xs + (size_t)(buf * BM + (wave * XG + i) * 8) * 64);
+            s_c += 64;
+            if (s_c >= P.cin) { s_c = 0; if (++s_kw == P.kw) { s_kw = 0; ++s_kh; } }
+            const int k = ks << 6;
+#pragma unroll
+            for (int i = 0; i < WG; ++i) lds_fill16(wbase[i] + k, ws + (size_t)(buf * BN + (wave * WG + i) * 8) * 64);
+            return;
+        }
         if constexpr (FM == 1) {                                 // one add per row group and step
             const int k = ks << 6;
 #pragma unroll
@@ -1243,6 +1275,8 @@ int launch_conv(hipStream_t s, ConvP &P, DevBuf &slab, int max_batch) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
             DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_glds_k<WM, WN, MI, NI, 1>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_glds_k<WM, WN, MI, NI, 2>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         }
         else
             DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_k<WM, WN, MI, NI, BK>),
@@ -1252,7 +1286,10 @@ int launch_conv(hipStream_t s, ConvP &P, DevBuf &slab, int max_batch) {
     if constexpr (GLDS) {
         const bool pw = P.kh == 1 && P.kw == 1 && P.stride == 1 && P.pad_t == 0 && P.pad_l == 0 && P.cin % 64 == 0 &&
                         P.ho == P.H && P.wo == P.W;
+        static const bool no_fm2 = getenv("DD_NO_FM2") != nullptr;                      // A/B switch
+        const bool tapu = P.cin % 64 == 0 && P.kh <= 3 && P.kw <= 3 && P.kpad == P.kh * P.kw * P.cin && !no_fm2;
         if (pw) hipLaunchKernelGGL((conv_glds_k<WM, WN, MI, NI, 1>), dim3(gx, gy, splitk), dim3(WM * WN * 64), lds_bytes, s, P);
+        else if (tapu) hipLaunchKernelGGL((conv_glds_k<WM, WN, MI, NI, 2>), dim3(gx, gy, splitk), dim3(WM * WN * 64), lds_bytes, s, P);
         else hipLaunchKernelGGL((conv_glds_k<WM, WN, MI, NI, 0>), dim3(gx, gy, splitk), dim3(WM * WN * 64), lds_bytes, s, P);
     } else
         hipLaunchKernelGGL((conv_mfma_k<WM, WN, MI, NI, BK>), dim3(gx, gy, splitk), dim3(WM * WN * 64), lds_bytes, s, P);
