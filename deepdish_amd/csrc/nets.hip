@@ -161,15 +161,17 @@ __device__ __forceinline__ Epi8 epi8_load(const ConvP &P, int co) {
 
 // ACT >= 0: the activation is known at compile time (the per-element switch on P.act would otherwise be
 // compiled into a chain of branches around every value).
-template <int ACT = -1, bool BIAS = true>           // BIAS = false: the accumulators were initialised with the bias
+// EF (epilogue flavour) 0: no residual, no second output; 1: both; -1: whatever P says.
+template <int ACT = -1, bool BIAS = true, int EF = -1>   // BIAS = false: the accumulators were initialised with the bias
 __device__ __forceinline__ void conv_epilogue_f16x8(const ConvP &P, const Epi8 &E, int m, int co, float v[8]) {
     const int act = ACT < 0 ? P.act : ACT;
+    const bool has_res = EF < 0 ? P.res != nullptr : EF == 1, has_out2 = EF < 0 ? P.out2 != nullptr : EF == 1;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         v[r] = apply_act(BIAS ? v[r] + E.b0[r] : v[r], act);
         v[4 + r] = apply_act(BIAS ? v[4 + r] + E.b1[r] : v[4 + r], act);
     }
-    if (P.res) {
+    if (has_res) {
         const h8 rv = *reinterpret_cast<const h8 *>(P.res + (size_t)m * P.cs_res + P.coff_res + co);
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] += (float)rv[r];
@@ -184,7 +186,7 @@ __device__ __forceinline__ void conv_epilogue_f16x8(const ConvP &P, const Epi8 &
             if (co + r >= P.cout) o[r] = (_Float16)0.f;
     }
     *reinterpret_cast<h8 *>(static_cast<_Float16 *>(P.out) + (size_t)m * P.cs_out + P.coff_out + co) = o;
-    if (P.out2) {                                   // second view: ELU(scale * raw + shift)
+    if (has_out2) {                                 // second view: ELU(scale * raw + shift)
         h8 o2;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -635,9 +637,10 @@ constexpr int RW_FILL = 11;                                    // 16 patch pixel
 constexpr int RW_MAX_PATCH = RW_FILL * 64;
 constexpr int RW_MB = 4;                                       // pixel fragments in flight per wave
 
-template <int NCO, int TW, int ACT, bool POOL>                 // TW: tile width when known at compile time (tap offsets
+template <int NCO, int TW, int ACT, bool POOL, int EF = -1>     // TW: tile width when known at compile time (tap offsets
 __global__ __launch_bounds__(256, 2) void conv3x3_rw_k(const ConvP P, const int total_tiles) {   // become ds_read immediates), else 0
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    constexpr int MB = EF == 1 ? 2 : RW_MB;                    // pixel fragments in flight per wave (the two-output epilogue needs the registers)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int tw = TW ? TW : P.tw;
@@ -699,38 +702,38 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rw_k(const ConvP P, const int 
         const int tn = t + gridDim.x;
         if (tn < total_tiles) fetch(tn);
 
-        for (int f0 = wave * RW_MB; f0 < nfrag; f0 += 4 * RW_MB) {
-            int base[RW_MB], mrow[RW_MB];
-            bool ok[RW_MB];
+        for (int f0 = wave * MB; f0 < nfrag; f0 += 4 * MB) {
+            int base[MB], mrow[MB];
+            bool ok[MB];
 #pragma unroll
-            for (int b = 0; b < RW_MB; ++b) {
+            for (int b = 0; b < MB; ++b) {
                 const int p = (f0 + b) * 16 + fr;
                 const int ty = (int)((p * rcp_tw) >> 16), tx = p - ty * tw;
                 ok[b] = p < tile_px && y0 + ty < P.ho && x0 + tx < P.wo;
                 base[b] = fq * plane + (ok[b] ? ty * PW + tx : 0) * 8;     // top-left tap of the pixel, in halves
                 mrow[b] = (n * P.ho + y0 + ty) * P.wo + x0 + tx;
             }
-            f4 acc[NCO][RW_MB];                                  // start from the bias of the lane's output channels
+            f4 acc[NCO][MB];                                  // start from the bias of the lane's output channels
 #pragma unroll
             for (int a = 0; a < NCO; ++a)
 #pragma unroll
-                for (int b = 0; b < RW_MB; ++b) acc[a][b] = (a & 1) ? E[a >> 1].b1 : E[a >> 1].b0;
+                for (int b = 0; b < MB; ++b) acc[a][b] = (a & 1) ? E[a >> 1].b1 : E[a >> 1].b0;
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
                     const int off = (dy * PW + dx) * 8;
-                    h8 xf[RW_MB];
+                    h8 xf[MB];
 #pragma unroll
-                    for (int b = 0; b < RW_MB; ++b) xf[b] = *reinterpret_cast<const h8 *>(lds + base[b] + off);
+                    for (int b = 0; b < MB; ++b) xf[b] = *reinterpret_cast<const h8 *>(lds + base[b] + off);
 #pragma unroll
                     for (int a = 0; a < NCO; ++a)
 #pragma unroll
-                        for (int b = 0; b < RW_MB; ++b)
+                        for (int b = 0; b < MB; ++b)
                             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[dy * 3 + dx][a], xf[b], acc[a][b], 0, 0, 0);
                 }
 #pragma unroll
-            for (int b = 0; b < RW_MB; ++b) {
+            for (int b = 0; b < MB; ++b) {
                 if (!ok[b]) continue;
 #pragma unroll
                 for (int g = 0; g < NCO / 2; ++g) {
@@ -747,7 +750,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rw_k(const ConvP P, const int 
                         }
                         *reinterpret_cast<h8 *>(stage + ((f0 + b) * 16 + fr) * (NCO * 16) + g * 32 + fq * 8) = hv;
                     } else {
-                        conv_epilogue_f16x8<ACT, false>(P, E[g], mrow[b], g * 32 + fq * 8, o);
+                        conv_epilogue_f16x8<ACT, false, EF>(P, E[g], mrow[b], g * 32 + fq * 8, o);
                     }
                 }
             }
@@ -856,7 +859,7 @@ __global__ __launch_bounds__(256) void stem_conv3_k(const ConvP P) {
             const f4 a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[1], xf[b], E.b1, 0, 0, 0);
             if (!ok[b]) continue;
             float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-            conv_epilogue_f16x8<ACT, false>(P, E, mrow[b], fq * 8, v);
+            conv_epilogue_f16x8<ACT, false, 0>(P, E, mrow[b], fq * 8, v);
         }
     }
 }
@@ -1009,7 +1012,7 @@ __global__ __launch_bounds__(256) void dwpw_k(const ConvP P) {
             float o[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) { o[r] = acc[2 * g2][b][r]; o[4 + r] = acc[2 * g2 + 1][b][r]; }
-            conv_epilogue_f16x8<ACT, false>(P, E[g2], m, n0 + wn * 64 + g2 * 32 + fq * 8, o);
+            conv_epilogue_f16x8<ACT, false, 0>(P, E[g2], m, n0 + wn * 64 + g2 * 32 + fq * 8, o);
         }
     }
 }
@@ -1337,12 +1340,13 @@ int launch_conv3x3_rw(hipStream_t s, ConvP &P, int nimg, bool pool) {
         DD_LAUNCH_CHECK();
         return DD_OK;
     }
-#define DD_RW(TW_, ACT_) hipLaunchKernelGGL((conv3x3_rw_k<2, TW_, ACT_, false>), dim3((unsigned)grid), dim3(256), lds_bytes, s, P, total)
-    if (P.tw == 32 && P.act == ACT_ELU) DD_RW(32, ACT_ELU);
-    else if (P.tw == 32 && P.act == ACT_SILU) DD_RW(32, ACT_SILU);
-    else if (P.tw == 15 && P.act == ACT_ELU) DD_RW(15, ACT_ELU);
-    else if (P.tw == 15 && P.act == ACT_NONE) DD_RW(15, ACT_NONE);
-    else DD_RW(0, -1);
+#define DD_RW(TW_, ACT_, EF_) hipLaunchKernelGGL((conv3x3_rw_k<2, TW_, ACT_, false, EF_>), dim3((unsigned)grid), dim3(256), lds_bytes, s, P, total)
+    const int ef = (!P.res && !P.out2) ? 0 : (P.res && P.out2) ? 1 : -1;
+    if (P.tw == 32 && P.act == ACT_ELU && ef == 0) DD_RW(32, ACT_ELU, 0);
+    else if (P.tw == 32 && P.act == ACT_SILU) DD_RW(32, ACT_SILU, -1);
+    else if (P.tw == 15 && P.act == ACT_ELU && ef == 0) DD_RW(15, ACT_ELU, 0);
+    else if (P.tw == 15 && P.act == ACT_NONE && ef == 1) DD_RW(15, ACT_NONE, 1);
+    else DD_RW(0, -1, -1);
 #undef DD_RW
     DD_LAUNCH_CHECK();
     return DD_OK;
