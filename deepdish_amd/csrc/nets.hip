@@ -1020,9 +1020,9 @@ __global__ __launch_bounds__(256) void dwpw_k(const ConvP P) {
 // Split-K tail: sum the partial slabs in a fixed order (bitwise reproducible) and run the epilogue.
 __global__ __launch_bounds__(256) void conv_splitk_finish_k(const ConvP P) {
     const int groups = P.cout_pad >> 2;
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)P.m * groups) return;
-    const int m = (int)(idx / groups), co = (int)(idx % groups) * 4;
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;   // launcher: m * groups < 2^31 (64-bit divisions cost ~100 instructions each)
+    if (idx >= (unsigned)P.m * (unsigned)groups) return;
+    const int m = (int)(idx / (unsigned)groups), co = (int)(idx % (unsigned)groups) * 4;
     float v[4] = {0.f, 0.f, 0.f, 0.f};
     for (int z = 0; z < P.splitk; ++z) {
         const f4 s = *reinterpret_cast<const f4 *>(P.slab + ((size_t)z * P.m + m) * P.cout_pad + co);
@@ -1049,14 +1049,14 @@ __global__ __launch_bounds__(256) void dwconv3_k(const DwP P) {
     constexpr int TX = 4, NCOL = (TX - 1) * STRIDE + 3;
     const int groups = P.c >> 3;
     const int wo4 = (P.wo + TX - 1) / TX;
-    const long long total = (long long)(P.m / P.wo) * wo4 * groups;       // m / wo = images * rows
-    const long long idx = (long long)dd_xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+    const unsigned total = (unsigned)(P.m / P.wo) * wo4 * groups;         // m / wo = images * rows; < 2^31 (checked by the launcher)
+    const unsigned idx = dd_xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    const int g = (int)(idx % groups);
-    long long t = idx / groups;
-    const int ox0 = (int)(t % wo4) * TX;
-    t /= wo4;
-    const int oy = (int)(t % P.ho), n = (int)(t / P.ho);
+    const int g = (int)(idx % (unsigned)groups);                          // 32-bit: a 64-bit division costs ~100 instructions
+    unsigned t = idx / (unsigned)groups;
+    const int ox0 = (int)(t % (unsigned)wo4) * TX;
+    t /= (unsigned)wo4;
+    const int oy = (int)(t % (unsigned)P.ho), n = (int)(t / (unsigned)P.ho);
     float acc[TX][8];
     {
         const f4 b0 = *reinterpret_cast<const f4 *>(P.bias + g * 8), b1 = *reinterpret_cast<const f4 *>(P.bias + g * 8 + 4);
@@ -1105,10 +1105,10 @@ struct PoolP {
 
 __global__ __launch_bounds__(256) void maxpool_k(const PoolP P) {
     const int groups = P.c >> 3;
-    const long long idx = (long long)dd_xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
-    if (idx >= (long long)P.m * groups) return;
-    const int g = (int)(idx % groups);
-    const int m = (int)(idx / groups);
+    const unsigned idx = dd_xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+    if (idx >= (unsigned)P.m * (unsigned)groups) return;
+    const int g = (int)(idx % (unsigned)groups);
+    const int m = (int)(idx / (unsigned)groups);
     const int hw = P.ho * P.wo;
     const int n = m / hw, r = m - n * hw;
     const int oy = r / P.wo, ox = r - oy * P.wo;
@@ -1136,10 +1136,10 @@ __global__ __launch_bounds__(256) void maxpool_k(const PoolP P) {
 __global__ __launch_bounds__(256) void upsample2_k(const _Float16 *__restrict__ in, int H, int W, int cs_in, int coff_in,
                                                    int c, int m_out, _Float16 *__restrict__ out, int cs_out, int coff_out) {
     const int groups = c >> 3;
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)m_out * groups) return;
-    const int g = (int)(idx % groups);
-    const int m = (int)(idx / groups);
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (unsigned)m_out * (unsigned)groups) return;
+    const int g = (int)(idx % (unsigned)groups);
+    const int m = (int)(idx / (unsigned)groups);
     const int wo = W * 2, hw = H * 2 * wo;
     const int n = m / hw, r = m - n * hw;
     const int oy = r / wo, ox = r - oy * wo;
@@ -1299,6 +1299,7 @@ int launch_conv(hipStream_t s, ConvP &P, DevBuf &slab, int max_batch) {
     DD_LAUNCH_CHECK();
     if (splitk > 1) {
         const long long total = (long long)P.m * (P.cout_pad >> 2);
+        DD_REQUIRE(total < (1LL << 31), DD_E_CAPACITY, "split-K finish of %lld items exceeds 32-bit indexing", total);
         hipLaunchKernelGGL(conv_splitk_finish_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, P);
         DD_LAUNCH_CHECK();
     }
@@ -1644,6 +1645,7 @@ int dd_net_forward(dd_net *net, const uint8_t *input, int nimg, void *stream) {
                 P.out = reinterpret_cast<_Float16 *>(base(dst)); P.cs_out = td->cs; P.coff_out = td->coff;
                 P.zero = net->d_zero;
                 const long long total = (long long)(P.m / P.wo) * ((P.wo + 3) / 4) * (P.c >> 3);
+                DD_REQUIRE(total < (1LL << 31), DD_E_CAPACITY, "dd_net_forward: depthwise layer of %lld items exceeds 32-bit indexing", total);
                 DD_REQUIRE(P.stride == 1 || P.stride == 2, DD_E_ARG, "dd_net_forward: depthwise stride %d", P.stride);
                 if (P.stride == 1)
                     hipLaunchKernelGGL(dwconv3_k<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, P);
@@ -1659,6 +1661,7 @@ int dd_net_forward(dd_net *net, const uint8_t *input, int nimg, void *stream) {
                 P.m = nimg * td->h * td->w;
                 P.out = reinterpret_cast<_Float16 *>(base(dst)); P.cs_out = td->cs; P.coff_out = td->coff;
                 const long long total = (long long)P.m * (P.c >> 3);
+                DD_REQUIRE(total < (1LL << 31), DD_E_CAPACITY, "dd_net_forward: pooling layer of %lld items exceeds 32-bit indexing", total);
                 hipLaunchKernelGGL(maxpool_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, P);
                 DD_LAUNCH_CHECK();
                 break;
@@ -1666,6 +1669,7 @@ int dd_net_forward(dd_net *net, const uint8_t *input, int nimg, void *stream) {
             case OP_UPSAMPLE: {
                 const int m = nimg * td->h * td->w;
                 const long long total = (long long)m * (o[12] >> 3);
+                DD_REQUIRE(total < (1LL << 31), DD_E_CAPACITY, "dd_net_forward: upsample layer of %lld items exceeds 32-bit indexing", total);
                 hipLaunchKernelGGL(upsample2_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
                                    reinterpret_cast<const _Float16 *>(base(src)), ts->h, ts->w, ts->cs, ts->coff, o[12], m,
                                    reinterpret_cast<_Float16 *>(base(dst)), td->cs, td->coff);
