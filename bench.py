@@ -195,11 +195,14 @@ def main():
             for f in range(f0, f1):
                 if f + 1 < f1:
                     ings[g].submit(f + 1)                         # the next step's upload runs under this step's kernels
-                pipes[g].step(ings[g].frames(f), injected[g][f])
+                nxt = ings[g].frames(f + 1) if f + 1 < f1 else None
+                pipes[g].step(ings[g].frames(f), injected[g][f], nxt)
                 ings[g].release(f)
             return
-        for f in range(f0, f1):
-            pipes[g].step(dev_frames[g][f], injected[g][f])       # blocking C call, releases the GIL
+        ahead = os.environ.get('DD_BENCH_NO_LOOKAHEAD') is None
+        for f in range(f0, f1):                                   # blocking C call, releases the GIL; the detector of
+            pipes[g].step(dev_frames[g][f], injected[g][f],       # frame f+1 is queued behind this step's own detections
+                          dev_frames[g][f + 1] if ahead and f + 1 < f1 else None)
 
     def run_all(f0, f1):
         if G == 1:

@@ -70,6 +70,7 @@ SIGNATURES = {
                            c_double, c_int, c_int, P, c_int, c_int, POINTER(P)],
     'dd_pipeline_destroy': [P],
     'dd_pipeline_step': [P, P, P, P, P, P],
+    'dd_pipeline_step2': [P, P, P, P, P, P, P],
     'dd_pipeline_counts': [P, P],
     'dd_pipeline_tracker': [P, c_int, POINTER(P)],
     'dd_pipeline_stage_seconds': [P, P, POINTER(ctypes.c_longlong)],

@@ -149,6 +149,12 @@ struct dd_pipeline {
     int crop_cap = 0;
     double t_det = 0, t_nms = 0, t_enc = 0, t_trk = 0;    // host wall seconds per stage, accumulated
     long long steps = 0;
+    // The detector has its own stream: like the reference, which keeps one detector call and one encoder call
+    // in flight on different frames (deepdish.py:935,985,1008), the detector of frame t+1 can be queued while
+    // frame t goes through NMS / encoder / tracker on the main stream.
+    hipStream_t det_stream = nullptr;
+    hipEvent_t det_done = nullptr, main_mark = nullptr;
+    const uint8_t *det_pending = nullptr;      // frames the queued detector run belongs to
 };
 
 namespace {
@@ -223,6 +229,9 @@ int dd_pipeline_create(dd_ctx *ctx, int n_streams, int frame_h, int frame_w, dd_
         int db = 0;
         if ((rc = dd_net_max_batch(detector, &db)) != DD_OK) return rc;
         DD_REQUIRE(db >= n_streams, DD_E_CAPACITY, "dd_pipeline_create: detector max_batch %d < %d streams", db, n_streams);
+        DD_HIP(hipStreamCreateWithFlags(&p->det_stream, hipStreamNonBlocking));
+        DD_HIP(hipEventCreateWithFlags(&p->det_done, hipEventDisableTiming));
+        DD_HIP(hipEventCreateWithFlags(&p->main_mark, hipEventDisableTiming));
         DD_HIP(hipMalloc(&p->d_anchors, (size_t)n_anchors * 4 * sizeof(float)));
         DD_HIP(hipMemcpy(p->d_anchors, anchors_host, (size_t)n_anchors * 4 * sizeof(float), hipMemcpyHostToDevice));
         const size_t S = n_streams;
@@ -247,6 +256,9 @@ int dd_pipeline_create(dd_ctx *ctx, int n_streams, int frame_h, int frame_w, dd_
 
 int dd_pipeline_destroy(dd_pipeline *p) {
     if (!p) return DD_OK;
+    if (p->det_stream) { (void)hipStreamSynchronize(p->det_stream); (void)hipStreamDestroy(p->det_stream); }
+    if (p->det_done) (void)hipEventDestroy(p->det_done);
+    if (p->main_mark) (void)hipEventDestroy(p->main_mark);
     for (auto &s : p->st) dd_tracker_destroy(s.trk);
     (void)hipFree(p->d_anchors);
     for (DevBuf *b : {&p->d_resized, &p->d_tmp, &p->d_post, &p->d_det, &p->d_fin, &p->d_nms, &p->d_crop, &p->d_patches, &p->d_feats}) b->release();
@@ -275,11 +287,60 @@ int dd_pipeline_stage_seconds(dd_pipeline *p, double *out4_host, long long *step
     return DD_OK;
 }
 
+}  // extern "C"
+
+namespace {
+
+// resize -> forward -> post-process -> adaptor tail -> pinned host block, all streams at once, on the
+// detector stream; det_done fires when the host block is complete.
+int enqueue_detector(dd_pipeline *p, const uint8_t *frames) {
+    hipStream_t s = p->det_stream;
+    const int S = p->S;
+    int rc;
+    // order after whatever the caller has queued on the main stream so far (e.g. the ingest ring's wait for the
+    // upload of these frames)
+    DD_HIP(hipEventRecord(p->main_mark, p->ctx->stream));
+    DD_HIP(hipStreamWaitEvent(s, p->main_mark, 0));
+    if ((rc = ddk::resize_lanczos(s, p->ctx->device, frames, p->H, p->W, 3, 1, p->d_resized.as<uint8_t>(), p->det_in,
+                                  p->det_in, p->d_tmp.as<uint8_t>(), S)) != DD_OK) return rc;      // ssd_mobilenet.py:54-57
+    if ((rc = dd_net_forward(p->det, p->d_resized.as<uint8_t>(), S, s)) != DD_OK) return rc;       // :102-103
+    void *raw = nullptr;
+    if ((rc = dd_net_output(p->det, -1, &raw, nullptr, nullptr, nullptr, nullptr, nullptr)) != DD_OK) return rc;
+    float *db = p->d_det.as<float>(), *dc = db + (size_t)S * MAX_DET * 4, *ds = dc + (size_t)S * MAX_DET;
+    int *dn = reinterpret_cast<int *>(ds + (size_t)S * MAX_DET);
+    if ((rc = ddk::ssd_postprocess(s, static_cast<const float *>(raw), p->d_anchors, p->n_anchors, p->n_classes, MAX_DET,
+                                   1e-8f, 0.6f, db, dc, ds, dn, S, p->d_post.p, p->d_post.cap)) != DD_OK) return rc;
+    double *fb = p->d_fin.as<double>(), *fs = fb + (size_t)S * MAX_DET * 4;
+    int *fc = reinterpret_cast<int *>(fs + (size_t)S * MAX_DET), *fn = fc + (size_t)S * MAX_DET;
+    hipLaunchKernelGGL(ssd_finish_k, dim3(S), dim3(64), 0, s, db, dc, ds, p->det_conf, 0.5, (double)p->W, (double)p->H, fb,
+                       fc, fs, fn);
+    DD_LAUNCH_CHECK();
+    const size_t fbytes = (size_t)S * (MAX_DET * (4 * 8 + 8 + 4) + 4);
+    DD_HIP(hipMemcpyAsync(p->h_fin.p, p->d_fin.p, fbytes, hipMemcpyDeviceToHost, s));
+    DD_HIP(hipEventRecord(p->det_done, s));
+    p->det_pending = frames;
+    return DD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 // frames: device u8 [S][H][W][3] BGR.  inj_*: optional injected detections that REPLACE the detector's
 // output (the detector still runs): boxes tlwh as the detector adaptor would return them (f64),
 // scores, class ids, stream s owns rows [inj_offsets[s], inj_offsets[s+1]).
+// frames_next (optional): the frames of the following step; their detector run is queued on the detector
+// stream as soon as this step has read its own detections, and overlaps this step's NMS / encoder / tracker.
+int dd_pipeline_step2(dd_pipeline *p, const uint8_t *frames, const uint8_t *frames_next, const double *inj_boxes_host,
+                      const double *inj_scores_host, const int *inj_cls_host, const int *inj_offsets_host);
+
 int dd_pipeline_step(dd_pipeline *p, const uint8_t *frames, const double *inj_boxes_host, const double *inj_scores_host,
                      const int *inj_cls_host, const int *inj_offsets_host) {
+    return dd_pipeline_step2(p, frames, nullptr, inj_boxes_host, inj_scores_host, inj_cls_host, inj_offsets_host);
+}
+
+int dd_pipeline_step2(dd_pipeline *p, const uint8_t *frames, const uint8_t *frames_next, const double *inj_boxes_host,
+                      const double *inj_scores_host, const int *inj_cls_host, const int *inj_offsets_host) {
     DD_REQUIRE(p && frames, DD_E_ARG, "dd_pipeline_step: NULL argument");
     hipStream_t s = p->ctx->stream;
     const int S = p->S;
@@ -292,23 +353,9 @@ int dd_pipeline_step(dd_pipeline *p, const uint8_t *frames, const double *inj_bo
     std::vector<std::vector<double>> scores0(S);
     std::vector<std::vector<int>> cls0(S);
     if (p->det) {
-        if ((rc = ddk::resize_lanczos(s, p->ctx->device, frames, p->H, p->W, 3, 1, p->d_resized.as<uint8_t>(), p->det_in,
-                                      p->det_in, p->d_tmp.as<uint8_t>(), S)) != DD_OK) return rc;      // ssd_mobilenet.py:54-57
-        if ((rc = dd_net_forward(p->det, p->d_resized.as<uint8_t>(), S, s)) != DD_OK) return rc;       // :102-103
-        void *raw = nullptr;
-        if ((rc = dd_net_output(p->det, -1, &raw, nullptr, nullptr, nullptr, nullptr, nullptr)) != DD_OK) return rc;
-        float *db = p->d_det.as<float>(), *dc = db + (size_t)S * MAX_DET * 4, *ds = dc + (size_t)S * MAX_DET;
-        int *dn = reinterpret_cast<int *>(ds + (size_t)S * MAX_DET);
-        if ((rc = ddk::ssd_postprocess(s, static_cast<const float *>(raw), p->d_anchors, p->n_anchors, p->n_classes, MAX_DET,
-                                       1e-8f, 0.6f, db, dc, ds, dn, S, p->d_post.p, p->d_post.cap)) != DD_OK) return rc;
-        double *fb = p->d_fin.as<double>(), *fs = fb + (size_t)S * MAX_DET * 4;
-        int *fc = reinterpret_cast<int *>(fs + (size_t)S * MAX_DET), *fn = fc + (size_t)S * MAX_DET;
-        hipLaunchKernelGGL(ssd_finish_k, dim3(S), dim3(64), 0, s, db, dc, ds, p->det_conf, 0.5, (double)p->W, (double)p->H, fb,
-                           fc, fs, fn);
-        DD_LAUNCH_CHECK();
-        const size_t fbytes = (size_t)S * (MAX_DET * (4 * 8 + 8 + 4) + 4);
-        DD_HIP(hipMemcpyAsync(p->h_fin.p, p->d_fin.p, fbytes, hipMemcpyDeviceToHost, s));
-        DD_HIP(hipStreamSynchronize(s));                                                               // round trip 1
+        if (p->det_pending != frames && (rc = enqueue_detector(p, frames)) != DD_OK) return rc;       // not queued ahead: run it now
+        DD_HIP(hipEventSynchronize(p->det_done));                                                      // round trip 1
+        p->det_pending = nullptr;
         const double *hb = p->h_fin.as<double>(), *hs = hb + (size_t)S * MAX_DET * 4;
         const int *hc = reinterpret_cast<const int *>(hs + (size_t)S * MAX_DET), *hn = hc + (size_t)S * MAX_DET;
         for (int z = 0; z < S; ++z)
@@ -321,6 +368,8 @@ int dd_pipeline_step(dd_pipeline *p, const uint8_t *frames, const double *inj_bo
                 scores0[z].push_back(sc);
                 cls0[z].push_back(hc[z * MAX_DET + i]);
             }
+        // the host block has been consumed: the detector buffers are free for the next frames
+        if (frames_next && (rc = enqueue_detector(p, frames_next)) != DD_OK) return rc;
     }
     if (inj_offsets_host) {
         DD_REQUIRE(inj_boxes_host && inj_scores_host && inj_cls_host, DD_E_ARG, "dd_pipeline_step: injected arrays missing");

@@ -91,14 +91,15 @@ class MultiStreamPipeline:
         return (np.ascontiguousarray(np.array(b, dtype=np.float64).reshape(-1, 4)), np.array(sc, dtype=np.float64),
                 np.array(cl, dtype=np.int32), off)
 
-    def step(self, frames_dev, injected=None):
-        """frames_dev: u8 [S, H, W, 3] BGR torch tensor in HBM; injected: pack_injected(...) or None."""
+    def step(self, frames_dev, injected=None, frames_next=None):
+        """frames_dev: u8 [S, H, W, 3] BGR torch tensor in HBM; injected: pack_injected(...) or None.
+        frames_next: the frames of the following step (same shape): their detector run is queued on the
+        detector stream and overlaps this step's NMS / encoder / tracker; the next step() must receive them."""
         assert tuple(frames_dev.shape) == (self.S, self.H, self.W, 3)
-        if injected is None:
-            check(lib().dd_pipeline_step(self._h, ptr(frames_dev), None, None, None, None), 'dd_pipeline_step')
-        else:
-            b, sc, cl, off = injected
-            check(lib().dd_pipeline_step(self._h, ptr(frames_dev), ptr(b), ptr(sc), ptr(cl), ptr(off)), 'dd_pipeline_step')
+        assert frames_next is None or tuple(frames_next.shape) == (self.S, self.H, self.W, 3)
+        b, sc, cl, off = injected if injected is not None else (None, None, None, None)
+        check(lib().dd_pipeline_step2(self._h, ptr(frames_dev), ptr(frames_next), ptr(b), ptr(sc), ptr(cl), ptr(off)),
+              'dd_pipeline_step')
 
     def counts(self):
         out = np.zeros((self.S, len(self.wanted), 4), dtype=np.int64)

@@ -231,6 +231,11 @@ int dd_pipeline_destroy(dd_pipeline *p);
  * [inj_offsets[s], inj_offsets[s+1]).  Blocks until the step is complete. */
 int dd_pipeline_step(dd_pipeline *p, const uint8_t *frames, const double *inj_boxes_host,
                      const double *inj_scores_host, const int *inj_cls_host, const int *inj_offsets_host);
+/* Same step with a look-ahead: the detector run of `frames_next` (may be NULL) is queued on the pipeline's detector
+ * stream once this step has read its own detections -- the reference keeps one detector call and one encoder call
+ * in flight on different frames the same way (deepdish.py:935,985,1008).  The next call must pass those frames. */
+int dd_pipeline_step2(dd_pipeline *p, const uint8_t *frames, const uint8_t *frames_next, const double *inj_boxes_host,
+                      const double *inj_scores_host, const int *inj_cls_host, const int *inj_offsets_host);
 /* counts_host: int64 [n_streams][n_wanted][4] = poscount, negcount, intcount, delcount */
 int dd_pipeline_counts(dd_pipeline *p, int64_t *counts_host);
 int dd_pipeline_tracker(dd_pipeline *p, int stream, dd_tracker **out);

@@ -334,3 +334,27 @@ def test_clean_boxes_and_hygiene_in_cpp_match():
     np.testing.assert_array_equal(ints[:, :5], want)
     np.testing.assert_allclose(means, np.array([t.mean for t in hp.tracker.tracks]), rtol=1e-12, atol=1e-12)
     assert len(want) == 3                                               # the 639x479 box exceeds 90 % of the frame
+
+
+def test_detector_lookahead_gives_the_same_results():
+    """step(frames, frames_next=...) queues the next detector run on the detector stream; detections, tracks and
+    counts must not depend on it (no injection here: the tracker is fed by the detector's own output)."""
+    from deepdish_amd.multipipe import MultiStreamPipeline
+    from deepdish_amd.synth import Scene
+    S, F = 3, 8
+    scenes = [Scene(seed=120 + z, n_obj=10, n_frames=F) for z in range(S)]
+    labels = [l.strip() for l in open(__import__('deepdish_amd.pipeline', fromlist=['DEFAULT_LABELS']).DEFAULT_LABELS)][1:]
+    frames = [torch.from_numpy(np.stack([sc.frame(f) for sc in scenes])).cuda() for f in range(F)]
+    res = []
+    for ahead in (False, True):
+        mp = MultiStreamPipeline(S, wanted_labels=labels)
+        for f in range(F):
+            mp.step(frames[f], None, frames[f + 1] if ahead and f + 1 < F else None)
+        res.append(([mp.tracker(z).table() for z in range(S)], mp.counts()))
+    seen = 0
+    for z in range(S):
+        np.testing.assert_array_equal(res[0][0][z][0], res[1][0][z][0])
+        np.testing.assert_array_equal(res[0][0][z][1], res[1][0][z][1])
+        seen += len(res[0][0][z][0])
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    assert seen > 0
