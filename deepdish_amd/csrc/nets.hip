@@ -876,6 +876,18 @@ __global__ __launch_bounds__(256) void stem_conv3_k(const ConvP P) {
 // The whole pointwise weight panel [BN][CIN] is resident in LDS (fetched while the depthwise part
 // runs); its rows are stored in fragment order of rw_weight_row, so a lane ends up with 8 consecutive
 // output channels of a pixel and stores 16 bytes without a transposition pass.
+// Halves offset of 16-byte chunk c of logical row `row` in a [rows][CIN] LDS image.  64-byte rows (CIN = 32)
+// are additionally stored at row ^ ((row >> 2) & 1): the depthwise phase writes rows r and r + 4 from one
+// 8-lane ds_write_b128 group, and unpermuted they sit 256 bytes apart on the same banks (PMC: 27 % of the
+// LDS cycles of this kernel were bank conflicts); every aligned quartet of rows stays a quartet, so the
+// fragment reads remain conflict-free.
+template <int CIN>
+__device__ __forceinline__ int dwpw_swz(int c, int row);
+template <int CIN>
+__device__ __forceinline__ int dwpw_at(int c, int row) {
+    const int prow = CIN == 32 ? row ^ ((row >> 2) & 1) : row;
+    return prow * CIN + dwpw_swz<CIN>(c, row) * 8;
+}
 template <int CIN>
 __device__ __forceinline__ int dwpw_swz(int c, int row) {         // position of 16-byte chunk c inside LDS row `row`
     if (CIN == 32) return c ^ ((4 - ((row >> 2) & 3)) & 3);
@@ -912,7 +924,7 @@ __global__ __launch_bounds__(256) void dwpw_k(const ConvP P) {
         for (int i = 0; i < CH; ++i) {
             const int idx = tid + i * 256;
             const int j = idx / G, c = idx % G;
-            *reinterpret_cast<h8 *>(ws + j * CIN + dwpw_swz<CIN>(c, j) * 8) = wv[i];
+            *reinterpret_cast<h8 *>(ws + dwpw_at<CIN>(c, j)) = wv[i];
         }
     }
 
@@ -969,7 +981,7 @@ __global__ __launch_bounds__(256) void dwpw_k(const ConvP P) {
             typedef unsigned u4v __attribute__((ext_vector_type(4)));
             u4v ou = __builtin_bit_cast(u4v, o);                   // rows past the edge are zeroed on the packed words
             ou &= pok ? 0xFFFFFFFFu : 0u;                          // (a per-element select gets compiled into 32 branches)
-            *reinterpret_cast<u4v *>(xs + prow * CIN + dwpw_swz<CIN>(g, prow) * 8) = ou;
+            *reinterpret_cast<u4v *>(xs + dwpw_at<CIN>(g, prow)) = ou;
             if (g == 0) mrow[prow] = pok ? (n * P.ho + oy) * P.wo + ox0 + j : -1;
         }
     }
@@ -991,12 +1003,12 @@ __global__ __launch_bounds__(256) void dwpw_k(const ConvP P) {
 #pragma unroll
         for (int b = 0; b < MI; ++b) {
             const int r = (wm * MI + b) * 16 + fr;
-            xf[b] = *reinterpret_cast<const h8 *>(xs + r * CIN + dwpw_swz<CIN>(c, r) * 8);
+            xf[b] = *reinterpret_cast<const h8 *>(xs + dwpw_at<CIN>(c, r));
         }
 #pragma unroll
         for (int a = 0; a < NI; ++a) {
             const int r = (wn * NI + a) * 16 + fr;
-            wf[a] = *reinterpret_cast<const h8 *>(ws + r * CIN + dwpw_swz<CIN>(c, r) * 8);
+            wf[a] = *reinterpret_cast<const h8 *>(ws + dwpw_at<CIN>(c, r));
         }
 #pragma unroll
         for (int a = 0; a < NI; ++a)
