@@ -613,8 +613,15 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_glds_k(const ConvP P) {
             __syncthreads();
         }
     }
-    if (direct) conv_finish_direct<WM, WN, MI, NI>(P, acc, m0, n0);
-    else conv_finish<WM, WN, MI, NI>(P, acc, lds, m0, n0, hw);
+    if constexpr (MI * NI >= 12) {
+        // 48 x 64 per wave and up: only the untransposed epilogue is compiled in (the launcher sends nothing else
+        // here); with the general one the accumulator array stops being promoted to registers and every K step
+        // stores all its fragments to scratch (seen with 64 x 64 per wave: 4x slower)
+        conv_finish_direct<WM, WN, MI, NI>(P, acc, m0, n0);
+    } else {
+        if (direct) conv_finish_direct<WM, WN, MI, NI>(P, acc, m0, n0);
+        else conv_finish<WM, WN, MI, NI>(P, acc, lds, m0, n0, hw);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1280,7 +1287,7 @@ int launch_conv(hipStream_t s, ConvP &P, DevBuf &slab, int max_batch) {
         P.slab = slab.as<float>();
     }
     constexpr size_t stage_bytes = (size_t)2 * (BM + BN) * (GLDS ? 64 : BK + 8) * sizeof(_Float16);
-    constexpr size_t out_bytes = (size_t)BM * (BN + 4) * sizeof(float);
+    constexpr size_t out_bytes = BM * BN > 128 * 128 ? 0 : (size_t)BM * (BN + 4) * sizeof(float);   // big tiles: direct epilogue only
     constexpr size_t lds_bytes = stage_bytes > out_bytes ? stage_bytes : out_bytes;
     static bool attr_done = false;                            // > 64 KiB of LDS needs the opt-in attribute
     if (!attr_done && lds_bytes > 65536) {
@@ -1592,8 +1599,17 @@ int dd_net_forward(dd_net *net, const uint8_t *input, int nimg, void *stream) {
                               : launch_conv<4, 1, 1, 2, 64, false>(s, P, net->slab, net->max_batch);
                 } else if (glds && net->tile_mode != 1 && P.m >= 16384 && P.cout_pad >= 128) {
                     // plenty of pixels: 128 x 128 with 8 waves -- a third less L2->LDS traffic per FLOP than 64 x 128
-                    // (24.3 us vs 26.6 us for 19x19x512 -> 512 at 64 frames; at 10x10 it halves the block count and loses)
-                    rc = launch_conv<4, 2, 2, 4, 64, true>(s, P, net->slab, net->max_batch);
+                    // (24.3 us vs 26.6 us for 19x19x512 -> 512 at 64 frames; at 10x10 it halves the block count and loses).
+                    // A K-capped run shows ~40 % of such a launch is per-round cost (prologue, epilogue, a partly filled
+                    // last round of the 512 resident blocks), so 192 x 128 is taken when it saves rounds:
+                    // 724 -> 484 tiles for 19x19x512 at 64 frames is one round instead of two (21.3 -> 18.0 us).
+                    const int gy128 = dd_ceil_div(P.cout_pad, 128);
+                    const int c128 = dd_ceil_div(dd_ceil_div(P.m, 128) * gy128, 512) * 128;
+                    const int c192 = dd_ceil_div(dd_ceil_div(P.m, 192) * gy128, 512) * 192;
+                    if (P.epi == EPI_F16 && c192 <= c128 && net->tile_mode != 2)
+                        rc = launch_conv<4, 2, 3, 4, 64, true>(s, P, net->slab, net->max_batch);
+                    else
+                        rc = launch_conv<4, 2, 2, 4, 64, true>(s, P, net->slab, net->max_batch);
                 } else if (glds && net->tile_mode != 1 && P.m >= 16384 && P.cout_pad == 64) {
                     rc = launch_conv<4, 2, 2, 2, 64, true>(s, P, net->slab, net->max_batch);      // 128 x 64, 8 waves
                 } else if (glds && net->tile_mode != 1 && P.m >= 4096 && P.cout_pad >= 128) {
