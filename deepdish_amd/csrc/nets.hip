@@ -140,6 +140,25 @@ __device__ __forceinline__ void conv_epilogue(const ConvP &P, int m, int co, flo
     }
 }
 
+// acc + x.half * w.half in one instruction with f32 accumulation (the product of two halves is exact in f32, so
+// this is bit-identical to converting and multiplying); left to itself the compiler converts most operands
+// with separate v_cvt_f32_f16 (232 of them per depthwise item).
+typedef unsigned u4v_t __attribute__((ext_vector_type(4)));
+template <int HI>
+__device__ __forceinline__ float fma_mix_f16(unsigned x, unsigned w, float acc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (HI) asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(acc) : "v"(x), "v"(w));
+    else asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(acc) : "v"(x), "v"(w));
+#endif
+    return acc;
+}
+__device__ __forceinline__ void dw_tap(float (&acc)[8], const h8 &x, const h8 &w) {
+    const u4v_t xv = __builtin_bit_cast(u4v_t, x), wv = __builtin_bit_cast(u4v_t, w);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        acc[i] = (i & 1) ? fma_mix_f16<1>(xv[i >> 1], wv[i >> 1], acc[i]) : fma_mix_f16<0>(xv[i >> 1], wv[i >> 1], acc[i]);
+}
+
 // Plain NHWC f16 output, 8 consecutive channels of one pixel (v = raw sums): one 16-byte store, so
 // eight neighbouring lanes write a full 128-byte line.  Epi8 = the per-channel constants of those
 // eight channels (kernels whose lanes keep the same channels for every pixel load them once).
@@ -972,9 +991,7 @@ __global__ __launch_bounds__(256) void dwpw_k(const ConvP P) {
             for (int kw = 0; kw < 3; ++kw) {
                 const h8 w = *reinterpret_cast<const h8 *>(P.dw_w + (size_t)(kh * 3 + kw) * CIN + g * 8);
 #pragma unroll
-                for (int j = 0; j < TX; ++j)
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) acc[j][i] += (float)x[j * STRIDE + kw][i] * (float)w[i];
+                for (int j = 0; j < TX; ++j) dw_tap(acc[j], x[j * STRIDE + kw], w);
             }
         }
         const int dact = DACT < 0 ? P.dw_act : DACT;
@@ -1100,9 +1117,7 @@ __global__ __launch_bounds__(256) void dwconv3_k(const DwP P) {
         for (int kw = 0; kw < 3; ++kw) {
             const h8 w = *reinterpret_cast<const h8 *>(P.w + (size_t)(kh * 3 + kw) * P.c + g * 8);
 #pragma unroll
-            for (int j = 0; j < TX; ++j)
-#pragma unroll
-                for (int i = 0; i < 8; ++i) acc[j][i] += (float)x[j * STRIDE + kw][i] * (float)w[i];
+            for (int j = 0; j < TX; ++j) dw_tap(acc[j], x[j * STRIDE + kw], w);
         }
     }
 #pragma unroll
