@@ -1080,7 +1080,7 @@ struct DwP {
 // Each lane produces TX = 4 consecutive output pixels of one row for one 8-channel group: the
 // 3 x (3 + 3*stride) input window is loaded once (18 or 27 sixteen-byte loads instead of 36) and the
 // nine filter taps stay in registers.
-template <int STRIDE>
+template <int STRIDE, int ACT>                                // ACT >= 0: activation known at compile time
 __global__ __launch_bounds__(256) void dwconv3_k(const DwP P) {
     constexpr int TX = 4, NCOL = (TX - 1) * STRIDE + 3;
     const int groups = P.c >> 3;
@@ -1125,7 +1125,7 @@ __global__ __launch_bounds__(256) void dwconv3_k(const DwP P) {
         if (ox0 + j >= P.wo) break;
         h8 o;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = (_Float16)apply_act(acc[j][i], P.act);
+        for (int i = 0; i < 8; ++i) o[i] = (_Float16)apply_act(acc[j][i], ACT < 0 ? P.act : ACT);
         const size_t m = ((size_t)n * P.ho + oy) * P.wo + ox0 + j;
         *reinterpret_cast<h8 *>(P.out + m * P.cs_out + P.coff_out + g * 8) = o;
     }
@@ -1690,10 +1690,12 @@ int dd_net_forward(dd_net *net, const uint8_t *input, int nimg, void *stream) {
                 const long long total = (long long)(P.m / P.wo) * ((P.wo + 3) / 4) * (P.c >> 3);
                 DD_REQUIRE(total < (1LL << 31), DD_E_CAPACITY, "dd_net_forward: depthwise layer of %lld items exceeds 32-bit indexing", total);
                 DD_REQUIRE(P.stride == 1 || P.stride == 2, DD_E_ARG, "dd_net_forward: depthwise stride %d", P.stride);
-                if (P.stride == 1)
-                    hipLaunchKernelGGL(dwconv3_k<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, P);
-                else
-                    hipLaunchKernelGGL(dwconv3_k<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, P);
+                const dim3 grid((unsigned)((total + 255) / 256));
+#define DD_DW(S_, A_) hipLaunchKernelGGL((dwconv3_k<S_, A_>), grid, dim3(256), 0, s, P)
+                if (P.act == ACT_RELU6) { if (P.stride == 1) DD_DW(1, ACT_RELU6); else DD_DW(2, ACT_RELU6); }
+                else if (P.act == ACT_SILU) { if (P.stride == 1) DD_DW(1, ACT_SILU); else DD_DW(2, ACT_SILU); }
+                else { if (P.stride == 1) DD_DW(1, -1); else DD_DW(2, -1); }
+#undef DD_DW
                 DD_LAUNCH_CHECK();
                 break;
             }
