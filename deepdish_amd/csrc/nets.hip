@@ -973,20 +973,18 @@ __global__ __launch_bounds__(256) void dwpw_k(const ConvP P) {
                 for (int i = 0; i < 4; ++i) { acc[j][i] = b0[i]; acc[j][4 + i] = b1[i]; }
         }
         const int ix0 = ox0 * STRIDE - P.pad_l;
+        const _Float16 *img = P.in + (size_t)n * P.H * P.W * P.cs_in + P.coff_in + g * 8;
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
             // out-of-image taps read a zero line instead of branching around the load: all 3 x NCOL loads
             // of the window are then independent and in flight together
             const int iy = oy * STRIDE - P.pad_t + kh;
-            const bool rok = qok && iy >= 0 && iy < P.H;
-            const _Float16 *row = P.in + ((size_t)(n * P.H + (rok ? iy : 0)) * P.W) * P.cs_in + P.coff_in + g * 8;
+            const bool rok = qok && (unsigned)iy < (unsigned)P.H;
+            const int roff = ((rok ? iy : 0) * P.W + ix0) * P.cs_in;   // 32-bit offset inside the image
             h8 x[NCOL];
 #pragma unroll
-            for (int cx = 0; cx < NCOL; ++cx) {
-                const int ix = ix0 + cx;
-                const _Float16 *src = (rok && ix >= 0 && ix < P.W) ? row + (size_t)ix * P.cs_in : P.zero;
-                x[cx] = *reinterpret_cast<const h8 *>(src);
-            }
+            for (int cx = 0; cx < NCOL; ++cx)
+                x[cx] = *reinterpret_cast<const h8 *>((rok && (unsigned)(ix0 + cx) < (unsigned)P.W) ? img + (roff + cx * P.cs_in) : P.zero);
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
                 const h8 w = *reinterpret_cast<const h8 *>(P.dw_w + (size_t)(kh * 3 + kw) * CIN + g * 8);
@@ -1102,17 +1100,16 @@ __global__ __launch_bounds__(256) void dwconv3_k(const DwP P) {
             for (int i = 0; i < 4; ++i) { acc[j][i] = b0[i]; acc[j][4 + i] = b1[i]; }
     }
     const int ix0 = ox0 * STRIDE - P.pad_l;
+    const _Float16 *img = P.in + (size_t)n * P.H * P.W * P.cs_in + P.coff_in + g * 8;
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
         const int iy = oy * STRIDE - P.pad_t + kh;
-        const bool rok = iy >= 0 && iy < P.H;                 // out-of-image taps read the zero line: no branches, all loads in flight
-        const _Float16 *row = P.in + ((size_t)(n * P.H + (rok ? iy : 0)) * P.W) * P.cs_in + P.coff_in + g * 8;
+        const bool rok = (unsigned)iy < (unsigned)P.H;        // out-of-image taps read the zero line: no branches, all loads in flight
+        const int roff = ((rok ? iy : 0) * P.W + ix0) * P.cs_in;     // 32-bit offset inside the image (64-bit index math per load doubled the address code)
         h8 x[NCOL];
 #pragma unroll
-        for (int cx = 0; cx < NCOL; ++cx) {
-            const int ix = ix0 + cx;
-            x[cx] = *reinterpret_cast<const h8 *>((rok && ix >= 0 && ix < P.W) ? row + (size_t)ix * P.cs_in : P.zero);
-        }
+        for (int cx = 0; cx < NCOL; ++cx)
+            x[cx] = *reinterpret_cast<const h8 *>((rok && (unsigned)(ix0 + cx) < (unsigned)P.W) ? img + (roff + cx * P.cs_in) : P.zero);
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
             const h8 w = *reinterpret_cast<const h8 *>(P.w + (size_t)(kh * 3 + kw) * P.c + g * 8);
