@@ -247,6 +247,62 @@ __global__ __launch_bounds__(256) void band_resample_k(const uint8_t *__restrict
     }
 }
 
+// Same product, 64 source rows per iteration in four 16-row MFMA tiles whose rows are interleaved (tile j takes
+// rows r0 + 16*(i/4) + 4*j + i%4): the lane that owns accumulator rows 4*fq.. of every tile then holds the sixteen
+// consecutive rows r0 + 16*fq .. +15 of its output column and writes them with one 16-byte store.  (With one tile
+// per iteration a lane wrote 4 bytes at a time and the fabric saw twice the algorithmic write bytes -- PMC.)
+// Needs R % 16 == 0 and pitch_o % 16 == 0: the horizontal pass.
+template <int KS>
+__global__ __launch_bounds__(256) void band_resample_wide_k(const uint8_t *__restrict__ src, size_t src_img_stride, int R,
+                                                            int pitch_s, const int *__restrict__ start,
+                                                            const i4v *__restrict__ coef, const int *__restrict__ bias,
+                                                            int n_groups, int C, uint8_t *__restrict__ outT,
+                                                            size_t out_img_stride, int pitch_o, int tiles_per_chunk) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = blockIdx.x * 4 + wave;
+    if (g >= n_groups) return;                                  // whole waves leave; the kernel has no barrier
+    const int fr = lane & 15, fq = lane >> 4;
+    i4v cf[KS][3];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) cf[ks][p] = coef[((size_t)(g * KS + ks) * 3 + p) * 64 + lane];
+    const int col = g * 16 + fr;
+    const int b = col < C ? bias[col] : 0;
+    const uint8_t *base = src + blockIdx.z * src_img_stride + start[g] + fq * 16;
+    uint8_t *obase = outT + blockIdx.z * out_img_stride + (size_t)col * pitch_o + fq * 16;
+    const int r_first = blockIdx.y * tiles_per_chunk * 64;      // tiles_per_chunk counts 64-row iterations here
+    const int row_in_tile = ((fr >> 2) << 4) + (fr & 3);        // + 4*j
+    for (int t = 0; t < tiles_per_chunk; ++t) {
+        const int r0 = r_first + t * 64;
+        if (r0 >= R) break;
+        uint32_t word[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint8_t *p = base + (size_t)min(r0 + row_in_tile + 4 * j, R - 1) * pitch_s;
+            i4v a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                i4v x = *reinterpret_cast<const i4v *>(p + ks * 64);
+                x ^= (int)0x80808080;                            // u8 -> i8: p - 128
+                a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, cf[ks][0], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, cf[ks][1], a1, 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, cf[ks][2], a2, 0, 0, 0);
+            }
+            uint32_t by[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int v = (int)((unsigned)a0[i] + ((unsigned)a1[i] << 8) + ((unsigned)a2[i] << 16) + (unsigned)b);
+                by[i] = (uint32_t)min(max(v >> PRECISION_BITS, 0), 255);
+            }
+            asm volatile("" : "+v"(by[0]), "+v"(by[1]), "+v"(by[2]), "+v"(by[3]));     // see lanczos_v4_k: keep v_ashr_pk_u8_i32 away
+            word[j] = by[0] | (by[1] << 8) | (by[2] << 16) | (by[3] << 24);              // rows r0 + 16*fq + 4*j .. +3
+        }
+        if (col < C && r0 + fq * 16 < R)
+            *reinterpret_cast<uint4 *>(obase + r0) = make_uint4(word[0], word[1], word[2], word[3]);
+    }
+}
+
 __global__ __launch_bounds__(256) void copy_rgb_k(const uint8_t *__restrict__ src, int n_px, int src_c, int swap_rb,
                                                   uint8_t *__restrict__ dst) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -439,11 +495,29 @@ int get_band(int device, int in_size, int out_size, int mode, int src_c, int swa
 
 int launch_band(hipStream_t s, const BandTable &b, const uint8_t *src, size_t src_img_stride, int R, int pitch_s, uint8_t *outT,
                 size_t out_img_stride, int pitch_o, int batch) {
+    const i4v *cf = static_cast<const i4v *>(b.coef);
+    static const bool no_wide = getenv("DD_LANCZOS_NO_WIDE") != nullptr;
+    if (!no_wide && R % 16 == 0 && pitch_o % 16 == 0 && (reinterpret_cast<uintptr_t>(outT) & 15) == 0 && out_img_stride % 16 == 0) {
+        const int tiles = dd_ceil_div(R, 64);                     // 64-row iterations, 16-byte stores
+        const int chunks = std::max(1, std::min(tiles, dd_ceil_div(8192, std::max(1, b.n_groups * batch))));
+        const int tpc = dd_ceil_div(tiles, chunks);
+        const dim3 grid((unsigned)dd_ceil_div(b.n_groups, 4), (unsigned)dd_ceil_div(tiles, tpc), (unsigned)batch);
+#define DD_BANDW(KS_) hipLaunchKernelGGL(band_resample_wide_k<KS_>, grid, dim3(256), 0, s, src, src_img_stride, R, pitch_s, b.start, cf, \
+                                         b.bias, b.n_groups, b.n_cols, outT, out_img_stride, pitch_o, tpc)
+        switch (b.ksteps) {
+            case 1: DD_BANDW(1); break;
+            case 2: DD_BANDW(2); break;
+            case 3: DD_BANDW(3); break;
+            default: DD_BANDW(4); break;
+        }
+#undef DD_BANDW
+        DD_LAUNCH_CHECK();
+        return DD_OK;
+    }
     const int tiles = dd_ceil_div(R, 16);
     const int chunks = std::max(1, std::min(tiles, dd_ceil_div(8192, std::max(1, b.n_groups * batch))));
     const int tpc = dd_ceil_div(tiles, chunks);
     const dim3 grid((unsigned)dd_ceil_div(b.n_groups, 4), (unsigned)dd_ceil_div(tiles, tpc), (unsigned)batch);
-    const i4v *cf = static_cast<const i4v *>(b.coef);
 #define DD_BAND(KS_) hipLaunchKernelGGL(band_resample_k<KS_>, grid, dim3(256), 0, s, src, src_img_stride, R, pitch_s, b.start, cf, b.bias, \
                                         b.n_groups, b.n_cols, outT, out_img_stride, pitch_o, tpc)
     switch (b.ksteps) {
