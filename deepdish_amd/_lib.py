@@ -54,6 +54,11 @@ SIGNATURES = {
     'dd_ingest_wait_uploaded': [P, c_int],
     'dd_ingest_acquire': [P, c_int, P, P],
     'dd_ingest_release': [P, c_int, P],
+    'dd_mog2_create': [P, c_int, c_int, c_int, c_int, c_double, c_int, POINTER(P)],
+    'dd_mog2_destroy': [P],
+    'dd_mog2_state': [P, c_int, P, P, P, P],
+    'dd_mog2_apply': [P, P, c_double, P, P, P],
+    'dd_mask_box_count': [P, P, c_int, c_int, c_int, P, P, c_int, P, P],
     'dd_net_create': [P, P, c_int, P, c_int64, c_int, POINTER(P)],
     'dd_net_destroy': [P],
     'dd_net_forward': [P, P, c_int, P],

@@ -173,6 +173,31 @@ int dd_ingest_submit(dd_ingest *g, int slot);
 int dd_ingest_acquire(dd_ingest *g, int slot, void *consumer_stream, const uint8_t **frames_dev);
 int dd_ingest_release(dd_ingest *g, int slot, void *consumer_stream);
 
+/* ---------------------------------------------------------------- background subtraction
+ * cv2.createBackgroundSubtractorMOG2(history, varThreshold, detectShadows) (deepdish.py:889) for n_streams
+ * independent streams of [height][width][3] u8 frames; every other parameter keeps OpenCV's default (5 modes,
+ * backgroundRatio 0.9, varThresholdGen 9, varInit 15, varMin 4, varMax 75, complexity reduction 0.05, shadow
+ * value 127, shadow threshold 0.5).  The model (101 bytes per pixel) lives in HBM inside the handle.
+ * dd_mog2_apply = backSub.apply(frame, learningRate) (deepdish.py:922) for all streams in one launch:
+ * frames device u8 [n_streams][H][W][3] -> mask device u8 [n_streams][H][W] (0 background, 127 shadow, 255
+ * foreground); learning_rate < 0 = OpenCV's automatic 1/min(2 nframes, history).  masked_frames (optional,
+ * device, same shape as frames) receives cv2.bitwise_and(frame, frame, mask=fgMask) (deepdish.py:924).
+ * Calls on one handle must be issued in frame order (the model update is sequential per stream). */
+typedef struct dd_mog2 dd_mog2;
+int dd_mog2_create(dd_ctx *ctx, int n_streams, int height, int width, int history, double var_threshold, int detect_shadows,
+                   dd_mog2 **out);
+int dd_mog2_destroy(dd_mog2 *m);
+int dd_mog2_apply(dd_mog2 *m, const uint8_t *frames, double learning_rate, uint8_t *mask, uint8_t *masked_frames, void *stream);
+/* Test aid: the model of one stream as host arrays -- weight, variance f32 [5][H*W], mean f32 [5][3][H*W]
+ * (zero past a pixel's mode count), nmodes u8 [H*W].  Synchronises. */
+int dd_mog2_state(dd_mog2 *m, int stream_index, float *weight_host, float *variance_host, float *mean_host, uint8_t *nmodes_host);
+/* np.count_nonzero(fgMask[y:y+h, x:x+w]) (deepdish.py:957) for n_boxes boxes: mask device u8
+ * [n_streams][height][width]; boxes_xywh_host int32 [n_boxes][4], already clipped to the frame as
+ * deepdish.py:951-952 does (anything else is DD_E_ARG); box_stream_host int32 [n_boxes]; counts_host int32
+ * [n_boxes].  Synchronises the stream. */
+int dd_mask_box_count(dd_ctx *ctx, const uint8_t *mask, int n_streams, int height, int width, const int *boxes_xywh_host,
+                      const int *box_stream_host, int n_boxes, int *counts_host, void *stream);
+
 /* ---------------------------------------------------------------- networks
  * Replaces tflite_runtime.Interpreter(model_path).invoke() at tools/ssd_mobilenet.py:35-38,102-109,
  * tools/yolov5.py:71-79,107-109 and tools/generate_detections.py:153-154,169-171.  A model is an op
