@@ -76,6 +76,8 @@ SIGNATURES = {
     'dd_pipeline_destroy': [P],
     'dd_pipeline_step': [P, P, P, P, P, P],
     'dd_pipeline_step2': [P, P, P, P, P, P, P],
+    'dd_pipeline_background_subtraction': [P, c_double, c_int],
+    'dd_pipeline_motion_mask': [P, P, c_int, POINTER(ctypes.c_longlong)],
     'dd_pipeline_counts': [P, P],
     'dd_pipeline_tracker': [P, c_int, POINTER(P)],
     'dd_pipeline_stage_seconds': [P, P, POINTER(ctypes.c_longlong)],

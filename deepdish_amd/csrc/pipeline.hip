@@ -14,7 +14,10 @@
 #include "common.h"
 
 struct dd_tracker;
+struct dd_mog2;
 namespace ddk {
+int mog2_apply(dd_mog2 *m, hipStream_t s, const uint8_t *frames, double learning_rate, uint8_t *mask, uint8_t *masked);
+int mask_box_count(hipStream_t s, const uint8_t *mask, int H, int W, const int *d_boxes, const int *d_box_stream, int K, int *d_counts);
 int tracker_group_create(dd_ctx *ctx, int n, double max_cos, double max_iou, int max_age, int n_init, int budget, int tcap,
                          int gcap, dd_tracker **out);
 int trackers_predict(dd_tracker **ts, int S);
@@ -155,6 +158,14 @@ struct dd_pipeline {
     hipStream_t det_stream = nullptr;
     hipEvent_t det_done = nullptr, main_mark = nullptr;
     const uint8_t *det_pending = nullptr;      // frames the queued detector run belongs to
+    // Background subtraction (deepdish.py:889,920-924,957; the reference's default, off in its benchmarks):
+    // MOG2 over every frame on the main stream, then only boxes with enough moving pixels reach NMS.
+    dd_mog2 *mog2 = nullptr;
+    double motion_ratio = -1.0;                // --background-subtraction-ratio; < 0 = disabled
+    bool bg_masking = false;                   // --enable-background-masking
+    DevBuf d_mask, d_masked, d_mbox;
+    PinBuf h_mbox;
+    long long motion_rejected = 0;
 };
 
 namespace {
@@ -201,6 +212,8 @@ int dd_tracker_read(dd_tracker *, int, int64_t *, double *, double *);
 int dd_net_forward(dd_net *, const uint8_t *, int, void *);
 int dd_net_output(dd_net *, int, void **, int *, int *, int *, int *, int *);
 int dd_net_read(dd_net *, int, int, void *, int, void *);
+int dd_mog2_create(dd_ctx *, int, int, int, int, double, int, dd_mog2 **);
+int dd_mog2_destroy(dd_mog2 *);
 
 int dd_pipeline_create(dd_ctx *ctx, int n_streams, int frame_h, int frame_w, dd_net *detector,
                        const float *anchors_host, int n_anchors, int n_classes, dd_net *encoder,
@@ -261,9 +274,43 @@ int dd_pipeline_destroy(dd_pipeline *p) {
     if (p->main_mark) (void)hipEventDestroy(p->main_mark);
     for (auto &s : p->st) dd_tracker_destroy(s.trk);
     (void)hipFree(p->d_anchors);
-    for (DevBuf *b : {&p->d_resized, &p->d_tmp, &p->d_post, &p->d_det, &p->d_fin, &p->d_nms, &p->d_crop, &p->d_patches, &p->d_feats}) b->release();
-    for (PinBuf *b : {&p->h_fin, &p->h_nms, &p->h_crop}) b->release();
+    dd_mog2_destroy(p->mog2);
+    for (DevBuf *b : {&p->d_resized, &p->d_tmp, &p->d_post, &p->d_det, &p->d_fin, &p->d_nms, &p->d_crop, &p->d_patches, &p->d_feats,
+                      &p->d_mask, &p->d_masked, &p->d_mbox}) b->release();
+    for (PinBuf *b : {&p->h_fin, &p->h_nms, &p->h_crop, &p->h_mbox}) b->release();
     delete p;
+    return DD_OK;
+}
+
+// deepdish.py:512,889: background subtraction on (ratio = --background-subtraction-ratio, default 0.25) or off
+// (ratio < 0 = --disable-background-subtraction).  Turning it on starts a fresh model; masking =
+// --enable-background-masking (the detector and the encoder then see cv2.bitwise_and(frame, frame, mask=fgMask)).
+int dd_pipeline_background_subtraction(dd_pipeline *p, double ratio, int masking) {
+    DD_REQUIRE(p && !(ratio > 1.0), DD_E_ARG, "dd_pipeline_background_subtraction: ratio must be <= 1 (negative = off)");
+    DD_HIP(hipStreamSynchronize(p->ctx->stream));
+    if (p->det_stream) DD_HIP(hipStreamSynchronize(p->det_stream));
+    p->det_pending = nullptr;                    // a detector run queued ahead is dropped: it may not match the new setting
+    dd_mog2_destroy(p->mog2);
+    p->mog2 = nullptr; p->motion_ratio = -1.0; p->bg_masking = false;
+    if (ratio < 0) return DD_OK;
+    int rc;
+    if ((rc = dd_mog2_create(p->ctx, p->S, p->H, p->W, 500, 16.0, 1, &p->mog2)) != DD_OK) return rc;
+    if ((rc = p->d_mask.reserve((size_t)p->S * p->H * p->W)) != DD_OK) return rc;
+    if (masking && (rc = p->d_masked.reserve((size_t)p->S * p->H * p->W * 3)) != DD_OK) return rc;
+    p->motion_ratio = ratio; p->bg_masking = masking != 0;
+    return DD_OK;
+}
+
+// Foreground mask of the last step, u8 [S][H][W], copied to dst (host or device memory); dst may be NULL to read
+// only the number of boxes the motion test has rejected so far.
+int dd_pipeline_motion_mask(dd_pipeline *p, uint8_t *dst, int dst_on_device, long long *rejected_host) {
+    DD_REQUIRE(p, DD_E_ARG, "dd_pipeline_motion_mask: NULL argument");
+    if (rejected_host) *rejected_host = p->motion_rejected;
+    if (!dst) return DD_OK;
+    DD_REQUIRE(p->mog2, DD_E_ARG, "dd_pipeline_motion_mask: background subtraction is off");
+    DD_HIP(hipMemcpyAsync(dst, p->d_mask.p, (size_t)p->S * p->H * p->W, dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                          p->ctx->stream));
+    DD_HIP(hipStreamSynchronize(p->ctx->stream));
     return DD_OK;
 }
 
@@ -339,14 +386,20 @@ int dd_pipeline_step(dd_pipeline *p, const uint8_t *frames, const double *inj_bo
     return dd_pipeline_step2(p, frames, nullptr, inj_boxes_host, inj_scores_host, inj_cls_host, inj_offsets_host);
 }
 
-int dd_pipeline_step2(dd_pipeline *p, const uint8_t *frames, const uint8_t *frames_next, const double *inj_boxes_host,
+int dd_pipeline_step2(dd_pipeline *p, const uint8_t *frames_in, const uint8_t *frames_next, const double *inj_boxes_host,
                       const double *inj_scores_host, const int *inj_cls_host, const int *inj_offsets_host) {
-    DD_REQUIRE(p && frames, DD_E_ARG, "dd_pipeline_step: NULL argument");
+    DD_REQUIRE(p && frames_in, DD_E_ARG, "dd_pipeline_step: NULL argument");
+    const uint8_t *frames = frames_in;
     hipStream_t s = p->ctx->stream;
     const int S = p->S;
     int rc;
     const double t0 = now_s();
     if ((rc = ddk::trackers_predict(p->trks.data(), S)) != DD_OK) return rc;            // deepdish.py:1028
+    if (p->mog2) {                                                                      // :920-924
+        if ((rc = ddk::mog2_apply(p->mog2, s, frames_in, -1.0, p->d_mask.as<uint8_t>(),
+                                  p->bg_masking ? p->d_masked.as<uint8_t>() : nullptr)) != DD_OK) return rc;
+        if (p->bg_masking) { frames = p->d_masked.as<uint8_t>(); frames_next = nullptr; p->det_pending = nullptr; }
+    }
 
     // ---------------- detector: resize -> forward -> post-process -> adaptor tail, all streams at once
     std::vector<std::vector<double>> boxes0(S);      // per stream: tlwh f64 rows
@@ -403,6 +456,36 @@ int dd_pipeline_step2(dd_pipeline *p, const uint8_t *frames, const uint8_t *fram
                 ic[z].push_back(cls0[z][i]);
             }
         off[z + 1] = off[z] + (int)is[z].size();
+    }
+    if (p->mog2 && off[S] > 0) {                                                        // :957 motion test on every candidate
+        const int K0 = off[S];
+        const size_t in_bytes = (size_t)K0 * 5 * sizeof(int), all_bytes = in_bytes + (size_t)K0 * sizeof(int);
+        if ((rc = p->h_mbox.reserve(all_bytes)) != DD_OK) return rc;
+        if ((rc = p->d_mbox.reserve(all_bytes)) != DD_OK) return rc;
+        int *hm = p->h_mbox.as<int>(), *dm = p->d_mbox.as<int>();
+        for (int z = 0; z < S; ++z)
+            for (size_t i = 0; i < is[z].size(); ++i) {
+                for (int q = 0; q < 4; ++q) hm[(size_t)(off[z] + i) * 4 + q] = (int)ib[z][i * 4 + q];
+                hm[(size_t)K0 * 4 + off[z] + i] = z;
+            }
+        DD_HIP(hipMemcpyAsync(dm, hm, in_bytes, hipMemcpyHostToDevice, s));
+        if ((rc = ddk::mask_box_count(s, p->d_mask.as<uint8_t>(), p->H, p->W, dm, dm + (size_t)K0 * 4, K0, dm + (size_t)K0 * 5)) != DD_OK) return rc;
+        DD_HIP(hipMemcpyAsync(hm + (size_t)K0 * 5, dm + (size_t)K0 * 5, (size_t)K0 * sizeof(int), hipMemcpyDeviceToHost, s));
+        DD_HIP(hipStreamSynchronize(s));                                                               // extra round trip
+        const int *cnt = hm + (size_t)K0 * 5;
+        std::vector<int> off0 = off;
+        for (int z = 0; z < S; ++z) {
+            size_t n = 0;
+            for (size_t i = 0; i < is[z].size(); ++i) {
+                const int64_t w = ib[z][i * 4 + 2], h = ib[z][i * 4 + 3];
+                if (!((double)cnt[off0[z] + i] >= p->motion_ratio * (double)w * (double)h)) { p->motion_rejected++; continue; }
+                for (int q = 0; q < 4; ++q) ib[z][n * 4 + q] = ib[z][i * 4 + q];
+                is[z][n] = is[z][i]; ic[z][n] = ic[z][i];
+                ++n;
+            }
+            ib[z].resize(n * 4); is[z].resize(n); ic[z].resize(n);
+            off[z + 1] = off[z] + (int)n;
+        }
     }
     const int K = off[S];
     std::vector<std::vector<int>> keep(S);

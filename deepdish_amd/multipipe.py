@@ -38,7 +38,8 @@ class MultiStreamPipeline:
     def __init__(self, n_streams, model='synthetic-ssd_mobilenet_v1', encoder_model='synthetic-mars-64x32x3',
                  labels=None, wanted_labels=('person',), input_size=(640, 480), line=None, max_cosine_distance=0.2,
                  nms_max_overlap=0.6, max_iou_distance=0.7, max_age=60, n_init=3, context=None, run_detector=True,
-                 encoder_max_batch=None, track_capacity=512, gallery_capacity=256):
+                 encoder_max_batch=None, track_capacity=512, gallery_capacity=256, background_subtraction_ratio=None,
+                 background_masking=False):
         self.ctx = context or default_context()
         self.S = int(n_streams)
         self.W, self.H = input_size
@@ -70,6 +71,21 @@ class MultiStreamPipeline:
                                        int(gallery_capacity), ctypes.byref(h)), 'dd_pipeline_create')
         self._h = h
         self._class_id = {name: i - 1 for i, name in enumerate(self.label_lines) if i > 0}
+        if background_subtraction_ratio is not None:
+            self.background_subtraction(background_subtraction_ratio, background_masking)
+
+    def background_subtraction(self, ratio, masking=False):
+        """deepdish.py:512,889,957: ratio = --background-subtraction-ratio (reference default 0.25); None or a negative
+        value = --disable-background-subtraction (how a pipeline starts, and how the reference's benchmarks run)."""
+        check(lib().dd_pipeline_background_subtraction(self._h, -1.0 if ratio is None else float(ratio), int(bool(masking))),
+              'dd_pipeline_background_subtraction')
+
+    def motion_mask(self, read=True):
+        """-> (fgMask of the last step as ndarray u8 [S, H, W], boxes rejected by the motion test so far)."""
+        n = ctypes.c_longlong()
+        out = np.zeros((self.S, self.H, self.W), dtype=np.uint8) if read else None
+        check(lib().dd_pipeline_motion_mask(self._h, ptr(out), 0, ctypes.byref(n)), 'dd_pipeline_motion_mask')
+        return out, n.value
 
     def __del__(self):
         try:

@@ -9,7 +9,9 @@ Flag names follow deepdish.py:1355-1506 for the parameters that touch the hot pa
 import os
 from time import time
 import numpy as np
+import torch
 
+from .background import createBackgroundSubtractorMOG2, motion_filter
 from .deep_sort import nn_matching, preprocessing
 from .deep_sort.detection import Detection
 from .deep_sort.tracker import Tracker
@@ -42,8 +44,9 @@ def make_detector(model, labels=None, wanted_labels=('person',), num_threads=4, 
     raise ValueError('Unsure what to do with model file {}'.format(model))
 
 
-def clean_boxes(boxes0, labels0, scores0, max_x, max_y):
-    """deepdish.py:940-960 with background subtraction disabled (--disable-background-subtraction)."""
+def clean_boxes(boxes0, labels0, scores0, max_x, max_y, motion=None):
+    """deepdish.py:940-960.  motion = None (--disable-background-subtraction) or (subtractor, ratio): a
+    background.BackgroundSubtractorMOG2 that has seen this frame, and --background-subtraction-ratio (:957)."""
     boxes, labels, scores = [], [], []
     if len(boxes0) and np.any(np.isnan(np.asarray(boxes0, dtype=np.float64))):
         return boxes, labels, scores                      # :947 drops every box of the frame
@@ -53,6 +56,10 @@ def clean_boxes(boxes0, labels0, scores0, max_x, max_y):
         if w * h > 0.9 * max_x * max_y:
             continue
         boxes.append((x, y, w, h)); labels.append(lbl); scores.append(scr)
+    if motion is not None and boxes:
+        sub, ratio = motion
+        ok = motion_filter(sub.box_counts(boxes), boxes, ratio)
+        boxes, labels, scores = ([v for v, k in zip(seq, ok) if k] for seq in (boxes, labels, scores))
     return boxes, labels, scores
 
 
@@ -62,9 +69,16 @@ class HotPath:
     def __init__(self, model='synthetic-ssd_mobilenet_v1', encoder_model='synthetic-mars-64x32x3', labels=None,
                  wanted_labels=('person',), input_size=(640, 480), line=None, max_cosine_distance=0.2,
                  nms_max_overlap=0.6, max_iou_distance=0.7, max_age=60, encoder_batch_size=32, num_threads=4,
-                 context=None, run_detector=True):
+                 context=None, run_detector=True, disable_background_subtraction=True, background_subtraction_ratio=0.25,
+                 enable_background_masking=False):
         self.ctx = context or default_context()
         self.input_size = tuple(input_size)
+        # deepdish.py:512,889: the reference defaults to background subtraction ON; its benchmarks (and this class)
+        # run with --disable-background-subtraction unless asked otherwise
+        self.background_subtraction = not disable_background_subtraction
+        self.background_subtraction_ratio = background_subtraction_ratio
+        self.enable_background_masking = enable_background_masking
+        self.backSub = createBackgroundSubtractorMOG2(context=self.ctx) if self.background_subtraction else None
         self.wanted_labels = list(wanted_labels)
         self.nms_max_overlap = nms_max_overlap
         self.object_detector = make_detector(model, labels, wanted_labels, num_threads, self.ctx) if run_detector else None
@@ -85,13 +99,19 @@ class HotPath:
         detections, since random weights detect nothing meaningful."""
         H, W = int(frame_dev.shape[0]), int(frame_dev.shape[1])
         t0 = time()
+        if self.background_subtraction:                                                           # :920-924
+            masked = torch.empty_like(frame_dev) if self.enable_background_masking else None
+            self.backSub.apply_device(frame_dev[None], masked_out=masked[None] if masked is not None else None)
+            if masked is not None:
+                frame_dev = masked
         if self.object_detector is not None:
             boxes0, labels0, scores0 = self.object_detector.detect_frame_device(frame_dev, H, W)   # :883
         else:
             boxes0, labels0, scores0 = [], [], []
         if injected is not None:
             boxes0, labels0, scores0 = injected
-        boxes, labels, scores = clean_boxes(boxes0, labels0, scores0, self.input_size[0], self.input_size[1])
+        boxes, labels, scores = clean_boxes(boxes0, labels0, scores0, self.input_size[0], self.input_size[1],
+                                            (self.backSub, self.background_subtraction_ratio) if self.background_subtraction else None)
         t1 = time()
         boxesA0, scoresA0 = np.array(boxes), np.array(scores)
         indices = preprocessing.non_max_suppression(boxesA0, self.nms_max_overlap, scoresA0, context=self.ctx)   # :995

@@ -262,6 +262,15 @@ int dd_pipeline_step(dd_pipeline *p, const uint8_t *frames, const double *inj_bo
 int dd_pipeline_step2(dd_pipeline *p, const uint8_t *frames, const uint8_t *frames_next, const double *inj_boxes_host,
                       const double *inj_scores_host, const int *inj_cls_host, const int *inj_offsets_host);
 /* counts_host: int64 [n_streams][n_wanted][4] = poscount, negcount, intcount, delcount */
+/* Background subtraction for every stream of the pipeline (deepdish.py:512,889,920-924,957): ratio =
+ * --background-subtraction-ratio (reference default 0.25), ratio < 0 = --disable-background-subtraction (the state
+ * a new pipeline starts in, as the reference's benchmarks run); masking = --enable-background-masking.  Each
+ * step then updates the MOG2 model with the step's frames and drops detector boxes with fewer than
+ * ratio * w * h moving pixels before NMS.  (Re-)enabling starts a fresh model. */
+int dd_pipeline_background_subtraction(dd_pipeline *p, double ratio, int masking);
+/* Foreground mask of the last step, u8 [n_streams][H][W], copied to dst (host, or device when dst_on_device);
+ * dst may be NULL to read only the number of boxes the motion test has rejected so far. */
+int dd_pipeline_motion_mask(dd_pipeline *p, uint8_t *dst, int dst_on_device, long long *rejected_host);
 int dd_pipeline_counts(dd_pipeline *p, int64_t *counts_host);
 int dd_pipeline_tracker(dd_pipeline *p, int stream, dd_tracker **out);
 /* accumulated host wall time per stage (objd, nms, feat, trak as in deepdish.py's TimingInfo labels) */
