@@ -45,6 +45,10 @@ def parse():
     ap.add_argument('--ingest-host', action='store_true',
                     help='secondary figure (never the headline value): frames start in pinned host memory and cross PCIe '
                          'inside the timed region through the ingest ring (deepdish_amd/ingest.py), one step ahead of the compute')
+    ap.add_argument('--background-subtraction', type=float, default=None, metavar='RATIO',
+                    help='secondary figure (never the headline value): run with the reference\'s default background subtraction '
+                         '(MOG2 on every frame + motion test on the detector boxes, deepdish.py:920-924,957; the reference uses '
+                         'RATIO 0.25).  BASELINE.json\'s configurations run with --disable-background-subtraction')
     ap.add_argument('--cpu-frames', type=int, default=300)
     return ap.parse_args()
 
@@ -164,7 +168,8 @@ def main():
     G = max(1, min(args.groups, args.streams))
     bounds = [round(g * args.streams / G) for g in range(G + 1)]
     ctxs = [Context(local_rank) for _ in range(G)]
-    pipes = [MultiStreamPipeline(bounds[g + 1] - bounds[g], context=ctxs[g]) for g in range(G)]
+    pipes = [MultiStreamPipeline(bounds[g + 1] - bounds[g], context=ctxs[g], background_subtraction_ratio=args.background_subtraction)
+             for g in range(G)]
     group_of = [g for g in range(G) for _ in range(bounds[g], bounds[g + 1])]
     ings = dev_frames = None
     if args.ingest_host:
@@ -248,6 +253,15 @@ def main():
             'counts_pos_neg_int_del': [int(v) for v in counts.cpu().numpy().reshape(-1)],
             'stage_ms_per_step': {k: round(v, 4) for k, v in stage_ms.items() if k != 'steps'},
         }
+        if args.background_subtraction is not None:
+            out['background_subtraction'] = {'ratio': args.background_subtraction,
+                                             'boxes_rejected_by_motion_test': int(sum(p.motion_mask(read=False)[1] for p in pipes)),
+                                             'note': 'reference default configuration; not the headline (BASELINE configs disable it)'}
+            if ings is None:
+                os.write(real_stdout, (json.dumps(out) + '\n').encode())
+                if dist_on:
+                    dist.barrier(); dist.destroy_process_group()
+                return
         if ings is not None:
             out['frames_start_in'] = 'pinned host memory (PCIe upload inside the timed region; not the headline configuration)'
             os.write(real_stdout, (json.dumps(out) + '\n').encode())

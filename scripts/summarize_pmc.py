@@ -9,7 +9,7 @@ fetch_dir, write_dir, out = sys.argv[1:4]
 
 def load(d):
     acc = collections.defaultdict(lambda: [0, 0.0])
-    for r in csv.DictReader(open(sorted(glob.glob(d + '/*/*counter_collection.csv'), key=os.path.getmtime)[-1])):
+    for r in csv.DictReader(open(sorted(glob.glob(d + '/*/*counter_collection.csv') + glob.glob(d + '/*counter_collection.csv'), key=os.path.getmtime)[-1])):
         a = acc[r['Kernel_Name']]
         a[0] += 1
         a[1] += float(r['Counter_Value'])
