@@ -18,6 +18,7 @@ from .deep_sort.tracker import Tracker
 from .tools import generate_detections as gdet
 from .tools.countline import CountLine
 from .runtime import default_context
+from .wire import ResultSink
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LABELS = os.path.join(HERE, 'assets', 'coco_labels_ssd.txt')
@@ -70,7 +71,8 @@ class HotPath:
                  wanted_labels=('person',), input_size=(640, 480), line=None, max_cosine_distance=0.2,
                  nms_max_overlap=0.6, max_iou_distance=0.7, max_age=60, encoder_batch_size=32, num_threads=4,
                  context=None, run_detector=True, disable_background_subtraction=True, background_subtraction_ratio=0.25,
-                 enable_background_masking=False):
+                 enable_background_masking=False, log=None, restore_from_log=False, mqtt_publish=None, mqtt_topic='default/topic',
+                 mqtt_acp_id=None, mqtt_verbosity=1, cpu_temp=None):
         self.ctx = context or default_context()
         self.input_size = tuple(input_size)
         # deepdish.py:512,889: the reference defaults to background subtraction ON; its benchmarks (and this class)
@@ -92,8 +94,15 @@ class HotPath:
         self.counter = CountLine(np.asarray(line, dtype=float), self.wanted_labels)
         self.frame_count = 0
         self.timings = {}
+        # result packaging (deepdish.py:545-561,1147-1185): MQTT payloads through the host's publish(topic, json) and
+        # the JSON-lines log the counters can be restored from
+        self.sink = None
+        if log is not None or mqtt_publish is not None:
+            self.sink = ResultSink(self.counter, acp_id=mqtt_acp_id, topic=mqtt_topic, publish=mqtt_publish,
+                                   mqtt_verbosity=mqtt_verbosity, log=log, restore_from_log=restore_from_log, temp=cpu_temp)
+            self.frame_count = self.sink.frame_count
 
-    def step(self, frame_dev, injected=None):
+    def step(self, frame_dev, injected=None, t_frame=None):
         """frame_dev: u8 [H, W, 3] BGR torch tensor in HBM.  injected = (boxes tlwh, labels, scores)
         replaces the detector's OUTPUT (the detector still runs) -- how bench.py feeds synthetic
         detections, since random weights detect nothing meaningful."""
@@ -130,6 +139,8 @@ class HotPath:
         events = self.counter.step(self.tracker)                                                         # :1035-1114
         t4 = time()
         self.frame_count += 1
+        if self.sink is not None:
+            self.sink.crossings(events, t0 if t_frame is None else t_frame, self.frame_count)            # :1116-1123
         self.timings = dict(objd=t1 - t0, feat=t2 - t1, trak=t3 - t2, proc=t4 - t3, e2e=t4 - t0)
         return events
 

@@ -358,3 +358,30 @@ def test_detector_lookahead_gives_the_same_results():
         seen += len(res[0][0][z][0])
     np.testing.assert_array_equal(res[0][1], res[1][1])
     assert seen > 0
+
+
+def test_host_path_reports_crossings_and_resumes_from_its_log(tmp_path):
+    """deepdish.py:1116-1123,1147-1166,545-561: one MQTT message + one log line per crossing, carrying the counters
+    after the update; --restore-from-log brings counters and frame count back."""
+    import json
+    from deepdish_amd.pipeline import HotPath
+    from deepdish_amd.synth import Scene
+    sc = Scene(seed=11, n_obj=12, n_frames=60)
+    path = str(tmp_path / 'dd.log')
+    sent = []
+    hp = HotPath(run_detector=False, log=path, mqtt_publish=lambda topic, msg: sent.append(json.loads(msg)), mqtt_acp_id='dd-test')
+    for f in range(60):
+        boxes, scores, _, _ = sc.detections(f)
+        inj = ([tuple(int(v) for v in b) for b in boxes], ['person'] * len(boxes), [float(s) for s in scores])
+        hp.step(torch.from_numpy(sc.frame(f)).cuda(), injected=inj, t_frame=1000.0 + f / 25)
+    pos, neg, tot, dele = hp.counts()[0]
+    assert tot > 0 and len(sent) == tot
+    assert [m['acp_event_value'] for m in sent].count('pos') == pos and [m['acp_event_value'] for m in sent].count('neg') == neg
+    assert [m['intcount_person'] for m in sent] == sorted(m['intcount_person'] for m in sent)      # counters only grow
+    assert (sent[-1]['poscount_person'], sent[-1]['negcount_person'], sent[-1]['diff_person']) == (pos, neg, pos - neg)
+    lines = [json.loads(l) for l in open(path)]
+    assert len(lines) == tot and lines[-1]['intcount_person'] == tot and 1 <= lines[-1]['frame_count'] <= 60
+    hp.sink.heartbeat(now=2000.0)
+    hp2 = HotPath(run_detector=False, log=path, restore_from_log=True)
+    np.testing.assert_array_equal(hp2.counts(), hp.counts())
+    assert hp2.frame_count == 60
