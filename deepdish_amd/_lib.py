@@ -41,6 +41,9 @@ SIGNATURES = {
     'dd_tracker_update': [P, P, P, c_int, c_int],
     'dd_tracker_count': [P, c_int, POINTER(c_int)],
     'dd_tracker_read': [P, c_int, P, P, P],
+    'dd_tracker_track_update': [P, c_int64, P, P, c_int],
+    'dd_tracker_track_set': [P, c_int64, c_int, c_int],
+    'dd_tracker_remove': [P, P, c_int],
     'dd_tracker_next_id': [P, POINTER(c_int64)],
     'dd_tracker_last_matches': [P, P, c_int, POINTER(c_int)],
     'dd_crop_resize': [P, P, c_int, c_int, P, c_int, c_int, c_int, P, P, P],

@@ -563,6 +563,82 @@ int dd_tracker_read(dd_tracker *t, int which, int64_t *ints6_host, double *means
     return DD_OK;
 }
 
+// ---- per-track calls the host makes outside Tracker.update (deepdish/framerecords.py:133-165 upstream)
+namespace {
+int find_live(const dd_tracker *t, int64_t id) {
+    for (size_t i = 0; i < t->tracks.size(); ++i) if (t->tracks[i].id == id) return (int)i;
+    return -1;
+}
+}  // namespace
+
+// Track.update(kf, detection) (track.py:127-152) for ONE live track: Kalman update with the detection's box, feature
+// appended to the track's gallery, hits += 1, time_since_update = 0, Tentative -> Confirmed once hits >= n_init.
+// The mirrored mean of the track is refreshed.  feat: 128 f32 (host or device), normalised here like every feature.
+int dd_tracker_track_update(dd_tracker *t, int64_t track_id, const double *tlwh_host, const float *feat, int feat_on_device) {
+    DD_REQUIRE(t && tlwh_host && feat, DD_E_ARG, "dd_tracker_track_update: NULL argument");
+    const int i = find_live(t, track_id);
+    DD_REQUIRE(i >= 0, DD_E_ARG, "dd_tracker_track_update: no live track with id %lld", (long long)track_id);
+    DD_REQUIRE(t->live_means.size() == t->tracks.size() * 8, DD_E_STATE, "dd_tracker_track_update: call update() first");
+    TrackerPool *p = t->pool;
+    hipStream_t s = p->ctx->stream;
+    TrackRec &tr = t->tracks[i];
+    int rc;
+    // staging: [tlwh f64 x4][pairs int x3][mean f64 x8 out] | raw feature | normalised feature
+    if ((rc = p->h_in.reserve(256)) != DD_OK) return rc;
+    if ((rc = p->d_in.reserve(256)) != DD_OK) return rc;
+    if ((rc = p->d_feats_raw.reserve(128 * sizeof(float))) != DD_OK) return rc;
+    if ((rc = p->d_feats_n.reserve(128 * sizeof(float))) != DD_OK) return rc;
+    if ((rc = p->d_gather.reserve(sizeof(int) + 8 * sizeof(double))) != DD_OK) return rc;
+    if ((rc = p->h_gather.reserve(sizeof(int) + 8 * sizeof(double))) != DD_OK) return rc;
+    char *h = p->h_in.as<char>(), *d = p->d_in.as<char>();
+    memcpy(h, tlwh_host, 4 * sizeof(double));
+    int *hp = reinterpret_cast<int *>(h + 32);
+    const int cap_eff = t->budget > 0 ? std::min(t->budget, p->gcap) : p->gcap;
+    hp[0] = tr.slot; hp[1] = 0; hp[2] = cap_eff;
+    DD_HIP(hipMemcpyAsync(d, h, 32 + 3 * sizeof(int), hipMemcpyHostToDevice, s));
+    DD_HIP(hipMemcpyAsync(p->d_feats_raw.p, feat, 128 * sizeof(float), feat_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    if ((rc = ddk::normalize_rows(s, p->d_feats_raw.as<float>(), p->d_feats_n.as<float>(), 1)) != DD_OK) return rc;
+    const int *dp = reinterpret_cast<const int *>(d + 32);
+    hipLaunchKernelGGL(tracker_apply_k, dim3(1), dim3(256), 0, s, p->d_means, p->d_covs, p->d_gallery, p->gcap, p->d_gal_count,
+                       p->d_gal_total, dp, dp + 1, dp + 2, 1, 0, reinterpret_cast<const double *>(d), p->d_feats_n.as<float>());
+    DD_LAUNCH_CHECK();
+    double *dg = p->d_gather.as<double>();
+    if ((rc = ddk::gather_state(s, p->d_means, p->d_covs, dp, 1, dg, nullptr)) != DD_OK) return rc;
+    DD_HIP(hipMemcpyAsync(p->h_gather.p, dg, 8 * sizeof(double), hipMemcpyDeviceToHost, s));
+    DD_HIP(hipStreamSynchronize(s));
+    memcpy(t->live_means.data() + (size_t)i * 8, p->h_gather.p, 8 * sizeof(double));
+    tr.hits += 1;
+    tr.tsu = 0;
+    if (tr.state == TENTATIVE && tr.hits >= t->n_init) tr.state = CONFIRMED;
+    return DD_OK;
+}
+
+// Host assignment to track.state / track.time_since_update (framerecords.py:160-161).  state: 1 Tentative, 2 Confirmed
+// (a track is deleted with dd_tracker_remove); time_since_update < 0 leaves it unchanged.
+int dd_tracker_track_set(dd_tracker *t, int64_t track_id, int state, int time_since_update) {
+    DD_REQUIRE(t && (state == TENTATIVE || state == CONFIRMED), DD_E_ARG, "dd_tracker_track_set: state must be 1 or 2");
+    const int i = find_live(t, track_id);
+    DD_REQUIRE(i >= 0, DD_E_ARG, "dd_tracker_track_set: no live track with id %lld", (long long)track_id);
+    t->tracks[i].state = state;
+    if (time_since_update >= 0) t->tracks[i].tsu = time_since_update;
+    return DD_OK;
+}
+
+// The host dropped tracks from tracker.tracks (deepdish.py:1047 assigns framerecords.process_tracking's list): they
+// leave the live set at once, their state slots are recycled at the next predict(); unknown ids are an error.
+int dd_tracker_remove(dd_tracker *t, const int64_t *track_ids_host, int n) {
+    DD_REQUIRE(t && n >= 0 && (n == 0 || track_ids_host), DD_E_ARG, "dd_tracker_remove: bad argument");
+    const bool have_means = t->live_means.size() == t->tracks.size() * 8;
+    for (int k = 0; k < n; ++k) {
+        const int i = find_live(t, track_ids_host[k]);
+        DD_REQUIRE(i >= 0, DD_E_ARG, "dd_tracker_remove: no live track with id %lld", (long long)track_ids_host[k]);
+        t->pending_free.push_back(t->tracks[i].slot);
+        t->tracks.erase(t->tracks.begin() + i);
+        if (have_means) t->live_means.erase(t->live_means.begin() + (size_t)i * 8, t->live_means.begin() + (size_t)(i + 1) * 8);
+    }
+    return DD_OK;
+}
+
 int dd_tracker_next_id(dd_tracker *t, int64_t *out_host) {
     DD_REQUIRE(t && out_host, DD_E_ARG, "dd_tracker_next_id: NULL argument");
     *out_host = t->next_id;

@@ -28,6 +28,7 @@ class Track:
         self.detections = [detection]
         self._n_init = n_init
         self._max_age = max_age
+        self._synced = _owner is not None          # from here on, assignments to state / time_since_update reach the device
 
     @property
     def covariance(self):
@@ -61,10 +62,30 @@ class Track:
         raise NotImplementedError('per-track predict is batched on the device: call Tracker.predict()')
 
     def update(self, kf, detection):
-        raise NotImplementedError('per-track update is batched on the device: call Tracker.update()')
+        """track.py:127-152 for this one track, outside Tracker.update (framerecords.py:158 calls it to extend a track
+        from an annotation): Kalman update + gallery append on the device (dd_tracker_track_update), label vote here."""
+        if self._owner is None:
+            raise RuntimeError('this track is not attached to a device tracker')
+        self._owner._track_update(self, detection)
 
     def mark_missed(self):
-        raise NotImplementedError('track management runs inside Tracker.update()')
+        """track.py:190-196.  A track that becomes Deleted leaves the device tracker at once (upstream it lingers in
+        tracker.tracks until the end of the next update, where nothing can match it any more)."""
+        if self.state == TrackState.Tentative or self.time_since_update > self._max_age:
+            self.state = TrackState.Deleted
+            if self._owner is not None:
+                self._owner._drop([self])
+
+    def _mirror(self, **fields):
+        """The tracker copying device-side book-keeping into this view: no write-back."""
+        for k, v in fields.items():
+            object.__setattr__(self, k, v)
+
+    def __setattr__(self, name, value):
+        # the host may assign state / time_since_update (framerecords.py:160-161): keep the device tracker's copy in step
+        object.__setattr__(self, name, value)
+        if name in ('state', 'time_since_update') and getattr(self, '_synced', False) and self._owner is not None:
+            self._owner._track_set(self)
 
     def get_label(self, return_confidence=False):
         if not self.labels:

@@ -19,7 +19,7 @@ class Tracker:
         self.n_init = n_init
         self.ctx = context or default_context()
         self.kf = kalman_filter.KalmanFilter(self.ctx)
-        self.tracks = []
+        self._tracks = []
         self.deleted_tracks = []
         self._by_id = {}
         budget = metric.budget if getattr(metric, 'budget', None) else 0
@@ -38,6 +38,48 @@ class Tracker:
             pass
 
     @property
+    def tracks(self):
+        return self._tracks
+
+    @tracks.setter
+    def tracks(self, new_tracks):
+        """deepdish.py:1047 assigns the list framerecords.process_tracking returns: live tracks that are no longer
+        in it leave the device tracker too."""
+        new_tracks = list(new_tracks)
+        unknown = [getattr(t, 'track_id', None) for t in new_tracks if self._by_id.get(getattr(t, 'track_id', None)) is not t]
+        if unknown:
+            raise ValueError('tracker.tracks may only be reduced or reordered; unknown tracks %r' % unknown)
+        keep = {id(t) for t in new_tracks}
+        self._drop([t for t in self._tracks if id(t) not in keep], relist=False)
+        self._tracks = new_tracks
+
+    def _drop(self, tracks, relist=True):
+        if not tracks:
+            return
+        ids = np.array([t.track_id for t in tracks], dtype=np.int64)
+        check(lib().dd_tracker_remove(self._h, ptr(ids), len(ids)), 'dd_tracker_remove')
+        for t in tracks:
+            self._by_id.pop(t.track_id, None)
+        if relist:
+            gone = {id(t) for t in tracks}
+            self._tracks = [t for t in self._tracks if id(t) not in gone]
+
+    def _track_update(self, trk, detection):
+        tlwh = np.ascontiguousarray(detection.tlwh, dtype=np.float64).reshape(4)
+        feat = np.ascontiguousarray(detection.feature, dtype=np.float32).reshape(128)
+        check(lib().dd_tracker_track_update(self._h, int(trk.track_id), ptr(tlwh), ptr(feat), 0), 'dd_tracker_track_update')
+        ints, means = self._read(0)
+        row = {int(r[0]): (r, m) for r, m in zip(ints, means)}[trk.track_id]
+        trk._note_update(detection)
+        trk._mirror(mean=row[1].copy(), _covariance=None, state=int(row[0][1]), time_since_update=int(row[0][2]),
+                    hits=int(row[0][3]))
+
+    def _track_set(self, trk):
+        if trk.state in (1, 2) and self._by_id.get(trk.track_id) is trk:
+            check(lib().dd_tracker_track_set(self._h, int(trk.track_id), int(trk.state), int(trk.time_since_update)),
+                  'dd_tracker_track_set')
+
+    @property
     def _next_id(self):
         v = ctypes.c_int64()
         check(lib().dd_tracker_next_id(self._h, ctypes.byref(v)), 'dd_tracker_next_id')
@@ -45,10 +87,8 @@ class Tracker:
 
     def predict(self):
         check(lib().dd_tracker_predict(self._h), 'dd_tracker_predict')
-        for t in self.tracks:                       # host mirror of track.py:124-125
-            t.age += 1
-            t.time_since_update += 1
-            t._covariance = None
+        for t in self._tracks:                      # host mirror of track.py:124-125
+            t._mirror(age=t.age + 1, time_since_update=t.time_since_update + 1, _covariance=None)
 
     def update(self, detections):
         n = len(detections)
@@ -88,21 +128,20 @@ class Tracker:
                     trk = Track(m.copy(), None, tid, self.n_init, self.max_age, det or _NO_DET, _owner=self)
                 elif det is not None:
                     trk._note_update(det)
-                trk.mean, trk._covariance = m.copy(), None
-                trk.state, trk.time_since_update, trk.hits, trk.age = state, tsu, hits, age
+                trk._mirror(mean=m.copy(), _covariance=None, state=state, time_since_update=tsu, hits=hits, age=age)
                 if which == 0:
                     by_id[tid] = trk
                 out[which].append(trk)
         self._by_id = by_id
-        self.tracks, self.deleted_tracks = out
+        self._tracks, self.deleted_tracks = out
 
     def _fill_covariances(self):
-        n = len(self.tracks)
+        n = len(self._tracks)
         if n == 0:
             return
         covs = np.zeros((n, 64), dtype=np.float64)
         check(lib().dd_tracker_read(self._h, 0, None, None, ptr(covs)), 'dd_tracker_read')
-        for t, c in zip(self.tracks, covs):
+        for t, c in zip(self._tracks, covs):
             t._covariance = c.reshape(8, 8).copy()
 
 

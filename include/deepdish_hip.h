@@ -127,6 +127,15 @@ int dd_tracker_count(dd_tracker *trk, int which, int *out_n_host);
  * means[n][8], covs[n][64]. */
 int dd_tracker_read(dd_tracker *trk, int which, int64_t *ints6_host, double *means_host,
                     double *covs_host);
+/* Per-track calls the host makes between two updates (deepdish/framerecords.py:133-165 via deepdish.py:1047):
+ * dd_tracker_track_update = Track.update(kf, detection) (deep_sort/track.py:127-152) for one live track -- Kalman
+ * update with the box, feature (128 f32, host or device) appended to the track's gallery, hits += 1,
+ * time_since_update = 0, Tentative -> Confirmed at n_init hits; the mirrored mean is refreshed (synchronises).
+ * dd_tracker_track_set = host assignment to track.state (1 Tentative, 2 Confirmed) and track.time_since_update
+ * (< 0: unchanged).  dd_tracker_remove = the host reassigned tracker.tracks without these ids. */
+int dd_tracker_track_update(dd_tracker *t, int64_t track_id, const double *tlwh_host, const float *feat, int feat_on_device);
+int dd_tracker_track_set(dd_tracker *t, int64_t track_id, int state, int time_since_update);
+int dd_tracker_remove(dd_tracker *t, const int64_t *track_ids_host, int n);
 int dd_tracker_next_id(dd_tracker *trk, int64_t *out_host);
 /* Rows of tracker.tracks reassigned by the host (deepdish.py:1047) are not supported: the
  * identity pass-through of framerecords.py:183 is the only behaviour reproduced. */
