@@ -47,6 +47,7 @@ SIGNATURES = {
     'dd_tracker_next_id': [P, POINTER(c_int64)],
     'dd_tracker_last_matches': [P, P, c_int, POINTER(c_int)],
     'dd_crop_resize': [P, P, c_int, c_int, P, c_int, c_int, c_int, P, P, P],
+    'dd_crop_resize_f64': [P, P, c_int, c_int, P, c_int, c_int, c_int, P, P, P],
     'dd_fake_encode': [P, P, c_int, c_int, P, P],
     'dd_resize_lanczos': [P, P, c_int, c_int, c_int, c_int, P, c_int, c_int, P],
     'dd_resize_bilinear': [P, P, c_int, c_int, c_int, P, c_int, c_int, P],

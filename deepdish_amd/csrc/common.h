@@ -107,6 +107,7 @@ int nms_batched_small(hipStream_t s, const double *boxes, const double *keys, co
                       double thr, int mode, int *out_idx, int *out_n);
 // tracker fused kernels
 int crop_box_host(const int64_t *b, int ph, int pw, int H, int W, int *sx, int *sy, int *cw, int *ch);
+int crop_box_host_f64(const double *b, int ph, int pw, int H, int W, int *sx, int *sy, int *cw, int *ch);
 // d_boxes: device array of {sx, sy, cw, ch, frame, 0, 0, 0} int32 records
 int crop_resize(hipStream_t s, const uint8_t *frames, int H, int W, const void *d_boxes, int n, int oh, int ow, uint8_t *out);
 int resize_lanczos(hipStream_t s, int device, const uint8_t *src, int H, int W, int src_c, int swap_rb, uint8_t *dst,

@@ -553,6 +553,25 @@ int crop_box_host(const int64_t *b, int ph, int pw, int H, int W, int *sx, int *
     return 1;
 }
 
+// The same statements on a float box (generate_detections.py:64-74 when bbox is a float array, e.g. a CVAT annotation
+// fed through framerecords.process_boxes): all arithmetic in f64, one truncation by astype(int) at the end.
+int crop_box_host_f64(const double *b, int ph, int pw, int H, int W, int *sx, int *sy, int *cw, int *ch) {
+    double x = b[0], y = b[1], w = b[2], h = b[3];
+    const double new_width = (double)pw / ph * h;
+    x -= (new_width - w) / 2;
+    w = new_width;
+    const double xe = x + w, ye = y + h;
+    if (!(fabs(x) < 9e15 && fabs(y) < 9e15 && fabs(xe) < 9e15 && fabs(ye) < 9e15)) { *sx = *sy = 0; *cw = *ch = 0; return 0; }
+    int64_t x1 = (int64_t)x, y1 = (int64_t)y, x2 = (int64_t)xe, y2 = (int64_t)ye;
+    if (x1 < 0) x1 = 0;
+    if (y1 < 0) y1 = 0;
+    if (x2 > W - 1) x2 = W - 1;
+    if (y2 > H - 1) y2 = H - 1;
+    if (x1 >= x2 || y1 >= y2) { *sx = *sy = 0; *cw = *ch = 0; return 0; }
+    *sx = (int)x1; *sy = (int)y1; *cw = (int)(x2 - x1); *ch = (int)(y2 - y1);
+    return 1;
+}
+
 int crop_resize(hipStream_t s, const uint8_t *frames, int H, int W, const void *d_boxes, int n, int oh, int ow,
                 uint8_t *out) {
     if (n <= 0) return DD_OK;
@@ -641,6 +660,27 @@ int dd_crop_resize(dd_ctx *ctx, const uint8_t *frame, int H, int W, const int64_
     for (int i = 0; i < n; ++i) {
         const int ok = ddk::crop_box_host(boxes_host + (size_t)i * 4, ph, pw, H, W, hb + 8 * i, hb + 8 * i + 1,
                                           hb + 8 * i + 2, hb + 8 * i + 3);
+        hb[8 * i + 4] = 0; hb[8 * i + 5] = 0; hb[8 * i + 6] = 0; hb[8 * i + 7] = 0;
+        if (valid_host) valid_host[i] = ok;
+    }
+    DD_HIP(hipMemcpyAsync(ctx->scratch[3].p, hb, (size_t)n * 32, hipMemcpyHostToDevice, s));
+    DD_HIP(hipStreamSynchronize(s));                        // the pinned block is reused by the next call
+    return ddk::crop_resize(s, frame, H, W, ctx->scratch[3].p, n, ph, pw, out);
+}
+
+int dd_crop_resize_f64(dd_ctx *ctx, const uint8_t *frame, int H, int W, const double *boxes_host, int n, int ph,
+                       int pw, uint8_t *out, int *valid_host, void *stream) {
+    DD_REQUIRE(ctx && n >= 0 && H > 0 && W > 0 && ph > 0 && pw > 0, DD_E_ARG, "dd_crop_resize_f64: bad argument");
+    if (n == 0) return DD_OK;
+    DD_REQUIRE(frame && boxes_host && out, DD_E_ARG, "dd_crop_resize_f64: NULL argument");
+    hipStream_t s = dd_pick_stream(ctx, stream);
+    int rc;
+    if ((rc = ctx->pin[1].reserve((size_t)n * 32)) != DD_OK) return rc;
+    if ((rc = ctx->scratch[3].reserve((size_t)n * 32)) != DD_OK) return rc;
+    int *hb = ctx->pin[1].as<int>();
+    for (int i = 0; i < n; ++i) {
+        const int ok = ddk::crop_box_host_f64(boxes_host + (size_t)i * 4, ph, pw, H, W, hb + 8 * i, hb + 8 * i + 1,
+                                              hb + 8 * i + 2, hb + 8 * i + 3);
         hb[8 * i + 4] = 0; hb[8 * i + 5] = 0; hb[8 * i + 6] = 0; hb[8 * i + 7] = 0;
         if (valid_host) valid_host[i] = ok;
     }

@@ -19,6 +19,7 @@ from .tools import generate_detections as gdet
 from .tools.countline import CountLine
 from .runtime import default_context
 from .wire import ResultSink
+from .framerecords import FrameRecords, load_cvat_annotations
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LABELS = os.path.join(HERE, 'assets', 'coco_labels_ssd.txt')
@@ -72,7 +73,7 @@ class HotPath:
                  nms_max_overlap=0.6, max_iou_distance=0.7, max_age=60, encoder_batch_size=32, num_threads=4,
                  context=None, run_detector=True, disable_background_subtraction=True, background_subtraction_ratio=0.25,
                  enable_background_masking=False, log=None, restore_from_log=False, mqtt_publish=None, mqtt_topic='default/topic',
-                 mqtt_acp_id=None, mqtt_verbosity=1, cpu_temp=None):
+                 mqtt_acp_id=None, mqtt_verbosity=1, cpu_temp=None, annotations=None):
         self.ctx = context or default_context()
         self.input_size = tuple(input_size)
         # deepdish.py:512,889: the reference defaults to background subtraction ON; its benchmarks (and this class)
@@ -94,6 +95,13 @@ class HotPath:
         self.counter = CountLine(np.asarray(line, dtype=float), self.wanted_labels)
         self.frame_count = 0
         self.timings = {}
+        # frame records (deepdish.py:613-641): always present upstream, a pass-through unless CVAT annotations are given
+        # (--input-cvat-dir; `annotations` = the parsed annotations.xml)
+        det_labels = getattr(self.object_detector, 'labels', None) or {i: l for i, l in enumerate(self.wanted_labels)}
+        self.framerec = FrameRecords(det_labels)
+        self.xmltree = annotations
+        if annotations is not None:
+            load_cvat_annotations(self.framerec, annotations, det_labels)
         # result packaging (deepdish.py:545-561,1147-1185): MQTT payloads through the host's publish(topic, json) and
         # the JSON-lines log the counters can be restored from
         self.sink = None
@@ -127,14 +135,25 @@ class HotPath:
         boxesA1 = boxesA0[indices] if len(indices) else np.zeros((0, 4), dtype=np.int64)
         scoresA1 = scoresA0[indices] if len(indices) else np.zeros(0)
         labels1 = [labels[i] for i in indices]
+        framenum = self.frame_count + 1
+        if self.xmltree is not None:                                                               # :1001
+            boxes2, labels1, scores2 = self.framerec.process_boxes(framenum, boxesA1, labels1, scoresA1)
+            boxesA1 = np.array(boxes2, dtype=np.float64).reshape(-1, 4)
+            scoresA1 = np.array(scores2, dtype=np.float64)
+            indices = list(range(len(labels1)))
         if len(indices):
-            feats_dev, _valid = self.encoder.encode_device(frame_dev, H, W, boxesA1.astype(np.int64))   # :1008
+            feats_dev, _valid = self.encoder.encode_device(frame_dev, H, W, boxesA1)                    # :1008
         else:
             feats_dev = None
         t2 = time()
         detections = [Detection(b, l, s, _NOFEAT) for b, l, s in zip(boxesA1, labels1, scoresA1)]        # :1014
         self.tracker.predict()                                                                          # :1028
+        if self.xmltree is not None:
+            detections = self.framerec.process_detections(framenum, detections)                         # :1017
         self.tracker.update_arrays(boxesA1.astype(np.float64), feats_dev, detections)                    # :1029
+        if self.xmltree is not None:
+            self._attach_features(detections, feats_dev)
+            self.tracker.tracks = self.framerec.process_tracking(framenum, self.tracker)                # :1047
         t3 = time()
         events = self.counter.step(self.tracker)                                                         # :1035-1114
         t4 = time()
@@ -143,6 +162,19 @@ class HotPath:
             self.sink.crossings(events, t0 if t_frame is None else t_frame, self.frame_count)            # :1116-1123
         self.timings = dict(objd=t1 - t0, feat=t2 - t1, trak=t3 - t2, proc=t4 - t3, e2e=t4 - t0)
         return events
+
+    def _attach_features(self, detections, feats_dev):
+        """With annotations a track may be extended from a detection later (framerecords.process_tracking): give the
+        detections their feature rows (one small device-to-host copy per frame, only in this mode)."""
+        if feats_dev is not None and len(detections):
+            host = self.ctx.to_host(feats_dev)[:len(detections)]
+            for d, f in zip(detections, host):
+                d.feature = f
+
+    def cvat_xml(self):
+        """deepdish.py:795-805: the annotations.xml of --output-cvat-dir as an ElementTree."""
+        meta = self.xmltree.getroot().find('./meta') if self.xmltree is not None else None
+        return self.framerec.xml_output(meta=meta)
 
     def counts(self):
         return self.counter.vector()

@@ -21,6 +21,11 @@ def crop_patches_device(ctx, frame_dev, H, W, boxes_int64, ph, pw):
     n = len(boxes_int64)
     out = ctx.empty((n, ph, pw, 3), torch.uint8)
     valid = np.ones(n, dtype=np.int32)
+    if np.asarray(boxes_int64).dtype.kind == 'f':       # float boxes (CVAT annotations): the reference's float arithmetic
+        b = np.ascontiguousarray(boxes_int64, dtype=np.float64).reshape(n, 4)
+        check(lib().dd_crop_resize_f64(ctx.handle, ptr(frame_dev), H, W, ptr(b), n, ph, pw, ptr(out), ptr(valid), None),
+              'dd_crop_resize_f64')
+        return out, valid
     b = np.ascontiguousarray(boxes_int64, dtype=np.int64).reshape(n, 4)
     check(lib().dd_crop_resize(ctx.handle, ptr(frame_dev), H, W, ptr(b), n, ph, pw, ptr(out), ptr(valid), None),
           'dd_crop_resize')
@@ -33,15 +38,6 @@ def extract_image_patch(image, bbox, patch_shape, context=None):
     img = np.ascontiguousarray(image, dtype=np.uint8)
     H, W = img.shape[:2]
     bb = np.array(bbox)
-    if bb.dtype.kind == 'f':         # float boxes: replay the reference's float arithmetic, then truncate
-        if patch_shape is not None:
-            new_width = float(patch_shape[1]) / patch_shape[0] * bb[3]
-            bb[0] -= (new_width - bb[2]) / 2
-            bb[2] = new_width
-        bb[2:] += bb[:2]
-        bb = bb.astype(np.int64)
-        bb[2:] -= bb[:2]
-        raise NotImplementedError('float boxes are not on the hot path (deepdish.py:950-951 makes them ints)')
     dev = ctx.to_device(img)
     out, valid = crop_patches_device(ctx, dev, H, W, bb.reshape(1, 4), patch_shape[0], patch_shape[1])
     if not valid[0]:
@@ -128,8 +124,9 @@ def create_box_encoder(model_filename, input_name="images", output_name="feature
         img = np.ascontiguousarray(image, dtype=np.uint8)
         frame_dev = ctx.to_device(img)
         t1 = time()
+        arr = np.asarray([np.asarray(b) for b in boxes])
         feats, valid = encode_device(frame_dev, img.shape[0], img.shape[1],
-                                     np.asarray([np.asarray(b) for b in boxes], dtype=np.int64))
+                                     arr.astype(np.float64 if arr.dtype.kind == 'f' else np.int64))
         result = ctx.to_host(feats)
         t2 = time()
         for box, ok in zip(boxes, valid):

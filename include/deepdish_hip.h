@@ -150,6 +150,11 @@ int dd_tracker_last_matches(dd_tracker *trk, int *pairs_host, int cap, int *out_
  * out: u8 [n][ph][pw][3].  valid_host[i] = 0 where the reference would return None. */
 int dd_crop_resize(dd_ctx *ctx, const uint8_t *frame, int H, int W, const int64_t *boxes_host,
                    int n, int ph, int pw, uint8_t *out, int *valid_host, void *stream);
+/* The same for float boxes (f64 [n][4] tlwh): generate_detections.py:64-74 evaluated in floating point with one
+ * truncation at `astype(np.int)` -- what happens upstream when a box comes from a CVAT annotation
+ * (deepdish/framerecords.py:109-118 feeds annotation boxes to the encoder). */
+int dd_crop_resize_f64(dd_ctx *ctx, const uint8_t *frame, int H, int W, const double *boxes_host, int n, int ph,
+                       int pw, uint8_t *out, int *valid_host, void *stream);
 
 /* tools/generate_detections.py:86-116 DummyImageEncoder (mode 0: channel-mean of 16x8 patches, -128,
  * L2-normalised) and ConstantImageEncoder (mode 1: e0): the reference's model-free test encoders.

@@ -39,6 +39,28 @@ def test_crop_resize_vs_oracle(ctx):
     assert image_np.crop_box(np.array([10, 10, 64, 128]), (64, 32), (480, 640)) == (10, 10, 74, 138)
 
 
+def test_crop_resize_of_float_boxes_vs_oracle(ctx):
+    """Boxes that come from CVAT annotations are floats (framerecords feeds them to the encoder): the reference then
+    does generate_detections.py:64-74 in floating point and truncates once; the int path truncates earlier."""
+    from deepdish_amd.tools.generate_detections import crop_patches_device, extract_image_patch
+    from oracle import image_np
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    boxes = np.c_[rng.uniform(-20, 630, 80), rng.uniform(-20, 470, 80), rng.uniform(2, 120, 80), rng.uniform(2, 200, 80)]
+    boxes = np.concatenate([boxes, [[40.5, 59.75, 30.0, 80.0], [100.9, 50.9, 40.9, 90.9], [-0.9, -0.9, 30.2, 60.2], [639.5, 10.0, 9.0, 9.0]]])
+    out, valid = crop_patches_device(ctx, ctx.to_device(img), 480, 640, boxes, 64, 32)
+    out = ctx.to_host(out)
+    differs_from_int_path = 0
+    for i, b in enumerate(boxes):
+        want = image_np.extract_image_patch(img, b, (64, 32))
+        assert bool(valid[i]) == (want is not None), (i, b)
+        if want is not None:
+            np.testing.assert_array_equal(out[i], want, err_msg=str(b))
+            differs_from_int_path += image_np.crop_box(b, (64, 32), (480, 640)) != image_np.crop_box(b.astype(np.int64), (64, 32), (480, 640))
+    assert differs_from_int_path > 10                           # the float arithmetic matters
+    np.testing.assert_array_equal(extract_image_patch(img, boxes[80], (64, 32)), image_np.extract_image_patch(img, boxes[80], (64, 32)))
+
+
 @pytest.mark.parametrize('shape', [(480, 640, 300, 300), (480, 640, 640, 640), (720, 1280, 300, 300), (97, 131, 300, 300),
                                    (200, 640, 150, 300)])     # last: rows not a multiple of 16 -> the LDS-staged scalar kernels
 def test_lanczos_vs_pillow(ctx, shape):
