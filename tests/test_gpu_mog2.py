@@ -173,3 +173,32 @@ def test_single_stream_host_path_applies_the_motion_test():
         key = lambda hp: [(t.track_id, t.state, t.time_since_update, t.hits, tuple(t.mean)) for t in hp.tracker.tracks]
         assert key(on) == key(off), f
     assert len(on.tracker.tracks) > 0 and not ok[-1]
+
+
+def test_masking_feeds_the_detector_masked_frames_and_ignores_lookahead():
+    """--enable-background-masking with the detector running: the detector (and the crops) must see
+    cv2.bitwise_and(frame, frame, mask=fgMask); a look-ahead request cannot be honoured (the next mask does not exist
+    yet) and must not change anything.  Compared with a plain pipeline that is handed the masked frames."""
+    from deepdish_amd.multipipe import MultiStreamPipeline
+    from deepdish_amd.pipeline import DEFAULT_LABELS
+    from deepdish_amd.synth import Scene
+    from oracle.mog2_np import MOG2
+    S, F = 2, 6
+    scenes = [Scene(seed=300 + z, n_obj=8, n_frames=F) for z in range(S)]
+    labels = [l.strip() for l in open(DEFAULT_LABELS)][1:]
+    a = MultiStreamPipeline(S, wanted_labels=labels, background_subtraction_ratio=0.0, background_masking=True)
+    b = MultiStreamPipeline(S, wanted_labels=labels)
+    ora = [MOG2() for _ in range(S)]
+    frames = [np.stack([sc.frame(f) for sc in scenes]) for f in range(F)]
+    dev = [torch.from_numpy(x).cuda() for x in frames]
+    seen = 0
+    for f in range(F):
+        a.step(dev[f], None, dev[f + 1] if f + 1 < F else None)
+        masks = np.stack([ora[z].apply(frames[f][z]) for z in range(S)])
+        b.step(torch.from_numpy(np.where(masks[..., None] != 0, frames[f], 0).astype(np.uint8)).cuda())
+        for z in range(S):
+            (ia, ma), (ib, mb) = a.tracker(z).table(), b.tracker(z).table()
+            np.testing.assert_array_equal(ia, ib, err_msg='stream %d frame %d' % (z, f))
+            np.testing.assert_array_equal(ma, mb)
+            seen += len(ia)
+    assert seen > 0                                                # ratio 0: every detector box passes the motion test
