@@ -132,6 +132,9 @@ class Tracker:
                 if which == 0:
                     by_id[tid] = trk
                 out[which].append(trk)
+        for trk in out[0]:                         # tracker.py:84-91: a confirmed track's feature cache moves to the metric
+            if trk.state == 2:                     # (here: the device gallery) at the end of every update
+                trk.features = []
         self._by_id = by_id
         self._tracks, self.deleted_tracks = out
 

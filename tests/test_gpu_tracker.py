@@ -66,6 +66,7 @@ def test_tracker_edge_cases():
     for _ in range(12):                                                        # overflow budget ring
         trk.predict(); trk.update([Detection([10, 10, 20, 40], 'person', 0.9, f)])
     assert len(trk.tracks) == 1 and trk.tracks[0].is_confirmed() and trk.tracks[0].hits == 12
+    assert trk.tracks[0].features == [] and len(trk.tracks[0].detections) == 12      # tracker.py:91 / track.py:152
     assert trk.tracks[0].get_label(True)[0] == 'person'
     for _ in range(4):                                                         # starve -> deleted after max_age
         trk.predict(); trk.update([])
