@@ -42,6 +42,7 @@ SIGNATURES = {
     'dd_tracker_count': [P, c_int, POINTER(c_int)],
     'dd_tracker_read': [P, c_int, P, P, P],
     'dd_tracker_track_update': [P, c_int64, P, P, c_int],
+    'dd_tracker_track_predict': [P, c_int64],
     'dd_tracker_track_set': [P, c_int64, c_int, c_int],
     'dd_tracker_remove': [P, P, c_int],
     'dd_tracker_next_id': [P, POINTER(c_int64)],

@@ -613,6 +613,33 @@ int dd_tracker_track_update(dd_tracker *t, int64_t track_id, const double *tlwh_
     return DD_OK;
 }
 
+// Track.predict(kf) (track.py:113-125) for ONE live track: Kalman predict, age += 1, time_since_update += 1.
+int dd_tracker_track_predict(dd_tracker *t, int64_t track_id) {
+    DD_REQUIRE(t, DD_E_ARG, "dd_tracker_track_predict: NULL tracker");
+    const int i = find_live(t, track_id);
+    DD_REQUIRE(i >= 0, DD_E_ARG, "dd_tracker_track_predict: no live track with id %lld", (long long)track_id);
+    DD_REQUIRE(t->live_means.size() == t->tracks.size() * 8, DD_E_STATE, "dd_tracker_track_predict: call update() first");
+    TrackerPool *p = t->pool;
+    hipStream_t s = p->ctx->stream;
+    int rc;
+    if (p->pred_inflight) DD_HIP(hipStreamSynchronize(s));
+    if ((rc = p->h_pred.reserve(sizeof(int))) != DD_OK) return rc;
+    if ((rc = p->d_pred.reserve(sizeof(int))) != DD_OK) return rc;
+    if ((rc = p->d_gather.reserve(sizeof(int) + 8 * sizeof(double))) != DD_OK) return rc;
+    if ((rc = p->h_gather.reserve(sizeof(int) + 8 * sizeof(double))) != DD_OK) return rc;
+    *p->h_pred.as<int>() = t->tracks[i].slot;
+    DD_HIP(hipMemcpyAsync(p->d_pred.p, p->h_pred.p, sizeof(int), hipMemcpyHostToDevice, s));
+    if ((rc = ddk::kf_predict(s, p->d_means, p->d_covs, p->d_pred.as<int>(), 1)) != DD_OK) return rc;
+    if ((rc = ddk::gather_state(s, p->d_means, p->d_covs, p->d_pred.as<int>(), 1, p->d_gather.as<double>(), nullptr)) != DD_OK) return rc;
+    DD_HIP(hipMemcpyAsync(p->h_gather.p, p->d_gather.p, 8 * sizeof(double), hipMemcpyDeviceToHost, s));
+    DD_HIP(hipStreamSynchronize(s));
+    p->pred_inflight = false;
+    memcpy(t->live_means.data() + (size_t)i * 8, p->h_gather.p, 8 * sizeof(double));
+    t->tracks[i].age += 1;
+    t->tracks[i].tsu += 1;
+    return DD_OK;
+}
+
 // Host assignment to track.state / track.time_since_update (framerecords.py:160-161).  state: 1 Tentative, 2 Confirmed
 // (a track is deleted with dd_tracker_remove); time_since_update < 0 leaves it unchanged.
 int dd_tracker_track_set(dd_tracker *t, int64_t track_id, int state, int time_since_update) {

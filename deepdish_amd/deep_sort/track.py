@@ -59,7 +59,10 @@ class Track:
         self.detections.append(detection)
 
     def predict(self, kf):
-        raise NotImplementedError('per-track predict is batched on the device: call Tracker.predict()')
+        """track.py:113-125 for this one track (Tracker.predict() does all of them in one launch)."""
+        if self._owner is None:
+            raise RuntimeError('this track is not attached to a device tracker')
+        self._owner._track_predict(self)
 
     def update(self, kf, detection):
         """track.py:127-152 for this one track, outside Tracker.update (framerecords.py:158 calls it to extend a track

@@ -74,6 +74,12 @@ class Tracker:
         trk._mirror(mean=row[1].copy(), _covariance=None, state=int(row[0][1]), time_since_update=int(row[0][2]),
                     hits=int(row[0][3]))
 
+    def _track_predict(self, trk):
+        check(lib().dd_tracker_track_predict(self._h, int(trk.track_id)), 'dd_tracker_track_predict')
+        ints, means = self._read(0)
+        row = {int(r[0]): (r, m) for r, m in zip(ints, means)}[trk.track_id]
+        trk._mirror(mean=row[1].copy(), _covariance=None, time_since_update=int(row[0][2]), age=int(row[0][4]))
+
     def _track_set(self, trk):
         if trk.state in (1, 2) and self._by_id.get(trk.track_id) is trk:
             check(lib().dd_tracker_track_set(self._h, int(trk.track_id), int(trk.state), int(trk.time_since_update)),

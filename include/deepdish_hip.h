@@ -134,6 +134,7 @@ int dd_tracker_read(dd_tracker *trk, int which, int64_t *ints6_host, double *mea
  * dd_tracker_track_set = host assignment to track.state (1 Tentative, 2 Confirmed) and track.time_since_update
  * (< 0: unchanged).  dd_tracker_remove = the host reassigned tracker.tracks without these ids. */
 int dd_tracker_track_update(dd_tracker *t, int64_t track_id, const double *tlwh_host, const float *feat, int feat_on_device);
+int dd_tracker_track_predict(dd_tracker *t, int64_t track_id);   /* Track.predict(kf), deep_sort/track.py:113-125, one track */
 int dd_tracker_track_set(dd_tracker *t, int64_t track_id, int state, int time_since_update);
 int dd_tracker_remove(dd_tracker *t, const int64_t *track_ids_host, int n);
 int dd_tracker_next_id(dd_tracker *trk, int64_t *out_host);

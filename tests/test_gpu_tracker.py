@@ -117,6 +117,9 @@ def test_host_interventions_between_updates_match_the_oracle():
             trk.tracks = [t for t in trk.tracks if t.track_id != victim]
             ora.tracks = [t for t in ora.tracks if t.track_id != victim]
             done['removed'] += 1
+        if f == 17 and trk.tracks:                                   # track.py:113-125 on one track
+            trk.tracks[0].predict(trk.kf); ora.tracks[0].predict()
+            np.testing.assert_allclose(trk.tracks[0].covariance, ora.tracks[0].covariance, rtol=1e-9, atol=1e-9)
         if f in (13, 26):
             for t, o in zip(list(trk.tracks), list(ora.tracks)):
                 if t.is_tentative():
