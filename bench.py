@@ -36,7 +36,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--streams', type=int, default=int(os.environ.get('DD_BENCH_STREAMS', '384')),
+    ap.add_argument('--streams', type=int, default=int(os.environ.get('DD_BENCH_STREAMS', '768')),
                     help='independent video streams per GPU (one frame of each per step)')
     ap.add_argument('--groups', type=int, default=int(os.environ.get('DD_BENCH_GROUPS', '4')),
                     help='worker threads per GPU: the streams are split into this many pipelines, each with its own '
