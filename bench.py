@@ -36,7 +36,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--streams', type=int, default=int(os.environ.get('DD_BENCH_STREAMS', '768')),
+    ap.add_argument('--streams', type=int, default=None,
                     help='independent video streams per GPU (one frame of each per step)')
     ap.add_argument('--groups', type=int, default=int(os.environ.get('DD_BENCH_GROUPS', '4')),
                     help='worker threads per GPU: the streams are split into this many pipelines, each with its own '
@@ -50,7 +50,10 @@ def parse():
                          '(MOG2 on every frame + motion test on the detector boxes, deepdish.py:920-924,957; the reference uses '
                          'RATIO 0.25).  BASELINE.json\'s configurations run with --disable-background-subtraction')
     ap.add_argument('--cpu-frames', type=int, default=300)
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.streams is None:        # --ingest-host keeps every step's frames in pinned host memory: a smaller default there
+        args.streams = int(os.environ.get('DD_BENCH_STREAMS', '256' if args.ingest_host else '768'))
+    return args
 
 
 def _gen_stream(args):
