@@ -282,15 +282,24 @@ __device__ __forceinline__ void conv_finish(const ConvP &P, f4 (&acc)[NI][MI], _
                 *reinterpret_cast<f4 *>(ot + ((wm * MI + b) * 16 + fr) * OROW + (wn * NI + a) * 16 + fq * 4) = acc[a][b];
         __syncthreads();
         const int A = P.p[5];
-        for (int pl = wave; pl < BM; pl += WM * WN) {
+        // a lane owns 4 consecutive columns: one ds_read_b128 + one 16-byte store (rows of A * (4 + C) floats are only
+        // 4-byte aligned: the store type says so); bias loaded once -- inside the pixel loop the load could not move
+        // above the previous pixel's stores (may alias)
+        typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+        constexpr int LPP = BN / 4, PPW = 64 / LPP;                // lanes per pixel row, pixels per wave pass
+        const int lc = (lane % LPP) * 4, lp = lane / LPP;
+        const int ch = n0 + lc;
+        const int nlive = min(4, max(0, P.cout - ch));            // columns of this lane inside the layer
+        f4 bias = f4{0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < nlive; ++q) bias[q] = P.bias[ch + q];
+        for (int pl = wave * PPW + lp; pl < BM; pl += WM * WN * PPW) {
             const int m = m0 + pl;
-            if (m >= P.m) break;
-            const int n = m / hw, p = m - n * hw;                 // wave-uniform
-            float *dst = static_cast<float *>(P.out) + ((size_t)n * P.p[1] + P.p[2] + (size_t)p * A) * P.p[3];
-            for (int c = lane; c < BN; c += 64) {
-                const int ch = n0 + c;
-                if (ch < P.cout) dst[ch] = ot[pl * OROW + c] + P.bias[ch];
-            }
+            if (m >= P.m || nlive == 0) continue;
+            const int n = m / hw, p = m - n * hw;
+            float *__restrict__ dst = static_cast<float *>(P.out) + ((size_t)n * P.p[1] + P.p[2] + (size_t)p * A) * P.p[3] + ch;
+            const f4 v = *reinterpret_cast<const f4 *>(ot + pl * OROW + lc) + bias;
+            if (nlive == 4) *reinterpret_cast<f4u *>(dst) = v;
+            else for (int q = 0; q < nlive; ++q) dst[q] = v[q];
         }
         return;
     }
