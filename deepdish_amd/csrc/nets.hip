@@ -182,7 +182,10 @@ __device__ __forceinline__ Epi8 epi8_load(const ConvP &P, int co) {
 // compiled into a chain of branches around every value).
 // EF (epilogue flavour) 0: no residual, no second output; 1: both; -1: whatever P says.
 template <int ACT = -1, bool BIAS = true, int EF = -1>   // BIAS = false: the accumulators were initialised with the bias
-__device__ __forceinline__ void conv_epilogue_f16x8(const ConvP &P, const Epi8 &E, int m, int co, float v[8]) {
+__device__ __forceinline__ void conv_epilogue_f16x8(const ConvP &P, const Epi8 &E, int m, int co, float v[8], const h8 *res_pre = nullptr) {
+    // res_pre: the residual vector of this (pixel, channel group), fetched by the caller before its first store -- a
+    // load issued here cannot be moved above the stores of the caller's previous pixel (they may alias), so a loop of
+    // epilogues would pay one memory round trip per pixel
     const int act = ACT < 0 ? P.act : ACT;
     const bool has_res = EF < 0 ? P.res != nullptr : EF == 1, has_out2 = EF < 0 ? P.out2 != nullptr : EF == 1;
 #pragma unroll
@@ -191,7 +194,7 @@ __device__ __forceinline__ void conv_epilogue_f16x8(const ConvP &P, const Epi8 &
         v[4 + r] = apply_act(BIAS ? v[4 + r] + E.b1[r] : v[4 + r], act);
     }
     if (has_res) {
-        const h8 rv = *reinterpret_cast<const h8 *>(P.res + (size_t)m * P.cs_res + P.coff_res + co);
+        const h8 rv = res_pre ? *res_pre : *reinterpret_cast<const h8 *>(P.res + (size_t)m * P.cs_res + P.coff_res + co);
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] += (float)rv[r];
     }
@@ -231,14 +234,17 @@ __device__ __forceinline__ void conv_epilogue_f16x8(const ConvP &P, int m, int c
 template <int ACT, int BM, int BN, int T>
 __device__ __forceinline__ void conv_finish_rows(const ConvP &P, const float *ot, int m0, int n0) {
     constexpr int OROW = BN + 4, G = BN / 8;                      // floats per staged pixel row, 8-channel groups per row
-    for (int t = threadIdx.x; t < BM * G; t += T) {
-        const int pl = t / G, g = t - pl * G;
-        const int m = m0 + pl, co = n0 + g * 8;
-        if (m >= P.m || co >= P.cout_pad) continue;
+    static_assert(T % G == 0, "a thread keeps its channel group over the row loop");
+    const int g = threadIdx.x % G, co = n0 + g * 8;
+    if (co >= P.cout_pad) return;
+    const Epi8 E = epi8_load(P, co);                              // once: inside the loop these loads could not move above
+    for (int pl = threadIdx.x / G; pl < BM; pl += T / G) {         // the previous row's stores (they may alias)
+        const int m = m0 + pl;
+        if (m >= P.m) break;
         const f4 lo = *reinterpret_cast<const f4 *>(ot + pl * OROW + g * 8);
         const f4 hi = *reinterpret_cast<const f4 *>(ot + pl * OROW + g * 8 + 4);
         float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        conv_epilogue_f16x8<ACT>(P, m, co, v);
+        conv_epilogue_f16x8<ACT>(P, E, m, co, v);
     }
 }
 
@@ -335,6 +341,14 @@ __device__ __forceinline__ void conv_finish_direct_act(const ConvP &P, f4 (&acc)
         const int co = n0 + (wn * NI + 2 * g) * 16 + fq * 8;
         if (co >= P.cout_pad) continue;
         const Epi8 E = epi8_load(P, co);
+        h8 rp[MI];
+        if (P.res) {
+#pragma unroll
+            for (int b = 0; b < MI; ++b) {
+                const int m = min(m0 + (wm * MI + b) * 16 + fr, P.m - 1);
+                rp[b] = *reinterpret_cast<const h8 *>(P.res + (size_t)m * P.cs_res + P.coff_res + co);
+            }
+        }
 #pragma unroll
         for (int b = 0; b < MI; ++b) {
             const int m = m0 + (wm * MI + b) * 16 + fr;
@@ -342,7 +356,7 @@ __device__ __forceinline__ void conv_finish_direct_act(const ConvP &P, f4 (&acc)
             float v[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) { v[r] = acc[2 * g][b][r]; v[4 + r] = acc[2 * g + 1][b][r]; }
-            conv_epilogue_f16x8<ACT>(P, E, m, co, v);
+            conv_epilogue_f16x8<ACT>(P, E, m, co, v, P.res ? &rp[b] : nullptr);
         }
     }
 }
@@ -767,6 +781,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rw_k(const ConvP P, const int 
                         for (int b = 0; b < MB; ++b)
                             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[dy * 3 + dx][a], xf[b], acc[a][b], 0, 0, 0);
                 }
+            h8 rp[MB][NCO / 2];
+            const bool pre = !POOL && (EF < 0 ? P.res != nullptr : EF == 1);
+            if (pre) {
+#pragma unroll
+                for (int b = 0; b < MB; ++b)
+#pragma unroll
+                    for (int g = 0; g < NCO / 2; ++g)
+                        rp[b][g] = *reinterpret_cast<const h8 *>(ok[b] ? P.res + (size_t)mrow[b] * P.cs_res + P.coff_res + g * 32 + fq * 8 : P.zero);
+            }
 #pragma unroll
             for (int b = 0; b < MB; ++b) {
                 if (!ok[b]) continue;
@@ -785,7 +808,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rw_k(const ConvP P, const int 
                         }
                         *reinterpret_cast<h8 *>(stage + ((f0 + b) * 16 + fr) * (NCO * 16) + g * 32 + fq * 8) = hv;
                     } else {
-                        conv_epilogue_f16x8<ACT, false, EF>(P, E[g], mrow[b], g * 32 + fq * 8, o);
+                        conv_epilogue_f16x8<ACT, false, EF>(P, E[g], mrow[b], g * 32 + fq * 8, o, pre ? &rp[b][g] : nullptr);
                     }
                 }
             }
