@@ -689,7 +689,8 @@ constexpr int RW_MB = 4;                                       // pixel fragment
 template <int NCO, int TW, int ACT, bool POOL, int EF = -1>     // TW: tile width when known at compile time (tap offsets
 __global__ __launch_bounds__(256, 2) void conv3x3_rw_k(const ConvP P, const int total_tiles) {   // become ds_read immediates), else 0
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
-    constexpr int MB = EF == 1 ? 2 : RW_MB;                    // pixel fragments in flight per wave (the two-output epilogue needs the registers)
+    constexpr int MB = (EF == 0 || POOL) ? RW_MB : 2;          // pixel fragments in flight per wave: the residual / two-output / run-time
+                                                               // epilogues need the registers (with 4 they spilled 9-19 VGPRs to scratch)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int tw = TW ? TW : P.tw;
@@ -781,15 +782,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rw_k(const ConvP P, const int 
                         for (int b = 0; b < MB; ++b)
                             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[dy * 3 + dx][a], xf[b], acc[a][b], 0, 0, 0);
                 }
-            h8 rp[MB][NCO / 2];
-            const bool pre = !POOL && (EF < 0 ? P.res != nullptr : EF == 1);
-            if (pre) {
-#pragma unroll
-                for (int b = 0; b < MB; ++b)
-#pragma unroll
-                    for (int g = 0; g < NCO / 2; ++g)
-                        rp[b][g] = *reinterpret_cast<const h8 *>(ok[b] ? P.res + (size_t)mrow[b] * P.cs_res + P.coff_res + g * 32 + fq * 8 : P.zero);
-            }
 #pragma unroll
             for (int b = 0; b < MB; ++b) {
                 if (!ok[b]) continue;
@@ -808,7 +800,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rw_k(const ConvP P, const int 
                         }
                         *reinterpret_cast<h8 *>(stage + ((f0 + b) * 16 + fr) * (NCO * 16) + g * 32 + fq * 8) = hv;
                     } else {
-                        conv_epilogue_f16x8<ACT, false, EF>(P, E[g], mrow[b], g * 32 + fq * 8, o, pre ? &rp[b][g] : nullptr);
+                        conv_epilogue_f16x8<ACT, false, EF>(P, E[g], mrow[b], g * 32 + fq * 8, o);
                     }
                 }
             }
