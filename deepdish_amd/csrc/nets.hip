@@ -857,11 +857,46 @@ __global__ __launch_bounds__(256) void stem_conv3_k(const ConvP P) {
 #pragma unroll
     for (int a = 0; a < 2; ++a) wf[a] = *reinterpret_cast<const h8 *>(P.w + rw_weight_row(a, fr) * 32 + fq * 8);
 
-    {   // patch fill, eight independent byte loads in flight per lane (a dependent load per element would
-        // leave the block waiting on one HBM round trip after another)
-        const int xs3 = (x0 * STRIDE - P.pad_l) * 3, w3 = P.W * 3, total = PH * PW3;
+    // LDS patch: PH rows of `pitch` halves; a pixel's filter row is nine consecutive halves starting at column
+    // (tx * STRIDE) * 3 + shift.  Dword fill (image rows 4-byte aligned, P.p[2]): a row starts at the aligned byte at
+    // or before the patch's first byte, shift = 0..3; byte fill: pitch = PW3, shift = 0.
+    const int xs3 = (x0 * STRIDE - P.pad_l) * 3, w3 = P.W * 3;
+    const bool dwords = P.p[2] != 0;
+    const int a0 = dwords ? (xs3 & ~3) : xs3;                       // & ~3 rounds towards -inf in two's complement
+    const int shift = xs3 - a0;
+    const int pitch = dwords ? ((PW3 + 6) & ~3) : PW3;
+    const uint8_t *img = P.src8 + (size_t)n * P.H * w3;
+    if (dwords) {
+        // eight independent 4-byte loads in flight per lane (a dependent load per element would leave the block waiting
+        // on one memory round trip after another); an aligned dword lies entirely inside or outside the image row
+        const int DW = pitch >> 2, total = PH * DW;
+        const unsigned rcp = 0xFFFFFFFFu / (unsigned)DW + 1u;      // __umulhi(i, rcp) == i / DW for i < 2^16
+        for (int i0 = tid; i0 < total; i0 += 8 * 256) {
+            unsigned raw[8];
+            bool in[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int idx = i0 + j * 256;
+                const int py = (int)__umulhi((unsigned)idx, rcp), dq = idx - py * DW;
+                const int y = y0 * STRIDE - P.pad_t + py, x3 = a0 + dq * 4;
+                in[j] = idx < total && y >= 0 && y < P.H && x3 >= 0 && x3 < w3;
+                raw[j] = in[j] ? *reinterpret_cast<const unsigned *>(img + (size_t)y * w3 + x3) : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int idx = i0 + j * 256;
+                if (idx >= total) continue;
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                h4 o;                                             // zero padding is applied after normalisation
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    o[q] = (_Float16)(in[j] ? ((float)((raw[j] >> (8 * q)) & 255u) - P.in_mean) * P.in_scale : 0.f);
+                *reinterpret_cast<h4 *>(lds + idx * 4) = o;
+            }
+        }
+    } else {
+        const int total = PH * PW3;
         const unsigned rcp = 0xFFFFFFFFu / (unsigned)PW3 + 1u;     // __umulhi(i, rcp) == i / PW3 for i < 2^16
-        const uint8_t *img = P.src8 + (size_t)n * P.H * w3;
         for (int i0 = tid; i0 < total; i0 += 8 * 256) {
             int raw[8];
 #pragma unroll
@@ -882,7 +917,7 @@ __global__ __launch_bounds__(256) void stem_conv3_k(const ConvP P) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int k = fq * 8 + j;
-        koff[j] = k < 27 ? (k / 9) * PW3 + (k % 9) : 0;             // k >= 27: weight is zero, any finite value will do
+        koff[j] = k < 27 ? (k / 9) * pitch + (k % 9) : 0;           // k >= 27: weight is zero, any finite value will do
     }
     __syncthreads();
 
@@ -898,7 +933,7 @@ __global__ __launch_bounds__(256) void stem_conv3_k(const ConvP P) {
             const int p = (f0 + b) * 16 + fr;
             const int ty = (int)((p * rcp_tw) >> 16), tx = p - ty * P.tw;
             ok[b] = p < tile_px && y0 + ty < P.ho && x0 + tx < P.wo;
-            const int e0 = ok[b] ? ty * STRIDE * PW3 + tx * STRIDE * 3 : 0;
+            const int e0 = ok[b] ? ty * STRIDE * pitch + tx * STRIDE * 3 + shift : shift;
             mrow[b] = (n * P.ho + y0 + ty) * P.wo + x0 + tx;
 #pragma unroll
             for (int j = 0; j < 8; ++j) xf[b][j] = lds[e0 + koff[j]];
@@ -1410,7 +1445,10 @@ int launch_conv3x3_rw(hipStream_t s, ConvP &P, int nimg, bool pool) {
 
 int launch_stem(hipStream_t s, ConvP &P, int nimg) {
     spatial_tile(P.ho, P.wo, P.stride, 0, P);
-    const size_t lds_bytes = (size_t)((P.th - 1) * P.stride + 3) * ((P.tw - 1) * P.stride + 3) * 3 * sizeof(_Float16);
+    // 4-byte loads for the patch fill need 4-byte aligned image rows (300 x 300 and 64 x 32 frames: yes)
+    P.p[2] = (P.W * 3) % 4 == 0 && ((size_t)P.H * P.W * 3) % 4 == 0 && (reinterpret_cast<uintptr_t>(P.src8) & 3) == 0;
+    const int pw3 = ((P.tw - 1) * P.stride + 3) * 3;
+    const size_t lds_bytes = (size_t)((P.th - 1) * P.stride + 3) * (P.p[2] ? ((pw3 + 6) & ~3) : pw3) * sizeof(_Float16);
     const dim3 grid((unsigned)(nimg * P.tiles_x * P.tiles_y));
     if (P.stride == 1 && P.act == ACT_ELU) hipLaunchKernelGGL((stem_conv3_k<1, ACT_ELU>), grid, dim3(256), lds_bytes, s, P);
     else if (P.stride == 2 && P.act == ACT_RELU6) hipLaunchKernelGGL((stem_conv3_k<2, ACT_RELU6>), grid, dim3(256), lds_bytes, s, P);
