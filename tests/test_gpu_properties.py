@@ -102,3 +102,27 @@ def test_kalman_256_tracks_stay_symmetric_and_gate_is_nonnegative():
             assert np.all(np.linalg.eigvalsh((cov + cov.T) / 2) > -1e-9)
             nxt.append((mean, cov))
         states = nxt
+
+
+@pytest.mark.parametrize('kind', ['mars', 'ssd'])
+def test_first_layer_does_not_depend_on_the_frame_pointer_alignment(kind):
+    """stem_conv3_k fills its input patch with 4-byte loads when the frame rows are 4-byte aligned and with byte loads
+    otherwise (a frame tensor that starts at an odd address): same bits either way."""
+    from deepdish_amd import nets
+    from deepdish_amd.engine import Net
+    if kind == 'mars':
+        prog, shape, n = nets.compile_mars(nets.synthetic_mars_weights()), (64, 32), 37
+    else:
+        prog, shape, n = nets.compile_ssd_mobilenet(nets.synthetic_ssd_weights()), (300, 300), 2
+    net = Net(prog, max_batch=n)
+    x = np.random.default_rng(8).integers(0, 256, (n,) + shape + (3,), dtype=np.uint8)
+    flat = torch.zeros(x.size + 16, dtype=torch.uint8, device='cuda')
+    outs = []
+    for off in (0, 1, 2):
+        view = flat[off:off + x.size].view(x.shape)
+        view.copy_(torch.from_numpy(x).cuda())
+        assert view.data_ptr() % 4 == off
+        net.forward(view)
+        outs.append(net.read().copy())
+    np.testing.assert_array_equal(outs[0], outs[1])
+    np.testing.assert_array_equal(outs[0], outs[2])
