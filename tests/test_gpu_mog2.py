@@ -202,3 +202,25 @@ def test_masking_feeds_the_detector_masked_frames_and_ignores_lookahead():
             np.testing.assert_array_equal(ma, mb)
             seen += len(ia)
     assert seen > 0                                                # ratio 0: every detector box passes the motion test
+
+
+def test_full_size_frames_match_the_oracle():
+    """BASELINE frame size (640x480), bench-style scenes: masks and mode counts bit-exact over the first frames, where
+    modes are created, matched, re-sorted and pruned all over the image."""
+    from deepdish_amd.background import createBackgroundSubtractorMOG2
+    from deepdish_amd.synth import Scene
+    from oracle.mog2_np import MOG2, live_state
+    S, F = 3, 5
+    scenes = [Scene(seed=500 + z, n_obj=20, n_frames=F) for z in range(S)]
+    sub = createBackgroundSubtractorMOG2(n_streams=S)
+    ora = [MOG2() for _ in range(S)]
+    rng = np.random.default_rng(21)
+    for f in range(F):
+        fr = np.stack([np.clip(sc.frame(f).astype(np.int16) + rng.integers(-3, 4, (480, 640, 3)), 0, 255).astype(np.uint8) for sc in scenes])
+        got = sub.apply(fr)
+        for z in range(S):
+            np.testing.assert_array_equal(got[z], ora[z].apply(fr[z]), err_msg='stream %d frame %d' % (z, f))
+    for z in range(S):
+        for name, a, b in zip(('weight', 'variance', 'mean', 'nmodes'), sub.state(z), live_state(ora[z])):
+            np.testing.assert_array_equal(a, b, err_msg='%s, stream %d' % (name, z))
+    assert 0 < (got != 0).mean() < 0.5
