@@ -126,3 +126,36 @@ def test_first_layer_does_not_depend_on_the_frame_pointer_alignment(kind):
         outs.append(net.read().copy())
     np.testing.assert_array_equal(outs[0], outs[1])
     np.testing.assert_array_equal(outs[0], outs[2])
+
+
+def test_nms_is_idempotent_and_order_free_at_full_size():
+    """4096 boxes, dd_nms's single-pass capacity (the reference hands it a few hundred: what passes the detector's
+    confidence threshold): suppressing the survivors again removes nothing, survivors come best-first, shuffling the
+    input only relabels them; one box more is a loud error."""
+    from deepdish_amd.deep_sort import preprocessing
+    rng = np.random.default_rng(17)
+    K = 4096
+    boxes = np.c_[rng.integers(0, 600, K), rng.integers(0, 440, K), rng.integers(8, 120, K), rng.integers(8, 160, K)].astype(np.int64)
+    scores = rng.permutation(K).astype(np.float64) / K                          # tie-free
+    keep = preprocessing.non_max_suppression(boxes, 0.6, scores)
+    assert 0 < len(keep) < K and len(set(keep)) == len(keep)
+    assert np.all(np.diff(scores[keep]) < 0)
+    again = preprocessing.non_max_suppression(boxes[keep], 0.6, scores[keep])
+    assert again == list(range(len(keep)))
+    perm = rng.permutation(K)
+    keep_p = preprocessing.non_max_suppression(boxes[perm], 0.6, scores[perm])
+    assert [int(perm[i]) for i in keep_p] == keep
+    with pytest.raises(RuntimeError):
+        preprocessing.non_max_suppression(np.concatenate([boxes, boxes[:1]]), 0.6, np.append(scores, 2.0))
+
+
+def test_embeddings_are_unit_vectors_at_full_batch():
+    """freeze_model.py:153-156 ends in an L2 normalisation: every row of a 3840-crop forward has norm 1."""
+    from deepdish_amd import nets
+    from deepdish_amd.engine import Net
+    net = Net(nets.compile_mars(nets.synthetic_mars_weights()), max_batch=3840)
+    x = np.random.default_rng(19).integers(0, 256, (3840, 64, 32, 3), dtype=np.uint8)
+    net.forward(x)
+    f = net.read().reshape(3840, -1)[:, :128]
+    assert np.isfinite(f).all()
+    np.testing.assert_allclose(np.linalg.norm(f.astype(np.float64), axis=1), 1.0, atol=1e-4)
