@@ -81,8 +81,7 @@ class Track:
 
     def _mirror(self, **fields):
         """The tracker copying device-side book-keeping into this view: no write-back."""
-        for k, v in fields.items():
-            object.__setattr__(self, k, v)
+        self.__dict__.update(fields)
 
     def __setattr__(self, name, value):
         # the host may assign state / time_since_update (framerecords.py:160-161): keep the device tracker's copy in step

@@ -126,8 +126,7 @@ class Tracker:
         by_id = {}
         out = [[], []]
         for which, (ints, means) in enumerate(((live_i, live_m), (dead_i, dead_m))):
-            for row, m in zip(ints, means):
-                tid, state, tsu, hits, age, last = (int(v) for v in row)
+            for (tid, state, tsu, hits, age, last), m in zip(ints.tolist(), means):
                 trk = self._by_id.get(tid)
                 det = detections[last] if (detections is not None and last >= 0) else None
                 if trk is None:
@@ -140,7 +139,7 @@ class Tracker:
                 out[which].append(trk)
         for trk in out[0]:                         # tracker.py:84-91: a confirmed track's feature cache moves to the metric
             if trk.state == 2:                     # (here: the device gallery) at the end of every update
-                trk.features = []
+                trk.__dict__['features'] = []
         self._by_id = by_id
         self._tracks, self.deleted_tracks = out
 
