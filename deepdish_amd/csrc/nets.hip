@@ -207,7 +207,9 @@ __device__ __forceinline__ void conv_epilogue_f16x8(const ConvP &P, const Epi8 &
         for (int r = 0; r < 8; ++r)
             if (co + r >= P.cout) o[r] = (_Float16)0.f;
     }
-    *reinterpret_cast<h8 *>(static_cast<_Float16 *>(P.out) + (size_t)m * P.cs_out + P.coff_out + co) = o;
+    // streaming store: same-box A/B -0.7 % on both networks (the activations of a layer exceed the L2 anyway); the
+    // depthwise kernel keeps plain stores -- its output is re-read at once by the following 1x1 layer (+4 % with nt)
+    __builtin_nontemporal_store(o, reinterpret_cast<h8 *>(static_cast<_Float16 *>(P.out) + (size_t)m * P.cs_out + P.coff_out + co));
     if (has_out2) {                                 // second view: ELU(scale * raw + shift)
         h8 o2;
 #pragma unroll
