@@ -1,21 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- end-to-end frames/s of the detect -> encode -> track hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--streams S]
+    python bench.py --gpus N --steps K --warmup W [--config {2,3,5}] [--streams S]
 
-A "step" is one pass of the hot path over one batch of synthetic input: one 640x480 BGR frame from
-each of the S independent video streams this rank owns (SSD-MobileNet-v1 forward + post-process on
-the frame, NMS + MARS encoder over ~20 synthetic detections per frame, deep_sort predict/update,
-count-line logic).  Frames and detections are generated before the timed region and the frames are
-resident in HBM when it starts.  With N > 1 (one rank per GPU under torch.distributed.run) every
-rank runs its own streams -- there is no data-path collective; the only exchange is one RCCL
-all-reduce of the (pos, neg, int, del) count vector after the timed region.
+A "step" is one pass of the hot path over one batch of synthetic input: one BGR frame from each of the S
+independent video streams this rank owns (detector forward + post-process on the frame, NMS + MARS encoder over
+~20 synthetic detections per frame, deep_sort predict/update, count-line logic).  Frames and detections are
+generated before the timed region and the frames are resident in HBM when it starts.
 
-Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for the roofline/cpu_baseline fields).
+--gpus N > 1: when this process was not started by a launcher (no RANK in the environment) it starts N ranks of
+itself with `python -m torch.distributed.run` (one per GPU, rendezvous on 127.0.0.1) BEFORE anything touches the
+GPU and relays rank 0's JSON line; under a launcher it checks WORLD_SIZE == N.  Every rank runs its own streams --
+there is no data-path collective; the only exchange is one RCCL all-reduce of the (pos, neg, int, del) count
+vector after the timed region (deepdish_amd/multistream.py).
+
+--config picks the BASELINE.json configuration (1-based): 2 = SSD-MobileNet-v1 + MARS + deep_sort on 640x480 frames
+(the headline; default), 3 = YOLOv5s-f16 detector on 640x640 frames, 5 = 1280x720 streams, one per GPU.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for the roofline / cpu_baseline fields).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -25,10 +32,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-W, H = 640, 480
 N_OBJ = 20
-PEAK_F16_TFLOPS = 2500.0      # dense f16 MFMA, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
-PEAK_HBM_GBS = 8000.0
+CONFIGS = {
+    2: dict(W=640, H=480, model='synthetic-ssd_mobilenet_v1', streams=768, groups=4,
+            workload='SSD-MobileNet-v1 (300x300) + MARS-64x32x3 + deep_sort on synthetic 640x480 BGR frames, '
+                     '~20 synthetic detections/frame (BASELINE.json configs[1])'),
+    3: dict(W=640, H=640, model='synthetic-yolov5s-fp16', streams=64, groups=2,
+            workload='YOLOv5s-f16 (640x640) + HIP NMS / IoU + MARS-64x32x3 + deep_sort on synthetic 640x640 BGR frames, '
+                     '~20 synthetic detections/frame (BASELINE.json configs[2])'),
+    5: dict(W=1280, H=720, model='synthetic-ssd_mobilenet_v1', streams=1, groups=1,
+            workload='SSD-MobileNet-v1 + MARS-64x32x3 + deep_sort on synthetic 1280x720 BGR streams, one stream per GPU '
+                     '(BASELINE.json configs[4]); latency-bound by construction: one frame per step'),
+}
 
 
 def parse():
@@ -36,9 +51,11 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--config', type=int, default=2, choices=sorted(CONFIGS),
+                    help='BASELINE.json configuration (1-based): 2 headline, 3 YOLOv5s detector, 5 one 1280x720 stream per GPU')
     ap.add_argument('--streams', type=int, default=None,
                     help='independent video streams per GPU (one frame of each per step)')
-    ap.add_argument('--groups', type=int, default=int(os.environ.get('DD_BENCH_GROUPS', '4')),
+    ap.add_argument('--groups', type=int, default=None,
                     help='worker threads per GPU: the streams are split into this many pipelines, each with its own '
                          'HIP stream, so one group\'s host phases (LSAP, count line) overlap the other\'s kernels')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -49,15 +66,47 @@ def parse():
                     help='secondary figure (never the headline value): run with the reference\'s default background subtraction '
                          '(MOG2 on every frame + motion test on the detector boxes, deepdish.py:920-924,957; the reference uses '
                          'RATIO 0.25).  BASELINE.json\'s configurations run with --disable-background-subtraction')
-    ap.add_argument('--cpu-frames', type=int, default=300)
+    ap.add_argument('--cpu-frames', type=int, default=40, help='frames per seed of the CPU baseline sample (3 seeds)')
+    ap.add_argument('--rehearse-cpu', action='store_true',
+                    help='launcher / rendezvous / count-reduction rehearsal over gloo on the CPU: no frames are processed and no '
+                         'throughput is reported (what tests/test_bench_launcher.py runs where there is no GPU)')
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
     if args.streams is None:        # --ingest-host keeps every step's frames in pinned host memory: a smaller default there
-        args.streams = int(os.environ.get('DD_BENCH_STREAMS', '256' if args.ingest_host else '768'))
+        args.streams = int(os.environ.get('DD_BENCH_STREAMS', '256' if args.ingest_host and args.config == 2 else cfg['streams']))
+    if args.groups is None:
+        args.groups = int(os.environ.get('DD_BENCH_GROUPS', cfg['groups']))
     return args
 
 
-def _gen_stream(args):
-    seed, n_frames = args
+def launch_ranks(args):
+    """--gpus N without a launcher: start N fresh ranks (never re-exec a process that has touched the GPU) and relay
+    rank 0's JSON line.  Returns the exit status for this parent."""
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')        # dmabuf IPC: RCCL needs it on this host driver
+    env.setdefault('OMP_NUM_THREADS', '1')
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in proc.stdout:
+        ln = ln.strip()
+        if ln.startswith('{') and '"metric"' in ln:
+            line = ln                                          # the ranks' other chatter (none expected) is dropped
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        rc = 1
+    return rc
+
+
+def _gen_stream(job):
+    seed, n_frames, W, H = job
     from deepdish_amd.synth import Scene
     sc = Scene(seed=seed, n_obj=N_OBJ, width=W, height=H, n_frames=n_frames)
     frames = np.stack([sc.frame(f) for f in range(n_frames)])
@@ -68,14 +117,15 @@ def _gen_stream(args):
     return frames, per
 
 
-def make_inputs(rank, streams, n_frames, sink):
+def make_inputs(rank, world, streams, n_frames, W, H, sink):
     """Seeded frames and injected detections of every stream (untimed).  sink(s, frames u8 [F, H, W, 3]) places a
     stream's frames (HBM tensor slice or pinned slot) as soon as a worker delivers them, so the host never holds
     more than the few streams in flight; returns the per-stream per-frame detections."""
     import multiprocessing as mp
     dets = [None] * streams
-    jobs = [(1000 * rank + s, n_frames) for s in range(streams)]
-    workers = max(1, min(16, (os.cpu_count() or 2) // 2, streams))
+    jobs = [(1000 * rank + s, n_frames, W, H) for s in range(streams)]
+    # the ranks of one node share its cores: each rank takes its share of half of them
+    workers = max(1, min(16, (os.cpu_count() or 2) // (2 * max(1, world)), streams))
     if workers > 1:
         with mp.get_context('spawn').Pool(workers) as pool:
             for s, (fr, per) in enumerate(pool.imap(_gen_stream, jobs)):
@@ -89,52 +139,109 @@ def make_inputs(rank, streams, n_frames, sink):
     return dets
 
 
-def cpu_baseline(n_frames):
-    """The oracle's CPU path on the same workload (kind "port"), bounded sample, rank 0 only."""
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def _cpu_model():
+    try:
+        for ln in open('/proc/cpuinfo'):
+            if ln.startswith('model name'):
+                return ln.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(n_frames, W, H):
+    """The oracle's CPU path on the same workload (kind "port"), bounded sample, rank 0 only -- SURVEY.md 8(d):
+    three seeds (median), every stage timed with 1 thread and with min(4, cores) threads (torch intra-op threads for
+    the networks, BLAS / OpenMP pool for the numpy tracker; the reference's default is --num-threads 4,
+    deepdish.py:1422) and the FASTER setting taken per stage, so the GPU / CPU ratio is not flattered.
+    Stages: detector = Pillow Lanczos + f32 SSD-MobileNet forward + post-process; encoder = crops + f32 MARS;
+    tracker = deep_sort NMS + predict / update + count line."""
     import torch
     from PIL import Image
+    from threadpoolctl import threadpool_limits
     from deepdish_amd import nets
     from deepdish_amd.synth import Scene
     from oracle import deepsort_np as ds, countline_np as cl, image_np, nets_torch
-    threads = min(4, os.cpu_count() or 1)              # reference default --num-threads 4 (deepdish.py:1422)
-    torch.set_num_threads(threads)
-    sc = Scene(seed=0, n_obj=N_OBJ, width=W, height=H, n_frames=n_frames + 2)
+    ncores = os.cpu_count() or 1
+    settings = sorted({1, min(4, ncores)})
     wd_ssd, wd_mars = nets.synthetic_ssd_weights(1234), nets.synthetic_mars_weights(1234)
     anchors, _ = nets.ssd_anchors(300)
-    trk = ds.Tracker(ds.Metric(0.2), max_iou_distance=0.7, max_age=60)
-    counter = cl.CountLine(sc.countline())
+    per_seed, stage_pick = [], {}
+    keep_for_parity = None
+    for seed in (0, 1, 2):
+        sc = Scene(seed=seed, n_obj=N_OBJ, width=W, height=H, n_frames=n_frames + 2)
+        frames = [sc.frame(f) for f in range(n_frames + 2)]
+        dets_in = [sc.detections(f) for f in range(n_frames + 2)]
+        keeps = [ds.non_max_suppression(d[0], 0.6, d[1]) for d in dets_in]
+        feats = [None] * (n_frames + 2)
+        best = {}
 
-    def one(f):
-        frame = sc.frame(f)
-        rgba = np.dstack([frame[..., ::-1], np.full((H, W, 1), 255, np.uint8)])
-        img = Image.fromarray(rgba, 'RGBA').convert('RGB').resize((300, 300), Image.LANCZOS)
-        raw = nets_torch.ssd_forward(wd_ssd, np.asarray(img)[None])
-        nets_torch.ssd_postprocess(raw[0], anchors)
-        boxes, scores, _, _ = sc.detections(f)
-        keep = ds.non_max_suppression(boxes, 0.6, scores)
-        patches = np.stack([image_np.extract_image_patch(frame, boxes[i], (64, 32)) for i in keep])
-        feats = nets_torch.mars_forward(wd_mars, patches)
-        dets = [ds.Det(boxes[i], 'person', scores[i], feats[j]) for j, i in enumerate(keep)]
-        trk.predict(); trk.update(dets); counter.step(trk)
+        def detector(f):
+            rgba = np.dstack([frames[f][..., ::-1], np.full((H, W, 1), 255, np.uint8)])
+            img = Image.fromarray(rgba, 'RGBA').convert('RGB').resize((300, 300), Image.LANCZOS)
+            raw = nets_torch.ssd_forward(wd_ssd, np.asarray(img)[None])
+            nets_torch.ssd_postprocess(raw[0], anchors)
 
-    one(0); one(1)                                       # warm-up, as the reference does (deepdish.py:895-898)
-    t0 = time.perf_counter()
-    for f in range(2, n_frames + 2):
-        one(f)
-    dt = time.perf_counter() - t0
-    table = [(int(t.track_id), int(t.state), int(t.time_since_update), int(t.hits)) for t in trk.tracks]
-    base = dict(value=n_frames / dt, unit='frames/s', cores=threads, kind='port',
-                sample='%d frames of the same 640x480 / ~20-detection workload, oracle path (Pillow Lanczos + '
-                       'torch-CPU f32 SSD-MobileNet-v1 and MARS + numpy deep_sort), %d torch threads' % (n_frames, threads))
-    return base, sc, [int(v) for v in np.asarray(counter.vector()).reshape(-1)], table
+        def encoder(f):
+            boxes = dets_in[f][0]
+            patches = np.stack([image_np.extract_image_patch(frames[f], boxes[i], (64, 32)) for i in keeps[f]])
+            feats[f] = nets_torch.mars_forward(wd_mars, patches)
+
+        for name, fn in (('detector', detector), ('encoder', encoder)):
+            for t in settings:
+                torch.set_num_threads(t)
+                fn(0); fn(1)                                       # warm-up, as the reference does (deepdish.py:895-898)
+                t0 = time.perf_counter()
+                for f in range(2, n_frames + 2):
+                    fn(f)
+                best.setdefault(name, {})[t] = (time.perf_counter() - t0) / n_frames
+        table = counts = None
+        for t in settings:
+            with threadpool_limits(limits=t):
+                trk = ds.Tracker(ds.Metric(0.2), max_iou_distance=0.7, max_age=60)
+                counter = cl.CountLine(sc.countline())
+                dt = 0.0
+                for f in range(n_frames + 2):
+                    boxes, scores = dets_in[f][0], dets_in[f][1]
+                    t0 = time.perf_counter()
+                    keep = ds.non_max_suppression(boxes, 0.6, scores)
+                    dets = [ds.Det(boxes[i], 'person', scores[i], feats[f][j]) for j, i in enumerate(keep)]
+                    trk.predict(); trk.update(dets); counter.step(trk)
+                    if f >= 2:
+                        dt += time.perf_counter() - t0
+                best.setdefault('tracker', {})[t] = dt / n_frames
+                table = [(int(x.track_id), int(x.state), int(x.time_since_update), int(x.hits)) for x in trk.tracks]
+                counts = [int(v) for v in np.asarray(counter.vector()).reshape(-1)]
+        if seed == 0:
+            keep_for_parity = (sc, counts, table)
+        sec = 0.0
+        for name, by_t in best.items():
+            t_best = min(by_t, key=by_t.get)
+            stage_pick.setdefault(name, []).append((t_best, by_t))
+            sec += by_t[t_best]
+        per_seed.append(1.0 / sec)
+    value = float(np.median(per_seed))
+    stages = {}
+    for name, picks in stage_pick.items():
+        stages[name] = {'ms_per_frame_by_threads': {str(t): round(1e3 * float(np.median([p[1][t] for p in picks])), 3) for t in settings},
+                        'threads_used': int(np.median([p[0] for p in picks]))}
+    used = max(s['threads_used'] for s in stages.values())
+    base = dict(value=value, unit='frames/s', cores=used, kind='port',
+                sample='3 seeds x %d frames of the same %dx%d / ~20-detection workload (median), oracle path: Pillow Lanczos + '
+                       'torch-CPU f32 SSD-MobileNet-v1 and MARS + numpy deep_sort; per stage the faster of %s threads'
+                       % (n_frames, W, H, ' / '.join(map(str, settings))),
+                per_seed=[round(v, 2) for v in per_seed], stages=stages,
+                host=dict(cpu_model=_cpu_model(), logical_cores=ncores))
+    return base, keep_for_parity
 
 
-def gpu_sample_check(sc, n_frames, oracle_counts, oracle_table, device):
-    """The HIP path over the very frames the CPU baseline just processed (one stream): crossing counts and the
+def gpu_sample_check(sc, n_frames, oracle_counts, oracle_table, device, W, H):
+    """The HIP path over the very frames the CPU baseline just processed (seed 0, one stream): crossing counts and the
     final track table (id, state, time_since_update, hits) must be identical."""
     import torch
     from deepdish_amd.multipipe import MultiStreamPipeline
-    mp1 = MultiStreamPipeline(1)
+    mp1 = MultiStreamPipeline(1, input_size=(W, H))
     for f in range(n_frames + 2):
         boxes, scores, _, _ = sc.detections(f)
         inj = mp1.pack_injected([([tuple(int(v) for v in b) for b in boxes], ['person'] * len(boxes), [float(x) for x in scores])])
@@ -146,17 +253,56 @@ def gpu_sample_check(sc, n_frames, oracle_counts, oracle_table, device):
                 identical=bool(counts == oracle_counts and table == oracle_table))
 
 
+# ------------------------------------------------------------------------------------------------ rehearsal
+def rehearse(args, rank, world, real_stdout):
+    """No GPU: the launcher, the rendezvous, the barrier / max-over-ranks timing protocol and the count reduction,
+    over gloo.  Nothing is measured and no frame is processed."""
+    import torch
+    import torch.distributed as dist
+    from deepdish_amd.multistream import reduce_counts
+    if world > 1 or 'RANK' in os.environ:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        dist.barrier()
+    t0 = time.perf_counter()
+    local = np.array([[rank + 1, 10 * (rank + 1), 11 * (rank + 1), 0]], dtype=np.int64)      # stands for this rank's counts
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64)
+    if dist.is_initialized():
+        dist.barrier()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    counts = reduce_counts(local)
+    if rank == 0:
+        out = {'metric': 'end-to-end frames/sec (detect+encode+track) at 640x480', 'value': None, 'unit': 'frames/s',
+               'n_gpus': world, 'steps': 0, 'warmup': 0, 'rehearsal': 'launcher / rendezvous / count reduction only (gloo, CPU): '
+               'no frames processed, nothing measured', 'counts_pos_neg_int_del': [int(v) for v in counts.reshape(-1)]}
+        os.write(real_stdout, (json.dumps(out) + '\n').encode())
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        sys.exit(launch_ranks(args))                         # before torch is imported or the GPU is touched
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        sys.stderr.write('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks\n' % (args.gpus, world))
+        sys.exit(2)
     # stdout carries exactly ONE JSON line: keep the real stdout aside and point fd 1 at stderr while
     # libraries (RCCL prints a version banner on stdout) are at work.
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
-    import torch
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.rehearse_cpu:
+        return rehearse(args, rank, world, real_stdout)
+    cfg = CONFIGS[args.config]
+    W, H = cfg['W'], cfg['H']
+    import torch
     dist_on = world > 1 or ('RANK' in os.environ and 'MASTER_PORT' in os.environ)    # launched by torch.distributed.run
     torch.cuda.set_device(local_rank)
     if dist_on:
@@ -166,12 +312,14 @@ def main():
 
     import threading
     from deepdish_amd.multipipe import MultiStreamPipeline
+    from deepdish_amd.multistream import reduce_counts
     from deepdish_amd.runtime import Context
     n_frames = args.warmup + args.steps
     G = max(1, min(args.groups, args.streams))
     bounds = [round(g * args.streams / G) for g in range(G + 1)]
     ctxs = [Context(local_rank) for _ in range(G)]
-    pipes = [MultiStreamPipeline(bounds[g + 1] - bounds[g], context=ctxs[g], background_subtraction_ratio=args.background_subtraction)
+    pipes = [MultiStreamPipeline(bounds[g + 1] - bounds[g], model=cfg['model'], input_size=(W, H), context=ctxs[g],
+                                 background_subtraction_ratio=args.background_subtraction)
              for g in range(G)]
     group_of = [g for g in range(G) for _ in range(bounds[g], bounds[g + 1])]
     ings = dev_frames = None
@@ -192,12 +340,13 @@ def main():
         def sink(s, fr):
             g = group_of[s]
             dev_frames[g][:, s - bounds[g]] = torch.from_numpy(fr).to(f'cuda:{local_rank}')
-    dets = make_inputs(rank, args.streams, n_frames, sink)
+    dets = make_inputs(rank, world, args.streams, n_frames, W, H, sink)
     injected = [[pipes[g].pack_injected([dets[s][f] for s in range(bounds[g], bounds[g + 1])]) for f in range(n_frames)]
                 for g in range(G)]
     torch.cuda.synchronize()
 
     def run(g, f0, f1):
+        torch.cuda.set_device(local_rank)                    # a fresh thread starts on device 0
         if ings is not None:
             ings[g].submit(f0)
             for f in range(f0, f1):
@@ -234,55 +383,50 @@ def main():
     stage_ms = pipes[0].stage_ms()
     local_counts = sum(p.counts().sum(axis=0) for p in pipes)
     tmax = torch.tensor([dt], dtype=torch.float64, device=f'cuda:{local_rank}')
-    counts = torch.from_numpy(local_counts).to(f'cuda:{local_rank}')
     if dist_on:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM)      # RCCL: the only exchange step of the path
+    counts = reduce_counts(local_counts, device=f'cuda:{local_rank}')      # RCCL: the only exchange step of the path
     dt = float(tmax.item())
     total_frames = args.steps * args.streams * world
 
     if rank == 0:
         out = {
-            'metric': 'end-to-end frames/sec (detect+encode+track) at 640x480',
+            'metric': 'end-to-end frames/sec (detect+encode+track) at %dx%d' % (W, H),
             'value': total_frames / dt, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
-            'config': {'workload': 'SSD-MobileNet-v1 (300x300) + MARS-64x32x3 + deep_sort on synthetic 640x480 BGR '
-                                   'frames, ~20 synthetic detections/frame (BASELINE.json configs[1])',
+            'config': {'workload': cfg['workload'], 'baseline_config': args.config,
                        'streams_per_gpu': args.streams, 'frames_per_step': args.streams * world,
                        'worker_threads_per_gpu': G,
                        'parallelism': 'independent streams, %d per GPU in %d worker groups' % (args.streams, G),
                        'weights': 'seeded synthetic (seed 1234)'},
-            'counts_pos_neg_int_del': [int(v) for v in counts.cpu().numpy().reshape(-1)],
+            'counts_pos_neg_int_del': [int(v) for v in np.asarray(counts).reshape(-1)],
             'stage_ms_per_step': {k: round(v, 4) for k, v in stage_ms.items() if k != 'steps'},
         }
+        if args.streams == 1:
+            out['latency_ms_per_frame'] = 1e3 * dt / args.steps        # the reference's own operating point: one stream
+        extra_only = False
         if args.background_subtraction is not None:
             out['background_subtraction'] = {'ratio': args.background_subtraction,
                                              'boxes_rejected_by_motion_test': int(sum(p.motion_mask(read=False)[1] for p in pipes)),
                                              'note': 'reference default configuration; not the headline (BASELINE configs disable it)'}
-            if ings is None:
-                os.write(real_stdout, (json.dumps(out) + '\n').encode())
-                if dist_on:
-                    dist.barrier(); dist.destroy_process_group()
-                return
+            extra_only = True
         if ings is not None:
             out['frames_start_in'] = 'pinned host memory (PCIe upload inside the timed region; not the headline configuration)'
-            os.write(real_stdout, (json.dumps(out) + '\n').encode())
-            if dist_on:
-                dist.barrier(); dist.destroy_process_group()
-            return
-        try:
-            from deepdish_amd.profile import dominant_kernel_roofline
-            out['roofline'] = dominant_kernel_roofline(pipes, lambda g, f: pipes[g].step(dev_frames[g][f], injected[g][f]), args)
-        except Exception as e:                            # never let the extra pass hide the headline number
-            out['roofline'] = None
-            out['roofline_error'] = repr(e)
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'], sc0, ocounts, otable = cpu_baseline(args.cpu_frames)
+            extra_only = True
+        if not extra_only:
             try:
-                out['parity_sample'] = gpu_sample_check(sc0, args.cpu_frames, ocounts, otable, f'cuda:{local_rank}')
-            except Exception as e:
-                out['parity_sample'] = dict(error=repr(e))
+                from deepdish_amd.profile import dominant_kernel_roofline
+                out['roofline'] = dominant_kernel_roofline(pipes, lambda g, f: pipes[g].step(dev_frames[g][f], injected[g][f]), args)
+            except Exception as e:                            # never let the extra pass hide the headline number
+                out['roofline'] = None
+                out['roofline_error'] = repr(e)
+            if world == 1 and not args.no_cpu_baseline and args.config in (2, 5):
+                out['cpu_baseline'], (sc0, ocounts, otable) = cpu_baseline(args.cpu_frames, W, H)
+                try:
+                    out['parity_sample'] = gpu_sample_check(sc0, args.cpu_frames, ocounts, otable, f'cuda:{local_rank}', W, H)
+                except Exception as e:
+                    out['parity_sample'] = dict(error=repr(e))
         os.write(real_stdout, (json.dumps(out) + '\n').encode())
     if dist_on:
         dist.barrier()

@@ -46,6 +46,7 @@ SIGNATURES = {
     'dd_tracker_track_set': [P, c_int64, c_int, c_int],
     'dd_tracker_remove': [P, P, c_int],
     'dd_tracker_next_id': [P, POINTER(c_int64)],
+    'dd_tracker_last_cost': [P, P, P, c_int, POINTER(c_int), POINTER(c_int)],
     'dd_tracker_last_matches': [P, P, c_int, POINTER(c_int)],
     'dd_crop_resize': [P, P, c_int, c_int, P, c_int, c_int, c_int, P, P, P],
     'dd_crop_resize_f64': [P, P, c_int, c_int, P, c_int, c_int, c_int, P, P, P],
@@ -75,6 +76,7 @@ SIGNATURES = {
     'dd_net_profile': [P, c_int],
     'dd_net_profile_read': [P, P, c_int, POINTER(c_int)],
     'dd_ssd_postprocess': [P, P, P, c_int, c_int, c_int, c_float, c_float, P, P, P, P, P],
+    'dd_ssd_detections': [P, P, P, P, c_int, c_int, c_double, c_double, c_double, c_double, P, P, P, P, P],
     'dd_yolov5_decode': [P, P, c_int, c_int, c_float, c_float, c_float, P, P, P, c_int, P, P],
     'dd_pipeline_create': [P, c_int, c_int, c_int, P, P, c_int, c_int, P, c_char_p, c_char_p, c_double, c_double,
                            c_double, c_int, c_int, P, c_int, c_int, POINTER(P)],

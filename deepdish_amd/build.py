@@ -19,7 +19,7 @@ ARCH = 'gfx950'
 COMMON = ['--offload-arch=' + ARCH, '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function',
           '-I', os.path.join(HERE, '..', 'include')]
 # The deep_sort math is parity-checked to the last bits in f64: keep a*b+c un-fused there.
-STRICT_FP = {'kalman.hip', 'cost.hip', 'nms.hip', 'tracker.hip', 'lsap.cpp', 'pyset.cpp', 'api.hip', 'image.hip', 'pipeline.hip', 'mog2.hip'}
+STRICT_FP = {'kalman.hip', 'cost.hip', 'nms.hip', 'tracker.hip', 'lsap.cpp', 'pyset.cpp', 'api.hip', 'image.hip', 'pipeline.hip', 'mog2.hip', 'post.hip'}
 
 
 def _sources():

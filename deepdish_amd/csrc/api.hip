@@ -67,6 +67,7 @@ int dd_ctx_stream(dd_ctx *ctx, void **out_stream) {
 
 int dd_ctx_sync(dd_ctx *ctx) {
     DD_REQUIRE(ctx, DD_E_ARG, "dd_ctx_sync: NULL ctx");
+    DD_DEVICE(ctx);
     DD_HIP(hipStreamSynchronize(ctx->stream));
     return DD_OK;
 }
@@ -74,29 +75,34 @@ int dd_ctx_sync(dd_ctx *ctx) {
 int dd_kf_initiate(dd_ctx *ctx, double *means, double *covs, const int *slots, const double *xyah, int n,
                    void *stream) {
     DD_REQUIRE(ctx && means && covs && xyah && n >= 0, DD_E_ARG, "dd_kf_initiate: bad argument");
+    DD_DEVICE(ctx);
     return ddk::kf_initiate(dd_pick_stream(ctx, stream), means, covs, slots, xyah, n);
 }
 
 int dd_kf_predict(dd_ctx *ctx, double *means, double *covs, const int *slots, int n, void *stream) {
     DD_REQUIRE(ctx && means && covs && n >= 0, DD_E_ARG, "dd_kf_predict: bad argument");
+    DD_DEVICE(ctx);
     return ddk::kf_predict(dd_pick_stream(ctx, stream), means, covs, slots, n);
 }
 
 int dd_kf_project(dd_ctx *ctx, const double *means, const double *covs, const int *slots, int n,
                   double *proj_mean, double *proj_cov, void *stream) {
     DD_REQUIRE(ctx && means && covs && proj_mean && proj_cov && n >= 0, DD_E_ARG, "dd_kf_project: bad argument");
+    DD_DEVICE(ctx);
     return ddk::kf_project(dd_pick_stream(ctx, stream), means, covs, slots, n, proj_mean, proj_cov);
 }
 
 int dd_kf_update(dd_ctx *ctx, double *means, double *covs, const int *slots, const double *xyah, int n,
                  void *stream) {
     DD_REQUIRE(ctx && means && covs && xyah && n >= 0, DD_E_ARG, "dd_kf_update: bad argument");
+    DD_DEVICE(ctx);
     return ddk::kf_update(dd_pick_stream(ctx, stream), means, covs, slots, xyah, n);
 }
 
 int dd_kf_gate(dd_ctx *ctx, const double *means, const double *covs, const int *slots, int n,
                const double *xyah, int n_det, int only_position, double *out_d2, void *stream) {
     DD_REQUIRE(ctx && means && covs && n >= 0 && n_det >= 0, DD_E_ARG, "dd_kf_gate: bad argument");
+    DD_DEVICE(ctx);
     DD_REQUIRE(n == 0 || n_det == 0 || (xyah && out_d2), DD_E_ARG, "dd_kf_gate: NULL argument");
     return ddk::kf_gate(dd_pick_stream(ctx, stream), means, covs, slots, n, xyah, n_det, only_position, out_d2);
 }
@@ -104,6 +110,7 @@ int dd_kf_gate(dd_ctx *ctx, const double *means, const double *covs, const int *
 int dd_iou_cost(dd_ctx *ctx, const double *tlwh_t, const int *tsu, int n_t, const double *tlwh_d, int n_d,
                 double *out, void *stream) {
     DD_REQUIRE(ctx && n_t >= 0 && n_d >= 0, DD_E_ARG, "dd_iou_cost: bad argument");
+    DD_DEVICE(ctx);
     DD_REQUIRE(n_t == 0 || n_d == 0 || (tlwh_t && tlwh_d && out), DD_E_ARG, "dd_iou_cost: NULL argument");
     return ddk::iou_cost(dd_pick_stream(ctx, stream), tlwh_t, tsu, n_t, tlwh_d, n_d, out);
 }
@@ -111,6 +118,7 @@ int dd_iou_cost(dd_ctx *ctx, const double *tlwh_t, const int *tsu, int n_t, cons
 int dd_cosine_nn_cost(dd_ctx *ctx, const float *gallery, const int *offsets_host, int n_t, const float *feats,
                       int n_d, double *out, void *stream) {
     DD_REQUIRE(ctx && n_t >= 0 && n_d >= 0, DD_E_ARG, "dd_cosine_nn_cost: bad argument");
+    DD_DEVICE(ctx);
     if (n_t == 0 || n_d == 0) return DD_OK;
     DD_REQUIRE(gallery && offsets_host && feats && out, DD_E_ARG, "dd_cosine_nn_cost: NULL argument");
     hipStream_t s = dd_pick_stream(ctx, stream);
@@ -141,6 +149,7 @@ int dd_cosine_nn_cost(dd_ctx *ctx, const float *gallery, const int *offsets_host
 static int nms_common(dd_ctx *ctx, const double *boxes, const double *keys, int k, double thr, int mode,
                       int *out_idx, int *out_n, void *stream, const char *who) {
     DD_REQUIRE(ctx && k >= 0 && out_n, DD_E_ARG, "%s: bad argument", who);
+    DD_DEVICE(ctx);
     DD_REQUIRE(k == 0 || (boxes && keys && out_idx), DD_E_ARG, "%s: NULL argument", who);
     hipStream_t s = dd_pick_stream(ctx, stream);
     int rc;

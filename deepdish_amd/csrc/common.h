@@ -30,6 +30,10 @@ void dd_set_error(const char *fmt, ...);
 
 #define DD_LAUNCH_CHECK() DD_HIP(hipGetLastError())
 
+// Every entry point that launches or allocates selects its context's device first: a fresh host thread starts on
+// device 0 whatever device the handle was created on.
+#define DD_DEVICE(ctx) DD_HIP(hipSetDevice((ctx)->device))
+
 // Growable device scratch buffer (never shrinks; growth happens outside graph capture).
 struct DevBuf {
     void *p = nullptr;
@@ -59,6 +63,24 @@ struct PinBuf {
     }
     void release() { if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; } }
     template <class T> T *as() { return reinterpret_cast<T *>(p); }
+};
+
+// One-time per-device set-up inside a launcher (hipFuncSetAttribute is a per-device property): run(device) returns
+// true to exactly one caller per device, which does the set-up while the others wait for it.
+#include <atomic>
+#include <mutex>
+struct DevOnce {
+    std::atomic<uint64_t> done{0};
+    std::mutex mu;
+    template <class F> int run(int device, F &&f) {
+        const uint64_t bit = 1ull << (device & 63);
+        if (done.load(std::memory_order_acquire) & bit) return DD_OK;
+        std::lock_guard<std::mutex> lk(mu);
+        if (done.load(std::memory_order_relaxed) & bit) return DD_OK;
+        const int rc = f();
+        if (rc == DD_OK) done.fetch_or(bit, std::memory_order_release);
+        return rc;
+    }
 };
 
 struct dd_ctx {

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void cosine_nn_k(const float *__restrict__ gal
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int d0 = blockIdx.y * 64 + wave * 16;
     if (d0 >= n_d) return;                                    // wave-uniform, no barriers below
-    const float best = nn_max_dot(gal + (size_t)row_start[t] * 128, row_count[t], feats, d0, n_d, lane);
+    const float best = nn_max_dot(FlatRows{gal + (size_t)row_start[t] * 128}, row_count[t], feats, d0, n_d, lane);
     const int c = lane & 15;
     if ((lane >> 4) == 0 && d0 + c < n_d) out[(size_t)t * ld_out + d0 + c] = (double)(1.0f - best);
 }

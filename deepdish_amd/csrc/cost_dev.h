@@ -20,13 +20,36 @@ __device__ __forceinline__ double iou_tlwh(const double *a, const double *b) {
     return inter / (area_a + area_b - inter);
 }
 
-// max over `count` gallery rows of <gal[g], feats[d]> for the 16 detections d0..d0+15 of this wave.
+// Where a track's gallery rows live.  FlatRows: one contiguous [count][128] block (dd_cosine_nn_cost).
+// ChunkRows: the tracker's growable gallery -- rows in 32-row chunks (16 KiB) drawn from arenas of 4096 chunks
+// (64 MiB); `tab` is the track's chunk list.  nn_budget=None upstream keeps every sample of a track
+// (deep_sort/nn_matching.py:137-154), so a gallery has no fixed size: chunks are added as a track is matched.
+constexpr int GAL_CH_SHIFT = 5, GAL_CH = 1 << GAL_CH_SHIFT;
+constexpr int GAL_ARENA_SHIFT = 12, GAL_ARENA_CHUNKS = 1 << GAL_ARENA_SHIFT;
+
+__device__ __forceinline__ float *gal_row(float *const *arenas, int chunk, int off) {
+    return arenas[chunk >> GAL_ARENA_SHIFT] + ((size_t)(chunk & (GAL_ARENA_CHUNKS - 1)) * GAL_CH + off) * 128;
+}
+
+struct FlatRows {
+    const float *base;
+    __device__ __forceinline__ const float *row(int r) const { return base + (size_t)r * 128; }
+};
+
+struct ChunkRows {
+    float *const *arenas;
+    const int *tab;
+    __device__ __forceinline__ const float *row(int r) const { return gal_row(arenas, tab[r >> GAL_CH_SHIFT], r & (GAL_CH - 1)); }
+};
+
+// max over `count` gallery rows of <row[g], feats[d]> for the 16 detections d0..d0+15 of this wave.
 // Both operands are already L2-normalised.  Lane (c = lane & 15, q = lane >> 4) returns the max
 // for detection d0 + c in every q (reduced across q).  v_mfma_f32_16x16x4_f32: lane supplies
 // A[row = lane & 15][k = lane >> 4] and B[k = lane >> 4][col = lane & 15]; D row = 4*(lane>>4)+reg,
 // col = lane & 15.  Each lane fetches 4 consecutive k as one 16-byte load and feeds them to four
 // MFMAs; A and B use the same k permutation, so every k is summed exactly once.
-__device__ __forceinline__ float nn_max_dot(const float *__restrict__ gal, int count,
+template <class Rows>
+__device__ __forceinline__ float nn_max_dot(const Rows rows, int count,
                                             const float *__restrict__ feats, int d0, int n_d, int lane) {
     const int c = lane & 15, q = lane >> 4;
     const int dd = min(d0 + c, n_d - 1);
@@ -37,7 +60,7 @@ __device__ __forceinline__ float nn_max_dot(const float *__restrict__ gal, int c
     float best = -__builtin_inff();
     for (int g = 0; g < count; g += 16) {
         const int r = min(g + c, count - 1);                 // clamp: a repeated row cannot change the max
-        const float *ap = gal + (size_t)r * 128 + 4 * q;
+        const float *ap = rows.row(r) + 4 * q;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 8; ++s) {

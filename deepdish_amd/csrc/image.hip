@@ -650,6 +650,7 @@ extern "C" {
 int dd_crop_resize(dd_ctx *ctx, const uint8_t *frame, int H, int W, const int64_t *boxes_host, int n, int ph,
                    int pw, uint8_t *out, int *valid_host, void *stream) {
     DD_REQUIRE(ctx && n >= 0 && H > 0 && W > 0 && ph > 0 && pw > 0, DD_E_ARG, "dd_crop_resize: bad argument");
+    DD_DEVICE(ctx);
     if (n == 0) return DD_OK;
     DD_REQUIRE(frame && boxes_host && out, DD_E_ARG, "dd_crop_resize: NULL argument");
     hipStream_t s = dd_pick_stream(ctx, stream);
@@ -671,6 +672,7 @@ int dd_crop_resize(dd_ctx *ctx, const uint8_t *frame, int H, int W, const int64_
 int dd_crop_resize_f64(dd_ctx *ctx, const uint8_t *frame, int H, int W, const double *boxes_host, int n, int ph,
                        int pw, uint8_t *out, int *valid_host, void *stream) {
     DD_REQUIRE(ctx && n >= 0 && H > 0 && W > 0 && ph > 0 && pw > 0, DD_E_ARG, "dd_crop_resize_f64: bad argument");
+    DD_DEVICE(ctx);
     if (n == 0) return DD_OK;
     DD_REQUIRE(frame && boxes_host && out, DD_E_ARG, "dd_crop_resize_f64: NULL argument");
     hipStream_t s = dd_pick_stream(ctx, stream);
@@ -691,6 +693,7 @@ int dd_crop_resize_f64(dd_ctx *ctx, const uint8_t *frame, int H, int W, const do
 
 int dd_fake_encode(dd_ctx *ctx, const uint8_t *patches, int n, int mode, float *out, void *stream) {
     DD_REQUIRE(ctx && n >= 0 && (mode == 0 || mode == 1), DD_E_ARG, "dd_fake_encode: bad argument");
+    DD_DEVICE(ctx);
     if (n == 0) return DD_OK;
     DD_REQUIRE(out && (mode == 1 || patches), DD_E_ARG, "dd_fake_encode: NULL argument");
     hipLaunchKernelGGL(fake_encode_k, dim3(dd_ceil_div(n, 4)), dim3(256), 0, dd_pick_stream(ctx, stream), patches, n, mode, out);
@@ -701,6 +704,7 @@ int dd_fake_encode(dd_ctx *ctx, const uint8_t *patches, int n, int mode, float *
 int dd_resize_lanczos(dd_ctx *ctx, const uint8_t *src, int H, int W, int src_c, int swap_rb, uint8_t *dst, int h,
                       int w, void *stream) {
     DD_REQUIRE(ctx && src && dst && H > 0 && W > 0 && h > 0 && w > 0, DD_E_ARG, "dd_resize_lanczos: bad argument");
+    DD_DEVICE(ctx);
     DD_REQUIRE(src_c == 3 || src_c == 4, DD_E_ARG, "dd_resize_lanczos: src_c must be 3 or 4");
     int rc;
     if ((rc = ctx->scratch[3].reserve((size_t)H * w * 3 + 64)) != DD_OK) return rc;
@@ -711,6 +715,7 @@ int dd_resize_lanczos(dd_ctx *ctx, const uint8_t *src, int H, int W, int src_c, 
 int dd_resize_bilinear(dd_ctx *ctx, const uint8_t *src, int H, int W, int c, uint8_t *dst, int h, int w,
                        void *stream) {
     DD_REQUIRE(ctx && src && dst && H > 0 && W > 0 && h > 0 && w > 0, DD_E_ARG, "dd_resize_bilinear: bad argument");
+    DD_DEVICE(ctx);
     DD_REQUIRE(c == 3, DD_E_ARG, "dd_resize_bilinear: 3-channel images only");
     hipStream_t s = dd_pick_stream(ctx, stream);
     int rc;

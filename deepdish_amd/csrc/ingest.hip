@@ -87,12 +87,14 @@ int dd_ingest_host_slot(dd_ingest *g, int slot, uint8_t **host_ptr, int64_t *n_b
 // The host may refill a pinned slot once its previous upload has left it.
 int dd_ingest_wait_uploaded(dd_ingest *g, int slot) {
     DD_REQUIRE(g && slot >= 0 && slot < g->slots, DD_E_ARG, "dd_ingest_wait_uploaded: bad slot");
+    DD_DEVICE(g->ctx);
     if (g->submitted[slot]) DD_HIP(hipEventSynchronize(g->ready[slot]));
     return DD_OK;
 }
 
 int dd_ingest_submit(dd_ingest *g, int slot) {
     DD_REQUIRE(g && slot >= 0 && slot < g->slots, DD_E_ARG, "dd_ingest_submit: bad slot");
+    DD_DEVICE(g->ctx);
     if (g->used[slot]) DD_HIP(hipStreamWaitEvent(g->copy, g->done[slot], 0));       // the previous consumer of this slot
     DD_HIP(hipMemcpyAsync(g->d_raw[slot], g->h_raw[slot], g->raw_bytes, hipMemcpyHostToDevice, g->copy));
     if (g->transform) {
@@ -106,6 +108,7 @@ int dd_ingest_submit(dd_ingest *g, int slot) {
 
 int dd_ingest_acquire(dd_ingest *g, int slot, void *consumer_stream, const uint8_t **frames_dev) {
     DD_REQUIRE(g && frames_dev && slot >= 0 && slot < g->slots, DD_E_ARG, "dd_ingest_acquire: bad argument");
+    DD_DEVICE(g->ctx);
     DD_HIP(hipStreamWaitEvent(dd_pick_stream(g->ctx, consumer_stream), g->ready[slot], 0));
     *frames_dev = g->d_out[slot];
     return DD_OK;
@@ -113,6 +116,7 @@ int dd_ingest_acquire(dd_ingest *g, int slot, void *consumer_stream, const uint8
 
 int dd_ingest_release(dd_ingest *g, int slot, void *consumer_stream) {
     DD_REQUIRE(g && slot >= 0 && slot < g->slots, DD_E_ARG, "dd_ingest_release: bad slot");
+    DD_DEVICE(g->ctx);
     DD_HIP(hipEventRecord(g->done[slot], dd_pick_stream(g->ctx, consumer_stream)));
     g->used[slot] = 1;
     return DD_OK;

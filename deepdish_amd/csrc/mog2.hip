@@ -257,12 +257,14 @@ int dd_mog2_destroy(dd_mog2 *m) {
 
 int dd_mog2_apply(dd_mog2 *m, const uint8_t *frames, double learning_rate, uint8_t *mask, uint8_t *masked_frames, void *stream) {
     DD_REQUIRE(m && frames && mask, DD_E_ARG, "dd_mog2_apply: NULL argument");
+    DD_DEVICE(m->ctx);
     return ddk::mog2_apply(m, dd_pick_stream(m->ctx, stream), frames, learning_rate, mask, masked_frames);
 }
 
 int dd_mog2_state(dd_mog2 *m, int stream_index, float *weight_host, float *variance_host, float *mean_host, uint8_t *nmodes_host) {
     DD_REQUIRE(m && stream_index >= 0 && stream_index < m->S && weight_host && variance_host && mean_host && nmodes_host, DD_E_ARG,
                "dd_mog2_state: bad argument");
+    DD_DEVICE(m->ctx);
     const size_t hw = (size_t)m->H * m->W;
     std::vector<float4> rec(hw * NMIX);
     std::vector<float> m2(hw * NMIX);
@@ -287,6 +289,7 @@ int dd_mask_box_count(dd_ctx *ctx, const uint8_t *mask, int n_streams, int heigh
                       const int *box_stream_host, int n_boxes, int *counts_host, void *stream) {
     DD_REQUIRE(ctx && mask && n_boxes >= 0 && (n_boxes == 0 || (boxes_xywh_host && box_stream_host && counts_host)), DD_E_ARG,
                "dd_mask_box_count: bad argument");
+    DD_DEVICE(ctx);
     if (n_boxes == 0) return DD_OK;
     for (int k = 0; k < n_boxes; ++k) {                     // shapes are checked here, never by a faulting kernel
         const int *b = boxes_xywh_host + (size_t)k * 4;

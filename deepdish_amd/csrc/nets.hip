@@ -1333,7 +1333,7 @@ inline size_t dtype_size(int dt) { return dt == DT_F16 ? 2 : (dt == DT_F32 ? 4 :
 // chain of (load -> barrier -> MFMA) steps is short; partial sums go through an f32 slab.
 // GLDS selects the direct-to-LDS kernel (needs padded Cin % 64 == 0 and BK == 64).
 template <int WM, int WN, int MI, int NI, int BK, bool GLDS>
-int launch_conv(hipStream_t s, ConvP &P, DevBuf &slab, int max_batch) {
+int launch_conv(hipStream_t s, ConvP &P, DevBuf &slab, int max_batch, int device) {
     constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
     const int gx = dd_ceil_div(P.m, BM), gy = dd_ceil_div(P.cout_pad, BN);
     const int ksteps = P.kpad / BK;
@@ -1362,21 +1362,23 @@ int launch_conv(hipStream_t s, ConvP &P, DevBuf &slab, int max_batch) {
     constexpr size_t stage_bytes = (size_t)2 * (BM + BN) * (GLDS ? 64 : BK + 8) * sizeof(_Float16);
     constexpr size_t out_bytes = BM * BN > 128 * 128 ? 0 : (size_t)BM * (BN + 4) * sizeof(float);   // big tiles: direct epilogue only
     constexpr size_t lds_bytes = stage_bytes > out_bytes ? stage_bytes : out_bytes;
-    static bool attr_done = false;                            // > 64 KiB of LDS needs the opt-in attribute
-    if (!attr_done && lds_bytes > 65536) {
-        if constexpr (GLDS)
-        {
-            DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_glds_k<WM, WN, MI, NI, 0>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-            DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_glds_k<WM, WN, MI, NI, 1>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-            DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_glds_k<WM, WN, MI, NI, 2>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        }
-        else
-            DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_k<WM, WN, MI, NI, BK>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        attr_done = true;
+    if (lds_bytes > 65536) {                                  // > 64 KiB of LDS needs the opt-in attribute, per device
+        static DevOnce once;
+        const int rc = once.run(device, [&]() -> int {
+            if constexpr (GLDS) {
+                DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_glds_k<WM, WN, MI, NI, 0>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+                DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_glds_k<WM, WN, MI, NI, 1>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+                DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_glds_k<WM, WN, MI, NI, 2>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            } else {
+                DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_k<WM, WN, MI, NI, BK>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            }
+            return DD_OK;
+        });
+        if (rc != DD_OK) return rc;
     }
     if constexpr (GLDS) {
         const bool pw = P.kh == 1 && P.kw == 1 && P.stride == 1 && P.pad_t == 0 && P.pad_l == 0 && P.cin % 64 == 0 &&
@@ -1410,7 +1412,7 @@ void spatial_tile(int ho, int wo, int stride, int max_patch, ConvP &P) {
     P.th = th; P.tw = tw; P.tiles_x = tiles_x; P.tiles_y = tiles_y;
 }
 
-int launch_conv3x3_rw(hipStream_t s, ConvP &P, int nimg, bool pool) {
+int launch_conv3x3_rw(hipStream_t s, ConvP &P, int nimg, bool pool, int device) {
     if (pool) {                                                  // 8 pooled rows per tile = 17 conv rows, full width
         P.tw = P.wo; P.th = 17; P.tiles_x = 1; P.tiles_y = dd_ceil_div(P.p[0], 8);
         DD_REQUIRE(P.wo == 32 && P.act == ACT_ELU && !P.res && !P.out2, DD_E_ARG, "conv3x3_rw: fused pooling needs a 32-wide ELU layer");
@@ -1422,11 +1424,14 @@ int launch_conv3x3_rw(hipStream_t s, ConvP &P, int nimg, bool pool) {
     const size_t lds_bytes = (size_t)4 * ((npix * 16 + 255) & ~255) + (pool ? (size_t)P.th * P.tw * 32 * sizeof(_Float16) : 0);
     const int total = nimg * P.tiles_x * P.tiles_y;
     const int grid = std::min(total, 2 * 256);                   // persistent: 2 blocks per CU (register-bound), multiple of 8
-    static bool attr_done = false;
-    if (pool && !attr_done) {
-        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_rw_k<2, 32, ACT_ELU, true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        attr_done = true;
+    if (pool) {
+        static DevOnce once;
+        const int rc = once.run(device, [&]() -> int {
+            DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_rw_k<2, 32, ACT_ELU, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            return DD_OK;
+        });
+        if (rc != DD_OK) return rc;
     }
     if (pool) {
         hipLaunchKernelGGL((conv3x3_rw_k<2, 32, ACT_ELU, true>), dim3((unsigned)grid), dim3(256), lds_bytes, s, P, total);
@@ -1461,18 +1466,21 @@ int launch_stem(hipStream_t s, ConvP &P, int nimg) {
 }
 
 template <int WM, int WN, int MI, int CIN, int STRIDE>
-int launch_dwpw(hipStream_t s, ConvP &P) {
+int launch_dwpw(hipStream_t s, ConvP &P, int device) {
     constexpr int BM = WM * MI * 16, BN = WN * 64;
     constexpr size_t lds_bytes = (size_t)(BM + BN) * CIN * sizeof(_Float16) + BM * sizeof(int);
     const dim3 grid((unsigned)dd_ceil_div(P.total_quads, BM / 4), (unsigned)dd_ceil_div(P.cout_pad, BN));
     const bool relu6 = P.act == ACT_RELU6 && P.dw_act == ACT_RELU6;
-    static bool attr_done = false;
-    if (!attr_done && lds_bytes > 65536) {
-        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dwpw_k<WM, WN, MI, CIN, STRIDE, ACT_RELU6, ACT_RELU6>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dwpw_k<WM, WN, MI, CIN, STRIDE, -1, -1>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        attr_done = true;
+    if (lds_bytes > 65536) {
+        static DevOnce once;
+        const int rc = once.run(device, [&]() -> int {
+            DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dwpw_k<WM, WN, MI, CIN, STRIDE, ACT_RELU6, ACT_RELU6>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dwpw_k<WM, WN, MI, CIN, STRIDE, -1, -1>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            return DD_OK;
+        });
+        if (rc != DD_OK) return rc;
     }
     if (relu6) hipLaunchKernelGGL((dwpw_k<WM, WN, MI, CIN, STRIDE, ACT_RELU6, ACT_RELU6>), grid, dim3(256), lds_bytes, s, P);
     else hipLaunchKernelGGL((dwpw_k<WM, WN, MI, CIN, STRIDE, -1, -1>), grid, dim3(256), lds_bytes, s, P);
@@ -1567,6 +1575,7 @@ int dd_net_output(dd_net *n, int tensor, void **dev_ptr, int *h, int *w, int *c,
 // Per-op device timing (HIP events on the launch stream) for bench.py's roofline line.
 int dd_net_profile(dd_net *n, int enable) {
     DD_REQUIRE(n, DD_E_ARG, "dd_net_profile: NULL net");
+    DD_DEVICE(n->ctx);
     if (enable && n->events.empty()) {
         n->events.resize(n->n_ops + 2);                 // + an empty bracket to price the event record itself
         for (auto &e : n->events) DD_HIP(hipEventCreate(&e));
@@ -1577,6 +1586,7 @@ int dd_net_profile(dd_net *n, int enable) {
 
 int dd_net_profile_read(dd_net *n, float *ms_host, int cap, int *n_ops_host) {
     DD_REQUIRE(n && ms_host && n_ops_host, DD_E_ARG, "dd_net_profile_read: NULL argument");
+    DD_DEVICE(n->ctx);
     DD_REQUIRE(n->profile && !n->events.empty(), DD_E_STATE, "dd_net_profile_read: profiling is off");
     DD_REQUIRE(cap >= n->n_ops, DD_E_ARG, "dd_net_profile_read: cap %d < %d ops", cap, n->n_ops);
     DD_HIP(hipEventSynchronize(n->events[n->n_ops + 1]));
@@ -1592,6 +1602,7 @@ int dd_net_profile_read(dd_net *n, float *ms_host, int cap, int *n_ops_host) {
 
 int dd_net_read(dd_net *n, int tensor, int n_img, void *dst, int dst_on_device, void *stream) {
     DD_REQUIRE(n && dst && n_img >= 0 && n_img <= n->max_batch, DD_E_ARG, "dd_net_read: bad argument");
+    DD_DEVICE(n->ctx);
     const int t = tensor < 0 ? n->out_tensor : tensor;
     DD_REQUIRE(t >= 0 && t < (int)n->tensors.size(), DD_E_ARG, "dd_net_read: tensor %d out of range", t);
     const TensorDesc &d = n->tensors[t];
@@ -1606,6 +1617,7 @@ int dd_net_read(dd_net *n, int tensor, int n_img, void *dst, int dst_on_device, 
 
 int dd_net_forward(dd_net *net, const uint8_t *input, int nimg, void *stream) {
     DD_REQUIRE(net && input && nimg >= 0, DD_E_ARG, "dd_net_forward: bad argument");
+    DD_DEVICE(net->ctx);
     DD_REQUIRE(nimg <= net->max_batch, DD_E_CAPACITY, "dd_net_forward: batch %d > max_batch %d", nimg, net->max_batch);
     if (nimg == 0) return DD_OK;
     net->last_batch = nimg;
@@ -1666,13 +1678,13 @@ int dd_net_forward(dd_net *net, const uint8_t *input, int nimg, void *stream) {
                     P.epi == EPI_F16 && P.pad_t == 1 && P.pad_l == 1) {
                     // whole filter in registers, input patch staged once (see conv3x3_rw_k)
                     if (o[29]) { P.p[0] = td->h; P.p[1] = td->w; }      // fused 3x3/2 max pool: dst is the pooled tensor
-                    rc = launch_conv3x3_rw(s, P, nimg, o[29] != 0);
+                    rc = launch_conv3x3_rw(s, P, nimg, o[29] != 0, net->ctx->device);
                 } else if (P.cout_pad <= 32) {
                     // 32 output channels: 128 pixels per block (each wave 32 px x 32 ch) once there are enough pixels
-                    rc = bk32 ? launch_conv<4, 1, 1, 2, 32, false>(s, P, net->slab, net->max_batch)
-                       : (glds && P.m >= 16384) ? launch_conv<4, 1, 2, 2, 64, true>(s, P, net->slab, net->max_batch)
-                       : glds ? launch_conv<4, 1, 1, 2, 64, true>(s, P, net->slab, net->max_batch)
-                              : launch_conv<4, 1, 1, 2, 64, false>(s, P, net->slab, net->max_batch);
+                    rc = bk32 ? launch_conv<4, 1, 1, 2, 32, false>(s, P, net->slab, net->max_batch, net->ctx->device)
+                       : (glds && P.m >= 16384) ? launch_conv<4, 1, 2, 2, 64, true>(s, P, net->slab, net->max_batch, net->ctx->device)
+                       : glds ? launch_conv<4, 1, 1, 2, 64, true>(s, P, net->slab, net->max_batch, net->ctx->device)
+                              : launch_conv<4, 1, 1, 2, 64, false>(s, P, net->slab, net->max_batch, net->ctx->device);
                 } else if (glds && net->tile_mode != 1 && P.m >= 16384 && P.cout_pad >= 128) {
                     // plenty of pixels: 128 x 128 with 8 waves -- a third less L2->LDS traffic per FLOP than 64 x 128
                     // (24.3 us vs 26.6 us for 19x19x512 -> 512 at 64 frames; at 10x10 it halves the block count and loses).
@@ -1683,19 +1695,19 @@ int dd_net_forward(dd_net *net, const uint8_t *input, int nimg, void *stream) {
                     const int c128 = dd_ceil_div(dd_ceil_div(P.m, 128) * gy128, 512) * 128;
                     const int c192 = dd_ceil_div(dd_ceil_div(P.m, 192) * gy128, 512) * 192;
                     if (P.epi == EPI_F16 && c192 <= c128 && net->tile_mode != 2)
-                        rc = launch_conv<4, 2, 3, 4, 64, true>(s, P, net->slab, net->max_batch);
+                        rc = launch_conv<4, 2, 3, 4, 64, true>(s, P, net->slab, net->max_batch, net->ctx->device);
                     else
-                        rc = launch_conv<4, 2, 2, 4, 64, true>(s, P, net->slab, net->max_batch);
+                        rc = launch_conv<4, 2, 2, 4, 64, true>(s, P, net->slab, net->max_batch, net->ctx->device);
                 } else if (glds && net->tile_mode != 1 && P.m >= 16384 && P.cout_pad == 64) {
-                    rc = launch_conv<4, 2, 2, 2, 64, true>(s, P, net->slab, net->max_batch);      // 128 x 64, 8 waves
+                    rc = launch_conv<4, 2, 2, 2, 64, true>(s, P, net->slab, net->max_batch, net->ctx->device);      // 128 x 64, 8 waves
                 } else if (glds && net->tile_mode != 1 && P.m >= 4096 && P.cout_pad >= 128) {
                     // 64 pixels x 128 channels: each staged pixel row feeds twice the MFMAs; measured 31 us vs 38 us
                     // for 19x19x512 -> 512 at 64 frames (128 x 64 gave nothing, 128 x 128 was 2.5x slower: 2 blocks/CU)
-                    rc = launch_conv<2, 2, 2, 4, 64, true>(s, P, net->slab, net->max_batch);
+                    rc = launch_conv<2, 2, 2, 4, 64, true>(s, P, net->slab, net->max_batch, net->ctx->device);
                 } else {
-                    rc = bk32 ? launch_conv<2, 2, 2, 2, 32, false>(s, P, net->slab, net->max_batch)
-                       : glds ? launch_conv<2, 2, 2, 2, 64, true>(s, P, net->slab, net->max_batch)
-                              : launch_conv<2, 2, 2, 2, 64, false>(s, P, net->slab, net->max_batch);
+                    rc = bk32 ? launch_conv<2, 2, 2, 2, 32, false>(s, P, net->slab, net->max_batch, net->ctx->device)
+                       : glds ? launch_conv<2, 2, 2, 2, 64, true>(s, P, net->slab, net->max_batch, net->ctx->device)
+                              : launch_conv<2, 2, 2, 2, 64, false>(s, P, net->slab, net->max_batch, net->ctx->device);
                 }
                 if (rc != DD_OK) return rc;
                 break;
@@ -1731,10 +1743,10 @@ int dd_net_forward(dd_net *net, const uint8_t *input, int nimg, void *stream) {
                 P.total_quads = nimg * P.ho * ((P.wo + 3) / 4);
                 P.out = base(dst); P.cs_out = td->cs; P.coff_out = td->coff;
                 int rc;
-                if (P.cin == 32 && P.cout_pad == 64 && P.stride == 1) rc = launch_dwpw<4, 1, 4, 32, 1>(s, P);
-                else if (P.cin == 64 && P.cout_pad == 128 && P.stride == 2) rc = launch_dwpw<2, 2, 4, 64, 2>(s, P);
-                else if (P.cin == 128 && P.cout_pad == 128 && P.stride == 1) rc = launch_dwpw<2, 2, 2, 128, 1>(s, P);
-                else if (P.cin == 128 && P.cout_pad == 256 && P.stride == 2) rc = launch_dwpw<1, 4, 4, 128, 2>(s, P);
+                if (P.cin == 32 && P.cout_pad == 64 && P.stride == 1) rc = launch_dwpw<4, 1, 4, 32, 1>(s, P, net->ctx->device);
+                else if (P.cin == 64 && P.cout_pad == 128 && P.stride == 2) rc = launch_dwpw<2, 2, 4, 64, 2>(s, P, net->ctx->device);
+                else if (P.cin == 128 && P.cout_pad == 128 && P.stride == 1) rc = launch_dwpw<2, 2, 2, 128, 1>(s, P, net->ctx->device);
+                else if (P.cin == 128 && P.cout_pad == 256 && P.stride == 2) rc = launch_dwpw<1, 4, 4, 128, 2>(s, P, net->ctx->device);
                 else DD_REQUIRE(false, DD_E_ARG, "dd_net_forward: no fused dw+pw kernel for %d -> %d stride %d", P.cin, P.cout_pad, P.stride);
                 if (rc != DD_OK) return rc;
                 break;

@@ -18,6 +18,8 @@ struct dd_mog2;
 namespace ddk {
 int mog2_apply(dd_mog2 *m, hipStream_t s, const uint8_t *frames, double learning_rate, uint8_t *mask, uint8_t *masked);
 int mask_box_count(hipStream_t s, const uint8_t *mask, int H, int W, const int *d_boxes, const int *d_box_stream, int K, int *d_counts);
+int ssd_finish(hipStream_t s, const float *boxes, const float *cls, const float *scores, int batch, int max_det, double conf,
+               double iou_thr, double img_w, double img_h, double *out_boxes, int *out_cls, double *out_scores, int *out_n);
 int tracker_group_create(dd_ctx *ctx, int n, double max_cos, double max_iou, int max_age, int n_init, int budget, int tcap,
                          int gcap, dd_tracker **out);
 int trackers_predict(dd_tracker **ts, int S);
@@ -32,65 +34,6 @@ namespace {
 
 constexpr int MAX_DET = 10;              // N_max of the stock SSD post-process op
 enum { CONFIRMED = 2, DELETED = 3 };
-
-// tools/ssd_mobilenet.py:111-150 on the <= 10 rows the post-process op returns, one wave per image
-// (lane 0 does the O(100) work): NaN scrub, score >= confidence, reorder + scale to pixels (f64),
-// per-class NMS with the +1-on-intersection-only IoU (:59-98).  Classes are visited in ascending
-// id (the reference walks a Python set); the order is irrelevant downstream (NMS re-sorts by score).
-__global__ void ssd_finish_k(const float *__restrict__ boxes, const float *__restrict__ cls, const float *__restrict__ scores,
-                             double conf, double iou_thr, double img_w, double img_h, double *__restrict__ out_boxes,
-                             int *__restrict__ out_cls, double *__restrict__ out_scores, int *__restrict__ out_n) {
-    if (threadIdx.x != 0) return;
-    const int z = blockIdx.x;
-    boxes += (size_t)z * MAX_DET * 4; cls += (size_t)z * MAX_DET; scores += (size_t)z * MAX_DET;
-    out_boxes += (size_t)z * MAX_DET * 4; out_cls += (size_t)z * MAX_DET; out_scores += (size_t)z * MAX_DET;
-    float sc[MAX_DET];
-    for (int i = 0; i < MAX_DET; ++i) sc[i] = scores[i];
-    for (int i = 0; i < MAX_DET; ++i)
-        for (int c = 0; c < 4; ++c)
-            if (isnan(boxes[i * 4 + c])) { sc[i] = 0.f; sc[c] = 0.f; }     // :111-113 (np.where rows AND cols)
-    for (int i = 0; i < MAX_DET; ++i) if (isnan(sc[i])) sc[i] = 0.f;      // :115-116
-    double bx[MAX_DET][4];
-    bool live[MAX_DET];
-    for (int i = 0; i < MAX_DET; ++i) {
-        live[i] = sc[i] >= (float)conf;
-        bx[i][0] = (double)boxes[i * 4 + 1] * img_w;                      // :121-127 reorder [1,0,3,2] * [w,h,w,h]
-        bx[i][1] = (double)boxes[i * 4 + 0] * img_h;
-        bx[i][2] = (double)boxes[i * 4 + 3] * img_w;
-        bx[i][3] = (double)boxes[i * 4 + 2] * img_h;
-    }
-    int n = 0;
-    bool done[MAX_DET] = {false};
-    for (;;) {
-        int cmin = 1 << 30;
-        for (int i = 0; i < MAX_DET; ++i) if (live[i] && !done[i]) cmin = min(cmin, (int)cls[i]);
-        if (cmin == (1 << 30)) break;
-        bool dead[MAX_DET] = {false};
-        for (;;) {                                                        // greedy by descending score within the class
-            int best = -1;
-            for (int i = 0; i < MAX_DET; ++i)
-                if (live[i] && !done[i] && (int)cls[i] == cmin && !dead[i] && (best < 0 || sc[i] > sc[best])) best = i;
-            if (best < 0) break;
-            done[best] = true;
-            for (int q = 0; q < 4; ++q) out_boxes[n * 4 + q] = bx[best][q];
-            out_cls[n] = cmin;
-            out_scores[n] = (double)sc[best];
-            ++n;
-            const double x = bx[best][0], y = bx[best][1], w = bx[best][2] - bx[best][0], h = bx[best][3] - bx[best][1];
-            for (int j = 0; j < MAX_DET; ++j) {
-                if (!live[j] || done[j] || (int)cls[j] != cmin || dead[j]) continue;
-                const double xj = bx[j][0], yj = bx[j][1], wj = bx[j][2] - bx[j][0], hj = bx[j][3] - bx[j][1];
-                const double xx1 = fmax(x, xj), yy1 = fmax(y, yj);
-                const double xx2 = fmin(x + w, xj + wj), yy2 = fmin(y + h, yj + hj);
-                const double w1 = fmax(0.0, xx2 - xx1 + 1), h1 = fmax(0.0, yy2 - yy1 + 1);
-                const double inter = w1 * h1;
-                const double ovr = inter / (w * h + wj * hj - inter);
-                if (!(ovr <= iou_thr)) { dead[j] = true; done[j] = true; }
-            }
-        }
-    }
-    out_n[z] = n;
-}
 
 struct Votes {                         // track.py:78-81,147-151: label -> confidences, in first-seen order
     std::vector<int> cls;
@@ -287,6 +230,7 @@ int dd_pipeline_destroy(dd_pipeline *p) {
 // --enable-background-masking (the detector and the encoder then see cv2.bitwise_and(frame, frame, mask=fgMask)).
 int dd_pipeline_background_subtraction(dd_pipeline *p, double ratio, int masking) {
     DD_REQUIRE(p && !(ratio > 1.0), DD_E_ARG, "dd_pipeline_background_subtraction: ratio must be <= 1 (negative = off)");
+    DD_DEVICE(p->ctx);
     DD_HIP(hipStreamSynchronize(p->ctx->stream));
     if (p->det_stream) DD_HIP(hipStreamSynchronize(p->det_stream));
     p->det_pending = nullptr;                    // a detector run queued ahead is dropped: it may not match the new setting
@@ -305,6 +249,7 @@ int dd_pipeline_background_subtraction(dd_pipeline *p, double ratio, int masking
 // only the number of boxes the motion test has rejected so far.
 int dd_pipeline_motion_mask(dd_pipeline *p, uint8_t *dst, int dst_on_device, long long *rejected_host) {
     DD_REQUIRE(p, DD_E_ARG, "dd_pipeline_motion_mask: NULL argument");
+    DD_DEVICE(p->ctx);
     if (rejected_host) *rejected_host = p->motion_rejected;
     if (!dst) return DD_OK;
     DD_REQUIRE(p->mog2, DD_E_ARG, "dd_pipeline_motion_mask: background subtraction is off");
@@ -359,9 +304,8 @@ int enqueue_detector(dd_pipeline *p, const uint8_t *frames) {
                                    1e-8f, 0.6f, db, dc, ds, dn, S, p->d_post.p, p->d_post.cap)) != DD_OK) return rc;
     double *fb = p->d_fin.as<double>(), *fs = fb + (size_t)S * MAX_DET * 4;
     int *fc = reinterpret_cast<int *>(fs + (size_t)S * MAX_DET), *fn = fc + (size_t)S * MAX_DET;
-    hipLaunchKernelGGL(ssd_finish_k, dim3(S), dim3(64), 0, s, db, dc, ds, p->det_conf, 0.5, (double)p->W, (double)p->H, fb,
-                       fc, fs, fn);
-    DD_LAUNCH_CHECK();
+    if ((rc = ddk::ssd_finish(s, db, dc, ds, S, MAX_DET, p->det_conf, 0.5, (double)p->W, (double)p->H, fb, fc, fs, fn)) != DD_OK)
+        return rc;                                                                                    // :111-150
     const size_t fbytes = (size_t)S * (MAX_DET * (4 * 8 + 8 + 4) + 4);
     DD_HIP(hipMemcpyAsync(p->h_fin.p, p->d_fin.p, fbytes, hipMemcpyDeviceToHost, s));
     DD_HIP(hipEventRecord(p->det_done, s));
@@ -389,6 +333,10 @@ int dd_pipeline_step(dd_pipeline *p, const uint8_t *frames, const double *inj_bo
 int dd_pipeline_step2(dd_pipeline *p, const uint8_t *frames_in, const uint8_t *frames_next, const double *inj_boxes_host,
                       const double *inj_scores_host, const int *inj_cls_host, const int *inj_offsets_host) {
     DD_REQUIRE(p && frames_in, DD_E_ARG, "dd_pipeline_step: NULL argument");
+    DD_REQUIRE(frames_next != frames_in, DD_E_ARG,
+               "dd_pipeline_step2: frames_next must be a different buffer from frames (its detector run is queued while "
+               "this step still reads frames, and the next step consumes it by address)");
+    DD_DEVICE(p->ctx);
     const uint8_t *frames = frames_in;
     hipStream_t s = p->ctx->stream;
     const int S = p->S;

@@ -88,6 +88,68 @@ __global__ void ssd_gather_k(const int *__restrict__ keep, const int *__restrict
     if (i == 0) *out_count = __popcll(b);
 }
 
+// tools/ssd_mobilenet.py:111-150 (SSDMobileNet.predict after the four get_tensor calls) on the <= 16 rows the
+// post-process op returns, one wave per image (lane 0 does the O(100) work): NaN scrub, score >= confidence,
+// reorder + scale to pixels (f64), per-class nms_boxes with its own overlap formula (:59-98: +1 on the intersection
+// extents only, areas without it, survivors ovr <= thr).  Classes are emitted in ascending id -- the reference
+// walks a Python set; the order is irrelevant downstream (deep_sort's NMS re-sorts by score) -- and inside a
+// class in pick order (descending score), exactly as nms_boxes returns them.
+constexpr int FIN_MAX = 16;
+__global__ void ssd_finish_k(const float *__restrict__ boxes, const float *__restrict__ cls, const float *__restrict__ scores,
+                             int max_det, double conf, double iou_thr, double img_w, double img_h, double *__restrict__ out_boxes,
+                             int *__restrict__ out_cls, double *__restrict__ out_scores, int *__restrict__ out_n) {
+    if (threadIdx.x != 0) return;
+    const int z = blockIdx.x, N = max_det;
+    boxes += (size_t)z * N * 4; cls += (size_t)z * N; scores += (size_t)z * N;
+    out_boxes += (size_t)z * N * 4; out_cls += (size_t)z * N; out_scores += (size_t)z * N;
+    float sc[FIN_MAX];
+    for (int i = 0; i < N; ++i) sc[i] = scores[i];
+    for (int i = 0; i < N; ++i)
+        for (int c = 0; c < 4; ++c)
+            if (isnan(boxes[i * 4 + c])) { sc[i] = 0.f; if (c < N) sc[c] = 0.f; }   // :111-113 (np.where rows AND cols)
+    for (int i = 0; i < N; ++i) if (isnan(sc[i])) sc[i] = 0.f;            // :115-116
+    double bx[FIN_MAX][4];
+    bool live[FIN_MAX];
+    for (int i = 0; i < N; ++i) {
+        live[i] = sc[i] >= (float)conf;                                   // :119
+        bx[i][0] = (double)boxes[i * 4 + 1] * img_w;                      // :121-127 reorder [1,0,3,2] * [w,h,w,h]
+        bx[i][1] = (double)boxes[i * 4 + 0] * img_h;
+        bx[i][2] = (double)boxes[i * 4 + 3] * img_w;
+        bx[i][3] = (double)boxes[i * 4 + 2] * img_h;
+    }
+    int n = 0;
+    bool done[FIN_MAX] = {false};
+    for (;;) {
+        int cmin = 1 << 30;
+        for (int i = 0; i < N; ++i) if (live[i] && !done[i]) cmin = min(cmin, (int)cls[i]);
+        if (cmin == (1 << 30)) break;
+        bool dead[FIN_MAX] = {false};
+        for (;;) {                                                        // greedy by descending score within the class
+            int best = -1;
+            for (int i = 0; i < N; ++i)
+                if (live[i] && !done[i] && (int)cls[i] == cmin && !dead[i] && (best < 0 || sc[i] > sc[best])) best = i;
+            if (best < 0) break;
+            done[best] = true;
+            for (int q = 0; q < 4; ++q) out_boxes[n * 4 + q] = bx[best][q];
+            out_cls[n] = cmin;
+            out_scores[n] = (double)sc[best];
+            ++n;
+            const double x = bx[best][0], y = bx[best][1], w = bx[best][2] - bx[best][0], h = bx[best][3] - bx[best][1];
+            for (int j = 0; j < N; ++j) {
+                if (!live[j] || done[j] || (int)cls[j] != cmin || dead[j]) continue;
+                const double xj = bx[j][0], yj = bx[j][1], wj = bx[j][2] - bx[j][0], hj = bx[j][3] - bx[j][1];
+                const double xx1 = fmax(x, xj), yy1 = fmax(y, yj);
+                const double xx2 = fmin(x + w, xj + wj), yy2 = fmin(y + h, yj + hj);
+                const double w1 = fmax(0.0, xx2 - xx1 + 1), h1 = fmax(0.0, yy2 - yy1 + 1);
+                const double inter = w1 * h1;
+                const double ovr = inter / (w * h + wj * hj - inter);
+                if (!(ovr <= iou_thr)) { dead[j] = true; done[j] = true; }
+            }
+        }
+    }
+    out_n[z] = n;
+}
+
 // tools/yolov5.py:120-131, first half: per-row confidence and class
 __global__ __launch_bounds__(256) void yolo_conf_k(const float *__restrict__ raw, int n_rows, int n_cls,
                                                    float *__restrict__ conf, int *__restrict__ cls) {
@@ -191,14 +253,34 @@ int ssd_postprocess(hipStream_t s, const float *raw, const float *anchors, int n
     return DD_OK;
 }
 
+int ssd_finish(hipStream_t s, const float *boxes, const float *cls, const float *scores, int batch, int max_det, double conf,
+               double iou_thr, double img_w, double img_h, double *out_boxes, int *out_cls, double *out_scores, int *out_n) {
+    DD_REQUIRE(batch > 0 && max_det > 0 && max_det <= FIN_MAX, DD_E_ARG, "ssd_finish: batch %d, max_det %d (<= %d)", batch, max_det, FIN_MAX);
+    hipLaunchKernelGGL(ssd_finish_k, dim3(batch), dim3(64), 0, s, boxes, cls, scores, max_det, conf, iou_thr, img_w, img_h,
+                       out_boxes, out_cls, out_scores, out_n);
+    DD_LAUNCH_CHECK();
+    return DD_OK;
+}
+
 }  // namespace ddk
 
 extern "C" {
+
+int dd_ssd_detections(dd_ctx *ctx, const float *boxes, const float *classes, const float *scores, int batch, int max_det,
+                      double confidence, double iou_thr, double img_w, double img_h, double *out_boxes, int *out_cls,
+                      double *out_scores, int *out_n, void *stream) {
+    DD_REQUIRE(ctx && boxes && classes && scores && out_boxes && out_cls && out_scores && out_n, DD_E_ARG,
+               "dd_ssd_detections: NULL argument");
+    DD_DEVICE(ctx);
+    return ddk::ssd_finish(dd_pick_stream(ctx, stream), boxes, classes, scores, batch, max_det, confidence, iou_thr, img_w, img_h,
+                           out_boxes, out_cls, out_scores, out_n);
+}
 
 int dd_ssd_postprocess(dd_ctx *ctx, const float *raw, const float *anchors, int n_anchors, int n_classes, int max_det,
                        float score_thr, float iou_thr, float *boxes, float *classes, float *scores, int *count,
                        void *stream) {
     DD_REQUIRE(ctx && raw && anchors && boxes && classes && scores && count, DD_E_ARG, "dd_ssd_postprocess: NULL argument");
+    DD_DEVICE(ctx);
     int rc;
     const size_t need = ddk::ssd_post_scratch_bytes(n_anchors, 1);
     if ((rc = ctx->scratch[2].reserve(need)) != DD_OK) return rc;
@@ -210,6 +292,7 @@ int dd_yolov5_decode(dd_ctx *ctx, const float *raw, int n_rows, int n_cls, float
                      float *out_boxes, float *out_scores, int *out_cls, int cap, int *out_n, void *stream) {
     DD_REQUIRE(ctx && raw && out_boxes && out_scores && out_cls && out_n && n_rows >= 0 && n_cls > 0 && cap >= 0,
                DD_E_ARG, "dd_yolov5_decode: bad argument");
+    DD_DEVICE(ctx);
     hipStream_t s = dd_pick_stream(ctx, stream);
     if (n_rows == 0) { DD_HIP(hipMemsetAsync(out_n, 0, sizeof(int), s)); return DD_OK; }
     int rc;
@@ -226,6 +309,7 @@ int dd_yolov5_decode(dd_ctx *ctx, const float *raw, int n_rows, int n_cls, float
 
 int dd_counts_accumulate(dd_ctx *ctx, int64_t *acc, const int64_t *counts_host, int n, void *stream) {
     DD_REQUIRE(ctx && acc && counts_host && n > 0, DD_E_ARG, "dd_counts_accumulate: bad argument");
+    DD_DEVICE(ctx);
     hipStream_t s = dd_pick_stream(ctx, stream);
     int rc;
     if ((rc = ctx->scratch[1].reserve((size_t)n * 8)) != DD_OK) return rc;

@@ -15,9 +15,12 @@
 //             host        -- per stream: matching cascade + LSAP on the small cost matrices;
 //             K2 "apply"  -- Kalman update / initiate + gallery append for the decided pairs;
 //             gather      -- means of all live / just-deleted tracks back to the host.
-// Layout: means[slot][8] f64, covs[slot][64] f64, gallery[slot][gcap][128] f32 (rows already
-// L2-normalised, ring buffer); a stream owns the slot range [slot_base, slot_base + tcap) of a pool,
-// slots recycled through a per-stream free list.
+// Layout: means[slot][8] f64, covs[slot][64] f64; a stream owns the slot range [slot_base, slot_base + tcap) of
+// a pool, slots recycled through a per-stream free list.  Appearance gallery: rows of 128 f32 (already
+// L2-normalised) in 32-row chunks drawn from 64 MiB arenas shared by the group; a track owns a chunk LIST (device
+// table tab[slot][stride]), extended whenever the track is matched -- nn_budget=None upstream keeps every sample
+// (deepdish.py:515, nn_matching.py:137-154), so a gallery has no fixed capacity here either; with nn_budget = B
+// the last B samples are kept (a ring over ceil(B / 32) chunks).  Chunks return to the pool with the track's slot.
 #include <algorithm>
 #include <numeric>
 #include "common.h"
@@ -43,11 +46,11 @@ __device__ __forceinline__ void tlwh_to_xyah(const double *b, double z[4]) {
 // grid (R rows of all streams, ceil(max n_det / 64)); 4 waves, 16 detections per wave.  Row r belongs to
 // one stream and sees only that stream's detections [det_off, det_off + n_det).
 __global__ __launch_bounds__(256) void tracker_assoc_k(
-    const double *__restrict__ means, const double *__restrict__ covs, const float *__restrict__ gallery,
-    int gcap, const int *__restrict__ row_slot, const int *__restrict__ row_state, const int *__restrict__ row_tsu,
-    const int *__restrict__ row_det_off, const int *__restrict__ row_ndet, const int *__restrict__ row_cost_off,
-    const int *__restrict__ row_iou_delta, const int *__restrict__ gal_count, const double *__restrict__ det_tlwh,
-    const float *__restrict__ feats_n, double *__restrict__ cost) {
+    const double *__restrict__ means, const double *__restrict__ covs, float *const *__restrict__ arenas,
+    const int *__restrict__ tab, int tab_stride, const int *__restrict__ row_slot, const int *__restrict__ row_state,
+    const int *__restrict__ row_tsu, const int *__restrict__ row_det_off, const int *__restrict__ row_ndet,
+    const int *__restrict__ row_cost_off, const int *__restrict__ row_iou_delta, const int *__restrict__ row_gcount,
+    const double *__restrict__ det_tlwh, const float *__restrict__ feats_n, double *__restrict__ cost) {
     const int row = blockIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n_det = row_ndet[row];
@@ -58,8 +61,8 @@ __global__ __launch_bounds__(256) void tracker_assoc_k(
     const bool confirmed = row_state[row] == CONFIRMED;
     float best = 0.f;
     if (confirmed)                                            // wave-uniform branch around the MFMAs
-        best = nn_max_dot(gallery + (size_t)slot * gcap * 128, gal_count[slot], feats_n + (size_t)det_off * 128, d0,
-                          n_det, lane);
+        best = nn_max_dot(ChunkRows{arenas, tab + (size_t)slot * tab_stride}, row_gcount[row],
+                          feats_n + (size_t)det_off * 128, d0, n_det, lane);
     const int d = d0 + (lane & 15);
     if ((lane >> 4) != 0 || d >= n_det) return;
     const double *m = means + (size_t)slot * 8;
@@ -87,33 +90,28 @@ __global__ __launch_bounds__(256) void tracker_assoc_k(
 }
 
 // One wave per decided pair: [0, n_upd) Kalman update + gallery append; [n_upd, n_upd+n_new) new track.
+// pair_row = chunk * 32 + row inside the chunk: where the host placed this sample (track.py:140 features.append).
 __global__ __launch_bounds__(256) void tracker_apply_k(
-    double *__restrict__ means, double *__restrict__ covs, float *__restrict__ gallery, int gcap,
-    int *__restrict__ gal_count, int *__restrict__ gal_total, const int *__restrict__ pair_slot,
-    const int *__restrict__ pair_det, const int *__restrict__ pair_cap, int n_upd, int n_new,
-    const double *__restrict__ det_tlwh, const float *__restrict__ feats_n) {
+    double *__restrict__ means, double *__restrict__ covs, float *const *__restrict__ arenas,
+    const int *__restrict__ pair_slot, const int *__restrict__ pair_det, const int *__restrict__ pair_row, int n_upd,
+    int n_new, const double *__restrict__ det_tlwh, const float *__restrict__ feats_n) {
     const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (w >= n_upd + n_new) return;
-    const int slot = pair_slot[w], det = pair_det[w], cap_eff = pair_cap[w];
+    const int slot = pair_slot[w], det = pair_det[w], grow = pair_row[w];
     double z[4];
     tlwh_to_xyah(det_tlwh + (size_t)det * 4, z);
     double *P = covs + (size_t)slot * 64, *m = means + (size_t)slot * 8;
-    int total;
-    if (w < n_upd) {
-        update_wave(P, m, z, lane);                           // track.py:138-139
-        total = gal_total[slot];
-    } else {
-        initiate_wave(P, m, z, lane);                         // tracker.py:135-138
-        total = 0;
-    }
-    const int pos = total % cap_eff;                          // track.py:140 features.append (ring when full)
+    if (w < n_upd) update_wave(P, m, z, lane);                // track.py:138-139
+    else initiate_wave(P, m, z, lane);                        // tracker.py:135-138
     const float2 f = reinterpret_cast<const float2 *>(feats_n + (size_t)det * 128)[lane];
-    reinterpret_cast<float2 *>(gallery + ((size_t)slot * gcap + pos) * 128)[lane] = f;
-    if (lane == 0) {
-        gal_total[slot] = total + 1;
-        gal_count[slot] = min(total + 1, cap_eff);
-    }
+    reinterpret_cast<float2 *>(gal_row(arenas, grow >> GAL_CH_SHIFT, grow & (GAL_CH - 1)))[lane] = f;
+}
+
+// tab[idx[i]] = val[i]: the chunk-table entries of this step's new chunks
+__global__ void tab_scatter_k(int *__restrict__ tab, const int *__restrict__ upd, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) tab[upd[2 * i]] = upd[2 * i + 1];
 }
 
 struct TrackRec {
@@ -124,12 +122,22 @@ struct TrackRec {
 }  // namespace
 
 // Device state shared by the trackers of one group + the group's staging buffers.
+constexpr int GAL_MAX_ARENAS = 4096;                      // x 64 MiB = 256 GiB: bounded by device memory, not by this
 struct TrackerPool {
     dd_ctx *ctx = nullptr;
-    int slots = 0, gcap = 0, refs = 0;
+    int slots = 0, refs = 0;
     double *d_means = nullptr, *d_covs = nullptr;
-    float *d_gallery = nullptr;
-    int *d_gal_count = nullptr, *d_gal_total = nullptr;
+    // gallery: arenas of GAL_ARENA_CHUNKS chunks, per-slot chunk lists (host) mirrored in d_tab[slot][tab_stride]
+    std::vector<float *> arenas;
+    float **d_arenas = nullptr;
+    std::vector<int> free_chunks;
+    std::vector<std::vector<int>> slot_chunks;
+    std::vector<int> slot_total;                          // samples appended to the slot's track so far
+    int *d_tab = nullptr, tab_stride = 0;
+    std::vector<int> tab_upd;                             // (table index, chunk) pairs not yet on the device
+    bool tab_rebuild = false;                             // the stride grew: rewrite the whole table
+    DevBuf d_tabupd;
+    PinBuf h_tabupd;
     DevBuf d_pred, d_in, d_feats_raw, d_feats_n, d_cost, d_pairs, d_gather;
     PinBuf h_pred, h_in, h_cost, h_pairs, h_gather;
     bool pred_inflight = false;
@@ -150,7 +158,7 @@ struct dd_tracker {
     std::vector<double> live_means, dead_means;           // host mirrors, [n][8]
     std::vector<int> last_pairs;                          // (track row before update, detection)
     int64_t next_id = 1;
-    int ph_n = 0, ph_T = 0;
+    int ph_n = 0, ph_T = 0, ph_cost_base = -1;            // ph_cost_base: where this tracker's cost matrices sit in pool->h_cost
 };
 
 namespace {
@@ -189,28 +197,120 @@ void min_cost_matching(const double *full, int n_det, double max_distance, const
     }
 }
 
-int pool_create(dd_ctx *ctx, int slots, int gcap, TrackerPool **out) {
+int pool_create(dd_ctx *ctx, int slots, int gallery_rows_hint, TrackerPool **out) {
     TrackerPool *p = new TrackerPool();
-    p->ctx = ctx; p->slots = slots; p->gcap = gcap;
+    p->ctx = ctx; p->slots = slots;
     DD_HIP(hipSetDevice(ctx->device));
     DD_HIP(hipMalloc(&p->d_means, (size_t)slots * 8 * sizeof(double)));
     DD_HIP(hipMalloc(&p->d_covs, (size_t)slots * 64 * sizeof(double)));
-    DD_HIP(hipMalloc(&p->d_gallery, (size_t)slots * gcap * 128 * sizeof(float)));
-    DD_HIP(hipMalloc(&p->d_gal_count, (size_t)slots * sizeof(int)));
-    DD_HIP(hipMalloc(&p->d_gal_total, (size_t)slots * sizeof(int)));
-    DD_HIP(hipMemsetAsync(p->d_gal_count, 0, (size_t)slots * sizeof(int), ctx->stream));
-    DD_HIP(hipMemsetAsync(p->d_gal_total, 0, (size_t)slots * sizeof(int), ctx->stream));
-    DD_HIP(hipStreamSynchronize(ctx->stream));
+    DD_HIP(hipMalloc(&p->d_arenas, (size_t)GAL_MAX_ARENAS * sizeof(float *)));
+    DD_HIP(hipMemset(p->d_arenas, 0, (size_t)GAL_MAX_ARENAS * sizeof(float *)));
+    p->tab_stride = std::max(1, dd_ceil_div(gallery_rows_hint, GAL_CH));
+    DD_HIP(hipMalloc(&p->d_tab, (size_t)slots * p->tab_stride * sizeof(int)));
+    DD_HIP(hipMemset(p->d_tab, 0, (size_t)slots * p->tab_stride * sizeof(int)));
+    p->slot_chunks.resize(slots);
+    p->slot_total.assign(slots, 0);
     *out = p;
+    return DD_OK;
+}
+
+// One more 64 MiB arena of gallery chunks.  Running out of device memory is the only capacity limit of a gallery.
+int pool_add_arena(TrackerPool *p) {
+    DD_REQUIRE((int)p->arenas.size() < GAL_MAX_ARENAS, DD_E_CAPACITY, "tracker gallery: %d arenas of 64 MiB exhausted", GAL_MAX_ARENAS);
+    float *a = nullptr;
+    const hipError_t e = hipMalloc(&a, (size_t)GAL_ARENA_CHUNKS * GAL_CH * 128 * sizeof(float));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        dd_set_error("tracker gallery: device memory exhausted after %zu arenas of 64 MiB (%s); nn_budget bounds a gallery",
+                     p->arenas.size(), hipGetErrorString(e));
+        return DD_E_CAPACITY;
+    }
+    const int k = (int)p->arenas.size();
+    p->arenas.push_back(a);
+    DD_HIP(hipMemcpy(p->d_arenas + k, &a, sizeof(float *), hipMemcpyHostToDevice));
+    for (int c = GAL_ARENA_CHUNKS - 1; c >= 0; --c) p->free_chunks.push_back(k * GAL_ARENA_CHUNKS + c);
+    return DD_OK;
+}
+
+// Where the next sample of `slot`'s track goes (track.py:140 / nn_matching.py:150-153): row `total` of its chunk
+// list, or row total % budget with nn_budget; a new chunk is taken from the pool when the list is too short.
+int gallery_place(TrackerPool *p, int slot, int budget, int *row_out) {
+    const int total = p->slot_total[slot];
+    const int pos = budget > 0 ? total % budget : total;
+    const int ci = pos >> GAL_CH_SHIFT;
+    std::vector<int> &chs = p->slot_chunks[slot];
+    if (ci >= (int)chs.size()) {
+        if (ci >= p->tab_stride) {                            // rare: double the table (flushed before the next launch reads it)
+            while (ci >= p->tab_stride) p->tab_stride *= 2;
+            p->tab_rebuild = true;
+        }
+        if (p->free_chunks.empty()) {
+            const int rc = pool_add_arena(p);
+            if (rc != DD_OK) return rc;
+        }
+        const int c = p->free_chunks.back();
+        p->free_chunks.pop_back();
+        chs.push_back(c);
+        p->tab_upd.push_back(slot);                           // resolved against the final stride in gallery_flush
+        p->tab_upd.push_back(ci);
+        p->tab_upd.push_back(c);
+    }
+    *row_out = chs[ci] * GAL_CH + (pos & (GAL_CH - 1));
+    p->slot_total[slot] = total + 1;
+    return DD_OK;
+}
+
+inline int gallery_count(const TrackerPool *p, int slot, int budget) {
+    const int total = p->slot_total[slot];
+    return budget > 0 ? std::min(total, budget) : total;
+}
+
+void gallery_free_slot(TrackerPool *p, int slot) {
+    for (int c : p->slot_chunks[slot]) p->free_chunks.push_back(c);
+    p->slot_chunks[slot].clear();
+    p->slot_total[slot] = 0;
+}
+
+// Bring the device chunk table up to date (same stream, after the launches that used the old contents).
+int gallery_flush(TrackerPool *p, hipStream_t s) {
+    if (p->tab_rebuild) {
+        DD_HIP(hipStreamSynchronize(s));                       // nothing in flight may still read the old table
+        DD_HIP(hipFree(p->d_tab));
+        p->d_tab = nullptr;
+        const size_t n = (size_t)p->slots * p->tab_stride;
+        DD_HIP(hipMalloc(&p->d_tab, n * sizeof(int)));
+        std::vector<int> host(n, 0);
+        for (int sl = 0; sl < p->slots; ++sl)
+            for (size_t i = 0; i < p->slot_chunks[sl].size(); ++i) host[(size_t)sl * p->tab_stride + i] = p->slot_chunks[sl][i];
+        DD_HIP(hipMemcpy(p->d_tab, host.data(), n * sizeof(int), hipMemcpyHostToDevice));
+        p->tab_rebuild = false;
+        p->tab_upd.clear();
+        return DD_OK;
+    }
+    const int n = (int)p->tab_upd.size() / 3;
+    if (n == 0) return DD_OK;
+    int rc;
+    if ((rc = p->h_tabupd.reserve((size_t)n * 2 * sizeof(int))) != DD_OK) return rc;
+    if ((rc = p->d_tabupd.reserve((size_t)n * 2 * sizeof(int))) != DD_OK) return rc;
+    int *h = p->h_tabupd.as<int>();
+    for (int i = 0; i < n; ++i) {
+        h[2 * i] = p->tab_upd[3 * i] * p->tab_stride + p->tab_upd[3 * i + 1];
+        h[2 * i + 1] = p->tab_upd[3 * i + 2];
+    }
+    p->tab_upd.clear();
+    DD_HIP(hipMemcpyAsync(p->d_tabupd.p, h, (size_t)n * 2 * sizeof(int), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(tab_scatter_k, dim3(dd_ceil_div(n, 256)), dim3(256), 0, s, p->d_tab, p->d_tabupd.as<int>(), n);
+    DD_LAUNCH_CHECK();
     return DD_OK;
 }
 
 void pool_release(TrackerPool *p) {
     if (!p || --p->refs > 0) return;
-    (void)hipFree(p->d_means); (void)hipFree(p->d_covs); (void)hipFree(p->d_gallery);
-    (void)hipFree(p->d_gal_count); (void)hipFree(p->d_gal_total);
-    for (DevBuf *b : {&p->d_pred, &p->d_in, &p->d_feats_raw, &p->d_feats_n, &p->d_cost, &p->d_pairs, &p->d_gather}) b->release();
-    for (PinBuf *b : {&p->h_pred, &p->h_in, &p->h_cost, &p->h_pairs, &p->h_gather}) b->release();
+    (void)hipFree(p->d_means); (void)hipFree(p->d_covs);
+    for (float *a : p->arenas) (void)hipFree(a);
+    (void)hipFree(p->d_arenas); (void)hipFree(p->d_tab);
+    for (DevBuf *b : {&p->d_pred, &p->d_in, &p->d_feats_raw, &p->d_feats_n, &p->d_cost, &p->d_pairs, &p->d_gather, &p->d_tabupd}) b->release();
+    for (PinBuf *b : {&p->h_pred, &p->h_in, &p->h_cost, &p->h_pairs, &p->h_gather, &p->h_tabupd}) b->release();
     delete p;
 }
 
@@ -234,7 +334,7 @@ namespace ddk {
 int tracker_group_create(dd_ctx *ctx, int n, double max_cos, double max_iou, int max_age, int n_init, int budget, int tcap,
                          int gcap, dd_tracker **out) {
     TrackerPool *pool = nullptr;
-    int rc = pool_create(ctx, n * tcap, gcap, &pool);
+    int rc = pool_create(ctx, n * tcap, gcap, &pool);             // gcap: initial rows per track the chunk table is sized for
     if (rc != DD_OK) return rc;
     for (int i = 0; i < n; ++i) out[i] = tracker_new(pool, i * tcap, tcap, max_cos, max_iou, max_age, n_init, budget);
     return DD_OK;
@@ -248,7 +348,7 @@ int trackers_predict(dd_tracker **ts, int S) {
     int n = 0;
     for (int z = 0; z < S; ++z) {
         dd_tracker *t = ts[z];
-        for (int sl : t->pending_free) t->free_slots.push_back(sl);
+        for (int sl : t->pending_free) { gallery_free_slot(p, sl); t->free_slots.push_back(sl); }
         t->pending_free.clear();
         n += (int)t->tracks.size();
     }
@@ -296,16 +396,16 @@ int trackers_update_begin(dd_tracker **ts, int S, const double *tlwh_host, const
     }
     p->D = D; p->R = R; p->have_cost = false;
     if (D == 0) return DD_OK;
-    // ---- stage inputs: [det tlwh f64 D*4][7 int arrays of R rows]
+    // ---- stage inputs: [det tlwh f64 D*4][8 int arrays of R rows]
     const size_t off_rows = (size_t)D * 4 * sizeof(double);
-    const size_t in_bytes = off_rows + (size_t)7 * R * sizeof(int);
+    const size_t in_bytes = off_rows + (size_t)8 * R * sizeof(int);
     if ((rc = p->h_in.reserve(in_bytes + 64)) != DD_OK) return rc;
     if ((rc = p->d_in.reserve(in_bytes + 64)) != DD_OK) return rc;
     char *h = p->h_in.as<char>();
     memcpy(h, tlwh_host, (size_t)D * 4 * sizeof(double));
     int *hr = reinterpret_cast<int *>(h + off_rows);
     int *h_slot = hr, *h_state = hr + R, *h_tsu = hr + 2 * R, *h_doff = hr + 3 * R, *h_nd = hr + 4 * R, *h_coff = hr + 5 * R,
-        *h_idel = hr + 6 * R;
+        *h_idel = hr + 6 * R, *h_gcnt = hr + 7 * R;
     int r = 0;
     for (int z = 0; z < S; ++z) {
         dd_tracker *t = ts[z];
@@ -317,6 +417,7 @@ int trackers_update_begin(dd_tracker **ts, int S, const double *tlwh_host, const
             h_nd[r] = t->ph_n;
             h_coff[r] = p->cost_base[z] + i * t->ph_n;
             h_idel[r] = t->ph_T * t->ph_n;
+            h_gcnt[r] = gallery_count(p, t->tracks[i].slot, t->budget);
         }
     }
     char *d = p->d_in.as<char>();
@@ -334,8 +435,8 @@ int trackers_update_begin(dd_tracker **ts, int S, const double *tlwh_host, const
         if ((rc = p->h_cost.reserve(cost_total * sizeof(double))) != DD_OK) return rc;
         const int *dr = reinterpret_cast<const int *>(d + off_rows);
         hipLaunchKernelGGL(tracker_assoc_k, dim3(R, dd_ceil_div(maxn, 64)), dim3(256), 0, s, p->d_means, p->d_covs,
-                           p->d_gallery, p->gcap, dr, dr + R, dr + 2 * R, dr + 3 * R, dr + 4 * R, dr + 5 * R, dr + 6 * R,
-                           p->d_gal_count, reinterpret_cast<const double *>(d), p->d_feats_n.as<float>(),
+                           p->d_arenas, p->d_tab, p->tab_stride, dr, dr + R, dr + 2 * R, dr + 3 * R, dr + 4 * R, dr + 5 * R,
+                           dr + 6 * R, dr + 7 * R, reinterpret_cast<const double *>(d), p->d_feats_n.as<float>(),
                            p->d_cost.as<double>());
         DD_LAUNCH_CHECK();
         DD_HIP(hipMemcpyAsync(p->h_cost.p, p->d_cost.p, cost_total * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -356,14 +457,14 @@ int trackers_update_match(dd_tracker **ts, int S) {
     size_t max_pairs = (size_t)p->R + D;
     if ((rc = p->h_pairs.reserve(max_pairs * 3 * sizeof(int) + 64)) != DD_OK) return rc;
     if ((rc = p->d_pairs.reserve(max_pairs * 3 * sizeof(int) + 64)) != DD_OK) return rc;
-    std::vector<int> upd_slot, upd_det, upd_cap, new_slot, new_det, new_cap;
+    std::vector<int> upd_slot, upd_det, upd_row, new_slot, new_det, new_row;
     std::vector<std::pair<int, int>> matches;
     std::vector<int> un_rows_final, un_dets, lvl_rows, tmp_rows, tmp_dets, confirmed, unconfirmed;
     for (int z = 0; z < S; ++z) {
         dd_tracker *t = ts[z];
         const int n = t->ph_n, T = t->ph_T, doff = p->det_off[z];
-        const int cap_eff = t->budget > 0 ? std::min(t->budget, p->gcap) : p->gcap;
         matches.clear(); un_rows_final.clear(); un_dets.clear();
+        t->ph_cost_base = (n > 0 && T > 0 && p->have_cost) ? p->cost_base[z] : -1;   // parity aid (dd_tracker_last_cost)
         if (n > 0 && T > 0) {
             const double *app = p->h_cost.as<double>() + p->cost_base[z], *iou = app + (size_t)T * n;
             // ---- tracker.py:95-133 _match
@@ -406,7 +507,9 @@ int trackers_update_match(dd_tracker **ts, int S) {
             tr.tsu = 0;
             tr.last_det = m.second;
             if (tr.state == TENTATIVE && tr.hits >= t->n_init) tr.state = CONFIRMED;
-            upd_slot.push_back(tr.slot); upd_det.push_back(doff + m.second); upd_cap.push_back(cap_eff);
+            int grow = 0;
+            if ((rc = gallery_place(p, tr.slot, t->budget, &grow)) != DD_OK) return rc;
+            upd_slot.push_back(tr.slot); upd_det.push_back(doff + m.second); upd_row.push_back(grow);
             t->last_pairs.push_back(m.first);
             t->last_pairs.push_back(m.second);
         }
@@ -425,7 +528,9 @@ int trackers_update_match(dd_tracker **ts, int S) {
             t->free_slots.pop_back();
             tr.last_det = dd;
             t->tracks.push_back(tr);
-            new_slot.push_back(tr.slot); new_det.push_back(doff + dd); new_cap.push_back(cap_eff);
+            int grow = 0;
+            if ((rc = gallery_place(p, tr.slot, t->budget, &grow)) != DD_OK) return rc;
+            new_slot.push_back(tr.slot); new_det.push_back(doff + dd); new_row.push_back(grow);
         }
         // ---- tracker.py:80-81 split live / deleted
         std::vector<TrackRec> live;
@@ -437,15 +542,15 @@ int trackers_update_match(dd_tracker **ts, int S) {
     const int n_upd = (int)upd_slot.size(), n_new = (int)new_slot.size(), np = n_upd + n_new;
     if (np > 0) {
         int *hp = p->h_pairs.as<int>();
-        for (int i = 0; i < n_upd; ++i) { hp[i] = upd_slot[i]; hp[np + i] = upd_det[i]; hp[2 * np + i] = upd_cap[i]; }
-        for (int i = 0; i < n_new; ++i) { hp[n_upd + i] = new_slot[i]; hp[np + n_upd + i] = new_det[i]; hp[2 * np + n_upd + i] = new_cap[i]; }
+        for (int i = 0; i < n_upd; ++i) { hp[i] = upd_slot[i]; hp[np + i] = upd_det[i]; hp[2 * np + i] = upd_row[i]; }
+        for (int i = 0; i < n_new; ++i) { hp[n_upd + i] = new_slot[i]; hp[np + n_upd + i] = new_det[i]; hp[2 * np + n_upd + i] = new_row[i]; }
         int *dp = p->d_pairs.as<int>();
         DD_HIP(hipMemcpyAsync(dp, hp, (size_t)3 * np * sizeof(int), hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(tracker_apply_k, dim3(dd_ceil_div(np, 4)), dim3(256), 0, s, p->d_means, p->d_covs, p->d_gallery,
-                           p->gcap, p->d_gal_count, p->d_gal_total, dp, dp + np, dp + 2 * np, n_upd, n_new,
-                           p->d_in.as<double>(), p->d_feats_n.as<float>());
+        hipLaunchKernelGGL(tracker_apply_k, dim3(dd_ceil_div(np, 4)), dim3(256), 0, s, p->d_means, p->d_covs, p->d_arenas,
+                           dp, dp + np, dp + 2 * np, n_upd, n_new, p->d_in.as<double>(), p->d_feats_n.as<float>());
         DD_LAUNCH_CHECK();
     }
+    if ((rc = gallery_flush(p, s)) != DD_OK) return rc;           // new chunks are in the table before the next association
     // ---- mirror the means of live + just-deleted tracks of every stream
     int ng = 0;
     for (int z = 0; z < S; ++z) ng += (int)(ts[z]->tracks.size() + ts[z]->deleted.size());
@@ -506,11 +611,13 @@ int dd_tracker_destroy(dd_tracker *t) {
 
 int dd_tracker_predict(dd_tracker *t) {
     DD_REQUIRE(t, DD_E_ARG, "dd_tracker_predict: NULL tracker");
+    DD_DEVICE(t->pool->ctx);
     return ddk::trackers_predict(&t, 1);
 }
 
 int dd_tracker_update(dd_tracker *t, const double *tlwh_host, const float *feats, int feats_on_device, int n) {
     DD_REQUIRE(t && n >= 0, DD_E_ARG, "dd_tracker_update: bad argument");
+    DD_DEVICE(t->pool->ctx);
     DD_REQUIRE(n == 0 || (tlwh_host && feats), DD_E_ARG, "dd_tracker_update: NULL detections");
     int rc;
     const int off[2] = {0, n};
@@ -530,6 +637,7 @@ int dd_tracker_count(dd_tracker *t, int which, int *out_n_host) {
 
 int dd_tracker_read(dd_tracker *t, int which, int64_t *ints6_host, double *means_host, double *covs_host) {
     DD_REQUIRE(t, DD_E_ARG, "dd_tracker_read: NULL tracker");
+    DD_DEVICE(t->pool->ctx);
     const std::vector<TrackRec> &v = which == 0 ? t->tracks : t->deleted;
     const std::vector<double> &mm = which == 0 ? t->live_means : t->dead_means;
     const int n = (int)v.size();
@@ -576,6 +684,7 @@ int find_live(const dd_tracker *t, int64_t id) {
 // The mirrored mean of the track is refreshed.  feat: 128 f32 (host or device), normalised here like every feature.
 int dd_tracker_track_update(dd_tracker *t, int64_t track_id, const double *tlwh_host, const float *feat, int feat_on_device) {
     DD_REQUIRE(t && tlwh_host && feat, DD_E_ARG, "dd_tracker_track_update: NULL argument");
+    DD_DEVICE(t->pool->ctx);
     const int i = find_live(t, track_id);
     DD_REQUIRE(i >= 0, DD_E_ARG, "dd_tracker_track_update: no live track with id %lld", (long long)track_id);
     DD_REQUIRE(t->live_means.size() == t->tracks.size() * 8, DD_E_STATE, "dd_tracker_track_update: call update() first");
@@ -593,15 +702,17 @@ int dd_tracker_track_update(dd_tracker *t, int64_t track_id, const double *tlwh_
     char *h = p->h_in.as<char>(), *d = p->d_in.as<char>();
     memcpy(h, tlwh_host, 4 * sizeof(double));
     int *hp = reinterpret_cast<int *>(h + 32);
-    const int cap_eff = t->budget > 0 ? std::min(t->budget, p->gcap) : p->gcap;
-    hp[0] = tr.slot; hp[1] = 0; hp[2] = cap_eff;
+    int grow = 0;
+    if ((rc = gallery_place(p, tr.slot, t->budget, &grow)) != DD_OK) return rc;
+    hp[0] = tr.slot; hp[1] = 0; hp[2] = grow;
     DD_HIP(hipMemcpyAsync(d, h, 32 + 3 * sizeof(int), hipMemcpyHostToDevice, s));
     DD_HIP(hipMemcpyAsync(p->d_feats_raw.p, feat, 128 * sizeof(float), feat_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
     if ((rc = ddk::normalize_rows(s, p->d_feats_raw.as<float>(), p->d_feats_n.as<float>(), 1)) != DD_OK) return rc;
     const int *dp = reinterpret_cast<const int *>(d + 32);
-    hipLaunchKernelGGL(tracker_apply_k, dim3(1), dim3(256), 0, s, p->d_means, p->d_covs, p->d_gallery, p->gcap, p->d_gal_count,
-                       p->d_gal_total, dp, dp + 1, dp + 2, 1, 0, reinterpret_cast<const double *>(d), p->d_feats_n.as<float>());
+    hipLaunchKernelGGL(tracker_apply_k, dim3(1), dim3(256), 0, s, p->d_means, p->d_covs, p->d_arenas, dp, dp + 1, dp + 2, 1, 0,
+                       reinterpret_cast<const double *>(d), p->d_feats_n.as<float>());
     DD_LAUNCH_CHECK();
+    if ((rc = gallery_flush(p, s)) != DD_OK) return rc;
     double *dg = p->d_gather.as<double>();
     if ((rc = ddk::gather_state(s, p->d_means, p->d_covs, dp, 1, dg, nullptr)) != DD_OK) return rc;
     DD_HIP(hipMemcpyAsync(p->h_gather.p, dg, 8 * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -616,6 +727,7 @@ int dd_tracker_track_update(dd_tracker *t, int64_t track_id, const double *tlwh_
 // Track.predict(kf) (track.py:113-125) for ONE live track: Kalman predict, age += 1, time_since_update += 1.
 int dd_tracker_track_predict(dd_tracker *t, int64_t track_id) {
     DD_REQUIRE(t, DD_E_ARG, "dd_tracker_track_predict: NULL tracker");
+    DD_DEVICE(t->pool->ctx);
     const int i = find_live(t, track_id);
     DD_REQUIRE(i >= 0, DD_E_ARG, "dd_tracker_track_predict: no live track with id %lld", (long long)track_id);
     DD_REQUIRE(t->live_means.size() == t->tracks.size() * 8, DD_E_STATE, "dd_tracker_track_predict: call update() first");
@@ -669,6 +781,23 @@ int dd_tracker_remove(dd_tracker *t, const int64_t *track_ids_host, int n) {
 int dd_tracker_next_id(dd_tracker *t, int64_t *out_host) {
     DD_REQUIRE(t && out_host, DD_E_ARG, "dd_tracker_next_id: NULL argument");
     *out_host = t->next_id;
+    return DD_OK;
+}
+
+// Parity aid: the cost matrices the last update() associated with -- appearance [T][n] (gated entries are 1e5, rows of
+// unconfirmed tracks unspecified) and IoU [T][n]; T = tracks before that update, n = its detections.  Valid until the
+// next update of any tracker of the group.
+int dd_tracker_last_cost(dd_tracker *t, double *app_host, double *iou_host, int cap, int *rows_host, int *cols_host) {
+    DD_REQUIRE(t && rows_host && cols_host, DD_E_ARG, "dd_tracker_last_cost: NULL argument");
+    const bool have = t->ph_cost_base >= 0;
+    *rows_host = have ? t->ph_T : 0;
+    *cols_host = have ? t->ph_n : 0;
+    if (!have || (!app_host && !iou_host)) return DD_OK;
+    const size_t tn = (size_t)t->ph_T * t->ph_n;
+    DD_REQUIRE((size_t)cap >= tn, DD_E_ARG, "dd_tracker_last_cost: cap %d < %zu", cap, tn);
+    const double *c0 = t->pool->h_cost.as<double>() + t->ph_cost_base;
+    if (app_host) memcpy(app_host, c0, tn * sizeof(double));
+    if (iou_host) memcpy(iou_host, c0 + tn, tn * sizeof(double));
     return DD_OK;
 }
 

@@ -111,6 +111,17 @@ class Tracker:
               'dd_tracker_update')
         self._refresh(detections)
 
+    def last_cost(self):
+        """(appearance cost [T, n], IoU cost [T, n]) the last update() associated with (parity tests): T = tracks before
+        that update, n = its detections; gated appearance entries are 1e5, rows of unconfirmed tracks unspecified."""
+        r, c = ctypes.c_int(), ctypes.c_int()
+        check(lib().dd_tracker_last_cost(self._h, None, None, 0, ctypes.byref(r), ctypes.byref(c)), 'dd_tracker_last_cost')
+        app = np.zeros((r.value, c.value)); iou = np.zeros((r.value, c.value))
+        if app.size:
+            check(lib().dd_tracker_last_cost(self._h, ptr(app), ptr(iou), app.size, ctypes.byref(r), ctypes.byref(c)),
+                  'dd_tracker_last_cost')
+        return app, iou
+
     def _read(self, which):
         n = ctypes.c_int()
         check(lib().dd_tracker_count(self._h, which, ctypes.byref(n)), 'dd_tracker_count')

@@ -56,13 +56,15 @@ class SSDMobileNet:
                                       ptr(self._resized), self.height, self.width, None), 'dd_resize_lanczos')
         return self._resized
 
-    def invoke_device(self, resized_dev):
-        """ssd_mobilenet.py:102-109: interpreter.invoke() and its four output tensors."""
+    def invoke_device(self, resized_dev, read=True):
+        """ssd_mobilenet.py:102-109: interpreter.invoke() and its four output tensors (read=False leaves them in HBM)."""
         self.net.forward(resized_dev)
         raw = self.net.output_ptr()
         check(lib().dd_ssd_postprocess(self.ctx.handle, raw, ptr(self._anchors_dev), len(self.anchors), self.n_classes,
                                        self.MAX_DET, 1e-8, 0.6, ptr(self._boxes), ptr(self._classes),
                                        ptr(self._scores), ptr(self._count), None), 'dd_ssd_postprocess')
+        if not read:
+            return None
         self.ctx.sync()
         return [self._boxes.cpu().numpy(), self._classes.cpu().numpy(), self._scores.cpu().numpy(),
                 float(self._count.cpu().numpy()[0])]
@@ -82,37 +84,46 @@ class SSDMobileNet:
             nboxes.append(b[keep]); nlabels.append(cl[keep]); nscores.append(s[keep])
         return nboxes, nlabels, nscores
 
-    def postprocess(self, output, confidence=0.5, iou_threshold=0.5, original_image_size=None):
-        """ssd_mobilenet.py:111-150."""
-        idx = np.where(np.isnan(output[0]))
-        output[2][np.reshape(idx, -1)] = 0
-        output[2][np.where(np.isnan(output[2]))] = 0
-        indices = np.where(output[2] >= confidence)
+    def _names(self, labels):
+        names = []
+        for li in labels:                                          # ssd_mobilenet.py:142-147
+            if 0 <= li < len(self.labels) - 1:
+                names.append(self.labels[li + 1])
+            else:
+                print("Invalid label index: {} in {}".format(li, labels))
+        return names
+
+    def finish_device(self, boxes_dev, classes_dev, scores_dev, n, confidence=0.5, iou_threshold=0.5,
+                      original_image_size=None):
+        """ssd_mobilenet.py:111-150 on the post-process op's outputs where they lie in HBM (csrc/post.hip
+        ssd_finish_k): NaN scrub, confidence filter, reorder + scale, per-class nms_boxes -- one launch."""
         w, h = original_image_size if original_image_size is not None else (self.width, self.height)
-        boxes = output[0][indices][:, [1, 0, 3, 2]] * [w, h, w, h]
-        labels = output[1][indices]
-        scores = output[2][indices]
-        n_boxes, n_labels, n_scores = self.nms_boxes(boxes, labels, scores, iou_threshold)
-        if n_boxes:
-            boxes = np.concatenate(n_boxes)
-            labels = np.concatenate(n_labels).astype(np.uint)
-            scores = np.concatenate(n_scores)
-            names = []
-            for li in labels:
-                if 0 <= li < len(self.labels) - 1:
-                    names.append(self.labels[li + 1])
-                else:
-                    print("Invalid label index: {} in {}".format(li, labels))
-            return boxes, names, scores
-        return [], [], []
+        c = self.ctx
+        ob, oc = c.empty((n, 4), torch.float64), c.empty((n,), torch.int32)
+        osc, on = c.empty((n,), torch.float64), c.empty((1,), torch.int32)
+        check(lib().dd_ssd_detections(c.handle, ptr(boxes_dev), ptr(classes_dev), ptr(scores_dev), 1, n, float(confidence),
+                                      float(iou_threshold), float(w), float(h), ptr(ob), ptr(oc), ptr(osc), ptr(on), None),
+              'dd_ssd_detections')
+        k = int(c.to_host(on)[0])
+        if k == 0:
+            return [], [], []
+        labels = c.to_host(oc)[:k].astype(np.uint)
+        return c.to_host(ob)[:k], self._names(labels), c.to_host(osc)[:k].astype(np.float32)
+
+    def postprocess(self, output, confidence=0.5, iou_threshold=0.5, original_image_size=None):
+        """ssd_mobilenet.py:111-150 for host arrays [boxes, classes, scores, count] (the four tensors predict() reads)."""
+        n = len(output[2])
+        c = self.ctx
+        return self.finish_device(c.to_device(output[0], np.float32), c.to_device(output[1], np.float32),
+                                  c.to_device(output[2], np.float32), n, confidence, iou_threshold, original_image_size)
 
     def predict_array(self, rgb, confidence=0.5, iou_threshold=0.5):
         """rgb: u8 ndarray [H,W,3 or 4] in RGB(A) order, original resolution."""
         rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
         H, W, C = rgb.shape
         dev = self.ctx.to_device(rgb)
-        out = self.invoke_device(self.prepare_image_device(dev, H, W, C))
-        return self.postprocess(out, confidence, iou_threshold, (W, H))
+        self.invoke_device(self.prepare_image_device(dev, H, W, C), read=False)
+        return self.finish_device(self._boxes, self._classes, self._scores, self.MAX_DET, confidence, iou_threshold, (W, H))
 
 
 class SSD_MOBILENET():
@@ -150,5 +161,5 @@ class SSD_MOBILENET():
         """Hot path: BGR u8 frame already in HBM (the BGR->RGB swap of deepdish.py:882 is fused into
         the resize kernel)."""
         s = self.ssdm
-        out = s.invoke_device(s.prepare_image_device(frame_dev, H, W, 3, swap_rb=True))
-        return self._filter(*s.postprocess(out, original_image_size=(W, H)))
+        s.invoke_device(s.prepare_image_device(frame_dev, H, W, 3, swap_rb=True), read=False)
+        return self._filter(*s.finish_device(s._boxes, s._classes, s._scores, s.MAX_DET, original_image_size=(W, H)))

@@ -109,7 +109,11 @@ int dd_pyset_difference_order_host(const int *a_host, int na, const int *b_host,
  * deep_sort/tracker.py:40-138 Tracker + track.py:67-196 Track state machine +
  * linear_assignment.py:11-190 (threshold, LSAP, cascade, gating) + nn_matching.py:137-154
  * partial_fit.  Kalman state and the appearance gallery live in device memory; the integer
- * book-keeping (ids, states, hits, age, time_since_update) lives on the host. */
+ * book-keeping (ids, states, hits, age, time_since_update) lives on the host.
+ * nn_budget <= 0 is the reference's budget=None (deepdish.py:515): a track keeps EVERY sample it was ever matched
+ * with -- galleries grow in 32-row chunks from a pool shared by the group and are bounded by device memory only
+ * (DD_E_CAPACITY when an allocation fails, never a silent overwrite).  nn_budget = B keeps the last B samples
+ * (nn_matching.py:150-153).  gallery_capacity is a sizing hint: the rows per track the chunk table starts with. */
 int dd_tracker_create(dd_ctx *ctx, double max_cosine_distance, double max_iou_distance,
                       int max_age, int n_init, int nn_budget /* <=0: None */,
                       int track_capacity, int gallery_capacity, dd_tracker **out);
@@ -141,7 +145,11 @@ int dd_tracker_next_id(dd_tracker *trk, int64_t *out_host);
 /* Rows of tracker.tracks reassigned by the host (deepdish.py:1047) are not supported: the
  * identity pass-through of framerecords.py:183 is the only behaviour reproduced. */
 
-/* last association, for parity tests: matches[m][2] = (track row, detection), in update order */
+/* last association, for parity tests: app_host / iou_host [rows][cols] = the appearance cost matrix (nn_matching.py:156-177
+ * after gate_cost_matrix, linear_assignment.py:181-189: gated entries 1e5; rows of unconfirmed tracks unspecified) and the
+ * IoU cost matrix (iou_matching.py:42-81) of the last update; rows = tracks before that update, cols = detections. */
+int dd_tracker_last_cost(dd_tracker *trk, double *app_host, double *iou_host, int cap, int *rows_host, int *cols_host);
+/* matches[m][2] = (track row, detection), in update order */
 int dd_tracker_last_matches(dd_tracker *trk, int *pairs_host, int cap, int *out_m_host);
 
 /* ---------------------------------------------------------------- crops
@@ -246,6 +254,17 @@ int dd_ssd_postprocess(dd_ctx *ctx, const float *raw, const float *anchors, int 
                        int n_classes, int max_det, float score_thr, float iou_thr,
                        float *boxes, float *classes, float *scores, int *count, void *stream);
 
+/* tools/ssd_mobilenet.py:111-150, SSDMobileNet.predict after its four get_tensor calls, for `batch` images at once:
+ * NaN scrub (:111-116), score >= confidence (:119), reorder [1,0,3,2] and scale by (w,h,w,h) in f64 (:121-127),
+ * per-class nms_boxes (:59-98, see dd_nms_ssd).  Inputs are the outputs of dd_ssd_postprocess (device):
+ * boxes f32 [batch][max_det][4], classes f32, scores f32 [batch][max_det], max_det <= 16.  Outputs (device):
+ * out_boxes f64 [batch][max_det][4] xyxy pixels, out_cls int32 (class id = label-file line - 1, :142-147),
+ * out_scores f64, out_n int32 [batch].  Rows come class by class in ascending id (the reference walks a Python
+ * set) and inside a class in nms_boxes' pick order. */
+int dd_ssd_detections(dd_ctx *ctx, const float *boxes, const float *classes, const float *scores, int batch,
+                      int max_det, double confidence, double iou_thr, double img_w, double img_h, double *out_boxes,
+                      int *out_cls, double *out_scores, int *out_n, void *stream);
+
 /* tools/yolov5.py:120-131: xywh->xyxy, cls*=obj, argmax, conf >= thr, scale to image.
  * raw f32 [n_rows][5+n_cls] -> out_boxes f32 [cap][4] xyxy pixels, out_scores, out_cls, *out_n
  * (rows in ascending row order, like np.where). */
@@ -273,7 +292,10 @@ int dd_pipeline_step(dd_pipeline *p, const uint8_t *frames, const double *inj_bo
                      const double *inj_scores_host, const int *inj_cls_host, const int *inj_offsets_host);
 /* Same step with a look-ahead: the detector run of `frames_next` (may be NULL) is queued on the pipeline's detector
  * stream once this step has read its own detections -- the reference keeps one detector call and one encoder call
- * in flight on different frames the same way (deepdish.py:935,985,1008).  The next call must pass those frames. */
+ * in flight on different frames the same way (deepdish.py:935,985,1008).  Contract: the next call must pass
+ * `frames_next` as its `frames`, and the memory behind it must stay UNMODIFIED until that call returns -- the queued
+ * result is matched to the next step by address, so a capture buffer that is refilled in place (a 1-slot ring) must
+ * not be handed in here (pass NULL instead).  frames_next == frames is rejected (DD_E_ARG). */
 int dd_pipeline_step2(dd_pipeline *p, const uint8_t *frames, const uint8_t *frames_next, const double *inj_boxes_host,
                       const double *inj_scores_host, const int *inj_cls_host, const int *inj_offsets_host);
 /* counts_host: int64 [n_streams][n_wanted][4] = poscount, negcount, intcount, delcount */

@@ -193,7 +193,7 @@ class RefCounter:
             self.del_ += d
 
 
-def golden_scene(name, scene, n_frames, max_age=60, keep_inputs=False):
+def golden_scene(name, scene, n_frames, max_age=60, keep_inputs=False, cost_frames=()):
     metric = nn_matching.NearestNeighborDistanceMetric('cosine', 0.2, None)   # deepdish.py:515-516
     tracker = Tracker(metric, max_iou_distance=0.7, max_age=max_age)          # deepdish.py:517
     counter = RefCounter(scene.countline())
@@ -207,7 +207,13 @@ def golden_scene(name, scene, n_frames, max_age=60, keep_inputs=False):
         keep = preprocessing.non_max_suppression(boxes, 0.6, scores)          # deepdish.py:995
         keeps += list(keep); keep_ptr.append(len(keeps))
         dets = [Detection(boxes[i], 'person', scores[i], feats[i]) for i in keep]   # deepdish.py:1014
-        tracker.predict(); tracker.update(dets)                               # deepdish.py:1028-1029
+        tracker.predict()                                                     # deepdish.py:1028
+        if f in cost_frames:       # what tracker._match's gated_metric reads from the metric (tracker.py:98-101): min over
+            ids = [t.track_id for t in tracker.tracks if t.is_confirmed()]    # EVERY stored sample of each confirmed track
+            inputs[f'cost_{f}'] = metric.distance(np.array([d.feature for d in dets]), ids)
+            inputs[f'cost_ids_{f}'] = np.array(ids, dtype=np.int64)
+            inputs[f'cost_samples_{f}'] = np.array([len(metric.samples[i]) for i in ids], dtype=np.int64)
+        tracker.update(dets)                                                  # deepdish.py:1029
         counter.step(tracker)
         for t in tracker.tracks:
             rows.append([t.track_id, t.state, t.time_since_update, t.hits, t.age] + list(t.mean))
@@ -226,6 +232,11 @@ def golden_scene(name, scene, n_frames, max_age=60, keep_inputs=False):
 
 
 if __name__ == '__main__':
+    if sys.argv[1:] == ['long']:
+        # nn_budget=None keeps EVERY sample (deepdish.py:515, nn_matching.py:137-154): eight objects that never leave
+        # the frame, 420 frames -> each track's gallery passes 256, 320, 384 ... samples
+        golden_scene('long_n8', Scene(seed=7, n_obj=8, n_frames=420, churn=False), 420, cost_frames=(200, 300, 360, 419))
+        sys.exit(0)
     golden_kalman()
     golden_iou_nms()
     golden_cosine()

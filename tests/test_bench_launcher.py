@@ -1,0 +1,40 @@
+"""CPU: `python bench.py --gpus N` starts N ranks itself (torch.distributed.run on 127.0.0.1) when no launcher did,
+relays ONE JSON line from rank 0 with n_gpus == N, and reduces the ranks' count vectors with one all-reduce
+(deepdish_amd/multistream.reduce_counts -- the same call the GPU run makes over RCCL).  --rehearse-cpu swaps the
+backend for gloo and processes no frames: this checks the launcher and the reduction, not throughput."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(argv, env_extra=None, timeout=300):
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT', 'MASTER_ADDR')}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + argv, capture_output=True, text=True, env=env,
+                          timeout=timeout, cwd=ROOT)
+
+
+def test_gpus_2_spawns_two_ranks_and_reduces_counts():
+    r = _run(['--gpus', '2', '--rehearse-cpu'])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout                     # exactly one JSON line on stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['value'] is None and 'rehearsal' in out
+    assert out['counts_pos_neg_int_del'] == [1 + 2, 10 + 20, 11 + 22, 0]       # rank r contributes (r+1) * (1, 10, 11, 0)
+
+
+def test_gpus_must_match_the_launcher_world_size():
+    r = _run(['--gpus', '4', '--rehearse-cpu'], env_extra={'RANK': '0', 'LOCAL_RANK': '0', 'WORLD_SIZE': '2',
+                                                          'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': '29999'})
+    assert r.returncode == 2 and 'WORLD_SIZE=2' in r.stderr
+
+
+def test_single_rank_rehearsal():
+    r = _run(['--rehearse-cpu'])
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip())
+    assert out['n_gpus'] == 1 and out['counts_pos_neg_int_del'] == [1, 10, 11, 0]

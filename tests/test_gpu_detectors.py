@@ -1,0 +1,131 @@
+"""GPU: the detector adaptors' tails against fixtures the REFERENCE's own classes produced
+(tests/golden/ssd_tail.npz, yolov5_tail.npz; scripts/make_golden_detectors.py) -- dd_nms_ssd, dd_ssd_detections
+(csrc/post.hip ssd_finish_k, the kernel the batched C++ pipeline runs) and dd_yolov5_decode, all through the C ABI.
+Everything here is bit-exact: the kernels do the reference's f64 / f32 operations in the reference's order."""
+import ctypes
+import os
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(__file__), 'golden')
+ASSETS = os.path.join(os.path.dirname(__file__), '..', 'deepdish_amd', 'assets')
+
+
+def _lines(name):
+    with open(os.path.join(ASSETS, name)) as f:
+        return {i: line.strip() for i, line in enumerate(f.readlines())}
+
+
+def _by_class(boxes, cls, scores):
+    """rows grouped per class id, pick order kept inside a class (the class order itself is a Python-set artefact)."""
+    out = {}
+    for b, c, s in zip(boxes, cls, scores):
+        out.setdefault(int(c), []).append((tuple(float(v) for v in b), float(s)))
+    return out
+
+
+def test_dd_nms_ssd_matches_reference_nms_boxes():
+    """tools/ssd_mobilenet.py:59-98 -- 60 reference cases (1..39 boxes, 1..3 classes, thresholds 0.3/0.5/0.7, half of
+    them with boxes a few pixels wide where the +1 on the intersection decides): kept rows identical, in order."""
+    from deepdish_amd._lib import lib, check
+    from deepdish_amd.runtime import default_context, ptr
+    ctx = default_context()
+    g = np.load(os.path.join(G, 'ssd_tail.npz'))
+    for i in range(len(g['n_thr'])):
+        a, b = g['n_off'][i], g['n_off'][i + 1]
+        boxes, labels, scores = g['n_boxes'][a:b], g['n_cls'][a:b], g['n_scores'][a:b]
+        got_b, got_c, got_s = [], [], []
+        for c in set(labels):                                   # same scalars, same interpreter => the reference's class order
+            idx = np.flatnonzero(labels == c)
+            k = len(idx)
+            db, ds_ = ctx.to_device(boxes[idx], np.float64), ctx.to_device(scores[idx], np.float64)
+            out, cnt = ctx.empty((k,), torch.int32), ctx.empty((1,), torch.int32)
+            check(lib().dd_nms_ssd(ctx.handle, ptr(db), ptr(ds_), k, float(g['n_thr'][i]), ptr(out), ptr(cnt), None), 'dd_nms_ssd')
+            keep = ctx.to_host(out)[:int(ctx.to_host(cnt)[0])]
+            got_b.append(boxes[idx][keep]); got_c.append(labels[idx][keep]); got_s.append(scores[idx][keep])
+        ka, kb = g['k_off'][i], g['k_off'][i + 1]
+        np.testing.assert_array_equal(np.concatenate(got_b), g['k_boxes'][ka:kb], err_msg=f'case {i}')
+        np.testing.assert_array_equal(np.concatenate(got_c), g['k_cls'][ka:kb])
+        np.testing.assert_array_equal(np.concatenate(got_s), g['k_scores'][ka:kb])
+
+
+def test_dd_ssd_detections_matches_reference_predict_tail():
+    """tools/ssd_mobilenet.py:111-150 -- 240 canned interpreter outputs (NaN boxes / scores, tiny boxes, low
+    confidence, four image sizes), all images of one size in ONE launch: boxes (f64), class ids and scores identical
+    to SSDMobileNet.predict's, class by class in pick order."""
+    from deepdish_amd._lib import lib, check
+    from deepdish_amd.runtime import default_context, ptr
+    ctx = default_context()
+    g = np.load(os.path.join(G, 'ssd_tail.npz'))
+    sizes = sorted({tuple(int(v) for v in s) for s in g['size']})
+    assert len(sizes) == 4
+    checked = 0
+    for size in sizes:
+        sel = np.flatnonzero((g['size'] == np.array(size)).all(axis=1))
+        n = len(sel)
+        db, dc, ds_ = (ctx.to_device(g[k][sel], np.float32) for k in ('boxes', 'cls', 'scores'))
+        ob, oc = ctx.empty((n, 10, 4), torch.float64), ctx.empty((n, 10), torch.int32)
+        osc, on = ctx.empty((n, 10), torch.float64), ctx.empty((n,), torch.int32)
+        check(lib().dd_ssd_detections(ctx.handle, ptr(db), ptr(dc), ptr(ds_), n, 10, 0.5, 0.5, float(size[0]), float(size[1]),
+                                      ptr(ob), ptr(oc), ptr(osc), ptr(on), None), 'dd_ssd_detections')
+        ob, oc, osc, on = (ctx.to_host(t) for t in (ob, oc, osc, on))
+        for j, i in enumerate(sel):
+            a, b = g['off'][i], g['off'][i + 1]
+            assert on[j] == b - a, (i, on[j], b - a)
+            want = _by_class(g['pred_boxes'][a:b], g['pred_cls'][a:b], g['pred_scores'][a:b])
+            got = _by_class(ob[j, :on[j]], oc[j, :on[j]], osc[j, :on[j]].astype(np.float32))
+            assert got == want, i
+            assert list(oc[j, :on[j]]) == sorted(oc[j, :on[j]])         # ascending class id, as documented
+            checked += int(on[j])
+    assert checked == g['off'][-1] > 1000
+
+
+def test_ssd_plugin_tail_matches_reference_detect_image():
+    """SSDMobileNet.postprocess + SSD_MOBILENET._filter (the Python plugin, routed through dd_ssd_detections) ==
+    the reference's detect_image on the same interpreter outputs: tlwh boxes, label names, scores."""
+    from deepdish_amd.pipeline import make_detector
+    g = np.load(os.path.join(G, 'ssd_tail.npz'))
+    lines = _lines('coco_labels_ssd.txt')
+    wanted = [str(x) for x in g['wanted_person']]
+    det = make_detector('synthetic-ssd_mobilenet_v1.tflite', wanted_labels=wanted)
+    name_to_id = {v: k - 1 for k, v in lines.items() if k > 0}
+    for i in range(0, len(g['boxes']), 3):
+        out = [g['boxes'][i].copy(), g['cls'][i].copy(), g['scores'][i].copy(), 10.0]
+        rb, rl, rs = det._filter(*det.ssdm.postprocess(out, original_image_size=tuple(int(v) for v in g['size'][i])))
+        a, b = g['poff'][i], g['poff'][i + 1]
+        assert len(rs) == b - a, i
+        got = _by_class(rb, [name_to_id[x] for x in rl], np.asarray(rs, np.float32))
+        want = _by_class(g['pdet_boxes'][a:b], g['pdet_cls'][a:b], g['pdet_scores'][a:b])
+        assert got == want, i
+
+
+def test_dd_yolov5_decode_matches_reference_detect_image():
+    """tools/yolov5.py:120-146 -- dd_yolov5_decode (xywh -> xyxy, cls *= obj, argmax, >= thr, scale) + the plugin's
+    label filter / tlwh conversion on the reference's canned head tensors: identical boxes (f32), labels, scores."""
+    from deepdish_amd.pipeline import make_detector
+    g = np.load(os.path.join(G, 'yolov5_tail.npz'))
+    lines = _lines('coco_classes.txt')
+    name_to_id = {v: k for k, v in lines.items()}
+    from deepdish_amd._lib import lib, check
+    from deepdish_amd.runtime import ptr
+    for i in range(len(g['thr'])):
+        wanted = str(g['wanted'][i]).split(',')
+        det = make_detector('synthetic-yolov5s-fp16.tflite', wanted_labels=wanted) if i == 0 else det
+        det.wanted_labels, det.score_threshold = wanted, float(g['thr'][i])
+        raw = g['raw_f16'][g['roff'][i]:g['roff'][i + 1]].astype(np.float32)
+        W, H = (int(v) for v in g['size'][i])
+        d_raw = det.ctx.to_device(raw)
+        check(lib().dd_yolov5_decode(det.ctx.handle, ptr(d_raw), len(raw), 80, float(g['thr'][i]), float(W), float(H),
+                                     ptr(det._boxes), ptr(det._scores), ptr(det._cls), det.MAX_ROWS, ptr(det._n), None),
+              'dd_yolov5_decode')
+        det.ctx.sync()
+        n = int(det._n.cpu().numpy()[0])
+        b, l, s = det._collect(det._boxes[:n].cpu().numpy(), det._scores[:n].cpu().numpy(), det._cls[:n].cpu().numpy())
+        a, e = g['off'][i], g['off'][i + 1]
+        assert len(s) == e - a, (i, len(s), e - a)
+        np.testing.assert_array_equal(np.asarray(b, np.float32), g['boxes'][a:e])
+        np.testing.assert_array_equal([name_to_id[x] for x in l], g['labels'][a:e])
+        np.testing.assert_array_equal(np.asarray(s, np.float32), g['scores'][a:e])

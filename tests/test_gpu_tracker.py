@@ -54,6 +54,50 @@ def test_scene_golden(name):
     assert np.all(np.linalg.eigvalsh((c + c.T) / 2) > 0)
 
 
+def test_long_scene_unbounded_gallery():
+    """nn_budget=None keeps every sample (deepdish.py:515, nn_matching.py:137-154): 420 frames, eight tracks alive
+    throughout, galleries of up to 413 samples.  Track table identical to the reference's every frame, and the
+    appearance costs the device associated with at frames 200 / 300 / 360 / 419 equal the reference metric's
+    (tests/test_oracle_golden.py shows a 256-sample ring misses them by > 1e-4).  gallery_capacity=64 starts the
+    chunk table at two chunks per track, so it is re-built at 4, 8 and 16 on the way."""
+    from deepdish_amd.deep_sort import nn_matching, preprocessing
+    from deepdish_amd.deep_sort.tracker import Tracker
+    from deepdish_amd.deep_sort.detection import Detection
+    from deepdish_amd.tools.countline import CountLine
+    from deepdish_amd.synth import Scene
+    g = np.load(os.path.join(G, 'scene_long_n8.npz'))
+    scene = Scene(seed=int(g['seed']), n_obj=int(g['n_obj']), n_frames=int(g['n_frames']), churn=False)
+    trk = Tracker(nn_matching.NearestNeighborDistanceMetric('cosine', 0.2, None), max_iou_distance=0.7,
+                  max_age=int(g['max_age']), gallery_capacity=64)
+    counter = CountLine(scene.countline())
+    fp, kp = g['frame_ptr'], g['keep_ptr']
+    compared, worst = 0, 0.0
+    for f in range(int(g['n_frames'])):
+        boxes, scores, who, feats = scene.detections(f)
+        keep = preprocessing.non_max_suppression(boxes, 0.6, scores)
+        assert keep == g['nms_keep'][kp[f]:kp[f + 1]].tolist(), f'nms frame {f}'
+        trk.predict()
+        before = [(t.track_id, t.is_confirmed()) for t in trk.tracks]
+        trk.update([Detection(boxes[i], 'person', scores[i], feats[i]) for i in keep])
+        counter.step(trk)
+        got_i = np.array([[t.track_id, t.state, t.time_since_update, t.hits, t.age] for t in trk.tracks],
+                         dtype=np.int64).reshape(-1, 5)
+        np.testing.assert_array_equal(got_i, g['track_int'][fp[f]:fp[f + 1]], err_msg=f'frame {f}')
+        np.testing.assert_allclose(np.array([t.mean for t in trk.tracks]), g['track_mean'][fp[f]:fp[f + 1]], rtol=1e-8, atol=1e-8)
+        if f'cost_{f}' in g:
+            app, _ = trk.last_cost()
+            rows = [r for r, (_, conf) in enumerate(before) if conf]
+            assert [before[r][0] for r in rows] == g[f'cost_ids_{f}'].tolist()
+            got, want = app[rows], g[f'cost_{f}']
+            live = got < 1e4                                        # gated entries are 1e5 (linear_assignment.py:181-189)
+            assert live.sum() >= len(rows)                           # at least every track's own detection
+            worst = max(worst, float(np.abs(got[live] - want[live]).max()))
+            compared += int(live.sum())
+    assert compared >= 30 and worst <= 2e-6, (compared, worst)      # stated cosine tolerance (f32 both sides)
+    np.testing.assert_array_equal(counter.vector()[0], g['counts'])
+    assert trk._next_id == int(g['next_id'])
+
+
 def test_tracker_edge_cases():
     from deepdish_amd.deep_sort import nn_matching
     from deepdish_amd.deep_sort.tracker import Tracker

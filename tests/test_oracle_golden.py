@@ -119,3 +119,157 @@ def test_scene_golden(name):
             np.testing.assert_allclose(np.array([t.mean for t in trk.tracks]), want_m, rtol=1e-9, atol=1e-9)
     assert trk._next_id == int(g['next_id'])
     np.testing.assert_array_equal(counter.vector()[0], g['counts'])
+
+
+def _long_scene(g):
+    return Scene(seed=int(g['seed']), n_obj=int(g['n_obj']), n_frames=int(g['n_frames']), churn=False)
+
+
+def _confirmed_cost(trk, dets):
+    ids = [t.track_id for t in trk.tracks if t.state == 2]
+    return ids, trk.metric.distance(np.array([d.feature for d in dets]), ids)
+
+
+@pytest.mark.parametrize('budget', [None, 256])
+def test_long_scene_gallery_is_unbounded(budget):
+    """nn_budget=None keeps every sample (deepdish.py:515, nn_matching.py:137-154).  420 frames, eight tracks that
+    never leave: with budget None the oracle reproduces the reference's track table every frame AND the appearance
+    cost matrices the reference's metric returned at frames 200 / 300 / 360 / 419 (galleries of up to 413 samples);
+    with a 256-sample ring -- what a fixed-capacity gallery silently turns into -- the cost matrices differ from the
+    reference's from frame 300 on although the track table still agrees: only the costs expose such a gallery."""
+    g = _load('scene_long_n8.npz')
+    scene = _long_scene(g)
+    trk = ds.Tracker(ds.Metric(0.2, budget), max_iou_distance=0.7, max_age=int(g['max_age']))
+    counter = cl.CountLine(scene.countline())
+    fp = g['frame_ptr']
+    differs = {}
+    for f in range(int(g['n_frames'])):
+        boxes, scores, who, feats = scene.detections(f)
+        assert _digest(boxes, scores, feats) == g['input_digest'][f], 'synthetic input stream changed'
+        keep = ds.non_max_suppression(boxes, 0.6, scores)
+        dets = [ds.Det(boxes[i], 'person', scores[i], feats[i]) for i in keep]
+        trk.predict()
+        if f'cost_{f}' in g:
+            ids, cost = _confirmed_cost(trk, dets)
+            np.testing.assert_array_equal(ids, g[f'cost_ids_{f}'])
+            differs[f] = float(np.abs(cost - g[f'cost_{f}']).max())
+            if budget is None:
+                assert [len(trk.metric.samples[i]) for i in ids] == g[f'cost_samples_{f}'].tolist()
+        trk.update(dets)
+        counter.step(trk)
+        got_i = np.array([[t.track_id, t.state, t.time_since_update, t.hits, t.age] for t in trk.tracks],
+                         dtype=np.int64).reshape(-1, 5)
+        np.testing.assert_array_equal(got_i, g['track_int'][fp[f]:fp[f + 1]], err_msg=f'frame {f}')
+    np.testing.assert_array_equal(counter.vector()[0], g['counts'])
+    assert max(g[f'cost_samples_{f}'].max() for f in (300, 360, 419)) > 256
+    if budget is None:
+        assert max(differs.values()) < 1e-6, differs
+    else:
+        assert differs[200] < 1e-6 and min(differs[300], differs[360], differs[419]) > 1e-4, differs
+
+
+# ----------------------------------------------------------------------------- detector adaptor tails (a11, a12)
+def _label_lines(path):
+    with open(path) as f:
+        return {i: line.strip() for i, line in enumerate(f.readlines())}
+
+
+SSD_LABELS = os.path.join(os.path.dirname(G), '..', 'deepdish_amd', 'assets', 'coco_labels_ssd.txt')
+YOLO_LABELS = os.path.join(os.path.dirname(G), '..', 'deepdish_amd', 'assets', 'coco_classes.txt')
+
+
+def test_ssd_nms_boxes_golden():
+    """oracle.ssd_nms_boxes == the reference's SSDMobileNet.nms_boxes (tools/ssd_mobilenet.py:59-98), bit for bit,
+    including the class order of set(labels); and the fixture tells the reference's overlap formula from its two
+    plausible 'fixes' (areas with +1 as in deep_sort's NMS; no +1 at all as in deep_sort's IoU)."""
+    from oracle import detectors_np as dn
+    g = _load('ssd_tail.npz')
+    flips_sym = flips_plain = 0
+    for i in range(len(g['n_thr'])):
+        a, b = g['n_off'][i], g['n_off'][i + 1]
+        ka, kb = g['k_off'][i], g['k_off'][i + 1]
+        ob, ol, osc = dn.ssd_nms_boxes(g['n_boxes'][a:b], g['n_cls'][a:b], g['n_scores'][a:b], float(g['n_thr'][i]))
+        np.testing.assert_array_equal(np.concatenate(ob), g['k_boxes'][ka:kb])
+        np.testing.assert_array_equal(np.concatenate(ol), g['k_cls'][ka:kb])
+        np.testing.assert_array_equal(np.concatenate(osc), g['k_scores'][ka:kb])
+        for variant in (1, 2):
+            kept = _ssd_nms_variant(g['n_boxes'][a:b], g['n_cls'][a:b], g['n_scores'][a:b], float(g['n_thr'][i]), variant)
+            differs = kept != sorted(map(tuple, g['k_boxes'][ka:kb]))
+            if variant == 1:
+                flips_sym += differs
+            else:
+                flips_plain += differs
+    assert flips_sym >= 5 and flips_plain >= 5, (flips_sym, flips_plain)
+
+
+def _ssd_nms_variant(boxes, labels, scores, thr, variant):
+    """The same greedy loop with the overlap formula 'fixed': 1 = +1 in the areas too, 2 = no +1 anywhere."""
+    out = []
+    for c in set(labels):
+        idx = np.flatnonzero(labels == c)
+        b, s = boxes[idx], scores[idx]
+        w, h = b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]
+        one = 1.0 if variant == 1 else 0.0
+        area = (w + one) * (h + one)
+        alive = list(np.argsort(s)[::-1])
+        while alive:
+            i = alive.pop(0)
+            out.append(tuple(b[i]))
+            nxt = []
+            for j in alive:
+                iw = max(0.0, min(b[i, 0] + w[i], b[j, 0] + w[j]) - max(b[i, 0], b[j, 0]) + one)
+                ih = max(0.0, min(b[i, 1] + h[i], b[j, 1] + h[j]) - max(b[i, 1], b[j, 1]) + one)
+                inter = iw * ih
+                if inter / (area[i] + area[j] - inter) <= thr:
+                    nxt.append(j)
+            alive = nxt
+    return sorted(out)
+
+
+def test_ssd_predict_tail_golden():
+    """oracle.ssd_predict_tail / ssd_detect_filter == the reference's SSDMobileNet.predict tail (:111-150) and
+    SSD_MOBILENET.detect_image (:198-213) on 240 canned interpreter outputs (NaN rows, tiny boxes, 4 image sizes)."""
+    from oracle import detectors_np as dn
+    g = _load('ssd_tail.npz')
+    lines = _label_lines(SSD_LABELS)
+    name_to_id = {v: k - 1 for k, v in lines.items() if k > 0}
+    all_names = [lines[k] for k in sorted(lines) if k > 0]
+    wanted_p = [str(x) for x in g['wanted_person']]
+    assert set(np.unique(g['kind'])) == {0, 1, 2, 3}
+    for i in range(len(g['boxes'])):
+        out = [g['boxes'][i], g['cls'][i], g['scores'][i], 10.0]
+        size = tuple(int(v) for v in g['size'][i])
+        pb, pl, ps = dn.ssd_predict_tail(out, lines, original_image_size=size)
+        a, b = g['off'][i], g['off'][i + 1]
+        assert len(ps) == b - a, i
+        if b > a:
+            np.testing.assert_array_equal(np.asarray(pb), g['pred_boxes'][a:b])
+            np.testing.assert_array_equal([name_to_id[x] for x in pl], g['pred_cls'][a:b])
+            np.testing.assert_array_equal(np.asarray(ps, np.float32), g['pred_scores'][a:b])
+        for wanted, off, kb, kc, ks in ((all_names, 'doff', 'det_boxes', 'det_cls', 'det_scores'),
+                                        (wanted_p, 'poff', 'pdet_boxes', 'pdet_cls', 'pdet_scores')):
+            db, dl, dsc = dn.ssd_detect_filter(pb, pl, ps, wanted, 0.5)
+            a, b = g[off][i], g[off][i + 1]
+            assert len(dsc) == b - a, (i, off)
+            if b > a:
+                np.testing.assert_array_equal(np.asarray(db, np.float64), g[kb][a:b])
+                np.testing.assert_array_equal([name_to_id[x] for x in dl], g[kc][a:b])
+                np.testing.assert_array_equal(np.asarray(dsc, np.float32), g[ks][a:b])
+
+
+def test_yolov5_tail_golden():
+    """oracle.yolov5_detect_tail == the reference's YOLOV5.detect_image after get_tensor (tools/yolov5.py:120-146):
+    tlwh boxes (f32), label, confidence of every returned row, bit for bit."""
+    from oracle import detectors_np as dn
+    g = _load('yolov5_tail.npz')
+    lines = _label_lines(YOLO_LABELS)
+    name_to_id = {v: k for k, v in lines.items()}
+    for i in range(len(g['thr'])):
+        raw = g['raw_f16'][g['roff'][i]:g['roff'][i + 1]].astype(np.float32)[None]
+        wanted = str(g['wanted'][i]).split(',')
+        b, l, s = dn.yolov5_detect_tail(raw, lines, wanted, float(g['thr'][i]), tuple(int(v) for v in g['size'][i]))
+        a, e = g['off'][i], g['off'][i + 1]
+        assert len(s) == e - a > 0, i
+        np.testing.assert_array_equal(np.asarray(b, np.float32), g['boxes'][a:e])
+        np.testing.assert_array_equal([name_to_id[x] for x in l], g['labels'][a:e])
+        np.testing.assert_array_equal(np.asarray(s, np.float32), g['scores'][a:e])
