@@ -150,7 +150,7 @@ def _cpu_model():
     return 'unknown'
 
 
-def cpu_baseline(n_frames, W, H):
+def cpu_baseline(n_frames, W, H, config=2):
     """The oracle's CPU path on the same workload (kind "port"), bounded sample, rank 0 only -- SURVEY.md 8(d):
     three seeds (median), every stage timed with 1 thread and with min(4, cores) threads (torch intra-op threads for
     the networks, BLAS / OpenMP pool for the numpy tracker; the reference's default is --num-threads 4,
@@ -165,8 +165,12 @@ def cpu_baseline(n_frames, W, H):
     from oracle import deepsort_np as ds, countline_np as cl, image_np, nets_torch
     ncores = os.cpu_count() or 1
     settings = sorted({1, min(4, ncores)})
-    wd_ssd, wd_mars = nets.synthetic_ssd_weights(1234), nets.synthetic_mars_weights(1234)
+    from oracle import detectors_np
+    yolo = config == 3
+    wd_mars = nets.synthetic_mars_weights(1234)
+    wd_det = nets.synthetic_yolov5s_weights(1234) if yolo else nets.synthetic_ssd_weights(1234)
     anchors, _ = nets.ssd_anchors(300)
+    yolo_labels = {i: l.strip() for i, l in enumerate(open(os.path.join(ROOT, 'deepdish_amd', 'assets', 'coco_classes.txt')))}
     per_seed, stage_pick = [], {}
     keep_for_parity = None
     for seed in (0, 1, 2):
@@ -179,8 +183,13 @@ def cpu_baseline(n_frames, W, H):
 
         def detector(f):
             rgba = np.dstack([frames[f][..., ::-1], np.full((H, W, 1), 255, np.uint8)])
+            if yolo:
+                img = Image.fromarray(rgba, 'RGBA').convert('RGB').resize((640, 640), Image.LANCZOS)
+                raw = nets_torch.yolov5s_forward(wd_det, np.asarray(img)[None])
+                detectors_np.yolov5_detect_tail(raw, yolo_labels, ['person'], 0.25, (W, H))
+                return
             img = Image.fromarray(rgba, 'RGBA').convert('RGB').resize((300, 300), Image.LANCZOS)
-            raw = nets_torch.ssd_forward(wd_ssd, np.asarray(img)[None])
+            raw = nets_torch.ssd_forward(wd_det, np.asarray(img)[None])
             nets_torch.ssd_postprocess(raw[0], anchors)
 
         def encoder(f):
@@ -229,19 +238,19 @@ def cpu_baseline(n_frames, W, H):
     used = max(s['threads_used'] for s in stages.values())
     base = dict(value=value, unit='frames/s', cores=used, kind='port',
                 sample='3 seeds x %d frames of the same %dx%d / ~20-detection workload (median), oracle path: Pillow Lanczos + '
-                       'torch-CPU f32 SSD-MobileNet-v1 and MARS + numpy deep_sort; per stage the faster of %s threads'
-                       % (n_frames, W, H, ' / '.join(map(str, settings))),
+                       'torch-CPU f32 %s and MARS + numpy deep_sort; per stage the faster of %s threads'
+                       % (n_frames, W, H, 'YOLOv5s' if yolo else 'SSD-MobileNet-v1', ' / '.join(map(str, settings))),
                 per_seed=[round(v, 2) for v in per_seed], stages=stages,
                 host=dict(cpu_model=_cpu_model(), logical_cores=ncores))
     return base, keep_for_parity
 
 
-def gpu_sample_check(sc, n_frames, oracle_counts, oracle_table, device, W, H):
+def gpu_sample_check(sc, n_frames, oracle_counts, oracle_table, device, W, H, model):
     """The HIP path over the very frames the CPU baseline just processed (seed 0, one stream): crossing counts and the
     final track table (id, state, time_since_update, hits) must be identical."""
     import torch
     from deepdish_amd.multipipe import MultiStreamPipeline
-    mp1 = MultiStreamPipeline(1, input_size=(W, H))
+    mp1 = MultiStreamPipeline(1, model=model, input_size=(W, H))
     for f in range(n_frames + 2):
         boxes, scores, _, _ = sc.detections(f)
         inj = mp1.pack_injected([([tuple(int(v) for v in b) for b in boxes], ['person'] * len(boxes), [float(x) for x in scores])])
@@ -421,10 +430,10 @@ def main():
             except Exception as e:                            # never let the extra pass hide the headline number
                 out['roofline'] = None
                 out['roofline_error'] = repr(e)
-            if world == 1 and not args.no_cpu_baseline and args.config in (2, 5):
-                out['cpu_baseline'], (sc0, ocounts, otable) = cpu_baseline(args.cpu_frames, W, H)
+            if world == 1 and not args.no_cpu_baseline:
+                out['cpu_baseline'], (sc0, ocounts, otable) = cpu_baseline(args.cpu_frames, W, H, args.config)
                 try:
-                    out['parity_sample'] = gpu_sample_check(sc0, args.cpu_frames, ocounts, otable, f'cuda:{local_rank}', W, H)
+                    out['parity_sample'] = gpu_sample_check(sc0, args.cpu_frames, ocounts, otable, f'cuda:{local_rank}', W, H, cfg['model'])
                 except Exception as e:
                     out['parity_sample'] = dict(error=repr(e))
         os.write(real_stdout, (json.dumps(out) + '\n').encode())

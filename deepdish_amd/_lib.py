@@ -70,6 +70,7 @@ SIGNATURES = {
     'dd_net_forward': [P, P, c_int, P],
     'dd_net_output': [P, c_int, POINTER(P), POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int),
                       POINTER(c_int)],
+    'dd_net_input_size': [P, POINTER(c_int), POINTER(c_int)],
     'dd_net_max_batch': [P, POINTER(c_int)],
     'dd_net_last_batch': [P, POINTER(c_int)],
     'dd_net_read': [P, c_int, c_int, P, c_int, P],

@@ -1112,6 +1112,299 @@ __global__ __launch_bounds__(256) void dwpw_k(const ConvP P) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// MobileNet block with many channels (Cin = 256 / 512 / 1024) in one launch: depthwise 3x3 -> pointwise 1x1 as a
+// K-looped GEMM whose pixel operand never exists in HBM.  For every 64-channel slab of K the block computes the
+// depthwise result of its 128 pixels (+bias, activation, rounded to f16 exactly as dwconv3_k stores it) straight
+// into the LDS image the MFMA fragments are read from, while the slab's [256][64] weight panel arrives by
+// global_load_lds.  One read of the block input (plus halo, served by L1 / L2) and one write of the block output
+// instead of two of each.
+//   * 512 threads = 8 waves; tile 128 pixels x 256 output channels (wave: 64 x 64, 64 accumulator registers).
+//   * pixels in "pair order": a pair is 2 consecutive output pixels of one row; thread (pair, 8-channel group)
+//     owns one depthwise item per slab: 3 x (3 + stride) window loads of 16 bytes through a buffer resource whose
+//     range check turns out-of-image taps into zeros (offsets are fixed per thread; the slab advances the scalar
+//     offset), nine filter taps from an LDS copy of the depthwise weights.
+//   * schedule per slab ks (one barrier): issue the window loads and the weight fill of slab ks+1, MFMAs of slab
+//     ks, depthwise of slab ks+1 into the other X buffer.  The loads of a slab are in flight under the MFMAs of
+//     the slab before it.
+//   * Cout > 256: the depthwise part is recomputed by each of the Cout / 256 channel tiles (they run back to back on
+//     one XCD, so the input is read from HBM once).
+constexpr int DWB_BM = 128, DWB_BN = 256;
+
+template <int STRIDE, int DACT, int ACT>
+__global__ __launch_bounds__(512) void dwpw_big_k(const ConvP P) {
+    constexpr int BM = DWB_BM, BN = DWB_BN, MI = 4, NI = 4, TX = 2, NCOL = (TX - 1) * STRIDE + 3;
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    const int C = P.cin;
+    _Float16 *xs = lds;                                          // [2][BM][64]
+    _Float16 *ws = lds + 2 * BM * 64;                            // [2][BN][64]
+    _Float16 *dww = ws + 2 * BN * 64;                            // [9][C]
+    float *dwb = reinterpret_cast<float *>(dww + 9 * C);         // [C]
+    int *mrow = reinterpret_cast<int *>(dwb + C);                // [BM] output pixel of each tile row, -1 = none
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int fr = lane & 15, fq = lane >> 4, sw = fr & 7;
+    const unsigned lin = dd_xcd_remap(blockIdx.x, gridDim.x);
+    const int gy = P.cout_pad / BN;
+    const int p0 = (int)(lin / gy) * (BM / TX), n0 = (int)(lin % gy) * BN;       // first pair of the tile; channel tiles fastest
+    const int KS = C >> 6;
+
+    // ---- depthwise weights and bias of the whole layer -> LDS
+    for (int i = tid; i < 9 * C / 8; i += 512) reinterpret_cast<h8 *>(dww)[i] = reinterpret_cast<const h8 *>(P.dw_w)[i];
+    for (int i = tid; i < C / 4; i += 512) reinterpret_cast<f4 *>(dwb)[i] = reinterpret_cast<const f4 *>(P.dw_bias)[i];
+
+    // ---- this thread's depthwise item: pair pl of the tile, channel group g of the slab
+    const int pl = tid >> 3, g = tid & 7;
+    unsigned woff[3][NCOL];                                      // byte offsets of the window taps at slab 0; 0x80000000 = outside
+    {
+        const int wo2 = (P.wo + TX - 1) / TX;
+        const int Q = p0 + pl;
+        const bool qok = Q < P.total_quads;
+        const int Qc = qok ? Q : 0;
+        const int oxq = Qc % wo2, t2 = Qc / wo2;
+        const int oy = t2 % P.ho, n = t2 / P.ho;
+        const int ox0 = oxq * TX;
+        const int ix0 = ox0 * STRIDE - P.pad_l, iy0 = oy * STRIDE - P.pad_t;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int cx = 0; cx < NCOL; ++cx) {
+                const int iy = iy0 + kh, ix = ix0 + cx;
+                const bool ok = qok && (unsigned)iy < (unsigned)P.H && (unsigned)ix < (unsigned)P.W;
+                woff[kh][cx] = ok ? (unsigned)((((n * P.H + iy) * P.W + ix) * P.cs_in + P.coff_in + g * 8) * 2) : 0x80000000u;
+            }
+        if (g == 0) {
+#pragma unroll
+            for (int j = 0; j < TX; ++j) mrow[pl * TX + j] = (qok && ox0 + j < P.wo) ? (n * P.ho + oy) * P.wo + ox0 + j : -1;
+        }
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(P.in), 0, P.p[0], 0x00020000);
+#endif
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    u4v win[3][NCOL];
+    auto load_window = [&](int ks) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int cx = 0; cx < NCOL; ++cx) win[kh][cx] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, woff[kh][cx], ks * 128, 0);
+#endif
+    };
+    // weight panel rows in fragment order (see rw_weight_row), 16-byte chunks XOR-swizzled on the source side
+    const int rr = lane >> 3, pp = lane & 7;
+    const _Float16 *wbase[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int L = (wave * 4 + i) * 8 + rr;
+        const int row = (L & ~31) | (((L & 15) >> 2) << 3) | (((L >> 4) & 1) << 2) | (L & 3);
+        wbase[i] = P.w + (size_t)(n0 + row) * P.kpad + (pp ^ rr) * 8;
+    }
+    auto fill_w = [&](int ks, int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lds_fill16(wbase[i] + (ks << 6), ws + (size_t)(buf * BN + (wave * 4 + i) * 8) * 64);
+    };
+    auto depthwise = [&](int ks, int buf) {                      // win[] holds slab ks -> X[buf]
+        const int c0 = (ks << 6) + g * 8;
+        float acc[TX][8];
+        {
+            const f4 b0 = *reinterpret_cast<const f4 *>(dwb + c0), b1 = *reinterpret_cast<const f4 *>(dwb + c0 + 4);
+#pragma unroll
+            for (int j = 0; j < TX; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { acc[j][i] = b0[i]; acc[j][4 + i] = b1[i]; }
+        }
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const h8 w = *reinterpret_cast<const h8 *>(dww + (kh * 3 + kw) * C + c0);
+#pragma unroll
+                for (int j = 0; j < TX; ++j) dw_tap(acc[j], __builtin_bit_cast(h8, win[kh][j * STRIDE + kw]), w);
+            }
+        const int dact = DACT < 0 ? P.dw_act : DACT;
+#pragma unroll
+        for (int j = 0; j < TX; ++j) {
+            const int prow = pl * TX + j;
+            h8 o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = (_Float16)apply_act(acc[j][i], dact);
+            u4v ou = __builtin_bit_cast(u4v, o);
+            ou &= mrow[prow] >= 0 ? 0xFFFFFFFFu : 0u;               // rows past the edge of the image / batch are zero
+            *reinterpret_cast<u4v *>(xs + (size_t)(buf * BM + prow) * 64 + ((g ^ (prow & 7)) << 3)) = ou;
+        }
+    };
+
+    // ---- pointwise accumulators start from the bias of the lane's output channels
+    Epi8 E[2];
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2) E[g2] = epi8_load(P, n0 + wn * 64 + g2 * 32 + fq * 8);
+    f4 acc[NI][MI];
+#pragma unroll
+    for (int a = 0; a < NI; ++a)
+#pragma unroll
+        for (int b = 0; b < MI; ++b) acc[a][b] = (a & 1) ? E[a >> 1].b1 : E[a >> 1].b0;
+
+    load_window(0);
+    fill_w(0, 0);
+    __syncthreads();                                              // dww / dwb / mrow visible (and slab 0 landed)
+    depthwise(0, 0);
+    __syncthreads();
+    for (int ks = 0; ks < KS; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < KS) { load_window(ks + 1); fill_w(ks + 1, buf ^ 1); }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            h8 xf[MI], wf[NI];
+#pragma unroll
+            for (int b = 0; b < MI; ++b)
+                xf[b] = *reinterpret_cast<const h8 *>(xs + (size_t)(buf * BM + (wm * MI + b) * 16 + fr) * 64 + (((kk << 2) + fq) ^ sw) * 8);
+#pragma unroll
+            for (int a = 0; a < NI; ++a)
+                wf[a] = *reinterpret_cast<const h8 *>(ws + (size_t)(buf * BN + (wn * NI + a) * 16 + fr) * 64 + (((kk << 2) + fq) ^ sw) * 8);
+#pragma unroll
+            for (int a = 0; a < NI; ++a)
+#pragma unroll
+                for (int b = 0; b < MI; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[a], xf[b], acc[a][b], 0, 0, 0);
+        }
+        if (ks + 1 < KS) depthwise(ks + 1, buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int b = 0; b < MI; ++b) {
+        const int m = mrow[(wm * MI + b) * 16 + fr];
+        if (m < 0) continue;
+#pragma unroll
+        for (int g2 = 0; g2 < 2; ++g2) {
+            float o[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { o[r] = acc[2 * g2][b][r]; o[4 + r] = acc[2 * g2 + 1][b][r]; }
+            conv_epilogue_f16x8<ACT, false, 0>(P, E[g2], m, n0 + wn * 64 + g2 * 32 + fq * 8, o);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Weight-stationary pointwise GEMM for the 1x1 layers with many pixels (MobileNet pointwise convs).
+//
+// conv_glds_k moves BOTH operands of every K step from L2 to LDS and is bound by that fill rate (17 B/clk per CU
+// measured).  Here the weight operand never touches LDS: a block of NW waves owns a slice of 32 * NW
+// output channels, every wave keeps the [32 channels][K] rows it needs as MFMA A-fragments in registers for the
+// whole launch (K = 512: 128 VGPRs), and persistent blocks stream 64-pixel tiles of the activation matrix through
+// an LDS ring of D stages, one 64-wide K slab (8 KiB) per stage:
+//   * fills are global_load_lds_dwordx4 issued D - 1 stages ahead and waited for with a counted vmcnt (never 0 inside
+//     the loop) followed by a raw s_barrier, so (D - 2) x 8 KiB stay in flight across barriers;
+//   * a filled byte feeds 32 * NW output channels (NW = 8: 256 FLOP per byte, twice what a 256 x 256 tile of the
+//     two-operand kernel gets) and the LDS is read for the pixel fragments only;
+//   * pixel fragments are read one K slice ahead of the MFMAs that use them (the first slice of stage s + 1 under the
+//     last MFMAs of stage s), so an LDS read latency is never exposed behind a barrier;
+//   * blocks that share a pixel range but own different channel slices sit on one XCD and walk their tiles in step,
+//     so the activations leave HBM once.
+// Epilogue stores count in vmcnt like the fills; the loop's wait is the store-free count, which only shortens the
+// prefetch distance for the few stages after a tile's stores (never too short a wait).
+constexpr int WS_BM = 64;
+
+template <int KS, int NW, int D, int ACT>
+__global__ __launch_bounds__(NW * 64) void conv_ws_k(const ConvP P, const int n_slices) {
+    constexpr int BM = WS_BM, MI = 4, NI = 2, G = 8 / NW;       // G: fills per wave and stage
+    static_assert((KS & (KS - 1)) == 0 && (D & (D - 1)) == 0 && KS % 2 == 0 && 8 % NW == 0, "stage arithmetic uses masks");
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];         // [D][64 pixels][64 halves]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4, sw = fr & 7;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int slice = j % n_slices, worker = (j / n_slices) * 8 + xcd;
+    const int n_workers = ((int)(gridDim.x >> 3) / n_slices) * 8;
+    const int T = (P.m + BM - 1) / BM;
+    const int ntiles = worker < T ? (T - worker + n_workers - 1) / n_workers : 0;
+    const int cbase = slice * (32 * NW) + wave * 32;
+
+    h8 wf[KS * 2][NI];                                          // this wave's weight rows, every K slice
+#pragma unroll
+    for (int k = 0; k < KS * 2; ++k)
+#pragma unroll
+        for (int a = 0; a < NI; ++a)
+            wf[k][a] = *reinterpret_cast<const h8 *>(P.w + (size_t)(cbase + rw_weight_row(a, fr)) * P.kpad + k * 32 + fq * 8);
+    const Epi8 E = epi8_load(P, cbase + fq * 8);
+    f4 acc[NI][MI];                                             // from zero, bias in the epilogue: the summation order of
+#pragma unroll                                                  // conv_glds_k, so a frame gives the same bits whichever kernel
+    for (int a = 0; a < NI; ++a)                                // its batch size selects
+#pragma unroll
+        for (int b = 0; b < MI; ++b) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
+    const int dbg = P.p[5];                                      // measurement aid (DD_WS_MODE): 1 = no fills in the loop, 2 = no MFMAs
+
+    const int rr = lane >> 3, pp = lane & 7;
+    const int gch = (pp ^ rr) * 8;
+    auto fill = [&](int st) {                                    // stage st of this block: tile st / KS, K slab st % KS
+        const int ti = st / KS, ks = st & (KS - 1);
+        const int m0 = (worker + ti * n_workers) * BM;
+        _Float16 *dst = lds + (size_t)(st & (D - 1)) * (BM * 64);
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int grp = wave * G + i;
+            const int m = m0 + grp * 8 + rr;
+            const _Float16 *src = (ti < ntiles && m < P.m) ? P.in + (size_t)m * P.cs_in + P.coff_in + (ks << 6) + gch : P.zero;
+            lds_fill16(src, dst + grp * 8 * 64);                 // past the last tile: a zero line, so the wait count stays uniform
+        }
+    };
+    h8 xa[MI], xb[MI];                                           // pixel fragments: K slice 0 of the next stage / slice 1 of this one
+    auto read_frags = [&](int st, int kk, h8 (&x)[MI]) {
+        const _Float16 *xs = lds + (size_t)(st & (D - 1)) * (BM * 64);
+#pragma unroll
+        for (int b = 0; b < MI; ++b)
+            x[b] = *reinterpret_cast<const h8 *>(xs + (b * 16 + fr) * 64 + (((kk << 2) + fq) ^ sw) * 8);
+    };
+    for (int st = 0; st < D - 1; ++st) fill(st);
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(G * (D - 2)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#endif
+    read_frags(0, 0, xa);
+    for (int ti = 0; ti < ntiles; ++ti) {
+        const int m0 = (worker + ti * n_workers) * BM;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int st = ti * KS + ks;
+#if defined(__HIP_DEVICE_COMPILE__)
+            // this wave's fills of stage st + 1 have landed and its reads of stage st - 1 have returned ...
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(G * (D - 3)) : "memory");
+            __builtin_amdgcn_s_barrier();                        // ... everybody's have
+            asm volatile("" ::: "memory");
+#endif
+            if (dbg != 1) fill(st + D - 1);                      // into the buffer stage st - 1 has left
+            read_frags(st, 1, xb);                               // lands under the MFMAs of slice 0
+            if (dbg != 2) {
+#pragma unroll
+                for (int a = 0; a < NI; ++a)
+#pragma unroll
+                    for (int b = 0; b < MI; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks * 2][a], xa[b], acc[a][b], 0, 0, 0);
+            }
+            read_frags(st + 1, 0, xa);                           // next stage's slice 0, under the MFMAs of slice 1
+            if (dbg != 2) {
+#pragma unroll
+                for (int a = 0; a < NI; ++a)
+#pragma unroll
+                    for (int b = 0; b < MI; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks * 2 + 1][a], xb[b], acc[a][b], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < MI; ++b) {
+            const int m = m0 + b * 16 + fr;
+            float o[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { o[r] = acc[0][b][r]; o[4 + r] = acc[1][b][r]; }
+            if (m < P.m) conv_epilogue_f16x8<ACT, true, 0>(P, E, m, cbase + fq * 8, o);
+            acc[0][b] = acc[1][b] = f4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the look-ahead fills past the last tile
+#endif
+}
+
 // Split-K tail: sum the partial slabs in a fixed order (bitwise reproducible) and run the epilogue.
 __global__ __launch_bounds__(256) void conv_splitk_finish_k(const ConvP P) {
     const int groups = P.cout_pad >> 2;
@@ -1488,6 +1781,68 @@ int launch_dwpw(hipStream_t s, ConvP &P, int device) {
     return DD_OK;
 }
 
+
+// 1x1 / stride 1 / unpadded layer with >= 16 K pixels and K = 256 or 512: weight-stationary persistent kernel.
+bool ws_eligible(const ConvP &P) {
+    // Opt-in (DD_WS=1).  Measured on 19x19x512 -> 512: 41-44 us against 49-53 us for conv_glds_k at 192 frames per launch, but
+    // at the 96-frame launches of the default bench configuration the persistent blocks lose to tile quantisation and to
+    // the other worker groups' kernels they cannot share a CU with (-1.5 % end to end, same-box A/B); see DESIGN.md.
+    static const bool on = getenv("DD_WS") != nullptr;
+    return on && P.kh == 1 && P.kw == 1 && P.stride == 1 && P.pad_t == 0 && P.pad_l == 0 && P.ho == P.H && P.wo == P.W &&
+           (P.cin == 256 || P.cin == 512) && P.kpad == P.cin && P.epi == EPI_F16 && !P.res && !P.out2 && P.m >= 16384 &&
+           P.cout_pad % 128 == 0 && (P.act == ACT_RELU6 || P.act == ACT_NONE || P.act == ACT_SILU);
+}
+
+template <int KS>
+int launch_conv_ws(hipStream_t s, ConvP &P, int device) {
+    constexpr int NW = 4, D = 8;                                 // 128-channel slices, 64 KiB ring: two blocks per CU (measured faster than
+                                                                 // one 8-wave block with a 128 KiB ring: 43.9 vs 46.8 us, 19x19x512 -> 512 at 192 frames)
+    const int n_slices = P.cout_pad / (32 * NW);
+    P.splitk = 1;
+    static const int dbg_mode = getenv("DD_WS_MODE") ? atoi(getenv("DD_WS_MODE")) : 0;
+    P.p[5] = dbg_mode;
+    constexpr size_t lds_bytes = (size_t)D * WS_BM * 64 * sizeof(_Float16);
+    DD_REQUIRE(n_slices >= 1 && (256 * 4 / NW / 4) % n_slices == 0, DD_E_ARG, "conv_ws: %d channel slices", n_slices);
+    static DevOnce once;
+    const int rc = once.run(device, [&]() -> int {
+        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_ws_k<KS, NW, D, ACT_RELU6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_ws_k<KS, NW, D, ACT_SILU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_ws_k<KS, NW, D, ACT_NONE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        return DD_OK;
+    });
+    if (rc != DD_OK) return rc;
+    const dim3 grid(2 * 256 * 4 / NW);                           // persistent: 8 waves per CU
+    if (P.act == ACT_RELU6) hipLaunchKernelGGL((conv_ws_k<KS, NW, D, ACT_RELU6>), grid, dim3(NW * 64), lds_bytes, s, P, n_slices);
+    else if (P.act == ACT_SILU) hipLaunchKernelGGL((conv_ws_k<KS, NW, D, ACT_SILU>), grid, dim3(NW * 64), lds_bytes, s, P, n_slices);
+    else hipLaunchKernelGGL((conv_ws_k<KS, NW, D, ACT_NONE>), grid, dim3(NW * 64), lds_bytes, s, P, n_slices);
+    DD_LAUNCH_CHECK();
+    return DD_OK;
+}
+
+template <int STRIDE>
+int launch_dwpw_big(hipStream_t s, ConvP &P, int device, int nimg) {
+    const size_t in_bytes = (size_t)nimg * P.H * P.W * P.cs_in * sizeof(_Float16);
+    DD_REQUIRE(in_bytes < (1ull << 31), DD_E_CAPACITY, "dwpw_big: input of %zu bytes exceeds the 2 GiB buffer-resource window", in_bytes);
+    P.p[0] = (int)in_bytes;
+    P.total_quads = nimg * P.ho * ((P.wo + 1) / 2);              // pairs
+    const size_t lds_bytes = (size_t)(2 * DWB_BM + 2 * DWB_BN) * 64 * sizeof(_Float16) + (size_t)P.cin * (18 + 4) + DWB_BM * sizeof(int);
+    const bool relu6 = P.act == ACT_RELU6 && P.dw_act == ACT_RELU6;
+    static DevOnce once;
+    const int rc = once.run(device, [&]() -> int {
+        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dwpw_big_k<STRIDE, ACT_RELU6, ACT_RELU6>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dwpw_big_k<STRIDE, -1, -1>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        return DD_OK;
+    });
+    if (rc != DD_OK) return rc;
+    const dim3 grid((unsigned)(dd_ceil_div(P.total_quads, DWB_BM / 2) * (P.cout_pad / DWB_BN)));
+    if (relu6) hipLaunchKernelGGL((dwpw_big_k<STRIDE, ACT_RELU6, ACT_RELU6>), grid, dim3(512), lds_bytes, s, P);
+    else hipLaunchKernelGGL((dwpw_big_k<STRIDE, -1, -1>), grid, dim3(512), lds_bytes, s, P);
+    DD_LAUNCH_CHECK();
+    return DD_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1549,6 +1904,12 @@ int dd_net_destroy(dd_net *n) {
 int dd_net_last_batch(dd_net *n, int *out_host) {
     DD_REQUIRE(n && out_host, DD_E_ARG, "dd_net_last_batch: NULL argument");
     *out_host = n->last_batch;
+    return DD_OK;
+}
+
+int dd_net_input_size(dd_net *n, int *h_host, int *w_host) {
+    DD_REQUIRE(n && h_host && w_host, DD_E_ARG, "dd_net_input_size: NULL argument");
+    *h_host = n->in_h; *w_host = n->in_w;
     return DD_OK;
 }
 
@@ -1679,6 +2040,8 @@ int dd_net_forward(dd_net *net, const uint8_t *input, int nimg, void *stream) {
                     // whole filter in registers, input patch staged once (see conv3x3_rw_k)
                     if (o[29]) { P.p[0] = td->h; P.p[1] = td->w; }      // fused 3x3/2 max pool: dst is the pooled tensor
                     rc = launch_conv3x3_rw(s, P, nimg, o[29] != 0, net->ctx->device);
+                } else if (ws_eligible(P)) {
+                    rc = P.cin == 256 ? launch_conv_ws<4>(s, P, net->ctx->device) : launch_conv_ws<8>(s, P, net->ctx->device);
                 } else if (P.cout_pad <= 32) {
                     // 32 output channels: 128 pixels per block (each wave 32 px x 32 ch) once there are enough pixels
                     rc = bk32 ? launch_conv<4, 1, 1, 2, 32, false>(s, P, net->slab, net->max_batch, net->ctx->device)
@@ -1747,6 +2110,8 @@ int dd_net_forward(dd_net *net, const uint8_t *input, int nimg, void *stream) {
                 else if (P.cin == 64 && P.cout_pad == 128 && P.stride == 2) rc = launch_dwpw<2, 2, 4, 64, 2>(s, P, net->ctx->device);
                 else if (P.cin == 128 && P.cout_pad == 128 && P.stride == 1) rc = launch_dwpw<2, 2, 2, 128, 1>(s, P, net->ctx->device);
                 else if (P.cin == 128 && P.cout_pad == 256 && P.stride == 2) rc = launch_dwpw<1, 4, 4, 128, 2>(s, P, net->ctx->device);
+                else if (P.cin >= 256 && P.cin % 64 == 0 && P.cin <= 1024 && P.cout_pad % DWB_BN == 0 && P.kpad == P.cin)
+                    rc = P.stride == 1 ? launch_dwpw_big<1>(s, P, net->ctx->device, nimg) : launch_dwpw_big<2>(s, P, net->ctx->device, nimg);
                 else DD_REQUIRE(false, DD_E_ARG, "dd_net_forward: no fused dw+pw kernel for %d -> %d stride %d", P.cin, P.cout_pad, P.stride);
                 if (rc != DD_OK) return rc;
                 break;

@@ -18,6 +18,8 @@ struct dd_mog2;
 namespace ddk {
 int mog2_apply(dd_mog2 *m, hipStream_t s, const uint8_t *frames, double learning_rate, uint8_t *mask, uint8_t *masked);
 int mask_box_count(hipStream_t s, const uint8_t *mask, int H, int W, const int *d_boxes, const int *d_box_stream, int K, int *d_counts);
+int yolov5_decode(hipStream_t s, const float *raw, int n_rows, int n_cls, float thr, float img_w, float img_h, float *out_boxes,
+                  float *out_scores, int *out_cls, int cap, int *out_n, int batch, void *scratch);
 int ssd_finish(hipStream_t s, const float *boxes, const float *cls, const float *scores, int batch, int max_det, double conf,
                double iou_thr, double img_w, double img_h, double *out_boxes, int *out_cls, double *out_scores, int *out_n);
 int tracker_group_create(dd_ctx *ctx, int n, double max_cos, double max_iou, int max_age, int n_init, int budget, int tcap,
@@ -29,10 +31,13 @@ int trackers_update_match(dd_tracker **ts, int S);
 int trackers_update_end(dd_tracker **ts, int S);
 }
 extern "C" int dd_net_max_batch(dd_net *net, int *out_host);
+extern "C" int dd_net_input_size(dd_net *net, int *h_host, int *w_host);
 
 namespace {
 
 constexpr int MAX_DET = 10;              // N_max of the stock SSD post-process op
+constexpr int YOLO_CAP = 4096;           // candidate rows per frame the YOLOv5 adaptor hands on (more is a loud DD_E_CAPACITY)
+enum { DET_SSD = 0, DET_YOLOV5 = 1 };
 enum { CONFIRMED = 2, DELETED = 3 };
 
 struct Votes {                         // track.py:78-81,147-151: label -> confidences, in first-seen order
@@ -82,7 +87,8 @@ struct dd_pipeline {
     dd_ctx *ctx = nullptr;
     int S = 0, H = 0, W = 0;
     dd_net *det = nullptr, *enc = nullptr;
-    int det_in = 300, n_anchors = 0, n_classes = 0, enc_batch = 0;
+    int det_kind = DET_SSD, det_in = 300, det_in_w = 300, n_anchors = 0, n_classes = 0, enc_batch = 0;
+    int label_offset = 1;                      // class id c is line c + label_offset of the label file (SSD 1, YOLOv5 0)
     float *d_anchors = nullptr;
     double nms_overlap = 0.6, det_conf = 0.5;
     double line[4] = {0, 0, 0, 0};
@@ -119,7 +125,7 @@ int wanted_index(const dd_pipeline *p, const std::string &name) {
 }
 
 std::string class_name(const dd_pipeline *p, int c) {
-    if (c >= 0 && c + 1 < (int)p->labels.size()) return p->labels[c + 1];
+    if (c >= 0 && c + p->label_offset < (int)p->labels.size()) return p->labels[c + p->label_offset];
     return std::string();
 }
 
@@ -165,7 +171,7 @@ int dd_pipeline_create(dd_ctx *ctx, int n_streams, int frame_h, int frame_w, dd_
                        int gallery_capacity, dd_pipeline **out) {
     DD_REQUIRE(ctx && encoder && out && n_streams > 0 && frame_h > 0 && frame_w > 0 && labels_nl && wanted_nl && line_host,
                DD_E_ARG, "dd_pipeline_create: bad argument");
-    DD_REQUIRE(!detector || (anchors_host && n_anchors > 64 && n_classes > 1), DD_E_ARG, "dd_pipeline_create: detector needs anchors");
+    DD_REQUIRE(!detector || (n_anchors > 64 && n_classes > 1), DD_E_ARG, "dd_pipeline_create: detector needs its head shape");
     dd_pipeline *p = new dd_pipeline();
     p->ctx = ctx; p->S = n_streams; p->H = frame_h; p->W = frame_w;
     p->det = detector; p->enc = encoder; p->n_anchors = n_anchors; p->n_classes = n_classes;
@@ -185,18 +191,28 @@ int dd_pipeline_create(dd_ctx *ctx, int n_streams, int frame_h, int frame_w, dd_
         int db = 0;
         if ((rc = dd_net_max_batch(detector, &db)) != DD_OK) return rc;
         DD_REQUIRE(db >= n_streams, DD_E_CAPACITY, "dd_pipeline_create: detector max_batch %d < %d streams", db, n_streams);
+        if ((rc = dd_net_input_size(detector, &p->det_in, &p->det_in_w)) != DD_OK) return rc;
+        p->det_kind = anchors_host ? DET_SSD : DET_YOLOV5;
+        if (p->det_kind == DET_YOLOV5) { p->label_offset = 0; p->det_conf = 0.25; }          // yolov5.py:38,134
         DD_HIP(hipStreamCreateWithFlags(&p->det_stream, hipStreamNonBlocking));
         DD_HIP(hipEventCreateWithFlags(&p->det_done, hipEventDisableTiming));
         DD_HIP(hipEventCreateWithFlags(&p->main_mark, hipEventDisableTiming));
-        DD_HIP(hipMalloc(&p->d_anchors, (size_t)n_anchors * 4 * sizeof(float)));
-        DD_HIP(hipMemcpy(p->d_anchors, anchors_host, (size_t)n_anchors * 4 * sizeof(float), hipMemcpyHostToDevice));
         const size_t S = n_streams;
-        if ((rc = p->d_resized.reserve(S * p->det_in * p->det_in * 3)) != DD_OK) return rc;
-        if ((rc = p->d_tmp.reserve(S * frame_h * p->det_in * 3 + 64)) != DD_OK) return rc;
-        if ((rc = p->d_post.reserve(ddk::ssd_post_scratch_bytes(n_anchors, n_streams))) != DD_OK) return rc;
-        if ((rc = p->d_det.reserve(S * MAX_DET * 6 * sizeof(float) + S * sizeof(int) + 256)) != DD_OK) return rc;
-        if ((rc = p->d_fin.reserve(S * (MAX_DET * (4 * 8 + 4 + 8) + 4) + 256)) != DD_OK) return rc;
-        if ((rc = p->h_fin.reserve(S * (MAX_DET * (4 * 8 + 4 + 8) + 4) + 256)) != DD_OK) return rc;
+        if ((rc = p->d_resized.reserve(S * p->det_in * p->det_in_w * 3)) != DD_OK) return rc;
+        if ((rc = p->d_tmp.reserve(S * frame_h * p->det_in_w * 3 + 64)) != DD_OK) return rc;
+        if (p->det_kind == DET_SSD) {
+            DD_HIP(hipMalloc(&p->d_anchors, (size_t)n_anchors * 4 * sizeof(float)));
+            DD_HIP(hipMemcpy(p->d_anchors, anchors_host, (size_t)n_anchors * 4 * sizeof(float), hipMemcpyHostToDevice));
+            if ((rc = p->d_post.reserve(ddk::ssd_post_scratch_bytes(n_anchors, n_streams))) != DD_OK) return rc;
+            if ((rc = p->d_det.reserve(S * MAX_DET * 6 * sizeof(float) + S * sizeof(int) + 256)) != DD_OK) return rc;
+            if ((rc = p->d_fin.reserve(S * (MAX_DET * (4 * 8 + 4 + 8) + 4) + 256)) != DD_OK) return rc;
+            if ((rc = p->h_fin.reserve(S * (MAX_DET * (4 * 8 + 4 + 8) + 4) + 256)) != DD_OK) return rc;
+        } else {
+            if ((rc = p->d_post.reserve(S * n_anchors * 8 + 256)) != DD_OK) return rc;              // per-row confidence + class
+            const size_t fin = S * ((size_t)YOLO_CAP * (4 * 4 + 4 + 4) + 4) + 256;                 // boxes f32x4, score, class, count
+            if ((rc = p->d_fin.reserve(fin)) != DD_OK) return rc;
+            if ((rc = p->h_fin.reserve(fin)) != DD_OK) return rc;
+        }
     }
     p->st.resize(n_streams);
     p->trks.resize(n_streams);
@@ -294,10 +310,22 @@ int enqueue_detector(dd_pipeline *p, const uint8_t *frames) {
     DD_HIP(hipEventRecord(p->main_mark, p->ctx->stream));
     DD_HIP(hipStreamWaitEvent(s, p->main_mark, 0));
     if ((rc = ddk::resize_lanczos(s, p->ctx->device, frames, p->H, p->W, 3, 1, p->d_resized.as<uint8_t>(), p->det_in,
-                                  p->det_in, p->d_tmp.as<uint8_t>(), S)) != DD_OK) return rc;      // ssd_mobilenet.py:54-57
-    if ((rc = dd_net_forward(p->det, p->d_resized.as<uint8_t>(), S, s)) != DD_OK) return rc;       // :102-103
+                                  p->det_in_w, p->d_tmp.as<uint8_t>(), S)) != DD_OK) return rc;    // ssd_mobilenet.py:54-57, yolov5.py:99
+    if ((rc = dd_net_forward(p->det, p->d_resized.as<uint8_t>(), S, s)) != DD_OK) return rc;       // :102-103 / yolov5.py:107-109
     void *raw = nullptr;
     if ((rc = dd_net_output(p->det, -1, &raw, nullptr, nullptr, nullptr, nullptr, nullptr)) != DD_OK) return rc;
+    if (p->det_kind == DET_YOLOV5) {                                                               // yolov5.py:120-131
+        float *yb = p->d_fin.as<float>(), *ys = yb + (size_t)S * YOLO_CAP * 4;
+        int *yc = reinterpret_cast<int *>(ys + (size_t)S * YOLO_CAP), *yn = yc + (size_t)S * YOLO_CAP;
+        if ((rc = ddk::yolov5_decode(s, static_cast<const float *>(raw), p->n_anchors, p->n_classes, (float)p->det_conf, (float)p->W,
+                                     (float)p->H, yb, ys, yc, YOLO_CAP, yn, S, p->d_post.p)) != DD_OK) return rc;
+        // the counts first, then the rows: a frame rarely fills its 4096-row share
+        const size_t ybytes = (size_t)S * ((size_t)YOLO_CAP * 24 + 4);
+        DD_HIP(hipMemcpyAsync(p->h_fin.p, p->d_fin.p, ybytes, hipMemcpyDeviceToHost, s));
+        DD_HIP(hipEventRecord(p->det_done, s));
+        p->det_pending = frames;
+        return DD_OK;
+    }
     float *db = p->d_det.as<float>(), *dc = db + (size_t)S * MAX_DET * 4, *ds = dc + (size_t)S * MAX_DET;
     int *dn = reinterpret_cast<int *>(ds + (size_t)S * MAX_DET);
     if ((rc = ddk::ssd_postprocess(s, static_cast<const float *>(raw), p->d_anchors, p->n_anchors, p->n_classes, MAX_DET,
@@ -357,9 +385,25 @@ int dd_pipeline_step2(dd_pipeline *p, const uint8_t *frames_in, const uint8_t *f
         if (p->det_pending != frames && (rc = enqueue_detector(p, frames)) != DD_OK) return rc;       // not queued ahead: run it now
         DD_HIP(hipEventSynchronize(p->det_done));                                                      // round trip 1
         p->det_pending = nullptr;
+        if (p->det_kind == DET_YOLOV5) {
+            const float *yb = p->h_fin.as<float>(), *ys = yb + (size_t)S * YOLO_CAP * 4;
+            const int *yc = reinterpret_cast<const int *>(ys + (size_t)S * YOLO_CAP), *yn = yc + (size_t)S * YOLO_CAP;
+            for (int z = 0; z < S; ++z) {
+                DD_REQUIRE(yn[z] <= YOLO_CAP, DD_E_CAPACITY, "dd_pipeline_step: stream %d: %d YOLOv5 candidates exceed %d", z, yn[z], YOLO_CAP);
+                for (int i = 0; i < yn[z]; ++i) {                                                      // yolov5.py:137-145
+                    const int c = yc[(size_t)z * YOLO_CAP + i];
+                    const float sc = ys[(size_t)z * YOLO_CAP + i];
+                    if (wanted_index(p, class_name(p, c)) < 0 || !(sc >= (float)p->det_conf)) continue;
+                    const float *b = yb + ((size_t)z * YOLO_CAP + i) * 4;
+                    boxes0[z].insert(boxes0[z].end(), {(double)b[0], (double)b[1], (double)(b[2] - b[0]), (double)(b[3] - b[1])});   // f32 arithmetic, :140-142
+                    scores0[z].push_back((double)sc);
+                    cls0[z].push_back(c);
+                }
+            }
+        }
         const double *hb = p->h_fin.as<double>(), *hs = hb + (size_t)S * MAX_DET * 4;
         const int *hc = reinterpret_cast<const int *>(hs + (size_t)S * MAX_DET), *hn = hc + (size_t)S * MAX_DET;
-        for (int z = 0; z < S; ++z)
+        for (int z = 0; z < S && p->det_kind == DET_SSD; ++z)
             for (int i = 0; i < hn[z]; ++i) {                                                          // :204-212
                 const std::string name = class_name(p, hc[z * MAX_DET + i]);
                 const double sc = hs[z * MAX_DET + i];

@@ -175,6 +175,11 @@ __global__ __launch_bounds__(1024) void yolo_compact_k(const float *__restrict__
                                                        int cap, int *__restrict__ out_n) {
     __shared__ int wave_cnt[16];
     __shared__ int base;
+    {   // blockIdx.x = image of a batch: rows, per-row confidences and outputs of that image
+        const size_t z = blockIdx.x;
+        raw += z * n_rows * (5 + n_cls); conf += z * n_rows; cls += z * n_rows;
+        out_boxes += z * cap * 4; out_scores += z * cap; out_cls += z * cap; out_n += z;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) base = 0;
     __syncthreads();
@@ -253,6 +258,23 @@ int ssd_postprocess(hipStream_t s, const float *raw, const float *anchors, int n
     return DD_OK;
 }
 
+// tools/yolov5.py:120-131 for `batch` images: raw f32 [batch][n_rows][5 + n_cls] -> per image the rows with
+// conf >= thr in ascending row order (out_boxes f32 [batch][cap][4] xyxy pixels, out_scores, out_cls, out_n [batch] --
+// out_n counts every passing row, also those beyond cap).  scratch: batch * n_rows * 8 bytes.
+int yolov5_decode(hipStream_t s, const float *raw, int n_rows, int n_cls, float thr, float img_w, float img_h, float *out_boxes,
+                  float *out_scores, int *out_cls, int cap, int *out_n, int batch, void *scratch) {
+    float *conf = static_cast<float *>(scratch);
+    int *cls = reinterpret_cast<int *>(conf + (size_t)batch * n_rows);
+    const long long total = (long long)batch * n_rows;
+    DD_REQUIRE(total < (1LL << 31), DD_E_CAPACITY, "yolov5_decode: %lld rows exceed 32-bit indexing", total);
+    hipLaunchKernelGGL(yolo_conf_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, raw, (int)total, n_cls, conf, cls);
+    DD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(yolo_compact_k, dim3(batch), dim3(1024), 0, s, raw, conf, cls, n_rows, n_cls, thr, img_w, img_h, out_boxes,
+                       out_scores, out_cls, cap, out_n);
+    DD_LAUNCH_CHECK();
+    return DD_OK;
+}
+
 int ssd_finish(hipStream_t s, const float *boxes, const float *cls, const float *scores, int batch, int max_det, double conf,
                double iou_thr, double img_w, double img_h, double *out_boxes, int *out_cls, double *out_scores, int *out_n) {
     DD_REQUIRE(batch > 0 && max_det > 0 && max_det <= FIN_MAX, DD_E_ARG, "ssd_finish: batch %d, max_det %d (<= %d)", batch, max_det, FIN_MAX);
@@ -297,14 +319,8 @@ int dd_yolov5_decode(dd_ctx *ctx, const float *raw, int n_rows, int n_cls, float
     if (n_rows == 0) { DD_HIP(hipMemsetAsync(out_n, 0, sizeof(int), s)); return DD_OK; }
     int rc;
     if ((rc = ctx->scratch[2].reserve((size_t)n_rows * 8 + 256)) != DD_OK) return rc;
-    float *conf = ctx->scratch[2].as<float>();
-    int *cls = reinterpret_cast<int *>(conf + n_rows);
-    hipLaunchKernelGGL(yolo_conf_k, dim3(dd_ceil_div(n_rows, 256)), dim3(256), 0, s, raw, n_rows, n_cls, conf, cls);
-    DD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(yolo_compact_k, dim3(1), dim3(1024), 0, s, raw, conf, cls, n_rows, n_cls, thr, img_w, img_h,
-                       out_boxes, out_scores, out_cls, cap, out_n);
-    DD_LAUNCH_CHECK();
-    return DD_OK;
+    return ddk::yolov5_decode(s, raw, n_rows, n_cls, thr, img_w, img_h, out_boxes, out_scores, out_cls, cap, out_n, 1,
+                              ctx->scratch[2].p);
 }
 
 int dd_counts_accumulate(dd_ctx *ctx, int64_t *acc, const int64_t *counts_host, int n, void *stream) {

@@ -8,7 +8,7 @@ from ._lib import lib, check, P
 from .runtime import default_context, ptr
 from . import nets
 from .engine import Net
-from .pipeline import DEFAULT_LABELS
+from .pipeline import DEFAULT_LABELS, DEFAULT_YOLO_LABELS
 from .tools.weights_io import load_named_weights
 
 
@@ -44,13 +44,20 @@ class MultiStreamPipeline:
         self.S = int(n_streams)
         self.W, self.H = input_size
         self.wanted = list(wanted_labels)
-        with open(labels or DEFAULT_LABELS) as f:
+        # the reference picks the detector plugin by a substring of --model (deepdish.py:482-502)
+        self.kind = 'yolov5' if 'yolov5' in model else 'ssd_mobilenet' if 'mobilenet' in model else None
+        if self.kind is None:
+            raise ValueError('the multi-stream pipeline batches the SSD-MobileNet and YOLOv5 detectors (got %s)' % model)
+        with open(labels or (DEFAULT_YOLO_LABELS if self.kind == 'yolov5' else DEFAULT_LABELS)) as f:
             self.label_lines = [l.strip() for l in f.readlines()]
         self.det = None
         anchors, n_anchors, n_classes = None, 0, 0
-        if run_detector:
-            if 'mobilenet' not in model:
-                raise ValueError('the multi-stream pipeline batches the SSD-MobileNet detector only (got %s)' % model)
+        if run_detector and self.kind == 'yolov5':
+            wd = load_named_weights(model, nets.synthetic_yolov5s_weights)
+            prog = nets.compile_yolov5s(wd)
+            self.det = Net(prog, max_batch=self.S, context=self.ctx)
+            n_anchors, n_classes = prog.meta['rows'], prog.meta['n_classes']
+        elif run_detector:
             wd = load_named_weights(model, nets.synthetic_ssd_weights)
             prog = nets.compile_ssd_mobilenet(wd)
             self.det = Net(prog, max_batch=self.S, context=self.ctx)
@@ -70,7 +77,8 @@ class MultiStreamPipeline:
                                        int(max_age), int(n_init), ptr(self.line), int(track_capacity),
                                        int(gallery_capacity), ctypes.byref(h)), 'dd_pipeline_create')
         self._h = h
-        self._class_id = {name: i - 1 for i, name in enumerate(self.label_lines) if i > 0}
+        off = 0 if self.kind == 'yolov5' else 1                     # yolov5.py:134 labels[idx]; ssd_mobilenet.py:142-147 labels[idx + 1]
+        self._class_id = {name: i - off for i, name in enumerate(self.label_lines) if i >= off}
         if background_subtraction_ratio is not None:
             self.background_subtraction(background_subtraction_ratio, background_masking)
 

@@ -15,6 +15,7 @@ No weight blobs ship with the reference (.MISSING_LARGE_BLOBS); `synthetic_*` be
 random weights of the right shapes so the HIP path and the oracle can be compared on equal terms.
 """
 import math
+import os
 import numpy as np
 
 OP_INPUT, OP_CONV, OP_DWCONV, OP_MAXPOOL, OP_UPSAMPLE, OP_FC, OP_L2NORM, OP_STEM, OP_DWPW = 1, 2, 3, 4, 5, 6, 7, 8, 9
@@ -193,6 +194,15 @@ class Program:
         return dst
 
     DWPW_SHAPES = {(32, 64, 1), (64, 128, 2), (128, 128, 1), (128, 256, 2)}     # (channels, pointwise cout, depthwise stride)
+    DWPW_BIG = os.environ.get('DD_DWPW_BIG') is not None   # blocks with 256..1024 channels: K-looped fused kernel (dwpw_big_k), opt-in
+
+    @classmethod
+    def _fusable(cls, c, cout, stride):
+        if (c, cout, stride) in cls.DWPW_SHAPES:
+            return 'dwpw_k'
+        if cls.DWPW_BIG and cls.DWPW_SHAPES and 256 <= c <= 1024 and c % 64 == 0 and cout % 256 == 0 and stride in (1, 2):
+            return 'dwpw_big_k'
+        return None
 
     def dwpw(self, src, dw_hwc, dw_bias, stride, dw_act, pw_hwio, pw_bias, pw_act):
         """Depthwise 3x3 (TF SAME) + pointwise 1x1 as one launch (csrc/nets.hip dwpw_k) for the block shapes
@@ -200,7 +210,8 @@ class Program:
         s = self.T(src)
         c = s['c']
         cout = pw_hwio.shape[3]
-        if (c, cout, stride) not in self.DWPW_SHAPES or c % 8 or cout % 8:
+        kernel = self._fusable(c, cout, stride)
+        if kernel is None or c % 8 or cout % 8:
             x = self.dwconv(src, dw_hwc, dw_bias, stride, dw_act)
             return self.conv(x, pw_hwio, pw_bias, act=pw_act)
         assert dw_hwc.shape == (3, 3, c) and pw_hwio.shape[:3] == (1, 1, c)
@@ -212,7 +223,7 @@ class Program:
         self._op(OP_DWPW, src=src, dst=dst, kh=1, kw=1, stride=stride, pad_t=pt, pad_l=pl, cin=c, cout=cout, cout_pad=cout,
                  kpad=c, act=pw_act, epi=EPI_F16, w_off=self.add_blob(wflat), b_off=self.add_blob(pw_bias.astype(np.float32)),
                  p=[self.add_blob(dwp), self.add_blob(dw_bias.astype(np.float32)), dw_act], ho=ho, wo=wo)
-        self.info[-1] = dict(kernel='dwpw_k', flops=2 * ho * wo * c * (9 + cout), bytes=2 * (s['h'] * s['w'] * c + ho * wo * cout),
+        self.info[-1] = dict(kernel=kernel, flops=2 * ho * wo * c * (9 + cout), bytes=2 * (s['h'] * s['w'] * c + ho * wo * cout),
                              wbytes=2 * c * (9 + cout) + 4 * (c + cout))
         return dst
 

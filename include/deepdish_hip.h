@@ -237,6 +237,7 @@ int dd_net_forward(dd_net *net, const uint8_t *input, int n, void *stream);
 int dd_net_output(dd_net *net, int tensor, void **dev_ptr_host, int *h_host, int *w_host, int *c_host,
                   int *cs_host, int *dtype_host);
 
+int dd_net_input_size(dd_net *net, int *h_host, int *w_host);   /* the model's input height / width (ssd_mobilenet.py:43, yolov5.py:79) */
 int dd_net_max_batch(dd_net *net, int *out_host);
 int dd_net_last_batch(dd_net *net, int *out_host);   /* images in the most recent forward */
 /* Copy the first n images of a (whole, un-sliced) tensor to caller memory: n*h*w*cs elements. */
@@ -276,8 +277,14 @@ int dd_yolov5_decode(dd_ctx *ctx, const float *raw, int n_rows, int n_cls, float
  * The per-frame call sequence of the reference's Pipeline (deepdish.py:880-885 run_object_detector,
  * :940-960 box hygiene, :995 NMS, :1008 encoder, :1028-1029 tracker, :1035-1114 count line) for
  * n_streams independent streams, one frame each per step, device work batched across streams.
- * detector may be NULL (detections are then always injected).  labels_nl: the label file's lines
- * joined by '\n' (line i+1 names class id i, tools/ssd_mobilenet.py:142-147); wanted_nl: --wanted-labels.
+ * detector may be NULL (detections are then always injected).  Which detector adaptor runs is chosen like the
+ * reference chooses its plugin (deepdish.py:482-502): anchors_host != NULL = SSD-MobileNet (tools/ssd_mobilenet.py:
+ * resize to the net's input, forward, TFLite_Detection_PostProcess, predict tail; labels_nl line i+1 names class
+ * id i, :142-147; score threshold 0.5); anchors_host == NULL = YOLOv5 (tools/yolov5.py:97-146: resize, forward with
+ * the Detect decode fused, dd_yolov5_decode, label filter, xyxy -> tlwh; n_anchors = rows of the head tensor,
+ * n_classes = classes; labels_nl line i names class id i, :134; score threshold 0.25; no NMS of its own -- every
+ * candidate goes on to deep_sort's NMS; more than 4096 candidates in one frame are DD_E_CAPACITY).
+ * labels_nl: the label file's lines joined by '\n'; wanted_nl: --wanted-labels.
  * line_host: count line x1,y1,x2,y2 (deepdish.py:739-744). */
 int dd_pipeline_create(dd_ctx *ctx, int n_streams, int frame_h, int frame_w, dd_net *detector,
                        const float *anchors_host, int n_anchors, int n_classes, dd_net *encoder,

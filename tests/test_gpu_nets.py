@@ -11,6 +11,17 @@ def _rel(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
 
 
+def _assert_close(name, got, want, atol, rtol):
+    """Per element |got - want| <= atol + rtol * |want|; prints how much of the bound the worst element uses."""
+    err = np.abs(got.astype(np.float64) - want.astype(np.float64))
+    bound = atol + rtol * np.abs(want.astype(np.float64))
+    worst = int(np.argmax(err / bound))
+    used = float((err / bound).reshape(-1)[worst])
+    print('%s: worst element uses %.0f %% of atol %.1e + rtol %.1e x |want| (|err| %.3e at |want| %.3e; max |err| %.3e)'
+          % (name, 100 * used, atol, rtol, float(err.reshape(-1)[worst]), float(np.abs(want).reshape(-1)[worst]), float(err.max())))
+    assert used <= 1.0, (name, used)
+
+
 @pytest.fixture(scope='module')
 def mars():
     from deepdish_amd import nets
@@ -76,9 +87,12 @@ def test_ssd_forward_vs_oracle():
     got = net.read()[:, :, 0, :]
     want = nets_torch.ssd_forward(wd, x, w16=True)
     assert got.shape == want.shape == (2, 1917, 95)
-    assert _rel(got, want) < 2e-2, _rel(got, want)
-    want32 = nets_torch.ssd_forward(wd, x, w16=False)
-    assert _rel(got, want32) < 4e-2, _rel(got, want32)
+    # stated tolerance, PER ELEMENT of the raw head (box encodings and class logits): f16 activations / f32 accumulation
+    # against the f32 restatement with the same f16-rounded weights; measured worst case (scripts/probe_head_errors.py):
+    # atol 4.4e-3 would do at this rtol
+    _assert_close('ssd head vs f32 restatement, f16-rounded weights', got, want, atol=8e-3, rtol=1e-2)
+    want32 = nets_torch.ssd_forward(wd, x, w16=False)                       # + the weight rounding itself (measured 6.2e-3)
+    _assert_close('ssd head vs f32 restatement, f32 weights', got, want32, atol=1.2e-2, rtol=1e-2)
 
 
 def test_yolov5s_forward_vs_oracle():
@@ -93,4 +107,6 @@ def test_yolov5s_forward_vs_oracle():
     got = net.read()[:, :, 0, :]
     want = nets_torch.yolov5s_forward(wd, x, w16=True)
     assert got.shape == want.shape == (1, 25200, 85)
-    assert np.abs(got - want).max() < 3e-2, np.abs(got - want).max()
+    # per element of the decoded rows (xywh normalised, objectness, class scores in (0, 1)); measured: rtol 1e-2 alone
+    # covers every element but a handful near zero (atol 2.1e-6)
+    _assert_close('yolov5s rows vs f32 restatement, f16-rounded weights', got, want, atol=2e-4, rtol=1e-2)

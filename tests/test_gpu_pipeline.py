@@ -193,6 +193,84 @@ def test_multistream_detector_output_matches_plugin():
     assert seen > 0
 
 
+def test_multistream_yolov5_pipeline_matches_plugin():
+    """BASELINE config 3 in the batched C++ pipeline (--model *yolov5*, deepdish.py:482-502): Lanczos to 640x640,
+    YOLOv5s forward with the fused Detect decode, batched dd_yolov5_decode, label filter + tlwh (tools/yolov5.py:
+    120-146), then box hygiene, deep_sort NMS over the (many) candidates, crops, MARS, tracker.  Two streams batched in
+    C++ must equal two single-stream Python pipelines built from the reference-shaped YOLOV5 plugin, frame by frame."""
+    from deepdish_amd.multipipe import MultiStreamPipeline
+    from deepdish_amd.pipeline import HotPath, DEFAULT_YOLO_LABELS
+    from deepdish_amd.synth import Scene
+    wanted = sorted({l.strip() for l in open(DEFAULT_YOLO_LABELS)})
+    scenes = [Scene(seed=3, n_obj=8, n_frames=4), Scene(seed=5, n_obj=5, n_frames=4)]
+    mp = MultiStreamPipeline(2, model='synthetic-yolov5s-fp16.tflite', wanted_labels=wanted)
+    hps = [HotPath(model='synthetic-yolov5s-fp16.tflite', wanted_labels=wanted) for _ in scenes]
+    seen = 0
+    for f in range(4):
+        frames = torch.from_numpy(np.stack([sc.frame(f) for sc in scenes])).cuda()
+        mp.step(frames)
+        for z, hp in enumerate(hps):
+            hp.step(frames[z])
+            ints, means = mp.tracker(z).table()
+            want = np.array([[t.track_id, t.state, t.time_since_update, t.hits, t.age] for t in hp.tracker.tracks],
+                            dtype=np.int64).reshape(-1, 5)
+            np.testing.assert_array_equal(ints[:, :5], want, err_msg=f'frame {f} stream {z}')
+            if len(want):
+                np.testing.assert_allclose(means, np.array([t.mean for t in hp.tracker.tracks]), rtol=1e-9, atol=1e-9)
+            seen = max(seen, len(want))
+    assert seen > 3, seen
+
+
+def test_detector_and_encoder_run_concurrently_on_two_contexts():
+    """SURVEY 8(b) threading: the reference keeps ONE detector call and ONE encoder call in flight on different pool
+    threads (deepdish.py:935,985,1008).  Two host threads, each with its own dd_ctx (own stream, own scratch), hammer
+    the SSD forward + post-process and the MARS forward at the same time: every result equals the single-threaded one."""
+    import threading
+    from deepdish_amd import nets
+    from deepdish_amd.engine import Net
+    from deepdish_amd.runtime import Context
+    from deepdish_amd.pipeline import make_detector, DEFAULT_LABELS
+    from deepdish_amd.tools import generate_detections as gdet
+    from deepdish_amd.synth import Scene
+    names = [l.strip() for l in open(DEFAULT_LABELS)][1:]
+    ctx_d, ctx_e = Context(0), Context(0)
+    det = make_detector('synthetic-ssd_mobilenet_v1.tflite', wanted_labels=names, context=ctx_d)
+    enc = gdet.create_box_encoder('synthetic-mars-64x32x3', batch_size=32, context=ctx_e)
+    sc = Scene(seed=12, n_obj=10, n_frames=8)
+    frames = [sc.frame(f) for f in range(8)]
+    boxes = [sc.detections(f)[0] for f in range(8)]
+    want_d = [det.detect_frame_device(torch.from_numpy(fr).cuda(), 480, 640) for fr in frames]
+    want_e = [enc(fr, [b for b in bx]) for fr, bx in zip(frames, boxes)]
+    got_d, got_e, errs = [], [], []
+
+    def run_d():
+        try:
+            for _ in range(6):
+                got_d.append([det.detect_frame_device(torch.from_numpy(fr).cuda(), 480, 640) for fr in frames])
+        except Exception as e:                       # surfaces in the main thread below
+            errs.append(e)
+
+    def run_e():
+        try:
+            for _ in range(6):
+                got_e.append([enc(fr, [b for b in bx]) for fr, bx in zip(frames, boxes)])
+        except Exception as e:
+            errs.append(e)
+
+    th = [threading.Thread(target=run_d), threading.Thread(target=run_e)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for rep in got_d:
+        for (b, l, s), (wb, wl, ws) in zip(rep, want_d):
+            assert l == wl and np.array_equal(np.asarray(b), np.asarray(wb)) and np.array_equal(np.asarray(s), np.asarray(ws))
+    for rep in got_e:
+        for g, w in zip(rep, want_e):
+            np.testing.assert_array_equal(g, w)
+
+
 def test_tflite_plugin_vs_oracle():
     """a13: generic TFLite-Task adaptor = cv2 bilinear stretch + SSD forward + post-process + int() boxes."""
     from deepdish_amd.pipeline import make_detector, DEFAULT_LABELS
