@@ -7,7 +7,7 @@ import os
 from ctypes import c_int, c_int64, c_double, c_float, c_void_p, c_char_p, POINTER
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libdeepdish_hip.so')
+LIB_PATH = os.environ.get('DD_LIB') or os.path.join(HERE, 'libdeepdish_hip.so')      # DD_LIB: another build of the same ABI (same-box A/B runs)
 
 P = c_void_p
 
@@ -70,6 +70,7 @@ SIGNATURES = {
     'dd_net_forward': [P, P, c_int, P],
     'dd_net_output': [P, c_int, POINTER(P), POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int),
                       POINTER(c_int)],
+    'dd_net_use_graph': [P, c_int],
     'dd_net_input_size': [P, POINTER(c_int), POINTER(c_int)],
     'dd_net_max_batch': [P, POINTER(c_int)],
     'dd_net_last_batch': [P, POINTER(c_int)],

@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <map>
 #include <string>
 #include "common.h"
 
@@ -770,6 +771,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rw_k(const ConvP P, const int 
             for (int a = 0; a < NCO; ++a)
 #pragma unroll
                 for (int b = 0; b < MB; ++b) acc[a][b] = (a & 1) ? E[a >> 1].b1 : E[a >> 1].b0;
+            // residual rows of this group's pixels: requested before the MFMAs, so the round trip runs under them (a load
+            // inside the epilogue cannot move above the previous pixel's stores -- they may alias -- and each pixel would
+            // wait for memory on its own: PMC had the two-output variant parked on s_waitcnt 65 % of its cycles)
+            h8 rp[MB][NCO / 2];
+            const bool has_res = !POOL && (EF < 0 ? P.res != nullptr : EF == 1);
+            if (has_res) {
+#pragma unroll
+                for (int b = 0; b < MB; ++b)
+#pragma unroll
+                    for (int g = 0; g < NCO / 2; ++g)
+                        rp[b][g] = *reinterpret_cast<const h8 *>(P.res + (size_t)(ok[b] ? mrow[b] : 0) * P.cs_res + P.coff_res + g * 32 + fq * 8);
+            }
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
@@ -802,7 +815,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rw_k(const ConvP P, const int 
                         }
                         *reinterpret_cast<h8 *>(stage + ((f0 + b) * 16 + fr) * (NCO * 16) + g * 32 + fq * 8) = hv;
                     } else {
-                        conv_epilogue_f16x8<ACT, false, EF>(P, E[g], mrow[b], g * 32 + fq * 8, o);
+                        conv_epilogue_f16x8<ACT, false, EF>(P, E[g], mrow[b], g * 32 + fq * 8, o, has_res ? &rp[b][g] : nullptr);
                     }
                 }
             }
@@ -882,7 +895,9 @@ __global__ __launch_bounds__(256) void stem_conv3_k(const ConvP P) {
                 const int py = (int)__umulhi((unsigned)idx, rcp), dq = idx - py * DW;
                 const int y = y0 * STRIDE - P.pad_t + py, x3 = a0 + dq * 4;
                 in[j] = idx < total && y >= 0 && y < P.H && x3 >= 0 && x3 < w3;
-                raw[j] = in[j] ? *reinterpret_cast<const unsigned *>(img + (size_t)y * w3 + x3) : 0u;
+                // a select between two ADDRESSES: "in ? load : 0" makes hipcc branch around every load and wait for each
+                // one separately (18 s_waitcnt vmcnt(0) for the 8 loads of an iteration)
+                raw[j] = *reinterpret_cast<const unsigned *>(in[j] ? img + (size_t)y * w3 + x3 : reinterpret_cast<const uint8_t *>(P.zero));
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -906,7 +921,9 @@ __global__ __launch_bounds__(256) void stem_conv3_k(const ConvP P) {
                 const int idx = i0 + j * 256;
                 const int py = (int)__umulhi((unsigned)idx, rcp), r = idx - py * PW3;
                 const int y = y0 * STRIDE - P.pad_t + py, x3 = xs3 + r;
-                raw[j] = (idx < total && y >= 0 && y < P.H && x3 >= 0 && x3 < w3) ? (int)img[(size_t)y * w3 + x3] : -1;
+                const bool ok = idx < total && y >= 0 && y < P.H && x3 >= 0 && x3 < w3;
+                const int v = (int)*(ok ? img + (size_t)y * w3 + x3 : reinterpret_cast<const uint8_t *>(P.zero));
+                raw[j] = ok ? v : -1;
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -1035,22 +1052,49 @@ __global__ __launch_bounds__(256) void dwpw_k(const ConvP P) {
         }
         const int ix0 = ox0 * STRIDE - P.pad_l;
         const _Float16 *img = P.in + (size_t)n * P.H * P.W * P.cs_in + P.coff_in + g * 8;
+        // Out-of-image taps read a zero line instead of branching around the load.  HOIST: all 3 x NCOL window loads and
+        // the nine filter taps are issued before the first multiply (as in dwconv3_k) -- pays only for the 32-channel
+        // block (232 -> 223 us at 192 frames); the others lose more to the registers it costs (block 2: 176 -> 231 us,
+        // block 3: 197 -> 229 us), so they keep hipcc's row-by-row order (three batches of loads per item).
+        constexpr bool HOIST = CIN == 32;
+        if constexpr (HOIST) {
+            h8 x[3][NCOL], w[9];
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            // out-of-image taps read a zero line instead of branching around the load: all 3 x NCOL loads
-            // of the window are then independent and in flight together
-            const int iy = oy * STRIDE - P.pad_t + kh;
-            const bool rok = qok && (unsigned)iy < (unsigned)P.H;
-            const int roff = ((rok ? iy : 0) * P.W + ix0) * P.cs_in;   // 32-bit offset inside the image
-            h8 x[NCOL];
+            for (int kh = 0; kh < 3; ++kh) {
+                const int iy = oy * STRIDE - P.pad_t + kh;
+                const bool rok = qok && (unsigned)iy < (unsigned)P.H;
+                const int roff = ((rok ? iy : 0) * P.W + ix0) * P.cs_in;   // 32-bit offset inside the image
 #pragma unroll
-            for (int cx = 0; cx < NCOL; ++cx)
-                x[cx] = *reinterpret_cast<const h8 *>((rok && (unsigned)(ix0 + cx) < (unsigned)P.W) ? img + (roff + cx * P.cs_in) : P.zero);
+                for (int cx = 0; cx < NCOL; ++cx)
+                    x[kh][cx] = *reinterpret_cast<const h8 *>((rok && (unsigned)(ix0 + cx) < (unsigned)P.W) ? img + (roff + cx * P.cs_in) : P.zero);
+            }
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const h8 w = *reinterpret_cast<const h8 *>(P.dw_w + (size_t)(kh * 3 + kw) * CIN + g * 8);
+            for (int t = 0; t < 9; ++t) w[t] = *reinterpret_cast<const h8 *>(P.dw_w + (size_t)t * CIN + g * 8);
+#if defined(__HIP_DEVICE_COMPILE__)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
-                for (int j = 0; j < TX; ++j) dw_tap(acc[j], x[j * STRIDE + kw], w);
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                    for (int j = 0; j < TX; ++j) dw_tap(acc[j], x[kh][j * STRIDE + kw], w[kh * 3 + kw]);
+        } else {
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int iy = oy * STRIDE - P.pad_t + kh;
+                const bool rok = qok && (unsigned)iy < (unsigned)P.H;
+                const int roff = ((rok ? iy : 0) * P.W + ix0) * P.cs_in;   // 32-bit offset inside the image
+                h8 x[NCOL];
+#pragma unroll
+                for (int cx = 0; cx < NCOL; ++cx)
+                    x[cx] = *reinterpret_cast<const h8 *>((rok && (unsigned)(ix0 + cx) < (unsigned)P.W) ? img + (roff + cx * P.cs_in) : P.zero);
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const h8 w = *reinterpret_cast<const h8 *>(P.dw_w + (size_t)(kh * 3 + kw) * CIN + g * 8);
+#pragma unroll
+                    for (int j = 0; j < TX; ++j) dw_tap(acc[j], x[j * STRIDE + kw], w);
+                }
             }
         }
         const int dact = DACT < 0 ? P.dw_act : DACT;
@@ -1455,22 +1499,31 @@ __global__ __launch_bounds__(256) void dwconv3_k(const DwP P) {
     }
     const int ix0 = ox0 * STRIDE - P.pad_l;
     const _Float16 *img = P.in + (size_t)n * P.H * P.W * P.cs_in + P.coff_in + g * 8;
+    // Every load of the item is issued before the first multiply: left to itself hipcc sinks each load next to its use
+    // to save registers (66 VGPRs) and the item becomes a chain of ~25 dependent memory round trips (PMC: waves parked
+    // on s_waitcnt 78-85 % of their cycles, 3.4-4 TB/s); with all 18 / 27 window loads and the nine filter taps in
+    // flight at once a wave waits for memory once.
+    h8 x[3][NCOL], w[9];
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
         const int iy = oy * STRIDE - P.pad_t + kh;
         const bool rok = (unsigned)iy < (unsigned)P.H;        // out-of-image taps read the zero line: no branches, all loads in flight
         const int roff = ((rok ? iy : 0) * P.W + ix0) * P.cs_in;     // 32-bit offset inside the image (64-bit index math per load doubled the address code)
-        h8 x[NCOL];
 #pragma unroll
         for (int cx = 0; cx < NCOL; ++cx)
-            x[cx] = *reinterpret_cast<const h8 *>((rok && (unsigned)(ix0 + cx) < (unsigned)P.W) ? img + (roff + cx * P.cs_in) : P.zero);
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-            const h8 w = *reinterpret_cast<const h8 *>(P.w + (size_t)(kh * 3 + kw) * P.c + g * 8);
-#pragma unroll
-            for (int j = 0; j < TX; ++j) dw_tap(acc[j], x[j * STRIDE + kw], w);
-        }
+            x[kh][cx] = *reinterpret_cast<const h8 *>((rok && (unsigned)(ix0 + cx) < (unsigned)P.W) ? img + (roff + cx * P.cs_in) : P.zero);
     }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) w[t] = *reinterpret_cast<const h8 *>(P.w + (size_t)t * P.c + g * 8);
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int j = 0; j < TX; ++j) dw_tap(acc[j], x[kh][j * STRIDE + kw], w[kh * 3 + kw]);
 #pragma unroll
     for (int j = 0; j < TX; ++j) {
         if (ox0 + j >= P.wo) break;
@@ -1616,7 +1669,21 @@ struct dd_net {
     bool use_rw = true;                      // DD_NO_RW=1: 3x3x32x32 layers fall back to the implicit-GEMM kernels (A/B measurements)
     int tile_mode = 0;                       // DD_TILE_MODE=1 forces the 64 x 64 tile everywhere (A/B measurements)
     std::vector<hipEvent_t> events;           // n_ops + 1 when profiling
+    // Latency mode (dd_net_use_graph): the launch train of one forward -- 20 to 75 short kernels at batch 1 -- captured
+    // once per (input pointer, batch) and replayed as one hipGraph launch; the first call of a key runs eagerly (it may
+    // still allocate split-K slabs and set function attributes), the second captures.
+    struct GraphEntry { int calls = 0; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
+    bool use_graph = false;
+    std::map<std::pair<const void *, int>, GraphEntry> graphs;
 };
+
+static void net_drop_graphs(dd_net *net) {
+    for (auto &kv : net->graphs) {
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+        if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+    }
+    net->graphs.clear();
+}
 
 namespace {
 
@@ -1894,6 +1961,7 @@ int dd_net_destroy(dd_net *n) {
     if (!n) return DD_OK;
     for (void *b : n->bufs) (void)hipFree(b);
     for (hipEvent_t e : n->events) (void)hipEventDestroy(e);
+    net_drop_graphs(n);
     n->slab.release();
     (void)hipFree(n->d_zero);
     (void)hipFree(n->d_weights);
@@ -1976,6 +2044,16 @@ int dd_net_read(dd_net *n, int tensor, int n_img, void *dst, int dst_on_device, 
     return DD_OK;
 }
 
+static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t s);
+
+int dd_net_use_graph(dd_net *net, int enable) {
+    DD_REQUIRE(net, DD_E_ARG, "dd_net_use_graph: NULL net");
+    DD_DEVICE(net->ctx);
+    net->use_graph = enable != 0;
+    if (!net->use_graph) net_drop_graphs(net);
+    return DD_OK;
+}
+
 int dd_net_forward(dd_net *net, const uint8_t *input, int nimg, void *stream) {
     DD_REQUIRE(net && input && nimg >= 0, DD_E_ARG, "dd_net_forward: bad argument");
     DD_DEVICE(net->ctx);
@@ -1983,6 +2061,24 @@ int dd_net_forward(dd_net *net, const uint8_t *input, int nimg, void *stream) {
     if (nimg == 0) return DD_OK;
     net->last_batch = nimg;
     hipStream_t s = dd_pick_stream(net->ctx, stream);
+    if (!net->use_graph || net->profile) return net_run_ops(net, input, nimg, s);
+    if (net->graphs.size() > 256) net_drop_graphs(net);           // a caller that keeps moving its input buffer
+    dd_net::GraphEntry &g = net->graphs[std::make_pair(static_cast<const void *>(input), nimg)];
+    if (g.exec) { DD_HIP(hipGraphLaunch(g.exec, s)); return DD_OK; }
+    if (g.calls++ == 0) return net_run_ops(net, input, nimg, s);  // first sight of this key: eager (allocations, attributes)
+    DD_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    const int rc = net_run_ops(net, input, nimg, s);
+    hipGraph_t graph = nullptr;
+    const hipError_t e = hipStreamEndCapture(s, &graph);
+    if (rc != DD_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    DD_HIP(e);
+    g.graph = graph;
+    DD_HIP(hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0));
+    DD_HIP(hipGraphLaunch(g.exec, s));
+    return DD_OK;
+}
+
+static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t s) {
     auto base = [&](int t) -> char * {
         const TensorDesc &d = net->tensors[t];
         return static_cast<char *>(net->bufs[d.buf]);
@@ -2079,6 +2175,7 @@ int dd_net_forward(dd_net *net, const uint8_t *input, int nimg, void *stream) {
                 ConvP P;
                 memset(&P, 0, sizeof(P));
                 P.src8 = input; P.H = net->in_h; P.W = net->in_w; P.in_mean = of[32]; P.in_scale = of[33];
+                P.zero = net->d_zero;
                 P.kh = P.kw = 3; P.stride = o[7]; P.pad_t = o[8]; P.pad_l = o[9];
                 P.cout = o[11]; P.cout_pad = o[12]; P.act = o[14]; P.epi = EPI_F16; P.splitk = 1;
                 DD_REQUIRE(P.cout_pad == 32 && (P.stride == 1 || P.stride == 2), DD_E_ARG, "dd_net_forward: stem needs 32 output channels, stride 1 or 2");

@@ -33,6 +33,10 @@ class Net:
         except Exception:
             pass
 
+    def use_graph(self, enable=True):
+        """Latency mode: replay each (input buffer, batch) forward as one hipGraph launch."""
+        check(lib().dd_net_use_graph(self._h, int(bool(enable))), 'dd_net_use_graph')
+
     def forward(self, images, stream=None):
         """images: u8 [n, in_h, in_w, 3] torch cuda tensor (or numpy, uploaded).  Enqueues only."""
         if isinstance(images, np.ndarray):

@@ -39,7 +39,7 @@ class MultiStreamPipeline:
                  labels=None, wanted_labels=('person',), input_size=(640, 480), line=None, max_cosine_distance=0.2,
                  nms_max_overlap=0.6, max_iou_distance=0.7, max_age=60, n_init=3, context=None, run_detector=True,
                  encoder_max_batch=None, track_capacity=512, gallery_capacity=256, background_subtraction_ratio=None,
-                 background_masking=False):
+                 background_masking=False, graph=None):
         self.ctx = context or default_context()
         self.S = int(n_streams)
         self.W, self.H = input_size
@@ -66,6 +66,16 @@ class MultiStreamPipeline:
         wd = load_named_weights(encoder_model, nets.synthetic_mars_weights)
         self.enc_weights = wd
         self.enc = Net(nets.compile_mars(wd), max_batch=encoder_max_batch or max(64, 32 * self.S), context=self.ctx)
+        # latency mode: with a handful of streams a forward is a train of 20-75 kernels of a few microseconds each;
+        # replaying it as one hipGraph takes the per-launch host cost out of the frame latency (DD_GRAPH=0/1 overrides)
+        import os
+        if graph is None:
+            graph = self.S <= 4 if os.environ.get('DD_GRAPH') is None else os.environ['DD_GRAPH'] == '1'
+        self.graph = bool(graph)
+        if self.graph:
+            self.enc.use_graph(True)
+            if self.det is not None:
+                self.det.use_graph(True)
         if line is None:
             line = np.array([[self.W / 2, 0], [self.W / 2, self.H]], dtype=int)        # deepdish.py:739-741
         self.line = np.ascontiguousarray(np.asarray(line, dtype=np.float64).reshape(4))

@@ -237,6 +237,9 @@ int dd_net_forward(dd_net *net, const uint8_t *input, int n, void *stream);
 int dd_net_output(dd_net *net, int tensor, void **dev_ptr_host, int *h_host, int *w_host, int *c_host,
                   int *cs_host, int *dtype_host);
 
+/* Latency mode for small batches (the reference runs ONE stream: deepdish.py:1324-1340): the kernels of a forward are
+ * captured once per (input pointer, n) into a hipGraph and replayed with one launch.  Results are identical. */
+int dd_net_use_graph(dd_net *net, int enable);
 int dd_net_input_size(dd_net *net, int *h_host, int *w_host);   /* the model's input height / width (ssd_mobilenet.py:43, yolov5.py:79) */
 int dd_net_max_batch(dd_net *net, int *out_host);
 int dd_net_last_batch(dd_net *net, int *out_host);   /* images in the most recent forward */

@@ -65,6 +65,48 @@ def test_fused_mobilenet_blocks_match_the_two_kernel_path():
     assert np.abs(a - b).max() <= 2e-3 * np.abs(b).max(), np.abs(a - b).max() / np.abs(b).max()
 
 
+def test_graph_replay_matches_eager():
+    """Latency mode (dd_net_use_graph): a forward replayed as one hipGraph launch gives the bits of the eager launch
+    train -- first call of an (input buffer, batch) key eager, second captured, later ones replayed -- and a one-stream
+    pipeline ends with the same tracks and counts with graphs on and off."""
+    import torch
+    from deepdish_amd import nets
+    from deepdish_amd.engine import Net
+    from deepdish_amd.multipipe import MultiStreamPipeline
+    from deepdish_amd.synth import Scene
+    wd = nets.synthetic_mars_weights(1234)
+    net = Net(nets.compile_mars(wd), max_batch=32)
+    rng = np.random.default_rng(5)
+    xs = [torch.from_numpy(rng.integers(0, 256, (n, 64, 32, 3), dtype=np.uint8)).cuda() for n in (21, 7, 21)]
+    want = []
+    for x in xs:
+        net.forward(x); want.append(net.read()[:, 0, 0, :].copy())
+    net.use_graph(True)
+    for rep in range(4):                                   # eager, capture, replay, replay -- per key
+        for x, w in zip(xs, want):
+            net.forward(x)
+            np.testing.assert_array_equal(net.read()[:, 0, 0, :], w, err_msg=f'rep {rep}')
+    xs[0].copy_(torch.from_numpy(rng.integers(0, 256, (21, 64, 32, 3), dtype=np.uint8)).cuda())    # same buffer, new contents
+    net.forward(xs[0]); got = net.read()[:, 0, 0, :].copy()
+    net.use_graph(False)
+    net.forward(xs[0])
+    np.testing.assert_array_equal(net.read()[:, 0, 0, :], got)
+    sc = Scene(seed=3, n_obj=6, n_frames=24)
+    res = []
+    for graph in (False, True):
+        mp = MultiStreamPipeline(1, graph=graph)
+        assert mp.graph == graph
+        for f in range(24):
+            boxes, scores, _, _ = sc.detections(f)
+            inj = mp.pack_injected([([tuple(int(v) for v in b) for b in boxes], ['person'] * len(boxes), [float(x) for x in scores])])
+            mp.step(torch.from_numpy(sc.frame(f)[None]).cuda(), inj)
+        res.append((mp.tracker(0).table(), mp.counts().copy()))
+    np.testing.assert_array_equal(res[0][0][0], res[1][0][0])
+    np.testing.assert_array_equal(res[0][0][1], res[1][0][1])
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    assert res[0][1].sum() > 0
+
+
 def test_stream_order_does_not_matter():
     """Streams are independent units: permuting which slot a stream occupies permutes the results."""
     from deepdish_amd.multipipe import MultiStreamPipeline
