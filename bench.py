@@ -126,6 +126,8 @@ def make_inputs(rank, world, streams, n_frames, W, H, sink):
     jobs = [(1000 * rank + s, n_frames, W, H) for s in range(streams)]
     # the ranks of one node share its cores: each rank takes its share of half of them
     workers = max(1, min(16, (os.cpu_count() or 2) // (2 * max(1, world)), streams))
+    if os.environ.get('DD_BENCH_GEN_WORKERS'):          # 1 = generate in-process: under `rocprofv3 --pmc` the profiler has
+        workers = int(os.environ['DD_BENCH_GEN_WORKERS'])   # initialised the GPU before main(), and worker processes may not be exec'ed
     if workers > 1:
         with mp.get_context('spawn').Pool(workers) as pool:
             for s, (fr, per) in enumerate(pool.imap(_gen_stream, jobs)):

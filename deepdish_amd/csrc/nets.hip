@@ -182,7 +182,7 @@ __device__ __forceinline__ Epi8 epi8_load(const ConvP &P, int co) {
 // ACT >= 0: the activation is known at compile time (the per-element switch on P.act would otherwise be
 // compiled into a chain of branches around every value).
 // EF (epilogue flavour) 0: no residual, no second output; 1: both; -1: whatever P says.
-template <int ACT = -1, bool BIAS = true, int EF = -1>   // BIAS = false: the accumulators were initialised with the bias
+template <int ACT = -1, bool BIAS = true, int EF = -1, bool NT = true>   // BIAS = false: the accumulators were initialised with the bias
 __device__ __forceinline__ void conv_epilogue_f16x8(const ConvP &P, const Epi8 &E, int m, int co, float v[8], const h8 *res_pre = nullptr) {
     // res_pre: the residual vector of this (pixel, channel group), fetched by the caller before its first store -- a
     // load issued here cannot be moved above the stores of the caller's previous pixel (they may alias), so a loop of
@@ -210,7 +210,9 @@ __device__ __forceinline__ void conv_epilogue_f16x8(const ConvP &P, const Epi8 &
     }
     // streaming store: same-box A/B -0.7 % on both networks (the activations of a layer exceed the L2 anyway); the
     // depthwise kernel keeps plain stores -- its output is re-read at once by the following 1x1 layer (+4 % with nt)
-    __builtin_nontemporal_store(o, reinterpret_cast<h8 *>(static_cast<_Float16 *>(P.out) + (size_t)m * P.cs_out + P.coff_out + co));
+    h8 *dst = reinterpret_cast<h8 *>(static_cast<_Float16 *>(P.out) + (size_t)m * P.cs_out + P.coff_out + co);
+    if constexpr (NT) __builtin_nontemporal_store(o, dst);
+    else *dst = o;
     if (has_out2) {                                 // second view: ELU(scale * raw + shift)
         h8 o2;
 #pragma unroll
@@ -1151,7 +1153,7 @@ __global__ __launch_bounds__(256) void dwpw_k(const ConvP P) {
             float o[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) { o[r] = acc[2 * g2][b][r]; o[4 + r] = acc[2 * g2 + 1][b][r]; }
-            conv_epilogue_f16x8<ACT, false, 0>(P, E[g2], m, n0 + wn * 64 + g2 * 32 + fq * 8, o);
+            conv_epilogue_f16x8<ACT, false, 0, false>(P, E[g2], m, n0 + wn * 64 + g2 * 32 + fq * 8, o);
         }
     }
 }

@@ -60,8 +60,9 @@ def pmc_traffic(kernel, streams):
     --pmc WRITE_SIZE passes of this same bench; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
     None when no summary exists for this stream count -- bench.py cannot run the profiler on itself."""
     import json, os
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'r01_pmc_traffic_s%d.json' % streams)
-    if not os.path.exists(path):
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles')
+    path = next((p for p in (os.path.join(root, 'r%02d_pmc_traffic_s%d.json' % (r, streams)) for r in (2, 1)) if os.path.exists(p)), None)
+    if path is None:                       # the newest round's summary for this stream count, if one was collected
         return None
     key = kernel.replace(',', ', ')
     tot_b = tot_n = 0.0
