@@ -123,7 +123,8 @@ def make_inputs(rank, world, streams, n_frames, W, H, sink):
     more than the few streams in flight; returns the per-stream per-frame detections."""
     import multiprocessing as mp
     dets = [None] * streams
-    jobs = [(1000 * rank + s, n_frames, W, H) for s in range(streams)]
+    seed_rank = int(os.environ.get('DD_BENCH_SEED_RANK', rank))     # tests: a single-GPU run of the streams rank k would own
+    jobs = [(1000 * seed_rank + s, n_frames, W, H) for s in range(streams)]
     # the ranks of one node share its cores: each rank takes its share of half of them
     workers = max(1, min(16, (os.cpu_count() or 2) // (2 * max(1, world)), streams))
     if os.environ.get('DD_BENCH_GEN_WORKERS'):          # 1 = generate in-process: under `rocprofv3 --pmc` the profiler has
@@ -315,11 +316,21 @@ def main():
     W, H = cfg['W'], cfg['H']
     import torch
     dist_on = world > 1 or ('RANK' in os.environ and 'MASTER_PORT' in os.environ)    # launched by torch.distributed.run
+    # Rehearsal on a one-GPU box (tests/test_gpu_pipeline.py): DD_BENCH_ONE_DEVICE=1 puts every rank on device 0 and
+    # DD_BENCH_BACKEND=gloo carries the count reduction (RCCL refuses two ranks on one device); everything else --
+    # launcher, per-rank worker threads, barriers, max-over-ranks timing -- is the N > 1 path as the driver runs it.
+    backend = os.environ.get('DD_BENCH_BACKEND', 'nccl')
+    if os.environ.get('DD_BENCH_ONE_DEVICE'):
+        local_rank = 0
+    red_dev = f'cuda:{local_rank}' if backend == 'nccl' else 'cpu'
     torch.cuda.set_device(local_rank)
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import threading
     from deepdish_amd.multipipe import MultiStreamPipeline
@@ -393,10 +404,10 @@ def main():
     dt = time.perf_counter() - t0
     stage_ms = pipes[0].stage_ms()
     local_counts = sum(p.counts().sum(axis=0) for p in pipes)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=f'cuda:{local_rank}')
+    tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
     if dist_on:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    counts = reduce_counts(local_counts, device=f'cuda:{local_rank}')      # RCCL: the only exchange step of the path
+    counts = reduce_counts(local_counts, device=red_dev)                  # RCCL: the only exchange step of the path
     dt = float(tmax.item())
     total_frames = args.steps * args.streams * world
 

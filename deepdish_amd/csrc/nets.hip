@@ -694,8 +694,11 @@ constexpr int RW_MB = 4;                                       // pixel fragment
 template <int NCO, int TW, int ACT, bool POOL, int EF = -1>     // TW: tile width when known at compile time (tap offsets
 __global__ __launch_bounds__(256, 2) void conv3x3_rw_k(const ConvP P, const int total_tiles) {   // become ds_read immediates), else 0
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
-    constexpr int MB = (EF == 0 || POOL) ? RW_MB : 2;          // pixel fragments in flight per wave: the residual / two-output / run-time
-                                                               // epilogues need the registers (with 4 they spilled 9-19 VGPRs to scratch)
+    // Pixel fragments in flight per wave.  The pooled conv1_2 tile is 17 x 32 pixels = 34 fragments: in groups of 4 that is
+    // 9 groups for 4 waves -- three rounds of which the last is a quarter full; groups of 3 give 12 groups = three full
+    // rounds of 3 (9 instead of 12 fragment slots per wave and tile).  The residual / two-output / run-time
+    constexpr int MB = POOL ? 3 : EF == 0 ? RW_MB : 2;
+                                                               // epilogues need the registers: 2 (with 4 they spilled 9-19 VGPRs to scratch)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int tw = TW ? TW : P.tw;
@@ -1002,7 +1005,7 @@ __device__ __forceinline__ int dwpw_swz(int c, int row) {         // position of
 }
 
 template <int WM, int WN, int MI, int CIN, int STRIDE, int DACT, int ACT>
-__global__ __launch_bounds__(256) void dwpw_k(const ConvP P) {
+__global__ __launch_bounds__(256) void dwpw_k(const ConvP P, const int n_tiles) {
     constexpr int NI = 4, BM = WM * MI * 16, BN = WN * 64, G = CIN / 8, KS = CIN / 32;
     constexpr int TX = 4, NCOL = (TX - 1) * STRIDE + 3;
     static_assert(WM * WN == 4 && (BM / 4) * G == 256, "one (quad, channel group) item per thread");
@@ -1012,10 +1015,12 @@ __global__ __launch_bounds__(256) void dwpw_k(const ConvP P) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int fr = lane & 15, fq = lane >> 4;
-    const int q0 = (int)dd_xcd_remap(blockIdx.x, gridDim.x) * (BM / 4);
     const int n0 = blockIdx.y * BN;
 
-    // ---- pointwise weight panel -> LDS (rows in fragment order)
+    // ---- pointwise weight panel -> LDS (rows in fragment order), ONCE per block: blocks are persistent and walk the
+    // pixel tiles (tile t of the launch is logical tile dd_xcd_remap(t): each XCD keeps to one contiguous range).  With
+    // one tile per block the panel was re-fetched for every 64-256 pixels -- 30 % (128 -> 128 channels) to 37 % (128 -> 256)
+    // of everything the block pulled through the texture path, which is what bounds these kernels (10-14 B/clk/CU).
     {
         constexpr int CH = BN * G / 256;
         h8 wv[CH];
@@ -1034,6 +1039,11 @@ __global__ __launch_bounds__(256) void dwpw_k(const ConvP P) {
         }
     }
 
+    Epi8 E[2];
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2) E[g2] = epi8_load(P, n0 + wn * 64 + g2 * 32 + fq * 8);
+    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const int q0 = (int)dd_xcd_remap((unsigned)t, (unsigned)n_tiles) * (BM / 4);
     // ---- depthwise part: this thread's quad and channel group
     {
         const int ql = tid / G, g = tid % G;
@@ -1117,9 +1127,6 @@ __global__ __launch_bounds__(256) void dwpw_k(const ConvP P) {
     __syncthreads();
 
     // ---- pointwise part: [BM pixels] x [BN channels] x CIN, everything already in LDS
-    Epi8 E[2];
-#pragma unroll
-    for (int g2 = 0; g2 < 2; ++g2) E[g2] = epi8_load(P, n0 + wn * 64 + g2 * 32 + fq * 8);
     f4 acc[NI][MI];                                             // start from the bias of the lane's output channels
 #pragma unroll
     for (int a = 0; a < NI; ++a)
@@ -1155,6 +1162,8 @@ __global__ __launch_bounds__(256) void dwpw_k(const ConvP P) {
             for (int r = 0; r < 4; ++r) { o[r] = acc[2 * g2][b][r]; o[4 + r] = acc[2 * g2 + 1][b][r]; }
             conv_epilogue_f16x8<ACT, false, 0, false>(P, E[g2], m, n0 + wn * 64 + g2 * 32 + fq * 8, o);
         }
+    }
+    __syncthreads();                                              // the next tile overwrites the pixel image and mrow
     }
 }
 
@@ -1831,7 +1840,10 @@ template <int WM, int WN, int MI, int CIN, int STRIDE>
 int launch_dwpw(hipStream_t s, ConvP &P, int device) {
     constexpr int BM = WM * MI * 16, BN = WN * 64;
     constexpr size_t lds_bytes = (size_t)(BM + BN) * CIN * sizeof(_Float16) + BM * sizeof(int);
-    const dim3 grid((unsigned)dd_ceil_div(P.total_quads, BM / 4), (unsigned)dd_ceil_div(P.cout_pad, BN));
+    const int n_tiles = dd_ceil_div(P.total_quads, BM / 4), gy = dd_ceil_div(P.cout_pad, BN);
+    // persistent: as many blocks as stay resident (LDS and, at 256 threads per block, one wave per SIMD each)
+    const int per_cu = std::max(1, std::min(4, (int)(160 * 1024 / lds_bytes)));
+    const dim3 grid((unsigned)std::min(n_tiles, std::max(8, per_cu * 256 / gy / 8 * 8)), (unsigned)gy);
     const bool relu6 = P.act == ACT_RELU6 && P.dw_act == ACT_RELU6;
     if (lds_bytes > 65536) {
         static DevOnce once;
@@ -1844,8 +1856,8 @@ int launch_dwpw(hipStream_t s, ConvP &P, int device) {
         });
         if (rc != DD_OK) return rc;
     }
-    if (relu6) hipLaunchKernelGGL((dwpw_k<WM, WN, MI, CIN, STRIDE, ACT_RELU6, ACT_RELU6>), grid, dim3(256), lds_bytes, s, P);
-    else hipLaunchKernelGGL((dwpw_k<WM, WN, MI, CIN, STRIDE, -1, -1>), grid, dim3(256), lds_bytes, s, P);
+    if (relu6) hipLaunchKernelGGL((dwpw_k<WM, WN, MI, CIN, STRIDE, ACT_RELU6, ACT_RELU6>), grid, dim3(256), lds_bytes, s, P, n_tiles);
+    else hipLaunchKernelGGL((dwpw_k<WM, WN, MI, CIN, STRIDE, -1, -1>), grid, dim3(256), lds_bytes, s, P, n_tiles);
     DD_LAUNCH_CHECK();
     return DD_OK;
 }

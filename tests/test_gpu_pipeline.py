@@ -67,15 +67,25 @@ def test_ssd_plugin_vs_oracle():
     ob, oc, osc, n = nets_torch.ssd_postprocess(raw, det.ssdm.anchors)
     out = det.ssdm.invoke_device(det.ssdm.prepare_image_device(torch.from_numpy(rgba).cuda(), 480, 640, 4))
     assert int(out[3]) == n == 10
-    # stated tolerance (f16 activations vs f32): scores within 5e-3; near-tied candidates may swap
-    # places, so rows are matched by (class, box) rather than by rank
+    # (1) the post-process op by itself: the oracle's restatement applied to the HIP head tensor must pick the SAME ten
+    # anchors -- classes identical row by row, boxes and scores equal to f32 rounding (expf vs numpy's exp)
+    raw_hip = det.ssdm.net.read()[0, :, 0, :]
+    hb, hc, hs, hn = nets_torch.ssd_postprocess(raw_hip, det.ssdm.anchors)
+    assert hn == 10
+    np.testing.assert_array_equal(out[1], hc)
+    np.testing.assert_allclose(out[0], hb, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(out[2], hs, rtol=0, atol=2e-6)
+    # (2) against the independent f32 forward (f16 activations vs f32): scores within 5e-3; candidates whose scores are
+    # closer than that may swap places or fall off the end of the top ten, so rows are matched by (class, box)
     np.testing.assert_allclose(out[2], osc, atol=5e-3)
     matched = 0
     for b, c in zip(out[0], out[1]):
         d = np.abs(ob - b).max(axis=1)
         j = int(np.argmin(d))
         matched += int(d[j] < 5e-3 and oc[j] == c)
-    assert matched >= 8, matched
+    gaps = np.abs(np.diff(np.sort(osc)))
+    print('ssd plugin vs f32 oracle: %d of 10 rows matched; smallest score gap among the oracle top ten %.1e' % (matched, gaps.min()))
+    assert matched >= 10 - int((gaps < 5e-3).sum()) - 1, matched       # every row not involved in a near-tie (one spare for the 10th / 11th boundary)
     assert len(boxes) > 0 and all(s >= 0.5 for s in scores)
 
 
@@ -494,3 +504,40 @@ def test_host_path_reports_crossings_and_resumes_from_its_log(tmp_path):
     hp2 = HotPath(run_detector=False, log=path, restore_from_log=True)
     np.testing.assert_array_equal(hp2.counts(), hp.counts())
     assert hp2.frame_count == 60
+
+
+def _bench_two_ranks(extra_env):
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT', 'MASTER_ADDR')}
+    env.update(extra_env)
+    args = ['--streams', '8', '--groups', '2', '--steps', '6', '--warmup', '2', '--no-cpu-baseline']
+    two = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2'] + args, capture_output=True, text=True, env=env, timeout=900)
+    assert two.returncode == 0, two.stderr[-3000:]
+    lines = [l for l in two.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, two.stdout
+    out2 = json.loads(lines[0])
+    assert out2['n_gpus'] == 2 and out2['config']['frames_per_step'] == 16 and out2['value'] > 0
+    singles = []
+    for rank in (0, 1):              # the same streams (seeds 1000 * rank + s) run as two single-GPU jobs
+        r = subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + args, capture_output=True, text=True,
+                           env=dict(env, DD_BENCH_SEED_RANK=str(rank)), timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        singles.append(json.loads(r.stdout.strip().splitlines()[-1])['counts_pos_neg_int_del'])
+    assert out2['counts_pos_neg_int_del'] == [a + b for a, b in zip(*singles)]
+    assert sum(out2['counts_pos_neg_int_del']) >= 0
+
+
+def test_bench_two_ranks_rehearsed_on_one_gpu():
+    """The N > 1 path of bench.py with real GPU compute on a one-GPU box: `--gpus 2` spawns two ranks (both mapped to
+    device 0, count reduction over gloo because RCCL refuses two ranks on one device), each with two worker threads;
+    one JSON line, n_gpus == 2, and the reduced crossing counts equal the sum of the two ranks run as single-GPU jobs."""
+    _bench_two_ranks({'DD_BENCH_ONE_DEVICE': '1', 'DD_BENCH_BACKEND': 'gloo'})
+
+
+def test_bench_two_ranks_on_two_gpus():
+    """the same over RCCL with one GPU per rank -- per-rank device selection, worker threads on LOCAL_RANK 1.
+    Needs two GPUs (the round's GPU box has one: skipped there; the driver's scaling run exercises it)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs 2 GPUs')
+    _bench_two_ranks({})
