@@ -98,6 +98,48 @@ def test_long_scene_unbounded_gallery():
     assert trk._next_id == int(g['next_id'])
 
 
+@pytest.mark.parametrize('budget', [40, 100])
+def test_budget_ring_across_chunks_matches_oracle(budget):
+    """nn_budget = B keeps the last B samples of a track (nn_matching.py:150-153).  On the device that is a ring over
+    ceil(B / 32) gallery chunks: B = 40 wraps inside the second chunk, B = 100 inside the fourth.  A scene with births,
+    deaths and misses (slots and chunks are recycled): track table every frame and the appearance costs the device
+    associated with equal the oracle's metric with the same budget."""
+    from deepdish_amd.deep_sort import nn_matching, preprocessing
+    from deepdish_amd.deep_sort.tracker import Tracker
+    from deepdish_amd.deep_sort.detection import Detection
+    from deepdish_amd.synth import Scene
+    from oracle import deepsort_np as ds
+    scene = Scene(seed=17, n_obj=10, n_frames=150, p_miss=0.08)
+    trk = Tracker(nn_matching.NearestNeighborDistanceMetric('cosine', 0.2, budget), max_iou_distance=0.7, max_age=8,
+                  track_capacity=24, gallery_capacity=32)
+    otrk = ds.Tracker(ds.Metric(0.2, budget), max_iou_distance=0.7, max_age=8)
+    compared, worst = 0, 0.0
+    for f in range(150):
+        boxes, scores, who, feats = scene.detections(f)
+        keep = preprocessing.non_max_suppression(boxes, 0.6, scores)
+        trk.predict(); otrk.predict()
+        ids = [t.track_id for t in otrk.tracks if t.state == 2]
+        odets = [ds.Det(boxes[i], 'person', scores[i], feats[i]) for i in keep]
+        want = otrk.metric.distance(np.array([d.feature for d in odets]), ids) if ids and odets else None
+        before = [(t.track_id, t.is_confirmed()) for t in trk.tracks]
+        trk.update([Detection(boxes[i], 'person', scores[i], feats[i]) for i in keep])
+        otrk.update(odets)
+        got_i = [(t.track_id, t.state, t.time_since_update, t.hits, t.age) for t in trk.tracks]
+        assert got_i == [(t.track_id, t.state, t.time_since_update, t.hits, t.age) for t in otrk.tracks], f
+        if want is not None:
+            app, _ = trk.last_cost()
+            rows = [r for r, (_, conf) in enumerate(before) if conf]
+            assert [before[r][0] for r in rows] == ids
+            got = app[rows]
+            live = got < 1e4
+            if live.any():
+                worst = max(worst, float(np.abs(got[live] - want[live]).max()))
+                compared += int(live.sum())
+    assert compared > 300 and worst <= 2e-6, (compared, worst)
+    assert trk._next_id > 12                                   # tracks died and were born: slots and chunks were recycled
+    assert max(len(v) for v in otrk.metric.samples.values()) == budget
+
+
 def test_tracker_edge_cases():
     from deepdish_amd.deep_sort import nn_matching
     from deepdish_amd.deep_sort.tracker import Tracker
