@@ -30,4 +30,5 @@ for r in range(reps):
 net.ctx.sync()
 us = np.array([ev[r].elapsed_time(ev[r + 1]) * 1e3 for r in range(reps)])
 ref = net.read().copy()
-print(f'{kind} batch {batch}: mean {us.mean():.1f} us  min {us.min():.1f} us  checksum {float(np.abs(ref).sum()):.6e}')
+import hashlib
+print(f'{kind} batch {batch}: mean {us.mean():.1f} us  min {us.min():.1f} us  checksum {float(np.abs(ref).sum()):.6e}  sha {hashlib.sha256(np.ascontiguousarray(ref).tobytes()).hexdigest()[:16]}')

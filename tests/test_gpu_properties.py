@@ -208,3 +208,21 @@ def test_embeddings_are_unit_vectors_at_full_batch():
     f = net.read().reshape(3840, -1)[:, :128]
     assert np.isfinite(f).all()
     np.testing.assert_allclose(np.linalg.norm(f.astype(np.float64), axis=1), 1.0, atol=1e-4)
+
+
+def test_opt_in_weight_stationary_kernel_gives_the_same_bits():
+    """conv_ws_k (DD_WS=1: weight rows in registers, activation tiles through a counted-vmcnt LDS ring) sums every output
+    in the order conv_glds_k does, so the whole SSD forward is bit-identical with it switched on (the switch is read once
+    per process: two child processes)."""
+    import os, re, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sums = []
+    for ws in (False, True):
+        env = {k: v for k, v in os.environ.items() if k != 'DD_WS'}
+        if ws:
+            env['DD_WS'] = '1'
+        r = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'time_forward.py'), 'ssd', '64'], capture_output=True,
+                           text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        sums.append(re.search(r'sha (\S+)', r.stdout).group(1))
+    assert sums[0] == sums[1], sums
