@@ -788,20 +788,32 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rw_k(const ConvP P, const int 
                     for (int g = 0; g < NCO / 2; ++g)
                         rp[b][g] = *reinterpret_cast<const h8 *>(P.res + (size_t)(ok[b] ? mrow[b] : 0) * P.cs_res + P.coff_res + g * 32 + fq * 8);
             }
+            // The pixel fragments of tap t + 1 are requested BEFORE the MFMAs of tap t (two register sets, the order pinned
+            // with sched_barrier): left to itself hipcc reads a fragment one or two instructions ahead of the MFMA pair that
+            // uses it, so every 32 cycles of matrix work waited ~100 cycles for LDS (SQ_VALU_MFMA_BUSY 0.27-0.29 at two
+            // waves per SIMD).
+            h8 xf[2][MB];
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
+            for (int b = 0; b < MB; ++b) xf[0][b] = *reinterpret_cast<const h8 *>(lds + base[b]);
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const int off = (dy * PW + dx) * 8;
-                    h8 xf[MB];
+            for (int t = 0; t < 9; ++t) {
+                if (t + 1 < 9) {
+                    const int off = (((t + 1) / 3) * PW + (t + 1) % 3) * 8;
 #pragma unroll
-                    for (int b = 0; b < MB; ++b) xf[b] = *reinterpret_cast<const h8 *>(lds + base[b] + off);
-#pragma unroll
-                    for (int a = 0; a < NCO; ++a)
-#pragma unroll
-                        for (int b = 0; b < MB; ++b)
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[dy * 3 + dx][a], xf[b], acc[a][b], 0, 0, 0);
+                    for (int b = 0; b < MB; ++b) xf[(t + 1) & 1][b] = *reinterpret_cast<const h8 *>(lds + base[b] + off);
                 }
+#if defined(__HIP_DEVICE_COMPILE__)
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+                for (int a = 0; a < NCO; ++a)
+#pragma unroll
+                    for (int b = 0; b < MB; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[t][a], xf[t & 1][b], acc[a][b], 0, 0, 0);
+#if defined(__HIP_DEVICE_COMPILE__)
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+            }
 #pragma unroll
             for (int b = 0; b < MB; ++b) {
                 if (!ok[b]) continue;
