@@ -1853,9 +1853,6 @@ int launch_dwpw(hipStream_t s, ConvP &P, int device) {
     constexpr int BM = WM * MI * 16, BN = WN * 64;
     constexpr size_t lds_bytes = (size_t)(BM + BN) * CIN * sizeof(_Float16) + BM * sizeof(int);
     const int n_tiles = dd_ceil_div(P.total_quads, BM / 4), gy = dd_ceil_div(P.cout_pad, BN);
-    // persistent: as many blocks as stay resident (LDS and, at 256 threads per block, one wave per SIMD each)
-    const int per_cu = std::max(1, std::min(4, (int)(160 * 1024 / lds_bytes)));
-    const dim3 grid((unsigned)std::min(n_tiles, std::max(8, per_cu * 256 / gy / 8 * 8)), (unsigned)gy);
     const bool relu6 = P.act == ACT_RELU6 && P.dw_act == ACT_RELU6;
     if (lds_bytes > 65536) {
         static DevOnce once;
@@ -1868,6 +1865,18 @@ int launch_dwpw(hipStream_t s, ConvP &P, int device) {
         });
         if (rc != DD_OK) return rc;
     }
+    // persistent: exactly as many blocks as stay resident (registers and LDS; a surplus block would only start when a
+    // resident one has walked all its tiles)
+    static std::atomic<int> per_cu_cache[64];                       // zero-initialised; threads that race compute the same number
+    int per_cu = per_cu_cache[device & 63].load(std::memory_order_relaxed);
+    if (per_cu == 0) {
+        int nb = 0;
+        DD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&dwpw_k<WM, WN, MI, CIN, STRIDE, ACT_RELU6, ACT_RELU6>),
+                                                            256, lds_bytes));
+        per_cu = std::max(1, std::min(8, nb));
+        per_cu_cache[device & 63].store(per_cu, std::memory_order_relaxed);
+    }
+    const dim3 grid((unsigned)std::min(n_tiles, std::max(8, per_cu * 256 / gy / 8 * 8)), (unsigned)gy);
     if (relu6) hipLaunchKernelGGL((dwpw_k<WM, WN, MI, CIN, STRIDE, ACT_RELU6, ACT_RELU6>), grid, dim3(256), lds_bytes, s, P, n_tiles);
     else hipLaunchKernelGGL((dwpw_k<WM, WN, MI, CIN, STRIDE, -1, -1>), grid, dim3(256), lds_bytes, s, P, n_tiles);
     DD_LAUNCH_CHECK();
