@@ -1499,37 +1499,40 @@ struct DwP {
 // Each lane produces TX = 4 consecutive output pixels of one row for one 8-channel group: the
 // 3 x (3 + 3*stride) input window is loaded once (18 or 27 sixteen-byte loads instead of 36) and the
 // nine filter taps stay in registers.
-template <int STRIDE, int ACT>                                // ACT >= 0: activation known at compile time
+template <int STRIDE, int ACT, int TY = 1>                    // ACT >= 0: activation known at compile time; TY output rows per item
 __global__ __launch_bounds__(256) void dwconv3_k(const DwP P) {
-    constexpr int TX = 4, NCOL = (TX - 1) * STRIDE + 3;
+    constexpr int TX = 4, NCOL = (TX - 1) * STRIDE + 3, NROW = (TY - 1) * STRIDE + 3;
     const int groups = P.c >> 3;
-    const int wo4 = (P.wo + TX - 1) / TX;
-    const unsigned total = (unsigned)(P.m / P.wo) * wo4 * groups;         // m / wo = images * rows; < 2^31 (checked by the launcher)
+    const int wo4 = (P.wo + TX - 1) / TX, hoy = (P.ho + TY - 1) / TY;
+    const unsigned total = (unsigned)(P.m / (P.wo * P.ho)) * hoy * wo4 * groups;     // < 2^31 (checked by the launcher)
     const unsigned idx = dd_xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int g = (int)(idx % (unsigned)groups);                          // 32-bit: a 64-bit division costs ~100 instructions
     unsigned t = idx / (unsigned)groups;
     const int ox0 = (int)(t % (unsigned)wo4) * TX;
     t /= (unsigned)wo4;
-    const int oy = (int)(t % (unsigned)P.ho), n = (int)(t / (unsigned)P.ho);
-    float acc[TX][8];
+    const int oy0 = (int)(t % (unsigned)hoy) * TY, n = (int)(t / (unsigned)hoy);
+    float acc[TY][TX][8];
     {
         const f4 b0 = *reinterpret_cast<const f4 *>(P.bias + g * 8), b1 = *reinterpret_cast<const f4 *>(P.bias + g * 8 + 4);
 #pragma unroll
-        for (int j = 0; j < TX; ++j)
+        for (int r = 0; r < TY; ++r)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { acc[j][i] = b0[i]; acc[j][4 + i] = b1[i]; }
+            for (int j = 0; j < TX; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { acc[r][j][i] = b0[i]; acc[r][j][4 + i] = b1[i]; }
     }
     const int ix0 = ox0 * STRIDE - P.pad_l;
     const _Float16 *img = P.in + (size_t)n * P.H * P.W * P.cs_in + P.coff_in + g * 8;
     // Every load of the item is issued before the first multiply: left to itself hipcc sinks each load next to its use
     // to save registers (66 VGPRs) and the item becomes a chain of ~25 dependent memory round trips (PMC: waves parked
-    // on s_waitcnt 78-85 % of their cycles, 3.4-4 TB/s); with all 18 / 27 window loads and the nine filter taps in
-    // flight at once a wave waits for memory once.
-    h8 x[3][NCOL], w[9];
+    // on s_waitcnt 78-85 % of their cycles, 3.4-4 TB/s); with all window loads and the nine filter taps in flight at
+    // once a wave waits for memory once.  TY = 2 (stride 1): two output rows share their four input rows -- 24 loads
+    // per 8 output pixels instead of 18 per 4, i.e. a third fewer bytes through the texture path per output.
+    h8 x[NROW][NCOL], w[9];
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-        const int iy = oy * STRIDE - P.pad_t + kh;
+    for (int kh = 0; kh < NROW; ++kh) {
+        const int iy = oy0 * STRIDE - P.pad_t + kh;
         const bool rok = (unsigned)iy < (unsigned)P.H;        // out-of-image taps read the zero line: no branches, all loads in flight
         const int roff = ((rok ? iy : 0) * P.W + ix0) * P.cs_in;     // 32-bit offset inside the image (64-bit index math per load doubled the address code)
 #pragma unroll
@@ -1542,19 +1545,25 @@ __global__ __launch_bounds__(256) void dwconv3_k(const DwP P) {
     __builtin_amdgcn_sched_barrier(0);
 #endif
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
+    for (int r = 0; r < TY; ++r)
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw)
+        for (int kh = 0; kh < 3; ++kh)                        // per output the order (kh, kw) of the one-row form: same bits
 #pragma unroll
-            for (int j = 0; j < TX; ++j) dw_tap(acc[j], x[kh][j * STRIDE + kw], w[kh * 3 + kw]);
+            for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
-    for (int j = 0; j < TX; ++j) {
-        if (ox0 + j >= P.wo) break;
-        h8 o;
+                for (int j = 0; j < TX; ++j) dw_tap(acc[r][j], x[r * STRIDE + kh][j * STRIDE + kw], w[kh * 3 + kw]);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = (_Float16)apply_act(acc[j][i], ACT < 0 ? P.act : ACT);
-        const size_t m = ((size_t)n * P.ho + oy) * P.wo + ox0 + j;
-        *reinterpret_cast<h8 *>(P.out + m * P.cs_out + P.coff_out + g * 8) = o;
+    for (int r = 0; r < TY; ++r) {
+        if (oy0 + r >= P.ho) break;
+#pragma unroll
+        for (int j = 0; j < TX; ++j) {
+            if (ox0 + j >= P.wo) break;
+            h8 o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = (_Float16)apply_act(acc[r][j][i], ACT < 0 ? P.act : ACT);
+            const size_t m = ((size_t)n * P.ho + oy0 + r) * P.wo + ox0 + j;
+            *reinterpret_cast<h8 *>(P.out + m * P.cs_out + P.coff_out + g * 8) = o;
+        }
     }
 }
 
@@ -2257,14 +2266,19 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
                 P.m = nimg * td->h * td->w; P.act = o[14];
                 P.out = reinterpret_cast<_Float16 *>(base(dst)); P.cs_out = td->cs; P.coff_out = td->coff;
                 P.zero = net->d_zero;
-                const long long total = (long long)(P.m / P.wo) * ((P.wo + 3) / 4) * (P.c >> 3);
+                static const bool two_rows = getenv("DD_DW_ONE_ROW") == nullptr;              // A/B switch
+                const int ty = (P.stride == 1 && two_rows) ? 2 : 1;
+                const long long total = (long long)nimg * ((P.ho + ty - 1) / ty) * ((P.wo + 3) / 4) * (P.c >> 3);
                 DD_REQUIRE(total < (1LL << 31), DD_E_CAPACITY, "dd_net_forward: depthwise layer of %lld items exceeds 32-bit indexing", total);
                 DD_REQUIRE(P.stride == 1 || P.stride == 2, DD_E_ARG, "dd_net_forward: depthwise stride %d", P.stride);
                 const dim3 grid((unsigned)((total + 255) / 256));
 #define DD_DW(S_, A_) hipLaunchKernelGGL((dwconv3_k<S_, A_>), grid, dim3(256), 0, s, P)
-                if (P.act == ACT_RELU6) { if (P.stride == 1) DD_DW(1, ACT_RELU6); else DD_DW(2, ACT_RELU6); }
+#define DD_DW2(A_) hipLaunchKernelGGL((dwconv3_k<1, A_, 2>), grid, dim3(256), 0, s, P)
+                if (ty == 2) { if (P.act == ACT_RELU6) DD_DW2(ACT_RELU6); else if (P.act == ACT_SILU) DD_DW2(ACT_SILU); else DD_DW2(-1); }
+                else if (P.act == ACT_RELU6) { if (P.stride == 1) DD_DW(1, ACT_RELU6); else DD_DW(2, ACT_RELU6); }
                 else if (P.act == ACT_SILU) { if (P.stride == 1) DD_DW(1, ACT_SILU); else DD_DW(2, ACT_SILU); }
                 else { if (P.stride == 1) DD_DW(1, -1); else DD_DW(2, -1); }
+#undef DD_DW2
 #undef DD_DW
                 DD_LAUNCH_CHECK();
                 break;
