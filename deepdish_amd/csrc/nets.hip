@@ -867,9 +867,159 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rw_k(const ConvP P, const int 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// 3x3 32->32 convolution (same padding) + activation + 3x3 stride-2 VALID max pool of a 32-pixel-wide image, ONE WAVE
+// PER IMAGE streaming down its rows: no workgroup barrier anywhere, no staging registers, no activated tile in LDS.
+//
+//   * Round k computes conv rows 2k and 2k+1 from input rows 2k-1 .. 2k+2, which sit in the wave's own ring of eight
+//     2 KiB row slots.  The two rows of round k+1 are requested at the top of round k by global_load_lds (4 DMAs of
+//     1 KiB) and waited for with a counted vmcnt one round later.
+//   * A row slot holds the even and the odd pixels separately, each as four 8-channel planes of 16 pixels
+//     ([parity][plane][16] x 16 B = the lane order of the DMA).  An MFMA pixel fragment is the 16 even (x = 2 fr) or the
+//     16 odd (x = 2 fr + 1) output pixels of a row, so the three taps of a filter row read
+//         even outputs:  odd[fr-1]  even[fr]  odd[fr]            odd outputs:  even[fr]  odd[fr]  even[fr+1]
+//     -- four distinct conflict-free ds_read_b128 per input row serve 12 (fragment, tap) pairs, and an input row is
+//     read once for both conv rows that use it: 16 LDS reads per 72 MFMAs (conv3x3_rw_k: one read per MFMA pair --
+//     there LDS bandwidth and the matrix pipe are the same bound).
+//   * Horizontal pooling is lane-local: max(even[fr], odd[fr], even[fr+1]) with one DPP row shift; vertical pooling
+//     carries max(h(2k), h(2k+1)) into the next round.  Activation and f16 rounding are monotonic, so they are applied
+//     to the pooled maximum -- the same bits as pooling the activated f16 tile, with 4.3x fewer exponentials.
+//   * Each accumulator sums its taps in the order t = 0..8 from the bias, as conv3x3_rw_k does: bit-identical output.
+// The pooled row of round k is stored at the top of round k+1, after that round's wait: a store issued just before a
+// counted wait would be waited for (stores and DMAs share vmcnt), this one has a whole round to complete.
+constexpr int PR_SLOTS = 8, PR_SLOT_HALVES = 1024;
+
+template <int ACT>
+__global__ __launch_bounds__(256, 2) void conv3x3_pool_rows_k(const ConvP P, const int n_units, const int split_dbg) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    _Float16 *ring = lds + (size_t)wave * (PR_SLOTS * PR_SLOT_HALVES);
+
+    h8 wf[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+            wf[t][a] = *reinterpret_cast<const h8 *>(P.w + (size_t)rw_weight_row(a, fr) * P.kpad + t * 32 + fq * 8);
+    const f4 bias0 = *reinterpret_cast<const f4 *>(P.bias + fq * 8), bias1 = *reinterpret_cast<const f4 *>(P.bias + fq * 8 + 4);
+    const int ph = P.p[0], pw = P.p[1];
+    const int H = P.H;
+    // fragment addresses inside a row slot (halves): B = even[fr], C = odd[fr], A = odd[fr-1], D = even[fr+1]
+    const int offB = (fq * 16 + fr) * 8, offC = 512 + offB;
+    const int offA = 512 + (fq * 16 + (fr ? fr - 1 : 0)) * 8, offD = (fq * 16 + (fr < 15 ? fr + 1 : 15)) * 8;
+    const unsigned keepA = fr ? 0xFFFFFFFFu : 0u, keepD = fr < 15 ? 0xFFFFFFFFu : 0u;   // x = -1 / x = 32: the zero padding
+    const int act = ACT < 0 ? P.act : ACT;
+    const int split = split_dbg & 255, dbg = split_dbg >> 8;   // dbg: measurement aid (DD_PR_DBG): 1 no MFMAs, 2 no pooling epilogue, 4 no DMAs in the loop
+
+    // unit = pooled rows [j0, j1) of one image (`split` units per image: few images still fill the chip; a unit's first
+    // round only builds the carry, so a split costs one recomputed round per extra unit)
+    for (int u = blockIdx.x * 4 + wave; u < n_units; u += gridDim.x * 4) {
+        const int n = u / split, part = u - n * split;
+        const int j0 = part * ph / split, j1 = (part + 1) * ph / split;
+        const _Float16 *img = P.in + (size_t)n * H * 32 * P.cs_in + P.coff_in + fq * 8;
+        auto fill_row = [&](int y) {                              // wave-uniform y; rows outside the image: zero lines
+            _Float16 *dst = ring + ((y + 1) & (PR_SLOTS - 1)) * PR_SLOT_HALVES;
+            const bool ok = (unsigned)y < (unsigned)H;
+            const _Float16 *src = img + ((size_t)(ok ? y : 0) * 32 + 2 * fr) * P.cs_in;
+            lds_fill16(ok ? src : P.zero, dst);
+            lds_fill16(ok ? src + P.cs_in : P.zero, dst + 512);
+        };
+        fill_row(2 * j0 - 1); fill_row(2 * j0); fill_row(2 * j0 + 1); fill_row(2 * j0 + 2);
+        f4 carry[2];
+        h8 pend;                                                  // pooled row of the previous round, not yet stored
+        _Float16 *out_img = static_cast<_Float16 *>(P.out) + (size_t)n * ph * pw * P.cs_out + P.coff_out + fq * 8;
+        for (int k = j0; k <= j1; ++k) {
+            if (!(dbg & 4)) { fill_row(2 * k + 3); fill_row(2 * k + 4); }
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // rows up to 2k+2 have landed (this wave's own DMAs: no barrier)
+#endif
+            if (k >= j0 + 2 && fr < pw) *reinterpret_cast<h8 *>(out_img + (size_t)((k - 2) * pw + fr) * P.cs_out) = pend;
+            f4 acc[2][2][2];                                      // [conv row][parity][channel half], from the bias
+#pragma unroll
+            for (int cr = 0; cr < 2; ++cr)
+#pragma unroll
+                for (int par = 0; par < 2; ++par) { acc[cr][par][0] = bias0; acc[cr][par][1] = bias1; }
+            typedef unsigned u4v __attribute__((ext_vector_type(4)));
+            h8 X[2][4];
+            auto read_row = [&](int i, h8 (&x)[4]) {
+                const _Float16 *rs = ring + ((2 * k + i) & (PR_SLOTS - 1)) * PR_SLOT_HALVES;     // slot of input row 2k-1+i
+                x[0] = *reinterpret_cast<const h8 *>(rs + offA);
+                x[1] = *reinterpret_cast<const h8 *>(rs + offB);
+                x[2] = *reinterpret_cast<const h8 *>(rs + offC);
+                x[3] = *reinterpret_cast<const h8 *>(rs + offD);
+            };
+            read_row(0, X[0]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                // order: wait for row i (requested one row of MFMAs ago), THEN request row i+1, then multiply -- hipcc's wait
+                // before the first use of row i is lgkmcnt(0), so a request issued ahead of it would be waited for as well
+                h8 (&x)[4] = X[i & 1];
+                x[0] = __builtin_bit_cast(h8, __builtin_bit_cast(u4v, x[0]) & keepA);
+                x[3] = __builtin_bit_cast(h8, __builtin_bit_cast(u4v, x[3]) & keepD);
+#if defined(__HIP_DEVICE_COMPILE__)
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+                if (i + 1 < 4) read_row(i + 1, X[(i + 1) & 1]);
+#if defined(__HIP_DEVICE_COMPILE__)
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                    for (int cr = 0; cr < 2; ++cr) {
+                        const int dy = i - cr;                    // filter row of conv row 2k+cr that meets input row 2k-1+i
+                        if (dy < 0 || dy > 2 || (dbg & 1)) continue;
+#pragma unroll
+                        for (int par = 0; par < 2; ++par)
+#pragma unroll
+                            for (int a = 0; a < 2; ++a)
+                                acc[cr][par][a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[dy * 3 + dx][a], x[dx + par], acc[cr][par][a], 0, 0, 0);
+                    }
+#if defined(__HIP_DEVICE_COMPILE__)
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+            }
+            if (dbg & 2) { pend = __builtin_bit_cast(h8, acc[0][0][0] + acc[1][1][1] + acc[0][1][0] + acc[1][0][1]); continue; }
+            // horizontal 3-max of each conv row: x = 2fr, 2fr+1 and 2fr+2 (the even fragment of lane fr+1)
+            f4 hm[2][2];
+#pragma unroll
+            for (int cr = 0; cr < 2; ++cr)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = acc[cr][0][a][r];
+                        float nx = e;
+#if defined(__HIP_DEVICE_COMPILE__)
+                        // lane 15 of a row gets 0 (bound_ctrl): it is pooled column 15, which does not exist and is never stored
+                        nx = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, e), 0x101 /* row_shl:1 */, 0xf, 0xf, true));
+#endif
+                        hm[cr][a][r] = fmaxf(fmaxf(e, acc[cr][1][a][r]), nx);
+                    }
+            if (k > j0) {                                         // pooled row k-1 = rows 2k-2, 2k-1 (carried) and 2k
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        pend[a * 4 + r] = (_Float16)apply_act(fmaxf(carry[a][r], hm[0][a][r]), act);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) carry[a][r] = fmaxf(hm[0][a][r], hm[1][a][r]);
+        }
+        if (fr < pw) *reinterpret_cast<h8 *>(out_img + (size_t)((j1 - 1) * pw + fr) * P.cs_out) = pend;
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the look-ahead DMAs of the last rounds
+#endif
+}
+
 // First layer of a network straight from the u8 image: (x - mean) * scale, 3x3 conv over 3 channels
-// (K = 27, one MFMA k-slice padded to 32; k = dy*9 + dx*3 + ch, so one filter row of a pixel is nine
-// consecutive halves of the LDS patch), bias, activation -> NHWC f16 with 32 channels.  Replaces the
+// (K = 27, one MFMA k-slice padded to 32; tap dy*9 + dx*3 + ch, so one filter row of a pixel is nine
+// consecutive halves of the LDS patch; k slots as in stem_conv_pool_rows_k, which must produce the same bits), bias, activation -> NHWC f16 with 32 channels.  Replaces the
 // separate input-conversion pass and its 8-channel f16 tensor.  Weights [32][32] f16, channel swap
 // (BGR -> RGB) already folded into them by the host.
 template <int STRIDE, int ACT>
@@ -952,8 +1102,9 @@ __global__ __launch_bounds__(256) void stem_conv3_k(const ConvP P) {
     int koff[8];                                                  // this lane's eight k positions inside a pixel's window
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int k = fq * 8 + j;
-        koff[j] = k < 27 ? (k / 9) * pitch + (k % 9) : 0;           // k >= 27: weight is zero, any finite value will do
+        // k slot (fq, j) -> tap (deepdish_amd/nets.py STEM_K_SLOT): group dy < 3 = taps 0..7 of filter row dy, group 3 =
+        // the ninth tap of rows 0..2; the other five slots have zero weights, any finite value will do
+        koff[j] = fq < 3 ? fq * pitch + j : j < 3 ? j * pitch + 8 : 0;
     }
     __syncthreads();
 
@@ -1808,6 +1959,29 @@ int launch_conv3x3_rw(hipStream_t s, ConvP &P, int nimg, bool pool, int device) 
     if (pool) {                                                  // 8 pooled rows per tile = 17 conv rows, full width
         P.tw = P.wo; P.th = 17; P.tiles_x = 1; P.tiles_y = dd_ceil_div(P.p[0], 8);
         DD_REQUIRE(P.wo == 32 && P.act == ACT_ELU && !P.res && !P.out2, DD_E_ARG, "conv3x3_rw: fused pooling needs a 32-wide ELU layer");
+        // one wave per image, rows streamed (conv3x3_pool_rows_k); DD_POOL_TILED=1 keeps the tiled kernel (same bits)
+        static const bool tiled = getenv("DD_POOL_TILED") && atoi(getenv("DD_POOL_TILED")) != 0;
+        // (measured at 3840 / 1024 / 256 / 64 images: rows 136 / 41 / 17 / 9.3 us, tiled 251 / 75 / 23 / 9.0 us; below
+        // ~160 images the tiled kernel's 16 waves per image win, profiles/r02_pool_rows_sweep.txt)
+        if (!tiled && nimg >= 160 && P.W == 32 && P.H == P.ho && P.H % 2 == 0 && P.p[0] == P.H / 2 - 1 && P.p[1] == 15 && P.pad_t == 1 && P.pad_l == 1 &&
+            P.cin == 32 && P.cout == 32) {
+            constexpr size_t ring_bytes = (size_t)4 * PR_SLOTS * PR_SLOT_HALVES * sizeof(_Float16);
+            static DevOnce once;
+            const int rc = once.run(device, [&]() -> int {
+                DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_pool_rows_k<ACT_ELU>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_bytes));
+                return DD_OK;
+            });
+            if (rc != DD_OK) return rc;
+            static const int force_split = getenv("DD_POOL_SPLIT") ? atoi(getenv("DD_POOL_SPLIT")) : 0;
+            const int split = force_split > 0 ? force_split : nimg >= 1536 ? 1 : nimg >= 768 ? 2 : 4;
+            const int n_units = nimg * split;
+            const int grid = std::min(dd_ceil_div(n_units, 4), 2 * 256);
+            static const int dbg = getenv("DD_PR_DBG") ? atoi(getenv("DD_PR_DBG")) : 0;
+            hipLaunchKernelGGL((conv3x3_pool_rows_k<ACT_ELU>), dim3((unsigned)grid), dim3(256), ring_bytes, s, P, n_units, split | (dbg << 8));
+            DD_LAUNCH_CHECK();
+            return DD_OK;
+        }
     } else {
         spatial_tile(P.ho, P.wo, 1, RW_MAX_PATCH, P);
     }

@@ -27,6 +27,10 @@ MAGIC = 0x314E4444
 BN_EPS = 1e-3
 
 
+# MFMA k slot of stem tap k = dy*9 + dx*3 + ch (csrc/nets.hip stem_koff): rem = k % 9 < 8 -> dy*8 + rem, else 24 + dy
+STEM_K_SLOT = np.array([(k // 9) * 8 + k % 9 if k % 9 < 8 else 24 + k // 9 for k in range(27)])
+
+
 def rup(x, m):
     return (x + m - 1) // m * m
 
@@ -101,14 +105,16 @@ class Program:
     def stem(self, w_hwio, bias, stride, act, swap_rb, mean=0.0, scale=1.0):
         """First layer straight from the u8 image: (x - mean) * scale -> 3x3 conv over the 3 colour channels
         (TF SAME) -> bias -> act -> NHWC f16 with 32 channels (csrc/nets.hip stem_conv3_k).  The channel swap
-        is folded into the weights; they are packed [32][32] f16 with k = dy*9 + dx*3 + ch (27 real)."""
+        is folded into the weights; they are packed [32][32] f16, tap k = dy*9 + dx*3 + ch at MFMA k slot
+        STEM_K_SLOT[k]: k-group dy holds the first eight taps of filter row dy (eight consecutive halves of an
+        image row) and group 3 the ninth tap of each row -- a lane gathers its eight operands from one image row."""
         kh, kw, cin, cout = w_hwio.shape
         assert (kh, kw, cin) == (3, 3, 3) and cout <= 32
         ho, pt = same_pad(self.in_h, 3, stride)
         wo, pl = same_pad(self.in_w, 3, stride)
         w = w_hwio[:, :, ::-1, :] if swap_rb else w_hwio
         wp = np.zeros((32, 32), dtype=np.float16)
-        wp[:cout, :27] = np.transpose(w, (3, 0, 1, 2)).reshape(cout, 27).astype(np.float16)
+        wp[:cout, STEM_K_SLOT] = np.transpose(w, (3, 0, 1, 2)).reshape(cout, 27).astype(np.float16)
         bp = np.zeros(32, dtype=np.float32)
         bp[:cout] = bias
         dst = self.tensor(ho, wo, cout)
