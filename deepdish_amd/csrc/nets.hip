@@ -887,15 +887,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rw_k(const ConvP P, const int 
 //   * Each accumulator sums its taps in the order t = 0..8 from the bias, as conv3x3_rw_k does: bit-identical output.
 // The pooled row of round k is stored at the top of round k+1, after that round's wait: a store issued just before a
 // counted wait would be waited for (stores and DMAs share vmcnt), this one has a whole round to complete.
-constexpr int PR_SLOTS = 8, PR_SLOT_HALVES = 1024;
+//
+// STEM = true: the input rows are not read at all -- the wave computes them from the u8 image (the network's first
+// layer, stem_conv3_k's arithmetic in the same k slots: same bits) two rows ahead of the round that needs them.  Two image
+// rows per round arrive as one dword per lane, are normalised to f16 into an 8-row ring (pitch 104 halves: x = -1 at
+// halves 1..3, x = 0 at half 4, x = 32 at 100..102; the pad columns are zeroed once), and a stem fragment gathers its
+// eight k operands with ds_read_u16 from one ring row per lane.  The 64x32x32 f16 tensor between the two layers (131 KB
+// per image written and read back -- what bounds the DMA version) never exists.
+constexpr int PR_SLOTS = 8, PR_SLOT_HALVES = 1024, PR_CROP_PITCH = 104;
+constexpr int pr_wave_halves(bool stem) { return PR_SLOTS * PR_SLOT_HALVES + (stem ? PR_SLOTS * PR_CROP_PITCH : 0); }
 
-template <int ACT>
+template <int ACT, bool STEM>
 __global__ __launch_bounds__(256, 2) void conv3x3_pool_rows_k(const ConvP P, const int n_units, const int split_dbg) {
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
-    _Float16 *ring = lds + (size_t)wave * (PR_SLOTS * PR_SLOT_HALVES);
+    _Float16 *ring = lds + (size_t)wave * pr_wave_halves(STEM);
+    _Float16 *crop = ring + PR_SLOTS * PR_SLOT_HALVES;
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
 
     h8 wf[9][2];
 #pragma unroll
@@ -904,6 +915,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_pool_rows_k(const ConvP P, con
         for (int a = 0; a < 2; ++a)
             wf[t][a] = *reinterpret_cast<const h8 *>(P.w + (size_t)rw_weight_row(a, fr) * P.kpad + t * 32 + fq * 8);
     const f4 bias0 = *reinterpret_cast<const f4 *>(P.bias + fq * 8), bias1 = *reinterpret_cast<const f4 *>(P.bias + fq * 8 + 4);
+    h8 ws[2];
+    f4 sb0, sb1;
+    if constexpr (STEM) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) ws[a] = *reinterpret_cast<const h8 *>(P.dw_w + rw_weight_row(a, fr) * 32 + fq * 8);
+        sb0 = *reinterpret_cast<const f4 *>(P.dw_bias + fq * 8); sb1 = *reinterpret_cast<const f4 *>(P.dw_bias + fq * 8 + 4);
+        if (lane < 2 * PR_SLOTS)                                  // pad columns of every ring row, never written again
+            *reinterpret_cast<h4 *>(crop + (lane >> 1) * PR_CROP_PITCH + ((lane & 1) ? 100 : 0)) = h4{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+    }
     const int ph = P.p[0], pw = P.p[1];
     const int H = P.H;
     // fragment addresses inside a row slot (halves): B = even[fr], C = odd[fr], A = odd[fr-1], D = even[fr+1]
@@ -911,14 +931,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_pool_rows_k(const ConvP P, con
     const int offA = 512 + (fq * 16 + (fr ? fr - 1 : 0)) * 8, offD = (fq * 16 + (fr < 15 ? fr + 1 : 15)) * 8;
     const unsigned keepA = fr ? 0xFFFFFFFFu : 0u, keepD = fr < 15 ? 0xFFFFFFFFu : 0u;   // x = -1 / x = 32: the zero padding
     const int act = ACT < 0 ? P.act : ACT;
-    const int split = split_dbg & 255, dbg = split_dbg >> 8;   // dbg: measurement aid (DD_PR_DBG): 1 no MFMAs, 2 no pooling epilogue, 4 no DMAs in the loop
+    const int split = split_dbg & 255, dbg = split_dbg >> 8;   // dbg: measurement aid (DD_PR_DBG): 1 no MFMAs, 2 no pooling epilogue, 4 no row production in the loop
+    const int crow = lane >> 5, cdw = lane & 31;                // image rows: two per step, one dword per lane (24 of 32 live)
+    const int cx = 1 + 6 * fr;                                  // window start (x - 1) of the even pixel x = 2 fr in a ring row
 
     // unit = pooled rows [j0, j1) of one image (`split` units per image: few images still fill the chip; a unit's first
     // round only builds the carry, so a split costs one recomputed round per extra unit)
     for (int u = blockIdx.x * 4 + wave; u < n_units; u += gridDim.x * 4) {
         const int n = u / split, part = u - n * split;
         const int j0 = part * ph / split, j1 = (part + 1) * ph / split;
-        const _Float16 *img = P.in + (size_t)n * H * 32 * P.cs_in + P.coff_in + fq * 8;
+        const _Float16 *img = STEM ? nullptr : P.in + (size_t)n * H * 32 * P.cs_in + P.coff_in + fq * 8;
+        const uint8_t *img8 = STEM ? P.src8 + (size_t)n * H * 96 : nullptr;
         auto fill_row = [&](int y) {                              // wave-uniform y; rows outside the image: zero lines
             _Float16 *dst = ring + ((y + 1) & (PR_SLOTS - 1)) * PR_SLOT_HALVES;
             const bool ok = (unsigned)y < (unsigned)H;
@@ -926,22 +949,77 @@ __global__ __launch_bounds__(256, 2) void conv3x3_pool_rows_k(const ConvP P, con
             lds_fill16(ok ? src : P.zero, dst);
             lds_fill16(ok ? src + P.cs_in : P.zero, dst + 512);
         };
-        fill_row(2 * j0 - 1); fill_row(2 * j0); fill_row(2 * j0 + 1); fill_row(2 * j0 + 2);
+        auto load_raw = [&](int r0) -> unsigned {                 // image rows r0, r0+1 (a select between addresses, not values)
+            const int r = r0 + crow;
+            const bool ok = (unsigned)r < (unsigned)H && cdw < 24;
+            return *reinterpret_cast<const unsigned *>(ok ? img8 + (size_t)r * 96 + cdw * 4 : reinterpret_cast<const uint8_t *>(P.zero));
+        };
+        auto put_crop = [&](int r0, unsigned raw) {               // normalise; rows outside the image are the zero padding
+            const int r = r0 + crow;
+            const bool ok = (unsigned)r < (unsigned)H;
+            h4 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = (_Float16)(ok ? ((float)((raw >> (8 * q)) & 255u) - P.in_mean) * P.in_scale : 0.f);
+            if (cdw < 24) *reinterpret_cast<h4 *>(crop + ((r + 1) & (PR_SLOTS - 1)) * PR_CROP_PITCH + 4 + cdw * 4) = o;
+        };
+        auto stem_row = [&](int y) {                              // first-layer row y -> its ring slot (wave-uniform y)
+            _Float16 *dst = ring + ((y + 1) & (PR_SLOTS - 1)) * PR_SLOT_HALVES;
+            if ((unsigned)y >= (unsigned)H) {                     // the second layer's zero padding
+                const h8 z = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+                *reinterpret_cast<h8 *>(dst + lane * 8) = z;
+                *reinterpret_cast<h8 *>(dst + 512 + lane * 8) = z;
+                return;
+            }
+            // image row y-1+d sits in ring row (y+d) & 7; k slots: group d < 3 = taps 0..7 of filter row d, group 3 = tap 8 of rows 0..2
+            const int L0 = (y & (PR_SLOTS - 1)) * PR_CROP_PITCH + cx, L1 = ((y + 1) & (PR_SLOTS - 1)) * PR_CROP_PITCH + cx,
+                      L2 = ((y + 2) & (PR_SLOTS - 1)) * PR_CROP_PITCH + cx;
+            const int Pb = fq == 0 ? L0 : fq == 1 ? L1 : L2;
+            const int A0 = fq == 3 ? L0 + 8 : Pb, A1 = fq == 3 ? L1 + 7 : Pb, A2 = fq == 3 ? L2 + 6 : Pb;
+#pragma unroll
+            for (int par = 0; par < 2; ++par) {
+                h8 xf;
+                xf[0] = crop[A0 + 3 * par]; xf[1] = crop[A1 + 1 + 3 * par]; xf[2] = crop[A2 + 2 + 3 * par];
+#pragma unroll
+                for (int j = 3; j < 8; ++j) xf[j] = crop[Pb + j + 3 * par];
+                const f4 a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ws[0], xf, sb0, 0, 0, 0);       // onto the bias, as stem_conv3_k
+                const f4 a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ws[1], xf, sb1, 0, 0, 0);
+                h8 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { o[r] = (_Float16)apply_act(a0[r], act); o[4 + r] = (_Float16)apply_act(a1[r], act); }   // launcher: both layers ELU
+                *reinterpret_cast<h8 *>(dst + par * 512 + (fq * 16 + fr) * 8) = o;
+            }
+        };
+        unsigned raw = 0;
+        if constexpr (STEM) {
+            put_crop(2 * j0 - 2, load_raw(2 * j0 - 2));
+            raw = load_raw(2 * j0);
+        } else {
+            fill_row(2 * j0 - 1); fill_row(2 * j0); fill_row(2 * j0 + 1); fill_row(2 * j0 + 2);
+        }
         f4 carry[2];
         h8 pend;                                                  // pooled row of the previous round, not yet stored
         _Float16 *out_img = static_cast<_Float16 *>(P.out) + (size_t)n * ph * pw * P.cs_out + P.coff_out + fq * 8;
-        for (int k = j0; k <= j1; ++k) {
-            if (!(dbg & 4)) { fill_row(2 * k + 3); fill_row(2 * k + 4); }
+        for (int k = STEM ? j0 - 2 : j0; k <= j1; ++k) {
+            if constexpr (STEM) {
+                // step k makes first-layer rows 2k+3 and 2k+4 (round k+1's new rows) from image rows 2k+2 .. 2k+5
+                if (k < j1 && !((dbg & 4) && k >= j0)) {
+                    put_crop(2 * k + 4, raw);
+                    raw = load_raw(2 * k + 6);
+                    stem_row(2 * k + 3); stem_row(2 * k + 4);
+                }
+                if (k < j0) continue;
+            } else {
+                if (!(dbg & 4)) { fill_row(2 * k + 3); fill_row(2 * k + 4); }
 #if defined(__HIP_DEVICE_COMPILE__)
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // rows up to 2k+2 have landed (this wave's own DMAs: no barrier)
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // rows up to 2k+2 have landed (this wave's own DMAs: no barrier)
 #endif
+            }
             if (k >= j0 + 2 && fr < pw) *reinterpret_cast<h8 *>(out_img + (size_t)((k - 2) * pw + fr) * P.cs_out) = pend;
             f4 acc[2][2][2];                                      // [conv row][parity][channel half], from the bias
 #pragma unroll
             for (int cr = 0; cr < 2; ++cr)
 #pragma unroll
                 for (int par = 0; par < 2; ++par) { acc[cr][par][0] = bias0; acc[cr][par][1] = bias1; }
-            typedef unsigned u4v __attribute__((ext_vector_type(4)));
             h8 X[2][4];
             auto read_row = [&](int i, h8 (&x)[4]) {
                 const _Float16 *rs = ring + ((2 * k + i) & (PR_SLOTS - 1)) * PR_SLOT_HALVES;     // slot of input row 2k-1+i
@@ -1955,30 +2033,40 @@ void spatial_tile(int ho, int wo, int stride, int max_patch, ConvP &P) {
     P.th = th; P.tw = tw; P.tiles_x = tiles_x; P.tiles_y = tiles_y;
 }
 
+// Can the pooled 3x3 layer P run as conv3x3_pool_rows_k on nimg images?  (P.p[0..1] = pooled height, width.)
+bool pool_rows_fusable(const ConvP &P, int nimg) {
+    static const bool tiled = getenv("DD_POOL_TILED") && atoi(getenv("DD_POOL_TILED")) != 0;
+    return !tiled && nimg >= 160 && P.W == 32 && P.wo == 32 && P.H == P.ho && P.H % 2 == 0 && P.p[0] == P.H / 2 - 1 && P.p[1] == 15 &&
+           P.pad_t == 1 && P.pad_l == 1 && P.cin == 32 && P.cout == 32 && P.act == ACT_ELU;
+}
+
 int launch_conv3x3_rw(hipStream_t s, ConvP &P, int nimg, bool pool, int device) {
     if (pool) {                                                  // 8 pooled rows per tile = 17 conv rows, full width
         P.tw = P.wo; P.th = 17; P.tiles_x = 1; P.tiles_y = dd_ceil_div(P.p[0], 8);
         DD_REQUIRE(P.wo == 32 && P.act == ACT_ELU && !P.res && !P.out2, DD_E_ARG, "conv3x3_rw: fused pooling needs a 32-wide ELU layer");
         // one wave per image, rows streamed (conv3x3_pool_rows_k); DD_POOL_TILED=1 keeps the tiled kernel (same bits)
-        static const bool tiled = getenv("DD_POOL_TILED") && atoi(getenv("DD_POOL_TILED")) != 0;
         // (measured at 3840 / 1024 / 256 / 64 images: rows 136 / 41 / 17 / 9.3 us, tiled 251 / 75 / 23 / 9.0 us; below
         // ~160 images the tiled kernel's 16 waves per image win, profiles/r02_pool_rows_sweep.txt)
-        if (!tiled && nimg >= 160 && P.W == 32 && P.H == P.ho && P.H % 2 == 0 && P.p[0] == P.H / 2 - 1 && P.p[1] == 15 && P.pad_t == 1 && P.pad_l == 1 &&
-            P.cin == 32 && P.cout == 32) {
-            constexpr size_t ring_bytes = (size_t)4 * PR_SLOTS * PR_SLOT_HALVES * sizeof(_Float16);
+        const bool stem = P.src8 != nullptr;                     // the caller folded the network's first layer in (pool_rows_fusable)
+        DD_REQUIRE(!stem || pool_rows_fusable(P, nimg), DD_E_ARG, "conv3x3_rw: first layer folded into a launch that cannot take it");
+        if (pool_rows_fusable(P, nimg)) {
+            const size_t ring_bytes = (size_t)4 * pr_wave_halves(stem) * sizeof(_Float16);
             static DevOnce once;
             const int rc = once.run(device, [&]() -> int {
-                DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_pool_rows_k<ACT_ELU>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_bytes));
+                DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_pool_rows_k<ACT_ELU, false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * pr_wave_halves(false) * sizeof(_Float16))));
+                DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_pool_rows_k<ACT_ELU, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * pr_wave_halves(true) * sizeof(_Float16))));
                 return DD_OK;
             });
             if (rc != DD_OK) return rc;
             static const int force_split = getenv("DD_POOL_SPLIT") ? atoi(getenv("DD_POOL_SPLIT")) : 0;
+            static const int dbg = getenv("DD_PR_DBG") ? atoi(getenv("DD_PR_DBG")) : 0;
             const int split = force_split > 0 ? force_split : nimg >= 1536 ? 1 : nimg >= 768 ? 2 : 4;
             const int n_units = nimg * split;
             const int grid = std::min(dd_ceil_div(n_units, 4), 2 * 256);
-            static const int dbg = getenv("DD_PR_DBG") ? atoi(getenv("DD_PR_DBG")) : 0;
-            hipLaunchKernelGGL((conv3x3_pool_rows_k<ACT_ELU>), dim3((unsigned)grid), dim3(256), ring_bytes, s, P, n_units, split | (dbg << 8));
+            if (stem) hipLaunchKernelGGL((conv3x3_pool_rows_k<ACT_ELU, true>), dim3((unsigned)grid), dim3(256), ring_bytes, s, P, n_units, split | (dbg << 8));
+            else hipLaunchKernelGGL((conv3x3_pool_rows_k<ACT_ELU, false>), dim3((unsigned)grid), dim3(256), ring_bytes, s, P, n_units, split | (dbg << 8));
             DD_LAUNCH_CHECK();
             return DD_OK;
         }
@@ -2301,6 +2389,8 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
         const TensorDesc &d = net->tensors[t];
         return static_cast<char *>(net->bufs[d.buf]);
     };
+    ConvP stem_p;                                                 // a first layer waiting to be folded into the next op's launch
+    bool stem_pending = false;
     for (int i = 0; i < net->n_ops; ++i) {
         if (net->profile) DD_HIP(hipEventRecord(net->events[i], s));
         const int32_t *o = net->prog.data() + net->ops_off + (size_t)i * OP_WORDS;
@@ -2308,6 +2398,11 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
         const int kind = o[0], src = o[1], dst = o[2], res = o[3], dst2 = o[4];
         const TensorDesc *ts = src >= 0 ? &net->tensors[src] : nullptr;
         const TensorDesc *td = dst >= 0 ? &net->tensors[dst] : nullptr;
+        if (stem_pending && !(kind == OP_CONV && o[29])) {            // not followed by the layer it was meant for: run it on its own
+            stem_pending = false;
+            const int rc = launch_stem(s, stem_p, nimg);
+            if (rc != DD_OK) return rc;
+        }
         switch (kind) {
             case OP_INPUT: {
                 const int s2d = o[5];
@@ -2353,6 +2448,16 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
                     P.epi == EPI_F16 && P.pad_t == 1 && P.pad_l == 1) {
                     // whole filter in registers, input patch staged once (see conv3x3_rw_k)
                     if (o[29]) { P.p[0] = td->h; P.p[1] = td->w; }      // fused 3x3/2 max pool: dst is the pooled tensor
+                    if (stem_pending) {
+                        stem_pending = false;
+                        if (o[29] && pool_rows_fusable(P, nimg) && stem_p.out == static_cast<const void *>(P.in) && !P.coff_in) {
+                            P.src8 = stem_p.src8; P.in_mean = stem_p.in_mean; P.in_scale = stem_p.in_scale;
+                            P.dw_w = stem_p.w; P.dw_bias = stem_p.bias; P.dw_act = stem_p.act;
+                        } else {
+                            rc = launch_stem(s, stem_p, nimg);
+                            if (rc != DD_OK) return rc;
+                        }
+                    }
                     rc = launch_conv3x3_rw(s, P, nimg, o[29] != 0, net->ctx->device);
                 } else if (ws_eligible(P)) {
                     rc = P.cin == 256 ? launch_conv_ws<4>(s, P, net->ctx->device) : launch_conv_ws<8>(s, P, net->ctx->device);
@@ -2401,6 +2506,14 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
                 P.bias = reinterpret_cast<const float *>(net->d_weights + (size_t)(uint32_t)o[17]);
                 P.ho = td->h; P.wo = td->w; P.m = nimg * P.ho * P.wo;
                 P.out = base(dst); P.cs_out = td->cs; P.coff_out = td->coff;
+                // o[30]: the next op is the pooled 3x3 layer reading this tensor and nothing else does -- with enough images
+                // both run as one launch (conv3x3_pool_rows_k<STEM>) and this tensor is never written
+                static const bool unfused = getenv("DD_STEM_UNFUSED") && atoi(getenv("DD_STEM_UNFUSED")) != 0;
+                if (o[30] && !unfused && i + 1 < net->n_ops && P.stride == 1 && P.pad_t == 1 && P.pad_l == 1 && P.cout == 32 && P.act == ACT_ELU &&
+                    P.W == 32 && (reinterpret_cast<uintptr_t>(input) & 3) == 0) {
+                    stem_p = P; stem_pending = true;
+                    break;
+                }
                 int rc = launch_stem(s, P, nimg);
                 if (rc != DD_OK) return rc;
                 break;

@@ -43,6 +43,8 @@ def same_pad(size, k, stride):
 
 
 class Program:
+    STEM_POOL_FUSE = os.environ.get('DD_STEM_POOL_FUSE', '1') != '0'   # MARS conv1_1 folded into conv1_2's launch
+
     def __init__(self, in_h, in_w):
         self.in_h, self.in_w = in_h, in_w
         self.tensors, self.bufs, self.ops = [], [], []
@@ -84,7 +86,7 @@ class Program:
         f = w.view(np.float32)
         w[0:5] = (kind, src, dst, res, dst2)
         names = dict(kh=5, kw=6, stride=7, pad_t=8, pad_l=9, cin=10, cout=11, cout_pad=12, kpad=13, act=14, epi=15,
-                     w_off=16, b_off=17, aff_off=18, has_aff=19, ho=26, wo=27, bk=28, pool=29)
+                     w_off=16, b_off=17, aff_off=18, has_aff=19, ho=26, wo=27, bk=28, pool=29, fuse_next=30)
         for k, v in kw.items():
             if k == 'p':
                 w[20:20 + len(v)] = v
@@ -170,7 +172,7 @@ class Program:
         self._op(OP_CONV, src=src, dst=dst, res=res, dst2=dst2, **kw_)
         tile = '4,1,1,2' if cout_pad <= 32 else '2,2,2,2'
         rw = (kh, kw, stride, cin_pad, cout_pad, epi, pt, pl) == (3, 3, 1, 32, 32, EPI_F16, 1, 1)
-        self.info[-1] = dict(kernel='conv3x3_rw_k' if rw else 'conv_glds_k' if bk == 64 else 'conv_mfma_k<%s,%d>' % (tile, bk),
+        self.info[-1] = dict(kernel='conv3x3_pool_rows_k' if rw and pool else 'conv3x3_rw_k' if rw else 'conv_glds_k' if bk == 64 else 'conv_mfma_k<%s,%d>' % (tile, bk),
                              flops=2 * ho * wo * kh * kw * cin * cout,
                              bytes=2 * s['h'] * s['w'] * cin + (4 if epi != EPI_F16 else 2) * (self.T(dst)['h'] * self.T(dst)['w'] if pool else ho * wo) * cout
                              + (2 * ho * wo * cout if res >= 0 else 0) + (2 * ho * wo * cout if dst2 >= 0 else 0),
@@ -342,6 +344,8 @@ def compile_mars(wd, in_h=64, in_w=32):
     P = Program(in_h, in_w)
     w, b = fold_conv_bn(wd, 'conv1_1')
     x = c11 = P.stem(w, b, 1, ACT_ELU, swap_rb=True)                           # :175-177 BGR -> RGB, :101-105
+    if Program.STEM_POOL_FUSE:       # conv1_1 is read by conv1_2 only: with >= 160 crops both run as one launch
+        P.ops[-1][30] = 1            # (conv3x3_pool_rows_k<STEM>) and the conv1_1 tensor is not written
     w, b = fold_conv_bn(wd, 'conv1_2'); x = pool = P.conv(x, w, b, act=ACT_ELU, pool=True)   # :106-110 + :116 VALID pool
     raw, pre = x, x                  # raw = block input (skip path), pre = what conv "1" reads
     for i, (name, c, inc, first) in enumerate(MARS_BLOCKS):

@@ -37,6 +37,39 @@ def test_mars_batch_of_1280_is_crop_independent():
         np.testing.assert_array_equal(net.read()[0, 0, 0, :], full[i])
 
 
+@pytest.mark.parametrize('n', [159, 160, 170, 800, 1600])
+def test_mars_first_layers_give_the_same_bits_in_every_launch_shape(n):
+    """conv1_1 + conv1_2 + pool: below 160 crops two launches (stem_conv3_k, tiled conv3x3_rw_k<POOL>), from 160 one
+    launch of one wave per row range (conv3x3_pool_rows_k<STEM>, 4 / 2 / 1 units per crop by batch size); a program
+    compiled without the fusion flag keeps the first layer separate and streams its rows by DMA.  All of them must give
+    the bits of the single-crop forward."""
+    from deepdish_amd import nets
+    from deepdish_amd.engine import Net
+    wd = nets.synthetic_mars_weights(1234)
+    rng = np.random.default_rng(n)
+    x = rng.integers(0, 256, (n, 64, 32, 3), dtype=np.uint8)
+    x[1] = 0; x[2] = 255                                   # flat crops: every pooled window is a tie
+    net = Net(nets.compile_mars(wd), max_batch=n)
+    assert net.program.ops[0][30] == 1
+    net.forward(x)
+    full = net.read()[:, 0, 0, :].copy()
+    pool = net.read(tensor=net.program.meta['tensors']['pool1']).copy()
+    for i in (0, 1, 2, n // 2, n - 1):
+        net.forward(x[i:i + 1])
+        np.testing.assert_array_equal(net.read()[0, 0, 0, :], full[i])
+        np.testing.assert_array_equal(net.read(tensor=net.program.meta['tensors']['pool1'])[0], pool[i])
+    old = nets.Program.STEM_POOL_FUSE
+    try:
+        nets.Program.STEM_POOL_FUSE = False
+        net2 = Net(nets.compile_mars(wd), max_batch=n)
+    finally:
+        nets.Program.STEM_POOL_FUSE = old
+    assert net2.program.ops[0][30] == 0
+    net2.forward(x)
+    np.testing.assert_array_equal(net2.read()[:, 0, 0, :], full)
+    np.testing.assert_array_equal(net2.read(tensor=net2.program.meta['tensors']['pool1']), pool)
+
+
 def test_fused_mobilenet_blocks_match_the_two_kernel_path():
     """dwpw_k (depthwise + pointwise in one launch) against dwconv3_k followed by the GEMM kernel: same f16
     rounding point between the two halves, so the head outputs agree to summation-order noise."""
