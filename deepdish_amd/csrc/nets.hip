@@ -1095,6 +1095,153 @@ __global__ __launch_bounds__(256, 2) void conv3x3_pool_rows_k(const ConvP P, con
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------
+// A whole residual unit of 3x3 32->32 layers on a 15-pixel-wide map as ONE launch, one wave per image streaming rows
+// (tools/freeze_model.py:43-75 for MARS conv2_1 / conv2_3):
+//     h1 = act(conv_A(pre) + bias_A)                         [conv3x3_rw_k<.., EF = 0>]
+//     out = conv_B(h1) + bias_B + raw,  out2 = ELU(scale * out + shift)   [conv3x3_rw_k<.., EF = 1>]
+// h1 lives only in a four-row LDS ring of the wave; both filters stay in registers (144 VGPRs).  Round r makes h1 rows
+// 2r, 2r+1 from pre rows 2r-1 .. 2r+2 and then output rows 2r-1, 2r from h1 rows 2r-2 .. 2r+1.  pre (and raw, when it is
+// a different tensor) rows arrive by global_load_lds one round ahead; the only wait is a vmcnt(0) just before the round's
+// stores, by which time the DMAs issued at its top have long landed and the previous round's stores have retired.
+// Row slot: four 8-channel planes of 16 pixel slots (1 KiB, the DMA's lane order); pixel slot 15 is always zero (the
+// DMA reads the zero line for it, the h1 epilogue writes zeros), so the right tap of pixel 14 and -- one slot earlier
+// in memory -- the left tap of pixel 0 of the next plane read the zero padding without a mask; a 16-byte zero pad in
+// front of each ring does the same for plane 0 of slot 0.  Lane 15 of a fragment computes a pixel that does not exist
+// and is never stored.  Every accumulator sums its taps in the order t = 0..8 from the bias and the epilogue is
+// conv_epilogue_f16x8 itself: the bits of the two-launch path.
+constexpr int RU_PRE_SLOTS = 8, RU_H1_SLOTS = 4, RU_RAW_SLOTS = 4, RU_SLOT = 512;     // halves
+constexpr int ru_wave_halves(bool raw_sep) { return 8 + RU_PRE_SLOTS * RU_SLOT + 8 + RU_H1_SLOTS * RU_SLOT + 8 + (raw_sep ? RU_RAW_SLOTS * RU_SLOT : 0) + 8; }
+
+template <int ACT_A, bool RAW_SEP>
+__global__ __launch_bounds__(256, 2) void res_unit_rows_k(const ConvP PA, const ConvP PB, const int n_img) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    _Float16 *wbase = lds + (size_t)wave * ru_wave_halves(RAW_SEP);
+    _Float16 *pre = wbase + 8, *h1 = pre + RU_PRE_SLOTS * RU_SLOT + 8, *rawr = h1 + RU_H1_SLOTS * RU_SLOT + 8;
+    const h8 zero8 = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+    // the whole region once: the pads, and the last pixel slot of rows no image has filled yet (an h1 row's left tap reads it)
+    for (int i = lane * 8; i < ru_wave_halves(RAW_SEP); i += 64 * 8) *reinterpret_cast<h8 *>(wbase + i) = zero8;
+
+    h8 wA[9][2], wB[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            wA[t][a] = *reinterpret_cast<const h8 *>(PA.w + (size_t)rw_weight_row(a, fr) * PA.kpad + t * 32 + fq * 8);
+            wB[t][a] = *reinterpret_cast<const h8 *>(PB.w + (size_t)rw_weight_row(a, fr) * PB.kpad + t * 32 + fq * 8);
+        }
+    const f4 bA0 = *reinterpret_cast<const f4 *>(PA.bias + fq * 8), bA1 = *reinterpret_cast<const f4 *>(PA.bias + fq * 8 + 4);
+    const Epi8 EB = epi8_load(PB, fq * 8);
+    const int H = PA.H, W = PA.W;                                 // W = 15
+    const int offC = (fq * 16 + fr) * 8;                          // centre tap; left = -8 halves, right = +8 halves
+    const int actA = ACT_A < 0 ? PA.act : ACT_A;
+
+    for (int n = blockIdx.x * 4 + wave; n < n_img; n += gridDim.x * 4) {
+        const _Float16 *img = PA.in + (size_t)n * H * W * PA.cs_in + PA.coff_in + fq * 8;
+        const _Float16 *rimg = PB.res + (size_t)n * H * W * PB.cs_res + PB.coff_res + fq * 8;
+        auto fill_pre = [&](int y) {                              // wave-uniform y; outside the image and pixel slot 15: zero line
+            const bool ok = (unsigned)y < (unsigned)H && fr < W;
+            lds_fill16(ok ? img + ((size_t)y * W + fr) * PA.cs_in : PA.zero, pre + ((y + 1) & (RU_PRE_SLOTS - 1)) * RU_SLOT);
+        };
+        auto fill_raw = [&](int y) {
+            const bool ok = (unsigned)y < (unsigned)H && fr < W;
+            lds_fill16(ok ? rimg + ((size_t)y * W + fr) * PB.cs_res : PA.zero, rawr + (y & (RU_RAW_SLOTS - 1)) * RU_SLOT);
+        };
+        fill_pre(-1); fill_pre(0); fill_pre(1); fill_pre(2);
+        if constexpr (RAW_SEP) { fill_raw(-1); fill_raw(0); }
+        *reinterpret_cast<h8 *>(h1 + ((-1) & (RU_H1_SLOTS - 1)) * RU_SLOT + lane * 8) = zero8;       // h1 row -1: padding
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        for (int r = 0; r <= H / 2; ++r) {                          // output rows 2r-1, 2r
+            fill_pre(2 * r + 3); fill_pre(2 * r + 4);
+            if constexpr (RAW_SEP) { fill_raw(2 * r + 1); fill_raw(2 * r + 2); }
+            // three fragments of input row `slot`: left / centre / right tap
+            auto conv2 = [&](const _Float16 *ringp, int slot0, int mask, const h8 (&w)[9][2], f4 (&acc)[2][2]) {
+                h8 X[2][3];
+                auto rd = [&](int i, h8 (&x)[3]) {
+                    const _Float16 *rs = ringp + ((slot0 + i) & mask) * RU_SLOT + offC;
+                    x[0] = *reinterpret_cast<const h8 *>(rs - 8);
+                    x[1] = *reinterpret_cast<const h8 *>(rs);
+                    x[2] = *reinterpret_cast<const h8 *>(rs + 8);
+                };
+                rd(0, X[0]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    h8 (&x)[3] = X[i & 1];
+#if defined(__HIP_DEVICE_COMPILE__)
+                    asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]));      // row i has arrived before row i+1 is requested
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
+                    if (i + 1 < 4) rd(i + 1, X[(i + 1) & 1]);
+#if defined(__HIP_DEVICE_COMPILE__)
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                        for (int cr = 0; cr < 2; ++cr) {
+                            const int dy = i - cr;
+                            if (dy < 0 || dy > 2) continue;
+#pragma unroll
+                            for (int a = 0; a < 2; ++a)
+                                acc[cr][a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[dy * 3 + dx][a], x[dx], acc[cr][a], 0, 0, 0);
+                        }
+#if defined(__HIP_DEVICE_COMPILE__)
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
+                }
+            };
+            // ---- layer A: h1 rows 2r, 2r+1 from pre rows 2r-1 .. 2r+2 (slots (y + 1) & 7)
+            {
+                f4 acc[2][2] = {{bA0, bA1}, {bA0, bA1}};
+                conv2(pre, 2 * r, RU_PRE_SLOTS - 1, wA, acc);
+#pragma unroll
+                for (int cr = 0; cr < 2; ++cr) {
+                    const int y = 2 * r + cr;
+                    const bool live = y < H && fr < W;             // past the image / pixel slot 15: layer B's zero padding
+                    h8 o;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        o[q] = (_Float16)apply_act(acc[cr][0][q], actA);
+                        o[4 + q] = (_Float16)apply_act(acc[cr][1][q], actA);
+                    }
+                    u4v_t ou = __builtin_bit_cast(u4v_t, o);
+                    ou &= live ? 0xFFFFFFFFu : 0u;
+                    *reinterpret_cast<u4v_t *>(h1 + (y & (RU_H1_SLOTS - 1)) * RU_SLOT + offC) = ou;
+                }
+            }
+            // ---- layer B: output rows 2r-1, 2r from h1 rows 2r-2 .. 2r+1 (slots y & 3)
+            {
+                f4 acc[2][2] = {{EB.b0, EB.b1}, {EB.b0, EB.b1}};
+                conv2(h1, 2 * r - 2, RU_H1_SLOTS - 1, wB, acc);
+                h8 rv[2];
+#pragma unroll
+                for (int cr = 0; cr < 2; ++cr) {
+                    const int y = 2 * r - 1 + cr;
+                    rv[cr] = RAW_SEP ? *reinterpret_cast<const h8 *>(rawr + (y & (RU_RAW_SLOTS - 1)) * RU_SLOT + offC)
+                                     : *reinterpret_cast<const h8 *>(pre + ((y + 1) & (RU_PRE_SLOTS - 1)) * RU_SLOT + offC);
+                }
+#if defined(__HIP_DEVICE_COMPILE__)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next round's rows have landed, last round's stores have retired
+#endif
+#pragma unroll
+                for (int cr = 0; cr < 2; ++cr) {
+                    const int y = 2 * r - 1 + cr;
+                    if ((unsigned)y >= (unsigned)H || fr >= W) continue;
+                    float o[8];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { o[q] = acc[cr][0][q]; o[4 + q] = acc[cr][1][q]; }
+                    conv_epilogue_f16x8<ACT_NONE, false, 1>(PB, EB, (n * H + y) * W + fr, fq * 8, o, &rv[cr]);
+                }
+            }
+        }
+    }
+}
+
 // First layer of a network straight from the u8 image: (x - mean) * scale, 3x3 conv over 3 channels
 // (K = 27, one MFMA k-slice padded to 32; tap dy*9 + dx*3 + ch, so one filter row of a pixel is nine
 // consecutive halves of the LDS patch; k slots as in stem_conv_pool_rows_k, which must produce the same bits), bias, activation -> NHWC f16 with 32 channels.  Replaces the
@@ -2104,6 +2251,37 @@ int launch_conv3x3_rw(hipStream_t s, ConvP &P, int nimg, bool pool, int device) 
     return DD_OK;
 }
 
+// Residual unit (layer A then layer B reading only A's output) as one launch of res_unit_rows_k?
+bool res_unit_fusable(const ConvP &A, const ConvP &B, int nimg) {
+    static const bool off = getenv("DD_RES_UNIT_UNFUSED") && atoi(getenv("DD_RES_UNIT_UNFUSED")) != 0;
+    // one wave per image: both layers of a unit take 56-60 us whatever the batch up to 2048 images; the two tiled launches
+    // take 34 / 52 / 58 / 77 us at 160 / 320 / 480 / 640 images (profiles/r02_res_unit_sweep.txt)
+    static const int min_img = getenv("DD_RES_UNIT_MIN") ? atoi(getenv("DD_RES_UNIT_MIN")) : 512;
+    auto plain = [](const ConvP &P) {
+        return P.kh == 3 && P.kw == 3 && P.stride == 1 && P.pad_t == 1 && P.pad_l == 1 && P.cin == 32 && P.cout == 32 && P.cout_pad == 32 &&
+               P.epi == EPI_F16 && P.W == 15 && P.wo == 15 && P.H == P.ho && P.splitk <= 1;
+    };
+    return !off && nimg >= min_img && plain(A) && plain(B) && A.act == ACT_ELU && !A.res && !A.out2 && !A.coff_out &&
+           B.act == ACT_NONE && B.res && B.out2 && B.in == static_cast<const _Float16 *>(A.out) && !B.coff_in && B.cs_in == A.cs_out && B.H == A.H;
+}
+
+int launch_res_unit(hipStream_t s, const ConvP &A, const ConvP &B, int nimg, int device) {
+    const bool raw_sep = !(B.res == A.in && B.cs_res == A.cs_in && B.coff_res == A.coff_in);
+    const size_t lds_bytes = (size_t)4 * ru_wave_halves(raw_sep) * sizeof(_Float16);
+    static DevOnce once;
+    const int rc = once.run(device, [&]() -> int {
+        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&res_unit_rows_k<ACT_ELU, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * ru_wave_halves(true) * sizeof(_Float16))));
+        return DD_OK;
+    });
+    if (rc != DD_OK) return rc;
+    const int grid = std::min(dd_ceil_div(nimg, 4), 2 * 256);
+    if (raw_sep) hipLaunchKernelGGL((res_unit_rows_k<ACT_ELU, true>), dim3((unsigned)grid), dim3(256), lds_bytes, s, A, B, nimg);
+    else hipLaunchKernelGGL((res_unit_rows_k<ACT_ELU, false>), dim3((unsigned)grid), dim3(256), lds_bytes, s, A, B, nimg);
+    DD_LAUNCH_CHECK();
+    return DD_OK;
+}
+
 int launch_stem(hipStream_t s, ConvP &P, int nimg) {
     spatial_tile(P.ho, P.wo, P.stride, 0, P);
     // 4-byte loads for the patch fill need 4-byte aligned image rows (300 x 300 and 64 x 32 frames: yes)
@@ -2391,6 +2569,8 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
     };
     ConvP stem_p;                                                 // a first layer waiting to be folded into the next op's launch
     bool stem_pending = false;
+    ConvP unit_a;                                                 // first 3x3 layer of a residual unit, likewise
+    bool unit_pending = false;
     for (int i = 0; i < net->n_ops; ++i) {
         if (net->profile) DD_HIP(hipEventRecord(net->events[i], s));
         const int32_t *o = net->prog.data() + net->ops_off + (size_t)i * OP_WORDS;
@@ -2398,6 +2578,11 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
         const int kind = o[0], src = o[1], dst = o[2], res = o[3], dst2 = o[4];
         const TensorDesc *ts = src >= 0 ? &net->tensors[src] : nullptr;
         const TensorDesc *td = dst >= 0 ? &net->tensors[dst] : nullptr;
+        if (unit_pending && kind != OP_CONV) {                        // (a program that sets the flag wrongly still computes the right thing)
+            unit_pending = false;
+            const int rc = launch_conv3x3_rw(s, unit_a, nimg, false, net->ctx->device);
+            if (rc != DD_OK) return rc;
+        }
         if (stem_pending && !(kind == OP_CONV && o[29])) {            // not followed by the layer it was meant for: run it on its own
             stem_pending = false;
             const int rc = launch_stem(s, stem_p, nimg);
@@ -2441,6 +2626,17 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
                 int rc;
                 DD_REQUIRE(!o[29] || (net->use_rw && P.kh == 3 && P.stride == 1 && P.cin == 32 && P.cout_pad == 32), DD_E_ARG,
                            "dd_net_forward: fused pooling is only built for the 3x3 32->32 kernel");
+                if (unit_pending) {                            // the previous op was a residual unit's first layer
+                    unit_pending = false;
+                    if (res_unit_fusable(unit_a, P, nimg)) {
+                        P.zero = net->d_zero;
+                        rc = launch_res_unit(s, unit_a, P, nimg, net->ctx->device);
+                        if (rc != DD_OK) return rc;
+                        break;
+                    }
+                    rc = launch_conv3x3_rw(s, unit_a, nimg, false, net->ctx->device);
+                    if (rc != DD_OK) return rc;
+                }
                 const bool bk32 = o[28] == 32;                 // shallow K (<= 96): one or few 32-wide steps
                 const bool glds = !bk32 && net->use_glds;          // K >= 97: direct-to-LDS fills, any Cin % 8 == 0
                 P.zero = net->d_zero;
@@ -2457,6 +2653,10 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
                             rc = launch_stem(s, stem_p, nimg);
                             if (rc != DD_OK) return rc;
                         }
+                    }
+                    if (o[30] && !o[29] && i + 1 < net->n_ops && nimg >= 160 && !P.res && !P.out2) {
+                        unit_a = P; unit_pending = true;       // o[30]: only the next op reads this layer's output
+                        break;
                     }
                     rc = launch_conv3x3_rw(s, P, nimg, o[29] != 0, net->ctx->device);
                 } else if (ws_eligible(P)) {

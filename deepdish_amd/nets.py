@@ -44,6 +44,7 @@ def same_pad(size, k, stride):
 
 class Program:
     STEM_POOL_FUSE = os.environ.get('DD_STEM_POOL_FUSE', '1') != '0'   # MARS conv1_1 folded into conv1_2's launch
+    RES_UNIT_FUSE = os.environ.get('DD_RES_UNIT_FUSE', '1') != '0'     # MARS conv2_x: both 3x3 layers of a residual unit in one launch
 
     def __init__(self, in_h, in_w):
         self.in_h, self.in_w = in_h, in_w
@@ -352,6 +353,8 @@ def compile_mars(wd, in_h=64, in_w=32):
         stride = 2 if inc else 1
         w, b = fold_conv_bn(wd, name + '/1')
         h1 = P.conv(pre, w, b, stride=stride, act=ACT_ELU)                      # :58-62
+        if Program.RES_UNIT_FUSE and not inc and c == 32:
+            P.ops[-1][30] = 1        # h1 is read by conv "2" only: both layers of the unit run as one launch (res_unit_rows_k)
         if inc:
             skip = P.conv(raw, wd[name + '/projection/weights'], np.zeros(c, np.float32), stride=2)   # :30-36
         else:
