@@ -1362,6 +1362,160 @@ __global__ __launch_bounds__(256) void stem_conv3_k(const ConvP P) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// First layer + first MobileNet block of the SSD in ONE launch, rows streamed by single waves (no workgroup barrier):
+//     u8 frame -> 3x3 stride-2 conv (3 -> 32) + act -> depthwise 3x3 + act -> pointwise 32 -> 64 + act -> f16 NHWC.
+// The 150x150x32 tensor between the two layers (1.44 MB per frame written and read back) and the depthwise output
+// stay in the wave's LDS.  A wave owns a strip of SF_SW = 30 output columns and a range of rows of one frame:
+//   * frame rows arrive two per step as aligned dwords (one per lane), are normalised to f16 into an 8-row ring;
+//   * the stem row y+1 (32 columns: the strip + one halo column each side; columns outside the map are the depthwise
+//     layer's zero padding) is computed with stem_conv3_k's arithmetic (same k slots, MFMA onto the bias) into a
+//     4-row ring of [channel group][pixel] x 16 B;
+//   * the depthwise row y is computed as dwpw_k does it (bias, then taps kh-major with v_fma_mix), one (pixel pair,
+//     channel group) per lane, into a 32-pixel MFMA operand tile; the pointwise layer is one k slice: 8 MFMAs per row.
+// Same summation orders and the same epilogue function as stem_conv3_k + dwpw_k: the same bits.
+constexpr int SF_SW = 30, SF_CROP_PITCH = 208, SF_CROP_SLOTS = 8, SF_STEM_SLOTS = 4, SF_ROW = 32 * 32;
+constexpr int sf_wave_halves() { return SF_CROP_SLOTS * SF_CROP_PITCH + SF_STEM_SLOTS * SF_ROW + SF_ROW + 64; }
+
+template <int ACT>                                              // all three activations (launcher: ReLU6)
+__global__ __launch_bounds__(256, 2) void ssd_front_k(const ConvP PS, const ConvP P, const int n_tasks, const int parts) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    _Float16 *crop = lds + (size_t)wave * sf_wave_halves();
+    _Float16 *stemr = crop + SF_CROP_SLOTS * SF_CROP_PITCH, *xt = stemr + SF_STEM_SLOTS * SF_ROW;
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    const h8 zero8 = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+    for (int i = lane * 8; i < sf_wave_halves(); i += 64 * 8) *reinterpret_cast<h8 *>(crop + i) = zero8;
+
+    h8 ws[2], wd[9], wp[4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) ws[a] = *reinterpret_cast<const h8 *>(PS.w + rw_weight_row(a, fr) * 32 + fq * 8);
+    const f4 sb0 = *reinterpret_cast<const f4 *>(PS.bias + fq * 8), sb1 = *reinterpret_cast<const f4 *>(PS.bias + fq * 8 + 4);
+    const int cg = fq, pp = fr;                                  // depthwise item of this lane: channel group, pixel pair
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wd[t] = *reinterpret_cast<const h8 *>(P.dw_w + (size_t)t * 32 + cg * 8);
+    const f4 db0 = *reinterpret_cast<const f4 *>(P.dw_bias + cg * 8), db1 = *reinterpret_cast<const f4 *>(P.dw_bias + cg * 8 + 4);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) wp[a] = *reinterpret_cast<const h8 *>(P.w + (size_t)rw_weight_row(a, fr) * P.kpad + fq * 8);
+    Epi8 E[2];
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2) E[g2] = epi8_load(P, g2 * 32 + fq * 8);
+
+    const int Hin = PS.H, Win3 = PS.W * 3, Ho = P.ho, Wo = P.wo;
+    const int strips = (Wo + SF_SW - 1) / SF_SW;
+    for (int task = blockIdx.x * 4 + wave; task < n_tasks; task += gridDim.x * 4) {
+        const int part = task % parts, t2 = task / parts;
+        const int strip = t2 % strips, n = t2 / strips;
+        const int x0 = strip * SF_SW, y0 = part * Ho / parts, y1 = (part + 1) * Ho / parts;
+        // frame bytes of the strip's rows: from column 2 (x0 - 1) - pad_l, 66 columns; aligned dwords from a0
+        const int b0 = (2 * (x0 - 1) - PS.pad_l) * 3, a0 = b0 & ~3, shift = b0 - a0;
+        const uint8_t *img8 = PS.src8 + (size_t)n * Hin * Win3;
+        const int bx = a0 + 4 * lane;                             // this lane's dword in a frame row
+        const bool bx_ok = lane < SF_CROP_PITCH / 4 && bx >= 0 && bx < Win3;
+        auto load_row = [&](int r) -> unsigned {                  // a select between addresses, not values
+            const bool ok = bx_ok && (unsigned)r < (unsigned)Hin;
+            return *reinterpret_cast<const unsigned *>(ok ? img8 + (size_t)r * Win3 + bx : reinterpret_cast<const uint8_t *>(PS.zero));
+        };
+        auto put_row = [&](int r, unsigned raw) {                 // zero padding is applied after normalisation
+            const bool ok = bx_ok && (unsigned)r < (unsigned)Hin;
+            h4 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = (_Float16)(ok ? ((float)((raw >> (8 * q)) & 255u) - PS.in_mean) * PS.in_scale : 0.f);
+            if (lane < SF_CROP_PITCH / 4) *reinterpret_cast<h4 *>(crop + (r & (SF_CROP_SLOTS - 1)) * SF_CROP_PITCH + 4 * lane) = o;
+        };
+        auto stem_row = [&](int ys) {                             // stem row ys of the strip (32 columns) -> ring slot ys & 3
+            _Float16 *dst = stemr + (ys & (SF_STEM_SLOTS - 1)) * SF_ROW;
+            if ((unsigned)ys >= (unsigned)Ho) {                   // the depthwise layer's zero padding
+                *reinterpret_cast<h8 *>(dst + lane * 8) = zero8;
+                *reinterpret_cast<h8 *>(dst + 512 + lane * 8) = zero8;
+                return;
+            }
+            const int r0 = 2 * ys - PS.pad_t;                     // frame row of filter row 0
+            const int cx = shift + 6 * fr;
+            const int L0 = (r0 & (SF_CROP_SLOTS - 1)) * SF_CROP_PITCH + cx, L1 = ((r0 + 1) & (SF_CROP_SLOTS - 1)) * SF_CROP_PITCH + cx,
+                      L2 = ((r0 + 2) & (SF_CROP_SLOTS - 1)) * SF_CROP_PITCH + cx;
+            const int Pb = fq == 0 ? L0 : fq == 1 ? L1 : L2;
+            const int A0 = fq == 3 ? L0 + 8 : Pb, A1 = fq == 3 ? L1 + 7 : Pb, A2 = fq == 3 ? L2 + 6 : Pb;
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                h8 xf;
+                xf[0] = crop[A0 + 96 * f]; xf[1] = crop[A1 + 1 + 96 * f]; xf[2] = crop[A2 + 2 + 96 * f];
+#pragma unroll
+                for (int j = 3; j < 8; ++j) xf[j] = crop[Pb + j + 96 * f];
+                const f4 c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ws[0], xf, sb0, 0, 0, 0);
+                const f4 c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ws[1], xf, sb1, 0, 0, 0);
+                const int xs = x0 - 1 + 16 * f + fr;
+                h8 o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { o[q] = (_Float16)apply_act(c0[q], ACT); o[4 + q] = (_Float16)apply_act(c1[q], ACT); }
+                u4v_t ou = __builtin_bit_cast(u4v_t, o);
+                ou &= (unsigned)xs < (unsigned)Wo ? 0xFFFFFFFFu : 0u;   // columns outside the map: zero padding
+                *reinterpret_cast<u4v_t *>(dst + (fq * 32 + 16 * f + fr) * 8) = ou;
+            }
+        };
+        // rows for stem rows y0-1 and y0, then the two rows step y0 will add
+        const int rp = 2 * (y0 - 1) - PS.pad_t;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) put_row(rp + i, load_row(rp + i));
+        unsigned raw0 = load_row(rp + 5), raw1 = load_row(rp + 6);
+        stem_row(y0 - 1); stem_row(y0);
+        for (int y = y0; y < y1; ++y) {
+            const int rn = 2 * (y + 1) - PS.pad_t;                // stem row y+1: frame rows rn (already there), rn+1, rn+2
+            put_row(rn + 1, raw0); put_row(rn + 2, raw1);
+            raw0 = load_row(rn + 3); raw1 = load_row(rn + 4);
+            stem_row(y + 1);
+            // ---- depthwise row y: output pixels 2pp, 2pp+1 of the strip = stem columns 2pp .. 2pp+3 of rows y-1 .. y+1
+            {
+                h8 x[3][4];
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        x[kh][c] = *reinterpret_cast<const h8 *>(stemr + ((y - 1 + kh) & (SF_STEM_SLOTS - 1)) * SF_ROW + (cg * 32 + 2 * pp + c) * 8);
+                float acc[2][8];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { acc[j][i] = db0[i]; acc[j][4 + i] = db1[i]; }
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) dw_tap(acc[j], x[kh][j + kw], wd[kh * 3 + kw]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    h8 o;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) o[i] = (_Float16)apply_act(acc[j][i], ACT);
+                    *reinterpret_cast<h8 *>(xt + (cg * 32 + 2 * pp + j) * 8) = o;
+                }
+            }
+            // ---- pointwise row y: [32 pixels] x [64 channels] x 32
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                const h8 xf = *reinterpret_cast<const h8 *>(xt + (fq * 32 + 16 * f + fr) * 8);
+                f4 acc[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wp[a], xf, (a & 1) ? E[a >> 1].b1 : E[a >> 1].b0, 0, 0, 0);
+                const int px = 16 * f + fr;
+                if (px < SF_SW && x0 + px < Wo) {
+                    const int m = (n * Ho + y) * Wo + x0 + px;
+#pragma unroll
+                    for (int g2 = 0; g2 < 2; ++g2) {
+                        float o[8];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { o[q] = acc[2 * g2][q]; o[4 + q] = acc[2 * g2 + 1][q]; }
+                        conv_epilogue_f16x8<ACT, false, 0, false>(P, E[g2], m, g2 * 32 + fq * 8, o);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // MobileNet block in one launch: depthwise 3x3 (+bias, activation) -> pointwise 1x1 (+bias, activation).
 // The depthwise result of a pixel tile never leaves the CU: it is rounded to f16 (exactly what the
 // two-kernel path stores) into the LDS image the MFMA fragments are read from, so the layer pair
@@ -2282,6 +2436,36 @@ int launch_res_unit(hipStream_t s, const ConvP &A, const ConvP &B, int nimg, int
     return DD_OK;
 }
 
+// First layer (S) + first MobileNet block (P, reading only S's output) as one launch of ssd_front_k?
+bool ssd_front_fusable(const ConvP &S, const ConvP &P, int nimg) {
+    static const bool off = getenv("DD_SSD_FRONT_UNFUSED") && atoi(getenv("DD_SSD_FRONT_UNFUSED")) != 0;
+    // whole forward at 8 / 16 / 32 / 48 / 96 / 192 frames: fused 305 / 366 / 507 / 627 / 969 / 1662 us, two launches 293 / 376 / 515 / 652 / 1024 / 1740 us
+    static const int min_img = getenv("DD_SSD_FRONT_MIN") ? atoi(getenv("DD_SSD_FRONT_MIN")) : 16;
+    return !off && nimg >= min_img && S.stride == 2 && S.cout == 32 && S.cout_pad == 32 && S.act == ACT_RELU6 && (S.W * 3) % 4 == 0 &&
+           (reinterpret_cast<uintptr_t>(S.src8) & 3) == 0 && S.pad_t >= 0 && S.pad_l >= 0 && S.pad_t <= 1 && S.pad_l <= 1 &&
+           P.cin == 32 && P.cout == 64 && P.cout_pad == 64 && P.kpad == 32 && P.stride == 1 && P.pad_t == 1 && P.pad_l == 1 &&
+           P.act == ACT_RELU6 && P.dw_act == ACT_RELU6 && P.in == static_cast<const _Float16 *>(S.out) && !P.coff_in && P.cs_in == 32 &&
+           P.H == S.ho && P.W == S.wo && P.ho == P.H && P.wo == P.W && !P.res && !P.out2;
+}
+
+int launch_ssd_front(hipStream_t s, const ConvP &S, const ConvP &P, int nimg, int device) {
+    const size_t lds_bytes = (size_t)4 * sf_wave_halves() * sizeof(_Float16);
+    static DevOnce once;
+    const int rc = once.run(device, [&]() -> int {
+        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ssd_front_k<ACT_RELU6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        return DD_OK;
+    });
+    if (rc != DD_OK) return rc;
+    const int strips = dd_ceil_div(P.wo, SF_SW);
+    static const int force_parts = getenv("DD_SSD_FRONT_PARTS") ? atoi(getenv("DD_SSD_FRONT_PARTS")) : 0;
+    const int parts = force_parts > 0 ? force_parts : std::max(1, std::min(8, 2048 / (nimg * strips)));   // 2048 wave slots at two per SIMD
+    const int n_tasks = nimg * strips * parts;
+    const int grid = std::min(dd_ceil_div(n_tasks, 4), 2 * 256);
+    hipLaunchKernelGGL((ssd_front_k<ACT_RELU6>), dim3((unsigned)grid), dim3(256), lds_bytes, s, S, P, n_tasks, parts);
+    DD_LAUNCH_CHECK();
+    return DD_OK;
+}
+
 int launch_stem(hipStream_t s, ConvP &P, int nimg) {
     spatial_tile(P.ho, P.wo, P.stride, 0, P);
     // 4-byte loads for the patch fill need 4-byte aligned image rows (300 x 300 and 64 x 32 frames: yes)
@@ -2583,7 +2767,7 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
             const int rc = launch_conv3x3_rw(s, unit_a, nimg, false, net->ctx->device);
             if (rc != DD_OK) return rc;
         }
-        if (stem_pending && !(kind == OP_CONV && o[29])) {            // not followed by the layer it was meant for: run it on its own
+        if (stem_pending && !(kind == OP_CONV && o[29]) && kind != OP_DWPW) {   // not followed by the layer it was meant for: run it on its own
             stem_pending = false;
             const int rc = launch_stem(s, stem_p, nimg);
             if (rc != DD_OK) return rc;
@@ -2714,6 +2898,10 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
                     stem_p = P; stem_pending = true;
                     break;
                 }
+                if (o[30] && i + 1 < net->n_ops && P.stride == 2) {       // followed by the first MobileNet block (ssd_front_k)
+                    stem_p = P; stem_p.zero = net->d_zero; stem_pending = true;
+                    break;
+                }
                 int rc = launch_stem(s, P, nimg);
                 if (rc != DD_OK) return rc;
                 break;
@@ -2734,6 +2922,16 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
                 P.total_quads = nimg * P.ho * ((P.wo + 3) / 4);
                 P.out = base(dst); P.cs_out = td->cs; P.coff_out = td->coff;
                 int rc;
+                if (stem_pending) {
+                    stem_pending = false;
+                    if (ssd_front_fusable(stem_p, P, nimg)) {
+                        rc = launch_ssd_front(s, stem_p, P, nimg, net->ctx->device);
+                        if (rc != DD_OK) return rc;
+                        break;
+                    }
+                    rc = launch_stem(s, stem_p, nimg);
+                    if (rc != DD_OK) return rc;
+                }
                 if (P.cin == 32 && P.cout_pad == 64 && P.stride == 1) rc = launch_dwpw<4, 1, 4, 32, 1>(s, P, net->ctx->device);
                 else if (P.cin == 64 && P.cout_pad == 128 && P.stride == 2) rc = launch_dwpw<2, 2, 4, 64, 2>(s, P, net->ctx->device);
                 else if (P.cin == 128 && P.cout_pad == 128 && P.stride == 1) rc = launch_dwpw<2, 2, 2, 128, 1>(s, P, net->ctx->device);

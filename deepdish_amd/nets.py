@@ -45,6 +45,7 @@ def same_pad(size, k, stride):
 class Program:
     STEM_POOL_FUSE = os.environ.get('DD_STEM_POOL_FUSE', '1') != '0'   # MARS conv1_1 folded into conv1_2's launch
     RES_UNIT_FUSE = os.environ.get('DD_RES_UNIT_FUSE', '1') != '0'     # MARS conv2_x: both 3x3 layers of a residual unit in one launch
+    SSD_FRONT_FUSE = os.environ.get('DD_SSD_FRONT_FUSE', '1') != '0'   # SSD conv0 + MobileNet block 1 in one launch
 
     def __init__(self, in_h, in_w):
         self.in_h, self.in_w = in_h, in_w
@@ -460,6 +461,8 @@ def compile_ssd_mobilenet(wd, in_size=300):
         s, t = bn_affine(wd, f'dw{i}/bn')
         w, b = fold_conv_bn(wd, f'pw{i}')
         x = P.dwpw(x, wd[f'dw{i}/weights'][:, :, :, 0] * s, t, st, ACT_RELU6, w, b, ACT_RELU6)
+        if i == 1 and Program.SSD_FRONT_FUSE and P.ops[-1][0] == OP_DWPW and P.ops[-2][0] == OP_STEM:
+            P.ops[-2][30] = 1        # conv0 is read by block 1 only: one launch (csrc/nets.hip ssd_front_k), conv0's tensor is not written
         if i in (11, 13):
             feats.append(x)
     for j in range(1, 5):

@@ -72,6 +72,35 @@ def test_mars_first_layers_give_the_same_bits_in_every_launch_shape(n):
     np.testing.assert_array_equal(net2.read(tensor=net2.program.meta['tensors']['pool1']), pool)
 
 
+@pytest.mark.parametrize('n', [15, 16, 100])
+def test_ssd_first_layers_give_the_same_bits_fused_and_separate(n):
+    """conv0 + MobileNet block 1: from 16 frames one launch (ssd_front_k: strips of 30 columns streamed by single waves,
+    neither the conv0 tensor nor the depthwise output leaves the CU), below that stem_conv3_k + dwpw_k; a program compiled
+    without the flag always runs the two launches.  Same bits, and a frame's result does not depend on its batch."""
+    from deepdish_amd import nets
+    from deepdish_amd.engine import Net
+    wd = nets.synthetic_ssd_weights(1234)
+    rng = np.random.default_rng(n)
+    x = rng.integers(0, 256, (n, 300, 300, 3), dtype=np.uint8)
+    x[1] = 0; x[2] = 255
+    net = Net(nets.compile_ssd_mobilenet(wd), max_batch=n)
+    assert net.program.ops[0][30] == 1
+    net.forward(x)
+    full = net.read().copy()
+    for i in (0, 1, 2, n - 1):
+        net.forward(x[i:i + 1])
+        np.testing.assert_array_equal(net.read()[0], full[i])
+    old = nets.Program.SSD_FRONT_FUSE
+    try:
+        nets.Program.SSD_FRONT_FUSE = False
+        net2 = Net(nets.compile_ssd_mobilenet(wd), max_batch=n)
+    finally:
+        nets.Program.SSD_FRONT_FUSE = old
+    assert net2.program.ops[0][30] == 0
+    net2.forward(x)
+    np.testing.assert_array_equal(net2.read(), full)
+
+
 def test_fused_mobilenet_blocks_match_the_two_kernel_path():
     """dwpw_k (depthwise + pointwise in one launch) against dwconv3_k followed by the GEMM kernel: same f16
     rounding point between the two halves, so the head outputs agree to summation-order noise."""
