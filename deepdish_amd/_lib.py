@@ -77,6 +77,7 @@ SIGNATURES = {
     'dd_net_read': [P, c_int, c_int, P, c_int, P],
     'dd_net_profile': [P, c_int],
     'dd_net_profile_read': [P, P, c_int, POINTER(c_int)],
+    'dd_net_op_launches': [P, P, c_int, POINTER(c_int)],
     'dd_ssd_postprocess': [P, P, P, c_int, c_int, c_int, c_float, c_float, P, P, P, P, P],
     'dd_ssd_detections': [P, P, P, P, c_int, c_int, c_double, c_double, c_double, c_double, P, P, P, P, P],
     'dd_yolov5_decode': [P, P, c_int, c_int, c_float, c_float, c_float, P, P, P, c_int, P, P],

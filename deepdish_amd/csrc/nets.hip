@@ -27,6 +27,8 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 enum { OP_INPUT = 1, OP_CONV = 2, OP_DWCONV = 3, OP_MAXPOOL = 4, OP_UPSAMPLE = 5, OP_FC = 6, OP_L2NORM = 7, OP_STEM = 8, OP_DWPW = 9 };
 enum { ACT_NONE = 0, ACT_RELU6 = 1, ACT_ELU = 2, ACT_SILU = 3, ACT_RELU = 4, ACT_SIGMOID = 5 };
 enum { EPI_F16 = 0, EPI_F32 = 1, EPI_SSD_HEAD = 2, EPI_YOLO = 3 };
+// dd_net_op_launches: 0 = the op's own kernel, 1 = no launch (folded into the next op's), else the fused / special kernel
+enum { OPK_DEFAULT = 0, OPK_FOLDED = 1, OPK_POOL_ROWS = 2, OPK_POOL_ROWS_STEM = 3, OPK_RES_UNIT = 4, OPK_SSD_FRONT = 5, OPK_C64_ROWS = 6 };
 enum { DT_F16 = 0, DT_F32 = 1, DT_U8 = 2 };
 
 constexpr int OP_WORDS = 48;       // int32 words per op record (see deepdish_amd/nets.py)
@@ -1242,6 +1244,150 @@ __global__ __launch_bounds__(256, 2) void res_unit_rows_k(const ConvP PA, const 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// 3x3 64->64 convolution (same padding, stride 1) on 8-pixel-wide maps (MARS conv3_x, 16x8), weight-stationary: a wave
+// owns 32 output channels of one image and keeps their whole filter in registers (9 taps x 2 k slices x 2 fragments =
+// 144 VGPRs); the image streams through the wave's own ring of row slots, filled by global_load_lds one round ahead.
+// A pixel fragment is two map rows (16 pixels).  Row slot: eight 8-channel planes of ten pixel slots (zero, 8 pixels,
+// zero -- the DMA reads the zero line for the two pad slots, so no tap needs a mask), pitch 1408 B: consecutive rows
+// sit 128 B apart modulo the 256-B bank row, so the two halves of a fragment read never meet on a bank.
+// conv_glds_k's summation order (zero, taps in order, two k slices per tap, bias in the epilogue) and its epilogue
+// call: the same bits as the generic kernel, which runs these layers at 370-540 TFLOP/s (one barrier per 8 MFMAs).
+// The rows of a wave's images form ONE stream (a zero row between images serves as the lower padding of one and the
+// upper padding of the next): stream row g sits in ring slot g % 11 and the DMAs run three rounds (6-7 rows) ahead of
+// the MFMAs, across image boundaries -- a round is ~1k cycles, a DMA under load takes several times that.  Nothing in
+// the loop but DMAs and stores touches vmcnt (the residual rows come by DMA too; an ordinary load would make hipcc drain
+// the queue at its first use), so the wait is counted: everything younger than the issue group of three rounds ago,
+// i.e. 3 x (4 row DMAs [+ 1 residual DMA]) + 3 x (1 [+ 1] stores); a round that issues a fifth and sixth row DMA (first
+// round of an image) only makes the wait stricter.
+constexpr int C64_PITCH = 704, C64_SLOTS = 11, C64_RES_SLOTS = 4, C64_LEAD = 3;   // 11: 4 rows being read + up to 7 requested (a group that crosses an image boundary)
+constexpr int c64_wave_halves() { return C64_SLOTS * C64_PITCH + C64_RES_SLOTS * 512; }
+
+template <int ACT, int EF>                                      // EF 0: plain layer; 1: residual input and second output
+__global__ __launch_bounds__(256, 2) void conv3x3_c64_rows_k(const ConvP P, const int n_img) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int j = fr >> 3, x = fr & 7;                            // fragment pixel: row j of the pair, column x
+    _Float16 *ring = lds + (size_t)wave * c64_wave_halves(), *resr = ring + C64_SLOTS * C64_PITCH;
+    const int H = P.H, S = H + 1, RPI = H / 2;                    // stream rows / rounds per image
+
+    const int half = wave & 1;                                    // a wave keeps its channel half for the whole launch: one filter load
+    h8 wf[9][2][2];                                               // [tap][k slice][fragment]
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+                wf[t][ks][a] = *reinterpret_cast<const h8 *>(P.w + (size_t)(half * 32 + rw_weight_row(a, fr)) * P.kpad + t * 64 + ks * 32 + fq * 8);
+    const Epi8 E = epi8_load(P, half * 32 + fq * 8);
+    const int lane_off = (fq * 10 + x) * 8;                       // plane fq of k slice 0, pixel slot x (= column x - 1)
+    const int n0 = blockIdx.x * 2 + (wave >> 1), nstep = gridDim.x * 2;
+    const int K = n0 < n_img ? (n_img - n0 + nstep - 1) / nstep : 0;      // images of this wave: n0 + k * nstep
+    const int T = K * S + 1, Q = K * RPI;                         // stream rows, rounds
+
+    // per-lane constants of the two row DMAs (chunk c = 16 * c2 + lane -> plane c / 10, pixel slot c % 10)
+    int dma_off[2];
+    bool dma_px[2];
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2) {
+        const int c = 16 * c2 + lane, pl = c / 10, sl = c - pl * 10;
+        dma_px[c2] = sl >= 1 && sl <= 8;
+        dma_off[c2] = (sl - 1) * P.cs_in + pl * 8;
+    }
+    int dq = 0, dq_slot = 0, dq_k = 0, dq_y = -1;                 // next stream row to request: its ring slot, image, map row
+    auto issue_row = [&]() {                                      // past the stream / between images: zero lines
+        const bool rok = dq < T && dq_y >= 0;
+        const _Float16 *row = P.in + ((size_t)(n0 + dq_k * nstep) * H + (rok ? dq_y : 0)) * 8 * P.cs_in + P.coff_in;
+        _Float16 *dst = ring + dq_slot * C64_PITCH;
+        // two full-wave DMAs: chunks 0..63 and 16..79 (48 chunks twice, with the same bytes).  A DMA under a divergent
+        // `if (lane < 16)` is not safe: hipcc threads consecutive such branches and the copies of the wave-wide DMA
+        // between them then take M0 from readfirstlane of a per-path value -- one path's lanes land in another row.
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) lds_fill16(rok && dma_px[c2] ? row + dma_off[c2] : P.zero, dst + 128 * c2);
+        ++dq;
+        dq_slot = dq_slot + 1 == C64_SLOTS ? 0 : dq_slot + 1;
+        if (++dq_y == H) { dq_y = -1; ++dq_k; }
+    };
+    int ga_k = 0, ga_r = 0;                                       // round q + LEAD: image, round inside the image
+    const int res_px = lane & 15, res_c = lane >> 4;
+    auto issue_group = [&](int qa) {                              // what round qa = q + LEAD needs: rows up to its last, its residual rows
+        const int last = ga_k * S + 2 * ga_r + 3;
+        while (dq <= last) issue_row();                           // 2 rows, 3 when round qa opens an image (first group: 4)
+        if constexpr (EF == 1) {                                  // residual rows 2 ga_r, 2 ga_r + 1 of image ga_k: [chunk fq][pixel] x 16 B
+            const bool ok = qa < Q;
+            const _Float16 *src = P.res + ((size_t)((n0 + ga_k * nstep) * H + 2 * ga_r) * 8 + res_px) * P.cs_res + P.coff_res + half * 32 + res_c * 8;
+            lds_fill16(ok ? src : P.zero, resr + (qa & (C64_RES_SLOTS - 1)) * 512);
+        }
+        if (++ga_r == RPI) { ga_r = 0; ++ga_k; }
+    };
+    for (int qa = 0; qa < C64_LEAD; ++qa) issue_group(qa);
+    int k = 0, r = 0, bslot = 0;                                  // this round: image, round inside it, ring slot of its first row (map row 2r - 1)
+    for (int q = 0; q < Q; ++q) {
+        issue_group(q + C64_LEAD);
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (q < C64_LEAD) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(C64_LEAD * (4 + EF)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(C64_LEAD * (4 + EF) + C64_LEAD * (1 + EF)) : "memory");
+#endif
+        const int m = ((n0 + k * nstep) * H + 2 * r + j) * 8 + x; // this lane's output pixel
+        f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+        const _Float16 *rowp[3];                                   // this lane's row of filter row dy: stream row first + dy + j
+        {
+            int sl = bslot;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int s1 = sl + 1 == C64_SLOTS ? 0 : sl + 1;
+                rowp[dy] = ring + (j ? s1 : sl) * C64_PITCH + lane_off;
+                sl = s1;
+            }
+        }
+        // (reads two taps ahead, as inline-asm ds_read with hand-counted lgkmcnt, changed nothing: 50.8 vs 51.6 us -- the round
+        // is bound by what it issues besides its 36 MFMAs: 4 DMAs at 100+ cycles each, the epilogue, the stores)
+        h8 X[2][2];
+        auto rd = [&](int t, h8 (&xv)[2]) {                       // tap t: pixel slot x + dx of that row, both k slices
+            const int dy = t / 3, dx = t - dy * 3;
+            xv[0] = *reinterpret_cast<const h8 *>(rowp[dy] + dx * 8);
+            xv[1] = *reinterpret_cast<const h8 *>(rowp[dy] + dx * 8 + 4 * 10 * 8);
+        };
+        rd(0, X[0]);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            h8 (&xv)[2] = X[t & 1];
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" : "+v"(xv[0]), "+v"(xv[1]));          // tap t has arrived before tap t+1 is requested
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            if (t + 1 < 9) rd(t + 1, X[(t + 1) & 1]);
+#if defined(__HIP_DEVICE_COMPILE__)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+                    acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[t][ks][a], xv[ks], acc[a], 0, 0, 0);
+#if defined(__HIP_DEVICE_COMPILE__)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+        h8 rp;
+        if constexpr (EF == 1) rp = *reinterpret_cast<const h8 *>(resr + (q & (C64_RES_SLOTS - 1)) * 512 + (fq * 16 + fr) * 8);
+        float o[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { o[i] = acc[0][i]; o[4 + i] = acc[1][i]; }
+        conv_epilogue_f16x8<ACT, true, EF>(P, E, m, half * 32 + fq * 8, o, EF == 1 ? &rp : nullptr);
+        // next round: two rows on, three across an image boundary
+        const int adv = r + 1 == RPI ? 3 : 2;
+        bslot += adv; if (bslot >= C64_SLOTS) bslot -= C64_SLOTS;
+        if (++r == RPI) { r = 0; ++k; }
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the look-ahead DMAs past the last round
+#endif
+}
+
 // First layer of a network straight from the u8 image: (x - mean) * scale, 3x3 conv over 3 channels
 // (K = 27, one MFMA k-slice padded to 32; tap dy*9 + dx*3 + ch, so one filter row of a pixel is nine
 // consecutive halves of the LDS patch; k slots as in stem_conv_pool_rows_k, which must produce the same bits), bias, activation -> NHWC f16 with 32 channels.  Replaces the
@@ -2231,6 +2377,7 @@ struct dd_net {
     bool use_rw = true;                      // DD_NO_RW=1: 3x3x32x32 layers fall back to the implicit-GEMM kernels (A/B measurements)
     int tile_mode = 0;                       // DD_TILE_MODE=1 forces the 64 x 64 tile everywhere (A/B measurements)
     std::vector<hipEvent_t> events;           // n_ops + 1 when profiling
+    std::vector<int32_t> op_launch;           // per op of the last forward: DD_OPK_* (which launch ran it)
     // Latency mode (dd_net_use_graph): the launch train of one forward -- 20 to 75 short kernels at batch 1 -- captured
     // once per (input pointer, batch) and replayed as one hipGraph launch; the first call of a key runs eagerly (it may
     // still allocate split-K slabs and set function attributes), the second captures.
@@ -2432,6 +2579,31 @@ int launch_res_unit(hipStream_t s, const ConvP &A, const ConvP &B, int nimg, int
     const int grid = std::min(dd_ceil_div(nimg, 4), 2 * 256);
     if (raw_sep) hipLaunchKernelGGL((res_unit_rows_k<ACT_ELU, true>), dim3((unsigned)grid), dim3(256), lds_bytes, s, A, B, nimg);
     else hipLaunchKernelGGL((res_unit_rows_k<ACT_ELU, false>), dim3((unsigned)grid), dim3(256), lds_bytes, s, A, B, nimg);
+    DD_LAUNCH_CHECK();
+    return DD_OK;
+}
+
+bool c64_rows_eligible(const ConvP &P, int nimg, int max_batch) {
+    static const bool off = getenv("DD_C64_ROWS_OFF") && atoi(getenv("DD_C64_ROWS_OFF")) != 0;
+    static const int min_img = getenv("DD_C64_ROWS_MIN") ? atoi(getenv("DD_C64_ROWS_MIN")) : 512;
+    return !off && nimg >= min_img && P.kh == 3 && P.kw == 3 && P.stride == 1 && P.pad_t == 1 && P.pad_l == 1 && P.cin == 64 && P.cout == 64 &&
+           P.cout_pad == 64 && P.kpad == 576 && P.epi == EPI_F16 && P.W == 8 && P.wo == 8 && P.H == P.ho && P.H % 2 == 0 && P.splitk <= 1 &&
+           ((P.act == ACT_ELU && !P.res && !P.out2) || (P.act == ACT_NONE && P.res && P.out2 && P.cs_res % 8 == 0 && P.coff_res % 8 == 0)) &&
+           (long long)dd_ceil_div(max_batch * P.ho * P.wo, 64) >= 256;    // launch_conv would not split K for this engine: same summation order
+}
+
+int launch_conv3x3_c64_rows(hipStream_t s, const ConvP &P, int nimg, int device) {
+    constexpr size_t lds_bytes = (size_t)4 * c64_wave_halves() * sizeof(_Float16);
+    static DevOnce once;
+    const int rc = once.run(device, [&]() -> int {
+        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_c64_rows_k<ACT_ELU, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_c64_rows_k<ACT_NONE, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        return DD_OK;
+    });
+    if (rc != DD_OK) return rc;
+    const int grid = std::min(dd_ceil_div(nimg, 2), 2 * 256);      // a block: two images x two channel halves
+    if (P.res) hipLaunchKernelGGL((conv3x3_c64_rows_k<ACT_NONE, 1>), dim3((unsigned)grid), dim3(256), lds_bytes, s, P, nimg);
+    else hipLaunchKernelGGL((conv3x3_c64_rows_k<ACT_ELU, 0>), dim3((unsigned)grid), dim3(256), lds_bytes, s, P, nimg);
     DD_LAUNCH_CHECK();
     return DD_OK;
 }
@@ -2697,6 +2869,14 @@ int dd_net_profile_read(dd_net *n, float *ms_host, int cap, int *n_ops_host) {
     return DD_OK;
 }
 
+int dd_net_op_launches(dd_net *n, int32_t *codes_host, int cap, int *n_ops_host) {
+    DD_REQUIRE(n && codes_host && n_ops_host, DD_E_ARG, "dd_net_op_launches: NULL argument");
+    DD_REQUIRE(cap >= n->n_ops, DD_E_ARG, "dd_net_op_launches: cap %d < %d ops", cap, n->n_ops);
+    for (int i = 0; i < n->n_ops; ++i) codes_host[i] = i < (int)n->op_launch.size() ? n->op_launch[i] : OPK_DEFAULT;
+    *n_ops_host = n->n_ops;
+    return DD_OK;
+}
+
 int dd_net_read(dd_net *n, int tensor, int n_img, void *dst, int dst_on_device, void *stream) {
     DD_REQUIRE(n && dst && n_img >= 0 && n_img <= n->max_batch, DD_E_ARG, "dd_net_read: bad argument");
     DD_DEVICE(n->ctx);
@@ -2751,6 +2931,7 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
         const TensorDesc &d = net->tensors[t];
         return static_cast<char *>(net->bufs[d.buf]);
     };
+    net->op_launch.assign((size_t)net->n_ops, OPK_DEFAULT);
     ConvP stem_p;                                                 // a first layer waiting to be folded into the next op's launch
     bool stem_pending = false;
     ConvP unit_a;                                                 // first 3x3 layer of a residual unit, likewise
@@ -2763,12 +2944,12 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
         const TensorDesc *ts = src >= 0 ? &net->tensors[src] : nullptr;
         const TensorDesc *td = dst >= 0 ? &net->tensors[dst] : nullptr;
         if (unit_pending && kind != OP_CONV) {                        // (a program that sets the flag wrongly still computes the right thing)
-            unit_pending = false;
+            unit_pending = false; net->op_launch[i - 1] = OPK_DEFAULT;
             const int rc = launch_conv3x3_rw(s, unit_a, nimg, false, net->ctx->device);
             if (rc != DD_OK) return rc;
         }
         if (stem_pending && !(kind == OP_CONV && o[29]) && kind != OP_DWPW) {   // not followed by the layer it was meant for: run it on its own
-            stem_pending = false;
+            stem_pending = false; net->op_launch[i - 1] = OPK_DEFAULT;
             const int rc = launch_stem(s, stem_p, nimg);
             if (rc != DD_OK) return rc;
         }
@@ -2816,8 +2997,10 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
                         P.zero = net->d_zero;
                         rc = launch_res_unit(s, unit_a, P, nimg, net->ctx->device);
                         if (rc != DD_OK) return rc;
+                        net->op_launch[i] = OPK_RES_UNIT;
                         break;
                     }
+                    net->op_launch[i - 1] = OPK_DEFAULT;
                     rc = launch_conv3x3_rw(s, unit_a, nimg, false, net->ctx->device);
                     if (rc != DD_OK) return rc;
                 }
@@ -2834,15 +3017,21 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
                             P.src8 = stem_p.src8; P.in_mean = stem_p.in_mean; P.in_scale = stem_p.in_scale;
                             P.dw_w = stem_p.w; P.dw_bias = stem_p.bias; P.dw_act = stem_p.act;
                         } else {
+                            net->op_launch[i - 1] = OPK_DEFAULT;
                             rc = launch_stem(s, stem_p, nimg);
                             if (rc != DD_OK) return rc;
                         }
                     }
                     if (o[30] && !o[29] && i + 1 < net->n_ops && nimg >= 160 && !P.res && !P.out2) {
                         unit_a = P; unit_pending = true;       // o[30]: only the next op reads this layer's output
+                        net->op_launch[i] = OPK_FOLDED;
                         break;
                     }
+                    if (o[29] && pool_rows_fusable(P, nimg)) net->op_launch[i] = P.src8 ? OPK_POOL_ROWS_STEM : OPK_POOL_ROWS;
                     rc = launch_conv3x3_rw(s, P, nimg, o[29] != 0, net->ctx->device);
+                } else if (c64_rows_eligible(P, nimg, net->max_batch)) {
+                    net->op_launch[i] = OPK_C64_ROWS;
+                    rc = launch_conv3x3_c64_rows(s, P, nimg, net->ctx->device);
                 } else if (ws_eligible(P)) {
                     rc = P.cin == 256 ? launch_conv_ws<4>(s, P, net->ctx->device) : launch_conv_ws<8>(s, P, net->ctx->device);
                 } else if (P.cout_pad <= 32) {
@@ -2895,11 +3084,11 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
                 static const bool unfused = getenv("DD_STEM_UNFUSED") && atoi(getenv("DD_STEM_UNFUSED")) != 0;
                 if (o[30] && !unfused && i + 1 < net->n_ops && P.stride == 1 && P.pad_t == 1 && P.pad_l == 1 && P.cout == 32 && P.act == ACT_ELU &&
                     P.W == 32 && (reinterpret_cast<uintptr_t>(input) & 3) == 0) {
-                    stem_p = P; stem_pending = true;
+                    stem_p = P; stem_pending = true; net->op_launch[i] = OPK_FOLDED;
                     break;
                 }
                 if (o[30] && i + 1 < net->n_ops && P.stride == 2) {       // followed by the first MobileNet block (ssd_front_k)
-                    stem_p = P; stem_p.zero = net->d_zero; stem_pending = true;
+                    stem_p = P; stem_p.zero = net->d_zero; stem_pending = true; net->op_launch[i] = OPK_FOLDED;
                     break;
                 }
                 int rc = launch_stem(s, P, nimg);
@@ -2927,8 +3116,10 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
                     if (ssd_front_fusable(stem_p, P, nimg)) {
                         rc = launch_ssd_front(s, stem_p, P, nimg, net->ctx->device);
                         if (rc != DD_OK) return rc;
+                        net->op_launch[i] = OPK_SSD_FRONT;
                         break;
                     }
+                    net->op_launch[i - 1] = OPK_DEFAULT;
                     rc = launch_stem(s, stem_p, nimg);
                     if (rc != DD_OK) return rc;
                 }

@@ -125,7 +125,8 @@ class Program:
         self._op(OP_STEM, dst=dst, stride=stride, pad_t=pt, pad_l=pl, cout=cout, cout_pad=32, act=act,
                  w_off=self.add_blob(wp), b_off=self.add_blob(bp), ho=ho, wo=wo, f=[mean, scale])
         self.info[-1] = dict(kernel='stem_conv3_k', flops=2 * ho * wo * 27 * cout,
-                             bytes=3 * self.in_h * self.in_w + 2 * ho * wo * cout, wbytes=2 * 27 * cout + 4 * cout)
+                             bytes=3 * self.in_h * self.in_w + 2 * ho * wo * cout, wbytes=2 * 27 * cout + 4 * cout,
+                             src_bytes=3 * self.in_h * self.in_w)
         return dst
 
     def conv(self, src, w_hwio, bias, stride=1, pad=None, act=ACT_NONE, dst=None, res=-1, dst2=-1, aff2=None,
@@ -178,7 +179,7 @@ class Program:
                              flops=2 * ho * wo * kh * kw * cin * cout,
                              bytes=2 * s['h'] * s['w'] * cin + (4 if epi != EPI_F16 else 2) * (self.T(dst)['h'] * self.T(dst)['w'] if pool else ho * wo) * cout
                              + (2 * ho * wo * cout if res >= 0 else 0) + (2 * ho * wo * cout if dst2 >= 0 else 0),
-                             wbytes=2 * kh * kw * cin * cout + 4 * cout)
+                             wbytes=2 * kh * kw * cin * cout + 4 * cout, src_bytes=2 * s['h'] * s['w'] * cin)
         return dst
 
     def dwconv(self, src, w_hwc, bias, stride, act, pad=None):
@@ -234,7 +235,7 @@ class Program:
                  kpad=c, act=pw_act, epi=EPI_F16, w_off=self.add_blob(wflat), b_off=self.add_blob(pw_bias.astype(np.float32)),
                  p=[self.add_blob(dwp), self.add_blob(dw_bias.astype(np.float32)), dw_act], ho=ho, wo=wo)
         self.info[-1] = dict(kernel=kernel, flops=2 * ho * wo * c * (9 + cout), bytes=2 * (s['h'] * s['w'] * c + ho * wo * cout),
-                             wbytes=2 * c * (9 + cout) + 4 * (c + cout))
+                             wbytes=2 * c * (9 + cout) + 4 * (c + cout), src_bytes=2 * s['h'] * s['w'] * c)
         return dst
 
     def maxpool(self, src, k, stride, pad, dst=None):

@@ -26,6 +26,36 @@ def net_op_times(net):
     return ms
 
 
+# dd_net_op_launches codes (include/deepdish_hip.h)
+OPK_FOLDED = 1
+OPK_NAMES = {2: 'conv3x3_pool_rows_k', 3: 'conv3x3_pool_rows_k<STEM>', 4: 'res_unit_rows_k', 5: 'ssd_front_k', 6: 'conv3x3_c64_rows_k'}
+
+
+def net_op_launches(net):
+    """Which launch ran each op of the last forward (fused launches are attributed to the kernel that ran)."""
+    n = len(net.program.ops)
+    codes = np.zeros(n, dtype=np.int32)
+    cnt = ctypes.c_int(0)
+    check(lib().dd_net_op_launches(net._h, ptr(codes), n, ctypes.byref(cnt)), 'dd_net_op_launches')
+    return codes
+
+
+def launches_of(net, ms, batch):
+    """[(kernel, ms, flops, bytes)] per LAUNCH of the last forward: an op folded into the next op's launch adds its FLOPs
+    and the bytes it reads to that launch, and the tensor between the two (never written) is not counted."""
+    out, pend = [], None
+    for t, info, code in zip(ms, net.program.info, net_op_launches(net)):
+        fl, by = info['flops'] * batch, info['bytes'] * batch + info.get('wbytes', 0)
+        if code == OPK_FOLDED:
+            pend = (float(t), fl, info.get('src_bytes', 0) * batch + info.get('wbytes', 0))
+            continue
+        if pend is not None:
+            t, fl, by = float(t) + pend[0], fl + pend[1], by - info.get('src_bytes', 0) * batch + pend[2]
+            pend = None
+        out.append((OPK_NAMES.get(int(code), info['kernel']), float(t), fl, by))
+    return out
+
+
 def profile_nets(run_once, nets_with_batch, reps=20):
     """run_once() runs one bench step; nets_with_batch: [(name, Net, images per forward)].
     Returns {kernel: dict(ms, flops, bytes, launches)} averaged per step.
@@ -42,9 +72,9 @@ def profile_nets(run_once, nets_with_batch, reps=20):
             for name, net, batch in nets_with_batch:
                 ms = net_op_times(net)
                 b = batch() if callable(batch) else batch
-                for t, info in zip(ms, net.program.info):
-                    k = acc.setdefault(info['kernel'], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
-                    k['ms'] += float(t); k['flops'] += info['flops'] * b; k['bytes'] += info['bytes'] * b + info.get('wbytes', 0); k['launches'] += 1
+                for kname, t, fl, by in launches_of(net, ms, b):
+                    k = acc.setdefault(kname, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+                    k['ms'] += t; k['flops'] += fl; k['bytes'] += by; k['launches'] += 1
     finally:
         for _, net, _ in nets_with_batch:
             check(lib().dd_net_profile(net._h, 0), 'dd_net_profile')
@@ -98,7 +128,7 @@ def dominant_kernel_roofline(pipes, step_group, args, reps=20):
     name, k = max(acc.items(), key=lambda kv: kv[1]['ms'])
     sec = k['ms'] * 1e-3
     avg_us = 1e3 * k['ms'] / max(k['launches'], 1e-9)
-    if 'conv_' in name:
+    if name.startswith('conv') or name.startswith('res_unit'):
         achieved = k['flops'] / sec / 1e12
         out = dict(bound='mfma', achieved=achieved, peak=PEAK_F16_TFLOPS, unit='TFLOP/s', frac=achieved / PEAK_F16_TFLOPS)
     else:
