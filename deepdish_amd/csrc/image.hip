@@ -207,9 +207,15 @@ __global__ __launch_bounds__(256) void band_resample_k(const uint8_t *__restrict
                                                        int pitch_s, const int *__restrict__ start,
                                                        const i4v *__restrict__ coef, const int *__restrict__ bias,
                                                        int n_groups, int C, uint8_t *__restrict__ outT,
-                                                       size_t out_img_stride, int pitch_o, int tiles_per_chunk) {
+                                                       size_t out_img_stride, int pitch_o, int tiles_per_chunk, int nx, int ny) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int g = blockIdx.x * 4 + wave;
+    // 1-D grid, logical block (bx, by, bz) with bx fastest: the column groups of one image's row chunk read overlapping
+    // windows of the same source rows, so they sit next to each other in the logical order and dd_xcd_remap puts them
+    // on one XCD (one L2).  Dealt round-robin over the XCDs every image was fetched by all eight of them: PMC had the
+    // horizontal pass of 192 640x480 frames at 505 MB read for 177 MB of frames.
+    const unsigned v = dd_xcd_remap(blockIdx.x, gridDim.x);
+    const int bx = (int)(v % (unsigned)nx), by = (int)((v / (unsigned)nx) % (unsigned)ny), bz = (int)(v / (unsigned)(nx * ny));
+    const int g = bx * 4 + wave;
     if (g >= n_groups) return;                                  // whole waves leave; the kernel has no barrier
     const int fr = lane & 15, fq = lane >> 4;
     i4v cf[KS][3];
@@ -219,9 +225,9 @@ __global__ __launch_bounds__(256) void band_resample_k(const uint8_t *__restrict
         for (int p = 0; p < 3; ++p) cf[ks][p] = coef[((size_t)(g * KS + ks) * 3 + p) * 64 + lane];
     const int col = g * 16 + fr;
     const int b = col < C ? bias[col] : 0;
-    const uint8_t *base = src + blockIdx.z * src_img_stride + start[g] + fq * 16;
-    uint8_t *obase = outT + blockIdx.z * out_img_stride + (size_t)col * pitch_o + fq * 4;
-    const int r_first = blockIdx.y * tiles_per_chunk * 16;
+    const uint8_t *base = src + bz * src_img_stride + start[g] + fq * 16;
+    uint8_t *obase = outT + bz * out_img_stride + (size_t)col * pitch_o + fq * 4;
+    const int r_first = by * tiles_per_chunk * 16;
     for (int t = 0; t < tiles_per_chunk; ++t) {
         const int r0 = r_first + t * 16;
         if (r0 >= R) break;
@@ -251,15 +257,17 @@ __global__ __launch_bounds__(256) void band_resample_k(const uint8_t *__restrict
 // rows r0 + 16*(i/4) + 4*j + i%4): the lane that owns accumulator rows 4*fq.. of every tile then holds the sixteen
 // consecutive rows r0 + 16*fq .. +15 of its output column and writes them with one 16-byte store.  (With one tile
 // per iteration a lane wrote 4 bytes at a time and the fabric saw twice the algorithmic write bytes -- PMC.)
-// Needs R % 16 == 0 and pitch_o % 16 == 0: the horizontal pass.
+// Needs R % 4 == 0 and 4-byte aligned output rows (both passes of the 640x480 -> 300x300 stretch: R = 480 and 900).
 template <int KS>
 __global__ __launch_bounds__(256) void band_resample_wide_k(const uint8_t *__restrict__ src, size_t src_img_stride, int R,
                                                             int pitch_s, const int *__restrict__ start,
                                                             const i4v *__restrict__ coef, const int *__restrict__ bias,
                                                             int n_groups, int C, uint8_t *__restrict__ outT,
-                                                            size_t out_img_stride, int pitch_o, int tiles_per_chunk) {
+                                                            size_t out_img_stride, int pitch_o, int tiles_per_chunk, int nx, int ny) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int g = blockIdx.x * 4 + wave;
+    const unsigned v = dd_xcd_remap(blockIdx.x, gridDim.x);      // see band_resample_k
+    const int bx = (int)(v % (unsigned)nx), by = (int)((v / (unsigned)nx) % (unsigned)ny), bz = (int)(v / (unsigned)(nx * ny));
+    const int g = bx * 4 + wave;
     if (g >= n_groups) return;                                  // whole waves leave; the kernel has no barrier
     const int fr = lane & 15, fq = lane >> 4;
     i4v cf[KS][3];
@@ -269,9 +277,9 @@ __global__ __launch_bounds__(256) void band_resample_wide_k(const uint8_t *__res
         for (int p = 0; p < 3; ++p) cf[ks][p] = coef[((size_t)(g * KS + ks) * 3 + p) * 64 + lane];
     const int col = g * 16 + fr;
     const int b = col < C ? bias[col] : 0;
-    const uint8_t *base = src + blockIdx.z * src_img_stride + start[g] + fq * 16;
-    uint8_t *obase = outT + blockIdx.z * out_img_stride + (size_t)col * pitch_o + fq * 16;
-    const int r_first = blockIdx.y * tiles_per_chunk * 64;      // tiles_per_chunk counts 64-row iterations here
+    const uint8_t *base = src + bz * src_img_stride + start[g] + fq * 16;
+    uint8_t *obase = outT + bz * out_img_stride + (size_t)col * pitch_o + fq * 16;
+    const int r_first = by * tiles_per_chunk * 64;              // tiles_per_chunk counts 64-row iterations here
     const int row_in_tile = ((fr >> 2) << 4) + (fr & 3);        // + 4*j
     for (int t = 0; t < tiles_per_chunk; ++t) {
         const int r0 = r_first + t * 64;
@@ -298,8 +306,16 @@ __global__ __launch_bounds__(256) void band_resample_wide_k(const uint8_t *__res
             asm volatile("" : "+v"(by[0]), "+v"(by[1]), "+v"(by[2]), "+v"(by[3]));     // see lanczos_v4_k: keep v_ashr_pk_u8_i32 away
             word[j] = by[0] | (by[1] << 8) | (by[2] << 16) | (by[3] << 24);              // rows r0 + 16*fq + 4*j .. +3
         }
-        if (col < C && r0 + fq * 16 < R)
-            *reinterpret_cast<uint4 *>(obase + r0) = make_uint4(word[0], word[1], word[2], word[3]);
+        typedef uint32_t u4a __attribute__((ext_vector_type(4), aligned(4)));      // pitch_o is only a multiple of 4 in the vertical pass
+        if (col < C) {
+            if (r0 + fq * 16 + 16 <= R) {
+                *reinterpret_cast<u4a *>(obase + r0) = u4a{word[0], word[1], word[2], word[3]};
+            } else {                                             // R % 64 != 0: the last rows in words (R % 4 == 0)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (r0 + fq * 16 + 4 * j + 4 <= R) *reinterpret_cast<uint32_t *>(obase + r0 + 4 * j) = word[j];
+            }
+        }
     }
 }
 
@@ -497,13 +513,14 @@ int launch_band(hipStream_t s, const BandTable &b, const uint8_t *src, size_t sr
                 size_t out_img_stride, int pitch_o, int batch) {
     const i4v *cf = static_cast<const i4v *>(b.coef);
     static const bool no_wide = getenv("DD_LANCZOS_NO_WIDE") != nullptr;
-    if (!no_wide && R % 16 == 0 && pitch_o % 16 == 0 && (reinterpret_cast<uintptr_t>(outT) & 15) == 0 && out_img_stride % 16 == 0) {
+    if (!no_wide && R % 4 == 0 && pitch_o % 4 == 0 && (reinterpret_cast<uintptr_t>(outT) & 3) == 0 && out_img_stride % 4 == 0) {
         const int tiles = dd_ceil_div(R, 64);                     // 64-row iterations, 16-byte stores
         const int chunks = std::max(1, std::min(tiles, dd_ceil_div(8192, std::max(1, b.n_groups * batch))));
         const int tpc = dd_ceil_div(tiles, chunks);
-        const dim3 grid((unsigned)dd_ceil_div(b.n_groups, 4), (unsigned)dd_ceil_div(tiles, tpc), (unsigned)batch);
+        const int nx = dd_ceil_div(b.n_groups, 4), ny = dd_ceil_div(tiles, tpc);
+        const dim3 grid((unsigned)(nx * ny * batch));
 #define DD_BANDW(KS_) hipLaunchKernelGGL(band_resample_wide_k<KS_>, grid, dim3(256), 0, s, src, src_img_stride, R, pitch_s, b.start, cf, \
-                                         b.bias, b.n_groups, b.n_cols, outT, out_img_stride, pitch_o, tpc)
+                                         b.bias, b.n_groups, b.n_cols, outT, out_img_stride, pitch_o, tpc, nx, ny)
         switch (b.ksteps) {
             case 1: DD_BANDW(1); break;
             case 2: DD_BANDW(2); break;
@@ -517,9 +534,10 @@ int launch_band(hipStream_t s, const BandTable &b, const uint8_t *src, size_t sr
     const int tiles = dd_ceil_div(R, 16);
     const int chunks = std::max(1, std::min(tiles, dd_ceil_div(8192, std::max(1, b.n_groups * batch))));
     const int tpc = dd_ceil_div(tiles, chunks);
-    const dim3 grid((unsigned)dd_ceil_div(b.n_groups, 4), (unsigned)dd_ceil_div(tiles, tpc), (unsigned)batch);
+    const int nx = dd_ceil_div(b.n_groups, 4), ny = dd_ceil_div(tiles, tpc);
+    const dim3 grid((unsigned)(nx * ny * batch));
 #define DD_BAND(KS_) hipLaunchKernelGGL(band_resample_k<KS_>, grid, dim3(256), 0, s, src, src_img_stride, R, pitch_s, b.start, cf, b.bias, \
-                                        b.n_groups, b.n_cols, outT, out_img_stride, pitch_o, tpc)
+                                        b.n_groups, b.n_cols, outT, out_img_stride, pitch_o, tpc, nx, ny)
     switch (b.ksteps) {
         case 1: DD_BAND(1); break;
         case 2: DD_BAND(2); break;
