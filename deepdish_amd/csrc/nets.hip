@@ -2630,7 +2630,14 @@ int launch_ssd_front(hipStream_t s, const ConvP &S, const ConvP &P, int nimg, in
     if (rc != DD_OK) return rc;
     const int strips = dd_ceil_div(P.wo, SF_SW);
     static const int force_parts = getenv("DD_SSD_FRONT_PARTS") ? atoi(getenv("DD_SSD_FRONT_PARTS")) : 0;
-    const int parts = force_parts > 0 ? force_parts : std::max(1, std::min(8, 2048 / (nimg * strips)));   // 2048 wave slots at two per SIMD
+    // row parts per strip: 2048 wave slots (two per SIMD) are filled in rounds; a part costs its rows + 2 (the two stem rows above it)
+    int parts = 1;
+    long long best = -1;
+    for (int p = 1; p <= 8; ++p) {
+        const long long rounds = ((long long)nimg * strips * p + 2047) / 2048, cost = rounds * (dd_ceil_div(P.ho, p) + 2);
+        if (best < 0 || cost < best) { best = cost; parts = p; }
+    }
+    if (force_parts > 0) parts = force_parts;
     const int n_tasks = nimg * strips * parts;
     const int grid = std::min(dd_ceil_div(n_tasks, 4), 2 * 256);
     hipLaunchKernelGGL((ssd_front_k<ACT_RELU6>), dim3((unsigned)grid), dim3(256), lds_bytes, s, S, P, n_tasks, parts);
