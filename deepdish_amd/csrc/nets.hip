@@ -28,7 +28,7 @@ enum { OP_INPUT = 1, OP_CONV = 2, OP_DWCONV = 3, OP_MAXPOOL = 4, OP_UPSAMPLE = 5
 enum { ACT_NONE = 0, ACT_RELU6 = 1, ACT_ELU = 2, ACT_SILU = 3, ACT_RELU = 4, ACT_SIGMOID = 5 };
 enum { EPI_F16 = 0, EPI_F32 = 1, EPI_SSD_HEAD = 2, EPI_YOLO = 3 };
 // dd_net_op_launches: 0 = the op's own kernel, 1 = no launch (folded into the next op's), else the fused / special kernel
-enum { OPK_DEFAULT = 0, OPK_FOLDED = 1, OPK_POOL_ROWS = 2, OPK_POOL_ROWS_STEM = 3, OPK_RES_UNIT = 4, OPK_SSD_FRONT = 5, OPK_C64_ROWS = 6 };
+enum { OPK_DEFAULT = 0, OPK_FOLDED = 1, OPK_POOL_ROWS = 2, OPK_POOL_ROWS_STEM = 3, OPK_RES_UNIT = 4, OPK_SSD_FRONT = 5, OPK_C64_ROWS = 6, OPK_S2_ROWS = 7 };
 enum { DT_F16 = 0, DT_F32 = 1, DT_U8 = 2 };
 
 constexpr int OP_WORDS = 48;       // int32 words per op record (see deepdish_amd/nets.py)
@@ -1388,6 +1388,101 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_rows_k(const ConvP P, cons
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------
+// 3x3 stride-2 convolution 32 -> 64 channels from a 31x15 map to 16x8 (MARS conv3_1/1), one wave per image with the
+// whole filter in registers (9 taps x 4 fragments = 144 VGPRs), rows streamed as in conv3x3_c64_rows_k: an image is 32
+// stream rows (31 + the zero row it shares with the next image) = 8 rounds of 4, so the DMA queue never breaks.  A row
+// slot keeps the odd and the even columns apart ([odd | even][plane][8] x 16 B, one DMA; odd slot 7 = column 15 is the
+// zero line, and with the 16 zero bytes in front of the row every left tap finds its padding without a mask); the pitch
+// of 1088 B puts the two map rows of a fragment read on different halves of the 256-B bank row.
+constexpr int S2_PITCH = 544, S2_SLOTS = 16, S2_LEAD = 2;         // halves per row slot (64 B pad + 1 KiB), ring depth, rounds of DMA lead
+
+template <int ACT>
+__global__ __launch_bounds__(256, 2) void conv3x3_s2_rows_k(const ConvP P, const int n_img) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int j = fr >> 3, ox = fr & 7;                           // fragment pixel: output row j of the pair, column ox
+    _Float16 *ring = lds + (size_t)wave * (S2_SLOTS * S2_PITCH);
+    const h8 zero8 = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+    for (int i = lane * 8; i < S2_SLOTS * S2_PITCH; i += 64 * 8) *reinterpret_cast<h8 *>(ring + i) = zero8;     // the pads in front of the rows
+    const int H = P.H, W = P.W, S = H + 1, RPI = S / 4;           // 31, 15, 32 stream rows and 8 rounds per image
+
+    h8 wf[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) wf[t][a] = *reinterpret_cast<const h8 *>(P.w + (size_t)rw_weight_row(a, fr) * P.kpad + t * 32 + fq * 8);
+    Epi8 E[2];
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2) E[g2] = epi8_load(P, g2 * 32 + fq * 8);
+    const int n0 = blockIdx.x * 4 + wave, nstep = gridDim.x * 4;
+    const int K = n0 < n_img ? (n_img - n0 + nstep - 1) / nstep : 0;      // images of this wave: n0 + k * nstep
+    const int T = K * S + 1, Q = K * RPI;                         // stream rows, rounds
+
+    // DMA lane -> chunk: [set: 0 odd columns, 1 even][plane][8]: column 2 * idx + (set ? 0 : 1)
+    const int dma_col = 2 * (lane & 7) + ((lane >> 5) ? 0 : 1);
+    const int dma_off = dma_col * P.cs_in + ((lane >> 3) & 3) * 8;
+    const bool dma_px = dma_col < W;
+    int dq = 0, dq_k = 0, dq_y = -1;                              // next stream row to request: image, map row
+    auto issue_row = [&]() {                                      // past the stream / between images: zero lines
+        const bool rok = dq < T && dq_y >= 0;
+        const _Float16 *row = P.in + ((size_t)(n0 + dq_k * nstep) * H + (rok ? dq_y : 0)) * W * P.cs_in + P.coff_in;
+        lds_fill16(rok && dma_px ? row + dma_off : P.zero, ring + (dq & (S2_SLOTS - 1)) * S2_PITCH + 32);
+        ++dq;
+        if (++dq_y == H) { dq_y = -1; ++dq_k; }
+    };
+    auto issue_group = [&](int qa) { while (dq <= 4 * qa + 4) issue_row(); };     // round qa reads stream rows 4 qa .. 4 qa + 4
+    for (int qa = 0; qa < S2_LEAD; ++qa) issue_group(qa);
+    // per-lane offsets inside a row slot (halves, after the 64-byte pad): left / centre / right tap of output column ox
+    const int off_dx[3] = {32 + (fq * 8 + ox - 1) * 8, 32 + ((4 + fq) * 8 + ox) * 8, 32 + (fq * 8 + ox) * 8};
+    int k = 0, r = 0;
+    for (int q = 0; q < Q; ++q) {
+        issue_group(q + S2_LEAD);
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (q < S2_LEAD) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(S2_LEAD * 4) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(S2_LEAD * 4 + S2_LEAD * 2) : "memory");
+#endif
+        const int m = ((n0 + k * nstep) * P.ho + 2 * r + j) * P.wo + ox;       // this lane's output pixel
+        f4 acc[4] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+        const _Float16 *rowp[3];                                   // this lane's input row of filter row dy: stream row 4q + 2j + dy
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) rowp[dy] = ring + ((4 * q + 2 * j + dy) & (S2_SLOTS - 1)) * S2_PITCH;
+        h8 X[2];
+        auto rd = [&](int t) -> h8 { return *reinterpret_cast<const h8 *>(rowp[t / 3] + off_dx[t % 3]); };
+        X[0] = rd(0);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            h8 &xv = X[t & 1];
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" : "+v"(xv));                          // tap t has arrived before tap t+1 is requested
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            if (t + 1 < 9) X[(t + 1) & 1] = rd(t + 1);
+#if defined(__HIP_DEVICE_COMPILE__)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[t][a], xv, acc[a], 0, 0, 0);
+#if defined(__HIP_DEVICE_COMPILE__)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+#pragma unroll
+        for (int g2 = 0; g2 < 2; ++g2) {
+            float o[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { o[i] = acc[2 * g2][i]; o[4 + i] = acc[2 * g2 + 1][i]; }
+            conv_epilogue_f16x8<ACT, true, 0>(P, E[g2], m, g2 * 32 + fq * 8, o);
+        }
+        if (++r == RPI) { r = 0; ++k; }
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the look-ahead DMAs past the last round
+#endif
+}
+
 // First layer of a network straight from the u8 image: (x - mean) * scale, 3x3 conv over 3 channels
 // (K = 27, one MFMA k-slice padded to 32; tap dy*9 + dx*3 + ch, so one filter row of a pixel is nine
 // consecutive halves of the LDS patch; k slots as in stem_conv_pool_rows_k, which must produce the same bits), bias, activation -> NHWC f16 with 32 channels.  Replaces the
@@ -2583,6 +2678,28 @@ int launch_res_unit(hipStream_t s, const ConvP &A, const ConvP &B, int nimg, int
     return DD_OK;
 }
 
+bool s2_rows_eligible(const ConvP &P, int nimg, int max_batch) {
+    static const bool off = getenv("DD_S2_ROWS_OFF") && atoi(getenv("DD_S2_ROWS_OFF")) != 0;
+    static const int min_img = getenv("DD_S2_ROWS_MIN") ? atoi(getenv("DD_S2_ROWS_MIN")) : 512;
+    return !off && nimg >= min_img && P.kh == 3 && P.kw == 3 && P.stride == 2 && P.pad_t == 1 && P.pad_l == 1 && P.cin == 32 && P.cout == 64 &&
+           P.cout_pad == 64 && P.kpad >= 288 && P.epi == EPI_F16 && P.W == 15 && P.H == 31 && P.ho == 16 && P.wo == 8 && P.splitk <= 1 &&
+           P.act == ACT_ELU && !P.res && !P.out2 && (long long)dd_ceil_div(max_batch * P.ho * P.wo, 64) >= 256;
+}
+
+int launch_conv3x3_s2_rows(hipStream_t s, const ConvP &P, int nimg, int device) {
+    constexpr size_t lds_bytes = (size_t)4 * S2_SLOTS * S2_PITCH * sizeof(_Float16);
+    static DevOnce once;
+    const int rc = once.run(device, [&]() -> int {
+        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_s2_rows_k<ACT_ELU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        return DD_OK;
+    });
+    if (rc != DD_OK) return rc;
+    const int grid = std::min(dd_ceil_div(nimg, 4), 2 * 256);
+    hipLaunchKernelGGL((conv3x3_s2_rows_k<ACT_ELU>), dim3((unsigned)grid), dim3(256), lds_bytes, s, P, nimg);
+    DD_LAUNCH_CHECK();
+    return DD_OK;
+}
+
 bool c64_rows_eligible(const ConvP &P, int nimg, int max_batch) {
     static const bool off = getenv("DD_C64_ROWS_OFF") && atoi(getenv("DD_C64_ROWS_OFF")) != 0;
     static const int min_img = getenv("DD_C64_ROWS_MIN") ? atoi(getenv("DD_C64_ROWS_MIN")) : 512;
@@ -3036,6 +3153,9 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
                     }
                     if (o[29] && pool_rows_fusable(P, nimg)) net->op_launch[i] = P.src8 ? OPK_POOL_ROWS_STEM : OPK_POOL_ROWS;
                     rc = launch_conv3x3_rw(s, P, nimg, o[29] != 0, net->ctx->device);
+                } else if (s2_rows_eligible(P, nimg, net->max_batch)) {
+                    net->op_launch[i] = OPK_S2_ROWS;
+                    rc = launch_conv3x3_s2_rows(s, P, nimg, net->ctx->device);
                 } else if (c64_rows_eligible(P, nimg, net->max_batch)) {
                     net->op_launch[i] = OPK_C64_ROWS;
                     rc = launch_conv3x3_c64_rows(s, P, nimg, net->ctx->device);
