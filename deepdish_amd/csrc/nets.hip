@@ -184,8 +184,8 @@ __device__ __forceinline__ Epi8 epi8_load(const ConvP &P, int co) {
 // ACT >= 0: the activation is known at compile time (the per-element switch on P.act would otherwise be
 // compiled into a chain of branches around every value).
 // EF (epilogue flavour) 0: no residual, no second output; 1: both; -1: whatever P says.
-template <int ACT = -1, bool BIAS = true, int EF = -1, bool NT = true>   // BIAS = false: the accumulators were initialised with the bias
-__device__ __forceinline__ void conv_epilogue_f16x8(const ConvP &P, const Epi8 &E, int m, int co, float v[8], const h8 *res_pre = nullptr) {
+template <int ACT = -1, bool BIAS = true, int EF = -1, bool NT = true, bool TAIL = true>   // BIAS = false: the accumulators were initialised with the bias;
+__device__ __forceinline__ void conv_epilogue_f16x8(const ConvP &P, const Epi8 &E, int m, int co, float v[8], const h8 *res_pre = nullptr) {   // TAIL = false: cout % 8 == 0
     // res_pre: the residual vector of this (pixel, channel group), fetched by the caller before its first store -- a
     // load issued here cannot be moved above the stores of the caller's previous pixel (they may alias), so a loop of
     // epilogues would pay one memory round trip per pixel
@@ -201,7 +201,7 @@ __device__ __forceinline__ void conv_epilogue_f16x8(const ConvP &P, const Epi8 &
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] += (float)rv[r];
     }
-    const bool tail = co + 8 > P.cout;             // only the last, partly padded channel group needs masking
+    const bool tail = TAIL && co + 8 > P.cout;     // only the last, partly padded channel group needs masking
     h8 o;
 #pragma unroll
     for (int r = 0; r < 8; ++r) o[r] = (_Float16)v[r];
@@ -1237,7 +1237,7 @@ __global__ __launch_bounds__(256, 2) void res_unit_rows_k(const ConvP PA, const 
                     float o[8];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { o[q] = acc[cr][0][q]; o[4 + q] = acc[cr][1][q]; }
-                    conv_epilogue_f16x8<ACT_NONE, false, 1>(PB, EB, (n * H + y) * W + fr, fq * 8, o, &rv[cr]);
+                    conv_epilogue_f16x8<ACT_NONE, false, 1, true, false>(PB, EB, (n * H + y) * W + fr, fq * 8, o, &rv[cr]);
                 }
             }
         }
@@ -1377,7 +1377,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_rows_k(const ConvP P, cons
         float o[8];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { o[i] = acc[0][i]; o[4 + i] = acc[1][i]; }
-        conv_epilogue_f16x8<ACT, true, EF>(P, E, m, half * 32 + fq * 8, o, EF == 1 ? &rp : nullptr);
+        conv_epilogue_f16x8<ACT, true, EF, true, false>(P, E, m, half * 32 + fq * 8, o, EF == 1 ? &rp : nullptr);
         // next round: two rows on, three across an image boundary
         const int adv = r + 1 == RPI ? 3 : 2;
         bslot += adv; if (bslot >= C64_SLOTS) bslot -= C64_SLOTS;
@@ -1474,7 +1474,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_rows_k(const ConvP P, const
             float o[8];
 #pragma unroll
             for (int i = 0; i < 4; ++i) { o[i] = acc[2 * g2][i]; o[4 + i] = acc[2 * g2 + 1][i]; }
-            conv_epilogue_f16x8<ACT, true, 0>(P, E[g2], m, g2 * 32 + fq * 8, o);
+            conv_epilogue_f16x8<ACT, true, 0, true, false>(P, E[g2], m, g2 * 32 + fq * 8, o);
         }
         if (++r == RPI) { r = 0; ++k; }
     }
@@ -1748,7 +1748,7 @@ __global__ __launch_bounds__(256, 2) void ssd_front_k(const ConvP PS, const Conv
                         float o[8];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) { o[q] = acc[2 * g2][q]; o[4 + q] = acc[2 * g2 + 1][q]; }
-                        conv_epilogue_f16x8<ACT, false, 0, false>(P, E[g2], m, g2 * 32 + fq * 8, o);
+                        conv_epilogue_f16x8<ACT, false, 0, false, false>(P, E[g2], m, g2 * 32 + fq * 8, o);
                     }
                 }
             }
