@@ -28,7 +28,7 @@ enum { OP_INPUT = 1, OP_CONV = 2, OP_DWCONV = 3, OP_MAXPOOL = 4, OP_UPSAMPLE = 5
 enum { ACT_NONE = 0, ACT_RELU6 = 1, ACT_ELU = 2, ACT_SILU = 3, ACT_RELU = 4, ACT_SIGMOID = 5 };
 enum { EPI_F16 = 0, EPI_F32 = 1, EPI_SSD_HEAD = 2, EPI_YOLO = 3 };
 // dd_net_op_launches: 0 = the op's own kernel, 1 = no launch (folded into the next op's), else the fused / special kernel
-enum { OPK_DEFAULT = 0, OPK_FOLDED = 1, OPK_POOL_ROWS = 2, OPK_POOL_ROWS_STEM = 3, OPK_RES_UNIT = 4, OPK_SSD_FRONT = 5, OPK_C64_ROWS = 6, OPK_S2_ROWS = 7 };
+enum { OPK_DEFAULT = 0, OPK_FOLDED = 1, OPK_POOL_ROWS = 2, OPK_POOL_ROWS_STEM = 3, OPK_RES_UNIT = 4, OPK_SSD_FRONT = 5, OPK_C64_ROWS = 6, OPK_S2_ROWS = 7, OPK_CONV_WS = 8 };
 enum { DT_F16 = 0, DT_F32 = 1, DT_U8 = 2 };
 
 constexpr int OP_WORDS = 48;       // int32 words per op record (see deepdish_amd/nets.py)
@@ -2815,11 +2815,13 @@ int launch_dwpw(hipStream_t s, ConvP &P, int device) {
 
 // 1x1 / stride 1 / unpadded layer with >= 16 K pixels and K = 256 or 512: weight-stationary persistent kernel.
 bool ws_eligible(const ConvP &P) {
-    // Opt-in (DD_WS=1).  Measured on 19x19x512 -> 512: 41-44 us against 49-53 us for conv_glds_k at 192 frames per launch, but
-    // at the 96-frame launches of the default bench configuration the persistent blocks lose to tile quantisation and to
-    // the other worker groups' kernels they cannot share a CU with (-1.5 % end to end, same-box A/B); see DESIGN.md.
-    static const bool on = getenv("DD_WS") != nullptr;
-    return on && P.kh == 1 && P.kw == 1 && P.stride == 1 && P.pad_t == 0 && P.pad_l == 0 && P.ho == P.H && P.wo == P.W &&
+    // From 160 images per launch (DD_WS=1: always, DD_WS=0: never).  Same-box A/B of the whole SSD forward, conv_glds_k -> conv_ws_k
+    // for its eligible layers, bit-identical: 48 / 64 frames +0.6 / +0.4 %, 96 / 128 / 160 / 192 / 256 frames -2.9 / -1.5 / -5.7 /
+    // -2.3 / -2.9 %; end to end at 256 frames per launch (4 worker groups) 68.8 -> 72.4 k frames/s.  At the 96-frame launches of an
+    // earlier default the persistent blocks lost to the other groups' kernels they cannot share a CU with (-1.5 % end to end).
+    static const int mode = getenv("DD_WS") ? atoi(getenv("DD_WS")) : -1;
+    const int nimg = P.m / std::max(1, P.ho * P.wo);
+    return (mode > 0 || (mode < 0 && nimg >= 160)) && P.kh == 1 && P.kw == 1 && P.stride == 1 && P.pad_t == 0 && P.pad_l == 0 && P.ho == P.H && P.wo == P.W &&
            (P.cin == 256 || P.cin == 512) && P.kpad == P.cin && P.epi == EPI_F16 && !P.res && !P.out2 && P.m >= 16384 &&
            P.cout_pad % 128 == 0 && (P.act == ACT_RELU6 || P.act == ACT_NONE || P.act == ACT_SILU);
 }
@@ -3160,6 +3162,7 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
                     net->op_launch[i] = OPK_C64_ROWS;
                     rc = launch_conv3x3_c64_rows(s, P, nimg, net->ctx->device);
                 } else if (ws_eligible(P)) {
+                    net->op_launch[i] = OPK_CONV_WS;
                     rc = P.cin == 256 ? launch_conv_ws<4>(s, P, net->ctx->device) : launch_conv_ws<8>(s, P, net->ctx->device);
                 } else if (P.cout_pad <= 32) {
                     // 32 output channels: 128 pixels per block (each wave 32 px x 32 ch) once there are enough pixels

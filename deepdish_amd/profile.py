@@ -28,7 +28,7 @@ def net_op_times(net):
 
 # dd_net_op_launches codes (include/deepdish_hip.h)
 OPK_FOLDED = 1
-OPK_NAMES = {2: 'conv3x3_pool_rows_k', 3: 'conv3x3_pool_rows_k<STEM>', 4: 'res_unit_rows_k', 5: 'ssd_front_k', 6: 'conv3x3_c64_rows_k', 7: 'conv3x3_s2_rows_k'}
+OPK_NAMES = {2: 'conv3x3_pool_rows_k', 3: 'conv3x3_pool_rows_k<STEM>', 4: 'res_unit_rows_k', 5: 'ssd_front_k', 6: 'conv3x3_c64_rows_k', 7: 'conv3x3_s2_rows_k', 8: 'conv_ws_k'}
 
 
 def net_op_launches(net):
@@ -94,10 +94,10 @@ def pmc_traffic(kernel, streams):
     path = next((p for p in (os.path.join(root, 'r%02d_pmc_traffic_s%d.json' % (r, streams)) for r in (2, 1)) if os.path.exists(p)), None)
     if path is None:                       # the newest round's summary for this stream count, if one was collected
         return None
-    key = kernel.replace(',', ', ')
+    keys = [part.replace(',', ', ') for part in kernel.split('+')]
     tot_b = tot_n = 0.0
     for k, v in json.load(open(path)).items():          # a kernel family (all tile shapes of conv_glds_k) is summed
-        if key in k:
+        if any(key in k for key in keys):
             tot_b += (v['hbm_read_bytes_corrected'] + v['hbm_write_bytes']) * v['launches']
             tot_n += v['launches']
     return tot_b / tot_n if tot_n else None
@@ -125,6 +125,12 @@ def dominant_kernel_roofline(pipes, step_group, args, reps=20):
         state['f'] = f0 + (state['f'] + 1 - f0) % max(1, args.steps)
 
     acc = profile_nets(run_once, nets, reps)
+    per_kernel = {n: round(v['ms'], 5) for n, v in sorted(acc.items(), key=lambda kv: -kv[1]['ms'])}
+    # the dense-convolution GEMMs are one family: conv_ws_k runs the large pointwise layers from 160 images per launch,
+    # conv_glds_k the rest and all of them below that (same layers, same arithmetic, batch-dependent choice)
+    if 'conv_glds_k' in acc and 'conv_ws_k' in acc:
+        a, b = acc.pop('conv_glds_k'), acc.pop('conv_ws_k')
+        acc['conv_glds_k+conv_ws_k'] = {f: a[f] + b[f] for f in ('ms', 'flops', 'bytes', 'launches')}
     name, k = max(acc.items(), key=lambda kv: kv[1]['ms'])
     sec = k['ms'] * 1e-3
     avg_us = 1e3 * k['ms'] / max(k['launches'], 1e-9)
@@ -138,5 +144,5 @@ def dominant_kernel_roofline(pipes, step_group, args, reps=20):
                frames_per_launch=p.S,
                algorithmic_per_launch=dict(flops=k['flops'] / max(k['launches'], 1e-9), bytes=k['bytes'] / max(k['launches'], 1e-9)),
                measured='HIP events on the launch stream, one worker group (%d streams) alone on the GPU' % p.S,
-               per_kernel_ms_per_step={n: round(v['ms'], 5) for n, v in sorted(acc.items(), key=lambda kv: -kv[1]['ms'])})
+               per_kernel_ms_per_step=per_kernel)
     return out

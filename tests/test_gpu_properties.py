@@ -72,11 +72,12 @@ def test_mars_first_layers_give_the_same_bits_in_every_launch_shape(n):
     np.testing.assert_array_equal(net2.read(tensor=net2.program.meta['tensors']['pool1']), pool)
 
 
-@pytest.mark.parametrize('n', [15, 16, 100])
+@pytest.mark.parametrize('n', [15, 16, 100, 176])
 def test_ssd_first_layers_give_the_same_bits_fused_and_separate(n):
     """conv0 + MobileNet block 1: from 16 frames one launch (ssd_front_k: strips of 30 columns streamed by single waves,
     neither the conv0 tensor nor the depthwise output leaves the CU), below that stem_conv3_k + dwpw_k; a program compiled
-    without the flag always runs the two launches.  Same bits, and a frame's result does not depend on its batch."""
+    without the flag always runs the two launches.  Same bits, and a frame's result does not depend on its batch (176: the
+    pointwise layers of blocks 5-12 run on conv_ws_k from 160 frames)."""
     from deepdish_amd import nets
     from deepdish_amd.engine import Net
     wd = nets.synthetic_ssd_weights(1234)
@@ -274,18 +275,17 @@ def test_embeddings_are_unit_vectors_at_full_batch():
     np.testing.assert_allclose(np.linalg.norm(f.astype(np.float64), axis=1), 1.0, atol=1e-4)
 
 
-def test_opt_in_weight_stationary_kernel_gives_the_same_bits():
-    """conv_ws_k (DD_WS=1: weight rows in registers, activation tiles through a counted-vmcnt LDS ring) sums every output
-    in the order conv_glds_k does, so the whole SSD forward is bit-identical with it switched on (the switch is read once
-    per process: two child processes)."""
+@pytest.mark.parametrize('batch', [64, 176])
+def test_weight_stationary_kernel_gives_the_same_bits(batch):
+    """conv_ws_k (weight rows in registers, activation tiles through a counted-vmcnt LDS ring; on from 160 images per launch,
+    DD_WS=1 / 0 forces it on / off) sums every output in the order conv_glds_k does, so the whole SSD forward is bit-identical
+    either way (the switch is read once per process: two child processes)."""
     import os, re, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sums = []
-    for ws in (False, True):
-        env = {k: v for k, v in os.environ.items() if k != 'DD_WS'}
-        if ws:
-            env['DD_WS'] = '1'
-        r = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'time_forward.py'), 'ssd', '64'], capture_output=True,
+    for ws in ('0', '1'):
+        env = dict(os.environ, DD_WS=ws)
+        r = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'time_forward.py'), 'ssd', str(batch)], capture_output=True,
                            text=True, env=env, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         sums.append(re.search(r'sha (\S+)', r.stdout).group(1))
