@@ -28,7 +28,7 @@ enum { OP_INPUT = 1, OP_CONV = 2, OP_DWCONV = 3, OP_MAXPOOL = 4, OP_UPSAMPLE = 5
 enum { ACT_NONE = 0, ACT_RELU6 = 1, ACT_ELU = 2, ACT_SILU = 3, ACT_RELU = 4, ACT_SIGMOID = 5 };
 enum { EPI_F16 = 0, EPI_F32 = 1, EPI_SSD_HEAD = 2, EPI_YOLO = 3 };
 // dd_net_op_launches: 0 = the op's own kernel, 1 = no launch (folded into the next op's), else the fused / special kernel
-enum { OPK_DEFAULT = 0, OPK_FOLDED = 1, OPK_POOL_ROWS = 2, OPK_POOL_ROWS_STEM = 3, OPK_RES_UNIT = 4, OPK_SSD_FRONT = 5, OPK_C64_ROWS = 6, OPK_S2_ROWS = 7, OPK_CONV_WS = 8 };
+enum { OPK_DEFAULT = 0, OPK_FOLDED = 1, OPK_POOL_ROWS = 2, OPK_POOL_ROWS_STEM = 3, OPK_RES_UNIT = 4, OPK_SSD_FRONT = 5, OPK_C64_ROWS = 6, OPK_S2_ROWS = 7, OPK_CONV_WS = 8, OPK_WS_DW = 9 };
 enum { DT_F16 = 0, DT_F32 = 1, DT_U8 = 2 };
 
 constexpr int OP_WORDS = 48;       // int32 words per op record (see deepdish_amd/nets.py)
@@ -2243,6 +2243,182 @@ __global__ __launch_bounds__(NW * 64) void conv_ws_k(const ConvP P, const int n_
 #endif
 }
 
+struct DwP {
+    const _Float16 *in; int H, W, cs_in, coff_in;
+    const _Float16 *w; const float *bias;
+    int stride, pad_t, pad_l, ho, wo, c, m, act;
+    _Float16 *out; int cs_out, coff_out;
+    const _Float16 *zero;           // >= 16 bytes of zeros: what out-of-image taps read
+};
+
+// conv_ws_k with the NEXT block's depthwise 3x3 (stride 1) folded into its epilogue -- a depthwise convolution is per
+// channel, so the wave that computes 32 output channels of the pointwise layer for a run of whole frames can apply the
+// depthwise taps to exactly those channels without sharing anything: its activated f16 outputs go into a private ring of
+// 128 pixels x 4 channel groups in LDS instead of memory, and once a 64-pixel tile is in, the 64 pixels that now have their
+// whole 3x3 neighbourhood (one map row + one pixel behind) get their nine taps from the ring (taps outside the frame read a
+// zero chunk), bias, activation and a 16-byte store.  The pointwise output tensor and the depthwise launch disappear.
+// Workers own whole frames (the pixel stream of a worker is contiguous, so the ring just keeps turning across frames);
+// four LDS stages instead of eight leave room for the rings at two blocks per CU (+0.5 % on the SSD forward by itself).
+// Same summation orders as conv_glds_k / conv_ws_k and dwconv3_k: same bits as the two launches.
+constexpr int WSD_RING = 128;
+
+template <int KS, int ACT, int DACT>
+__global__ __launch_bounds__(256, 2) void conv_ws_dw_k(const ConvP P, const DwP Q, const int n_slices, const int n_frames) {
+    constexpr int NW = 4, D = 4, BM = WS_BM, MI = 4, NI = 2, G = 8 / NW;
+    static_assert((KS & (KS - 1)) == 0 && KS % 2 == 0 && KS >= D, "stage arithmetic uses masks");
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];         // [D][64 pixels][64 halves] | 4 x y ring | zero chunk
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4, sw = fr & 7;
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int slice = jb % n_slices, worker = (jb / n_slices) * 8 + xcd;
+    const int n_workers = ((int)(gridDim.x >> 3) / n_slices) * 8;
+    const int HW = Q.H * Q.W, Wm = Q.W, Hm = Q.H, L = Wm + 1;
+    const int f0 = (int)((long long)worker * n_frames / n_workers), f1 = (int)((long long)(worker + 1) * n_frames / n_workers);
+    const int px0 = f0 * HW, px1 = f1 * HW;                        // this worker's pixels (whole frames)
+    const int ntiles = (px1 - px0 + BM - 1) / BM;
+    const int cbase = slice * (32 * NW) + wave * 32;
+    _Float16 *yring = lds + D * BM * 64 + wave * (4 * WSD_RING * 8);
+    _Float16 *zchunk = lds + D * BM * 64 + NW * (4 * WSD_RING * 8), *dwt = zchunk + 8;      // zero chunk | depthwise taps [9][128 channels of the slice]
+    if (tid < 8) zchunk[tid] = (_Float16)0.f;
+    if (tid < 9 * 16) {                                         // (an ordinary global load inside the loop would make hipcc drain the fill queue at its use)
+        const int t = tid >> 4, c8 = tid & 15;
+        *reinterpret_cast<h8 *>(dwt + t * 128 + c8 * 8) = *reinterpret_cast<const h8 *>(Q.w + (size_t)t * Q.c + slice * 128 + c8 * 8);
+    }
+    __syncthreads();
+
+    h8 wf[KS * 2][NI];                                          // this wave's weight rows, every K slice
+#pragma unroll
+    for (int k = 0; k < KS * 2; ++k)
+#pragma unroll
+        for (int a = 0; a < NI; ++a)
+            wf[k][a] = *reinterpret_cast<const h8 *>(P.w + (size_t)(cbase + rw_weight_row(a, fr)) * P.kpad + k * 32 + fq * 8);
+    const f4 pb0 = *reinterpret_cast<const f4 *>(P.bias + cbase + fq * 8), pb1 = *reinterpret_cast<const f4 *>(P.bias + cbase + fq * 8 + 4);
+    f4 acc[NI][MI];
+#pragma unroll
+    for (int a = 0; a < NI; ++a)
+#pragma unroll
+        for (int b = 0; b < MI; ++b) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
+
+    const int rr = lane >> 3, pp = lane & 7;
+    const int gch = (pp ^ rr) * 8;
+    auto fill = [&](int st) {                                    // stage st of this block: tile st / KS, K slab st % KS
+        const int ti = st / KS, ks = st & (KS - 1);
+        const int m0 = px0 + ti * BM;
+        _Float16 *dst = lds + (size_t)(st & (D - 1)) * (BM * 64);
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int grp = wave * G + i;
+            const int m = m0 + grp * 8 + rr;
+            const _Float16 *src = (ti < ntiles && m < px1) ? P.in + (size_t)m * P.cs_in + P.coff_in + (ks << 6) + gch : P.zero;
+            lds_fill16(src, dst + grp * 8 * 64);                 // past the last tile: a zero line, so the wait count stays uniform
+        }
+    };
+    h8 xa[MI], xb[MI];
+    auto read_frags = [&](int st, int kk, h8 (&x)[MI]) {
+        const _Float16 *xs = lds + (size_t)(st & (D - 1)) * (BM * 64);
+#pragma unroll
+        for (int b = 0; b < MI; ++b)
+            x[b] = *reinterpret_cast<const h8 *>(xs + (b * 16 + fr) * 64 + (((kk << 2) + fq) ^ sw) * 8);
+    };
+    // depthwise pass: the 64 pixels [p_lo, p_lo + 64) of this worker's stream, 16 per step (lane = pixel x channel group)
+    const unsigned inv_hw = 0xFFFFFFFFu / (unsigned)HW + 1u, inv_w = 0xFFFFFFFFu / (unsigned)Wm + 1u;     // exact q / d for q < 2^16 * ... (checked by the launcher)
+    const f4 db0 = *reinterpret_cast<const f4 *>(Q.bias + cbase + fq * 8), db1 = *reinterpret_cast<const f4 *>(Q.bias + cbase + fq * 8 + 4);
+    const int x_step = 16 % Wm, y_step = 16 / Wm;                 // what 16 pixels further means for (y, x)
+    const char *lds_c = reinterpret_cast<const char *>(lds);
+    const unsigned ring_b = (unsigned)((yring - lds) * 2) + (unsigned)fq * (WSD_RING * 16), zero_b = (unsigned)((zchunk - lds) * 2);
+    auto dw_pass = [&](int p_lo) {
+        const _Float16 *wtap = dwt + wave * 32 + fq * 8;           // this lane's taps (its channel group): re-read per use, 36 registers short
+        // (y, x) of the lane's first pixel by division, of the following three by stepping
+        int q = p_lo + fr;
+        const unsigned qc = (unsigned)(q + HW);                  // one frame up: the first pass starts a row + a pixel before the stream (never stored,
+        const unsigned f = __umulhi(qc, inv_hw), r = qc - f * (unsigned)HW;      // but its coordinates must step into the first real pixels correctly)
+        int y = (int)__umulhi(r, inv_w), x = (int)r - y * Wm;
+#pragma unroll 1
+        for (int step = 0; step < 4; ++step) {
+            const bool live = q >= px0 && q < px1;
+            // all nine reads first (taps outside the frame read the zero chunk), then the 72 multiply-adds.  32-bit LDS byte
+            // offsets throughout: ring slot of pixel p is (p - px0) & 127, 16 bytes each, plane fq
+            const unsigned rb = (unsigned)(q - px0);
+            const bool top = y > 0, bot = y < Hm - 1, lef = x > 0, rig = x < Wm - 1;
+            h8 xv[9];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const bool ok = (kh == 0 ? top : kh == 2 ? bot : true) && (kw == 0 ? lef : kw == 2 ? rig : true);
+                    const unsigned off = ((rb + (unsigned)((kh - 1) * Wm + (kw - 1))) & (WSD_RING - 1)) * 16u + ring_b;
+                    xv[kh * 3 + kw] = *reinterpret_cast<const h8 *>(lds_c + (ok ? off : zero_b));
+                }
+#if defined(__HIP_DEVICE_COMPILE__)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            float a[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[i] = db0[i]; a[4 + i] = db1[i]; }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) dw_tap(a, xv[t], *reinterpret_cast<const h8 *>(wtap + t * 128));
+            h8 o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = (_Float16)apply_act(a[i], DACT);
+            if (live) *reinterpret_cast<h8 *>(Q.out + (size_t)q * Q.cs_out + Q.coff_out + cbase + fq * 8) = o;
+            q += 16;
+            x += x_step; y += y_step;
+            if (x >= Wm) { x -= Wm; ++y; }
+            if (y >= Hm) y -= Hm;                                // into the next frame
+        }
+    };
+
+    for (int st = 0; st < D - 1; ++st) fill(st);
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(G * (D - 2)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#endif
+    read_frags(0, 0, xa);
+    for (int ti = 0; ti < ntiles; ++ti) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int st = ti * KS + ks;
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(G * (D - 3)) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+#endif
+            fill(st + D - 1);
+            read_frags(st, 1, xb);
+#pragma unroll
+            for (int a = 0; a < NI; ++a)
+#pragma unroll
+                for (int b = 0; b < MI; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks * 2][a], xa[b], acc[a][b], 0, 0, 0);
+            read_frags(st + 1, 0, xa);
+#pragma unroll
+            for (int a = 0; a < NI; ++a)
+#pragma unroll
+                for (int b = 0; b < MI; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks * 2 + 1][a], xb[b], acc[a][b], 0, 0, 0);
+        }
+        // pointwise epilogue into the ring (bias, activation, f16: conv_epilogue_f16x8's arithmetic), then the depthwise pass
+#pragma unroll
+        for (int b = 0; b < MI; ++b) {
+            h8 yv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                yv[r] = (_Float16)apply_act(acc[0][b][r] + pb0[r], ACT);
+                yv[4 + r] = (_Float16)apply_act(acc[1][b][r] + pb1[r], ACT);
+            }
+            *reinterpret_cast<h8 *>(yring + (fq * WSD_RING + ((ti * BM + b * 16 + fr) & (WSD_RING - 1))) * 8) = yv;
+            acc[0][b] = acc[1][b] = f4{0.f, 0.f, 0.f, 0.f};
+        }
+        dw_pass(px0 + ti * BM - L);
+    }
+    dw_pass(px0 + ntiles * BM - L);                              // the last map row + pixel of the worker's last frame
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the look-ahead fills past the last tile
+#endif
+}
+
 // Split-K tail: sum the partial slabs in a fixed order (bitwise reproducible) and run the epilogue.
 __global__ __launch_bounds__(256) void conv_splitk_finish_k(const ConvP P) {
     const int groups = P.cout_pad >> 2;
@@ -2259,13 +2435,6 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_k(const ConvP P) {
 }
 
 // Depthwise 3x3: one lane per (pixel, 8-channel group); weights [3][3][C] f16, bias f32 [C].
-struct DwP {
-    const _Float16 *in; int H, W, cs_in, coff_in;
-    const _Float16 *w; const float *bias;
-    int stride, pad_t, pad_l, ho, wo, c, m, act;
-    _Float16 *out; int cs_out, coff_out;
-    const _Float16 *zero;           // >= 16 bytes of zeros: what out-of-image taps read
-};
 
 // Each lane produces TX = 4 consecutive output pixels of one row for one 8-channel group: the
 // 3 x (3 + 3*stride) input window is loaded once (18 or 27 sixteen-byte loads instead of 36) and the
@@ -2852,6 +3021,37 @@ int launch_conv_ws(hipStream_t s, ConvP &P, int device) {
     return DD_OK;
 }
 
+// Pointwise layer P (conv_ws_k material) followed by the depthwise layer Q that alone reads its output: one launch of conv_ws_dw_k?
+bool ws_dw_fusable(const ConvP &P, const DwP &Q, int nimg) {
+    static const bool off = getenv("DD_WS_DW_OFF") && atoi(getenv("DD_WS_DW_OFF")) != 0;
+    if (off || !ws_eligible(P) || P.act != ACT_RELU6 || Q.act != ACT_RELU6 || Q.stride != 1 || Q.pad_t != 1 || Q.pad_l != 1) return false;
+    if (Q.in != static_cast<const _Float16 *>(P.out) || Q.coff_in || Q.cs_in != P.cs_out || P.coff_out || Q.H != P.ho || Q.W != P.wo ||
+        Q.ho != Q.H || Q.wo != Q.W || Q.c != P.cout || P.cout != P.cout_pad || 64 + 2 * (Q.W + 1) > WSD_RING || (long long)nimg * Q.H * Q.W >= (1 << 23))
+        return false;
+    const int n_slices = P.cout_pad / 128, n_workers = (512 / 8 / n_slices) * 8;
+    if (n_slices < 1 || (512 / 8) % n_slices) return false;
+    const int per = dd_ceil_div(nimg, n_workers);                // whole frames per worker: only when that balances (256 frames on 128 workers: 2 each)
+    return (double)nimg / ((double)per * n_workers) >= 0.85;
+}
+
+template <int KS>
+int launch_conv_ws_dw(hipStream_t s, ConvP &P, const DwP &Q, int nimg, int device) {
+    constexpr int NW = 4, D = 4;
+    const int n_slices = P.cout_pad / (32 * NW);
+    P.splitk = 1;
+    constexpr size_t lds_bytes = ((size_t)D * WS_BM * 64 + NW * 4 * WSD_RING * 8 + 8 + 9 * 128) * sizeof(_Float16);
+    static DevOnce once;
+    const int rc = once.run(device, [&]() -> int {
+        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_ws_dw_k<KS, ACT_RELU6, ACT_RELU6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        return DD_OK;
+    });
+    if (rc != DD_OK) return rc;
+    hipLaunchKernelGGL((conv_ws_dw_k<KS, ACT_RELU6, ACT_RELU6>), dim3(512), dim3(NW * 64), lds_bytes, s, P, Q, n_slices, nimg);
+    DD_LAUNCH_CHECK();
+    return DD_OK;
+}
+
+
 template <int STRIDE>
 int launch_dwpw_big(hipStream_t s, ConvP &P, int device, int nimg) {
     const size_t in_bytes = (size_t)nimg * P.H * P.W * P.cs_in * sizeof(_Float16);
@@ -3062,6 +3262,9 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
     bool stem_pending = false;
     ConvP unit_a;                                                 // first 3x3 layer of a residual unit, likewise
     bool unit_pending = false;
+    ConvP pw_p;                                                   // pointwise layer whose only reader is the next (depthwise) op
+    bool pw_pending = false;
+    auto run_ws = [&](ConvP &P) { return P.cin == 256 ? launch_conv_ws<4>(s, P, net->ctx->device) : launch_conv_ws<8>(s, P, net->ctx->device); };
     for (int i = 0; i < net->n_ops; ++i) {
         if (net->profile) DD_HIP(hipEventRecord(net->events[i], s));
         const int32_t *o = net->prog.data() + net->ops_off + (size_t)i * OP_WORDS;
@@ -3069,6 +3272,11 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
         const int kind = o[0], src = o[1], dst = o[2], res = o[3], dst2 = o[4];
         const TensorDesc *ts = src >= 0 ? &net->tensors[src] : nullptr;
         const TensorDesc *td = dst >= 0 ? &net->tensors[dst] : nullptr;
+        if (pw_pending && kind != OP_DWCONV) {
+            pw_pending = false; net->op_launch[i - 1] = OPK_CONV_WS;
+            const int rc = run_ws(pw_p);
+            if (rc != DD_OK) return rc;
+        }
         if (unit_pending && kind != OP_CONV) {                        // (a program that sets the flag wrongly still computes the right thing)
             unit_pending = false; net->op_launch[i - 1] = OPK_DEFAULT;
             const int rc = launch_conv3x3_rw(s, unit_a, nimg, false, net->ctx->device);
@@ -3161,6 +3369,9 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
                 } else if (c64_rows_eligible(P, nimg, net->max_batch)) {
                     net->op_launch[i] = OPK_C64_ROWS;
                     rc = launch_conv3x3_c64_rows(s, P, nimg, net->ctx->device);
+                } else if (ws_eligible(P) && o[30] && i + 1 < net->n_ops && P.act == ACT_RELU6) {
+                    pw_p = P; pw_pending = true; net->op_launch[i] = OPK_FOLDED;     // o[30]: only the next (depthwise) op reads this output
+                    break;
                 } else if (ws_eligible(P)) {
                     net->op_launch[i] = OPK_CONV_WS;
                     rc = P.cin == 256 ? launch_conv_ws<4>(s, P, net->ctx->device) : launch_conv_ws<8>(s, P, net->ctx->device);
@@ -3272,6 +3483,18 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
                 P.m = nimg * td->h * td->w; P.act = o[14];
                 P.out = reinterpret_cast<_Float16 *>(base(dst)); P.cs_out = td->cs; P.coff_out = td->coff;
                 P.zero = net->d_zero;
+                if (pw_pending) {
+                    pw_pending = false;
+                    if (ws_dw_fusable(pw_p, P, nimg)) {
+                        const int rc = pw_p.cin == 256 ? launch_conv_ws_dw<4>(s, pw_p, P, nimg, net->ctx->device) : launch_conv_ws_dw<8>(s, pw_p, P, nimg, net->ctx->device);
+                        if (rc != DD_OK) return rc;
+                        net->op_launch[i] = OPK_WS_DW;
+                        break;
+                    }
+                    net->op_launch[i - 1] = OPK_CONV_WS;
+                    const int rc = run_ws(pw_p);
+                    if (rc != DD_OK) return rc;
+                }
                 static const bool two_rows = getenv("DD_DW_ONE_ROW") == nullptr;              // A/B switch
                 const int ty = (P.stride == 1 && two_rows) ? 2 : 1;
                 const long long total = (long long)nimg * ((P.ho + ty - 1) / ty) * ((P.wo + 3) / 4) * (P.c >> 3);

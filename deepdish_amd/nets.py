@@ -46,10 +46,12 @@ class Program:
     STEM_POOL_FUSE = os.environ.get('DD_STEM_POOL_FUSE', '1') != '0'   # MARS conv1_1 folded into conv1_2's launch
     RES_UNIT_FUSE = os.environ.get('DD_RES_UNIT_FUSE', '1') != '0'     # MARS conv2_x: both 3x3 layers of a residual unit in one launch
     SSD_FRONT_FUSE = os.environ.get('DD_SSD_FRONT_FUSE', '1') != '0'   # SSD conv0 + MobileNet block 1 in one launch
+    PW_DW_FUSE = os.environ.get('DD_PW_DW_FUSE', '1') != '0'           # MobileNet: pointwise layer + the next block's depthwise layer in one launch
 
     def __init__(self, in_h, in_w):
         self.in_h, self.in_w = in_h, in_w
         self.tensors, self.bufs, self.ops = [], [], []
+        self.keep = set()       # tensors somebody else reads later (feature maps): never folded away
         self.blob = bytearray()
         self.out_tensor = -1
         self.meta = {}
@@ -201,7 +203,8 @@ class Program:
         dst = self.tensor(ho, wo, c)
         self._op(OP_DWCONV, src=src, dst=dst, stride=stride, pad_t=pt, pad_l=pl, cout_pad=cp, act=act,
                  w_off=self.add_blob(wp), b_off=self.add_blob(bp))
-        self.info[-1] = dict(kernel='dwconv3_k', flops=2 * ho * wo * 9 * c, bytes=2 * (s['h'] * s['w'] * c + ho * wo * c), wbytes=2 * 9 * c + 4 * c)
+        self.info[-1] = dict(kernel='dwconv3_k', flops=2 * ho * wo * 9 * c, bytes=2 * (s['h'] * s['w'] * c + ho * wo * c), wbytes=2 * 9 * c + 4 * c,
+                             src_bytes=2 * s['h'] * s['w'] * c)
         return dst
 
     DWPW_SHAPES = {(32, 64, 1), (64, 128, 2), (128, 128, 1), (128, 256, 2)}     # (channels, pointwise cout, depthwise stride)
@@ -223,6 +226,11 @@ class Program:
         cout = pw_hwio.shape[3]
         kernel = self._fusable(c, cout, stride)
         if kernel is None or c % 8 or cout % 8:
+            # the previous op is the previous block's pointwise layer and this depthwise layer is its only reader: from 160
+            # frames both can run as one launch (csrc/nets.hip conv_ws_dw_k; the executor checks shapes, batch and balance)
+            if (self.PW_DW_FUSE and stride == 1 and self.ops and self.ops[-1][0] == OP_CONV and self.ops[-1][2] == src
+                    and tuple(self.ops[-1][5:8]) == (1, 1, 1) and src not in self.keep):
+                self.ops[-1][30] = 1
             x = self.dwconv(src, dw_hwc, dw_bias, stride, dw_act)
             return self.conv(x, pw_hwio, pw_bias, act=pw_act)
         assert dw_hwc.shape == (3, 3, c) and pw_hwio.shape[:3] == (1, 1, c)
@@ -466,6 +474,7 @@ def compile_ssd_mobilenet(wd, in_size=300):
             P.ops[-2][30] = 1        # conv0 is read by block 1 only: one launch (csrc/nets.hip ssd_front_k), conv0's tensor is not written
         if i in (11, 13):
             feats.append(x)
+            P.keep.add(x)
     for j in range(1, 5):
         w, b = fold_conv_bn(wd, f'extra{j}_1'); x = P.conv(x, w, b, act=ACT_RELU6)
         w, b = fold_conv_bn(wd, f'extra{j}_2'); x = P.conv(x, w, b, stride=2, act=ACT_RELU6)

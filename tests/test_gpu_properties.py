@@ -290,3 +290,19 @@ def test_weight_stationary_kernel_gives_the_same_bits(batch):
         assert r.returncode == 0, r.stderr[-2000:]
         sums.append(re.search(r'sha (\S+)', r.stdout).group(1))
     assert sums[0] == sums[1], sums
+
+
+def test_pointwise_plus_next_depthwise_in_one_launch_gives_the_same_bits():
+    """conv_ws_dw_k: from a batch that splits into whole frames per worker (256 frames on 128 workers) the pointwise layers of
+    MobileNet blocks 6-10 and 12 run with the next block's depthwise 3x3 folded into their epilogue (the pointwise output lives
+    in a per-wave LDS ring); DD_WS_DW_OFF=1 keeps the two launches.  Same bits."""
+    import os, re, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sums = []
+    for off in ('0', '1'):
+        env = dict(os.environ, DD_WS_DW_OFF=off)
+        r = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'time_forward.py'), 'ssd', '256'], capture_output=True,
+                           text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        sums.append(re.search(r'sha (\S+)', r.stdout).group(1))
+    assert sums[0] == sums[1], sums
