@@ -2260,9 +2260,12 @@ struct DwP {
 // Workers own whole frames (the pixel stream of a worker is contiguous, so the ring just keeps turning across frames);
 // four LDS stages instead of eight leave room for the rings at two blocks per CU (+0.5 % on the SSD forward by itself).
 // Same summation orders as conv_glds_k / conv_ws_k and dwconv3_k: same bits as the two launches.
-constexpr int WSD_RING = 128;
+// The ring has 128 slots per channel group plus 48 that mirror slots 0..47: the nine taps of a pixel then sit at compile-time
+// offsets (kh * W + kw) * 16 from the slot of its top-left tap with no wrap-around arithmetic -- the depthwise step is 72
+// multiply-adds, 18 LDS reads, nine address selects (an invalid tap points at a zero chunk) and little else.
+constexpr int WSD_RING = 128, WSD_MIRROR = 48, WSD_SLOTS = WSD_RING + WSD_MIRROR;
 
-template <int KS, int ACT, int DACT>
+template <int KS, int WMAP, int ACT, int DACT>
 __global__ __launch_bounds__(256, 2) void conv_ws_dw_k(const ConvP P, const DwP Q, const int n_slices, const int n_frames) {
     constexpr int NW = 4, D = 4, BM = WS_BM, MI = 4, NI = 2, G = 8 / NW;
     static_assert((KS & (KS - 1)) == 0 && KS % 2 == 0 && KS >= D, "stage arithmetic uses masks");
@@ -2273,13 +2276,15 @@ __global__ __launch_bounds__(256, 2) void conv_ws_dw_k(const ConvP P, const DwP 
     const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
     const int slice = jb % n_slices, worker = (jb / n_slices) * 8 + xcd;
     const int n_workers = ((int)(gridDim.x >> 3) / n_slices) * 8;
-    const int HW = Q.H * Q.W, Wm = Q.W, Hm = Q.H, L = Wm + 1;
+    constexpr int Wm = WMAP, L = Wm + 1;
+    static_assert(2 * WMAP + 2 < WSD_MIRROR && 64 + 2 * (WMAP + 1) <= WSD_RING, "ring sizes");
+    const int HW = Q.H * Wm, Hm = Q.H;
     const int f0 = (int)((long long)worker * n_frames / n_workers), f1 = (int)((long long)(worker + 1) * n_frames / n_workers);
     const int px0 = f0 * HW, px1 = f1 * HW;                        // this worker's pixels (whole frames)
     const int ntiles = (px1 - px0 + BM - 1) / BM;
     const int cbase = slice * (32 * NW) + wave * 32;
-    _Float16 *yring = lds + D * BM * 64 + wave * (4 * WSD_RING * 8);
-    _Float16 *zchunk = lds + D * BM * 64 + NW * (4 * WSD_RING * 8), *dwt = zchunk + 8;      // zero chunk | depthwise taps [9][128 channels of the slice]
+    _Float16 *yring = lds + D * BM * 64 + wave * (4 * WSD_SLOTS * 8);
+    _Float16 *zchunk = lds + D * BM * 64 + NW * (4 * WSD_SLOTS * 8), *dwt = zchunk + 8;      // zero chunk | depthwise taps [9][128 channels of the slice]
     if (tid < 8) zchunk[tid] = (_Float16)0.f;
     if (tid < 9 * 16) {                                         // (an ordinary global load inside the loop would make hipcc drain the fill queue at its use)
         const int t = tid >> 4, c8 = tid & 15;
@@ -2326,47 +2331,52 @@ __global__ __launch_bounds__(256, 2) void conv_ws_dw_k(const ConvP P, const DwP 
     const f4 db0 = *reinterpret_cast<const f4 *>(Q.bias + cbase + fq * 8), db1 = *reinterpret_cast<const f4 *>(Q.bias + cbase + fq * 8 + 4);
     const int x_step = 16 % Wm, y_step = 16 / Wm;                 // what 16 pixels further means for (y, x)
     const char *lds_c = reinterpret_cast<const char *>(lds);
-    const unsigned ring_b = (unsigned)((yring - lds) * 2) + (unsigned)fq * (WSD_RING * 16), zero_b = (unsigned)((zchunk - lds) * 2);
-    auto dw_pass = [&](int p_lo) {
-        const _Float16 *wtap = dwt + wave * 32 + fq * 8;           // this lane's taps (its channel group): re-read per use, 36 registers short
-        // (y, x) of the lane's first pixel by division, of the following three by stepping
-        int q = p_lo + fr;
-        const unsigned qc = (unsigned)(q + HW);                  // one frame up: the first pass starts a row + a pixel before the stream (never stored,
-        const unsigned f = __umulhi(qc, inv_hw), r = qc - f * (unsigned)HW;      // but its coordinates must step into the first real pixels correctly)
-        int y = (int)__umulhi(r, inv_w), x = (int)r - y * Wm;
-#pragma unroll 1
-        for (int step = 0; step < 4; ++step) {
-            const bool live = q >= px0 && q < px1;
-            // all nine reads first (taps outside the frame read the zero chunk), then the 72 multiply-adds.  32-bit LDS byte
-            // offsets throughout: ring slot of pixel p is (p - px0) & 127, 16 bytes each, plane fq
-            const unsigned rb = (unsigned)(q - px0);
-            const bool top = y > 0, bot = y < Hm - 1, lef = x > 0, rig = x < Wm - 1;
-            h8 xv[9];
+    const unsigned ring_b = (unsigned)((yring - lds) * 2) + (unsigned)fq * (WSD_SLOTS * 16), zero_b = (unsigned)((zchunk - lds) * 2);
+    // The depthwise pass of a tile (64 pixels = four steps of 16) runs INSIDE the next tile's K loop, a step every KS / 4
+    // stages: its ~300 vector instructions issue while the matrix pipe works through the stage's 32 MFMAs instead of
+    // after them.  (The ring slots it reads are only overwritten by the next tile's epilogue, which comes after its K loop.)
+    const _Float16 *wtap = dwt + wave * 32 + fq * 8;               // this lane's taps (its channel group): re-read per use, 36 registers short
+    int dq = 0, dy = 0, dx = 0, dleft = 0;                        // pending pass: next pixel of this lane, its (y, x), steps left
+    auto dw_begin = [&](int p_lo) {                               // (y, x) of the lane's first pixel by division, the rest by stepping
+        dq = p_lo + fr;
+        const unsigned qc = (unsigned)(dq + HW);                 // one frame up: the first pass starts a row + a pixel before the stream (never
+        const unsigned f = __umulhi(qc, inv_hw), r = qc - f * (unsigned)HW;      // stored, but it must step into the first real pixels correctly)
+        dy = (int)__umulhi(r, inv_w); dx = (int)r - dy * Wm;
+        dleft = 4;
+    };
+    auto dw_step = [&]() {
+        if (dleft == 0) return;                                  // wave-uniform
+        --dleft;
+        const int q = dq, y = dy, x = dx;
+        const bool live = q >= px0 && q < px1;
+        // nine reads (taps outside the frame read the zero chunk), then the 72 multiply-adds.  32-bit LDS byte offsets: the
+        // top-left tap of pixel q sits in ring slot (q - px0 - L) & 127 of plane fq, tap (kh, kw) 16 * (kh * W + kw) bytes on
+        const unsigned p_tl = ring_b + (((unsigned)(q - px0 - L)) & (WSD_RING - 1)) * 16u;
+        const bool top = y > 0, bot = y < Hm - 1, lef = x > 0, rig = x < Wm - 1;
+        float a[8];
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
+        for (int i = 0; i < 4; ++i) { a[i] = db0[i]; a[4 + i] = db1[i]; }
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const bool ok = (kh == 0 ? top : kh == 2 ? bot : true) && (kw == 0 ? lef : kw == 2 ? rig : true);
-                    const unsigned off = ((rb + (unsigned)((kh - 1) * Wm + (kw - 1))) & (WSD_RING - 1)) * 16u + ring_b;
-                    xv[kh * 3 + kw] = *reinterpret_cast<const h8 *>(lds_c + (ok ? off : zero_b));
-                }
-#if defined(__HIP_DEVICE_COMPILE__)
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-            float a[8];
+        for (int kh = 0; kh < 3; ++kh) {
+            h8 xv[3];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { a[i] = db0[i]; a[4 + i] = db1[i]; }
+            for (int kw = 0; kw < 3; ++kw) {
+                constexpr int dummy = 0; (void)dummy;
+                const bool ok = (kh == 0 ? top : kh == 2 ? bot : true) && (kw == 0 ? lef : kw == 2 ? rig : true);
+                const unsigned toff = (unsigned)(kh * Wm + kw) * 16u;                  // compile-time: becomes the ds_read offset
+                xv[kw] = *reinterpret_cast<const h8 *>(lds_c + (ok ? p_tl : zero_b - toff) + toff);
+            }
 #pragma unroll
-            for (int t = 0; t < 9; ++t) dw_tap(a, xv[t], *reinterpret_cast<const h8 *>(wtap + t * 128));
-            h8 o;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) o[i] = (_Float16)apply_act(a[i], DACT);
-            if (live) *reinterpret_cast<h8 *>(Q.out + (size_t)q * Q.cs_out + Q.coff_out + cbase + fq * 8) = o;
-            q += 16;
-            x += x_step; y += y_step;
-            if (x >= Wm) { x -= Wm; ++y; }
-            if (y >= Hm) y -= Hm;                                // into the next frame
+            for (int kw = 0; kw < 3; ++kw) dw_tap(a, xv[kw], *reinterpret_cast<const h8 *>(wtap + (kh * 3 + kw) * 128));
         }
+        h8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (_Float16)apply_act(a[i], DACT);
+        if (live) *reinterpret_cast<h8 *>(Q.out + (size_t)q * Q.cs_out + Q.coff_out + cbase + fq * 8) = o;
+        dq += 16;
+        dx += x_step; dy += y_step;
+        if (dx >= Wm) { dx -= Wm; ++dy; }
+        if (dy >= Hm) dy -= Hm;                                  // into the next frame
     };
 
     for (int st = 0; st < D - 1; ++st) fill(st);
@@ -2381,6 +2391,8 @@ __global__ __launch_bounds__(256, 2) void conv_ws_dw_k(const ConvP P, const DwP 
         for (int ks = 0; ks < KS; ++ks) {
             const int st = ti * KS + ks;
 #if defined(__HIP_DEVICE_COMPILE__)
+            // (the depthwise steps' stores count in vmcnt too: the wait is the store-free count, i.e. at most one fill stricter than
+            // needed; an exact count with an unconditional store per step -- lanes without a pixel writing to a dump -- was slower)
             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(G * (D - 3)) : "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -2398,8 +2410,9 @@ __global__ __launch_bounds__(256, 2) void conv_ws_dw_k(const ConvP P, const DwP 
 #pragma unroll
                 for (int b = 0; b < MI; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks * 2 + 1][a], xb[b], acc[a][b], 0, 0, 0);
+            if ((ks + 1) % (KS / 4) == 0) dw_step();             // the previous tile's depthwise pass, a quarter at a time
         }
-        // pointwise epilogue into the ring (bias, activation, f16: conv_epilogue_f16x8's arithmetic), then the depthwise pass
+        // pointwise epilogue into the ring (bias, activation, f16: conv_epilogue_f16x8's arithmetic)
 #pragma unroll
         for (int b = 0; b < MI; ++b) {
             h8 yv;
@@ -2408,12 +2421,16 @@ __global__ __launch_bounds__(256, 2) void conv_ws_dw_k(const ConvP P, const DwP 
                 yv[r] = (_Float16)apply_act(acc[0][b][r] + pb0[r], ACT);
                 yv[4 + r] = (_Float16)apply_act(acc[1][b][r] + pb1[r], ACT);
             }
-            *reinterpret_cast<h8 *>(yring + (fq * WSD_RING + ((ti * BM + b * 16 + fr) & (WSD_RING - 1))) * 8) = yv;
+            const int slot = (ti * BM + b * 16 + fr) & (WSD_RING - 1);
+            *reinterpret_cast<h8 *>(yring + (fq * WSD_SLOTS + slot) * 8) = yv;
+            if (slot < WSD_MIRROR) *reinterpret_cast<h8 *>(yring + (fq * WSD_SLOTS + slot + WSD_RING) * 8) = yv;
             acc[0][b] = acc[1][b] = f4{0.f, 0.f, 0.f, 0.f};
         }
-        dw_pass(px0 + ti * BM - L);
+        dw_begin(px0 + ti * BM - L);
     }
-    dw_pass(px0 + ntiles * BM - L);                              // the last map row + pixel of the worker's last frame
+    for (int i = 0; i < 4; ++i) dw_step();                       // the last tile's pass,
+    dw_begin(px0 + ntiles * BM - L);                             // then the last map row + pixel of the worker's last frame
+    for (int i = 0; i < 4; ++i) dw_step();
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the look-ahead fills past the last tile
 #endif
@@ -3026,7 +3043,7 @@ bool ws_dw_fusable(const ConvP &P, const DwP &Q, int nimg) {
     static const bool off = getenv("DD_WS_DW_OFF") && atoi(getenv("DD_WS_DW_OFF")) != 0;
     if (off || !ws_eligible(P) || P.act != ACT_RELU6 || Q.act != ACT_RELU6 || Q.stride != 1 || Q.pad_t != 1 || Q.pad_l != 1) return false;
     if (Q.in != static_cast<const _Float16 *>(P.out) || Q.coff_in || Q.cs_in != P.cs_out || P.coff_out || Q.H != P.ho || Q.W != P.wo ||
-        Q.ho != Q.H || Q.wo != Q.W || Q.c != P.cout || P.cout != P.cout_pad || 64 + 2 * (Q.W + 1) > WSD_RING || (long long)nimg * Q.H * Q.W >= (1 << 23))
+        Q.ho != Q.H || Q.wo != Q.W || Q.c != P.cout || P.cout != P.cout_pad || (Q.W != 19 && Q.W != 10) || (long long)nimg * Q.H * Q.W >= (1 << 23))
         return false;
     const int n_slices = P.cout_pad / 128, n_workers = (512 / 8 / n_slices) * 8;
     if (n_slices < 1 || (512 / 8) % n_slices) return false;
@@ -3034,19 +3051,19 @@ bool ws_dw_fusable(const ConvP &P, const DwP &Q, int nimg) {
     return (double)nimg / ((double)per * n_workers) >= 0.85;
 }
 
-template <int KS>
+template <int KS, int WMAP>
 int launch_conv_ws_dw(hipStream_t s, ConvP &P, const DwP &Q, int nimg, int device) {
     constexpr int NW = 4, D = 4;
     const int n_slices = P.cout_pad / (32 * NW);
     P.splitk = 1;
-    constexpr size_t lds_bytes = ((size_t)D * WS_BM * 64 + NW * 4 * WSD_RING * 8 + 8 + 9 * 128) * sizeof(_Float16);
+    constexpr size_t lds_bytes = ((size_t)D * WS_BM * 64 + NW * 4 * WSD_SLOTS * 8 + 8 + 9 * 128) * sizeof(_Float16);
     static DevOnce once;
     const int rc = once.run(device, [&]() -> int {
-        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_ws_dw_k<KS, ACT_RELU6, ACT_RELU6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_ws_dw_k<KS, WMAP, ACT_RELU6, ACT_RELU6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         return DD_OK;
     });
     if (rc != DD_OK) return rc;
-    hipLaunchKernelGGL((conv_ws_dw_k<KS, ACT_RELU6, ACT_RELU6>), dim3(512), dim3(NW * 64), lds_bytes, s, P, Q, n_slices, nimg);
+    hipLaunchKernelGGL((conv_ws_dw_k<KS, WMAP, ACT_RELU6, ACT_RELU6>), dim3(512), dim3(NW * 64), lds_bytes, s, P, Q, n_slices, nimg);
     DD_LAUNCH_CHECK();
     return DD_OK;
 }
@@ -3486,7 +3503,8 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
                 if (pw_pending) {
                     pw_pending = false;
                     if (ws_dw_fusable(pw_p, P, nimg)) {
-                        const int rc = pw_p.cin == 256 ? launch_conv_ws_dw<4>(s, pw_p, P, nimg, net->ctx->device) : launch_conv_ws_dw<8>(s, pw_p, P, nimg, net->ctx->device);
+                        const int rc = P.W == 10 ? (pw_p.cin == 256 ? launch_conv_ws_dw<4, 10>(s, pw_p, P, nimg, net->ctx->device) : launch_conv_ws_dw<8, 10>(s, pw_p, P, nimg, net->ctx->device))
+                                                 : (pw_p.cin == 256 ? launch_conv_ws_dw<4, 19>(s, pw_p, P, nimg, net->ctx->device) : launch_conv_ws_dw<8, 19>(s, pw_p, P, nimg, net->ctx->device));
                         if (rc != DD_OK) return rc;
                         net->op_launch[i] = OPK_WS_DW;
                         break;
