@@ -34,7 +34,7 @@ if ROOT not in sys.path:
 
 N_OBJ = 20
 CONFIGS = {
-    2: dict(W=640, H=480, model='synthetic-ssd_mobilenet_v1', streams=1024, groups=4,
+    2: dict(W=640, H=480, model='synthetic-ssd_mobilenet_v1', streams=1536, groups=4,
             workload='SSD-MobileNet-v1 (300x300) + MARS-64x32x3 + deep_sort on synthetic 640x480 BGR frames, '
                      '~20 synthetic detections/frame (BASELINE.json configs[1])'),
     3: dict(W=640, H=640, model='synthetic-yolov5s-fp16', streams=64, groups=2,

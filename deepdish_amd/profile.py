@@ -128,9 +128,10 @@ def dominant_kernel_roofline(pipes, step_group, args, reps=20):
     per_kernel = {n: round(v['ms'], 5) for n, v in sorted(acc.items(), key=lambda kv: -kv[1]['ms'])}
     # the dense-convolution GEMMs are one family: conv_ws_k runs the large pointwise layers from 160 images per launch,
     # conv_glds_k the rest and all of them below that (same layers, same arithmetic, batch-dependent choice)
-    if 'conv_glds_k' in acc and 'conv_ws_k' in acc:
-        a, b = acc.pop('conv_glds_k'), acc.pop('conv_ws_k')
-        acc['conv_glds_k+conv_ws_k'] = {f: a[f] + b[f] for f in ('ms', 'flops', 'bytes', 'launches')}
+    fam = [n for n in ('conv_glds_k', 'conv_ws_k', 'conv_ws_dw_k') if n in acc]     # conv_ws_dw_k: conv_ws_k with the next depthwise layer in its epilogue
+    if len(fam) > 1:
+        parts = [acc.pop(n) for n in fam]
+        acc['+'.join(fam)] = {f: sum(p[f] for p in parts) for f in ('ms', 'flops', 'bytes', 'launches')}
     name, k = max(acc.items(), key=lambda kv: kv[1]['ms'])
     sec = k['ms'] * 1e-3
     avg_us = 1e3 * k['ms'] / max(k['launches'], 1e-9)
