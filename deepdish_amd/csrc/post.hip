@@ -37,9 +37,17 @@ __global__ __launch_bounds__(256) void ssd_decode_k(const float *__restrict__ ra
     const float *r = raw + (size_t)(live ? a : 0) * (4 + n_classes);
     float best = -__builtin_inff();
     int bi = 0x7fffffff;
-    for (int c = 1 + sub; c < n_classes; c += 16) {           // class 0 = background
-        const float v = r[4 + c];
-        if (v > best) { best = v; bi = c - 1; }
+    // all loads of a sweep first (8 x 16 classes per pass): in a load-compare loop hipcc waits for every load before the next
+    // one is issued (PMC: 76 % of the wave cycles parked on s_waitcnt) -- out-of-range slots re-read the lane's first class
+    for (int c0 = 1 + sub; c0 < n_classes; c0 += 128) {       // class 0 = background
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = r[4 + (c0 + 16 * i < n_classes ? c0 + 16 * i : c0)];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = c0 + 16 * i;
+            if (c < n_classes && v[i] > best) { best = v[i]; bi = c - 1; }
+        }
     }
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) {
