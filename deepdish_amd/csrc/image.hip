@@ -277,6 +277,17 @@ __global__ __launch_bounds__(256) void band_resample_wide_k(const uint8_t *__res
         for (int p = 0; p < 3; ++p) cf[ks][p] = coef[((size_t)(g * KS + ks) * 3 + p) * 64 + lane];
     const int col = g * 16 + fr;
     const int b = col < C ? bias[col] : 0;
+    // Which 16-byte chunks of the window does any of the group's 16 columns use?  This lane supplies chunk fq of every k step to
+    // the MFMAs, and the coefficient lanes of chunk fq are its own 16-lane row: a chunk whose coefficients are all zero (the tail
+    // of a window that is rounded up to whole 64-byte steps) is not loaded -- the kernel is bound by the number of 16-byte row
+    // pieces it pulls through the texture path (PMC: 56 % of its wave cycles parked on s_waitcnt, 6 % issuing).
+    bool need[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const i4v o = cf[ks][0] | cf[ks][1] | cf[ks][2];
+        const unsigned long long m = __ballot((o[0] | o[1] | o[2] | o[3]) != 0);
+        need[ks] = ((m >> (fq * 16)) & 0xFFFFull) != 0;
+    }
     const uint8_t *base = src + bz * src_img_stride + start[g] + fq * 16;
     uint8_t *obase = outT + bz * out_img_stride + (size_t)col * pitch_o + fq * 16;
     const int r_first = by * tiles_per_chunk * 64;              // tiles_per_chunk counts 64-row iterations here
@@ -291,7 +302,8 @@ __global__ __launch_bounds__(256) void band_resample_wide_k(const uint8_t *__res
             i4v a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                i4v x = *reinterpret_cast<const i4v *>(p + ks * 64);
+                i4v x = {0, 0, 0, 0};
+                if (need[ks]) x = *reinterpret_cast<const i4v *>(p + ks * 64);
                 x ^= (int)0x80808080;                            // u8 -> i8: p - 128
                 a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, cf[ks][0], a0, 0, 0, 0);
                 a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, cf[ks][1], a1, 0, 0, 0);
