@@ -28,7 +28,7 @@ enum { OP_INPUT = 1, OP_CONV = 2, OP_DWCONV = 3, OP_MAXPOOL = 4, OP_UPSAMPLE = 5
 enum { ACT_NONE = 0, ACT_RELU6 = 1, ACT_ELU = 2, ACT_SILU = 3, ACT_RELU = 4, ACT_SIGMOID = 5 };
 enum { EPI_F16 = 0, EPI_F32 = 1, EPI_SSD_HEAD = 2, EPI_YOLO = 3 };
 // dd_net_op_launches: 0 = the op's own kernel, 1 = no launch (folded into the next op's), else the fused / special kernel
-enum { OPK_DEFAULT = 0, OPK_FOLDED = 1, OPK_POOL_ROWS = 2, OPK_POOL_ROWS_STEM = 3, OPK_RES_UNIT = 4, OPK_SSD_FRONT = 5, OPK_C64_ROWS = 6, OPK_S2_ROWS = 7, OPK_CONV_WS = 8, OPK_WS_DW = 9 };
+enum { OPK_DEFAULT = 0, OPK_FOLDED = 1, OPK_POOL_ROWS = 2, OPK_POOL_ROWS_STEM = 3, OPK_RES_UNIT = 4, OPK_SSD_FRONT = 5, OPK_C64_ROWS = 6, OPK_S2_ROWS = 7, OPK_CONV_WS = 8, OPK_WS_DW = 9, OPK_DWPW_ROWS = 10 };
 enum { DT_F16 = 0, DT_F32 = 1, DT_U8 = 2 };
 
 constexpr int OP_WORDS = 48;       // int32 words per op record (see deepdish_amd/nets.py)
@@ -1757,6 +1757,124 @@ __global__ __launch_bounds__(256, 2) void ssd_front_k(const ConvP PS, const Conv
 }
 
 // ---------------------------------------------------------------------------------------------------
+// MobileNet block with 128 -> 128 channels (depthwise 3x3 stride 1 + pointwise; block 3 of the SSD at 75x75) as strips
+// streamed by single waves, like ssd_front_k: a wave owns 6 output columns (8 input columns) of a row range of one frame
+// and produces two output rows per round -- one 16-pixel MFMA fragment.  Input rows arrive by global_load_lds (a row
+// slot is [8 pixels][16 channel groups] x 16 B = 2 KiB, two DMAs, a pixel's 256 bytes contiguous on both sides); the
+// depthwise stage is dwpw_k's arithmetic with three output pixels per lane (lane = channel group x (row, half)), its
+// f16 result goes into a [channel group][17 pixel slots] operand tile (the odd pitch keeps the 16 writing lanes on 16
+// different bank groups), the pointwise stage is 4 k slices x 8 fragments with the whole 128 x 128 filter in registers.
+// dwpw_k runs this block at 3.2 TB/s of algorithmic traffic with 44 % of its wave cycles parked on memory.
+constexpr int DR_SW = 6, DR_SLOTS = 6, DR_ROW = 8 * 16 * 8, DR_XT = 16 * 17 * 8;        // halves
+constexpr int dr_wave_halves() { return DR_SLOTS * DR_ROW + DR_XT; }
+
+template <int ACT>
+__global__ __launch_bounds__(256, 2) void dwpw_rows_k(const ConvP P, const int n_tasks, const int parts) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    _Float16 *ring = lds + (size_t)wave * dr_wave_halves(), *xt = ring + DR_SLOTS * DR_ROW;
+    _Float16 *dwt = lds + 4 * dr_wave_halves();                  // block-shared: depthwise taps [9][128] f16, then biases (f32)
+    float *dwb = reinterpret_cast<float *>(dwt + 9 * 128), *pwb = dwb + 128;
+    if (tid < 9 * 16) *reinterpret_cast<h8 *>(dwt + tid * 8) = *reinterpret_cast<const h8 *>(P.dw_w + (size_t)(tid >> 4) * 128 + (tid & 15) * 8);
+    if (tid < 128) { dwb[tid] = P.dw_bias[tid]; pwb[tid] = P.bias[tid]; }
+    __syncthreads();
+
+    h8 wp[4][8];                                                  // [k slice][fragment]: the pointwise filter
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int a = 0; a < 8; ++a) wp[ks][a] = *reinterpret_cast<const h8 *>(P.w + (size_t)rw_weight_row(a, fr) * P.kpad + ks * 32 + fq * 8);
+    Epi8 E;                                                       // the epilogue takes no constants (bias in the accumulators, no second output)
+    E.b0 = E.b1 = E.s0 = E.s1 = E.t0 = E.t1 = f4{0.f, 0.f, 0.f, 0.f};
+    const int H = P.H, W = P.W;
+    const int strips = (W + DR_SW - 1) / DR_SW;
+    // depthwise item of this lane: channel group cg, output row dj of the pair, pixels 3 * dh .. 3 * dh + 2
+    const int cg = lane & 15, dj = lane >> 5, dh = (lane >> 4) & 1;
+    // pointwise fragment pixel of this lane: row pj of the pair, column px
+    const int pj = fr >> 3, px = fr & 7;
+
+    for (int task = blockIdx.x * 4 + wave; task < n_tasks; task += gridDim.x * 4) {
+        const int part = task % parts, t2 = task / parts;
+        const int strip = t2 % strips, n = t2 / strips;
+        const int x0 = strip * DR_SW;
+        int y0 = (int)((long long)part * H / parts), y1 = (int)((long long)(part + 1) * H / parts);
+        y0 &= ~1; if (part + 1 < parts) y1 &= ~1;                 // parts start on even rows (rounds are row pairs)
+        const _Float16 *img = P.in + (size_t)n * H * W * P.cs_in + P.coff_in;
+        auto fill_row = [&](int y) {                              // wave-uniform y; outside the map: zero lines
+            _Float16 *dst = ring + ((y + 1) % DR_SLOTS) * DR_ROW;
+            const bool rok = (unsigned)y < (unsigned)H;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int pxl = 4 * k + (lane >> 4), xin = x0 - 1 + pxl;
+                const bool ok = rok && (unsigned)xin < (unsigned)W;
+                lds_fill16(ok ? img + ((size_t)y * W + xin) * P.cs_in + (lane & 15) * 8 : P.zero, dst + 512 * k);
+            }
+        };
+        fill_row(y0 - 1); fill_row(y0); fill_row(y0 + 1); fill_row(y0 + 2);
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        for (int y = y0; y < y1; y += 2) {
+            fill_row(y + 3); fill_row(y + 4);
+            // ---- depthwise rows y, y+1: this lane's row y + dj, output pixels 3 dh .. 3 dh + 2 = input pixel slots 3 dh .. 3 dh + 4
+            {
+                float acc[3][8];
+                const f4 b0 = *reinterpret_cast<const f4 *>(dwb + cg * 8), b1 = *reinterpret_cast<const f4 *>(dwb + cg * 8 + 4);
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { acc[i][c] = b0[c]; acc[i][4 + c] = b1[c]; }
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    const _Float16 *rs = ring + ((y + dj + kh) % DR_SLOTS) * DR_ROW + (3 * dh * 16 + cg) * 8;      // map row y + dj + kh - 1
+                    h8 xv[5];
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) xv[c] = *reinterpret_cast<const h8 *>(rs + c * 16 * 8);
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const h8 wv = *reinterpret_cast<const h8 *>(dwt + (kh * 3 + kw) * 128 + cg * 8);
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) dw_tap(acc[i], xv[i + kw], wv);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    h8 o;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) o[c] = (_Float16)apply_act(acc[i][c], ACT);
+                    *reinterpret_cast<h8 *>(xt + (cg * 17 + dj * 8 + 3 * dh + i) * 8) = o;
+                }
+            }
+            // ---- pointwise rows y, y+1: [16 pixel slots] x [128 channels] x 128, from the bias
+            f4 acc[8];
+#pragma unroll
+            for (int a = 0; a < 8; ++a) acc[a] = *reinterpret_cast<const f4 *>(pwb + (a >> 1) * 32 + fq * 8 + (a & 1) * 4);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const h8 xf = *reinterpret_cast<const h8 *>(xt + ((ks * 4 + fq) * 17 + fr) * 8);
+#pragma unroll
+                for (int a = 0; a < 8; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wp[ks][a], xf, acc[a], 0, 0, 0);
+            }
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // next round's rows have landed, last round's stores have retired
+#endif
+            if (px < DR_SW && x0 + px < W && y + pj < y1) {
+                const int m = (n * H + y + pj) * W + x0 + px;
+#pragma unroll
+                for (int g2 = 0; g2 < 4; ++g2) {
+                    float o[8];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { o[c] = acc[2 * g2][c]; o[4 + c] = acc[2 * g2 + 1][c]; }
+                    conv_epilogue_f16x8<ACT, false, 0, false, false>(P, E, m, g2 * 32 + fq * 8, o);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // MobileNet block in one launch: depthwise 3x3 (+bias, activation) -> pointwise 1x1 (+bias, activation).
 // The depthwise result of a pixel tile never leaves the CU: it is rounded to f16 (exactly what the
 // two-kernel path stores) into the LDS image the MFMA fragments are read from, so the layer pair
@@ -2963,6 +3081,37 @@ int launch_stem(hipStream_t s, ConvP &P, int nimg) {
     return DD_OK;
 }
 
+bool dwpw_rows_eligible(const ConvP &P, int nimg) {
+    static const bool off = getenv("DD_DWPW_ROWS_OFF") && atoi(getenv("DD_DWPW_ROWS_OFF")) != 0;
+    static const int min_img = getenv("DD_DWPW_ROWS_MIN") ? atoi(getenv("DD_DWPW_ROWS_MIN")) : 96;     // 64 frames: 745 vs 741 us for the whole forward; 384: 2767 vs 2859
+    return !off && nimg >= min_img && P.cin == 128 && P.cout == 128 && P.cout_pad == 128 && P.kpad == 128 && P.stride == 1 && P.pad_t == 1 && P.pad_l == 1 &&
+           P.act == ACT_RELU6 && P.dw_act == ACT_RELU6 && P.ho == P.H && P.wo == P.W && !P.res && !P.out2 && P.cs_in % 8 == 0 && P.coff_in % 8 == 0;
+}
+
+int launch_dwpw_rows(hipStream_t s, const ConvP &P, int nimg, int device) {
+    const size_t lds_bytes = (size_t)(4 * dr_wave_halves() + 9 * 128) * sizeof(_Float16) + 2 * 128 * sizeof(float);
+    static DevOnce once;
+    const int rc = once.run(device, [&]() -> int {
+        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dwpw_rows_k<ACT_RELU6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        return DD_OK;
+    });
+    if (rc != DD_OK) return rc;
+    const int strips = dd_ceil_div(P.W, DR_SW);
+    static const int force_parts = getenv("DD_DWPW_ROWS_PARTS") ? atoi(getenv("DD_DWPW_ROWS_PARTS")) : 0;
+    int parts = 1;                                               // row parts per strip, as in launch_ssd_front
+    long long best = -1;
+    for (int p = 1; p <= 8; ++p) {
+        const long long rounds = ((long long)nimg * strips * p + 2047) / 2048, cost = rounds * (dd_ceil_div(P.H, p) + 3);
+        if (best < 0 || cost < best) { best = cost; parts = p; }
+    }
+    if (force_parts > 0) parts = force_parts;
+    const int n_tasks = nimg * strips * parts;
+    const int grid = std::min(dd_ceil_div(n_tasks, 4), 2 * 256);
+    hipLaunchKernelGGL((dwpw_rows_k<ACT_RELU6>), dim3((unsigned)grid), dim3(256), lds_bytes, s, P, n_tasks, parts);
+    DD_LAUNCH_CHECK();
+    return DD_OK;
+}
+
 template <int WM, int WN, int MI, int CIN, int STRIDE>
 int launch_dwpw(hipStream_t s, ConvP &P, int device) {
     constexpr int BM = WM * MI * 16, BN = WN * 64;
@@ -3483,6 +3632,7 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
                 }
                 if (P.cin == 32 && P.cout_pad == 64 && P.stride == 1) rc = launch_dwpw<4, 1, 4, 32, 1>(s, P, net->ctx->device);
                 else if (P.cin == 64 && P.cout_pad == 128 && P.stride == 2) rc = launch_dwpw<2, 2, 4, 64, 2>(s, P, net->ctx->device);
+                else if (dwpw_rows_eligible(P, nimg)) { net->op_launch[i] = OPK_DWPW_ROWS; rc = launch_dwpw_rows(s, P, nimg, net->ctx->device); }
                 else if (P.cin == 128 && P.cout_pad == 128 && P.stride == 1) rc = launch_dwpw<2, 2, 2, 128, 1>(s, P, net->ctx->device);
                 else if (P.cin == 128 && P.cout_pad == 256 && P.stride == 2) rc = launch_dwpw<1, 4, 4, 128, 2>(s, P, net->ctx->device);
                 else if (P.cin >= 256 && P.cin % 64 == 0 && P.cin <= 1024 && P.cout_pad % DWB_BN == 0 && P.kpad == P.cin)
