@@ -117,28 +117,42 @@ def _gen_stream(job):
     return frames, per
 
 
-def make_inputs(rank, world, streams, n_frames, W, H, sink):
-    """Seeded frames and injected detections of every stream (untimed).  sink(s, frames u8 [F, H, W, 3]) places a
-    stream's frames (HBM tensor slice or pinned slot) as soon as a worker delivers them, so the host never holds
-    more than the few streams in flight; returns the per-stream per-frame detections."""
-    import multiprocessing as mp
-    dets = [None] * streams
-    seed_rank = int(os.environ.get('DD_BENCH_SEED_RANK', rank))     # tests: a single-GPU run of the streams rank k would own
-    jobs = [(1000 * seed_rank + s, n_frames, W, H) for s in range(streams)]
-    # the ranks of one node share its cores: each rank takes its share of half of them
+def gen_workers(world, streams):
+    """Generator processes of this rank: the ranks of one node share its cores, each rank takes its share of half of them."""
     workers = max(1, min(16, (os.cpu_count() or 2) // (2 * max(1, world)), streams))
     if os.environ.get('DD_BENCH_GEN_WORKERS'):          # 1 = generate in-process: under `rocprofv3 --pmc` the profiler has
         workers = int(os.environ['DD_BENCH_GEN_WORKERS'])   # initialised the GPU before main(), and worker processes may not be exec'ed
-    if workers > 1:
-        with mp.get_context('spawn').Pool(workers) as pool:
-            for s, (fr, per) in enumerate(pool.imap(_gen_stream, jobs)):
-                sink(s, fr)
-                dets[s] = per
-    else:
-        for s, job in enumerate(jobs):
-            fr, per = _gen_stream(job)
-            sink(s, fr)
-            dets[s] = per
+    return workers
+
+
+def host_threads(world, groups):
+    """Threads of the C++ pipeline's host pool (csrc/hostpool.h: detector-adaptor filter, box hygiene, matching cascade + LSAP,
+    count line, one stream per task) for one rank: its share of the node's cores minus its worker-group threads and the main thread."""
+    return max(1, min(12, (os.cpu_count() or 2) // max(1, world) - groups - 1))
+
+
+def start_gen_pool(world, streams):
+    """The generator pool, started BEFORE this process touches the GPU (torch.cuda.set_device, RCCL init, the first HIP call):
+    a process that has initialised the GPU must not start children on this pool, and N ranks doing so together is where it hurts."""
+    import multiprocessing as mp
+    workers = gen_workers(world, streams)
+    return mp.get_context('spawn').Pool(workers) if workers > 1 else None
+
+
+def make_inputs(pool, rank, streams, n_frames, W, H, sink):
+    """Seeded frames and injected detections of every stream (untimed).  sink(s, frames u8 [F, H, W, 3]) places a
+    stream's frames (HBM tensor slice or pinned slot) as soon as a worker delivers them, so the host never holds
+    more than the few streams in flight; returns the per-stream per-frame detections."""
+    dets = [None] * streams
+    seed_rank = int(os.environ.get('DD_BENCH_SEED_RANK', rank))     # tests: a single-GPU run of the streams rank k would own
+    jobs = [(1000 * seed_rank + s, n_frames, W, H) for s in range(streams)]
+    it = pool.imap(_gen_stream, jobs) if pool is not None else map(_gen_stream, jobs)
+    for s, (fr, per) in enumerate(it):
+        sink(s, fr)
+        dets[s] = per
+    if pool is not None:
+        pool.close()
+        pool.join()
     return dets
 
 
@@ -162,7 +176,13 @@ def cpu_baseline(n_frames, W, H, config=2):
     tracker = deep_sort NMS + predict / update + count line."""
     import torch
     from PIL import Image
-    from threadpoolctl import threadpool_limits
+    try:
+        from threadpoolctl import threadpool_limits
+    except ImportError:                                  # not a declared dependency: the numpy tracker then runs at the pool's default
+        import contextlib
+
+        def threadpool_limits(limits=None):
+            return contextlib.nullcontext()
     from deepdish_amd import nets
     from deepdish_amd.synth import Scene
     from oracle import deepsort_np as ds, countline_np as cl, image_np, nets_torch
@@ -248,21 +268,31 @@ def cpu_baseline(n_frames, W, H, config=2):
     return base, keep_for_parity
 
 
-def gpu_sample_check(sc, n_frames, oracle_counts, oracle_table, device, W, H, model):
-    """The HIP path over the very frames the CPU baseline just processed (seed 0, one stream): crossing counts and the
-    final track table (id, state, time_since_update, hits) must be identical."""
+def gpu_sample_check(sc, n_frames, oracle_counts, oracle_table, device, W, H, model, streams):
+    """The HIP path over the very frames the CPU baseline just processed (seed 0), at the LAUNCH SHAPE of the timed region: a
+    `streams`-stream pipeline (one worker group of the bench) in which every slot replays those frames, so the detector,
+    the encoder and the tracker kernels run at the batch sizes the headline was measured at.  Every stream must end with
+    the oracle's crossing counts and final track table (id, state, time_since_update, hits)."""
     import torch
     from deepdish_amd.multipipe import MultiStreamPipeline
-    mp1 = MultiStreamPipeline(1, model=model, input_size=(W, H))
+    mp1 = MultiStreamPipeline(streams, model=model, input_size=(W, H))
     for f in range(n_frames + 2):
         boxes, scores, _, _ = sc.detections(f)
-        inj = mp1.pack_injected([([tuple(int(v) for v in b) for b in boxes], ['person'] * len(boxes), [float(x) for x in scores])])
-        mp1.step(torch.from_numpy(sc.frame(f)[None]).to(device), inj)
-    ints, _ = mp1.tracker(0).table()
-    table = [tuple(int(v) for v in r[:4]) for r in ints]
-    counts = [int(v) for v in np.asarray(mp1.counts()[0]).reshape(-1)]
-    return dict(frames=n_frames + 2, counts_hip=counts, counts_oracle=oracle_counts,
-                identical=bool(counts == oracle_counts and table == oracle_table))
+        one = ([tuple(int(v) for v in b) for b in boxes], ['person'] * len(boxes), [float(x) for x in scores])
+        inj = mp1.pack_injected([one] * streams)
+        frames = torch.from_numpy(sc.frame(f)[None]).to(device).expand(streams, H, W, 3).contiguous()
+        mp1.step(frames, inj)
+    all_counts = mp1.counts()
+    bad = []
+    for z in range(streams):
+        ints, _ = mp1.tracker(z).table()
+        table = [tuple(int(v) for v in r[:4]) for r in ints]
+        counts = [int(v) for v in np.asarray(all_counts[z]).reshape(-1)]
+        if counts != oracle_counts or table != oracle_table:
+            bad.append(z)
+    counts0 = [int(v) for v in np.asarray(all_counts[0]).reshape(-1)]
+    return dict(frames=n_frames + 2, streams=streams, counts_hip=counts0, counts_oracle=oracle_counts,
+                identical=not bad, streams_that_differ=bad[:8])
 
 
 # ------------------------------------------------------------------------------------------------ rehearsal
@@ -285,10 +315,18 @@ def rehearse(args, rank, world, real_stdout):
         dist.barrier()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     counts = reduce_counts(local)
+    # what every rank would start on the host for the real run (its share of the node's cores)
+    G = max(1, min(args.groups, args.streams))
+    mine = dict(rank=rank, generator_processes=gen_workers(world, args.streams), worker_groups=G, host_pool_threads=host_threads(world, G))
+    budgets = [mine]
+    if dist.is_initialized():
+        budgets = [None] * world
+        dist.all_gather_object(budgets, mine)
     if rank == 0:
         out = {'metric': 'end-to-end frames/sec (detect+encode+track) at 640x480', 'value': None, 'unit': 'frames/s',
                'n_gpus': world, 'steps': 0, 'warmup': 0, 'rehearsal': 'launcher / rendezvous / count reduction only (gloo, CPU): '
-               'no frames processed, nothing measured', 'counts_pos_neg_int_del': [int(v) for v in counts.reshape(-1)]}
+               'no frames processed, nothing measured', 'counts_pos_neg_int_del': [int(v) for v in counts.reshape(-1)],
+               'host_cores': os.cpu_count(), 'per_rank_host': budgets}
         os.write(real_stdout, (json.dumps(out) + '\n').encode())
     if dist.is_initialized():
         dist.barrier()
@@ -314,6 +352,10 @@ def main():
         return rehearse(args, rank, world, real_stdout)
     cfg = CONFIGS[args.config]
     W, H = cfg['W'], cfg['H']
+    gen_pool = start_gen_pool(world, args.streams)          # before anything touches the GPU
+    G = max(1, min(args.groups, args.streams))
+    # host threads of the C++ pipeline's per-stream phases (csrc/hostpool.h): this rank's share of the cores minus its worker groups
+    os.environ.setdefault('DD_HOST_THREADS', str(host_threads(world, G)))
     import torch
     dist_on = world > 1 or ('RANK' in os.environ and 'MASTER_PORT' in os.environ)    # launched by torch.distributed.run
     # Rehearsal on a one-GPU box (tests/test_gpu_pipeline.py): DD_BENCH_ONE_DEVICE=1 puts every rank on device 0 and
@@ -337,7 +379,6 @@ def main():
     from deepdish_amd.multistream import reduce_counts
     from deepdish_amd.runtime import Context
     n_frames = args.warmup + args.steps
-    G = max(1, min(args.groups, args.streams))
     bounds = [round(g * args.streams / G) for g in range(G + 1)]
     ctxs = [Context(local_rank) for _ in range(G)]
     pipes = [MultiStreamPipeline(bounds[g + 1] - bounds[g], model=cfg['model'], input_size=(W, H), context=ctxs[g],
@@ -362,7 +403,7 @@ def main():
         def sink(s, fr):
             g = group_of[s]
             dev_frames[g][:, s - bounds[g]] = torch.from_numpy(fr).to(f'cuda:{local_rank}')
-    dets = make_inputs(rank, world, args.streams, n_frames, W, H, sink)
+    dets = make_inputs(gen_pool, rank, args.streams, n_frames, W, H, sink)
     injected = [[pipes[g].pack_injected([dets[s][f] for s in range(bounds[g], bounds[g + 1])]) for f in range(n_frames)]
                 for g in range(G)]
     torch.cuda.synchronize()
@@ -383,25 +424,43 @@ def main():
             pipes[g].step(dev_frames[g][f], injected[g][f],       # frame f+1 is queued behind this step's own detections
                           dev_frames[g][f + 1] if ahead and f + 1 < f1 else None)
 
-    def run_all(f0, f1):
-        if G == 1:
-            return run(0, f0, f1)
-        th = [threading.Thread(target=run, args=(g, f0, f1)) for g in range(G)]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
+    # Worker threads exist and have finished the warm-up before the clock starts: they park on `go`, the main thread
+    # synchronises the device (and the ranks), takes t0 and releases them -- no thread start inside the timed region.
+    warm = threading.Barrier(G + 1)
+    go = threading.Event()
+    errors = []
 
-    run_all(0, args.warmup)
+    def worker(g):
+        try:
+            run(g, 0, args.warmup)
+        except BaseException as e:                           # noqa: BLE001 -- reported by the main thread
+            errors.append(e)
+        warm.wait()
+        go.wait()
+        if errors:
+            return
+        try:
+            run(g, args.warmup, n_frames)
+        except BaseException as e:                           # noqa: BLE001
+            errors.append(e)
+
+    th = [threading.Thread(target=worker, args=(g,)) for g in range(G)]
+    for t in th:
+        t.start()
+    warm.wait()
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
     t0 = time.perf_counter()
-    run_all(args.warmup, n_frames)
+    go.set()
+    for t in th:
+        t.join()
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
     dt = time.perf_counter() - t0
+    if errors:
+        raise errors[0]
     stage_ms = pipes[0].stage_ms()
     local_counts = sum(p.counts().sum(axis=0) for p in pipes)
     tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
@@ -444,11 +503,22 @@ def main():
                 out['roofline'] = None
                 out['roofline_error'] = repr(e)
             if world == 1 and not args.no_cpu_baseline:
-                out['cpu_baseline'], (sc0, ocounts, otable) = cpu_baseline(args.cpu_frames, W, H, args.config)
-                try:
-                    out['parity_sample'] = gpu_sample_check(sc0, args.cpu_frames, ocounts, otable, f'cuda:{local_rank}', W, H, cfg['model'])
+                try:                                          # never let the extra passes hide the headline number
+                    out['cpu_baseline'], (sc0, ocounts, otable) = cpu_baseline(args.cpu_frames, W, H, args.config)
                 except Exception as e:
-                    out['parity_sample'] = dict(error=repr(e))
+                    out['cpu_baseline'] = None
+                    out['cpu_baseline_error'] = repr(e)
+                    sc0 = None
+                if sc0 is not None:
+                    try:
+                        per_group = bounds[1] - bounds[0]
+                        del injected, dev_frames
+                        pipes.clear()
+                        torch.cuda.empty_cache()
+                        out['parity_sample'] = gpu_sample_check(sc0, args.cpu_frames, ocounts, otable, f'cuda:{local_rank}', W, H,
+                                                                cfg['model'], per_group)
+                    except Exception as e:
+                        out['parity_sample'] = dict(error=repr(e))
         os.write(real_stdout, (json.dumps(out) + '\n').encode())
     if dist_on:
         dist.barrier()

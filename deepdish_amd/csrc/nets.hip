@@ -2770,7 +2770,8 @@ struct dd_net {
     int in_h = 0, in_w = 0, out_tensor = -1;
     bool profile = false;
     int last_batch = 0;
-    DevBuf slab;                             // split-K partial sums
+    DevBuf slab;                             // split-K partial sums (sized for max_batch: see launch_conv)
+    bool slab_moved = false;                 // the slab was reallocated during the last eager forward: captured graphs hold a dead pointer
     _Float16 *d_zero = nullptr;              // 256 bytes of zeros (padding taps of the direct-to-LDS fills)
     bool use_glds = true;
     bool use_rw = true;                      // DD_NO_RW=1: 3x3x32x32 layers fall back to the implicit-GEMM kernels (A/B measurements)
@@ -2797,11 +2798,25 @@ namespace {
 
 inline size_t dtype_size(int dt) { return dt == DT_F16 ? 2 : (dt == DT_F32 ? 4 : 1); }
 
+// K split of a dense conv layer (1 = none): a function of the layer shape and the engine's max_batch only.
+int conv_splitk(int ho, int wo, int cout_pad, int ksteps, int max_batch) {
+    int splitk = 1;
+    const int gy64 = dd_ceil_div(cout_pad, 64);
+    const int blocks_per_image = dd_ceil_div(ho * wo, 64) * gy64;
+    const long long blocks_full = (long long)dd_ceil_div(max_batch * ho * wo, 64) * gy64;
+    if (blocks_per_image <= 8 && ksteps >= 8 && blocks_full < 256) {        // fewer blocks than CUs at full batch
+        splitk = std::min(16, ksteps / 4);
+        const int per = dd_ceil_div(ksteps, splitk);
+        splitk = dd_ceil_div(ksteps, per);                    // no empty split
+    }
+    return splitk;
+}
+
 // Few blocks and a long K axis: split K over blockIdx.z so the chip is busy and each block's serial
 // chain of (load -> barrier -> MFMA) steps is short; partial sums go through an f32 slab.
 // GLDS selects the direct-to-LDS kernel (needs padded Cin % 64 == 0 and BK == 64).
 template <int WM, int WN, int MI, int NI, int BK, bool GLDS>
-int launch_conv(hipStream_t s, ConvP &P, DevBuf &slab, int max_batch, int device) {
+int launch_conv(hipStream_t s, ConvP &P, DevBuf &slab, int max_batch, int device, bool *slab_moved = nullptr) {
     constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
     const int gx = dd_ceil_div(P.m, BM), gy = dd_ceil_div(P.cout_pad, BN);
     const int ksteps = P.kpad / BK;
@@ -2811,20 +2826,17 @@ int launch_conv(hipStream_t s, ConvP &P, DevBuf &slab, int max_batch, int device
     // and the f32 partial-sum slabs (splitk x the layer output, written and re-read) would dominate.
     // Counted in 64 x 64 tiles whatever tile this launch uses: the tile is picked from the batch of the call,
     // the split must not be.
-    int splitk = 1;
-    const int gy64 = dd_ceil_div(P.cout_pad, 64);
-    const int blocks_per_image = dd_ceil_div(P.ho * P.wo, 64) * gy64;
-    const long long blocks_full = (long long)dd_ceil_div(max_batch * P.ho * P.wo, 64) * gy64;
-    if (blocks_per_image <= 8 && ksteps >= 8 && blocks_full < 256) {        // fewer blocks than CUs at full batch
-        splitk = std::min(16, ksteps / 4);
-        const int per = dd_ceil_div(ksteps, splitk);
-        splitk = dd_ceil_div(ksteps, per);                    // no empty split
-    }
+    const int splitk = conv_splitk(P.ho, P.wo, P.cout_pad, ksteps, max_batch);
     P.splitk = splitk;
     P.slab = nullptr;
     if (splitk > 1) {
-        int rc = slab.reserve((size_t)splitk * P.m * P.cout_pad * sizeof(float));
+        // Sized for the engine's max_batch, never for the batch of the call: the slab pointer is a kernel argument, and a
+        // forward captured into a hipGraph (dd_net_use_graph) must not find it freed and reallocated because a later call
+        // with more images grew it.  After the first forward of an engine the slab never moves again.
+        void *before = slab.p;
+        int rc = slab.reserve((size_t)splitk * max_batch * P.ho * P.wo * P.cout_pad * sizeof(float));
         if (rc != DD_OK) return rc;
+        if (before && slab.p != before && slab_moved) *slab_moved = true;     // a later layer needs more than an earlier one reserved
         P.slab = slab.as<float>();
     }
     constexpr size_t stage_bytes = (size_t)2 * (BM + BN) * (GLDS ? 64 : BK + 8) * sizeof(_Float16);
@@ -3277,6 +3289,17 @@ int dd_net_create(dd_ctx *ctx, const int32_t *program_host, int n_words, const v
     }
     n->n_ops = no;
     n->ops_off = (int)(p - program_host);
+    {   // the split-K slab, once, for the largest dense layer at max_batch (launch_conv: same formula): its pointer is baked into
+        // captured graphs, so it must never be reallocated by a forward
+        size_t need = 0;
+        for (int i = 0; i < no; ++i) {
+            const int32_t *o = p + (size_t)i * OP_WORDS;
+            if (o[0] != OP_CONV) continue;
+            const int bk = o[28] == 32 ? 32 : 64, sk = conv_splitk(o[26], o[27], o[12], o[13] / bk, max_batch);
+            if (sk > 1) need = std::max(need, (size_t)sk * max_batch * o[26] * o[27] * o[12] * sizeof(float));
+        }
+        if (need) { const int rc = n->slab.reserve(need); if (rc != DD_OK) return rc; }
+    }
     n->weight_bytes = n_weight_bytes;
     DD_HIP(hipMalloc(&n->d_zero, 256));
     DD_HIP(hipMemset(n->d_zero, 0, 256));
@@ -3376,6 +3399,15 @@ int dd_net_read(dd_net *n, int tensor, int n_img, void *dst, int dst_on_device, 
     DD_REQUIRE(t >= 0 && t < (int)n->tensors.size(), DD_E_ARG, "dd_net_read: tensor %d out of range", t);
     const TensorDesc &d = n->tensors[t];
     DD_REQUIRE(d.coff == 0, DD_E_ARG, "dd_net_read: tensor %d is a channel slice", t);
+    // A tensor whose producing op ran inside the NEXT op's launch in the last forward (conv1_1 in conv3x3_pool_rows_k<STEM>,
+    // conv0 in ssd_front_k, the first layer of a residual unit, a pointwise layer in conv_ws_dw_k; batch dependent) was
+    // never written: reading it would return stale or uninitialised data.
+    for (int i = 0; i < n->n_ops && i < (int)n->op_launch.size(); ++i) {
+        const int32_t *o = n->prog.data() + n->ops_off + (size_t)i * OP_WORDS;
+        DD_REQUIRE(!((o[2] == t || o[4] == t) && n->op_launch[i] == OPK_FOLDED), DD_E_STATE,
+                   "dd_net_read: tensor %d was not written by the last forward (op %d ran inside the next op's launch at this batch "
+                   "size and its output stayed on chip); run a smaller batch or a program compiled without the fusion flags", t, i);
+    }
     hipStream_t s = dd_pick_stream(n->ctx, stream);
     const size_t bytes = (size_t)n_img * d.h * d.w * d.cs * dtype_size(d.dtype);
     if (!bytes) return DD_OK;
@@ -3401,11 +3433,16 @@ int dd_net_forward(dd_net *net, const uint8_t *input, int nimg, void *stream) {
     if (nimg == 0) return DD_OK;
     net->last_batch = nimg;
     hipStream_t s = dd_pick_stream(net->ctx, stream);
-    if (!net->use_graph || net->profile) return net_run_ops(net, input, nimg, s);
+    auto eager = [&]() -> int {
+        const int rc = net_run_ops(net, input, nimg, s);
+        if (net->slab_moved) { net->slab_moved = false; net_drop_graphs(net); }     // (cannot happen since dd_net_create reserves it)
+        return rc;
+    };
+    if (!net->use_graph || net->profile) return eager();
     if (net->graphs.size() > 256) net_drop_graphs(net);           // a caller that keeps moving its input buffer
     dd_net::GraphEntry &g = net->graphs[std::make_pair(static_cast<const void *>(input), nimg)];
     if (g.exec) { DD_HIP(hipGraphLaunch(g.exec, s)); return DD_OK; }
-    if (g.calls++ == 0) return net_run_ops(net, input, nimg, s);  // first sight of this key: eager (allocations, attributes)
+    if (g.calls++ == 0) return eager();                           // first sight of this key: eager (allocations, attributes)
     DD_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     const int rc = net_run_ops(net, input, nimg, s);
     hipGraph_t graph = nullptr;
@@ -3543,10 +3580,10 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
                     rc = P.cin == 256 ? launch_conv_ws<4>(s, P, net->ctx->device) : launch_conv_ws<8>(s, P, net->ctx->device);
                 } else if (P.cout_pad <= 32) {
                     // 32 output channels: 128 pixels per block (each wave 32 px x 32 ch) once there are enough pixels
-                    rc = bk32 ? launch_conv<4, 1, 1, 2, 32, false>(s, P, net->slab, net->max_batch, net->ctx->device)
-                       : (glds && P.m >= 16384) ? launch_conv<4, 1, 2, 2, 64, true>(s, P, net->slab, net->max_batch, net->ctx->device)
-                       : glds ? launch_conv<4, 1, 1, 2, 64, true>(s, P, net->slab, net->max_batch, net->ctx->device)
-                              : launch_conv<4, 1, 1, 2, 64, false>(s, P, net->slab, net->max_batch, net->ctx->device);
+                    rc = bk32 ? launch_conv<4, 1, 1, 2, 32, false>(s, P, net->slab, net->max_batch, net->ctx->device, &net->slab_moved)
+                       : (glds && P.m >= 16384) ? launch_conv<4, 1, 2, 2, 64, true>(s, P, net->slab, net->max_batch, net->ctx->device, &net->slab_moved)
+                       : glds ? launch_conv<4, 1, 1, 2, 64, true>(s, P, net->slab, net->max_batch, net->ctx->device, &net->slab_moved)
+                              : launch_conv<4, 1, 1, 2, 64, false>(s, P, net->slab, net->max_batch, net->ctx->device, &net->slab_moved);
                 } else if (glds && net->tile_mode != 1 && P.m >= 16384 && P.cout_pad >= 128) {
                     // plenty of pixels: 128 x 128 with 8 waves -- a third less L2->LDS traffic per FLOP than 64 x 128
                     // (24.3 us vs 26.6 us for 19x19x512 -> 512 at 64 frames; at 10x10 it halves the block count and loses).
@@ -3557,19 +3594,19 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
                     const int c128 = dd_ceil_div(dd_ceil_div(P.m, 128) * gy128, 512) * 128;
                     const int c192 = dd_ceil_div(dd_ceil_div(P.m, 192) * gy128, 512) * 192;
                     if (P.epi == EPI_F16 && c192 <= c128 && net->tile_mode != 2)
-                        rc = launch_conv<4, 2, 3, 4, 64, true>(s, P, net->slab, net->max_batch, net->ctx->device);
+                        rc = launch_conv<4, 2, 3, 4, 64, true>(s, P, net->slab, net->max_batch, net->ctx->device, &net->slab_moved);
                     else
-                        rc = launch_conv<4, 2, 2, 4, 64, true>(s, P, net->slab, net->max_batch, net->ctx->device);
+                        rc = launch_conv<4, 2, 2, 4, 64, true>(s, P, net->slab, net->max_batch, net->ctx->device, &net->slab_moved);
                 } else if (glds && net->tile_mode != 1 && P.m >= 16384 && P.cout_pad == 64) {
-                    rc = launch_conv<4, 2, 2, 2, 64, true>(s, P, net->slab, net->max_batch, net->ctx->device);      // 128 x 64, 8 waves
+                    rc = launch_conv<4, 2, 2, 2, 64, true>(s, P, net->slab, net->max_batch, net->ctx->device, &net->slab_moved);      // 128 x 64, 8 waves
                 } else if (glds && net->tile_mode != 1 && P.m >= 4096 && P.cout_pad >= 128) {
                     // 64 pixels x 128 channels: each staged pixel row feeds twice the MFMAs; measured 31 us vs 38 us
                     // for 19x19x512 -> 512 at 64 frames (128 x 64 gave nothing, 128 x 128 was 2.5x slower: 2 blocks/CU)
-                    rc = launch_conv<2, 2, 2, 4, 64, true>(s, P, net->slab, net->max_batch, net->ctx->device);
+                    rc = launch_conv<2, 2, 2, 4, 64, true>(s, P, net->slab, net->max_batch, net->ctx->device, &net->slab_moved);
                 } else {
-                    rc = bk32 ? launch_conv<2, 2, 2, 2, 32, false>(s, P, net->slab, net->max_batch, net->ctx->device)
-                       : glds ? launch_conv<2, 2, 2, 2, 64, true>(s, P, net->slab, net->max_batch, net->ctx->device)
-                              : launch_conv<2, 2, 2, 2, 64, false>(s, P, net->slab, net->max_batch, net->ctx->device);
+                    rc = bk32 ? launch_conv<2, 2, 2, 2, 32, false>(s, P, net->slab, net->max_batch, net->ctx->device, &net->slab_moved)
+                       : glds ? launch_conv<2, 2, 2, 2, 64, true>(s, P, net->slab, net->max_batch, net->ctx->device, &net->slab_moved)
+                              : launch_conv<2, 2, 2, 2, 64, false>(s, P, net->slab, net->max_batch, net->ctx->device, &net->slab_moved);
                 }
                 if (rc != DD_OK) return rc;
                 break;

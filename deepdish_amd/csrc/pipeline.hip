@@ -12,6 +12,7 @@
 #include <map>
 #include <string>
 #include "common.h"
+#include "hostpool.h"
 
 struct dd_tracker;
 struct dd_mog2;
@@ -20,6 +21,7 @@ int mog2_apply(dd_mog2 *m, hipStream_t s, const uint8_t *frames, double learning
 int mask_box_count(hipStream_t s, const uint8_t *mask, int H, int W, const int *d_boxes, const int *d_box_stream, int K, int *d_counts);
 int yolov5_decode(hipStream_t s, const float *raw, int n_rows, int n_cls, float thr, float img_w, float img_h, float *out_boxes,
                   float *out_scores, int *out_cls, int cap, int *out_n, int batch, void *scratch);
+int yolov5_pack(hipStream_t s, const float *boxes, const float *scores, const int *cls, const int *n_rows, int cap, int batch, float *packed);
 int ssd_finish(hipStream_t s, const float *boxes, const float *cls, const float *scores, int batch, int max_det, double conf,
                double iou_thr, double img_w, double img_h, double *out_boxes, int *out_cls, double *out_scores, int *out_n);
 int tracker_group_create(dd_ctx *ctx, int n, double max_cos, double max_iou, int max_age, int n_init, int budget, int tcap,
@@ -29,6 +31,7 @@ int trackers_update_begin(dd_tracker **ts, int S, const double *tlwh_host, const
                           const int *det_off);
 int trackers_update_match(dd_tracker **ts, int S);
 int trackers_update_end(dd_tracker **ts, int S);
+int tracker_read_host(dd_tracker *t, int which, int64_t *ints6_host, double *means_host);
 }
 extern "C" int dd_net_max_batch(dd_net *net, int *out_host);
 extern "C" int dd_net_input_size(dd_net *net, int *h_host, int *w_host);
@@ -36,7 +39,7 @@ extern "C" int dd_net_input_size(dd_net *net, int *h_host, int *w_host);
 namespace {
 
 constexpr int MAX_DET = 10;              // N_max of the stock SSD post-process op
-constexpr int YOLO_CAP = 4096;           // candidate rows per frame the YOLOv5 adaptor hands on (more is a loud DD_E_CAPACITY)
+constexpr int YOLO_HOST_ROWS = 128;      // YOLOv5 rows per stream the first device-to-host copy of a step has room for (the rest, if any, follows)
 enum { DET_SSD = 0, DET_YOLOV5 = 1 };
 enum { CONFIRMED = 2, DELETED = 3 };
 
@@ -57,6 +60,14 @@ struct StreamState {
     std::vector<int64_t> counts;                                     // [n_wanted][4] pos, neg, int, del
     std::vector<int> det_cls;                                        // class of every detection of this step
     std::vector<double> det_conf;
+    // per-step scratch of the host phases (kept across steps: no allocation in the steady state)
+    std::vector<double> boxes0, scores0;                             // detector adaptor output: tlwh f64 rows, scores
+    std::vector<int> cls0;
+    std::vector<int64_t> ib;                                         // after box hygiene: int boxes, scores, classes
+    std::vector<double> is;
+    std::vector<int> ic, keep;
+    std::vector<int64_t> ints;                                       // count line: track table rows
+    std::vector<double> means;
 };
 
 double cross2(double ax, double ay, double bx, double by) { return ax * by - ay * bx; }
@@ -96,7 +107,9 @@ struct dd_pipeline {
     std::vector<std::string> wanted;
     std::vector<StreamState> st;
     std::vector<dd_tracker *> trks;
-    DevBuf d_resized, d_tmp, d_post, d_det, d_fin, d_nms, d_crop, d_patches, d_feats;
+    DevBuf d_resized, d_tmp, d_post, d_det, d_fin, d_pack, d_nms, d_crop, d_patches, d_feats;
+    size_t yolo_host_rows = 0;                 // YOLOv5: packed rows the first copy of a step brings to the host
+    std::vector<size_t> ybase;
     PinBuf h_fin, h_nms, h_crop;
     int crop_cap = 0;
     double t_det = 0, t_nms = 0, t_enc = 0, t_trk = 0;    // host wall seconds per stage, accumulated
@@ -115,6 +128,8 @@ struct dd_pipeline {
     DevBuf d_mask, d_masked, d_mbox;
     PinBuf h_mbox;
     long long motion_rejected = 0;
+    std::vector<int> off, doff;                // per-step prefix sums (candidates, kept detections) over the streams
+    std::vector<double> tlwh;
 };
 
 namespace {
@@ -209,9 +224,13 @@ int dd_pipeline_create(dd_ctx *ctx, int n_streams, int frame_h, int frame_w, dd_
             if ((rc = p->h_fin.reserve(S * (MAX_DET * (4 * 8 + 4 + 8) + 4) + 256)) != DD_OK) return rc;
         } else {
             if ((rc = p->d_post.reserve(S * n_anchors * 8 + 256)) != DD_OK) return rc;              // per-row confidence + class
-            const size_t fin = S * ((size_t)YOLO_CAP * (4 * 4 + 4 + 4) + 4) + 256;                 // boxes f32x4, score, class, count
+            // every row of the head may pass the threshold: yolov5.py:120-145 has no limit, so neither has this (device: per image
+            // n_anchors rows of boxes f32x4, score, class + a count; then the same rows packed over the images)
+            const size_t fin = S * ((size_t)n_anchors * 24 + 4) + 256;
             if ((rc = p->d_fin.reserve(fin)) != DD_OK) return rc;
-            if ((rc = p->h_fin.reserve(fin)) != DD_OK) return rc;
+            if ((rc = p->d_pack.reserve(S * (size_t)n_anchors * 24 + 256)) != DD_OK) return rc;
+            p->yolo_host_rows = (size_t)S * YOLO_HOST_ROWS;
+            if ((rc = p->h_fin.reserve(S * 4 + 64 + p->yolo_host_rows * 24)) != DD_OK) return rc;
         }
     }
     p->st.resize(n_streams);
@@ -234,7 +253,7 @@ int dd_pipeline_destroy(dd_pipeline *p) {
     for (auto &s : p->st) dd_tracker_destroy(s.trk);
     (void)hipFree(p->d_anchors);
     dd_mog2_destroy(p->mog2);
-    for (DevBuf *b : {&p->d_resized, &p->d_tmp, &p->d_post, &p->d_det, &p->d_fin, &p->d_nms, &p->d_crop, &p->d_patches, &p->d_feats,
+    for (DevBuf *b : {&p->d_resized, &p->d_tmp, &p->d_post, &p->d_det, &p->d_fin, &p->d_pack, &p->d_nms, &p->d_crop, &p->d_patches, &p->d_feats,
                       &p->d_mask, &p->d_masked, &p->d_mbox}) b->release();
     for (PinBuf *b : {&p->h_fin, &p->h_nms, &p->h_crop, &p->h_mbox}) b->release();
     delete p;
@@ -315,13 +334,17 @@ int enqueue_detector(dd_pipeline *p, const uint8_t *frames) {
     void *raw = nullptr;
     if ((rc = dd_net_output(p->det, -1, &raw, nullptr, nullptr, nullptr, nullptr, nullptr)) != DD_OK) return rc;
     if (p->det_kind == DET_YOLOV5) {                                                               // yolov5.py:120-131
-        float *yb = p->d_fin.as<float>(), *ys = yb + (size_t)S * YOLO_CAP * 4;
-        int *yc = reinterpret_cast<int *>(ys + (size_t)S * YOLO_CAP), *yn = yc + (size_t)S * YOLO_CAP;
+        const size_t cap = (size_t)p->n_anchors;
+        float *yb = p->d_fin.as<float>(), *ys = yb + S * cap * 4;
+        int *yc = reinterpret_cast<int *>(ys + S * cap), *yn = yc + S * cap;
         if ((rc = ddk::yolov5_decode(s, static_cast<const float *>(raw), p->n_anchors, p->n_classes, (float)p->det_conf, (float)p->W,
-                                     (float)p->H, yb, ys, yc, YOLO_CAP, yn, S, p->d_post.p)) != DD_OK) return rc;
-        // the counts first, then the rows: a frame rarely fills its 4096-row share
-        const size_t ybytes = (size_t)S * ((size_t)YOLO_CAP * 24 + 4);
-        DD_HIP(hipMemcpyAsync(p->h_fin.p, p->d_fin.p, ybytes, hipMemcpyDeviceToHost, s));
+                                     (float)p->H, yb, ys, yc, p->n_anchors, yn, S, p->d_post.p)) != DD_OK) return rc;
+        // the passing rows of all streams packed behind one another; the host block is [S counts | pad to 64 B | rows x 24 B]: the
+        // counts and the first yolo_host_rows rows now, whatever lies beyond them when the step consumes the block
+        if ((rc = ddk::yolov5_pack(s, yb, ys, yc, yn, p->n_anchors, S, p->d_pack.as<float>())) != DD_OK) return rc;
+        const size_t head = ((size_t)S * 4 + 63) / 64 * 64;
+        DD_HIP(hipMemcpyAsync(p->h_fin.p, yn, (size_t)S * 4, hipMemcpyDeviceToHost, s));
+        DD_HIP(hipMemcpyAsync(p->h_fin.as<char>() + head, p->d_pack.p, p->yolo_host_rows * 24, hipMemcpyDeviceToHost, s));
         DD_HIP(hipEventRecord(p->det_done, s));
         p->det_pending = frames;
         return DD_OK;
@@ -339,6 +362,70 @@ int enqueue_detector(dd_pipeline *p, const uint8_t *frames) {
     DD_HIP(hipEventRecord(p->det_done, s));
     p->det_pending = frames;
     return DD_OK;
+}
+
+// Count-line logic of one stream after its tracker update (deepdish.py:1035-1114, 1303-1312); host only.
+void count_line_one_stream(dd_pipeline *p, StreamState &st) {
+    int nd = 0, nl = 0;
+    dd_tracker_count(st.trk, 1, &nd);
+    dd_tracker_count(st.trk, 0, &nl);
+    std::vector<int64_t> &ints = st.ints;
+    std::vector<double> &means = st.means;
+    std::map<std::string, int> delcounts;
+    if (nd) {
+        ints.resize((size_t)nd * 6);
+        ddk::tracker_read_host(st.trk, 1, ints.data(), nullptr);
+        for (int i = 0; i < nd; ++i) {
+            const int64_t id = ints[(size_t)i * 6];
+            delcounts.clear();                                  // overwritten per deleted track (:1040-1044)
+            auto it = st.db.find(id);
+            if (it != st.db.end() && it->second.size() > 1) {
+                bool hit = false;
+                for (size_t q = 0; q + 1 < it->second.size() && !hit; ++q) {
+                    const double a[2] = {it->second[q].first, it->second[q].second};
+                    const double b[2] = {it->second[q + 1].first, it->second[q + 1].second};
+                    hit = seg_intersect(p->line, p->line + 2, a, b);
+                }
+                if (hit) delcounts[vote_label(p, st.votes[id])] += 1;
+                it->second.clear();
+            }
+            st.votes.erase(id);
+        }
+    }
+    if (nl) {
+        ints.resize((size_t)nl * 6);
+        means.resize((size_t)nl * 8);
+        ddk::tracker_read_host(st.trk, 0, ints.data(), means.data());
+    }
+    std::vector<std::pair<std::string, double>> events;
+    for (int i = 0; i < nl; ++i) {
+        const int64_t *r = ints.data() + (size_t)i * 6;
+        const int64_t id = r[0];
+        if (r[5] >= 0) st.votes[id].add(st.det_cls[r[5]], st.det_conf[r[5]]);
+        if (r[1] != CONFIRMED || r[2] > 1) continue;
+        const double *m = means.data() + (size_t)i * 8;
+        const double w = m[2] * m[3];                            // track.py:84-111 to_tlbr
+        const double x1 = m[0] - w / 2, y1 = m[1] - m[3] / 2;
+        const double x2 = x1 + w, y2 = y1 + m[3];
+        auto &pts = st.db[id];
+        pts.emplace_back((x1 + x2) / 2.0, y2);
+        if (pts.size() > 1) {
+            const double p2[2] = {pts.back().first, pts.back().second};
+            const double q2[2] = {pts[pts.size() - 2].first, pts[pts.size() - 2].second};
+            const double cp = cross2(p->line[2] - p->line[0], p->line[3] - p->line[1], q2[0] - p2[0], q2[1] - p2[1]);
+            if (seg_intersect(p->line, p->line + 2, p2, q2)) events.emplace_back(vote_label(p, st.votes[id]), cp);
+        }
+    }
+    for (auto &e : events) {
+        const int wi = wanted_index(p, e.first);
+        if (wi < 0) continue;
+        st.counts[wi * 4 + (e.second >= 0 ? 0 : 1)] += 1;
+        st.counts[wi * 4 + 2] += 1;
+    }
+    for (auto &d : delcounts) {
+        const int wi = wanted_index(p, d.first);
+        if (wi >= 0) st.counts[wi * 4 + 3] += d.second;
+    }
 }
 
 }  // namespace
@@ -378,77 +465,107 @@ int dd_pipeline_step2(dd_pipeline *p, const uint8_t *frames_in, const uint8_t *f
     }
 
     // ---------------- detector: resize -> forward -> post-process -> adaptor tail, all streams at once
-    std::vector<std::vector<double>> boxes0(S);      // per stream: tlwh f64 rows
-    std::vector<std::vector<double>> scores0(S);
-    std::vector<std::vector<int>> cls0(S);
+    // (host phases below: one parallel_for over the streams each -- they share nothing; hostpool.h)
+    constexpr int GRAIN = 16;
+    std::vector<StreamState> &st = p->st;
     if (p->det) {
         if (p->det_pending != frames && (rc = enqueue_detector(p, frames)) != DD_OK) return rc;       // not queued ahead: run it now
         DD_HIP(hipEventSynchronize(p->det_done));                                                      // round trip 1
         p->det_pending = nullptr;
         if (p->det_kind == DET_YOLOV5) {
-            const float *yb = p->h_fin.as<float>(), *ys = yb + (size_t)S * YOLO_CAP * 4;
-            const int *yc = reinterpret_cast<const int *>(ys + (size_t)S * YOLO_CAP), *yn = yc + (size_t)S * YOLO_CAP;
-            for (int z = 0; z < S; ++z) {
-                DD_REQUIRE(yn[z] <= YOLO_CAP, DD_E_CAPACITY, "dd_pipeline_step: stream %d: %d YOLOv5 candidates exceed %d", z, yn[z], YOLO_CAP);
-                for (int i = 0; i < yn[z]; ++i) {                                                      // yolov5.py:137-145
-                    const int c = yc[(size_t)z * YOLO_CAP + i];
-                    const float sc = ys[(size_t)z * YOLO_CAP + i];
-                    if (wanted_index(p, class_name(p, c)) < 0 || !(sc >= (float)p->det_conf)) continue;
-                    const float *b = yb + ((size_t)z * YOLO_CAP + i) * 4;
-                    boxes0[z].insert(boxes0[z].end(), {(double)b[0], (double)b[1], (double)(b[2] - b[0]), (double)(b[3] - b[1])});   // f32 arithmetic, :140-142
-                    scores0[z].push_back((double)sc);
-                    cls0[z].push_back(c);
+            const size_t head = ((size_t)S * 4 + 63) / 64 * 64;
+            const int *yn = p->h_fin.as<int>();
+            std::vector<size_t> &ybase = p->ybase;
+            ybase.assign(S + 1, 0);
+            for (int z = 0; z < S; ++z) ybase[z + 1] = ybase[z] + (size_t)std::min(yn[z], p->n_anchors);
+            if (ybase[S] > p->yolo_host_rows) {                    // a busy step: fetch the rest (the detector stream is idle here) and
+                const size_t have = p->yolo_host_rows, total = ybase[S];      // make room for twice as many from now on
+                PinBuf bigger;
+                if ((rc = bigger.reserve(head + 2 * total * 24)) != DD_OK) return rc;
+                memcpy(bigger.p, p->h_fin.p, head + have * 24);
+                DD_HIP(hipMemcpyAsync(bigger.as<char>() + head + have * 24, p->d_pack.as<char>() + have * 24, (total - have) * 24,
+                                      hipMemcpyDeviceToHost, p->det_stream));
+                DD_HIP(hipStreamSynchronize(p->det_stream));
+                p->h_fin.release();
+                p->h_fin = bigger;
+                p->yolo_host_rows = 2 * total;
+                yn = p->h_fin.as<int>();
+            }
+            const float *rows = reinterpret_cast<const float *>(p->h_fin.as<char>() + head);
+            ddk::parallel_for(S, GRAIN, [&](int z0, int z1) {
+                for (int z = z0; z < z1; ++z) {
+                    StreamState &q = st[z];
+                    q.boxes0.clear(); q.scores0.clear(); q.cls0.clear();
+                    const int n = (int)(ybase[z + 1] - ybase[z]);
+                    for (int i = 0; i < n; ++i) {                                                      // yolov5.py:137-145
+                        const float *b = rows + (ybase[z] + i) * 6;
+                        int c;
+                        memcpy(&c, b + 5, 4);
+                        const float sc = b[4];
+                        if (wanted_index(p, class_name(p, c)) < 0 || !(sc >= (float)p->det_conf)) continue;
+                        q.boxes0.insert(q.boxes0.end(), {(double)b[0], (double)b[1], (double)(b[2] - b[0]), (double)(b[3] - b[1])});   // f32 arithmetic, :140-142
+                        q.scores0.push_back((double)sc);
+                        q.cls0.push_back(c);
+                    }
                 }
-            }
+            });
+        } else {
+            const double *hb = p->h_fin.as<double>(), *hs = hb + (size_t)S * MAX_DET * 4;
+            const int *hc = reinterpret_cast<const int *>(hs + (size_t)S * MAX_DET), *hn = hc + (size_t)S * MAX_DET;
+            ddk::parallel_for(S, GRAIN, [&](int z0, int z1) {
+                for (int z = z0; z < z1; ++z) {
+                    StreamState &q = st[z];
+                    q.boxes0.clear(); q.scores0.clear(); q.cls0.clear();
+                    for (int i = 0; i < hn[z]; ++i) {                                                  // :204-212
+                        const double sc = hs[z * MAX_DET + i];
+                        if (!(sc >= p->det_conf) || wanted_index(p, class_name(p, hc[z * MAX_DET + i])) < 0) continue;
+                        const double *b = hb + ((size_t)z * MAX_DET + i) * 4;
+                        q.boxes0.insert(q.boxes0.end(), {b[0], b[1], b[2] - b[0], b[3] - b[1]});
+                        q.scores0.push_back(sc);
+                        q.cls0.push_back(hc[z * MAX_DET + i]);
+                    }
+                }
+            });
         }
-        const double *hb = p->h_fin.as<double>(), *hs = hb + (size_t)S * MAX_DET * 4;
-        const int *hc = reinterpret_cast<const int *>(hs + (size_t)S * MAX_DET), *hn = hc + (size_t)S * MAX_DET;
-        for (int z = 0; z < S && p->det_kind == DET_SSD; ++z)
-            for (int i = 0; i < hn[z]; ++i) {                                                          // :204-212
-                const std::string name = class_name(p, hc[z * MAX_DET + i]);
-                const double sc = hs[z * MAX_DET + i];
-                if (wanted_index(p, name) < 0 || !(sc >= p->det_conf)) continue;
-                const double *b = hb + ((size_t)z * MAX_DET + i) * 4;
-                boxes0[z].insert(boxes0[z].end(), {b[0], b[1], b[2] - b[0], b[3] - b[1]});
-                scores0[z].push_back(sc);
-                cls0[z].push_back(hc[z * MAX_DET + i]);
-            }
         // the host block has been consumed: the detector buffers are free for the next frames
         if (frames_next && (rc = enqueue_detector(p, frames_next)) != DD_OK) return rc;
+    } else {
+        for (auto &q : st) { q.boxes0.clear(); q.scores0.clear(); q.cls0.clear(); }
     }
-    if (inj_offsets_host) {
+    if (inj_offsets_host)
         DD_REQUIRE(inj_boxes_host && inj_scores_host && inj_cls_host, DD_E_ARG, "dd_pipeline_step: injected arrays missing");
-        for (int z = 0; z < S; ++z) {
-            const int a = inj_offsets_host[z], b = inj_offsets_host[z + 1];
-            boxes0[z].assign(inj_boxes_host + (size_t)a * 4, inj_boxes_host + (size_t)b * 4);
-            scores0[z].assign(inj_scores_host + a, inj_scores_host + b);
-            cls0[z].assign(inj_cls_host + a, inj_cls_host + b);
-        }
-    }
     const double t1 = now_s();
 
     // ---------------- box hygiene (deepdish.py:940-960, background subtraction off) + batched NMS (:995)
-    std::vector<int> off(S + 1, 0);
-    std::vector<std::vector<int64_t>> ib(S);          // int boxes per stream
-    std::vector<std::vector<double>> is(S);
-    std::vector<std::vector<int>> ic(S);
-    for (int z = 0; z < S; ++z) {
-        const int k0 = (int)scores0[z].size();
-        bool any_nan = false;
-        for (double v : boxes0[z]) if (v != v) any_nan = true;
-        if (!any_nan)
+    std::vector<int> &off = p->off;
+    off.assign(S + 1, 0);
+    ddk::parallel_for(S, GRAIN, [&](int z0, int z1) {
+        for (int z = z0; z < z1; ++z) {
+            StreamState &q = st[z];
+            if (inj_offsets_host) {
+                const int a = inj_offsets_host[z], b = inj_offsets_host[z + 1];
+                q.boxes0.assign(inj_boxes_host + (size_t)a * 4, inj_boxes_host + (size_t)b * 4);
+                q.scores0.assign(inj_scores_host + a, inj_scores_host + b);
+                q.cls0.assign(inj_cls_host + a, inj_cls_host + b);
+            }
+            q.ib.clear(); q.is.clear(); q.ic.clear();
+            const int k0 = (int)q.scores0.size();
+            bool any_nan = false;
+            for (double v : q.boxes0) if (v != v) any_nan = true;
+            if (any_nan) continue;
             for (int i = 0; i < k0; ++i) {
-                const double *b = boxes0[z].data() + (size_t)i * 4;
+                const double *b = q.boxes0.data() + (size_t)i * 4;
                 auto clipi = [](double v, double lo, double hi) { return (int64_t)(v < lo ? lo : (v > hi ? hi : v)); };
                 const int64_t x = clipi(b[0], 0, p->W), y = clipi(b[1], 0, p->H);
                 const int64_t w = clipi(b[2], 0, (double)(p->W - x)), h = clipi(b[3], 0, (double)(p->H - y));
                 if ((double)(w * h) > 0.9 * p->W * p->H) continue;
-                ib[z].insert(ib[z].end(), {x, y, w, h});
-                is[z].push_back(scores0[z][i]);
-                ic[z].push_back(cls0[z][i]);
+                q.ib.insert(q.ib.end(), {x, y, w, h});
+                q.is.push_back(q.scores0[i]);
+                q.ic.push_back(q.cls0[i]);
             }
-        off[z + 1] = off[z] + (int)is[z].size();
-    }
+        }
+    });
+    for (int z = 0; z < S; ++z) off[z + 1] = off[z] + (int)st[z].is.size();
     if (p->mog2 && off[S] > 0) {                                                        // :957 motion test on every candidate
         const int K0 = off[S];
         const size_t in_bytes = (size_t)K0 * 5 * sizeof(int), all_bytes = in_bytes + (size_t)K0 * sizeof(int);
@@ -456,8 +573,8 @@ int dd_pipeline_step2(dd_pipeline *p, const uint8_t *frames_in, const uint8_t *f
         if ((rc = p->d_mbox.reserve(all_bytes)) != DD_OK) return rc;
         int *hm = p->h_mbox.as<int>(), *dm = p->d_mbox.as<int>();
         for (int z = 0; z < S; ++z)
-            for (size_t i = 0; i < is[z].size(); ++i) {
-                for (int q = 0; q < 4; ++q) hm[(size_t)(off[z] + i) * 4 + q] = (int)ib[z][i * 4 + q];
+            for (size_t i = 0; i < st[z].is.size(); ++i) {
+                for (int q = 0; q < 4; ++q) hm[(size_t)(off[z] + i) * 4 + q] = (int)st[z].ib[i * 4 + q];
                 hm[(size_t)K0 * 4 + off[z] + i] = z;
             }
         DD_HIP(hipMemcpyAsync(dm, hm, in_bytes, hipMemcpyHostToDevice, s));
@@ -467,20 +584,20 @@ int dd_pipeline_step2(dd_pipeline *p, const uint8_t *frames_in, const uint8_t *f
         const int *cnt = hm + (size_t)K0 * 5;
         std::vector<int> off0 = off;
         for (int z = 0; z < S; ++z) {
+            StreamState &q = st[z];
             size_t n = 0;
-            for (size_t i = 0; i < is[z].size(); ++i) {
-                const int64_t w = ib[z][i * 4 + 2], h = ib[z][i * 4 + 3];
+            for (size_t i = 0; i < q.is.size(); ++i) {
+                const int64_t w = q.ib[i * 4 + 2], h = q.ib[i * 4 + 3];
                 if (!((double)cnt[off0[z] + i] >= p->motion_ratio * (double)w * (double)h)) { p->motion_rejected++; continue; }
-                for (int q = 0; q < 4; ++q) ib[z][n * 4 + q] = ib[z][i * 4 + q];
-                is[z][n] = is[z][i]; ic[z][n] = ic[z][i];
+                for (int c = 0; c < 4; ++c) q.ib[n * 4 + c] = q.ib[i * 4 + c];
+                q.is[n] = q.is[i]; q.ic[n] = q.ic[i];
                 ++n;
             }
-            ib[z].resize(n * 4); is[z].resize(n); ic[z].resize(n);
+            q.ib.resize(n * 4); q.is.resize(n); q.ic.resize(n);
             off[z + 1] = off[z] + (int)n;
         }
     }
     const int K = off[S];
-    std::vector<std::vector<int>> keep(S);
     if (K > 0) {
         bool small = true;
         for (int z = 0; z < S; ++z) if (off[z + 1] - off[z] > 64) small = false;
@@ -490,10 +607,13 @@ int dd_pipeline_step2(dd_pipeline *p, const uint8_t *frames_in, const uint8_t *f
         if ((rc = p->d_nms.reserve(in_bytes + out_bytes + 256 + (small ? 0 : ddk::nms_scratch_bytes(4096)))) != DD_OK) return rc;
         double *hb = p->h_nms.as<double>(), *hk = hb + (size_t)K * 4;
         int *ho = reinterpret_cast<int *>(hk + K);
-        for (int z = 0; z < S; ++z) {
-            for (size_t i = 0; i < ib[z].size(); ++i) hb[(size_t)off[z] * 4 + i] = (double)ib[z][i];   // astype(np.float)
-            for (size_t i = 0; i < is[z].size(); ++i) hk[off[z] + i] = is[z][i];
-        }
+        ddk::parallel_for(S, GRAIN, [&](int z0, int z1) {
+            for (int z = z0; z < z1; ++z) {
+                const StreamState &q = st[z];
+                for (size_t i = 0; i < q.ib.size(); ++i) hb[(size_t)off[z] * 4 + i] = (double)q.ib[i];   // astype(np.float)
+                for (size_t i = 0; i < q.is.size(); ++i) hk[off[z] + i] = q.is[i];
+            }
+        });
         memcpy(ho, off.data(), (size_t)(S + 1) * sizeof(int));
         char *d = p->d_nms.as<char>();
         DD_HIP(hipMemcpyAsync(d, hb, in_bytes, hipMemcpyHostToDevice, s));
@@ -514,34 +634,41 @@ int dd_pipeline_step2(dd_pipeline *p, const uint8_t *frames_in, const uint8_t *f
         DD_HIP(hipMemcpyAsync(hidx, didx, out_bytes, hipMemcpyDeviceToHost, s));
         DD_HIP(hipStreamSynchronize(s));                                                               // round trip 2
         const int *hnk = hidx + K;
-        for (int z = 0; z < S; ++z) keep[z].assign(hidx + off[z], hidx + off[z] + hnk[z]);
+        for (int z = 0; z < S; ++z) st[z].keep.assign(hidx + off[z], hidx + off[z] + hnk[z]);
+    } else {
+        for (auto &q : st) q.keep.clear();
     }
     const double t2 = now_s();
 
     // ---------------- crops + MARS for every kept box of every stream (deepdish.py:1008)
-    std::vector<int> doff(S + 1, 0);
-    for (int z = 0; z < S; ++z) doff[z + 1] = doff[z] + (int)keep[z].size();
+    std::vector<int> &doff = p->doff;
+    doff.assign(S + 1, 0);
+    for (int z = 0; z < S; ++z) doff[z + 1] = doff[z] + (int)st[z].keep.size();
     const int D = doff[S];
-    std::vector<double> tlwh((size_t)D * 4);
+    std::vector<double> &tlwh = p->tlwh;
+    tlwh.resize((size_t)D * 4);
     if (D > 0) {
         if ((rc = p->h_crop.reserve((size_t)D * 32)) != DD_OK) return rc;
         if ((rc = p->d_crop.reserve((size_t)D * 32)) != DD_OK) return rc;
         if ((rc = p->d_patches.reserve((size_t)D * 64 * 32 * 3)) != DD_OK) return rc;
         if ((rc = p->d_feats.reserve((size_t)D * 128 * sizeof(float))) != DD_OK) return rc;
         int *hc = p->h_crop.as<int>();
-        for (int z = 0; z < S; ++z) {
-            p->st[z].det_cls.clear(); p->st[z].det_conf.clear();
-            for (size_t j = 0; j < keep[z].size(); ++j) {
-                const int i = keep[z][j];
-                const int64_t *b = ib[z].data() + (size_t)i * 4;
-                int *c = hc + (size_t)(doff[z] + j) * 8;
-                ddk::crop_box_host(b, 64, 32, p->H, p->W, c, c + 1, c + 2, c + 3);     // generate_detections.py:63-80
-                c[4] = z; c[5] = c[6] = c[7] = 0;
-                for (int q = 0; q < 4; ++q) tlwh[(size_t)(doff[z] + j) * 4 + q] = (double)b[q];
-                p->st[z].det_cls.push_back(ic[z][i]);
-                p->st[z].det_conf.push_back(is[z][i]);
+        ddk::parallel_for(S, GRAIN, [&](int z0, int z1) {
+            for (int z = z0; z < z1; ++z) {
+                StreamState &q = st[z];
+                q.det_cls.clear(); q.det_conf.clear();
+                for (size_t j = 0; j < q.keep.size(); ++j) {
+                    const int i = q.keep[j];
+                    const int64_t *b = q.ib.data() + (size_t)i * 4;
+                    int *c = hc + (size_t)(doff[z] + j) * 8;
+                    ddk::crop_box_host(b, 64, 32, p->H, p->W, c, c + 1, c + 2, c + 3);     // generate_detections.py:63-80
+                    c[4] = z; c[5] = c[6] = c[7] = 0;
+                    for (int c4 = 0; c4 < 4; ++c4) tlwh[(size_t)(doff[z] + j) * 4 + c4] = (double)b[c4];
+                    q.det_cls.push_back(q.ic[i]);
+                    q.det_conf.push_back(q.is[i]);
+                }
             }
-        }
+        });
         DD_HIP(hipMemcpyAsync(p->d_crop.p, hc, (size_t)D * 32, hipMemcpyHostToDevice, s));
         if ((rc = ddk::crop_resize(s, frames, p->H, p->W, p->d_crop.p, D, 64, 32, p->d_patches.as<uint8_t>())) != DD_OK) return rc;
         for (int a = 0; a < D; a += p->enc_batch) {
@@ -550,7 +677,7 @@ int dd_pipeline_step2(dd_pipeline *p, const uint8_t *frames_in, const uint8_t *f
             if ((rc = dd_net_read(p->enc, -1, n, p->d_feats.as<float>() + (size_t)a * 128, 1, s)) != DD_OK) return rc;
         }
     } else {
-        for (auto &st : p->st) { st.det_cls.clear(); st.det_conf.clear(); }
+        for (auto &q : st) { q.det_cls.clear(); q.det_conf.clear(); }
     }
     const double t3 = now_s();
 
@@ -561,70 +688,9 @@ int dd_pipeline_step2(dd_pipeline *p, const uint8_t *frames_in, const uint8_t *f
     if ((rc = ddk::trackers_update_match(p->trks.data(), S)) != DD_OK) return rc;
     DD_HIP(hipStreamSynchronize(s));                                                                   // round trip 4
     if ((rc = ddk::trackers_update_end(p->trks.data(), S)) != DD_OK) return rc;
-    std::vector<int64_t> ints;
-    std::vector<double> means;
-    for (int z = 0; z < S; ++z) {
-        StreamState &st = p->st[z];
-        // ---------------- count line (deepdish.py:1035-1114, 1303-1312)
-        int nd = 0, nl = 0;
-        dd_tracker_count(st.trk, 1, &nd);
-        dd_tracker_count(st.trk, 0, &nl);
-        std::map<std::string, int> delcounts;
-        if (nd) {
-            ints.resize((size_t)nd * 6);
-            dd_tracker_read(st.trk, 1, ints.data(), nullptr, nullptr);
-            for (int i = 0; i < nd; ++i) {
-                const int64_t id = ints[(size_t)i * 6];
-                delcounts.clear();                                  // overwritten per deleted track (:1040-1044)
-                auto it = st.db.find(id);
-                if (it != st.db.end() && it->second.size() > 1) {
-                    bool hit = false;
-                    for (size_t q = 0; q + 1 < it->second.size() && !hit; ++q) {
-                        const double a[2] = {it->second[q].first, it->second[q].second};
-                        const double b[2] = {it->second[q + 1].first, it->second[q + 1].second};
-                        hit = seg_intersect(p->line, p->line + 2, a, b);
-                    }
-                    if (hit) delcounts[vote_label(p, st.votes[id])] += 1;
-                    it->second.clear();
-                }
-                st.votes.erase(id);
-            }
-        }
-        if (nl) {
-            ints.resize((size_t)nl * 6);
-            means.resize((size_t)nl * 8);
-            dd_tracker_read(st.trk, 0, ints.data(), means.data(), nullptr);
-        }
-        std::vector<std::pair<std::string, double>> events;
-        for (int i = 0; i < nl; ++i) {
-            const int64_t *r = ints.data() + (size_t)i * 6;
-            const int64_t id = r[0];
-            if (r[5] >= 0) st.votes[id].add(st.det_cls[r[5]], st.det_conf[r[5]]);
-            if (r[1] != CONFIRMED || r[2] > 1) continue;
-            const double *m = means.data() + (size_t)i * 8;
-            const double w = m[2] * m[3];                            // track.py:84-111 to_tlbr
-            const double x1 = m[0] - w / 2, y1 = m[1] - m[3] / 2;
-            const double x2 = x1 + w, y2 = y1 + m[3];
-            auto &pts = st.db[id];
-            pts.emplace_back((x1 + x2) / 2.0, y2);
-            if (pts.size() > 1) {
-                const double p2[2] = {pts.back().first, pts.back().second};
-                const double q2[2] = {pts[pts.size() - 2].first, pts[pts.size() - 2].second};
-                const double cp = cross2(p->line[2] - p->line[0], p->line[3] - p->line[1], q2[0] - p2[0], q2[1] - p2[1]);
-                if (seg_intersect(p->line, p->line + 2, p2, q2)) events.emplace_back(vote_label(p, st.votes[id]), cp);
-            }
-        }
-        for (auto &e : events) {
-            const int wi = wanted_index(p, e.first);
-            if (wi < 0) continue;
-            st.counts[wi * 4 + (e.second >= 0 ? 0 : 1)] += 1;
-            st.counts[wi * 4 + 2] += 1;
-        }
-        for (auto &d : delcounts) {
-            const int wi = wanted_index(p, d.first);
-            if (wi >= 0) st.counts[wi * 4 + 3] += d.second;
-        }
-    }
+    ddk::parallel_for(S, GRAIN, [&](int z0, int z1) {
+        for (int z = z0; z < z1; ++z) count_line_one_stream(p, st[z]);
+    });
     const double t4 = now_s();
     p->t_det += t1 - t0; p->t_nms += t2 - t1; p->t_enc += t3 - t2; p->t_trk += t4 - t3;
     p->steps += 1;

@@ -221,6 +221,27 @@ __global__ __launch_bounds__(1024) void yolo_compact_k(const float *__restrict__
     if (tid == 0) *out_n = base;
 }
 
+// Rows of all images behind one another (image z starts at the sum of the counts before it): what the pipeline copies to
+// the host is then proportional to what passed the threshold, not to a per-image capacity.  One block per image.
+__global__ __launch_bounds__(256) void yolo_pack_k(const float *__restrict__ boxes, const float *__restrict__ scores, const int *__restrict__ cls,
+                                                   const int *__restrict__ n_rows, int cap, float *__restrict__ packed) {
+    __shared__ int part[256];
+    const int z = blockIdx.x, tid = threadIdx.x;
+    int acc = 0;
+    for (int i = tid; i < z; i += 256) acc += min(n_rows[i], cap);
+    part[tid] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) part[tid] += part[tid + o]; __syncthreads(); }
+    const int base = part[0], n = min(n_rows[z], cap);
+    for (int i = tid; i < n; i += 256) {
+        float *o = packed + (size_t)(base + i) * 6;
+        const float *b = boxes + ((size_t)z * cap + i) * 4;
+        o[0] = b[0]; o[1] = b[1]; o[2] = b[2]; o[3] = b[3];
+        o[4] = scores[(size_t)z * cap + i];
+        o[5] = __int_as_float(cls[(size_t)z * cap + i]);
+    }
+}
+
 __global__ void counts_add_k(long long *__restrict__ acc, const long long *__restrict__ add, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) acc[i] += add[i];
@@ -279,6 +300,13 @@ int yolov5_decode(hipStream_t s, const float *raw, int n_rows, int n_cls, float 
     DD_LAUNCH_CHECK();
     hipLaunchKernelGGL(yolo_compact_k, dim3(batch), dim3(1024), 0, s, raw, conf, cls, n_rows, n_cls, thr, img_w, img_h, out_boxes,
                        out_scores, out_cls, cap, out_n);
+    DD_LAUNCH_CHECK();
+    return DD_OK;
+}
+
+// per-image [cap] outputs of yolov5_decode -> packed rows {x1, y1, x2, y2, score, class bits} of all images in image order
+int yolov5_pack(hipStream_t s, const float *boxes, const float *scores, const int *cls, const int *n_rows, int cap, int batch, float *packed) {
+    hipLaunchKernelGGL(yolo_pack_k, dim3(batch), dim3(256), 0, s, boxes, scores, cls, n_rows, cap, packed);
     DD_LAUNCH_CHECK();
     return DD_OK;
 }

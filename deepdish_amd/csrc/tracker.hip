@@ -22,8 +22,10 @@
 // (deepdish.py:515, nn_matching.py:137-154), so a gallery has no fixed capacity here either; with nn_budget = B
 // the last B samples are kept (a ring over ceil(B / 32) chunks).  Chunks return to the pool with the track's slot.
 #include <algorithm>
+#include <atomic>
 #include <numeric>
 #include "common.h"
+#include "hostpool.h"
 #include "kalman_dev.h"
 #include "cost_dev.h"
 
@@ -135,7 +137,8 @@ struct TrackerPool {
     std::vector<int> slot_total;                          // samples appended to the slot's track so far
     int *d_tab = nullptr, tab_stride = 0;
     std::vector<int> tab_upd;                             // (table index, chunk) pairs not yet on the device
-    bool tab_rebuild = false;                             // the stride grew: rewrite the whole table
+    int tab_need = 0;                                     // longest chunk list placed so far; the stride follows it in gallery_flush ONLY
+                                                          // (tab_stride always describes the d_tab the device holds, also on an error path)
     DevBuf d_tabupd;
     PinBuf h_tabupd;
     DevBuf d_pred, d_in, d_feats_raw, d_feats_n, d_cost, d_pairs, d_gather;
@@ -159,6 +162,7 @@ struct dd_tracker {
     std::vector<int> last_pairs;                          // (track row before update, detection)
     int64_t next_id = 1;
     int ph_n = 0, ph_T = 0, ph_cost_base = -1;            // ph_cost_base: where this tracker's cost matrices sit in pool->h_cost
+    std::vector<int> m_upd, m_new;                        // decisions of the current update: (slot, detection) pairs, matched / new tracks
 };
 
 namespace {
@@ -240,10 +244,7 @@ int gallery_place(TrackerPool *p, int slot, int budget, int *row_out) {
     const int ci = pos >> GAL_CH_SHIFT;
     std::vector<int> &chs = p->slot_chunks[slot];
     if (ci >= (int)chs.size()) {
-        if (ci >= p->tab_stride) {                            // rare: double the table (flushed before the next launch reads it)
-            while (ci >= p->tab_stride) p->tab_stride *= 2;
-            p->tab_rebuild = true;
-        }
+        p->tab_need = std::max(p->tab_need, ci + 1);          // rare: beyond the stride -> gallery_flush doubles and rewrites the table
         if (p->free_chunks.empty()) {
             const int rc = pool_add_arena(p);
             if (rc != DD_OK) return rc;
@@ -273,17 +274,20 @@ void gallery_free_slot(TrackerPool *p, int slot) {
 
 // Bring the device chunk table up to date (same stream, after the launches that used the old contents).
 int gallery_flush(TrackerPool *p, hipStream_t s) {
-    if (p->tab_rebuild) {
+    if (p->tab_need > p->tab_stride) {
+        int stride = p->tab_stride;
+        while (p->tab_need > stride) stride *= 2;
         DD_HIP(hipStreamSynchronize(s));                       // nothing in flight may still read the old table
-        DD_HIP(hipFree(p->d_tab));
-        p->d_tab = nullptr;
-        const size_t n = (size_t)p->slots * p->tab_stride;
-        DD_HIP(hipMalloc(&p->d_tab, n * sizeof(int)));
+        const size_t n = (size_t)p->slots * stride;
+        int *fresh = nullptr;
+        DD_HIP(hipMalloc(&fresh, n * sizeof(int)));
         std::vector<int> host(n, 0);
         for (int sl = 0; sl < p->slots; ++sl)
-            for (size_t i = 0; i < p->slot_chunks[sl].size(); ++i) host[(size_t)sl * p->tab_stride + i] = p->slot_chunks[sl][i];
-        DD_HIP(hipMemcpy(p->d_tab, host.data(), n * sizeof(int), hipMemcpyHostToDevice));
-        p->tab_rebuild = false;
+            for (size_t i = 0; i < p->slot_chunks[sl].size(); ++i) host[(size_t)sl * stride + i] = p->slot_chunks[sl][i];
+        const hipError_t e = hipMemcpy(fresh, host.data(), n * sizeof(int), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(fresh); DD_HIP(e); }
+        (void)hipFree(p->d_tab);
+        p->d_tab = fresh; p->tab_stride = stride;              // committed together, only now
         p->tab_upd.clear();
         return DD_OK;
     }
@@ -377,6 +381,9 @@ int trackers_update_begin(dd_tracker **ts, int S, const double *tlwh_host, const
     TrackerPool *p = ts[0]->pool;
     hipStream_t s = p->ctx->stream;
     int rc;
+    // an update that failed between gallery_place and gallery_flush (capacity) leaves table entries pending: the association
+    // launch below must see them
+    if ((p->tab_need > p->tab_stride || !p->tab_upd.empty()) && (rc = gallery_flush(p, s)) != DD_OK) return rc;
     p->cur.assign(ts, ts + S);
     p->det_off.assign(det_off, det_off + S + 1);
     p->cost_base.assign(S, 0);
@@ -447,7 +454,88 @@ int trackers_update_begin(dd_tracker **ts, int S, const double *tlwh_host, const
 
 // phase 2 (the cost matrices have landed): per stream matching cascade + LSAP + track management on
 // the host, then ONE launch for all Kalman updates / new tracks / gallery appends of the group and
-// ONE gather of the means.
+// ONE gather of the means.  The per-stream part touches only that stream's tracker, so the streams are spread over
+// the host pool (hostpool.h); gallery chunks are then handed out serially in stream order, as a single thread would.
+namespace {
+// tracker.py:59-93 for one stream: decisions + integer book-keeping.  Fills t->m_upd / t->m_new with (slot, detection) pairs.
+int match_one_stream(TrackerPool *p, dd_tracker *t, int z) {
+    const int n = t->ph_n, T = t->ph_T, doff = p->det_off[z];
+    std::vector<std::pair<int, int>> matches;
+    std::vector<int> un_rows_final, un_dets, lvl_rows, tmp_rows, tmp_dets, confirmed, unconfirmed;
+    t->m_upd.clear(); t->m_new.clear();
+    t->ph_cost_base = (n > 0 && T > 0 && p->have_cost) ? p->cost_base[z] : -1;   // parity aid (dd_tracker_last_cost)
+    if (n > 0 && T > 0) {
+        const double *app = p->h_cost.as<double>() + p->cost_base[z], *iou = app + (size_t)T * n;
+        // ---- tracker.py:95-133 _match
+        for (int i = 0; i < T; ++i) (t->tracks[i].state == CONFIRMED ? confirmed : unconfirmed).push_back(i);
+        un_dets.resize(n);
+        std::iota(un_dets.begin(), un_dets.end(), 0);
+        for (int level = 0; level < t->max_age; ++level) {            // linear_assignment.py:78-141
+            if (un_dets.empty()) break;
+            lvl_rows.clear();
+            for (int k : confirmed) if (t->tracks[k].tsu == 1 + level) lvl_rows.push_back(k);
+            if (lvl_rows.empty()) continue;
+            min_cost_matching(app, n, t->max_cos, lvl_rows, un_dets, matches, tmp_rows, tmp_dets);
+            un_dets = tmp_dets;
+        }
+        // unmatched_tracks_a = list(set(track_indices) - set(k for k, _ in matches)) (linear_assignment.py:140):
+        // the reference's order is CPython's set iteration order, reproduced by csrc/pyset.cpp, because it
+        // becomes the row order of the IoU assignment below (tracker.py:120-123).
+        std::vector<int> matched_rows, un_a_all;
+        for (auto &m : matches) matched_rows.push_back(m.first);
+        ddk::pyset_difference_order(confirmed, matched_rows, un_a_all);
+        std::vector<int> iou_rows = unconfirmed, un_rows_a;
+        for (int k : un_a_all) {
+            if (t->tracks[k].tsu == 1) iou_rows.push_back(k); else un_rows_a.push_back(k);
+        }
+        std::vector<int> un_rows_b;
+        min_cost_matching(iou, n, t->max_iou, iou_rows, un_dets, matches, un_rows_b, tmp_dets);
+        un_dets = tmp_dets;
+        un_rows_final = un_rows_a;
+        un_rows_final.insert(un_rows_final.end(), un_rows_b.begin(), un_rows_b.end());
+    } else {
+        un_dets.resize(n);
+        std::iota(un_dets.begin(), un_dets.end(), 0);
+        for (int i = 0; i < T; ++i) un_rows_final.push_back(i);
+    }
+    // ---- tracker.py:70-79 apply to the integer book-keeping
+    for (auto &m : matches) {                                  // track.py:127-152
+        TrackRec &tr = t->tracks[m.first];
+        tr.hits += 1;
+        tr.tsu = 0;
+        tr.last_det = m.second;
+        if (tr.state == TENTATIVE && tr.hits >= t->n_init) tr.state = CONFIRMED;
+        t->m_upd.push_back(tr.slot); t->m_upd.push_back(doff + m.second);
+        t->last_pairs.push_back(m.first);
+        t->last_pairs.push_back(m.second);
+    }
+    for (int r : un_rows_final) {                              // track.py:190-196
+        TrackRec &tr = t->tracks[r];
+        if (tr.state == TENTATIVE) tr.state = DELETED;
+        else if (tr.tsu > t->max_age) tr.state = DELETED;
+    }
+    DD_REQUIRE((int)t->free_slots.size() >= (int)un_dets.size(), DD_E_CAPACITY,
+               "dd_tracker_update: track capacity %d exhausted", t->tcap);
+    for (int dd : un_dets) {                                   // tracker.py:135-138
+        TrackRec tr;
+        tr.id = t->next_id++;
+        tr.state = TENTATIVE; tr.tsu = 0; tr.hits = 1; tr.age = 1;
+        tr.slot = t->free_slots.back();
+        t->free_slots.pop_back();
+        tr.last_det = dd;
+        t->tracks.push_back(tr);
+        t->m_new.push_back(tr.slot); t->m_new.push_back(doff + dd);
+    }
+    // ---- tracker.py:80-81 split live / deleted
+    std::vector<TrackRec> live;
+    t->deleted.clear();
+    for (auto &tr : t->tracks) (tr.state == DELETED ? t->deleted : live).push_back(tr);
+    t->tracks.swap(live);
+    for (auto &tr : t->deleted) t->pending_free.push_back(tr.slot);
+    return DD_OK;
+}
+}  // namespace
+
 int trackers_update_match(dd_tracker **ts, int S) {
     TrackerPool *p = ts[0]->pool;
     hipStream_t s = p->ctx->stream;
@@ -458,86 +546,29 @@ int trackers_update_match(dd_tracker **ts, int S) {
     if ((rc = p->h_pairs.reserve(max_pairs * 3 * sizeof(int) + 64)) != DD_OK) return rc;
     if ((rc = p->d_pairs.reserve(max_pairs * 3 * sizeof(int) + 64)) != DD_OK) return rc;
     std::vector<int> upd_slot, upd_det, upd_row, new_slot, new_det, new_row;
-    std::vector<std::pair<int, int>> matches;
-    std::vector<int> un_rows_final, un_dets, lvl_rows, tmp_rows, tmp_dets, confirmed, unconfirmed;
-    for (int z = 0; z < S; ++z) {
+    std::atomic<int> first_err{DD_OK};
+    ddk::parallel_for(S, 8, [&](int z0, int z1) {
+        for (int z = z0; z < z1; ++z) {
+            const int r = match_one_stream(p, ts[z], z);
+            if (r != DD_OK) { int ok = DD_OK; first_err.compare_exchange_strong(ok, r); }
+        }
+    });
+    if (first_err.load() != DD_OK) {                               // (dd_last_error is per thread: restate it on the caller's)
+        dd_set_error("dd_tracker_update: track capacity %d of a stream exhausted", ts[0]->tcap);
+        return first_err.load();
+    }
+    for (int z = 0; z < S; ++z) {                                  // gallery placement: serial, stream order (track.py:140 features.append)
         dd_tracker *t = ts[z];
-        const int n = t->ph_n, T = t->ph_T, doff = p->det_off[z];
-        matches.clear(); un_rows_final.clear(); un_dets.clear();
-        t->ph_cost_base = (n > 0 && T > 0 && p->have_cost) ? p->cost_base[z] : -1;   // parity aid (dd_tracker_last_cost)
-        if (n > 0 && T > 0) {
-            const double *app = p->h_cost.as<double>() + p->cost_base[z], *iou = app + (size_t)T * n;
-            // ---- tracker.py:95-133 _match
-            confirmed.clear(); unconfirmed.clear();
-            for (int i = 0; i < T; ++i) (t->tracks[i].state == CONFIRMED ? confirmed : unconfirmed).push_back(i);
-            un_dets.resize(n);
-            std::iota(un_dets.begin(), un_dets.end(), 0);
-            for (int level = 0; level < t->max_age; ++level) {            // linear_assignment.py:78-141
-                if (un_dets.empty()) break;
-                lvl_rows.clear();
-                for (int k : confirmed) if (t->tracks[k].tsu == 1 + level) lvl_rows.push_back(k);
-                if (lvl_rows.empty()) continue;
-                min_cost_matching(app, n, t->max_cos, lvl_rows, un_dets, matches, tmp_rows, tmp_dets);
-                un_dets = tmp_dets;
-            }
-            // unmatched_tracks_a = list(set(track_indices) - set(k for k, _ in matches)) (linear_assignment.py:140):
-            // the reference's order is CPython's set iteration order, reproduced by csrc/pyset.cpp, because it
-            // becomes the row order of the IoU assignment below (tracker.py:120-123).
-            std::vector<int> matched_rows, un_a_all;
-            for (auto &m : matches) matched_rows.push_back(m.first);
-            ddk::pyset_difference_order(confirmed, matched_rows, un_a_all);
-            std::vector<int> iou_rows = unconfirmed, un_rows_a;
-            for (int k : un_a_all) {
-                if (t->tracks[k].tsu == 1) iou_rows.push_back(k); else un_rows_a.push_back(k);
-            }
-            std::vector<int> un_rows_b;
-            min_cost_matching(iou, n, t->max_iou, iou_rows, un_dets, matches, un_rows_b, tmp_dets);
-            un_dets = tmp_dets;
-            un_rows_final = un_rows_a;
-            un_rows_final.insert(un_rows_final.end(), un_rows_b.begin(), un_rows_b.end());
-        } else {
-            un_dets.resize(n);
-            std::iota(un_dets.begin(), un_dets.end(), 0);
-            for (int i = 0; i < T; ++i) un_rows_final.push_back(i);
-        }
-        // ---- tracker.py:70-79 apply to the integer book-keeping
-        for (auto &m : matches) {                                  // track.py:127-152
-            TrackRec &tr = t->tracks[m.first];
-            tr.hits += 1;
-            tr.tsu = 0;
-            tr.last_det = m.second;
-            if (tr.state == TENTATIVE && tr.hits >= t->n_init) tr.state = CONFIRMED;
+        for (size_t i = 0; i + 1 < t->m_upd.size(); i += 2) {
             int grow = 0;
-            if ((rc = gallery_place(p, tr.slot, t->budget, &grow)) != DD_OK) return rc;
-            upd_slot.push_back(tr.slot); upd_det.push_back(doff + m.second); upd_row.push_back(grow);
-            t->last_pairs.push_back(m.first);
-            t->last_pairs.push_back(m.second);
+            if ((rc = gallery_place(p, t->m_upd[i], t->budget, &grow)) != DD_OK) return rc;
+            upd_slot.push_back(t->m_upd[i]); upd_det.push_back(t->m_upd[i + 1]); upd_row.push_back(grow);
         }
-        for (int r : un_rows_final) {                              // track.py:190-196
-            TrackRec &tr = t->tracks[r];
-            if (tr.state == TENTATIVE) tr.state = DELETED;
-            else if (tr.tsu > t->max_age) tr.state = DELETED;
-        }
-        DD_REQUIRE((int)t->free_slots.size() >= (int)un_dets.size(), DD_E_CAPACITY,
-                   "dd_tracker_update: track capacity %d exhausted", t->tcap);
-        for (int dd : un_dets) {                                   // tracker.py:135-138
-            TrackRec tr;
-            tr.id = t->next_id++;
-            tr.state = TENTATIVE; tr.tsu = 0; tr.hits = 1; tr.age = 1;
-            tr.slot = t->free_slots.back();
-            t->free_slots.pop_back();
-            tr.last_det = dd;
-            t->tracks.push_back(tr);
+        for (size_t i = 0; i + 1 < t->m_new.size(); i += 2) {
             int grow = 0;
-            if ((rc = gallery_place(p, tr.slot, t->budget, &grow)) != DD_OK) return rc;
-            new_slot.push_back(tr.slot); new_det.push_back(doff + dd); new_row.push_back(grow);
+            if ((rc = gallery_place(p, t->m_new[i], t->budget, &grow)) != DD_OK) return rc;
+            new_slot.push_back(t->m_new[i]); new_det.push_back(t->m_new[i + 1]); new_row.push_back(grow);
         }
-        // ---- tracker.py:80-81 split live / deleted
-        std::vector<TrackRec> live;
-        t->deleted.clear();
-        for (auto &tr : t->tracks) (tr.state == DELETED ? t->deleted : live).push_back(tr);
-        t->tracks.swap(live);
-        for (auto &tr : t->deleted) t->pending_free.push_back(tr.slot);
     }
     const int n_upd = (int)upd_slot.size(), n_new = (int)new_slot.size(), np = n_upd + n_new;
     if (np > 0) {
@@ -590,6 +621,24 @@ int trackers_update_end(dd_tracker **ts, int S) {
     return DD_OK;
 }
 
+// The host mirrors of a tracker (what dd_tracker_read returns without the covariances): no device call, so the pipeline's
+// pool threads may use it.  which: 0 live tracks, 1 the tracks the last update deleted.
+int tracker_read_host(dd_tracker *t, int which, int64_t *ints6_host, double *means_host) {
+    const std::vector<TrackRec> &v = which == 0 ? t->tracks : t->deleted;
+    const std::vector<double> &mm = which == 0 ? t->live_means : t->dead_means;
+    const int n = (int)v.size();
+    if (ints6_host)
+        for (int i = 0; i < n; ++i) {
+            int64_t *o = ints6_host + (size_t)i * 6;
+            o[0] = v[i].id; o[1] = v[i].state; o[2] = v[i].tsu; o[3] = v[i].hits; o[4] = v[i].age; o[5] = v[i].last_det;
+        }
+    if (means_host && n) {
+        DD_REQUIRE(mm.size() == (size_t)n * 8, DD_E_STATE, "dd_tracker_read: means are only mirrored after update()");
+        memcpy(means_host, mm.data(), (size_t)n * 8 * sizeof(double));
+    }
+    return DD_OK;
+}
+
 }  // namespace ddk
 
 extern "C" {
@@ -637,20 +686,12 @@ int dd_tracker_count(dd_tracker *t, int which, int *out_n_host) {
 
 int dd_tracker_read(dd_tracker *t, int which, int64_t *ints6_host, double *means_host, double *covs_host) {
     DD_REQUIRE(t, DD_E_ARG, "dd_tracker_read: NULL tracker");
-    DD_DEVICE(t->pool->ctx);
+    int rc0 = ddk::tracker_read_host(t, which, ints6_host, means_host);
+    if (rc0 != DD_OK) return rc0;
     const std::vector<TrackRec> &v = which == 0 ? t->tracks : t->deleted;
-    const std::vector<double> &mm = which == 0 ? t->live_means : t->dead_means;
     const int n = (int)v.size();
-    if (ints6_host)
-        for (int i = 0; i < n; ++i) {
-            int64_t *o = ints6_host + (size_t)i * 6;
-            o[0] = v[i].id; o[1] = v[i].state; o[2] = v[i].tsu; o[3] = v[i].hits; o[4] = v[i].age; o[5] = v[i].last_det;
-        }
-    if (means_host && n) {
-        DD_REQUIRE(mm.size() == (size_t)n * 8, DD_E_STATE, "dd_tracker_read: means are only mirrored after update()");
-        memcpy(means_host, mm.data(), (size_t)n * 8 * sizeof(double));
-    }
     if (covs_host && n) {
+        DD_DEVICE(t->pool->ctx);
         TrackerPool *p = t->pool;
         hipStream_t s = p->ctx->stream;
         int rc;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Whole-forward device time of a network (HIP events on the launch stream), no per-op instrumentation.
-Usage: python scripts/time_forward.py ssd|mars|yolo BATCH"""
+Usage: python scripts/time_forward.py ssd|mars|yolo BATCH [kernels]   (kernels: also print which special launches ran)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -32,3 +32,6 @@ us = np.array([ev[r].elapsed_time(ev[r + 1]) * 1e3 for r in range(reps)])
 ref = net.read().copy()
 import hashlib
 print(f'{kind} batch {batch}: mean {us.mean():.1f} us  min {us.min():.1f} us  checksum {float(np.abs(ref).sum()):.6e}  sha {hashlib.sha256(np.ascontiguousarray(ref).tobytes()).hexdigest()[:16]}')
+if len(sys.argv) > 3 and sys.argv[3] == 'kernels':
+    from deepdish_amd.profile import net_op_launches, OPK_NAMES
+    print('launches:', ' '.join(sorted({OPK_NAMES[int(c)] for c in net_op_launches(net) if int(c) in OPK_NAMES})))

@@ -38,3 +38,24 @@ def test_single_rank_rehearsal():
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads(r.stdout.strip())
     assert out['n_gpus'] == 1 and out['counts_pos_neg_int_del'] == [1, 10, 11, 0]
+
+
+def test_gpus_8_rehearsal_keeps_the_node_within_its_cores():
+    """The driver's scaling run is N = 1, 2, 4, 8 on one node: eight ranks come up, one JSON line, n_gpus == 8, counts summed
+    over all eight, and what the ranks would start on the host (generator processes, worker-group threads, host-pool
+    threads) is each rank's share of the node's cores -- generators cores // (2 * 8), never fewer than one of anything."""
+    r = _run(['--gpus', '8', '--rehearse-cpu'], timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 8 and out['value'] is None
+    tri = sum(range(1, 9))
+    assert out['counts_pos_neg_int_del'] == [tri, 10 * tri, 11 * tri, 0]
+    cores = out['host_cores']
+    ranks = out['per_rank_host']
+    assert sorted(b['rank'] for b in ranks) == list(range(8))
+    for b in ranks:
+        assert b['generator_processes'] == max(1, min(16, cores // 16))
+        assert b['host_pool_threads'] == max(1, min(12, cores // 8 - b['worker_groups'] - 1))
+        assert b['worker_groups'] >= 1

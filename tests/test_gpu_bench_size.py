@@ -1,0 +1,99 @@
+"""GPU: the launch shapes bench.py's headline is measured at (384 frames per detector launch, ~7 000 crops per encoder
+launch, conv_ws_dw_k at 3 whole frames per worker) tied to the oracle.
+
+The reference has no such notion -- it runs one stream, one frame at a time (deepdish.py:1324-1340 upstream) -- so this is
+the build's own batching and its own obligation: the kernels that only run from some batch size on (conv3x3_pool_rows_k<STEM>,
+res_unit_rows_k, conv3x3_c64_rows_k, conv3x3_s2_rows_k, ssd_front_k, dwpw_rows_k, conv_ws_k, conv_ws_dw_k) must give, for
+every image of a bench-sized launch, the bits of that image's own single-image forward, and those single-image forwards are
+what tests/test_gpu_nets.py holds against oracle/nets_torch.py -- repeated here on images taken out of the big launch."""
+import hashlib
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _close(got, want, atol, rtol):
+    err = np.abs(got.astype(np.float64) - want.astype(np.float64))
+    return float((err / (atol + rtol * np.abs(want.astype(np.float64)))).max())
+
+
+def test_ssd_launch_of_384_frames_is_frame_independent_and_matches_the_oracle():
+    """One 384-frame launch (bench: 384 streams per worker group): frames 0, 1, 2, n/2, n-1 bit-identical to their single-frame
+    forwards; two of them against the f32 restatement at test_gpu_nets.py's per-element tolerance."""
+    from deepdish_amd import nets
+    from deepdish_amd.engine import Net
+    from deepdish_amd.profile import net_op_launches, OPK_NAMES
+    from oracle import nets_torch
+    n = 384
+    wd = nets.synthetic_ssd_weights(1234)
+    net = Net(nets.compile_ssd_mobilenet(wd), max_batch=n)
+    rng = np.random.default_rng(384)
+    x = rng.integers(0, 256, (n, 300, 300, 3), dtype=np.uint8)
+    x[1] = 0; x[2] = 255
+    net.forward(x)
+    ran = {OPK_NAMES.get(int(c)) for c in net_op_launches(net)}
+    assert {'ssd_front_k', 'dwpw_rows_k', 'conv_ws_k', 'conv_ws_dw_k'} <= ran, ran       # the bench's kernels did run
+    full = net.read()[:, :, 0, :].copy()
+    assert np.isfinite(full).all()
+    picks = (0, 1, 2, n // 2, n - 1)
+    for i in picks:
+        net.forward(x[i:i + 1])
+        np.testing.assert_array_equal(net.read()[0, :, 0, :], full[i], err_msg='frame %d' % i)
+    two = [0, n - 1]
+    want = nets_torch.ssd_forward(wd, x[two], w16=True)
+    assert _close(full[two], want, 8e-3, 1e-2) <= 1.0
+
+
+def test_mars_launch_of_7680_crops_is_crop_independent_and_matches_the_oracle():
+    """One 7 680-crop launch (384 streams x 20 detections: conv3x3_pool_rows_k<STEM> with one unit per crop, the residual-unit
+    and conv3_x row kernels on every CU): crops 0, 1, 2, n/2, n-1 bit-identical to single-crop forwards; eight crops
+    against the f32 restatement within test_gpu_nets.py's tolerance (5e-3 absolute, 5e-4 cosine)."""
+    from deepdish_amd import nets
+    from deepdish_amd.engine import Net
+    from deepdish_amd.profile import net_op_launches, OPK_NAMES
+    from oracle import nets_torch
+    n = 7680
+    wd = nets.synthetic_mars_weights(1234)
+    net = Net(nets.compile_mars(wd), max_batch=n)
+    rng = np.random.default_rng(7680)
+    x = rng.integers(0, 256, (n, 64, 32, 3), dtype=np.uint8)
+    x[1] = 0; x[2] = 255
+    net.forward(x)
+    ran = {OPK_NAMES.get(int(c)) for c in net_op_launches(net)}
+    assert 'conv3x3_pool_rows_k<STEM>' in ran and len(ran - {None}) >= 4, ran
+    full = net.read()[:, 0, 0, :].copy()
+    np.testing.assert_allclose(np.linalg.norm(full.astype(np.float64), axis=1), 1.0, atol=1e-4)
+    one = Net(nets.compile_mars(wd), max_batch=n)                  # same engine size: same split-K decisions
+    for i in (0, 1, 2, n // 2, n - 1):
+        one.forward(x[i:i + 1])
+        np.testing.assert_array_equal(one.read()[0, 0, 0, :], full[i], err_msg='crop %d' % i)
+    eight = [0, 1, 2, 3, n // 2, n // 2 + 1, n - 2, n - 1]
+    want = nets_torch.mars_forward(wd, x[eight], w16=True)
+    got = full[eight]
+    assert np.abs(got - want).max() < 5e-3
+    assert (1.0 - np.sum(got * want, axis=1)).max() < 5e-4
+
+
+@pytest.mark.parametrize('batch', [192, 256, 300, 384])
+def test_pointwise_plus_depthwise_launch_at_the_bench_batch_sizes(batch):
+    """conv_ws_dw_k takes whole frames per worker: 256 frames = 2 per worker, 384 = 3 (the bench's case: another ring phase),
+    192 and 300 = uneven (only the layer whose frames balance over its workers fuses, the others run as two launches).
+    Whatever runs, the forward has the bits of the unfused path (DD_WS_DW_OFF=1; the switch is read once per process: two
+    child processes)."""
+    sums, fused = [], []
+    for off in ('0', '1'):
+        env = dict(os.environ, DD_WS_DW_OFF=off)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'time_forward.py'), 'ssd', str(batch), 'kernels'],
+                           capture_output=True, text=True, env=env, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        sums.append(re.search(r'sha (\S+)', r.stdout).group(1))
+        fused.append('conv_ws_dw_k' in r.stdout)
+    assert sums[0] == sums[1], sums
+    assert fused[1] is False and (fused[0] or batch not in (256, 384)), (batch, fused)

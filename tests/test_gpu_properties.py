@@ -172,6 +172,48 @@ def test_graph_replay_matches_eager():
     assert res[0][1].sum() > 0
 
 
+def test_graph_replay_survives_a_larger_batch_in_between():
+    """The split-K slab pointer is baked into a captured forward: it is sized for the engine's max_batch at creation, so a call
+    with more crops between two replays of a small batch cannot free and reallocate it under the graph (round 2 sized it by
+    the batch of the call).  3 crops twice (captured), 48 crops, 3 crops again (replayed) == the eager results."""
+    import torch
+    from deepdish_amd import nets
+    from deepdish_amd.engine import Net
+    wd = nets.synthetic_mars_weights(1234)
+    rng = np.random.default_rng(11)
+    small = torch.from_numpy(rng.integers(0, 256, (3, 64, 32, 3), dtype=np.uint8)).cuda()
+    big = torch.from_numpy(rng.integers(0, 256, (48, 64, 32, 3), dtype=np.uint8)).cuda()
+    ref = Net(nets.compile_mars(wd), max_batch=64)
+    ref.forward(small); want_small = ref.read()[:, 0, 0, :].copy()
+    ref.forward(big); want_big = ref.read()[:, 0, 0, :].copy()
+    net = Net(nets.compile_mars(wd), max_batch=64)              # MARS at max_batch 64 splits K for fc1 and the 64-channel layers
+    net.use_graph(True)
+    for _ in range(3):                                          # eager, capture, replay
+        net.forward(small)
+        np.testing.assert_array_equal(net.read()[:, 0, 0, :], want_small)
+    net.forward(big)
+    np.testing.assert_array_equal(net.read()[:, 0, 0, :], want_big)
+    for _ in range(2):
+        net.forward(small)                                      # replays the graph captured before the larger batch ran
+        np.testing.assert_array_equal(net.read()[:, 0, 0, :], want_small)
+
+
+def test_reading_a_tensor_that_stayed_on_chip_is_an_error():
+    """From 160 crops MARS conv1_1 runs inside conv1_2's launch and its tensor is never written: dd_net_read on it must fail
+    loudly instead of handing back stale bytes; at a batch where the layer runs on its own the read works."""
+    from deepdish_amd import nets
+    from deepdish_amd.engine import Net
+    net = Net(nets.compile_mars(nets.synthetic_mars_weights(1234)), max_batch=256)
+    t = net.program.meta['tensors']['conv1_1']
+    x = np.random.default_rng(12).integers(0, 256, (256, 64, 32, 3), dtype=np.uint8)
+    net.forward(x[:8])
+    assert np.isfinite(net.read(tensor=t)).all()
+    net.forward(x)
+    with pytest.raises(RuntimeError, match='not written'):
+        net.read(tensor=t)
+    net.read(tensor=net.program.meta['tensors']['pool1'])       # the launch's own output is there
+
+
 def test_stream_order_does_not_matter():
     """Streams are independent units: permuting which slot a stream occupies permutes the results."""
     from deepdish_amd.multipipe import MultiStreamPipeline
