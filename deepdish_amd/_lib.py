@@ -79,6 +79,11 @@ SIGNATURES = {
     'dd_net_profile_read': [P, P, c_int, POINTER(c_int)],
     'dd_net_op_launches': [P, P, c_int, POINTER(c_int)],
     'dd_ssd_postprocess': [P, P, P, c_int, c_int, c_int, c_float, c_float, P, P, P, P, P],
+    'dd_ssd_decode': [P, P, P, c_int, c_int, c_float, P, P, P, P, c_int, P],
+    'dd_ssd_postprocess_decoded': [P, P, P, P, P, c_int, c_int, c_float, c_float, P, P, P, P, c_int, P],
+    'dd_net_ssd_decode': [P, P, c_int, c_float, c_int],
+    'dd_net_ssd_decoded': [P, POINTER(P), POINTER(P), POINTER(P), POINTER(P)],
+    'dd_net_ssd_decoded_read': [P, c_int, P, P, P, P],
     'dd_ssd_detections': [P, P, P, P, c_int, c_int, c_double, c_double, c_double, c_double, P, P, P, P, P],
     'dd_yolov5_decode': [P, P, c_int, c_int, c_float, c_float, c_float, P, P, P, c_int, P, P],
     'dd_pipeline_create': [P, c_int, c_int, c_int, P, P, c_int, c_int, P, c_char_p, c_char_p, c_double, c_double,

@@ -17,6 +17,7 @@
 #include <map>
 #include <string>
 #include "common.h"
+#include "ssd_dev.h"
 
 namespace {
 
@@ -28,7 +29,7 @@ enum { OP_INPUT = 1, OP_CONV = 2, OP_DWCONV = 3, OP_MAXPOOL = 4, OP_UPSAMPLE = 5
 enum { ACT_NONE = 0, ACT_RELU6 = 1, ACT_ELU = 2, ACT_SILU = 3, ACT_RELU = 4, ACT_SIGMOID = 5 };
 enum { EPI_F16 = 0, EPI_F32 = 1, EPI_SSD_HEAD = 2, EPI_YOLO = 3 };
 // dd_net_op_launches: 0 = the op's own kernel, 1 = no launch (folded into the next op's), else the fused / special kernel
-enum { OPK_DEFAULT = 0, OPK_FOLDED = 1, OPK_POOL_ROWS = 2, OPK_POOL_ROWS_STEM = 3, OPK_RES_UNIT = 4, OPK_SSD_FRONT = 5, OPK_C64_ROWS = 6, OPK_S2_ROWS = 7, OPK_CONV_WS = 8, OPK_WS_DW = 9, OPK_DWPW_ROWS = 10 };
+enum { OPK_DEFAULT = 0, OPK_FOLDED = 1, OPK_POOL_ROWS = 2, OPK_POOL_ROWS_STEM = 3, OPK_RES_UNIT = 4, OPK_SSD_FRONT = 5, OPK_C64_ROWS = 6, OPK_S2_ROWS = 7, OPK_CONV_WS = 8, OPK_WS_DW = 9, OPK_DWPW_ROWS = 10, OPK_SSD_HEAD_DEC = 11 };
 enum { DT_F16 = 0, DT_F32 = 1, DT_U8 = 2 };
 
 constexpr int OP_WORDS = 48;       // int32 words per op record (see deepdish_amd/nets.py)
@@ -64,6 +65,8 @@ struct ConvP {
     const uint8_t *src8; float in_mean, in_scale;      // stem: u8 [N][H][W][3] source, (x - mean) * scale
     // fused depthwise 3x3 -> pointwise (dwpw_k): the depthwise half (H, W, stride, pad_* describe it; kh = kw = 1)
     const _Float16 *dw_w; const float *dw_bias; int dw_act; int total_quads;
+    // SSD head with the decode in its epilogue (ssd_head_finish): per-anchor outputs [max_batch][n_anchors] instead of the head matrix
+    const float *anchors; float *dec_boxes, *dec_score, *dec_keys; int *dec_cls; float dec_thr;
 };
 
 
@@ -335,6 +338,68 @@ __device__ __forceinline__ void conv_finish(const ConvP &P, f4 (&acc)[NI][MI], _
     }
 }
 
+// SSD head tile whose 96 output channels are ONE anchor of the feature map (host layout: 4 box encodings, class 0 =
+// background, classes 1 .. C-1, zero padding up to 96; nets.py packs the head weights that way for this kernel): the
+// first stage of TFLite_Detection_PostProcess runs here, on the accumulators -- best class logit (lowest class on ties, as
+// ssd_decode_k's scan + butterfly), anchor decode, sigmoid, score threshold (ssd_dev.h: the same arithmetic, the same bits)
+// -- and the [n][1917][4 + C] f32 head matrix (140 MB per 384 frames, written here and read straight back by
+// ssd_decode_k) never exists.  Two lanes per pixel scan the classes of the staged tile row, lane 0 of the pair decodes.
+template <int WM, int WN, int MI, int NI>
+__device__ __forceinline__ void ssd_head_finish(const ConvP &P, f4 (&acc)[NI][MI], _Float16 *lds, int m0, int n0, int hw) {
+    constexpr int BM = WM * MI * 16, BN = WN * NI * 16, T = WM * WN * 64;
+    static_assert(BN == 96 && T == 2 * BM, "one anchor per channel tile, two lanes per pixel");
+    constexpr int OROW = BN + 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int fr = lane & 15, fq = lane >> 4;
+    float *ot = reinterpret_cast<float *>(lds);
+#pragma unroll
+    for (int b = 0; b < MI; ++b)
+#pragma unroll
+        for (int a = 0; a < NI; ++a)
+            *reinterpret_cast<f4 *>(ot + ((wm * MI + b) * 16 + fr) * OROW + (wn * NI + a) * 16 + fq * 4) = acc[a][b];
+    __syncthreads();
+    const int pl = tid >> 1, h = tid & 1;
+    const int m = m0 + pl;
+    const int C = P.p[0];                                       // classes incl. background: columns 4 .. 4 + C - 1 of the anchor
+    const float *row = ot + pl * OROW;
+    const float *bias = P.bias + n0;
+    float best = -__builtin_inff();
+    int bi = 0x7fffffff;
+    // lane h scans columns [4 + 48 h, 4 + 48 h + 48): ascending, strict `>` = the lowest class wins a tie
+#pragma unroll
+    for (int c4 = 0; c4 < 12; ++c4) {
+        const int col = 4 + 48 * h + 4 * c4;
+        const f4 v = (col < BN) ? *reinterpret_cast<const f4 *>(row + col) + *reinterpret_cast<const f4 *>(bias + col) : f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int cls = col + q - 4;                        // class id (0 = background, skipped)
+            if (cls >= 1 && cls < C && v[q] > best) { best = v[q]; bi = cls - 1; }
+        }
+    }
+    {
+        const float ob = __shfl_xor(best, 1, 64);
+        const int oi = __shfl_xor(bi, 1, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (h == 0 && m < P.m) {
+        const int n = m / hw, p = m - n * hw;
+        const int A = P.p[5], K = P.p[1];
+        const int a = P.p[2] + p * A + n0 / BN;                // anchor index inside the image
+        const f4 rv = *reinterpret_cast<const f4 *>(row) + *reinterpret_cast<const f4 *>(bias);
+        const float r[4] = {rv[0], rv[1], rv[2], rv[3]};
+        const f4 av = *reinterpret_cast<const f4 *>(P.anchors + (size_t)a * 4);
+        const float an[4] = {av[0], av[1], av[2], av[3]};
+        float bx[4];
+        const float sc = ssddev::decode_anchor(r, an, best, bx);
+        const size_t o = (size_t)n * K + a;
+        *reinterpret_cast<f4 *>(P.dec_boxes + o * 4) = f4{bx[0], bx[1], bx[2], bx[3]};
+        P.dec_score[o] = sc;
+        P.dec_cls[o] = bi;
+        P.dec_keys[o] = sc >= P.dec_thr ? sc : -1.f;
+    }
+}
+
 // Epilogue without the LDS transposition: used when the weight rows of the tile were staged in the
 // fragment order of rw_weight_row (conv_glds_k does that for plain f16 outputs), so the lane that owns
 // rows fq*4.. of fragments 2g and 2g+1 holds 8 consecutive output channels of its pixel.
@@ -515,7 +580,7 @@ __device__ __forceinline__ void lds_fill16(const _Float16 *g, _Float16 *lds_wave
 // for every lane, so the tap walk is scalar and a lane does one add and a two-bit test per row group; 0: anything
 // else.  (The general per-lane walk costs more issue slots per K step than the MFMAs: 19x19x512 -> 512 went
 // 24.9 -> 21.8 us with FM 1, the MARS 16x8x64 -> 64 layers 28.8 -> 24.5 us with FM 2.)
-template <int WM, int WN, int MI, int NI, int FM = 0>
+template <int WM, int WN, int MI, int NI, int FM = 0, bool DEC = false>       // DEC: SSD head, one anchor per 96-channel tile, decode in the epilogue
 __global__ __launch_bounds__(WM *WN * 64) void conv_glds_k(const ConvP P) {
     constexpr int NW = WM * WN;
     constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
@@ -662,7 +727,9 @@ __global__ __launch_bounds__(WM *WN * 64) void conv_glds_k(const ConvP P) {
             __syncthreads();
         }
     }
-    if constexpr (MI * NI >= 12) {
+    if constexpr (DEC) {
+        ssd_head_finish<WM, WN, MI, NI>(P, acc, lds, m0, n0, hw);
+    } else if constexpr (MI * NI >= 12) {
         // 48 x 64 per wave and up: only the untransposed epilogue is compiled in (the launcher sends nothing else
         // here); with the general one the accumulator array stops being promoted to registers and every K step
         // stores all its fragments to scratch (seen with 64 x 64 per wave: 4x slower)
@@ -2771,6 +2838,10 @@ struct dd_net {
     bool profile = false;
     int last_batch = 0;
     DevBuf slab;                             // split-K partial sums (sized for max_batch: see launch_conv)
+    // dd_net_ssd_decode: the SSD head ops decode in their epilogue into these per-anchor arrays ([max_batch][n_anchors] each)
+    bool ssd_dec = false;
+    int dec_anchors = 0; float dec_thr = 0.f;
+    float *d_anchors = nullptr, *dec_boxes = nullptr, *dec_score = nullptr, *dec_keys = nullptr; int *dec_cls = nullptr;
     bool slab_moved = false;                 // the slab was reallocated during the last eager forward: captured graphs hold a dead pointer
     _Float16 *d_zero = nullptr;              // 256 bytes of zeros (padding taps of the direct-to-LDS fills)
     bool use_glds = true;
@@ -2877,6 +2948,22 @@ int launch_conv(hipStream_t s, ConvP &P, DevBuf &slab, int max_batch, int device
         hipLaunchKernelGGL(conv_splitk_finish_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, P);
         DD_LAUNCH_CHECK();
     }
+    return DD_OK;
+}
+
+// SSD head layer with the decode in its epilogue: 128 pixels x one anchor (96 channels) per block, weights in the
+// per-anchor layout nets.py packs for it (P.w / P.bias already point at that copy).
+int launch_ssd_head_dec(hipStream_t s, ConvP &P) {
+    constexpr int WM = 2, WN = 2, MI = 4, NI = 3, BM = WM * MI * 16, BN = WN * NI * 16;
+    static_assert(BN == 96, "one anchor per tile");
+    DD_REQUIRE(P.kh == 1 && P.kw == 1 && P.stride == 1 && P.pad_t == 0 && P.pad_l == 0 && P.cin % 64 == 0 && P.kpad == P.cin &&
+               P.ho == P.H && P.wo == P.W && 4 + P.p[0] <= BN, DD_E_ARG, "ssd head decode: layer shape");
+    P.splitk = 1; P.slab = nullptr;
+    constexpr size_t lds_bytes = (size_t)2 * (BM + BN) * 64 * sizeof(_Float16);
+    static_assert(lds_bytes >= (size_t)BM * (BN + 4) * sizeof(float) && lds_bytes <= 65536, "staged tile fits the operand buffers");
+    const int gx = dd_ceil_div(P.m, BM), gy = P.p[5];           // channel tiles = anchors per pixel
+    hipLaunchKernelGGL((conv_glds_k<WM, WN, MI, NI, 1, true>), dim3(gx, gy, 1), dim3(WM * WN * 64), lds_bytes, s, P);
+    DD_LAUNCH_CHECK();
     return DD_OK;
 }
 
@@ -3320,6 +3407,7 @@ int dd_net_destroy(dd_net *n) {
     n->slab.release();
     (void)hipFree(n->d_zero);
     (void)hipFree(n->d_weights);
+    for (void *q : {(void *)n->d_anchors, (void *)n->dec_boxes, (void *)n->dec_score, (void *)n->dec_keys, (void *)n->dec_cls}) (void)hipFree(q);
     delete n;
     return DD_OK;
 }
@@ -3404,6 +3492,9 @@ int dd_net_read(dd_net *n, int tensor, int n_img, void *dst, int dst_on_device, 
     // never written: reading it would return stale or uninitialised data.
     for (int i = 0; i < n->n_ops && i < (int)n->op_launch.size(); ++i) {
         const int32_t *o = n->prog.data() + n->ops_off + (size_t)i * OP_WORDS;
+        DD_REQUIRE(!(o[2] == t && n->op_launch[i] == OPK_SSD_HEAD_DEC), DD_E_STATE,
+                   "dd_net_read: tensor %d (the SSD head matrix) was not written: the head layers decoded in their epilogue "
+                   "(dd_net_ssd_decode); read dd_net_ssd_decoded instead", t);
         DD_REQUIRE(!((o[2] == t || o[4] == t) && n->op_launch[i] == OPK_FOLDED), DD_E_STATE,
                    "dd_net_read: tensor %d was not written by the last forward (op %d ran inside the next op's launch at this batch "
                    "size and its output stayed on chip); run a smaller batch or a program compiled without the fusion flags", t, i);
@@ -3423,6 +3514,66 @@ int dd_net_use_graph(dd_net *net, int enable) {
     DD_DEVICE(net->ctx);
     net->use_graph = enable != 0;
     if (!net->use_graph) net_drop_graphs(net);
+    return DD_OK;
+}
+
+// SSD detector: run the first stage of TFLite_Detection_PostProcess (tools/ssd_mobilenet.py:103: best class, anchor decode,
+// sigmoid, score threshold) inside the head layers' epilogues.  anchors_host f32 [n_anchors][4] (yc, xc, h, w).
+int dd_net_ssd_decode(dd_net *net, const float *anchors_host, int n_anchors, float score_thr, int enable) {
+    DD_REQUIRE(net, DD_E_ARG, "dd_net_ssd_decode: NULL net");
+    DD_DEVICE(net->ctx);
+    net_drop_graphs(net);
+    if (!enable) { net->ssd_dec = false; return DD_OK; }
+    DD_REQUIRE(anchors_host && n_anchors > 0, DD_E_ARG, "dd_net_ssd_decode: anchors missing");
+    int heads = 0;
+    for (int i = 0; i < net->n_ops; ++i) {
+        const int32_t *o = net->prog.data() + net->ops_off + (size_t)i * OP_WORDS;
+        if (o[0] == OP_CONV && o[15] == EPI_SSD_HEAD) {
+            DD_REQUIRE(o[18] && o[21] == n_anchors && 4 + o[20] <= 96, DD_E_ARG,
+                       "dd_net_ssd_decode: head op %d has no per-anchor weight copy, or %d anchors / %d classes do not fit", i, o[21], o[20]);
+            ++heads;
+        }
+    }
+    DD_REQUIRE(heads > 0, DD_E_ARG, "dd_net_ssd_decode: the program has no SSD head");
+    if (net->dec_anchors != n_anchors) {
+        for (void *q : {(void *)net->d_anchors, (void *)net->dec_boxes, (void *)net->dec_score, (void *)net->dec_keys, (void *)net->dec_cls}) (void)hipFree(q);
+        net->d_anchors = net->dec_boxes = net->dec_score = net->dec_keys = nullptr; net->dec_cls = nullptr; net->dec_anchors = 0;
+        const size_t per = (size_t)net->max_batch * n_anchors;
+        DD_HIP(hipMalloc(&net->d_anchors, (size_t)n_anchors * 4 * sizeof(float)));
+        DD_HIP(hipMalloc(&net->dec_boxes, per * 4 * sizeof(float)));
+        DD_HIP(hipMalloc(&net->dec_score, per * sizeof(float)));
+        DD_HIP(hipMalloc(&net->dec_keys, per * sizeof(float)));
+        DD_HIP(hipMalloc(&net->dec_cls, per * sizeof(int)));
+        net->dec_anchors = n_anchors;
+    }
+    DD_HIP(hipMemcpy(net->d_anchors, anchors_host, (size_t)n_anchors * 4 * sizeof(float), hipMemcpyHostToDevice));
+    net->dec_thr = score_thr;
+    net->ssd_dec = true;
+    return DD_OK;
+}
+
+// Device arrays the last forward decoded into: boxes f32 [n][n_anchors][4] (ymin, xmin, ymax, xmax), scores f32, classes
+// int32 (class id - 1), keys f32 (score, or -1 below the threshold) [n][n_anchors] -- what ssd_decode_k makes of the head matrix.
+int dd_net_ssd_decoded(dd_net *net, float **boxes, float **scores, int **classes, float **keys) {
+    DD_REQUIRE(net && net->ssd_dec, DD_E_STATE, "dd_net_ssd_decoded: dd_net_ssd_decode is off");
+    if (boxes) *boxes = net->dec_boxes;
+    if (scores) *scores = net->dec_score;
+    if (classes) *classes = net->dec_cls;
+    if (keys) *keys = net->dec_keys;
+    return DD_OK;
+}
+
+int dd_net_ssd_decoded_read(dd_net *net, int n, float *boxes_host, float *scores_host, int *classes_host, float *keys_host) {
+    DD_REQUIRE(net && net->ssd_dec && n >= 0 && n <= net->max_batch, DD_E_STATE, "dd_net_ssd_decoded_read: decode is off or n out of range");
+    DD_DEVICE(net->ctx);
+    hipStream_t s = net->ctx->stream;
+    DD_HIP(hipStreamSynchronize(s));
+    const size_t per = (size_t)n * net->dec_anchors;
+    if (!per) return DD_OK;
+    if (boxes_host) DD_HIP(hipMemcpy(boxes_host, net->dec_boxes, per * 4 * sizeof(float), hipMemcpyDeviceToHost));
+    if (scores_host) DD_HIP(hipMemcpy(scores_host, net->dec_score, per * sizeof(float), hipMemcpyDeviceToHost));
+    if (classes_host) DD_HIP(hipMemcpy(classes_host, net->dec_cls, per * sizeof(int), hipMemcpyDeviceToHost));
+    if (keys_host) DD_HIP(hipMemcpy(keys_host, net->dec_keys, per * sizeof(float), hipMemcpyDeviceToHost));
     return DD_OK;
 }
 
@@ -3540,6 +3691,18 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
                     net->op_launch[i - 1] = OPK_DEFAULT;
                     rc = launch_conv3x3_rw(s, unit_a, nimg, false, net->ctx->device);
                     if (rc != DD_OK) return rc;
+                }
+                if (P.epi == EPI_SSD_HEAD && net->ssd_dec && o[18] && !o[19]) {   // o[18] / o[31]: the per-anchor copy of weights / bias
+                    DD_REQUIRE(P.p[1] == net->dec_anchors, DD_E_ARG, "dd_net_forward: head of %d anchors, decode set up for %d", P.p[1], net->dec_anchors);
+                    P.w = reinterpret_cast<const _Float16 *>(net->d_weights + (size_t)(uint32_t)o[18]);
+                    P.bias = reinterpret_cast<const float *>(net->d_weights + (size_t)(uint32_t)o[31]);
+                    P.zero = net->d_zero;
+                    P.anchors = net->d_anchors; P.dec_boxes = net->dec_boxes; P.dec_score = net->dec_score; P.dec_keys = net->dec_keys;
+                    P.dec_cls = net->dec_cls; P.dec_thr = net->dec_thr;
+                    rc = launch_ssd_head_dec(s, P);
+                    if (rc != DD_OK) return rc;
+                    net->op_launch[i] = OPK_SSD_HEAD_DEC;
+                    break;
                 }
                 const bool bk32 = o[28] == 32;                 // shallow K (<= 96): one or few 32-wide steps
                 const bool glds = !bk32 && net->use_glds;          // K >= 97: direct-to-LDS fills, any Cin % 8 == 0

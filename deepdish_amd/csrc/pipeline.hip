@@ -9,6 +9,7 @@
 // independent DeepDish processes would.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include "common.h"
@@ -21,6 +22,10 @@ int mog2_apply(dd_mog2 *m, hipStream_t s, const uint8_t *frames, double learning
 int mask_box_count(hipStream_t s, const uint8_t *mask, int H, int W, const int *d_boxes, const int *d_box_stream, int K, int *d_counts);
 int yolov5_decode(hipStream_t s, const float *raw, int n_rows, int n_cls, float thr, float img_w, float img_h, float *out_boxes,
                   float *out_scores, int *out_cls, int cap, int *out_n, int batch, void *scratch);
+size_t ssd_post_decoded_scratch_bytes(int n_anchors, int batch);
+int ssd_postprocess_decoded(hipStream_t s, const float *d_boxes, const float *d_score, const int *d_cls, const float *d_keys,
+                            int n_anchors, int max_det, float score_thr, float iou_thr, float *boxes, float *classes, float *scores,
+                            int *count, int batch, void *scratch, size_t scratch_bytes);
 int yolov5_pack(hipStream_t s, const float *boxes, const float *scores, const int *cls, const int *n_rows, int cap, int batch, float *packed);
 int ssd_finish(hipStream_t s, const float *boxes, const float *cls, const float *scores, int batch, int max_det, double conf,
                double iou_thr, double img_w, double img_h, double *out_boxes, int *out_cls, double *out_scores, int *out_n);
@@ -34,11 +39,14 @@ int trackers_update_end(dd_tracker **ts, int S);
 int tracker_read_host(dd_tracker *t, int which, int64_t *ints6_host, double *means_host);
 }
 extern "C" int dd_net_max_batch(dd_net *net, int *out_host);
+extern "C" int dd_net_ssd_decode(dd_net *net, const float *anchors_host, int n_anchors, float score_thr, int enable);
+extern "C" int dd_net_ssd_decoded(dd_net *net, float **boxes, float **scores, int **classes, float **keys);
 extern "C" int dd_net_input_size(dd_net *net, int *h_host, int *w_host);
 
 namespace {
 
 constexpr int MAX_DET = 10;              // N_max of the stock SSD post-process op
+constexpr float SSD_SCORE_THR = 1e-8f, SSD_IOU_THR = 0.6f;    // its score / NMS thresholds
 constexpr int YOLO_HOST_ROWS = 128;      // YOLOv5 rows per stream the first device-to-host copy of a step has room for (the rest, if any, follows)
 enum { DET_SSD = 0, DET_YOLOV5 = 1 };
 enum { CONFIRMED = 2, DELETED = 3 };
@@ -108,6 +116,7 @@ struct dd_pipeline {
     std::vector<StreamState> st;
     std::vector<dd_tracker *> trks;
     DevBuf d_resized, d_tmp, d_post, d_det, d_fin, d_pack, d_nms, d_crop, d_patches, d_feats;
+    bool ssd_dec = false;                      // SSD: the head layers decode in their epilogue (dd_net_ssd_decode)
     size_t yolo_host_rows = 0;                 // YOLOv5: packed rows the first copy of a step brings to the host
     std::vector<size_t> ybase;
     PinBuf h_fin, h_nms, h_crop;
@@ -219,6 +228,11 @@ int dd_pipeline_create(dd_ctx *ctx, int n_streams, int frame_h, int frame_w, dd_
             DD_HIP(hipMalloc(&p->d_anchors, (size_t)n_anchors * 4 * sizeof(float)));
             DD_HIP(hipMemcpy(p->d_anchors, anchors_host, (size_t)n_anchors * 4 * sizeof(float), hipMemcpyHostToDevice));
             if ((rc = p->d_post.reserve(ddk::ssd_post_scratch_bytes(n_anchors, n_streams))) != DD_OK) return rc;
+            // the op's first stage (best class, anchor decode, sigmoid, threshold) runs in the head layers' epilogues: the head
+            // matrix is never written (DD_SSD_DEC=0 keeps the separate ssd_decode_k pass: same bits, for A/B runs)
+            const char *e = getenv("DD_SSD_DEC");
+            p->ssd_dec = !(e && atoi(e) == 0);
+            if (p->ssd_dec && (rc = dd_net_ssd_decode(detector, anchors_host, n_anchors, SSD_SCORE_THR, 1)) != DD_OK) return rc;
             if ((rc = p->d_det.reserve(S * MAX_DET * 6 * sizeof(float) + S * sizeof(int) + 256)) != DD_OK) return rc;
             if ((rc = p->d_fin.reserve(S * (MAX_DET * (4 * 8 + 4 + 8) + 4) + 256)) != DD_OK) return rc;
             if ((rc = p->h_fin.reserve(S * (MAX_DET * (4 * 8 + 4 + 8) + 4) + 256)) != DD_OK) return rc;
@@ -351,8 +365,14 @@ int enqueue_detector(dd_pipeline *p, const uint8_t *frames) {
     }
     float *db = p->d_det.as<float>(), *dc = db + (size_t)S * MAX_DET * 4, *ds = dc + (size_t)S * MAX_DET;
     int *dn = reinterpret_cast<int *>(ds + (size_t)S * MAX_DET);
-    if ((rc = ddk::ssd_postprocess(s, static_cast<const float *>(raw), p->d_anchors, p->n_anchors, p->n_classes, MAX_DET,
-                                   1e-8f, 0.6f, db, dc, ds, dn, S, p->d_post.p, p->d_post.cap)) != DD_OK) return rc;
+    if (p->ssd_dec) {
+        float *eb = nullptr, *es = nullptr, *ek = nullptr;
+        int *ec = nullptr;
+        if ((rc = dd_net_ssd_decoded(p->det, &eb, &es, &ec, &ek)) != DD_OK) return rc;
+        if ((rc = ddk::ssd_postprocess_decoded(s, eb, es, ec, ek, p->n_anchors, MAX_DET, SSD_SCORE_THR, SSD_IOU_THR, db, dc, ds, dn, S,
+                                               p->d_post.p, p->d_post.cap)) != DD_OK) return rc;
+    } else if ((rc = ddk::ssd_postprocess(s, static_cast<const float *>(raw), p->d_anchors, p->n_anchors, p->n_classes, MAX_DET,
+                                          SSD_SCORE_THR, SSD_IOU_THR, db, dc, ds, dn, S, p->d_post.p, p->d_post.cap)) != DD_OK) return rc;
     double *fb = p->d_fin.as<double>(), *fs = fb + (size_t)S * MAX_DET * 4;
     int *fc = reinterpret_cast<int *>(fs + (size_t)S * MAX_DET), *fn = fc + (size_t)S * MAX_DET;
     if ((rc = ddk::ssd_finish(s, db, dc, ds, S, MAX_DET, p->det_conf, 0.5, (double)p->W, (double)p->H, fb, fc, fs, fn)) != DD_OK)

@@ -8,6 +8,7 @@
 //   * dd_counts_accumulate : int64 count vector (deepdish.py:1141-1145) kept on the device for the
 //     end-of-run RCCL reduction.
 #include "common.h"
+#include "ssd_dev.h"
 
 namespace ddk {
 int nms_f32(hipStream_t s, const float *boxes_yxyx, const float *keys, int k, float thr, int max_keep, int *out_idx,
@@ -56,16 +57,12 @@ __global__ __launch_bounds__(256) void ssd_decode_k(const float *__restrict__ ra
         if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
     }
     if (live && sub == 0) {
-        const float ay = anchors[a * 4 + 0], ax = anchors[a * 4 + 1], ah = anchors[a * 4 + 2], aw = anchors[a * 4 + 3];
-        const float yc = r[0] / 10.f * ah + ay;
-        const float xc = r[1] / 10.f * aw + ax;
-        const float hh = 0.5f * expf(r[2] / 5.f) * ah;
-        const float hw = 0.5f * expf(r[3] / 5.f) * aw;
-        boxes[a * 4 + 0] = yc - hh;
-        boxes[a * 4 + 1] = xc - hw;
-        boxes[a * 4 + 2] = yc + hh;
-        boxes[a * 4 + 3] = xc + hw;
-        const float sc = 1.f / (1.f + expf(-best));
+        const float rr[4] = {r[0], r[1], r[2], r[3]};
+        const float an[4] = {anchors[a * 4 + 0], anchors[a * 4 + 1], anchors[a * 4 + 2], anchors[a * 4 + 3]};
+        float bx[4];
+        const float sc = ssddev::decode_anchor(rr, an, best, bx);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) boxes[a * 4 + q] = bx[q];
         best_score[a] = sc;
         best_cls[a] = bi;
         keys[a] = sc >= score_thr ? sc : -1.f;
@@ -287,6 +284,32 @@ int ssd_postprocess(hipStream_t s, const float *raw, const float *anchors, int n
     return DD_OK;
 }
 
+// The same op from the decoded per-anchor arrays (dd_net_ssd_decode: the detector's head GEMMs decode in their epilogue and
+// the raw head matrix does not exist): d_boxes [batch][n_anchors][4], d_score / d_cls / d_keys [batch][n_anchors].
+size_t ssd_post_decoded_scratch_bytes(int n_anchors, int batch) {
+    return (size_t)batch * n_anchors * 4 + (size_t)batch * 4 + 512 + (size_t)batch * nms_scratch_bytes(n_anchors) + 512;
+}
+
+int ssd_postprocess_decoded(hipStream_t s, const float *d_boxes, const float *d_score, const int *d_cls, const float *d_keys,
+                            int n_anchors, int max_det, float score_thr, float iou_thr, float *boxes, float *classes, float *scores,
+                            int *count, int batch, void *scratch, size_t scratch_bytes) {
+    DD_REQUIRE(n_anchors > 64 && n_anchors <= 4096 && max_det > 0 && max_det <= 64 && batch > 0, DD_E_ARG,
+               "ssd_postprocess_decoded: bad shape (anchors %d, max_det %d, batch %d)", n_anchors, max_det, batch);
+    DD_REQUIRE(scratch_bytes >= ssd_post_decoded_scratch_bytes(n_anchors, batch), DD_E_ARG, "ssd_postprocess_decoded: scratch too small");
+    const size_t per = (size_t)n_anchors * batch;
+    char *p = static_cast<char *>(scratch);
+    int *d_keep = reinterpret_cast<int *>(p);
+    int *d_nkeep = d_keep + per;
+    const size_t head = ((per * 4 + (size_t)batch * 4) + 255) / 256 * 256;
+    int rc;
+    if ((rc = nms_f32_batched(s, d_boxes, d_keys, n_anchors, iou_thr, max_det, d_keep, d_nkeep, p + head, scratch_bytes - head,
+                              batch)) != DD_OK) return rc;
+    hipLaunchKernelGGL(ssd_gather_k, dim3(batch), dim3(64), 0, s, d_keep, d_nkeep, d_boxes, d_score, d_cls, score_thr, max_det,
+                       n_anchors, boxes, classes, scores, count);
+    DD_LAUNCH_CHECK();
+    return DD_OK;
+}
+
 // tools/yolov5.py:120-131 for `batch` images: raw f32 [batch][n_rows][5 + n_cls] -> per image the rows with
 // conf >= thr in ascending row order (out_boxes f32 [batch][cap][4] xyxy pixels, out_scores, out_cls, out_n [batch] --
 // out_n counts every passing row, also those beyond cap).  scratch: batch * n_rows * 8 bytes.
@@ -344,6 +367,33 @@ int dd_ssd_postprocess(dd_ctx *ctx, const float *raw, const float *anchors, int 
     if ((rc = ctx->scratch[2].reserve(need)) != DD_OK) return rc;
     return ddk::ssd_postprocess(dd_pick_stream(ctx, stream), raw, anchors, n_anchors, n_classes, max_det, score_thr, iou_thr,
                                 boxes, classes, scores, count, 1, ctx->scratch[2].p, ctx->scratch[2].cap);
+}
+
+// First stage of the op alone (what the detector's head layers do in their epilogue when dd_net_ssd_decode is on), for `batch`
+// images: raw f32 [batch][n_anchors][4 + n_classes] -> boxes f32 [batch][n_anchors][4], scores, classes (id - 1), keys.
+int dd_ssd_decode(dd_ctx *ctx, const float *raw, const float *anchors, int n_anchors, int n_classes, float score_thr, float *boxes,
+                  float *scores, int *classes, float *keys, int batch, void *stream) {
+    DD_REQUIRE(ctx && raw && anchors && boxes && scores && classes && keys && n_anchors > 0 && n_classes > 1 && batch > 0, DD_E_ARG,
+               "dd_ssd_decode: bad argument");
+    DD_DEVICE(ctx);
+    hipLaunchKernelGGL(ssd_decode_k, dim3(dd_ceil_div(n_anchors, 16), batch), dim3(256), 0, dd_pick_stream(ctx, stream), raw, anchors,
+                       n_anchors, n_classes, score_thr, boxes, scores, classes, keys);
+    DD_LAUNCH_CHECK();
+    return DD_OK;
+}
+
+// dd_ssd_postprocess from decoded per-anchor arrays (dd_net_ssd_decoded / dd_ssd_decode), `batch` images at once.
+int dd_ssd_postprocess_decoded(dd_ctx *ctx, const float *dec_boxes, const float *dec_scores, const int *dec_classes, const float *dec_keys,
+                               int n_anchors, int max_det, float score_thr, float iou_thr, float *boxes, float *classes, float *scores,
+                               int *count, int batch, void *stream) {
+    DD_REQUIRE(ctx && dec_boxes && dec_scores && dec_classes && dec_keys && boxes && classes && scores && count, DD_E_ARG,
+               "dd_ssd_postprocess_decoded: NULL argument");
+    DD_DEVICE(ctx);
+    int rc;
+    const size_t need = ddk::ssd_post_decoded_scratch_bytes(n_anchors, batch);
+    if ((rc = ctx->scratch[2].reserve(need)) != DD_OK) return rc;
+    return ddk::ssd_postprocess_decoded(dd_pick_stream(ctx, stream), dec_boxes, dec_scores, dec_classes, dec_keys, n_anchors, max_det,
+                                        score_thr, iou_thr, boxes, classes, scores, count, batch, ctx->scratch[2].p, ctx->scratch[2].cap);
 }
 
 int dd_yolov5_decode(dd_ctx *ctx, const float *raw, int n_rows, int n_cls, float thr, float img_w, float img_h,

@@ -37,6 +37,21 @@ class Net:
         """Latency mode: replay each (input buffer, batch) forward as one hipGraph launch."""
         check(lib().dd_net_use_graph(self._h, int(bool(enable))), 'dd_net_use_graph')
 
+    def ssd_decode(self, anchors, score_thr, enable=True):
+        """SSD detector: first stage of TFLite_Detection_PostProcess inside the head layers' epilogues (the head matrix is then
+        never written); results via ssd_decoded()."""
+        a = np.ascontiguousarray(anchors, dtype=np.float32)
+        check(lib().dd_net_ssd_decode(self._h, ptr(a), len(a), float(score_thr), int(bool(enable))), 'dd_net_ssd_decode')
+        self._dec_anchors = len(a) if enable else 0
+
+    def ssd_decoded(self, n=None):
+        """(boxes [n, A, 4] f32, scores [n, A] f32, classes [n, A] i32, keys [n, A] f32) of the last forward, on the host."""
+        n = self._last_n if n is None else n
+        A = self._dec_anchors
+        out = (np.zeros((n, A, 4), np.float32), np.zeros((n, A), np.float32), np.zeros((n, A), np.int32), np.zeros((n, A), np.float32))
+        check(lib().dd_net_ssd_decoded_read(self._h, n, *[ptr(o) for o in out]), 'dd_net_ssd_decoded_read')
+        return out
+
     def forward(self, images, stream=None):
         """images: u8 [n, in_h, in_w, 3] torch cuda tensor (or numpy, uploaded).  Enqueues only."""
         if isinstance(images, np.ndarray):

@@ -90,7 +90,7 @@ class Program:
         f = w.view(np.float32)
         w[0:5] = (kind, src, dst, res, dst2)
         names = dict(kh=5, kw=6, stride=7, pad_t=8, pad_l=9, cin=10, cout=11, cout_pad=12, kpad=13, act=14, epi=15,
-                     w_off=16, b_off=17, aff_off=18, has_aff=19, ho=26, wo=27, bk=28, pool=29, fuse_next=30)
+                     w_off=16, b_off=17, aff_off=18, has_aff=19, ho=26, wo=27, bk=28, pool=29, fuse_next=30, aux_off=31)
         for k, v in kw.items():
             if k == 'p':
                 w[20:20 + len(v)] = v
@@ -174,6 +174,18 @@ class Program:
             a[0, :cout], a[1, :cout] = aff2
             kw_['aff_off'] = self.add_blob(a)
             kw_['has_aff'] = 1
+        if epi == EPI_SSD_HEAD and (kh, kw, stride) == (1, 1, 1) and cin_pad % 64 == 0 and 4 + p[0] <= 96:
+            # second copy of the head weights, one anchor per 96 rows (4 box encodings, C class logits, zero rows): the layout of
+            # the kernel that decodes in its epilogue (csrc/nets.hip ssd_head_finish; dd_net_ssd_decode switches it on)
+            per, a_n = 4 + p[0], p[5]
+            assert cout == a_n * per and kpad == cin_pad
+            w96 = np.zeros((a_n * 96, kpad), dtype=np.float16)
+            b96 = np.zeros(a_n * 96, dtype=np.float32)
+            for an in range(a_n):
+                w96[an * 96:an * 96 + per] = wflat[an * per:(an + 1) * per]
+                b96[an * 96:an * 96 + per] = bp[an * per:(an + 1) * per]
+            kw_['aff_off'] = self.add_blob(w96)
+            kw_['aux_off'] = self.add_blob(b96)
         self._op(OP_CONV, src=src, dst=dst, res=res, dst2=dst2, **kw_)
         tile = '4,1,1,2' if cout_pad <= 32 else '2,2,2,2'
         rw = (kh, kw, stride, cin_pad, cout_pad, epi, pt, pl) == (3, 3, 1, 32, 32, EPI_F16, 1, 1)

@@ -252,7 +252,8 @@ int dd_net_profile(dd_net *net, int enable);
 int dd_net_profile_read(dd_net *net, float *ms_host, int cap, int *n_ops_host);
 /* Which launch ran each op of the last forward: 0 the op's own kernel, 1 none (folded into the next op's launch),
  * 2 conv3x3_pool_rows_k, 3 conv3x3_pool_rows_k with the first layer folded in, 4 res_unit_rows_k, 5 ssd_front_k,
- * 6 conv3x3_c64_rows_k, 7 conv3x3_s2_rows_k, 8 conv_ws_k, 9 conv_ws_dw_k, 10 dwpw_rows_k -- so that a per-kernel time table attributes a fused launch to the kernel that ran. */
+ * 6 conv3x3_c64_rows_k, 7 conv3x3_s2_rows_k, 8 conv_ws_k, 9 conv_ws_dw_k, 10 dwpw_rows_k, 11 SSD head with the decode in its
+ * epilogue -- so that a per-kernel time table attributes a fused launch to the kernel that ran. */
 int dd_net_op_launches(dd_net *net, int32_t *codes_host, int cap, int *n_ops_host);
 
 /* TFLite_Detection_PostProcess (inside the reference's .tflite graph, tools/ssd_mobilenet.py:103-109):
@@ -261,6 +262,24 @@ int dd_net_op_launches(dd_net *net, int32_t *codes_host, int cap, int *n_ops_hos
 int dd_ssd_postprocess(dd_ctx *ctx, const float *raw, const float *anchors, int n_anchors,
                        int n_classes, int max_det, float score_thr, float iou_thr,
                        float *boxes, float *classes, float *scores, int *count, void *stream);
+
+/* The op's first stage alone, `batch` images: raw f32 [batch][n_anchors][4+n_classes] -> per anchor boxes f32 [.][4]
+ * (ymin,xmin,ymax,xmax), scores (sigmoid of the best class logit, background excluded), classes int32 (id - 1, lowest
+ * on ties), keys f32 (score, or -1 below score_thr) -- and its second stage (class-agnostic NMS, top max_det) from
+ * those arrays.  dd_ssd_postprocess = the two in one call for one image. */
+int dd_ssd_decode(dd_ctx *ctx, const float *raw, const float *anchors, int n_anchors, int n_classes, float score_thr,
+                  float *boxes, float *scores, int *classes, float *keys, int batch, void *stream);
+int dd_ssd_postprocess_decoded(dd_ctx *ctx, const float *dec_boxes, const float *dec_scores, const int *dec_classes,
+                               const float *dec_keys, int n_anchors, int max_det, float score_thr, float iou_thr,
+                               float *boxes, float *classes, float *scores, int *count, int batch, void *stream);
+/* SSD detector engines (tools/ssd_mobilenet.py:102-109): run that first stage inside the head layers' GEMM epilogues,
+ * straight from the accumulators -- the [n][n_anchors][4+n_classes] head matrix is then never written (dd_net_read of
+ * it is DD_E_STATE) and dd_net_ssd_decoded hands out the per-anchor arrays of the last forward ([n][n_anchors] each,
+ * same bits as dd_ssd_decode on the head matrix).  anchors_host f32 [n_anchors][4] (yc, xc, h, w). */
+int dd_net_ssd_decode(dd_net *net, const float *anchors_host, int n_anchors, float score_thr, int enable);
+int dd_net_ssd_decoded(dd_net *net, float **boxes_dev, float **scores_dev, int **classes_dev, float **keys_dev);
+/* the same arrays of the first n images of the last forward copied to host memory (any pointer may be NULL) */
+int dd_net_ssd_decoded_read(dd_net *net, int n, float *boxes_host, float *scores_host, int *classes_host, float *keys_host);
 
 /* tools/ssd_mobilenet.py:111-150, SSDMobileNet.predict after its four get_tensor calls, for `batch` images at once:
  * NaN scrub (:111-116), score >= confidence (:119), reorder [1,0,3,2] and scale by (w,h,w,h) in f64 (:121-127),
@@ -290,7 +309,7 @@ int dd_yolov5_decode(dd_ctx *ctx, const float *raw, int n_rows, int n_cls, float
  * id i, :142-147; score threshold 0.5); anchors_host == NULL = YOLOv5 (tools/yolov5.py:97-146: resize, forward with
  * the Detect decode fused, dd_yolov5_decode, label filter, xyxy -> tlwh; n_anchors = rows of the head tensor,
  * n_classes = classes; labels_nl line i names class id i, :134; score threshold 0.25; no NMS of its own -- every
- * candidate goes on to deep_sort's NMS; more than 4096 candidates in one frame are DD_E_CAPACITY).
+ * candidate goes on to deep_sort's NMS, however many pass the threshold).
  * labels_nl: the label file's lines joined by '\n'; wanted_nl: --wanted-labels.
  * line_host: count line x1,y1,x2,y2 (deepdish.py:739-744). */
 int dd_pipeline_create(dd_ctx *ctx, int n_streams, int frame_h, int frame_w, dd_net *detector,

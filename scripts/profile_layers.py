@@ -18,6 +18,8 @@ elif kind == 'mars':
 else:
     prog = nets.compile_yolov5s(nets.synthetic_yolov5s_weights()); shape = (640, 640)
 net = Net(prog, max_batch=batch)
+if kind == 'ssd' and os.environ.get('DD_SSD_DEC', '1') != '0':      # as the pipeline runs it: the heads decode in their epilogue
+    net.ssd_decode(prog.meta['anchors'], 1e-8)
 x = torch.randint(0, 256, (batch,) + shape + (3,), dtype=torch.uint8, device='cuda')
 check(lib().dd_net_profile(net._h, 1))
 acc = np.zeros(len(prog.ops))

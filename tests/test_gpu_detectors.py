@@ -129,3 +129,62 @@ def test_dd_yolov5_decode_matches_reference_detect_image():
         np.testing.assert_array_equal(np.asarray(b, np.float32), g['boxes'][a:e])
         np.testing.assert_array_equal([name_to_id[x] for x in l], g['labels'][a:e])
         np.testing.assert_array_equal(np.asarray(s, np.float32), g['scores'][a:e])
+
+
+@pytest.mark.parametrize('n,thr', [(3, 1e-8), (40, 0.3)])
+def test_ssd_head_layers_decode_in_their_epilogue_with_the_same_bits(n, thr):
+    """dd_net_ssd_decode: the six head GEMMs of the SSD run one anchor per 96-channel tile and do the first stage of
+    TFLite_Detection_PostProcess on their accumulators (best class with the lowest index on ties, anchor decode, sigmoid,
+    threshold) -- per anchor the bits of dd_ssd_decode on the head matrix of an engine without the switch, then the same
+    top-10 from dd_ssd_postprocess_decoded as from dd_ssd_postprocess.  The head matrix of the decoding engine is never written:
+    reading it is an error.  Frames 1 and 2 are flat (every class logit of an anchor column ties across pixels)."""
+    from deepdish_amd import nets
+    from deepdish_amd.engine import Net
+    from deepdish_amd._lib import lib, check, DeepDishHipError
+    from deepdish_amd.runtime import default_context, ptr
+    ctx = default_context()
+    wd = nets.synthetic_ssd_weights(1234)
+    prog = nets.compile_ssd_mobilenet(wd)
+    anchors = np.ascontiguousarray(prog.meta['anchors'], dtype=np.float32)
+    A, C = len(anchors), prog.meta['n_classes']
+    rng = np.random.default_rng(n)
+    x = rng.integers(0, 256, (n, 300, 300, 3), dtype=np.uint8)
+    if n > 2:
+        x[1] = 0; x[2] = 255
+    plain = Net(prog, max_batch=n, context=ctx)
+    plain.forward(x)
+    d_anchors = ctx.to_device(anchors, np.float32)
+    want = [ctx.empty((n, A, 4), torch.float32), ctx.empty((n, A), torch.float32), ctx.empty((n, A), torch.int32), ctx.empty((n, A), torch.float32)]
+    check(lib().dd_ssd_decode(ctx.handle, plain.output_ptr(), ptr(d_anchors), A, C, float(thr), *[ptr(t) for t in want], n, None), 'dd_ssd_decode')
+    want = [ctx.to_host(t) for t in want]
+    fused = Net(nets.compile_ssd_mobilenet(wd), max_batch=n, context=ctx)
+    fused.ssd_decode(anchors, thr)
+    fused.forward(x)
+    got = fused.ssd_decoded()
+    for name, g, w in zip(('boxes', 'scores', 'classes', 'keys'), got, want):
+        np.testing.assert_array_equal(g, w, err_msg=name)
+    assert np.isfinite(got[0]).all() and (got[3] >= 0).any() and ((got[3] < 0).any() or thr < 1e-6)
+    with pytest.raises(DeepDishHipError, match='head matrix'):
+        fused.read()
+    # second stage from the decoded arrays == the whole op from the head matrix, frame by frame
+    ps = [ctypes.c_void_p() for _ in range(4)]
+    check(lib().dd_net_ssd_decoded(fused._h, *[ctypes.byref(p) for p in ps]), 'dd_net_ssd_decoded')
+    ob, oc, os_, on = ctx.empty((n, 10, 4), torch.float32), ctx.empty((n, 10), torch.float32), ctx.empty((n, 10), torch.float32), ctx.empty((n,), torch.int32)
+    check(lib().dd_ssd_postprocess_decoded(ctx.handle, *ps, A, 10, float(thr), 0.6, ptr(ob), ptr(oc), ptr(os_), ptr(on), n, None),
+          'dd_ssd_postprocess_decoded')
+    ob, oc, os_, on = (ctx.to_host(t) for t in (ob, oc, os_, on))
+    raw = plain.output_ptr()
+    stride = A * (4 + C) * 4
+    for z in range(n):
+        b1, c1, s1, n1 = ctx.empty((10, 4), torch.float32), ctx.empty((10,), torch.float32), ctx.empty((10,), torch.float32), ctx.empty((1,), torch.int32)
+        check(lib().dd_ssd_postprocess(ctx.handle, ctypes.c_void_p(raw + z * stride), ptr(d_anchors), A, C, 10, float(thr), 0.6, ptr(b1), ptr(c1),
+                                       ptr(s1), ptr(n1), None), 'dd_ssd_postprocess')
+        k = int(ctx.to_host(n1)[0])
+        assert k == on[z]
+        np.testing.assert_array_equal(ctx.to_host(b1)[:k], ob[z, :k])
+        np.testing.assert_array_equal(ctx.to_host(c1)[:k], oc[z, :k])
+        np.testing.assert_array_equal(ctx.to_host(s1)[:k], os_[z, :k])
+    # switching it off brings the head matrix back
+    fused.ssd_decode(anchors, thr, enable=False)
+    fused.forward(x)
+    np.testing.assert_array_equal(fused.read(), plain.read())
