@@ -29,7 +29,7 @@ enum { OP_INPUT = 1, OP_CONV = 2, OP_DWCONV = 3, OP_MAXPOOL = 4, OP_UPSAMPLE = 5
 enum { ACT_NONE = 0, ACT_RELU6 = 1, ACT_ELU = 2, ACT_SILU = 3, ACT_RELU = 4, ACT_SIGMOID = 5 };
 enum { EPI_F16 = 0, EPI_F32 = 1, EPI_SSD_HEAD = 2, EPI_YOLO = 3 };
 // dd_net_op_launches: 0 = the op's own kernel, 1 = no launch (folded into the next op's), else the fused / special kernel
-enum { OPK_DEFAULT = 0, OPK_FOLDED = 1, OPK_POOL_ROWS = 2, OPK_POOL_ROWS_STEM = 3, OPK_RES_UNIT = 4, OPK_SSD_FRONT = 5, OPK_C64_ROWS = 6, OPK_S2_ROWS = 7, OPK_CONV_WS = 8, OPK_WS_DW = 9, OPK_DWPW_ROWS = 10, OPK_SSD_HEAD_DEC = 11 };
+enum { OPK_DEFAULT = 0, OPK_FOLDED = 1, OPK_POOL_ROWS = 2, OPK_POOL_ROWS_STEM = 3, OPK_RES_UNIT = 4, OPK_SSD_FRONT = 5, OPK_C64_ROWS = 6, OPK_S2_ROWS = 7, OPK_CONV_WS = 8, OPK_WS_DW = 9, OPK_DWPW_ROWS = 10, OPK_SSD_HEAD_DEC = 11, OPK_RES_PAIR = 12 };
 enum { DT_F16 = 0, DT_F32 = 1, DT_U8 = 2 };
 
 constexpr int OP_WORDS = 48;       // int32 words per op record (see deepdish_amd/nets.py)
@@ -1309,6 +1309,218 @@ __global__ __launch_bounds__(256, 2) void res_unit_rows_k(const ConvP PA, const 
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// TWO consecutive residual units (MARS conv2_1 and conv2_3: the whole conv2_x stage, tools/freeze_model.py:118-121) as ONE
+// launch.  res_unit_rows_k keeps a unit's inner tensor on the CU; between the units the block output `out` and its BN + ELU
+// view `out2` (2 x 14.9 KB per crop) still went through HBM -- written by one launch, read back by the next.  Here a PAIR of
+// waves owns an image: wave A runs the first unit exactly as res_unit_rows_k does, but its epilogue writes the rows of `out`
+// and `out2` into two 8-row LDS rings instead of memory; wave B runs the second unit from those rings two rounds behind
+// (it needs rows up to 2r + 2 of `out2` for its round r) and stores the stage's outputs.  The stage then reads its input
+// once and writes its two outputs once: 685 MB instead of 1 828 MB per 7 680 crops.
+//   * A block is four pairs: waves 0-3 are the A waves, 4-7 their B partners (the hardware deals a block's waves over the
+//     SIMDs cyclically, so every SIMD hosts one A and one B wave); one raw s_barrier per round keeps the pairs in step --
+//     all eight waves do the same amount of matrix work per round.
+//   * The images of a pair form ONE stream of 32 rows each (31 map rows + the zero row they share as lower / upper
+//     padding): stream row s sits in slot (s + 1) & 7 of the input-type rings and s & 3 of the h1 rings, round g of a wave
+//     makes h1 rows 2g, 2g + 1 and output rows 2g - 1, 2g.  A writes rows 2g - 1, 2g while B (at its round g - 2) reads rows
+//     2g - 5 .. 2g - 2: never the same slot.  Rows that are padding are written as zeros by A -- B reads them as its own padding.
+//   * Same summation orders and the same epilogue statements as res_unit_rows_k / conv3x3_rw_k: the same bits.
+constexpr int RP_X_SLOTS = 8;
+constexpr int rp_pair_halves() { return 6 * 8 + (RU_PRE_SLOTS + 2 * RU_H1_SLOTS + 2 * RP_X_SLOTS) * RU_SLOT; }   // 16-byte zero pads around the rings
+
+template <int ACT_A>
+__global__ __launch_bounds__(512, 2) void res_pair_rows_k(const ConvP P1A, const ConvP P1B, const ConvP P2A, const ConvP P2B, const int n_img) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pair = wave & 3, role = wave >> 2;               // role 0 = A (first unit), 1 = B (second unit)
+    const int fr = lane & 15, fq = lane >> 4;
+    _Float16 *pbase = lds + (size_t)pair * rp_pair_halves();
+    _Float16 *pre = pbase + 8;                                    // A: input rows (DMA)
+    _Float16 *h1a = pre + RU_PRE_SLOTS * RU_SLOT + 8;             // A: rows between its two layers
+    _Float16 *xo = h1a + RU_H1_SLOTS * RU_SLOT + 8;               // exchange: rows of the first unit's `out` (B's skip rows)
+    _Float16 *xo2 = xo + RP_X_SLOTS * RU_SLOT + 8;                // exchange: rows of its `out2` (B's input rows)
+    _Float16 *h1b = xo2 + RP_X_SLOTS * RU_SLOT + 8;               // B: rows between its two layers
+    const h8 zero8 = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+    for (int i = (role * 64 + lane) * 8; i < rp_pair_halves(); i += 128 * 8) *reinterpret_cast<h8 *>(pbase + i) = zero8;
+
+    // this wave's unit: first-layer filter wA (ELU), second-layer filter wB (residual + second output)
+    const _Float16 *wa_p = role ? P2A.w : P1A.w, *wb_p = role ? P2B.w : P1B.w;
+    const int kpa = role ? P2A.kpad : P1A.kpad, kpb = role ? P2B.kpad : P1B.kpad;
+    h8 wA[9][2], wB[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            wA[t][a] = *reinterpret_cast<const h8 *>(wa_p + (size_t)rw_weight_row(a, fr) * kpa + t * 32 + fq * 8);
+            wB[t][a] = *reinterpret_cast<const h8 *>(wb_p + (size_t)rw_weight_row(a, fr) * kpb + t * 32 + fq * 8);
+        }
+    const float *ba_p = role ? P2A.bias : P1A.bias, *bb_p = role ? P2B.bias : P1B.bias, *af_p = role ? P2B.aff2 : P1B.aff2;
+    const int cpad = role ? P2B.cout_pad : P1B.cout_pad;
+    const f4 bA0 = *reinterpret_cast<const f4 *>(ba_p + fq * 8), bA1 = *reinterpret_cast<const f4 *>(ba_p + fq * 8 + 4);
+    Epi8 EB;
+    EB.b0 = *reinterpret_cast<const f4 *>(bb_p + fq * 8); EB.b1 = *reinterpret_cast<const f4 *>(bb_p + fq * 8 + 4);
+    EB.s0 = *reinterpret_cast<const f4 *>(af_p + fq * 8); EB.s1 = *reinterpret_cast<const f4 *>(af_p + fq * 8 + 4);
+    EB.t0 = *reinterpret_cast<const f4 *>(af_p + cpad + fq * 8); EB.t1 = *reinterpret_cast<const f4 *>(af_p + cpad + fq * 8 + 4);
+    const int H = P1A.H, W = P1A.W;                               // 31, 15 (launcher)
+    const int offC = (fq * 16 + fr) * 8;
+    const int actA = ACT_A < 0 ? P1A.act : ACT_A;
+    _Float16 *inr = role ? xo2 : pre, *h1r = role ? h1b : h1a, *resr = role ? xo : pre;
+
+    const int n0 = blockIdx.x * 4 + pair, nstep = gridDim.x * 4;
+    const int K = n0 < n_img ? (n_img - n0 + nstep - 1) / nstep : 0;                 // images of this pair: n0 + k * nstep
+    const int base4 = blockIdx.x * 4;
+    const int Kmax = base4 < n_img ? (n_img - base4 + nstep - 1) / nstep : 0;        // of the block's first pair: every wave loops alike
+    const int GA = 16 * K, Gall = 16 * Kmax + 2;
+    auto fill_pre = [&](int s) {                                  // stream row s of the pair (wave-uniform); padding rows / past the stream: zero lines
+        const int kk = (s + 1) >> 5, y = ((s + 1) & 31) - 1;
+        const bool ok = kk < K && y >= 0 && fr < W;
+        const _Float16 *src = P1A.in + ((size_t)(n0 + (ok ? kk : 0) * nstep) * H * W + (size_t)(ok ? y : 0) * W + fr) * P1A.cs_in + P1A.coff_in + fq * 8;
+        lds_fill16(ok ? src : P1A.zero, pre + ((s + 1) & (RU_PRE_SLOTS - 1)) * RU_SLOT);
+    };
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                 // the rings are zero before the first row arrives
+    asm volatile("" ::: "memory");
+#endif
+    if (role == 0 && K > 0) { fill_pre(-1); fill_pre(0); fill_pre(1); fill_pre(2); }
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    // three fragments of an input row: left / centre / right tap (res_unit_rows_k's loop)
+    auto conv2 = [&](const _Float16 *ringp, int slot0, int mask, const h8 (&w)[9][2], f4 (&acc)[2][2]) {
+        h8 X[2][3];
+        auto rd = [&](int i, h8 (&x)[3]) {
+            const _Float16 *rs = ringp + ((slot0 + i) & mask) * RU_SLOT + offC;
+            x[0] = *reinterpret_cast<const h8 *>(rs - 8);
+            x[1] = *reinterpret_cast<const h8 *>(rs);
+            x[2] = *reinterpret_cast<const h8 *>(rs + 8);
+        };
+        rd(0, X[0]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            h8 (&x)[3] = X[i & 1];
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]));
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            if (i + 1 < 4) rd(i + 1, X[(i + 1) & 1]);
+#if defined(__HIP_DEVICE_COMPILE__)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                for (int cr = 0; cr < 2; ++cr) {
+                    const int dy = i - cr;
+                    if (dy < 0 || dy > 2) continue;
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+                        acc[cr][a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[dy * 3 + dx][a], x[dx], acc[cr][a], 0, 0, 0);
+                }
+#if defined(__HIP_DEVICE_COMPILE__)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+    };
+    // The two waves of a SIMD are an A and a B wave that leave every barrier together: run alike they would both multiply, then
+    // both do their epilogue arithmetic, and the matrix pipe would idle half the time.  B therefore defers the epilogue of its
+    // second layer (residual add, second BN + ELU, the stores) to the top of its next round: its vector work meets A's matrix work.
+    f4 accC[2][2];
+    int grC = -1;
+    auto b_store = [&]() {
+#pragma unroll
+        for (int cr = 0; cr < 2; ++cr) {
+            const int s = 2 * grC - 1 + cr;
+            const int kk = (s + 1) >> 5, y = ((s + 1) & 31) - 1;
+            if (y < 0 || fr >= W) continue;
+            float o[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { o[q] = accC[cr][0][q]; o[4 + q] = accC[cr][1][q]; }
+            // the skip row is still in its ring slot: A is four rows further on (slots (s + 1) & 7 of rows s and s + 6 .. s + 7 differ)
+            const h8 rv = *reinterpret_cast<const h8 *>(resr + ((s + 1) & (RU_PRE_SLOTS - 1)) * RU_SLOT + offC);
+            conv_epilogue_f16x8<ACT_NONE, false, 1, true, false>(P2B, EB, ((n0 + kk * nstep) * H + y) * W + fr, fq * 8, o, &rv);
+        }
+    };
+    for (int g = 0; g < Gall; ++g) {
+        const int gr = role ? g - 2 : g;                          // this wave's round
+        const bool active = role ? (gr >= 0 && gr < GA) : (K > 0 && gr <= GA);   // A's round GA only writes the trailing padding row
+        if (grC >= 0) { b_store(); grC = -1; }
+        if (active) {
+            if (role == 0) { fill_pre(2 * gr + 3); fill_pre(2 * gr + 4); }
+            // ---- first layer: h1 stream rows 2gr, 2gr + 1 from input rows 2gr - 1 .. 2gr + 2
+            {
+                f4 acc[2][2] = {{bA0, bA1}, {bA0, bA1}};
+                conv2(inr, 2 * gr, RU_PRE_SLOTS - 1, wA, acc);
+#pragma unroll
+                for (int cr = 0; cr < 2; ++cr) {
+                    const int s = 2 * gr + cr;
+                    const bool live = ((s + 1) & 31) != 0 && fr < W;   // the padding row between images / pixel slot 15: zeros
+                    h8 o;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        o[q] = (_Float16)apply_act(acc[cr][0][q], actA);
+                        o[4 + q] = (_Float16)apply_act(acc[cr][1][q], actA);
+                    }
+                    u4v_t ou = __builtin_bit_cast(u4v_t, o);
+                    ou &= live ? 0xFFFFFFFFu : 0u;
+                    *reinterpret_cast<u4v_t *>(h1r + (s & (RU_H1_SLOTS - 1)) * RU_SLOT + offC) = ou;
+                }
+            }
+            // ---- second layer: output stream rows 2gr - 1, 2gr from h1 rows 2gr - 2 .. 2gr + 1
+            {
+                f4 acc[2][2] = {{EB.b0, EB.b1}, {EB.b0, EB.b1}};
+                conv2(h1r, 2 * gr - 2, RU_H1_SLOTS - 1, wB, acc);
+                h8 rv[2];
+#pragma unroll
+                for (int cr = 0; cr < 2; ++cr) rv[cr] = *reinterpret_cast<const h8 *>(resr + ((2 * gr + cr) & (RU_PRE_SLOTS - 1)) * RU_SLOT + offC);   // row 2gr - 1 + cr
+                if (role == 0) {
+#pragma unroll
+                    for (int cr = 0; cr < 2; ++cr) {
+                        const int s = 2 * gr - 1 + cr;
+                        const bool live = ((s + 1) & 31) != 0 && fr < W;
+                        // conv_epilogue_f16x8<ACT_NONE, false, 1>'s statements: out = f16(v + res), out2 = f16(ELU(scale * (v + res) + shift))
+                        float v[8];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { v[q] = acc[cr][0][q]; v[4 + q] = acc[cr][1][q]; }
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] += (float)rv[cr][q];
+                        h8 o, o2;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) o[q] = (_Float16)v[q];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const float sc = q < 4 ? EB.s0[q] : EB.s1[q - 4], sh = q < 4 ? EB.t0[q] : EB.t1[q - 4];
+                            o2[q] = (_Float16)apply_act(sc * v[q] + sh, ACT_ELU);
+                        }
+                        u4v_t ou = __builtin_bit_cast(u4v_t, o), ou2 = __builtin_bit_cast(u4v_t, o2);
+                        ou &= live ? 0xFFFFFFFFu : 0u;
+                        ou2 &= live ? 0xFFFFFFFFu : 0u;
+                        *reinterpret_cast<u4v_t *>(xo + ((s + 1) & (RP_X_SLOTS - 1)) * RU_SLOT + offC) = ou;
+                        *reinterpret_cast<u4v_t *>(xo2 + ((s + 1) & (RP_X_SLOTS - 1)) * RU_SLOT + offC) = ou2;
+                    }
+#if defined(__HIP_DEVICE_COMPILE__)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next round's input rows have landed
+#endif
+                } else {                                            // B keeps its sums: their epilogue opens its NEXT round (see b_store)
+#pragma unroll
+                    for (int cr = 0; cr < 2; ++cr) { accC[cr][0] = acc[cr][0]; accC[cr][1] = acc[cr][1]; }
+                    grC = gr;
+                }
+            }
+        }
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // this round's ring rows are written ...
+        __builtin_amdgcn_s_barrier();                                 // ... before the partner reads them (stores to memory are not waited for)
+        asm volatile("" ::: "memory");
+#endif
+    }
+    if (grC >= 0) b_store();
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // A: the look-ahead DMAs past the stream
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -3081,6 +3293,32 @@ int launch_res_unit(hipStream_t s, const ConvP &A, const ConvP &B, int nimg, int
     return DD_OK;
 }
 
+// Two residual units in a row (A1, B1 then A2, B2; each pair res_unit_fusable) as one launch of res_pair_rows_k?  The caller
+// knows from the program (op flag 2 on B1) that B1's two outputs are read by the second unit only.
+bool res_pair_fusable(const ConvP &A1, const ConvP &B1, const ConvP &A2, const ConvP &B2, int nimg) {
+    static const bool off = getenv("DD_RES_PAIR_OFF") && atoi(getenv("DD_RES_PAIR_OFF")) != 0;
+    static const int min_img = getenv("DD_RES_PAIR_MIN") ? atoi(getenv("DD_RES_PAIR_MIN")) : 1024;    // four image pairs per CU
+    return !off && nimg >= min_img && A1.H == 31 && A1.W == 15 &&
+           B1.res == A1.in && B1.cs_res == A1.cs_in && B1.coff_res == A1.coff_in &&                  // first unit: skip tensor = its input
+           A2.in == static_cast<const _Float16 *>(B1.out2) && A2.cs_in == B1.cs_out2 && !A2.coff_in && !B1.coff_out2 &&
+           B2.res == static_cast<const _Float16 *>(B1.out) && B2.cs_res == B1.cs_out && B2.coff_res == B1.coff_out &&
+           A2.H == A1.H && A2.W == A1.W && A1.act == ACT_ELU && A2.act == ACT_ELU;
+}
+
+int launch_res_pair(hipStream_t s, const ConvP &A1, const ConvP &B1, const ConvP &A2, const ConvP &B2, int nimg, int device) {
+    constexpr size_t lds_bytes = (size_t)4 * rp_pair_halves() * sizeof(_Float16);
+    static DevOnce once;
+    const int rc = once.run(device, [&]() -> int {
+        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&res_pair_rows_k<ACT_ELU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        return DD_OK;
+    });
+    if (rc != DD_OK) return rc;
+    const int grid = std::min(dd_ceil_div(nimg, 4), 256);          // one block (four wave pairs, 128 KiB of rings) per CU
+    hipLaunchKernelGGL((res_pair_rows_k<ACT_ELU>), dim3((unsigned)grid), dim3(512), lds_bytes, s, A1, B1, A2, B2, nimg);
+    DD_LAUNCH_CHECK();
+    return DD_OK;
+}
+
 bool s2_rows_eligible(const ConvP &P, int nimg, int max_batch) {
     static const bool off = getenv("DD_S2_ROWS_OFF") && atoi(getenv("DD_S2_ROWS_OFF")) != 0;
     static const int min_img = getenv("DD_S2_ROWS_MIN") ? atoi(getenv("DD_S2_ROWS_MIN")) : 512;
@@ -3618,6 +3856,14 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
     bool unit_pending = false;
     ConvP pw_p;                                                   // pointwise layer whose only reader is the next (depthwise) op
     bool pw_pending = false;
+    ConvP pair_a, pair_b;                                         // a whole residual unit held back: it may run with the next unit (res_pair_rows_k)
+    bool pair_pending = false;
+    int pair_op = -1;
+    auto flush_pair = [&]() -> int {                              // ... or on its own after all
+        pair_pending = false;
+        net->op_launch[pair_op] = OPK_RES_UNIT;
+        return launch_res_unit(s, pair_a, pair_b, nimg, net->ctx->device);
+    };
     auto run_ws = [&](ConvP &P) { return P.cin == 256 ? launch_conv_ws<4>(s, P, net->ctx->device) : launch_conv_ws<8>(s, P, net->ctx->device); };
     for (int i = 0; i < net->n_ops; ++i) {
         if (net->profile) DD_HIP(hipEventRecord(net->events[i], s));
@@ -3626,6 +3872,7 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
         const int kind = o[0], src = o[1], dst = o[2], res = o[3], dst2 = o[4];
         const TensorDesc *ts = src >= 0 ? &net->tensors[src] : nullptr;
         const TensorDesc *td = dst >= 0 ? &net->tensors[dst] : nullptr;
+        if (pair_pending && kind != OP_CONV) { const int rc = flush_pair(); if (rc != DD_OK) return rc; }
         if (pw_pending && kind != OP_DWCONV) {
             pw_pending = false; net->op_launch[i - 1] = OPK_CONV_WS;
             const int rc = run_ws(pw_p);
@@ -3683,14 +3930,37 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
                     unit_pending = false;
                     if (res_unit_fusable(unit_a, P, nimg)) {
                         P.zero = net->d_zero;
+                        if (pair_pending) {                        // ... and the unit before is waiting for this one
+                            if (res_pair_fusable(pair_a, pair_b, unit_a, P, nimg)) {
+                                pair_pending = false;
+                                rc = launch_res_pair(s, pair_a, pair_b, unit_a, P, nimg, net->ctx->device);
+                                if (rc != DD_OK) return rc;
+                                net->op_launch[i] = OPK_RES_PAIR;  // ops i - 3 .. i - 1 stay "in the next launch"
+                                break;
+                            }
+                            if ((rc = flush_pair()) != DD_OK) return rc;
+                        }
+                        // o[30] == 2: this unit's outputs are read by the next residual unit only -- hold it back, the two may run as one launch
+                        if (o[30] == 2 && i + 2 < net->n_ops) {
+                            pair_a = unit_a; pair_b = P; pair_pending = true; pair_op = i;
+                            net->op_launch[i] = OPK_FOLDED;
+                            break;
+                        }
                         rc = launch_res_unit(s, unit_a, P, nimg, net->ctx->device);
                         if (rc != DD_OK) return rc;
                         net->op_launch[i] = OPK_RES_UNIT;
                         break;
                     }
+                    if (pair_pending && (rc = flush_pair()) != DD_OK) return rc;
                     net->op_launch[i - 1] = OPK_DEFAULT;
                     rc = launch_conv3x3_rw(s, unit_a, nimg, false, net->ctx->device);
                     if (rc != DD_OK) return rc;
+                }
+                if (pair_pending) {                            // a held unit waits only for the first layer of the unit that reads it
+                    const bool next_a = net->use_rw && P.kh == 3 && P.kw == 3 && P.stride == 1 && P.cin == 32 && P.cout_pad == 32 && P.epi == EPI_F16 &&
+                                        P.pad_t == 1 && P.pad_l == 1 && o[30] && !o[29] && i + 1 < net->n_ops && nimg >= 160 && !P.res && !P.out2 &&
+                                        P.in == static_cast<const _Float16 *>(pair_b.out2);
+                    if (!next_a && (rc = flush_pair()) != DD_OK) return rc;
                 }
                 if (P.epi == EPI_SSD_HEAD && net->ssd_dec && o[18] && !o[19]) {   // o[18] / o[31]: the per-anchor copy of weights / bias
                     DD_REQUIRE(P.p[1] == net->dec_anchors, DD_E_ARG, "dd_net_forward: head of %d anchors, decode set up for %d", P.p[1], net->dec_anchors);
@@ -3723,6 +3993,7 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
                         }
                     }
                     if (o[30] && !o[29] && i + 1 < net->n_ops && nimg >= 160 && !P.res && !P.out2) {
+                        if (pair_pending && P.in != static_cast<const _Float16 *>(pair_b.out2) && (rc = flush_pair()) != DD_OK) return rc;
                         unit_a = P; unit_pending = true;       // o[30]: only the next op reads this layer's output
                         net->op_launch[i] = OPK_FOLDED;
                         break;
@@ -3913,6 +4184,7 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
                 DD_REQUIRE(false, DD_E_ARG, "dd_net_forward: unknown op kind %d at %d", kind, i);
         }
     }
+    if (pair_pending) { const int rc = flush_pair(); if (rc != DD_OK) return rc; }
     if (net->profile) {
         DD_HIP(hipEventRecord(net->events[net->n_ops], s));
         DD_HIP(hipEventRecord(net->events[net->n_ops + 1], s));

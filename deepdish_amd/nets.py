@@ -45,6 +45,7 @@ def same_pad(size, k, stride):
 class Program:
     STEM_POOL_FUSE = os.environ.get('DD_STEM_POOL_FUSE', '1') != '0'   # MARS conv1_1 folded into conv1_2's launch
     RES_UNIT_FUSE = os.environ.get('DD_RES_UNIT_FUSE', '1') != '0'     # MARS conv2_x: both 3x3 layers of a residual unit in one launch
+    RES_PAIR_FUSE = os.environ.get('DD_RES_PAIR_FUSE', '1') != '0'     # ... and the two units of the stage in one launch (res_pair_rows_k)
     SSD_FRONT_FUSE = os.environ.get('DD_SSD_FRONT_FUSE', '1') != '0'   # SSD conv0 + MobileNet block 1 in one launch
     PW_DW_FUSE = os.environ.get('DD_PW_DW_FUSE', '1') != '0'           # MobileNet: pointwise layer + the next block's depthwise layer in one launch
 
@@ -388,6 +389,10 @@ def compile_mars(wd, in_h=64, in_w=32):
             out2 = P.tensor(s['h'], s['w'], c)
             P.conv(h1, wd[name + '/2/weights'], wd[name + '/2/biases'], dst=out, res=skip, dst2=out2,
                    aff2=bn_affine(wd, nxt + '/bn'))                             # :68-72 + :37/:39 skip add
+            nb = MARS_BLOCKS[i + 1]
+            if Program.RES_UNIT_FUSE and Program.RES_PAIR_FUSE and not inc and c == 32 and not nb[2] and nb[1] == 32:
+                P.ops[-1][30] = 2    # out / out2 are read by the next residual unit only (its skip and its first layer): with enough
+                                     # crops both units run as one launch (res_pair_rows_k) and neither tensor is written
             raw, pre = out, out2
         else:
             P.conv(h1, wd[name + '/2/weights'], wd[name + '/2/biases'], dst=out, res=skip)

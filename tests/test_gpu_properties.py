@@ -37,13 +37,15 @@ def test_mars_batch_of_1280_is_crop_independent():
         np.testing.assert_array_equal(net.read()[0, 0, 0, :], full[i])
 
 
-@pytest.mark.parametrize('n', [159, 160, 170, 511, 512, 800, 1600])
+@pytest.mark.parametrize('n', [159, 160, 170, 511, 512, 800, 1023, 1024, 1030, 1600, 2100])
 def test_mars_first_layers_give_the_same_bits_in_every_launch_shape(n):
     """conv1_1 + conv1_2 + pool: below 160 crops two launches (stem_conv3_k, tiled conv3x3_rw_k<POOL>), from 160 one
     launch of one wave per row range (conv3x3_pool_rows_k<STEM>, 4 / 2 / 1 units per crop by batch size); a program
     compiled without the fusion flag keeps the first layer separate and streams its rows by DMA.  Likewise the two
     residual units of conv2_x: two launches of conv3x3_rw_k each, or from 512 crops one res_unit_rows_k launch each
-    (the intermediate tensor stays in LDS).  All of them must give the bits of the single-crop forward."""
+    (the intermediate tensor stays in LDS), or from 1024 crops BOTH units as one launch of wave pairs (res_pair_rows_k: the
+    tensors between the units stay in LDS too; 1030 = some pairs own two images, most one).  All of them must give the bits
+    of the single-crop forward."""
     from deepdish_amd import nets
     from deepdish_amd.engine import Net
     wd = nets.synthetic_mars_weights(1234)
@@ -66,7 +68,10 @@ def test_mars_first_layers_give_the_same_bits_in_every_launch_shape(n):
     finally:
         nets.Program.STEM_POOL_FUSE, nets.Program.RES_UNIT_FUSE = old
     assert net2.program.ops[0][30] == 0 and not any(op[30] for op in net2.program.ops)
-    assert sum(int(op[30]) for op in net.program.ops) == 3          # conv1_1, conv2_1/1, conv2_3/1
+    assert [int(op[30]) for op in net.program.ops if op[30]] == [1, 1, 2, 1]      # conv1_1, conv2_1/1, conv2_1/2 (pair), conv2_3/1
+    from deepdish_amd.profile import net_op_launches
+    net.forward(x)
+    assert (12 in [int(c) for c in net_op_launches(net)]) == (n >= 1024)         # 12 = res_pair_rows_k
     net2.forward(x)
     np.testing.assert_array_equal(net2.read()[:, 0, 0, :], full)
     np.testing.assert_array_equal(net2.read(tensor=net2.program.meta['tensors']['pool1']), pool)
