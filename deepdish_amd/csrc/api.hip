@@ -1,5 +1,6 @@
 // Flat C ABI: context management and the per-function entry points of include/deepdish_hip.h
 // (the handle-based entry points live next to their kernels: tracker.hip, nets.hip, pipeline.hip).
+#include <cstdlib>
 #include <mutex>
 #include "common.h"
 
@@ -43,7 +44,16 @@ int dd_ctx_create(int device, dd_ctx **out) {
                "dd_ctx_create: this library is built for gfx950 only, device is %s", prop.gcnArchName);
     dd_ctx *c = new dd_ctx();
     c->device = device;
-    DD_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    // The context's stream carries the short latency-critical kernels of a step (NMS, crops, association, Kalman updates: the
+    // host waits for each); a pipeline's detector stream carries one long train of big kernels for the NEXT frame.  With equal
+    // priorities a 10 us NMS kernel queues behind whatever part of that train is resident; DD_STREAM_PRIO=0 restores that.
+    {
+        int least = 0, greatest = 0;
+        const char *e = getenv("DD_STREAM_PRIO");
+        DD_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        if (!(e && atoi(e) == 0) && greatest != least) DD_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest));
+        else DD_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    }
     *out = c;
     return DD_OK;
 }

@@ -32,7 +32,8 @@ __device__ __forceinline__ void lin_coeff(int d, int dst, int src, int &s, int &
     a1 = (int)rintf(f * 2048.f);
 }
 
-struct CropBox { int sx, sy, cw, ch, frame, flip, r1, r2; };   // cw <= 0 marks a box the reference rejects; flip: rows read bottom-up (cv2.flip(frame, 0))
+struct CropBox { int sx, sy, cw, ch, frame, flip, swap_rb, r2; };   // cw <= 0 marks a box the reference rejects; flip: rows read bottom-up (cv2.flip(frame, 0));
+                                                                    // swap_rb: channels written in reverse order (a BGR frame resampled into the RGB a detector reads)
 
 // grid (ceil(oh*ow/256), n); one thread per output pixel (3 channels).
 __global__ __launch_bounds__(256) void crop_resize_k(const uint8_t *__restrict__ frames, int H, int W,
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(256) void crop_resize_k(const uint8_t *__restrict__
     if (b.cw == 2 * ow && b.ch == 2 * oh) {       // exact 2x decimation: INTER_AREA shortcut
         const uint8_t *r0 = base + (ptrdiff_t)(2 * dy) * rs + (size_t)(2 * dx) * 3, *r1 = r0 + rs;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) o[c] = (uint8_t)((r0[c] + r0[c + 3] + r1[c] + r1[c + 3] + 2) >> 2);
+        for (int c = 0; c < 3; ++c) o[b.swap_rb ? 2 - c : c] = (uint8_t)((r0[c] + r0[c + 3] + r1[c] + r1[c + 3] + 2) >> 2);
         return;
     }
     int sx, xa0, xa1, sy, ya0, ya1;
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256) void crop_resize_k(const uint8_t *__restrict__
         const int h0 = r0[sx * 3 + c] * xa0 + r0[sx1 * 3 + c] * xa1;      // scale 2^11
         const int h1 = r1[sx * 3 + c] * xa0 + r1[sx1 * 3 + c] * xa1;
         const int v = (((ya0 * (h0 >> 4)) >> 16) + ((ya1 * (h1 >> 4)) >> 16) + 2) >> 2;
-        o[c] = (uint8_t)min(max(v, 0), 255);
+        o[b.swap_rb ? 2 - c : c] = (uint8_t)min(max(v, 0), 255);
     }
 }
 

@@ -48,7 +48,7 @@ namespace {
 constexpr int MAX_DET = 10;              // N_max of the stock SSD post-process op
 constexpr float SSD_SCORE_THR = 1e-8f, SSD_IOU_THR = 0.6f;    // its score / NMS thresholds
 constexpr int YOLO_HOST_ROWS = 128;      // YOLOv5 rows per stream the first device-to-host copy of a step has room for (the rest, if any, follows)
-enum { DET_SSD = 0, DET_YOLOV5 = 1 };
+enum { DET_SSD = 0, DET_YOLOV5 = 1, DET_TFLITE = 2 };
 enum { CONFIRMED = 2, DELETED = 3 };
 
 struct Votes {                         // track.py:78-81,147-151: label -> confidences, in first-seen order
@@ -116,6 +116,9 @@ struct dd_pipeline {
     std::vector<StreamState> st;
     std::vector<dd_tracker *> trks;
     DevBuf d_resized, d_tmp, d_post, d_det, d_fin, d_pack, d_nms, d_crop, d_patches, d_feats;
+    DevBuf d_tfl_boxes;                        // generic TFLite adaptor: one whole-frame CropBox per stream (bilinear stretch, BGR -> RGB)
+    std::vector<std::string> tfl_labels;       // its label list: the label file's lines after the first, empty lines dropped (tflite.py:22, tflite_object_detector.py)
+    bool det_late = true;                      // where the look-ahead detector run is queued (dd_pipeline_step2)
     bool ssd_dec = false;                      // SSD: the head layers decode in their epilogue (dd_net_ssd_decode)
     size_t yolo_host_rows = 0;                 // YOLOv5: packed rows the first copy of a step brings to the host
     std::vector<size_t> ybase;
@@ -218,7 +221,13 @@ int dd_pipeline_create(dd_ctx *ctx, int n_streams, int frame_h, int frame_w, dd_
         if ((rc = dd_net_input_size(detector, &p->det_in, &p->det_in_w)) != DD_OK) return rc;
         p->det_kind = anchors_host ? DET_SSD : DET_YOLOV5;
         if (p->det_kind == DET_YOLOV5) { p->label_offset = 0; p->det_conf = 0.25; }          // yolov5.py:38,134
-        DD_HIP(hipStreamCreateWithFlags(&p->det_stream, hipStreamNonBlocking));
+        {   // the look-ahead detector run yields to the main stream's short kernels (see dd_ctx_create)
+            int least = 0, greatest = 0;
+            const char *e = getenv("DD_STREAM_PRIO");
+            DD_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            if (!(e && atoi(e) == 0) && greatest != least) DD_HIP(hipStreamCreateWithPriority(&p->det_stream, hipStreamNonBlocking, least));
+            else DD_HIP(hipStreamCreateWithFlags(&p->det_stream, hipStreamNonBlocking));
+        }
         DD_HIP(hipEventCreateWithFlags(&p->det_done, hipEventDisableTiming));
         DD_HIP(hipEventCreateWithFlags(&p->main_mark, hipEventDisableTiming));
         const size_t S = n_streams;
@@ -247,6 +256,7 @@ int dd_pipeline_create(dd_ctx *ctx, int n_streams, int frame_h, int frame_w, dd_
             if ((rc = p->h_fin.reserve(S * 4 + 64 + p->yolo_host_rows * 24)) != DD_OK) return rc;
         }
     }
+    { const char *e = getenv("DD_DET_LATE"); p->det_late = !(e && atoi(e) == 0); }
     p->st.resize(n_streams);
     p->trks.resize(n_streams);
     if ((rc = ddk::tracker_group_create(ctx, n_streams, max_cosine_distance, max_iou_distance, max_age, n_init, 0,
@@ -267,10 +277,32 @@ int dd_pipeline_destroy(dd_pipeline *p) {
     for (auto &s : p->st) dd_tracker_destroy(s.trk);
     (void)hipFree(p->d_anchors);
     dd_mog2_destroy(p->mog2);
-    for (DevBuf *b : {&p->d_resized, &p->d_tmp, &p->d_post, &p->d_det, &p->d_fin, &p->d_pack, &p->d_nms, &p->d_crop, &p->d_patches, &p->d_feats,
+    for (DevBuf *b : {&p->d_resized, &p->d_tmp, &p->d_post, &p->d_det, &p->d_fin, &p->d_pack, &p->d_tfl_boxes, &p->d_nms, &p->d_crop, &p->d_patches, &p->d_feats,
                       &p->d_mask, &p->d_masked, &p->d_mbox}) b->release();
     for (PinBuf *b : {&p->h_fin, &p->h_nms, &p->h_crop, &p->h_mbox}) b->release();
     delete p;
+    return DD_OK;
+}
+
+// Which adaptor consumes an SSD-type detector (deepdish.py:482-502 picks the plugin by the model's file name): 0 =
+// tools/ssd_mobilenet.py (the default of a pipeline created with anchors: Pillow Lanczos stretch, predict tail with per-class
+// nms_boxes), 2 = the generic TFLite-Task adaptor (tools/tflite.py + tools/tflite_object_detector.py: cv2 bilinear stretch of
+// the RGB frame, the post-process op's rows with score >= 0.5, int() corners, sorted by score).  Call before the first step.
+int dd_pipeline_detector_adaptor(dd_pipeline *p, int adaptor) {
+    DD_REQUIRE(p && p->det && p->det_kind != DET_YOLOV5 && (adaptor == DET_SSD || adaptor == DET_TFLITE), DD_E_ARG,
+               "dd_pipeline_detector_adaptor: needs a pipeline with an SSD-type detector; adaptor 0 (ssd_mobilenet) or 2 (tflite)");
+    DD_REQUIRE(p->steps == 0 && !p->det_pending, DD_E_STATE, "dd_pipeline_detector_adaptor: call before the first step");
+    DD_DEVICE(p->ctx);
+    p->det_kind = adaptor;
+    if (adaptor == DET_TFLITE) {
+        p->tfl_labels.clear();
+        for (size_t i = 1; i < p->labels.size(); ++i) if (!p->labels[i].empty()) p->tfl_labels.push_back(p->labels[i]);
+        std::vector<int> hb((size_t)p->S * 8, 0);
+        for (int z = 0; z < p->S; ++z) { int *b = hb.data() + (size_t)z * 8; b[2] = p->W; b[3] = p->H; b[4] = z; b[6] = 1; }   // whole frame, swap_rb
+        int rc;
+        if ((rc = p->d_tfl_boxes.reserve(hb.size() * sizeof(int))) != DD_OK) return rc;
+        DD_HIP(hipMemcpy(p->d_tfl_boxes.p, hb.data(), hb.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
     return DD_OK;
 }
 
@@ -342,8 +374,10 @@ int enqueue_detector(dd_pipeline *p, const uint8_t *frames) {
     // upload of these frames)
     DD_HIP(hipEventRecord(p->main_mark, p->ctx->stream));
     DD_HIP(hipStreamWaitEvent(s, p->main_mark, 0));
-    if ((rc = ddk::resize_lanczos(s, p->ctx->device, frames, p->H, p->W, 3, 1, p->d_resized.as<uint8_t>(), p->det_in,
-                                  p->det_in_w, p->d_tmp.as<uint8_t>(), S)) != DD_OK) return rc;    // ssd_mobilenet.py:54-57, yolov5.py:99
+    if (p->det_kind == DET_TFLITE) {                           // tflite_object_detector.py:207-211: cv2.resize (INTER_LINEAR) of the RGB frame
+        if ((rc = ddk::crop_resize(s, frames, p->H, p->W, p->d_tfl_boxes.p, S, p->det_in, p->det_in_w, p->d_resized.as<uint8_t>())) != DD_OK) return rc;
+    } else if ((rc = ddk::resize_lanczos(s, p->ctx->device, frames, p->H, p->W, 3, 1, p->d_resized.as<uint8_t>(), p->det_in,
+                                         p->det_in_w, p->d_tmp.as<uint8_t>(), S)) != DD_OK) return rc;    // ssd_mobilenet.py:54-57, yolov5.py:99
     if ((rc = dd_net_forward(p->det, p->d_resized.as<uint8_t>(), S, s)) != DD_OK) return rc;       // :102-103 / yolov5.py:107-109
     void *raw = nullptr;
     if ((rc = dd_net_output(p->det, -1, &raw, nullptr, nullptr, nullptr, nullptr, nullptr)) != DD_OK) return rc;
@@ -373,6 +407,13 @@ int enqueue_detector(dd_pipeline *p, const uint8_t *frames) {
                                                p->d_post.p, p->d_post.cap)) != DD_OK) return rc;
     } else if ((rc = ddk::ssd_postprocess(s, static_cast<const float *>(raw), p->d_anchors, p->n_anchors, p->n_classes, MAX_DET,
                                           SSD_SCORE_THR, SSD_IOU_THR, db, dc, ds, dn, S, p->d_post.p, p->d_post.cap)) != DD_OK) return rc;
+    if (p->det_kind == DET_TFLITE) {                           // the generic adaptor's tail is a few integer truncations: on the host (step2)
+        const size_t dbytes = (size_t)S * MAX_DET * 6 * sizeof(float) + (size_t)S * sizeof(int);
+        DD_HIP(hipMemcpyAsync(p->h_fin.p, p->d_det.p, dbytes, hipMemcpyDeviceToHost, s));
+        DD_HIP(hipEventRecord(p->det_done, s));
+        p->det_pending = frames;
+        return DD_OK;
+    }
     double *fb = p->d_fin.as<double>(), *fs = fb + (size_t)S * MAX_DET * 4;
     int *fc = reinterpret_cast<int *>(fs + (size_t)S * MAX_DET), *fn = fc + (size_t)S * MAX_DET;
     if ((rc = ddk::ssd_finish(s, db, dc, ds, S, MAX_DET, p->det_conf, 0.5, (double)p->W, (double)p->H, fb, fc, fs, fn)) != DD_OK)
@@ -529,6 +570,31 @@ int dd_pipeline_step2(dd_pipeline *p, const uint8_t *frames_in, const uint8_t *f
                     }
                 }
             });
+        } else if (p->det_kind == DET_TFLITE) {
+            // tflite_object_detector.py:234-295 (_postprocess) + tools/tflite.py:26-41: score >= threshold, int() of the scaled
+            // corners (f32 arithmetic, truncation), label = label_list[class], stable sort by descending score, wanted labels only
+            const float *hb = p->h_fin.as<float>(), *hc = hb + (size_t)S * MAX_DET * 4, *hs = hc + (size_t)S * MAX_DET;
+            const int *hn = reinterpret_cast<const int *>(hs + (size_t)S * MAX_DET);
+            ddk::parallel_for(S, GRAIN, [&](int z0, int z1) {
+                for (int z = z0; z < z1; ++z) {
+                    StreamState &q = st[z];
+                    q.boxes0.clear(); q.scores0.clear(); q.cls0.clear();
+                    int order[MAX_DET], n = 0;
+                    for (int i = 0; i < hn[z] && i < MAX_DET; ++i)
+                        if (hs[z * MAX_DET + i] >= (float)p->det_conf) order[n++] = i;
+                    std::stable_sort(order, order + n, [&](int a, int b) { return hs[z * MAX_DET + a] > hs[z * MAX_DET + b]; });
+                    for (int k = 0; k < n; ++k) {
+                        const int i = order[k], c = (int)hc[z * MAX_DET + i];
+                        if (c < 0 || c >= (int)p->tfl_labels.size() || wanted_index(p, p->tfl_labels[c]) < 0) continue;
+                        const float *b = hb + ((size_t)z * MAX_DET + i) * 4;                          // ymin, xmin, ymax, xmax (normalised)
+                        const int top = (int)(b[0] * (float)p->H), left = (int)(b[1] * (float)p->W);
+                        const int bottom = (int)(b[2] * (float)p->H), right = (int)(b[3] * (float)p->W);
+                        q.boxes0.insert(q.boxes0.end(), {(double)left, (double)top, (double)(right - left), (double)(bottom - top)});
+                        q.scores0.push_back((double)hs[z * MAX_DET + i]);
+                        q.cls0.push_back(c);
+                    }
+                }
+            });
         } else {
             const double *hb = p->h_fin.as<double>(), *hs = hb + (size_t)S * MAX_DET * 4;
             const int *hc = reinterpret_cast<const int *>(hs + (size_t)S * MAX_DET), *hn = hc + (size_t)S * MAX_DET;
@@ -548,7 +614,7 @@ int dd_pipeline_step2(dd_pipeline *p, const uint8_t *frames_in, const uint8_t *f
             });
         }
         // the host block has been consumed: the detector buffers are free for the next frames
-        if (frames_next && (rc = enqueue_detector(p, frames_next)) != DD_OK) return rc;
+        if (frames_next && !p->det_late && (rc = enqueue_detector(p, frames_next)) != DD_OK) return rc;
     } else {
         for (auto &q : st) { q.boxes0.clear(); q.scores0.clear(); q.cls0.clear(); }
     }
@@ -704,6 +770,12 @@ int dd_pipeline_step2(dd_pipeline *p, const uint8_t *frames_in, const uint8_t *f
     // ---------------- deep_sort update, phase-split so all streams share two round trips (:1029)
     if ((rc = ddk::trackers_update_begin(p->trks.data(), S, tlwh.data(), D ? p->d_feats.as<float>() : nullptr, 1,
                                          doff.data())) != DD_OK) return rc;
+    // Look-ahead, late form (default): the detector run of the next frames is queued HERE, behind this step's NMS / crops / encoder /
+    // association kernels (enqueue_detector orders the detector stream after what the main stream holds so far).  Queued at the
+    // consume point instead (DD_DET_LATE=0) it shares the GPU with the encoder from the start, the chain the host waits for takes
+    // twice as long, and then the GPU idles through the host's matching / count-line tail: one worker group ran 6.3 ms per
+    // 384-frame step for 5.0 ms of kernels.  Here the chain runs alone, and the detector fills the tail.
+    if (p->det && frames_next && p->det_late && (rc = enqueue_detector(p, frames_next)) != DD_OK) return rc;
     DD_HIP(hipStreamSynchronize(s));                                                                   // round trip 3
     if ((rc = ddk::trackers_update_match(p->trks.data(), S)) != DD_OK) return rc;
     DD_HIP(hipStreamSynchronize(s));                                                                   // round trip 4

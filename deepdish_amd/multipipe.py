@@ -45,9 +45,10 @@ class MultiStreamPipeline:
         self.W, self.H = input_size
         self.wanted = list(wanted_labels)
         # the reference picks the detector plugin by a substring of --model (deepdish.py:482-502)
-        self.kind = 'yolov5' if 'yolov5' in model else 'ssd_mobilenet' if 'mobilenet' in model else None
+        self.kind = ('yolov5' if 'yolov5' in model else None if ('yolo' in model or 'saved_model' in model) else
+                     'ssd_mobilenet' if 'mobilenet' in model else 'tflite' if 'tflite' in model else None)
         if self.kind is None:
-            raise ValueError('the multi-stream pipeline batches the SSD-MobileNet and YOLOv5 detectors (got %s)' % model)
+            raise ValueError('the multi-stream pipeline batches the SSD-MobileNet, YOLOv5 and generic TFLite detectors (got %s)' % model)
         with open(labels or (DEFAULT_YOLO_LABELS if self.kind == 'yolov5' else DEFAULT_LABELS)) as f:
             self.label_lines = [l.strip() for l in f.readlines()]
         self.det = None
@@ -87,6 +88,8 @@ class MultiStreamPipeline:
                                        int(max_age), int(n_init), ptr(self.line), int(track_capacity),
                                        int(gallery_capacity), ctypes.byref(h)), 'dd_pipeline_create')
         self._h = h
+        if self.kind == 'tflite' and self.det is not None:          # tools/tflite.py's adaptor instead of tools/ssd_mobilenet.py's
+            check(lib().dd_pipeline_detector_adaptor(self._h, 2), 'dd_pipeline_detector_adaptor')
         off = 0 if self.kind == 'yolov5' else 1                     # yolov5.py:134 labels[idx]; ssd_mobilenet.py:142-147 labels[idx + 1]
         self._class_id = {name: i - off for i, name in enumerate(self.label_lines) if i >= off}
         if background_subtraction_ratio is not None:

@@ -612,8 +612,11 @@ def compile_yolov5s(wd, in_size=640):
     s = P.T(x)
     spp = P.tensor(s['h'], s['w'], 1024)                                    # [x | mp5 | mp9 | mp13]
     x = cv('m8.cv1', x, dst=P.view(spp, 0, 256))
+    src = x
     for i, k in enumerate((5, 9, 13)):
-        P.maxpool(x, k, 1, k // 2, dst=P.view(spp, 256 * (i + 1), 256))
+        # 5x5, 9x9 and 13x13 stride-1 max pools of x as a cascade of 5x5 pools (a max over a window of windows; taps outside the map
+        # are skipped, so the borders agree too): the same values with 75 taps per output instead of 275
+        src = P.maxpool(src, 5, 1, 2, dst=P.view(spp, 256 * (i + 1), 256))
     x = cv('m8.cv2', spp)
     x = c3('m9', x, 512, 1, False)
     cat23 = P.tensor(s['h'], s['w'], 512)                                   # [m21 | m10]

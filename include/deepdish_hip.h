@@ -318,6 +318,11 @@ int dd_pipeline_create(dd_ctx *ctx, int n_streams, int frame_h, int frame_w, dd_
                        double nms_max_overlap, double max_iou_distance, int max_age, int n_init,
                        const double *line_host, int track_capacity, int gallery_capacity, dd_pipeline **out);
 int dd_pipeline_destroy(dd_pipeline *p);
+/* Adaptor that consumes an SSD-type detector's output, chosen like the reference chooses its plugin class from the model
+ * file name (deepdish.py:482-502): 0 = tools/ssd_mobilenet.py (default), 2 = the generic TFLite-Task adaptor
+ * (tools/tflite.py:9-41 over tools/tflite_object_detector.py:180-295: cv2.resize INTER_LINEAR of the RGB frame, rows of the
+ * post-process op with score >= 0.5, int() of the scaled corners, sorted by score).  Before the first step. */
+int dd_pipeline_detector_adaptor(dd_pipeline *p, int adaptor);
 /* frames: device u8 [n_streams][H][W][3] BGR.  inj_*: optional detections that REPLACE the detector's
  * output (it still runs): tlwh f64 rows, scores, class ids; stream s owns rows
  * [inj_offsets[s], inj_offsets[s+1]).  Blocks until the step is complete. */

@@ -231,6 +231,37 @@ def test_multistream_yolov5_pipeline_matches_plugin():
     assert seen > 3, seen
 
 
+def test_multistream_generic_tflite_pipeline_matches_plugin():
+    """a13 in the batched C++ pipeline: a --model name with 'tflite' but neither 'yolo' nor 'mobilenet' selects the generic
+    TFLite-Task adaptor (deepdish.py:493-495): cv2 bilinear stretch of the RGB frame, SSD forward, post-process op, then
+    tflite_object_detector.py:234-295 + tools/tflite.py:26-41 (score >= 0.5, int() corners, stable sort by score, wanted
+    labels).  Three streams batched in C++ == three single-stream Python pipelines built from the TFLITE plugin."""
+    from deepdish_amd.multipipe import MultiStreamPipeline
+    from deepdish_amd.pipeline import HotPath, DEFAULT_LABELS
+    from deepdish_amd.synth import Scene
+    wanted = sorted({l.strip() for l in open(DEFAULT_LABELS)} - {'???'})
+    model = 'synthetic-efficientdet_lite0.tflite'
+    scenes = [Scene(seed=3, n_obj=8, n_frames=5), Scene(seed=5, n_obj=5, n_frames=5), Scene(seed=9, n_obj=8, n_frames=5)]
+    mp = MultiStreamPipeline(3, model=model, wanted_labels=wanted)
+    assert mp.kind == 'tflite'
+    hps = [HotPath(model=model, wanted_labels=wanted) for _ in scenes]
+    assert type(hps[0].object_detector).__name__ == "TFLITE"
+    seen = 0
+    for f in range(5):
+        frames = torch.from_numpy(np.stack([sc.frame(f) for sc in scenes])).cuda()
+        mp.step(frames)
+        for z, hp in enumerate(hps):
+            hp.step(frames[z])
+            ints, means = mp.tracker(z).table()
+            want = np.array([[t.track_id, t.state, t.time_since_update, t.hits, t.age] for t in hp.tracker.tracks],
+                            dtype=np.int64).reshape(-1, 5)
+            np.testing.assert_array_equal(ints[:, :5], want, err_msg=f'frame {f} stream {z}')
+            if len(want):
+                np.testing.assert_allclose(means, np.array([t.mean for t in hp.tracker.tracks]), rtol=1e-9, atol=1e-9)
+            seen = max(seen, len(want))
+    assert seen > 0, seen
+
+
 def test_detector_and_encoder_run_concurrently_on_two_contexts():
     """SURVEY 8(b) threading: the reference keeps ONE detector call and ONE encoder call in flight on different pool
     threads (deepdish.py:935,985,1008).  Two host threads, each with its own dd_ctx (own stream, own scratch), hammer
