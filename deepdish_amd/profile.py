@@ -28,7 +28,7 @@ def net_op_times(net):
 
 # dd_net_op_launches codes (include/deepdish_hip.h)
 OPK_FOLDED = 1
-OPK_NAMES = {2: 'conv3x3_pool_rows_k', 3: 'conv3x3_pool_rows_k<STEM>', 4: 'res_unit_rows_k', 5: 'ssd_front_k', 6: 'conv3x3_c64_rows_k', 7: 'conv3x3_s2_rows_k', 8: 'conv_ws_k', 9: 'conv_ws_dw_k', 10: 'dwpw_rows_k', 11: 'conv_glds_k<ssd head + decode>', 12: 'res_pair_rows_k'}
+OPK_NAMES = {2: 'conv3x3_pool_rows_k', 3: 'conv3x3_pool_rows_k<STEM>', 4: 'res_unit_rows_k', 5: 'ssd_front_k', 6: 'conv3x3_c64_rows_k', 7: 'conv3x3_s2_rows_k', 8: 'conv_ws_k', 9: 'conv_ws_dw_k', 10: 'dwpw_rows_k', 11: 'conv_glds_k<ssd_head_decode>', 12: 'res_pair_rows_k'}
 
 
 def net_op_launches(net):
@@ -91,7 +91,7 @@ def pmc_traffic(kernel, streams):
     None when no summary exists for this stream count -- bench.py cannot run the profiler on itself."""
     import json, os
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles')
-    path = next((p for p in (os.path.join(root, 'r%02d_pmc_traffic_s%d.json' % (r, streams)) for r in (2, 1)) if os.path.exists(p)), None)
+    path = next((p for p in (os.path.join(root, 'r%02d_pmc_traffic_s%d.json' % (r, streams)) for r in (3, 2, 1)) if os.path.exists(p)), None)
     if path is None:                       # the newest round's summary for this stream count, if one was collected
         return None
     keys = [part.replace(',', ', ') for part in kernel.split('+')]
@@ -128,7 +128,7 @@ def dominant_kernel_roofline(pipes, step_group, args, reps=20):
     per_kernel = {n: round(v['ms'], 5) for n, v in sorted(acc.items(), key=lambda kv: -kv[1]['ms'])}
     # the dense-convolution GEMMs are one family: conv_ws_k runs the large pointwise layers from 160 images per launch,
     # conv_glds_k the rest and all of them below that (same layers, same arithmetic, batch-dependent choice)
-    fam = [n for n in ('conv_glds_k', 'conv_ws_k', 'conv_ws_dw_k', 'conv_glds_k<ssd head + decode>') if n in acc]     # conv_ws_dw_k: conv_ws_k with the next depthwise layer in its epilogue
+    fam = [n for n in ('conv_glds_k', 'conv_ws_k', 'conv_ws_dw_k', 'conv_glds_k<ssd_head_decode>') if n in acc]     # conv_ws_dw_k: conv_ws_k with the next depthwise layer in its epilogue
     if len(fam) > 1:
         parts = [acc.pop(n) for n in fam]
         acc['+'.join(fam)] = {f: sum(p[f] for p in parts) for f in ('ms', 'flops', 'bytes', 'launches')}
