@@ -44,14 +44,16 @@ int dd_ctx_create(int device, dd_ctx **out) {
                "dd_ctx_create: this library is built for gfx950 only, device is %s", prop.gcnArchName);
     dd_ctx *c = new dd_ctx();
     c->device = device;
-    // The context's stream carries the short latency-critical kernels of a step (NMS, crops, association, Kalman updates: the
-    // host waits for each); a pipeline's detector stream carries one long train of big kernels for the NEXT frame.  With equal
-    // priorities a 10 us NMS kernel queues behind whatever part of that train is resident; DD_STREAM_PRIO=0 restores that.
+    // DD_STREAM_PRIO=1 (experiment, off by default): the context's stream (the short kernels of a step the host waits for: NMS, crops,
+    // association, Kalman updates) gets the highest stream priority and a pipeline's detector stream the lowest.  Measured on this
+    // stack: no effect -- a 10 us NMS kernel still queues behind whatever part of the detector's train is resident (same-box A/B,
+    // profiles/r03_ab_runs.txt) -- and a stream created with a priority makes a legacy-stream hipMemcpy of another thread fail while
+    // it is being captured ("would make the legacy stream depend on a capturing blocking stream"), so latency-mode graphs need it off.
     {
         int least = 0, greatest = 0;
         const char *e = getenv("DD_STREAM_PRIO");
         DD_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        if (!(e && atoi(e) == 0) && greatest != least) DD_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest));
+        if (e && atoi(e) == 1 && greatest != least) DD_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest));
         else DD_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     }
     *out = c;

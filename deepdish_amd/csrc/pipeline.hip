@@ -225,7 +225,7 @@ int dd_pipeline_create(dd_ctx *ctx, int n_streams, int frame_h, int frame_w, dd_
             int least = 0, greatest = 0;
             const char *e = getenv("DD_STREAM_PRIO");
             DD_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-            if (!(e && atoi(e) == 0) && greatest != least) DD_HIP(hipStreamCreateWithPriority(&p->det_stream, hipStreamNonBlocking, least));
+            if (e && atoi(e) == 1 && greatest != least) DD_HIP(hipStreamCreateWithPriority(&p->det_stream, hipStreamNonBlocking, least));
             else DD_HIP(hipStreamCreateWithFlags(&p->det_stream, hipStreamNonBlocking));
         }
         DD_HIP(hipEventCreateWithFlags(&p->det_done, hipEventDisableTiming));
@@ -256,7 +256,9 @@ int dd_pipeline_create(dd_ctx *ctx, int n_streams, int frame_h, int frame_w, dd_
             if ((rc = p->h_fin.reserve(S * 4 + 64 + p->yolo_host_rows * 24)) != DD_OK) return rc;
         }
     }
-    { const char *e = getenv("DD_DET_LATE"); p->det_late = !(e && atoi(e) == 0); }
+    // late look-ahead (dd_pipeline_step2) when a step's kernels fill the GPU; with a handful of streams they do not, and the detector of
+    // the next frame runs beside the encoder from the consume point on (one stream: 0.46 ms per frame early, 0.66 ms late)
+    { const char *e = getenv("DD_DET_LATE"); p->det_late = e ? atoi(e) != 0 : n_streams >= 64; }
     p->st.resize(n_streams);
     p->trks.resize(n_streams);
     if ((rc = ddk::tracker_group_create(ctx, n_streams, max_cosine_distance, max_iou_distance, max_age, n_init, 0,

@@ -100,59 +100,79 @@ __global__ void ssd_gather_k(const int *__restrict__ keep, const int *__restrict
 // walks a Python set; the order is irrelevant downstream (deep_sort's NMS re-sorts by score) -- and inside a
 // class in pick order (descending score), exactly as nms_boxes returns them.
 constexpr int FIN_MAX = 16;
-__global__ void ssd_finish_k(const float *__restrict__ boxes, const float *__restrict__ cls, const float *__restrict__ scores,
-                             int max_det, double conf, double iou_thr, double img_w, double img_h, double *__restrict__ out_boxes,
-                             int *__restrict__ out_cls, double *__restrict__ out_scores, int *__restrict__ out_n) {
-    if (threadIdx.x != 0) return;
-    const int z = blockIdx.x, N = max_det;
+// One wave per image, lane i = row i of the op's output (N <= 16 rows): the greedy loops run on wave reductions and
+// broadcasts -- class by class in ascending id, inside a class the best remaining score first (lowest row on ties, as the
+// reference's strict `>` scan), every other row of the class tested against it in parallel.  (One lane walking all of it
+// alone took 83 us per 384-image launch: a chain of dependent loads and branches.)  Same f64 expressions, same order of the
+// emitted rows.
+__device__ __forceinline__ double shfl_f64(double v, int src) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __shfl((int)(b & 0xffffffffLL), src, 64), hi = __shfl((int)(b >> 32), src, 64);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__global__ __launch_bounds__(64) void ssd_finish_k(const float *__restrict__ boxes, const float *__restrict__ cls, const float *__restrict__ scores,
+                                                   int max_det, double conf, double iou_thr, double img_w, double img_h, double *__restrict__ out_boxes,
+                                                   int *__restrict__ out_cls, double *__restrict__ out_scores, int *__restrict__ out_n) {
+    const int z = blockIdx.x, N = max_det, i = threadIdx.x;
     boxes += (size_t)z * N * 4; cls += (size_t)z * N; scores += (size_t)z * N;
     out_boxes += (size_t)z * N * 4; out_cls += (size_t)z * N; out_scores += (size_t)z * N;
-    float sc[FIN_MAX];
-    for (int i = 0; i < N; ++i) sc[i] = scores[i];
-    for (int i = 0; i < N; ++i)
-        for (int c = 0; c < 4; ++c)
-            if (isnan(boxes[i * 4 + c])) { sc[i] = 0.f; if (c < N) sc[c] = 0.f; }   // :111-113 (np.where rows AND cols)
-    for (int i = 0; i < N; ++i) if (isnan(sc[i])) sc[i] = 0.f;            // :115-116
-    double bx[FIN_MAX][4];
-    bool live[FIN_MAX];
-    for (int i = 0; i < N; ++i) {
-        live[i] = sc[i] >= (float)conf;                                   // :119
-        bx[i][0] = (double)boxes[i * 4 + 1] * img_w;                      // :121-127 reorder [1,0,3,2] * [w,h,w,h]
-        bx[i][1] = (double)boxes[i * 4 + 0] * img_h;
-        bx[i][2] = (double)boxes[i * 4 + 3] * img_w;
-        bx[i][3] = (double)boxes[i * 4 + 2] * img_h;
+    const bool in = i < N;
+    float sc = in ? scores[i] : 0.f;
+    const int cl = in ? (int)cls[i] : 0;
+    float bf[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) bf[c] = in ? boxes[i * 4 + c] : 0.f;
+    // :111-113 scores[np.where(np.isnan(boxes))] = 0 -- np.where yields (rows, cols) and BOTH index the score vector
+    bool nan_row = false;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const bool nn = in && isnan(bf[c]);
+        nan_row |= nn;
+        if (__any(nn) && i == c && c < N) sc = 0.f;
     }
+    if (nan_row) sc = 0.f;
+    if (isnan(sc)) sc = 0.f;                                              // :115-116
+    bool done = !(in && sc >= (float)conf);                               // :119 (rows below the confidence never take part)
+    const double x1 = (double)bf[1] * img_w, y1 = (double)bf[0] * img_h;  // :121-127 reorder [1,0,3,2] * [w,h,w,h]
+    const double x2 = (double)bf[3] * img_w, y2 = (double)bf[2] * img_h;
     int n = 0;
-    bool done[FIN_MAX] = {false};
     for (;;) {
-        int cmin = 1 << 30;
-        for (int i = 0; i < N; ++i) if (live[i] && !done[i]) cmin = min(cmin, (int)cls[i]);
-        if (cmin == (1 << 30)) break;
-        bool dead[FIN_MAX] = {false};
+        int cmin = done ? 0x7fffffff : cl;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cmin = min(cmin, __shfl_xor(cmin, o, 64));
+        if (cmin == 0x7fffffff) break;                                    // wave-uniform
+        bool cand = !done && cl == cmin;
         for (;;) {                                                        // greedy by descending score within the class
-            int best = -1;
-            for (int i = 0; i < N; ++i)
-                if (live[i] && !done[i] && (int)cls[i] == cmin && !dead[i] && (best < 0 || sc[i] > sc[best])) best = i;
-            if (best < 0) break;
-            done[best] = true;
-            for (int q = 0; q < 4; ++q) out_boxes[n * 4 + q] = bx[best][q];
-            out_cls[n] = cmin;
-            out_scores[n] = (double)sc[best];
+            float bs = cand ? sc : -__builtin_inff();
+            int bi = cand ? i : 64;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float os = __shfl_xor(bs, o, 64);
+                const int oi = __shfl_xor(bi, o, 64);
+                if (os > bs || (os == bs && oi < bi)) { bs = os; bi = oi; }
+            }
+            if (bi >= 64) break;
+            if (i == bi) {
+                out_boxes[n * 4 + 0] = x1; out_boxes[n * 4 + 1] = y1; out_boxes[n * 4 + 2] = x2; out_boxes[n * 4 + 3] = y2;
+                out_cls[n] = cmin;
+                out_scores[n] = (double)sc;
+                done = true; cand = false;
+            }
             ++n;
-            const double x = bx[best][0], y = bx[best][1], w = bx[best][2] - bx[best][0], h = bx[best][3] - bx[best][1];
-            for (int j = 0; j < N; ++j) {
-                if (!live[j] || done[j] || (int)cls[j] != cmin || dead[j]) continue;
-                const double xj = bx[j][0], yj = bx[j][1], wj = bx[j][2] - bx[j][0], hj = bx[j][3] - bx[j][1];
+            const double bx1 = shfl_f64(x1, bi), by1 = shfl_f64(y1, bi), bx2 = shfl_f64(x2, bi), by2 = shfl_f64(y2, bi);
+            if (cand) {
+                const double x = bx1, y = by1, w = bx2 - bx1, h = by2 - by1;
+                const double xj = x1, yj = y1, wj = x2 - x1, hj = y2 - y1;
                 const double xx1 = fmax(x, xj), yy1 = fmax(y, yj);
                 const double xx2 = fmin(x + w, xj + wj), yy2 = fmin(y + h, yj + hj);
                 const double w1 = fmax(0.0, xx2 - xx1 + 1), h1 = fmax(0.0, yy2 - yy1 + 1);
                 const double inter = w1 * h1;
                 const double ovr = inter / (w * h + wj * hj - inter);
-                if (!(ovr <= iou_thr)) { dead[j] = true; done[j] = true; }
+                if (!(ovr <= iou_thr)) { done = true; cand = false; }
             }
         }
     }
-    out_n[z] = n;
+    if (i == 0) out_n[z] = n;
 }
 
 // tools/yolov5.py:120-131, first half: per-row confidence and class
