@@ -38,8 +38,16 @@ constexpr int TENSOR_WORDS = 8;
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
         case ACT_RELU6: return __builtin_amdgcn_fmed3f(v, 0.f, 6.f);      // one v_med3_f32 (fmin(fmax()) costs an extra canonicalising v_max)
-        case ACT_ELU:                                   // exp(v) - 1: absolute error ~1e-7, far below the f16 the result is stored in
-            return v > 0.f ? v : __expf(v) - 1.f;
+        case ACT_ELU: {
+            // max(v, exp(min(v, 0)) - 1): the min is the clamp modifier of v_exp_f32 (its result is clamped to [0, 1]: med3 with
+            // 0 and 1 folds into the instruction), the max a v_med3 with a huge finite third operand (no canonicalising copy) -- four instructions per
+            // element and no compare / VCC / select round trip with its wait states (v_mul, v_exp, v_add, v_cmp, s_nop, v_cndmask:
+            // the row-streaming kernels are bound by instruction issue).  The product v * log2(e) is the one
+            // __expf forms; exp(v) - 1: absolute error ~1e-7, far below the f16 the result is stored in.  For v > 0 the result is v.
+            float e = __builtin_amdgcn_exp2f(v * 1.44269504088896340736f);
+            e = __builtin_amdgcn_fmed3f(e, 0.f, 1.f);
+            return __builtin_amdgcn_fmed3f(v, e - 1.f, 3.0e38f);   // (with +inf hipcc rewrites the med3 as a max and canonicalises v first: a fifth instruction)
+        }
         case ACT_SILU: return v / (1.f + __expf(-v));
         case ACT_RELU: return fmaxf(v, 0.f);
         case ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
@@ -1000,7 +1008,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_pool_rows_k(const ConvP P, con
     const int offA = 512 + (fq * 16 + (fr ? fr - 1 : 0)) * 8, offD = (fq * 16 + (fr < 15 ? fr + 1 : 15)) * 8;
     const unsigned keepA = fr ? 0xFFFFFFFFu : 0u, keepD = fr < 15 ? 0xFFFFFFFFu : 0u;   // x = -1 / x = 32: the zero padding
     const int act = ACT < 0 ? P.act : ACT;
-    const int split = split_dbg & 255, dbg = split_dbg >> 8;   // dbg: measurement aid (DD_PR_DBG): 1 no MFMAs, 2 no pooling epilogue, 4 no row production in the loop
+    const int split = split_dbg & 255;
+#ifdef DD_KERNEL_DBG
+    const int dbg = split_dbg >> 8;                             // measurement aid (DD_PR_DBG): 1 no MFMAs, 2 no pooling epilogue, 4 no row production in the loop
+#else
+    constexpr int dbg = 0;                                      // compiled out of the product build: as a run-time value it put ~30 scalar branches
+#endif                                                          // into every round of a kernel that is bound by instruction issue (build with -DDD_KERNEL_DBG)
     const int crow = lane >> 5, cdw = lane & 31;                // image rows: two per step, one dword per lane (24 of 32 live)
     const int cx = 1 + 6 * fr;                                  // window start (x - 1) of the even pixel x = 2 fr in a ring row
 
@@ -1287,24 +1300,23 @@ __global__ __launch_bounds__(256, 2) void res_unit_rows_k(const ConvP PA, const 
             {
                 f4 acc[2][2] = {{EB.b0, EB.b1}, {EB.b0, EB.b1}};
                 conv2(h1, 2 * r - 2, RU_H1_SLOTS - 1, wB, acc);
-                h8 rv[2];
-#pragma unroll
-                for (int cr = 0; cr < 2; ++cr) {
-                    const int y = 2 * r - 1 + cr;
-                    rv[cr] = RAW_SEP ? *reinterpret_cast<const h8 *>(rawr + (y & (RU_RAW_SLOTS - 1)) * RU_SLOT + offC)
-                                     : *reinterpret_cast<const h8 *>(pre + ((y + 1) & (RU_PRE_SLOTS - 1)) * RU_SLOT + offC);
-                }
+                // the skip rows: read from their ring slots row by row (both at once cost the RAW_SEP variant its last registers:
+                // 256 VGPRs + 20 bytes of scratch; the slots are not refilled before the next round's DMAs land)
+                h8 rv0 = RAW_SEP ? *reinterpret_cast<const h8 *>(rawr + ((2 * r - 1) & (RU_RAW_SLOTS - 1)) * RU_SLOT + offC)
+                                 : *reinterpret_cast<const h8 *>(pre + ((2 * r) & (RU_PRE_SLOTS - 1)) * RU_SLOT + offC);
 #if defined(__HIP_DEVICE_COMPILE__)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next round's rows have landed, last round's stores have retired
 #endif
 #pragma unroll
                 for (int cr = 0; cr < 2; ++cr) {
                     const int y = 2 * r - 1 + cr;
+                    if (cr == 1) rv0 = RAW_SEP ? *reinterpret_cast<const h8 *>(rawr + (y & (RU_RAW_SLOTS - 1)) * RU_SLOT + offC)
+                                               : *reinterpret_cast<const h8 *>(pre + ((y + 1) & (RU_PRE_SLOTS - 1)) * RU_SLOT + offC);
                     if ((unsigned)y >= (unsigned)H || fr >= W) continue;
                     float o[8];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { o[q] = acc[cr][0][q]; o[4 + q] = acc[cr][1][q]; }
-                    conv_epilogue_f16x8<ACT_NONE, false, 1, true, false>(PB, EB, (n * H + y) * W + fr, fq * 8, o, &rv[cr]);
+                    conv_epilogue_f16x8<ACT_NONE, false, 1, true, false>(PB, EB, (n * H + y) * W + fr, fq * 8, o, &rv0);
                 }
             }
         }
@@ -2566,7 +2578,11 @@ __global__ __launch_bounds__(NW * 64) void conv_ws_k(const ConvP P, const int n_
     for (int a = 0; a < NI; ++a)                                // its batch size selects
 #pragma unroll
         for (int b = 0; b < MI; ++b) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
+#ifdef DD_KERNEL_DBG
     const int dbg = P.p[5];                                      // measurement aid (DD_WS_MODE): 1 = no fills in the loop, 2 = no MFMAs
+#else
+    constexpr int dbg = 0;                                       // compiled out of the product build (-DDD_KERNEL_DBG brings it back)
+#endif
 
     const int rr = lane >> 3, pp = lane & 7;
     const int gch = (pp ^ rr) * 8;
