@@ -2551,8 +2551,9 @@ __global__ __launch_bounds__(512) void dwpw_big_k(const ConvP P) {
 // prefetch distance for the few stages after a tile's stores (never too short a wait).
 constexpr int WS_BM = 64;
 
-template <int KS, int NW, int D, int ACT>
+template <int KS, int NW, int D, int ACT, int SPB = 1>
 __global__ __launch_bounds__(NW * 64) void conv_ws_k(const ConvP P, const int n_slices) {
+    static_assert((SPB == 1 || SPB == 2) && KS % SPB == 0 && D >= 2 * SPB + 2, "stages per barrier");
     constexpr int BM = WS_BM, MI = 4, NI = 2, G = 8 / NW;       // G: fills per wave and stage
     static_assert((KS & (KS - 1)) == 0 && (D & (D - 1)) == 0 && KS % 2 == 0 && 8 % NW == 0, "stage arithmetic uses masks");
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];         // [D][64 pixels][64 halves]
@@ -2605,9 +2606,12 @@ __global__ __launch_bounds__(NW * 64) void conv_ws_k(const ConvP P, const int n_
         for (int b = 0; b < MI; ++b)
             x[b] = *reinterpret_cast<const h8 *>(xs + (b * 16 + fr) * 64 + (((kk << 2) + fq) ^ sw) * 8);
     };
-    for (int st = 0; st < D - 1; ++st) fill(st);
+    // SPB stages per barrier (DD_WS_SPB).  SPB = 2 = one wait + barrier per TWO K slabs, 32 MFMAs per wave between barriers instead of
+    // 16 (fills D - 2 .. D - 1 stages ahead, D - 5 stages left in flight by the wait): built to test whether barrier skew between the
+    // four waves of a block is what a stage pays for -- it is not: no change on either layer (round 3, same-box A/B).  Default 1.
+    for (int st = 0; st < D - SPB; ++st) fill(st);
 #if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(G * (D - 2)) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(G * (D - SPB - 1)) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 #endif
@@ -2617,13 +2621,18 @@ __global__ __launch_bounds__(NW * 64) void conv_ws_k(const ConvP P, const int n_
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int st = ti * KS + ks;
+            if (ks % SPB == 0) {
 #if defined(__HIP_DEVICE_COMPILE__)
-            // this wave's fills of stage st + 1 have landed and its reads of stage st - 1 have returned ...
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(G * (D - 3)) : "memory");
-            __builtin_amdgcn_s_barrier();                        // ... everybody's have
-            asm volatile("" ::: "memory");
+                // this wave's fills of stages st + 1 .. st + SPB have landed and its reads of the stages before st have returned ...
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(G * (D - 2 * SPB - 1)) : "memory");
+                __builtin_amdgcn_s_barrier();                    // ... everybody's have
+                asm volatile("" ::: "memory");
 #endif
-            if (dbg != 1) fill(st + D - 1);                      // into the buffer stage st - 1 has left
+                if (dbg != 1) {
+#pragma unroll
+                    for (int q = 0; q < SPB; ++q) fill(st + D - SPB + q);   // into the buffers stages st - SPB .. st - 1 have left
+                }
+            }
             read_frags(st, 1, xb);                               // lands under the MFMAs of slice 0
             if (dbg != 2) {
 #pragma unroll
@@ -3533,6 +3542,22 @@ int launch_conv_ws(hipStream_t s, ConvP &P, int device) {
     });
     if (rc != DD_OK) return rc;
     const dim3 grid(2 * 256 * 4 / NW);                           // persistent: 8 waves per CU
+    static const int spb = getenv("DD_WS_SPB") ? atoi(getenv("DD_WS_SPB")) : 1;     // stages per barrier; 2 measured null (19x19x512 93.6 / 91.8 vs 94.5 / 92.0 us, same bits)
+    if (spb == 2) {
+        static DevOnce once2;
+        const int rc2 = once2.run(device, [&]() -> int {
+            DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_ws_k<KS, NW, D, ACT_RELU6, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_ws_k<KS, NW, D, ACT_SILU, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_ws_k<KS, NW, D, ACT_NONE, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            return DD_OK;
+        });
+        if (rc2 != DD_OK) return rc2;
+        if (P.act == ACT_RELU6) hipLaunchKernelGGL((conv_ws_k<KS, NW, D, ACT_RELU6, 2>), grid, dim3(NW * 64), lds_bytes, s, P, n_slices);
+        else if (P.act == ACT_SILU) hipLaunchKernelGGL((conv_ws_k<KS, NW, D, ACT_SILU, 2>), grid, dim3(NW * 64), lds_bytes, s, P, n_slices);
+        else hipLaunchKernelGGL((conv_ws_k<KS, NW, D, ACT_NONE, 2>), grid, dim3(NW * 64), lds_bytes, s, P, n_slices);
+        DD_LAUNCH_CHECK();
+        return DD_OK;
+    }
     if (P.act == ACT_RELU6) hipLaunchKernelGGL((conv_ws_k<KS, NW, D, ACT_RELU6>), grid, dim3(NW * 64), lds_bytes, s, P, n_slices);
     else if (P.act == ACT_SILU) hipLaunchKernelGGL((conv_ws_k<KS, NW, D, ACT_SILU>), grid, dim3(NW * 64), lds_bytes, s, P, n_slices);
     else hipLaunchKernelGGL((conv_ws_k<KS, NW, D, ACT_NONE>), grid, dim3(NW * 64), lds_bytes, s, P, n_slices);
