@@ -52,6 +52,7 @@ SIGNATURES = {
     'dd_crop_resize_f64': [P, P, c_int, c_int, P, c_int, c_int, c_int, P, P, P],
     'dd_fake_encode': [P, P, c_int, c_int, P, P],
     'dd_resize_lanczos': [P, P, c_int, c_int, c_int, c_int, P, c_int, c_int, P],
+    'dd_resize_lanczos_batch': [P, P, c_int, c_int, c_int, c_int, c_int, P, c_int, c_int, P],
     'dd_resize_bilinear': [P, P, c_int, c_int, c_int, P, c_int, c_int, P],
     'dd_ingest_create': [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
     'dd_ingest_destroy': [P],

@@ -332,6 +332,199 @@ __global__ __launch_bounds__(256) void band_resample_wide_k(const uint8_t *__res
     }
 }
 
+// Four values of one column -> (v >> 22) clipped to a byte each, packed into a word.  gfx950 has the instruction for it,
+// v_ashr_pk_u8_i32: D[7:0] = sat_u8(S0 >> S2), D[15:8] = sat_u8(S1 >> S2) into the half of D that op_sel[3] names, the other half
+// kept (which is why hipcc's own use of it, followed by an OR that assumes zeros there, corrupts bytes: lanczos_v4_k).
+// The operands must come from ordinary VALU results: hipcc places no wait states between an MFMA and inline assembly that reads
+// its destination (tried: 98 % of the bytes wrong).
+__device__ __forceinline__ uint32_t band_pack4(int v0, int v1, int v2, int v3) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_ashr_pk_u8_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v0), "v"(v1), "v"(PRECISION_BITS));
+    asm("v_ashr_pk_u8_i32 %0, %1, %2, %3 op_sel:[0,0,0,1]" : "+v"(r) : "v"(v2), "v"(v3), "v"(PRECISION_BITS));
+    return r;
+#else
+    return 0;
+#endif
+}
+
+// The three digit products of four tiles: digit 2's accumulator shifted left by 8 is what digit 1 accumulates onto; digit 0
+// accumulates onto the bias in a chain of its own; (hi << 8) + lo = d0 + (d1 << 8) + (d2 << 16) + bias modulo 2^32 -- two VALU
+// operations per value instead of four, and with the MFMA results in VGPRs (__launch_bounds__(256, 2)) and band_pack4 a tile costs
+// ~20 VALU issues instead of 110 (the first form of the fused kernel spent 72 % of its issue slots on that arithmetic).
+template <int KS, int NJ>
+__device__ __forceinline__ void band_digits(const i4v (&x)[NJ][KS], const i4v (&cf)[KS][3], int bias, uint32_t (&word)[NJ]) {
+    i4v xx[NJ][KS], hi[NJ], lo[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) xx[j][ks] = x[j][ks] ^ (int)0x80808080;      // u8 -> i8: p - 128 (the bias carries 128 * sum(coef))
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { hi[j] = i4v{0, 0, 0, 0}; lo[j] = i4v{bias, bias, bias, bias}; }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            hi[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(xx[j][ks], cf[ks][2], hi[j], 0, 0, 0);
+            lo[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(xx[j][ks], cf[ks][0], lo[j], 0, 0, 0);
+        }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hi[j][i] = (int)((unsigned)hi[j][i] << 8);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) hi[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(xx[j][ks], cf[ks][1], hi[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        int v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (int)(((unsigned)hi[j][i] << 8) + (unsigned)lo[j][i]);
+        word[j] = band_pack4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// Both passes in ONE launch, through LDS.  band_resample_wide_k feeds its MFMAs straight from global memory in fragment
+// shape: lane = (row fr, 16-byte chunk fq), so every 16-lane pass of a load touches 16 different rows -- 64 cache-line
+// look-ups per wave load, and the passes ran at 92 CU cycles per wave load (1.3 M of them for 384 frames: the whole 224 us of
+// the horizontal pass), with the transposed intermediate written to and read back from HBM on top (PMC round 3: 406 + 203
+// and 169 + 179 MB for 354 MB of frames and 104 MB of output).  Here a block owns 64 columns of the transposed intermediate
+// (four 16-column groups, one per wave) of ONE frame:
+//   * the union of the four groups' source windows (<= 256 bytes of every row) is loaded coalesced -- 16 lanes x 16 B per
+//     row, four rows per wave load -- 64 rows at a time, through registers into a double-buffered LDS tile S[64][272];
+//   * the horizontal product reads its fragments from S (chunk c of row r at c ^ 4 (r / 16 % 4), as T below), same three digit MFMAs, same
+//     packing; its bytes go to T[64 columns][<= 512 rows] in LDS, 16-byte chunk q of column c stored at q ^ 4 (c / 16 % 4)
+//     so that both the writing lanes (16 columns) and the reading lanes (columns 16 a + 4 j + b) fall on 16 bank groups;
+//   * the vertical product (output row groups dealt over the waves, coefficient fragments from L2) reads T and stores
+//     16 bytes per lane into the [h][w][3] result.
+// HBM sees the frame once and the output once.  Same integers as the two-pass form: the same bytes.
+constexpr int LF_ROWS = 64, LF_SP = 272, LF_TP = 528, LF_NVG = 5;      // LF_NVG: output row groups per wave (h <= 320)
+constexpr int lf_lds_bytes() { return 2 * LF_ROWS * LF_SP + 64 * LF_TP; }
+
+template <int KH, int KV>
+__global__ __launch_bounds__(256, 2) void lanczos_fused_k(const uint8_t *__restrict__ src, size_t src_img_stride, int H, int pitch_s,
+                                                       const int *__restrict__ start_h, const int *__restrict__ slab_u0,
+                                                       const i4v *__restrict__ coef_h, const int *__restrict__ bias_h,
+                                                       int n_groups_h, int C, const int *__restrict__ start_v,
+                                                       const i4v *__restrict__ coef_v, const int *__restrict__ bias_v,
+                                                       int n_groups_v, int h, uint8_t *__restrict__ dst, size_t dst_img_stride,
+                                                       int n_slabs) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lf_smem[];
+    uint8_t *S = lf_smem, *T = lf_smem + 2 * LF_ROWS * LF_SP;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const unsigned v = dd_xcd_remap(blockIdx.x, gridDim.x);      // the slabs of a frame sit next to each other: one XCD, one L2
+    const int slab = (int)(v % (unsigned)n_slabs), n = (int)(v / (unsigned)n_slabs);
+    const int g = slab * 4 + wave;
+    const bool g_ok = g < n_groups_h;                            // wave-uniform; such a wave still loads and meets the barriers
+    const int u0 = slab_u0[slab];
+    i4v cf[KH][3];
+#pragma unroll
+    for (int ks = 0; ks < KH; ++ks)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) cf[ks][p] = g_ok ? coef_h[((size_t)(g * KH + ks) * 3 + p) * 64 + lane] : i4v{0, 0, 0, 0};
+    const int so = g_ok ? start_h[g] - u0 : 0;
+    const int bh = (g_ok && g * 16 + fr < C) ? bias_h[g * 16 + fr] : 0;
+    // vertical pass: fragments, bias and window of ALL the wave's row groups (every fourth), fetched now: fetched one group ahead
+    // each round of that pass waited out an L2 round trip (47 us of 183 at 384 frames)
+    i4v cva[LF_NVG][KV][3];
+    int bva[LF_NVG], sva[LF_NVG];
+#pragma unroll
+    for (int i = 0; i < LF_NVG; ++i) {
+        const int gg = min(wave + 4 * i, n_groups_v - 1);
+#pragma unroll
+        for (int ks = 0; ks < KV; ++ks)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) cva[i][ks][p] = coef_v[((size_t)(gg * KV + ks) * 3 + p) * 64 + lane];
+        bva[i] = gg * 16 + fr < h ? bias_v[gg * 16 + fr] : 0;
+        sva[i] = start_v[gg];
+    }
+    const int lc = tid & 15, lr = tid >> 4;                      // load item: 16-byte chunk lc of rows lr + 16 i
+    const uint8_t *img = src + (size_t)n * src_img_stride + min(u0 + lc * 16, pitch_s - 16);      // chunks past the row end belong to no window
+    const int NC = (H + LF_ROWS - 1) / LF_ROWS;
+    constexpr int PF = 4;                                         // chunks in flight (5 and 6 spill at 256 VGPRs and lose: 189 / 199 vs 171 us): a chunk is loaded PF iterations before its product
+    i4v rg[PF][4];                                               // (one chunk ahead left the block waiting on HBM every iteration: 2 blocks x 16 KB per CU in flight)
+    auto load_chunk = [&](int ch, i4v (&r)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const i4v *>(img + (size_t)min(ch * LF_ROWS + lr + 16 * i, H - 1) * pitch_s);
+    };
+    auto write_chunk = [&](int buf, const i4v (&r)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<i4v *>(S + buf * (LF_ROWS * LF_SP) + (lr + 16 * i) * LF_SP + ((lc ^ (4 * i)) << 4)) = r[i];
+    };
+#pragma unroll
+    for (int i = 0; i < PF; ++i) load_chunk(i, rg[i]);            // chunks past the last one re-read row H - 1 (never used)
+    write_chunk(0, rg[0]);
+    load_chunk(PF, rg[0]);
+    __syncthreads();
+    const int row_in_tile = ((fr >> 2) << 4) + (fr & 3);        // + 4 j: see band_resample_wide_k
+    typedef uint32_t u4l __attribute__((ext_vector_type(4)));
+    auto h_chunk = [&](int ch) {
+        if (!g_ok) return;
+        const uint8_t *sb = S + (ch & 1) * (LF_ROWS * LF_SP);
+        const int sc = (so >> 4) + fq, ca = fr >> 2;              // chunk c of row r sits at c ^ 4 (r / 16 % 4): rows 16 a + b + 4 j on 16 bank groups
+        // all fragment reads of the round, then all MFMAs, then the packing: written tile by tile hipcc kept that order and every
+        // tile waited out its own LDS and MFMA latencies (2.7 k cycles per round, 35 k per block)
+        i4v x[4][KH];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int ks = 0; ks < KH; ++ks) x[j][ks] = *reinterpret_cast<const i4v *>(sb + (row_in_tile + 4 * j) * LF_SP + (((sc + ks * 4) ^ (4 * ca)) << 4));
+        uint32_t word[4];
+        band_digits<KH, 4>(x, cf, bh, word);
+        // rows ch * 64 + fq * 16 .. + 15 of column wave * 16 + fr
+        *reinterpret_cast<u4l *>(T + (wave * 16 + fr) * LF_TP + (((ch * 4 + fq) ^ (4 * wave)) << 4)) = u4l{word[0], word[1], word[2], word[3]};
+    };
+    // No branch around the loads or the LDS writes: with `if (ch + 1 < NC)` there hipcc's wait-count pass had paths with different
+    // numbers of loads in flight and settled for vmcnt(0) in front of every write_chunk -- the prefetch depth was 1 whatever PF said.
+    // Rounds past the last chunk load row H - 1 again and fill an S buffer nobody reads.
+    for (int c0 = 0; c0 < NC; c0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {                            // chunk ch = c0 + u: set u held it, set (u + 1) % PF holds chunk ch + 1
+            const int ch = c0 + u;
+            if (ch >= NC) break;                                  // block-uniform; leaving is no branch AROUND a load
+            h_chunk(ch);
+            write_chunk((ch + 1) & 1, rg[(u + 1) % PF]);
+            load_chunk(ch + 1 + PF, rg[(u + 1) % PF]);
+            __syncthreads();
+        }
+    }
+    // ---- vertical product: output rows gv * 16 + fr, bytes slab * 64 + fq * 16 .. + 15 of them
+    uint8_t *out = dst + (size_t)n * dst_img_stride;
+    const int ca = fr >> 2;                                       // column / 16 of this lane's fragment rows
+#pragma unroll
+    for (int vi = 0; vi < LF_NVG; ++vi) {
+        const int gv = wave + 4 * vi;
+        if (gv >= n_groups_v) break;                              // wave-uniform
+        const i4v (&cv)[KV][3] = cva[vi];
+        const int y = gv * 16 + fr;
+        const int bv = bva[vi];
+        const int q0 = (sva[vi] >> 4) + fq;
+        i4v x[4][KV];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int ks = 0; ks < KV; ++ks)
+                x[j][ks] = *reinterpret_cast<const i4v *>(T + (row_in_tile + 4 * j) * LF_TP + (((q0 + ks * 4) ^ (4 * ca)) << 4));
+        uint32_t word[4];
+        band_digits<KV, 4>(x, cv, bv, word);
+        if (y < h) {
+            const int cb = slab * 64 + fq * 16;
+            uint8_t *o = out + (size_t)y * C + cb;
+            typedef uint32_t u4a __attribute__((ext_vector_type(4), aligned(4)));
+            if (cb + 16 <= C) {
+                *reinterpret_cast<u4a *>(o) = u4a{word[0], word[1], word[2], word[3]};
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (cb + 4 * j + 4 <= C) *reinterpret_cast<uint32_t *>(o + 4 * j) = word[j];
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void copy_rgb_k(const uint8_t *__restrict__ src, int n_px, int src_c, int swap_rb,
                                                   uint8_t *__restrict__ dst) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -437,7 +630,8 @@ int get_table(int device, int in_size, int out_size, DevTable *out) {
 
 // Banded-product tables for band_resample_k.  `taps(col)` yields (source byte index, coefficient)
 // pairs of output column `col`; pitch = bytes per source row (the window of a column group must fit).
-struct BandTable { int n_groups = 0, ksteps = 0, n_cols = 0; int *start = nullptr; void *coef = nullptr; int *bias = nullptr; bool ok = false; };
+struct BandTable { int n_groups = 0, ksteps = 0, n_cols = 0; int *start = nullptr; void *coef = nullptr; int *bias = nullptr; bool ok = false;
+                   int *slab_u0 = nullptr; int n_slabs = 0, slab_width = 0; };     // lanczos_fused_k: first window byte of every 4 groups, widest union
 std::map<std::tuple<int, int, int, int, int, int, int>, BandTable> g_bands;     // (device, in, out, mode, src_c, swap, pitch)
 
 template <class TapFn>
@@ -515,6 +709,16 @@ int get_band(int device, int in_size, int out_size, int mode, int src_c, int swa
             DD_HIP(hipMemcpy(b.start, start.data(), start.size() * sizeof(int), hipMemcpyHostToDevice));
             DD_HIP(hipMemcpy(b.coef, coef.data(), coef.size(), hipMemcpyHostToDevice));
             DD_HIP(hipMemcpy(b.bias, bias.data(), bias.size() * sizeof(int), hipMemcpyHostToDevice));
+            b.n_slabs = (b.n_groups + 3) / 4;
+            std::vector<int> u0(b.n_slabs);
+            for (int sl = 0; sl < b.n_slabs; ++sl) {
+                int lo = INT32_MAX, hi = 0;
+                for (int g = sl * 4; g < std::min(b.n_groups, sl * 4 + 4); ++g) { lo = std::min(lo, start[g]); hi = std::max(hi, start[g] + ksteps * 64); }
+                u0[sl] = lo;
+                b.slab_width = std::max(b.slab_width, hi - lo);
+            }
+            DD_HIP(hipMalloc(&b.slab_u0, u0.size() * sizeof(int)));
+            DD_HIP(hipMemcpy(b.slab_u0, u0.data(), u0.size() * sizeof(int), hipMemcpyHostToDevice));
         }
         it = g_bands.emplace(key, b).first;
     }
@@ -558,6 +762,26 @@ int launch_band(hipStream_t s, const BandTable &b, const uint8_t *src, size_t sr
         default: DD_BAND(4); break;
     }
 #undef DD_BAND
+    DD_LAUNCH_CHECK();
+    return DD_OK;
+}
+
+int launch_lanczos_fused(hipStream_t s, int device, const BandTable &bh, const BandTable &bv, const uint8_t *src, size_t src_img_stride,
+                         int H, int pitch_s, uint8_t *dst, size_t dst_img_stride, int h, int batch) {
+    static DevOnce once;
+    const int rc = once.run(device, [&]() -> int {
+        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lanczos_fused_k<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lf_lds_bytes()));
+        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lanczos_fused_k<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lf_lds_bytes()));
+        return DD_OK;
+    });
+    if (rc != DD_OK) return rc;
+    const dim3 grid((unsigned)(bh.n_slabs * batch));
+#define DD_LF(KH_, KV_) hipLaunchKernelGGL((lanczos_fused_k<KH_, KV_>), grid, dim3(256), lf_lds_bytes(), s, src, src_img_stride, H, pitch_s, bh.start, \
+                                           bh.slab_u0, static_cast<const i4v *>(bh.coef), bh.bias, bh.n_groups, bh.n_cols, bv.start,                 \
+                                           static_cast<const i4v *>(bv.coef), bv.bias, bv.n_groups, h, dst, dst_img_stride, bh.n_slabs)
+    if (bh.ksteps == 1) DD_LF(1, 1);
+    else DD_LF(2, 1);
+#undef DD_LF
     DD_LAUNCH_CHECK();
     return DD_OK;
 }
@@ -625,6 +849,9 @@ int resize_lanczos(hipStream_t s, int device, const uint8_t *src, int H, int W, 
         if (rc != DD_OK) return rc;
         rc = get_band(device, H, h, 1, 1, 0, H, &bv);
         if (rc != DD_OK) return rc;
+        static const bool fused_off = getenv("DD_LANCZOS_FUSED") && atoi(getenv("DD_LANCZOS_FUSED")) == 0;
+        if (bh.ok && bv.ok && !fused_off && bh.ksteps <= 2 && bv.ksteps == 1 && bv.n_groups <= 4 * LF_NVG && H <= 512 && bh.slab_width <= 256 && W * src_c >= 256)
+            return launch_lanczos_fused(s, device, bh, bv, src, (size_t)H * W * src_c, H, W * src_c, dst, (size_t)h * w * 3, h, batch);
         if (bh.ok && bv.ok) {
             rc = launch_band(s, bh, src, (size_t)H * W * src_c, H, W * src_c, tmp, (size_t)w * 3 * H, H, batch);
             if (rc != DD_OK) return rc;
@@ -741,6 +968,17 @@ int dd_resize_lanczos(dd_ctx *ctx, const uint8_t *src, int H, int W, int src_c, 
     if ((rc = ctx->scratch[3].reserve((size_t)H * w * 3 + 64)) != DD_OK) return rc;
     return ddk::resize_lanczos(dd_pick_stream(ctx, stream), ctx->device, src, H, W, src_c, swap_rb, dst, h, w,
                                ctx->scratch[3].as<uint8_t>(), 1);
+}
+
+int dd_resize_lanczos_batch(dd_ctx *ctx, const uint8_t *src, int batch, int H, int W, int src_c, int swap_rb, uint8_t *dst,
+                            int h, int w, void *stream) {
+    DD_REQUIRE(ctx && src && dst && batch > 0 && H > 0 && W > 0 && h > 0 && w > 0, DD_E_ARG, "dd_resize_lanczos_batch: bad argument");
+    DD_DEVICE(ctx);
+    DD_REQUIRE(src_c == 3 || src_c == 4, DD_E_ARG, "dd_resize_lanczos_batch: src_c must be 3 or 4");
+    int rc;
+    if ((rc = ctx->scratch[3].reserve((size_t)batch * H * w * 3 + 64)) != DD_OK) return rc;
+    return ddk::resize_lanczos(dd_pick_stream(ctx, stream), ctx->device, src, H, W, src_c, swap_rb, dst, h, w,
+                               ctx->scratch[3].as<uint8_t>(), batch);
 }
 
 int dd_resize_bilinear(dd_ctx *ctx, const uint8_t *src, int H, int W, int c, uint8_t *dst, int h, int w,

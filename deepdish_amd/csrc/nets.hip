@@ -2665,6 +2665,136 @@ __global__ __launch_bounds__(NW * 64) void conv_ws_k(const ConvP P, const int n_
 #endif
 }
 
+// conv_ws_k with the pixel tiles staged THROUGH REGISTERS instead of by LDS-DMA.  In-kernel stamps (round 3, -DDD_KERNEL_STAMP build
+// of conv_ws_k: scripts/stamp_conv_ws.sh) put the two global_load_lds of a stage at 336 of its 876 cycles per wave -- with the
+// address chain hoisted out of the loop still 233: an LDS-DMA costs the issuing wave ~115 cycles here, and a weight-stationary wave
+// issues two of them per 16 MFMAs.  A global_load_dwordx4 to registers costs the wave a few cycles to issue and a ds_write_b128 13;
+// the price is 32 VGPRs for four stages in flight.  Stage s is loaded LA + 2 = 6 stages before its MFMAs, written to LDS two
+// stages before them (behind that stage's barrier: the buffer's last reader is two barriers back), read like conv_ws_k reads it.
+// hipcc counts these loads itself (no LDS-DMA in the kernel), so the waits in front of the ds_writes are exact.  Same LDS image,
+// same fragment reads, same MFMA order, same epilogue: the same bits.
+template <int KS, int NW, int ACT, int NG = 1>
+__global__ __launch_bounds__(NW * 64) void conv_wsr_k(const ConvP P, const int n_slices) {
+    constexpr int BM = WS_BM, MI = 4, NI = 2 * NG, G = 8 / NW, D = 4, LA = 4;
+    static_assert(KS % LA == 0 && 8 % NW == 0, "register sets rotate with the unrolled K loop");
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];         // [D][64 pixels][64 halves]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4, sw = fr & 7;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int slice = j % n_slices, worker = (j / n_slices) * 8 + xcd;
+    const int n_workers = ((int)(gridDim.x >> 3) / n_slices) * 8;
+    const int T = (P.m + BM - 1) / BM;
+    const int ntiles = worker < T ? (T - worker + n_workers - 1) / n_workers : 0;
+    const int cbase = slice * (32 * NG * NW) + wave * (32 * NG);
+
+    h8 wf[KS * 2][NI];
+#pragma unroll
+    for (int k = 0; k < KS * 2; ++k)
+#pragma unroll
+        for (int a = 0; a < NI; ++a)
+            wf[k][a] = *reinterpret_cast<const h8 *>(P.w + (size_t)(cbase + rw_weight_row(a, fr)) * P.kpad + k * 32 + fq * 8);
+    Epi8 E[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) E[g] = epi8_load(P, cbase + g * 32 + fq * 8);
+    f4 acc[NI][MI];
+#pragma unroll
+    for (int a = 0; a < NI; ++a)
+#pragma unroll
+        for (int b = 0; b < MI; ++b) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
+
+    const int rr = lane >> 3, pp = lane & 7;
+    const int gch = (pp ^ rr) * 8;
+    // per-lane source pointers of a tile's G row groups (K chunk gch of pixel row grp * 8 + rr), once per tile; a load is then the
+    // pointer plus an immediate K-slab offset.  Rows past the tensor / tiles past the last one read pixel 0 (never stored).
+    auto tile_base = [&](int ti, const _Float16 *(&tb)[G]) {
+        const int m0 = (worker + ti * n_workers) * BM;
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int m = m0 + (wave * G + i) * 8 + rr;
+            tb[i] = P.in + (size_t)((ti < ntiles && m < P.m) ? m : 0) * P.cs_in + P.coff_in + gch;
+        }
+    };
+    h8 rs[LA][G];                                                // stages in flight: set s % LA holds stage s between its load and its LDS write
+    auto load_stage = [&](const _Float16 *const (&tb)[G], int ksp, h8 (&r)[G]) {
+#pragma unroll
+        for (int i = 0; i < G; ++i) r[i] = *reinterpret_cast<const h8 *>(tb[i] + ksp * 64);
+    };
+    auto write_stage = [&](int buf, const h8 (&r)[G]) {
+        _Float16 *dst = lds + (size_t)buf * (BM * 64);
+#pragma unroll
+        for (int i = 0; i < G; ++i) *reinterpret_cast<h8 *>(dst + ((wave * G + i) * 8 + rr) * 64 + pp * 8) = r[i];
+    };
+    h8 xa[MI], xb[MI];
+    auto read_frags = [&](int st, int kk, h8 (&x)[MI]) {
+        const _Float16 *xs = lds + (size_t)(st & (D - 1)) * (BM * 64);
+#pragma unroll
+        for (int b = 0; b < MI; ++b)
+            x[b] = *reinterpret_cast<const h8 *>(xs + (b * 16 + fr) * 64 + (((kk << 2) + fq) ^ sw) * 8);
+    };
+    constexpr int AH = LA + 2;                                   // a stage is loaded AH stages ahead: tile ti + OA or ti + OA + 1
+    constexpr int OA = AH / KS;
+    const _Float16 *tbA[G], *tbB[G];
+    {   // stages 0, 1 -> LDS; stages 2 .. AH - 1 -> their register sets
+        const _Float16 *t[G];
+#pragma unroll
+        for (int tt = 0; tt * KS < AH; ++tt) {
+            tile_base(tt, t);
+#pragma unroll
+            for (int st = tt * KS; st < (tt + 1) * KS && st < AH; ++st) {
+                load_stage(t, st - tt * KS, rs[st % LA]);
+                if (st < 2) write_stage(st, rs[st % LA]);
+            }
+        }
+    }
+    tile_base(OA, tbA);
+    tile_base(OA + 1, tbB);
+    __syncthreads();
+    read_frags(0, 0, xa);
+    for (int ti = 0; ti < ntiles; ++ti) {
+        const int m0 = (worker + ti * n_workers) * BM;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int st = ti * KS + ks;
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my writes of stage st + 1 (last stage) and my reads of stage st - 1 are done ...
+            __builtin_amdgcn_s_barrier();                        // ... everybody's are
+            asm volatile("" ::: "memory");
+#endif
+            write_stage((st + 2) & (D - 1), rs[(ks + 2) % LA]);  // stage st + 2 (its loads were issued LA stages ago)
+            if ((ks + AH) / KS == OA) load_stage(tbA, (ks + AH) % KS, rs[(ks + 2) % LA]);   // stage st + AH into the set just written out
+            else load_stage(tbB, (ks + AH) % KS, rs[(ks + 2) % LA]);
+            read_frags(st, 1, xb);
+#pragma unroll
+            for (int a = 0; a < NI; ++a)
+#pragma unroll
+                for (int b = 0; b < MI; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks * 2][a], xa[b], acc[a][b], 0, 0, 0);
+            read_frags(st + 1, 0, xa);
+#pragma unroll
+            for (int a = 0; a < NI; ++a)
+#pragma unroll
+                for (int b = 0; b < MI; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks * 2 + 1][a], xb[b], acc[a][b], 0, 0, 0);
+        }
+#pragma unroll
+        for (int b = 0; b < MI; ++b) {
+            const int m = m0 + b * 16 + fr;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                float o[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { o[r] = acc[2 * g][b][r]; o[4 + r] = acc[2 * g + 1][b][r]; }
+                if (m < P.m) conv_epilogue_f16x8<ACT, true, 0>(P, E[g], m, cbase + g * 32 + fq * 8, o);
+                acc[2 * g][b] = acc[2 * g + 1][b] = f4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < G; ++i) tbA[i] = tbB[i];
+        tile_base(ti + OA + 2, tbB);
+    }
+}
+
 struct DwP {
     const _Float16 *in; int H, W, cs_in, coff_in;
     const _Float16 *w; const float *bias;
@@ -3542,6 +3672,28 @@ int launch_conv_ws(hipStream_t s, ConvP &P, int device) {
     });
     if (rc != DD_OK) return rc;
     const dim3 grid(2 * 256 * 4 / NW);                           // persistent: 8 waves per CU
+    // DD_WSR=1: register-staged fills (conv_wsr_k), =2: that with 64 channels per wave (weights spill into AGPRs, one block per CU).
+    // Same bits; measured at 384 frames: 19x19x512 94.5 (LDS-DMA ring) / 93.8 / 88.6 us, 38x38x256 119 / 119 / 126 us -- neither the
+    // fills' issue cost nor the LDS read bandwidth is what holds the loop at 0.37 MFMA-busy, so the ring stays the default.
+    static const int wsr = getenv("DD_WSR") ? atoi(getenv("DD_WSR")) : 0;
+    if (wsr == 2 && P.cout_pad % 256 == 0) {                     // 64 channels per wave, one block per CU: half the LDS reads per MFMA
+        constexpr size_t lds_r = (size_t)4 * WS_BM * 64 * sizeof(_Float16);
+        const int ns = P.cout_pad / 256;
+        if (P.act == ACT_RELU6) hipLaunchKernelGGL((conv_wsr_k<KS, NW, ACT_RELU6, 2>), dim3(256), dim3(NW * 64), lds_r, s, P, ns);
+        else if (P.act == ACT_SILU) hipLaunchKernelGGL((conv_wsr_k<KS, NW, ACT_SILU, 2>), dim3(256), dim3(NW * 64), lds_r, s, P, ns);
+        else hipLaunchKernelGGL((conv_wsr_k<KS, NW, ACT_NONE, 2>), dim3(256), dim3(NW * 64), lds_r, s, P, ns);
+        DD_LAUNCH_CHECK();
+        return DD_OK;
+    }
+    if (wsr) {
+        constexpr size_t lds_r = (size_t)4 * WS_BM * 64 * sizeof(_Float16);
+        const dim3 grid_r(2 * 256 * 4 / NW);
+        if (P.act == ACT_RELU6) hipLaunchKernelGGL((conv_wsr_k<KS, NW, ACT_RELU6>), grid_r, dim3(NW * 64), lds_r, s, P, n_slices);
+        else if (P.act == ACT_SILU) hipLaunchKernelGGL((conv_wsr_k<KS, NW, ACT_SILU>), grid_r, dim3(NW * 64), lds_r, s, P, n_slices);
+        else hipLaunchKernelGGL((conv_wsr_k<KS, NW, ACT_NONE>), grid_r, dim3(NW * 64), lds_r, s, P, n_slices);
+        DD_LAUNCH_CHECK();
+        return DD_OK;
+    }
     static const int spb = getenv("DD_WS_SPB") ? atoi(getenv("DD_WS_SPB")) : 1;     // stages per barrier; 2 measured null (19x19x512 93.6 / 91.8 vs 94.5 / 92.0 us, same bits)
     if (spb == 2) {
         static DevOnce once2;

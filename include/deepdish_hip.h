@@ -175,6 +175,10 @@ int dd_fake_encode(dd_ctx *ctx, const uint8_t *patches, int n, int mode, float *
  * used, optionally swapped BGR->RGB), dst u8 [h][w][3]. */
 int dd_resize_lanczos(dd_ctx *ctx, const uint8_t *src, int H, int W, int src_c, int swap_rb,
                       uint8_t *dst, int h, int w, void *stream);
+/* The same resize of `batch` frames of one geometry, densely packed on both sides (what the batched pipeline
+ * does with a step's frames: one launch, both passes through LDS when the geometry allows). */
+int dd_resize_lanczos_batch(dd_ctx *ctx, const uint8_t *src, int batch, int H, int W, int src_c, int swap_rb,
+                            uint8_t *dst, int h, int w, void *stream);
 /* cv2.resize INTER_LINEAR stretch as tools/tflite_object_detector.py:211 */
 int dd_resize_bilinear(dd_ctx *ctx, const uint8_t *src, int H, int W, int c,
                        uint8_t *dst, int h, int w, void *stream);
