@@ -455,7 +455,7 @@ __device__ __forceinline__ void conv_finish_direct(const ConvP &P, f4 (&acc)[NI]
 // Block tile: (WM*MI*16) pixels x (WN*NI*16) output channels, K step BK (32 for shallow K, else 64:
 // two MFMA k-slices per barrier); blockIdx.z = K split.  Staged rows carry 8 halves of padding.
 template <int WM, int WN, int MI, int NI, int BK>
-__global__ __launch_bounds__(WM *WN * 64) void conv_mfma_k(const ConvP P) {
+__global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_k(const ConvP P) {
     constexpr int LDS_ROW = BK + 8;
     constexpr int T = WM * WN * 64;
     constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
@@ -589,7 +589,7 @@ __device__ __forceinline__ void lds_fill16(const _Float16 *g, _Float16 *lds_wave
 // else.  (The general per-lane walk costs more issue slots per K step than the MFMAs: 19x19x512 -> 512 went
 // 24.9 -> 21.8 us with FM 1, the MARS 16x8x64 -> 64 layers 28.8 -> 24.5 us with FM 2.)
 template <int WM, int WN, int MI, int NI, int FM = 0, bool DEC = false>       // DEC: SSD head, one anchor per 96-channel tile, decode in the epilogue
-__global__ __launch_bounds__(WM *WN * 64) void conv_glds_k(const ConvP P) {
+__global__ __launch_bounds__(WM *WN * 64, 2) void conv_glds_k(const ConvP P) {
     constexpr int NW = WM * WN;
     constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
     constexpr int XG = BM / 8 / NW, WG = BN / 8 / NW;           // 8-row groups per wave
@@ -1780,7 +1780,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_rows_k(const ConvP P, const
 // separate input-conversion pass and its 8-channel f16 tensor.  Weights [32][32] f16, channel swap
 // (BGR -> RGB) already folded into them by the host.
 template <int STRIDE, int ACT>
-__global__ __launch_bounds__(256) void stem_conv3_k(const ConvP P) {
+__global__ __launch_bounds__(256, 2) void stem_conv3_k(const ConvP P) {
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
@@ -2197,7 +2197,7 @@ __device__ __forceinline__ int dwpw_swz(int c, int row) {         // position of
 }
 
 template <int WM, int WN, int MI, int CIN, int STRIDE, int DACT, int ACT>
-__global__ __launch_bounds__(256) void dwpw_k(const ConvP P, const int n_tiles) {
+__global__ __launch_bounds__(256, 2) void dwpw_k(const ConvP P, const int n_tiles) {
     constexpr int NI = 4, BM = WM * MI * 16, BN = WN * 64, G = CIN / 8, KS = CIN / 32;
     constexpr int TX = 4, NCOL = (TX - 1) * STRIDE + 3;
     static_assert(WM * WN == 4 && (BM / 4) * G == 256, "one (quad, channel group) item per thread");
@@ -2552,7 +2552,7 @@ __global__ __launch_bounds__(512) void dwpw_big_k(const ConvP P) {
 constexpr int WS_BM = 64;
 
 template <int KS, int NW, int D, int ACT, int SPB = 1>
-__global__ __launch_bounds__(NW * 64) void conv_ws_k(const ConvP P, const int n_slices) {
+__global__ __launch_bounds__(NW * 64, 2) void conv_ws_k(const ConvP P, const int n_slices) {
     static_assert((SPB == 1 || SPB == 2) && KS % SPB == 0 && D >= 2 * SPB + 2, "stages per barrier");
     constexpr int BM = WS_BM, MI = 4, NI = 2, G = 8 / NW;       // G: fills per wave and stage
     static_assert((KS & (KS - 1)) == 0 && (D & (D - 1)) == 0 && KS % 2 == 0 && 8 % NW == 0, "stage arithmetic uses masks");

@@ -90,3 +90,28 @@ def test_bilinear_stretch_vs_oracle(ctx):
         dst = ctx.empty((h, w, 3), torch.uint8)
         check(lib().dd_resize_bilinear(ctx.handle, ptr(ctx.to_device(img)), 480, 640, 3, ptr(dst), h, w, None))
         np.testing.assert_array_equal(ctx.to_host(dst), image_np.resize_linear_u8(img, w, h))
+
+
+def test_lanczos_batch_one_launch_vs_pillow(ctx):
+    """A batch of frames through dd_resize_lanczos_batch (640x480 -> 300x300 runs both passes in ONE launch through LDS:
+    lanczos_fused_k): every frame equals Pillow's bytes -- noise (overshoot both ways: the clamp instruction), constants at both
+    ends of the range, a checkerboard, a ramp -- and a geometry the one-launch form does not take (720p) goes the two-pass way."""
+    from PIL import Image
+    from deepdish_amd._lib import lib, check
+    from deepdish_amd.runtime import ptr
+    rng = np.random.default_rng(5)
+    for (H, W, h, w, n) in ((480, 640, 300, 300, 7), (480, 640, 320, 320, 2), (720, 1280, 300, 300, 2)):
+        frames = rng.integers(0, 256, (n, H, W, 3), dtype=np.uint8)
+        frames[1] = 255
+        if n > 3:
+            frames[2] = 0
+            yy, xx = np.mgrid[0:H, 0:W]
+            frames[3] = (((yy // 3 + xx // 5) & 1) * 255).astype(np.uint8)[..., None]
+            frames[4] = ((xx * 255) // (W - 1)).astype(np.uint8)[..., None]
+        dst = ctx.empty((n, h, w, 3), torch.uint8)
+        check(lib().dd_resize_lanczos_batch(ctx.handle, ptr(ctx.to_device(frames)), n, H, W, 3, 1, ptr(dst), h, w, None))
+        got = ctx.to_host(dst)
+        for i in range(n):
+            rgba = np.dstack([frames[i][..., ::-1], np.full((H, W, 1), 255, np.uint8)])
+            want = np.asarray(Image.fromarray(rgba, 'RGBA').convert('RGB').resize((w, h), Image.LANCZOS))
+            np.testing.assert_array_equal(got[i], want, err_msg=f'{H}x{W}->{h}x{w} frame {i}')
