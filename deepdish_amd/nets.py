@@ -103,9 +103,10 @@ class Program:
         self.info.append(dict(kernel='?', flops=0, bytes=0, wbytes=0))
 
     # ---- ops
-    def input(self, swap_rb, mean=0.0, scale=1.0, s2d=False):
+    def input(self, swap_rb, mean=0.0, scale=1.0, s2d=False, c_pad=0):
+        """c_pad: channels of the output tensor (the real ones first, zeros behind them; 0 = 12 of 16 / 3 of 8)."""
         h, w = (self.in_h // 2, self.in_w // 2) if s2d else (self.in_h, self.in_w)
-        t = self.tensor(h, w, 12 if s2d else 3, cs=16 if s2d else 8)
+        t = self.tensor(h, w, c_pad if c_pad else 12 if s2d else 3, cs=c_pad if c_pad else 16 if s2d else 8)
         self._op(OP_INPUT, dst=t, kh=int(s2d), kw=int(swap_rb), f=[mean, scale])
         return t
 
@@ -518,6 +519,7 @@ def compile_ssd_mobilenet(wd, in_size=300):
 # ------------------------------------------------------------------------------------------- YOLOv5s
 YOLO_ANCHORS = [[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]]   # yolov5s.yaml:6-10
 YOLO_NC = 80
+FOCUS32 = os.environ.get('DD_YOLO_FOCUS32', '1') != '0'
 
 
 class _YoloNames:
@@ -597,8 +599,20 @@ def compile_yolov5s(wd, in_size=640):
         cv(name + '.cv2', src, dst=right)
         return cv(name + '.cv3', cat, dst=dst)
 
-    x = P.input(swap_rb=False, s2d=True)                                    # Focus slicing
-    x = cv('m0.focus', x, 3)
+    # Focus slicing.  The 12 sliced channels are written as a 32-channel tensor (20 zero channels, zero weight columns): the 3x3 conv
+    # behind it is then a 32 -> 32 layer for conv3x3_rw_k (whole filter in registers, input patch staged once, one tap = one
+    # MFMA k slice) instead of conv_glds_k gathering 32-byte pixels nine times (881 us per 128 frames at 1.3 TB/s, the slowest
+    # layer of the network; DD_YOLO_FOCUS32=0 keeps the 16-channel form).
+    if FOCUS32:
+        x = P.input(swap_rb=False, s2d=True, c_pad=32)
+        w, b = fold_conv_bn(wd, 'm0.focus')
+        w32 = np.zeros((3, 3, 32, w.shape[3]), dtype=w.dtype)
+        w32[:, :, :12] = w
+        x = P.conv(x, w32, b, pad=1, act=ACT_SILU)
+        P.info[-1]['flops'] = 2 * 320 * 320 * 9 * 12 * 32 * (in_size // 640) ** 2      # algorithmic: the zero channels do not count
+    else:
+        x = P.input(swap_rb=False, s2d=True)
+        x = cv('m0.focus', x, 3)
     x = cv('m1', x, 3, 2); x = c3('m2', x, 64, 1, True)
     x = cv('m3', x, 3, 2)
     s = P.T(x)
