@@ -195,7 +195,10 @@ __device__ __forceinline__ Epi8 epi8_load(const ConvP &P, int co) {
 // ACT >= 0: the activation is known at compile time (the per-element switch on P.act would otherwise be
 // compiled into a chain of branches around every value).
 // EF (epilogue flavour) 0: no residual, no second output; 1: both; -1: whatever P says.
-template <int ACT = -1, bool BIAS = true, int EF = -1, bool NT = true, bool TAIL = true>   // BIAS = false: the accumulators were initialised with the bias;
+#ifndef DD_EPI_NT
+#define DD_EPI_NT true
+#endif
+template <int ACT = -1, bool BIAS = true, int EF = -1, bool NT = DD_EPI_NT, bool TAIL = true>   // BIAS = false: the accumulators were initialised with the bias;
 __device__ __forceinline__ void conv_epilogue_f16x8(const ConvP &P, const Epi8 &E, int m, int co, float v[8], const h8 *res_pre = nullptr) {   // TAIL = false: cout % 8 == 0
     // res_pre: the residual vector of this (pixel, channel group), fetched by the caller before its first store -- a
     // load issued here cannot be moved above the stores of the caller's previous pixel (they may alias), so a loop of
@@ -2580,7 +2583,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_ws_k(const ConvP P, const int
 #pragma unroll
         for (int b = 0; b < MI; ++b) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
 #ifdef DD_KERNEL_DBG
-    const int dbg = P.p[5];                                      // measurement aid (DD_WS_MODE): 1 = no fills in the loop, 2 = no MFMAs
+    const int dbg = P.p[5];                                      // measurement aid (DD_WS_MODE), bits: 1 = no fills in the loop, 2 = no MFMAs, 4 = no epilogue, 8 = no fragment reads
 #else
     constexpr int dbg = 0;                                       // compiled out of the product build (-DDD_KERNEL_DBG brings it back)
 #endif
@@ -2628,21 +2631,21 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_ws_k(const ConvP P, const int
                 __builtin_amdgcn_s_barrier();                    // ... everybody's have
                 asm volatile("" ::: "memory");
 #endif
-                if (dbg != 1) {
+                if (!(dbg & 1)) {
 #pragma unroll
                     for (int q = 0; q < SPB; ++q) fill(st + D - SPB + q);   // into the buffers stages st - SPB .. st - 1 have left
                 }
             }
-            read_frags(st, 1, xb);                               // lands under the MFMAs of slice 0
-            if (dbg != 2) {
+            if (!(dbg & 8)) read_frags(st, 1, xb);               // lands under the MFMAs of slice 0
+            if (!(dbg & 2)) {
 #pragma unroll
                 for (int a = 0; a < NI; ++a)
 #pragma unroll
                     for (int b = 0; b < MI; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks * 2][a], xa[b], acc[a][b], 0, 0, 0);
             }
-            read_frags(st + 1, 0, xa);                           // next stage's slice 0, under the MFMAs of slice 1
-            if (dbg != 2) {
+            if (!(dbg & 8)) read_frags(st + 1, 0, xa);           // next stage's slice 0, under the MFMAs of slice 1
+            if (!(dbg & 2)) {
 #pragma unroll
                 for (int a = 0; a < NI; ++a)
 #pragma unroll
@@ -2656,7 +2659,12 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_ws_k(const ConvP P, const int
             float o[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) { o[r] = acc[0][b][r]; o[4 + r] = acc[1][b][r]; }
-            if (m < P.m) conv_epilogue_f16x8<ACT, true, 0>(P, E, m, cbase + fq * 8, o);
+            // Plain stores, not the streaming ones of the other GEMM epilogues: a wave writes 64-byte halves of a pixel's lines here, and
+            // the counted waits of the K loop count stores too -- a store that has to reach HBM holds the next stages' fills back.
+            // Ablation at 384 frames, 19x19x512 -> 512 (-DDD_KERNEL_DBG, DD_WS_MODE bits): all 98 us, no MFMAs 94, no fills 65, no
+            // epilogue 70, fills alone 44, loop skeleton 19: the matrix work is free, the layer is its memory path (146 MB read +
+            // 182 MB written at the fabric for 142 + 142); plain stores 100.5 -> 89.6 us (38x38x256: 122.9 -> 111.0), same bits.
+            if (m < P.m && !(dbg & 4)) conv_epilogue_f16x8<ACT, true, 0, false>(P, E, m, cbase + fq * 8, o);
             acc[0][b] = acc[1][b] = f4{0.f, 0.f, 0.f, 0.f};
         }
     }
@@ -2857,6 +2865,11 @@ __global__ __launch_bounds__(256, 2) void conv_ws_dw_k(const ConvP P, const DwP 
 #pragma unroll
         for (int b = 0; b < MI; ++b) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
 
+#ifdef DD_KERNEL_DBG
+    const int dbg = P.p[5];                                      // measurement aid (DD_WS_MODE), bits: 1 no fills in the loop, 2 no MFMAs, 4 no depthwise steps, 8 no ring writes
+#else
+    constexpr int dbg = 0;
+#endif
     const int rr = lane >> 3, pp = lane & 7;
     const int gch = (pp ^ rr) * 8;
     auto fill = [&](int st) {                                    // stage st of this block: tile st / KS, K slab st % KS
@@ -2949,20 +2962,24 @@ __global__ __launch_bounds__(256, 2) void conv_ws_dw_k(const ConvP P, const DwP 
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
 #endif
-            fill(st + D - 1);
+            if (!(dbg & 1)) fill(st + D - 1);
             read_frags(st, 1, xb);
+            if (!(dbg & 2)) {
 #pragma unroll
             for (int a = 0; a < NI; ++a)
 #pragma unroll
                 for (int b = 0; b < MI; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks * 2][a], xa[b], acc[a][b], 0, 0, 0);
+            }
             read_frags(st + 1, 0, xa);
+            if (!(dbg & 2)) {
 #pragma unroll
             for (int a = 0; a < NI; ++a)
 #pragma unroll
                 for (int b = 0; b < MI; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks * 2 + 1][a], xb[b], acc[a][b], 0, 0, 0);
-            if ((ks + 1) % (KS / 4) == 0) dw_step();             // the previous tile's depthwise pass, a quarter at a time
+            }
+            if ((ks + 1) % (KS / 4) == 0 && !(dbg & 4)) dw_step();             // the previous tile's depthwise pass, a quarter at a time
         }
         // pointwise epilogue into the ring (bias, activation, f16: conv_epilogue_f16x8's arithmetic)
 #pragma unroll
@@ -2974,8 +2991,8 @@ __global__ __launch_bounds__(256, 2) void conv_ws_dw_k(const ConvP P, const DwP 
                 yv[4 + r] = (_Float16)apply_act(acc[1][b][r] + pb1[r], ACT);
             }
             const int slot = (ti * BM + b * 16 + fr) & (WSD_RING - 1);
-            *reinterpret_cast<h8 *>(yring + (fq * WSD_SLOTS + slot) * 8) = yv;
-            if (slot < WSD_MIRROR) *reinterpret_cast<h8 *>(yring + (fq * WSD_SLOTS + slot + WSD_RING) * 8) = yv;
+            if (!(dbg & 8)) *reinterpret_cast<h8 *>(yring + (fq * WSD_SLOTS + slot) * 8) = yv;
+            if (slot < WSD_MIRROR && !(dbg & 8)) *reinterpret_cast<h8 *>(yring + (fq * WSD_SLOTS + slot + WSD_RING) * 8) = yv;
             acc[0][b] = acc[1][b] = f4{0.f, 0.f, 0.f, 0.f};
         }
         dw_begin(px0 + ti * BM - L);
@@ -3773,6 +3790,8 @@ int launch_conv_ws_dw(hipStream_t s, ConvP &P, const DwP &Q, int nimg, int devic
         return DD_OK;
     });
     if (rc != DD_OK) return rc;
+    static const int dbg_mode = getenv("DD_WS_MODE") ? atoi(getenv("DD_WS_MODE")) : 0;
+    P.p[5] = dbg_mode;
     hipLaunchKernelGGL((conv_ws_dw_k<KS, WMAP, ACT_RELU6, ACT_RELU6>), dim3(512), dim3(NW * 64), lds_bytes, s, P, Q, n_slices, nimg);
     DD_LAUNCH_CHECK();
     return DD_OK;
