@@ -330,6 +330,72 @@ __device__ __forceinline__ void conv_finish(const ConvP &P, f4 (&acc)[NI][MI], _
         }
         return;
     }
+    if (P.epi == EPI_YOLO && P.splitk == 1) {
+        // ---- decoded Detect rows: the (5 + C) floats of a (pixel, anchor) are contiguous, so stage the tile in LDS and let
+        // consecutive lanes take consecutive 4-column groups of a pixel (one 16-byte store per lane where the group stays
+        // inside one anchor's row; rows are only 4-byte aligned).  With a lane per (pixel, 4 channels) of the MFMA layout every
+        // value was its own 4-byte store, 16 pixels x 340 bytes apart per instruction: the 80x80 head ran at 1.6 TB/s.
+        // Same expressions per value as conv_epilogue.
+        constexpr int OROW = BN + 4;
+        float *ot = reinterpret_cast<float *>(lds);
+#pragma unroll
+        for (int b = 0; b < MI; ++b)
+#pragma unroll
+            for (int a = 0; a < NI; ++a)
+                *reinterpret_cast<f4 *>(ot + ((wm * MI + b) * 16 + fr) * OROW + (wn * NI + a) * 16 + fq * 4) = acc[a][b];
+        __syncthreads();
+        typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+        constexpr int LPP = BN / 4, PPW = 64 / LPP;
+        const int lc = (lane % LPP) * 4, lp = lane / LPP;
+        const int ch = n0 + lc;
+        const int nlive = min(4, max(0, P.cout - ch));
+        const int no = P.p[0];
+        f4 bias = f4{0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < nlive; ++q) bias[q] = P.bias[ch + q];
+        int an[4], oo[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { an[q] = (ch + q) / no; oo[q] = (ch + q) - an[q] * no; }
+        const bool one_row = nlive == 4 && an[0] == an[3];
+        // The four box columns of a row are 4 of 85: their arithmetic (a division each) sits behind one branch that two or three
+        // lanes of a wave take, as ONE expression with per-lane constants -- as an if / else chain per value every wave ran all four
+        // variants for all four values of every lane (the 80x80 head: 580 us, most of it this).
+        bool box_q[4]; float mulc[4], divc[4];
+        bool any_box = false;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            box_q[q] = oo[q] < 4;
+            any_box |= box_q[q];
+            mulc[q] = oo[q] < 2 ? P.f[6] : P.f[2 * an[q] + (oo[q] & 1)];
+            divc[q] = (oo[q] & 1) ? (float)P.p[4] : P.f[7];
+        }
+        for (int pl = wave * PPW + lp; pl < BM; pl += WM * WN * PPW) {
+            const int m = m0 + pl;
+            if (m >= P.m || nlive == 0) continue;
+            const int n = m / hw, p = m - n * hw;
+            const f4 v = *reinterpret_cast<const f4 *>(ot + pl * OROW + lc) + bias;
+            f4 val;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) val[q] = 1.f / (1.f + __expf(-v[q]));
+            if (any_box) {
+                const int py = p / P.wo, px = p - py * P.wo;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float sg = val[q];
+                    // o = 0, 1: (s * 2 - 0.5 + grid) * stride / size;  o = 2, 3: (s * 2) * (s * 2) * anchor / size
+                    const float num = oo[q] < 2 ? sg * 2.f - 0.5f + (float)((oo[q] & 1) ? py : px) : (sg * 2.f) * (sg * 2.f);
+                    const float r = num * mulc[q] / divc[q];
+                    if (box_q[q]) val[q] = r;
+                }
+            }
+            float *__restrict__ out = static_cast<float *>(P.out);
+            if (one_row) {
+                *reinterpret_cast<f4u *>(out + ((size_t)n * P.p[1] + P.p[2] + (size_t)an[0] * hw + p) * no + oo[0]) = val;
+            } else {
+                for (int q = 0; q < nlive; ++q) out[((size_t)n * P.p[1] + P.p[2] + (size_t)an[q] * hw + p) * no + oo[q]] = val[q];
+            }
+        }
+        return;
+    }
     // ---- lane holds channels co..co+3 of pixel m
 #pragma unroll
     for (int b = 0; b < MI; ++b) {
