@@ -157,6 +157,7 @@ def test_graph_replay_matches_eager():
             net.forward(x)
             np.testing.assert_array_equal(net.read()[:, 0, 0, :], w, err_msg=f'rep {rep}')
     xs[0].copy_(torch.from_numpy(rng.integers(0, 256, (21, 64, 32, 3), dtype=np.uint8)).cuda())    # same buffer, new contents
+    torch.cuda.synchronize()                               # the copy runs on torch's stream, the forward on the engine's own
     net.forward(xs[0]); got = net.read()[:, 0, 0, :].copy()
     net.use_graph(False)
     net.forward(xs[0])
@@ -282,6 +283,7 @@ def test_first_layer_does_not_depend_on_the_frame_pointer_alignment(kind):
     for off in (0, 1, 2):
         view = flat[off:off + x.size].view(x.shape)
         view.copy_(torch.from_numpy(x).cuda())
+        torch.cuda.synchronize()                           # torch's stream, not the engine's
         assert view.data_ptr() % 4 == off
         net.forward(view)
         outs.append(net.read().copy())
