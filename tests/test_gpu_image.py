@@ -100,7 +100,8 @@ def test_lanczos_batch_one_launch_vs_pillow(ctx):
     from deepdish_amd._lib import lib, check
     from deepdish_amd.runtime import ptr
     rng = np.random.default_rng(5)
-    for (H, W, h, w, n) in ((480, 640, 300, 300, 7), (480, 640, 320, 320, 2), (720, 1280, 300, 300, 2)):
+    for (H, W, h, w, n) in ((480, 640, 300, 300, 7), (480, 640, 320, 320, 2), (480, 640, 320, 512, 2),      # the third: one 64-byte window step
+                            (512, 512, 128, 200, 2), (720, 1280, 300, 300, 2)):
         frames = rng.integers(0, 256, (n, H, W, 3), dtype=np.uint8)
         frames[1] = 255
         if n > 3:
