@@ -85,6 +85,9 @@ SIGNATURES = {
     'dd_net_ssd_decode': [P, P, c_int, c_float, c_int],
     'dd_net_ssd_decoded': [P, POINTER(P), POINTER(P), POINTER(P), POINTER(P)],
     'dd_net_ssd_decoded_read': [P, c_int, P, P, P, P],
+    'dd_net_yolo_decode': [P, c_int],
+    'dd_net_yolo_decoded': [P, P, P, P, P],
+    'dd_net_yolo_decoded_read': [P, c_int, P, P, P],
     'dd_ssd_detections': [P, P, P, P, c_int, c_int, c_double, c_double, c_double, c_double, P, P, P, P, P],
     'dd_yolov5_decode': [P, P, c_int, c_int, c_float, c_float, c_float, P, P, P, c_int, P, P],
     'dd_pipeline_create': [P, c_int, c_int, c_int, P, P, c_int, c_int, P, c_char_p, c_char_p, c_double, c_double,

@@ -29,7 +29,7 @@ enum { OP_INPUT = 1, OP_CONV = 2, OP_DWCONV = 3, OP_MAXPOOL = 4, OP_UPSAMPLE = 5
 enum { ACT_NONE = 0, ACT_RELU6 = 1, ACT_ELU = 2, ACT_SILU = 3, ACT_RELU = 4, ACT_SIGMOID = 5 };
 enum { EPI_F16 = 0, EPI_F32 = 1, EPI_SSD_HEAD = 2, EPI_YOLO = 3 };
 // dd_net_op_launches: 0 = the op's own kernel, 1 = no launch (folded into the next op's), else the fused / special kernel
-enum { OPK_DEFAULT = 0, OPK_FOLDED = 1, OPK_POOL_ROWS = 2, OPK_POOL_ROWS_STEM = 3, OPK_RES_UNIT = 4, OPK_SSD_FRONT = 5, OPK_C64_ROWS = 6, OPK_S2_ROWS = 7, OPK_CONV_WS = 8, OPK_WS_DW = 9, OPK_DWPW_ROWS = 10, OPK_SSD_HEAD_DEC = 11, OPK_RES_PAIR = 12 };
+enum { OPK_DEFAULT = 0, OPK_FOLDED = 1, OPK_POOL_ROWS = 2, OPK_POOL_ROWS_STEM = 3, OPK_RES_UNIT = 4, OPK_SSD_FRONT = 5, OPK_C64_ROWS = 6, OPK_S2_ROWS = 7, OPK_CONV_WS = 8, OPK_WS_DW = 9, OPK_DWPW_ROWS = 10, OPK_SSD_HEAD_DEC = 11, OPK_RES_PAIR = 12, OPK_YOLO_HEAD_DEC = 13 };
 enum { DT_F16 = 0, DT_F32 = 1, DT_U8 = 2 };
 
 constexpr int OP_WORDS = 48;       // int32 words per op record (see deepdish_amd/nets.py)
@@ -477,6 +477,74 @@ __device__ __forceinline__ void ssd_head_finish(const ConvP &P, f4 (&acc)[NI][MI
     }
 }
 
+// YOLOv5 Detect head, one anchor per 96-channel tile (columns x, y, w, h, objectness, C classes, zeros): what tools/yolov5.py:120-128
+// makes of a decoded row -- cls *= obj, argmax, confidence -- in the epilogue, so the [rows][5 + C] f32 matrix (8.6 MB per frame,
+// written by the heads and read straight back by yolo_conf_k) never exists.  Per row: the box (conv_epilogue's expressions), the
+// confidence and the class, np.argmax's rules as yolo_conf_k restates them (first maximum; a NaN product is the answer, the first
+// one's index).  Two lanes per pixel scan 40 classes each.
+template <int WM, int WN, int MI, int NI>
+__device__ __forceinline__ void yolo_head_finish(const ConvP &P, f4 (&acc)[NI][MI], _Float16 *lds, int m0, int n0, int hw) {
+    constexpr int BM = WM * MI * 16, BN = WN * NI * 16, T = WM * WN * 64;
+    static_assert(BN == 96 && T == 2 * BM, "one anchor per channel tile, two lanes per pixel");
+    constexpr int OROW = BN + 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int fr = lane & 15, fq = lane >> 4;
+    float *ot = reinterpret_cast<float *>(lds);
+#pragma unroll
+    for (int b = 0; b < MI; ++b)
+#pragma unroll
+        for (int a = 0; a < NI; ++a)
+            *reinterpret_cast<f4 *>(ot + ((wm * MI + b) * 16 + fr) * OROW + (wn * NI + a) * 16 + fq * 4) = acc[a][b];
+    __syncthreads();
+    const int pl = tid >> 1, h = tid & 1;
+    const int m = m0 + pl;
+    const int no = P.p[0], C = no - 5;
+    const float *row = ot + pl * OROW;
+    const float *bias = P.bias + n0;
+    const float sobj = 1.f / (1.f + __expf(-(row[4] + bias[4])));
+    float best = -__builtin_inff();
+    int bi = 0x7fffffff, nan_i = 0x7fffffff;
+    const int half = (C + 1) >> 1;                              // lane h scans classes [h * half, min(C, h * half + half)), ascending
+    const int c_lo = h * half, c_hi = min(C, c_lo + half);
+    for (int c4 = (5 + c_lo) & ~3; c4 < 5 + c_hi; c4 += 4) {
+        const f4 v = *reinterpret_cast<const f4 *>(row + c4) + *reinterpret_cast<const f4 *>(bias + c4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ci = c4 + q - 5;
+            if (ci < c_lo || ci >= c_hi) continue;
+            const float pq = (1.f / (1.f + __expf(-v[q]))) * sobj;
+            if (pq != pq) nan_i = min(nan_i, ci);
+            if (pq > best) { best = pq; bi = ci; }
+        }
+    }
+    {
+        const float ob = __shfl_xor(best, 1, 64);
+        const int oi = __shfl_xor(bi, 1, 64), on = __shfl_xor(nan_i, 1, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        nan_i = min(nan_i, on);
+    }
+    if (h == 0 && m < P.m) {
+        const int n = m / hw, p = m - n * hw;
+        const int py = p / P.wo, px = p - py * P.wo;
+        const int an = n0 / BN;
+        const size_t r = (size_t)n * P.p[1] + P.p[2] + (size_t)an * hw + p;
+        const f4 rv = *reinterpret_cast<const f4 *>(row) + *reinterpret_cast<const f4 *>(bias);
+        float sg[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sg[q] = 1.f / (1.f + __expf(-rv[q]));
+        f4 bx;
+        bx[0] = (sg[0] * 2.f - 0.5f + (float)px) * P.f[6] / P.f[7];
+        bx[1] = (sg[1] * 2.f - 0.5f + (float)py) * P.f[6] / (float)P.p[4];
+        bx[2] = (sg[2] * 2.f) * (sg[2] * 2.f) * P.f[2 * an] / P.f[7];
+        bx[3] = (sg[3] * 2.f) * (sg[3] * 2.f) * P.f[2 * an + 1] / (float)P.p[4];
+        *reinterpret_cast<f4 *>(P.dec_boxes + r * 4) = bx;
+        const bool has_nan = nan_i != 0x7fffffff;
+        P.dec_score[r] = has_nan ? __builtin_nanf("") : best;
+        P.dec_cls[r] = has_nan ? nan_i : bi;
+    }
+}
+
 // Epilogue without the LDS transposition: used when the weight rows of the tile were staged in the
 // fragment order of rw_weight_row (conv_glds_k does that for plain f16 outputs), so the lane that owns
 // rows fq*4.. of fragments 2g and 2g+1 holds 8 consecutive output channels of its pixel.
@@ -657,7 +725,7 @@ __device__ __forceinline__ void lds_fill16(const _Float16 *g, _Float16 *lds_wave
 // for every lane, so the tap walk is scalar and a lane does one add and a two-bit test per row group; 0: anything
 // else.  (The general per-lane walk costs more issue slots per K step than the MFMAs: 19x19x512 -> 512 went
 // 24.9 -> 21.8 us with FM 1, the MARS 16x8x64 -> 64 layers 28.8 -> 24.5 us with FM 2.)
-template <int WM, int WN, int MI, int NI, int FM = 0, bool DEC = false>       // DEC: SSD head, one anchor per 96-channel tile, decode in the epilogue
+template <int WM, int WN, int MI, int NI, int FM = 0, int DEC = 0>       // DEC: one anchor per 96-channel tile, decode in the epilogue (1 SSD head, 2 YOLOv5 Detect)
 __global__ __launch_bounds__(WM *WN * 64, 2) void conv_glds_k(const ConvP P) {
     constexpr int NW = WM * WN;
     constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
@@ -804,8 +872,10 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_glds_k(const ConvP P) {
             __syncthreads();
         }
     }
-    if constexpr (DEC) {
+    if constexpr (DEC == 1) {
         ssd_head_finish<WM, WN, MI, NI>(P, acc, lds, m0, n0, hw);
+    } else if constexpr (DEC == 2) {
+        yolo_head_finish<WM, WN, MI, NI>(P, acc, lds, m0, n0, hw);
     } else if constexpr (MI * NI >= 12) {
         // 48 x 64 per wave and up: only the untransposed epilogue is compiled in (the launcher sends nothing else
         // here); with the general one the accumulator array stops being promoted to registers and every K step
@@ -3320,7 +3390,7 @@ struct dd_net {
     int last_batch = 0;
     DevBuf slab;                             // split-K partial sums (sized for max_batch: see launch_conv)
     // dd_net_ssd_decode: the SSD head ops decode in their epilogue into these per-anchor arrays ([max_batch][n_anchors] each)
-    bool ssd_dec = false;
+    bool ssd_dec = false, yolo_dec = false;                      // dd_net_yolo_decode: the Detect heads reduce their rows to (box, confidence, class); dec_anchors = rows per image
     int dec_anchors = 0; float dec_thr = 0.f;
     float *d_anchors = nullptr, *dec_boxes = nullptr, *dec_score = nullptr, *dec_keys = nullptr; int *dec_cls = nullptr;
     bool slab_moved = false;                 // the slab was reallocated during the last eager forward: captured graphs hold a dead pointer
@@ -3443,7 +3513,19 @@ int launch_ssd_head_dec(hipStream_t s, ConvP &P) {
     constexpr size_t lds_bytes = (size_t)2 * (BM + BN) * 64 * sizeof(_Float16);
     static_assert(lds_bytes >= (size_t)BM * (BN + 4) * sizeof(float) && lds_bytes <= 65536, "staged tile fits the operand buffers");
     const int gx = dd_ceil_div(P.m, BM), gy = P.p[5];           // channel tiles = anchors per pixel
-    hipLaunchKernelGGL((conv_glds_k<WM, WN, MI, NI, 1, true>), dim3(gx, gy, 1), dim3(WM * WN * 64), lds_bytes, s, P);
+    hipLaunchKernelGGL((conv_glds_k<WM, WN, MI, NI, 1, 1>), dim3(gx, gy, 1), dim3(WM * WN * 64), lds_bytes, s, P);
+    DD_LAUNCH_CHECK();
+    return DD_OK;
+}
+
+int launch_yolo_head_dec(hipStream_t s, ConvP &P) {
+    constexpr int WM = 2, WN = 2, MI = 4, NI = 3, BM = WM * MI * 16, BN = WN * NI * 16;
+    DD_REQUIRE(P.kh == 1 && P.kw == 1 && P.stride == 1 && P.pad_t == 0 && P.pad_l == 0 && P.cin % 64 == 0 && P.kpad == P.cin &&
+               P.ho == P.H && P.wo == P.W && P.p[0] >= 6 && P.p[0] <= BN && P.cout % P.p[0] == 0, DD_E_ARG, "yolo head decode: layer shape");
+    P.splitk = 1; P.slab = nullptr;
+    constexpr size_t lds_bytes = (size_t)2 * (BM + BN) * 64 * sizeof(_Float16);
+    const int gx = dd_ceil_div(P.m, BM), gy = P.cout / P.p[0];    // channel tiles = anchors per pixel
+    hipLaunchKernelGGL((conv_glds_k<WM, WN, MI, NI, 1, 2>), dim3(gx, gy, 1), dim3(WM * WN * 64), lds_bytes, s, P);
     DD_LAUNCH_CHECK();
     return DD_OK;
 }
@@ -4042,6 +4124,9 @@ int dd_net_read(dd_net *n, int tensor, int n_img, void *dst, int dst_on_device, 
         DD_REQUIRE(!(o[2] == t && n->op_launch[i] == OPK_SSD_HEAD_DEC), DD_E_STATE,
                    "dd_net_read: tensor %d (the SSD head matrix) was not written: the head layers decoded in their epilogue "
                    "(dd_net_ssd_decode); read dd_net_ssd_decoded instead", t);
+        DD_REQUIRE(!(o[2] == t && n->op_launch[i] == OPK_YOLO_HEAD_DEC), DD_E_STATE,
+                   "dd_net_read: tensor %d (the Detect matrix) was not written: the head layers reduced their rows in their epilogue "
+                   "(dd_net_yolo_decode); read dd_net_yolo_decoded instead", t);
         DD_REQUIRE(!((o[2] == t || o[4] == t) && n->op_launch[i] == OPK_FOLDED), DD_E_STATE,
                    "dd_net_read: tensor %d was not written by the last forward (op %d ran inside the next op's launch at this batch "
                    "size and its output stayed on chip); run a smaller batch or a program compiled without the fusion flags", t, i);
@@ -4098,6 +4183,62 @@ int dd_net_ssd_decode(dd_net *net, const float *anchors_host, int n_anchors, flo
     net->ssd_dec = true;
     return DD_OK;
 }
+
+// YOLOv5 detector: tools/yolov5.py:120-128 (cls *= obj, argmax, confidence) inside the Detect layers' epilogues: per row the
+// decoded box (x, y, w, h normalised), the confidence and the class instead of the [rows][5 + C] matrix.
+int dd_net_yolo_decode(dd_net *net, int enable) {
+    DD_REQUIRE(net, DD_E_ARG, "dd_net_yolo_decode: NULL net");
+    DD_DEVICE(net->ctx);
+    net_drop_graphs(net);
+    if (!enable) { net->yolo_dec = false; return DD_OK; }
+    DD_REQUIRE(!net->ssd_dec, DD_E_STATE, "dd_net_yolo_decode: the SSD decode is on for this network");
+    int heads = 0, rows = 0;
+    for (int i = 0; i < net->n_ops; ++i) {
+        const int32_t *o = net->prog.data() + net->ops_off + (size_t)i * OP_WORDS;
+        if (o[0] == OP_CONV && o[15] == EPI_YOLO) {
+            DD_REQUIRE(o[18] && !o[19] && o[20] >= 6 && o[20] <= 96, DD_E_ARG,
+                       "dd_net_yolo_decode: head op %d has no per-anchor weight copy, or %d columns per row do not fit", i, o[20]);
+            DD_REQUIRE(rows == 0 || rows == o[21], DD_E_ARG, "dd_net_yolo_decode: heads disagree on the rows per image");
+            rows = o[21];
+            ++heads;
+        }
+    }
+    DD_REQUIRE(heads > 0 && rows > 0, DD_E_ARG, "dd_net_yolo_decode: the program has no YOLOv5 Detect head");
+    if (net->dec_anchors != rows || !net->dec_boxes) {
+        for (void *q : {(void *)net->d_anchors, (void *)net->dec_boxes, (void *)net->dec_score, (void *)net->dec_keys, (void *)net->dec_cls}) (void)hipFree(q);
+        net->d_anchors = net->dec_boxes = net->dec_score = net->dec_keys = nullptr; net->dec_cls = nullptr; net->dec_anchors = 0;
+        const size_t per = (size_t)net->max_batch * rows;
+        DD_HIP(hipMalloc(&net->dec_boxes, per * 4 * sizeof(float)));
+        DD_HIP(hipMalloc(&net->dec_score, per * sizeof(float)));
+        DD_HIP(hipMalloc(&net->dec_cls, per * sizeof(int)));
+        net->dec_anchors = rows;
+    }
+    net->yolo_dec = true;
+    return DD_OK;
+}
+
+// Device pointers to what the last forward's Detect heads wrote: boxes f32 [n][rows][4] (x, y, w, h as the matrix's first four
+// columns), conf f32 [n][rows], classes int32 [n][rows] -- what yolo_conf_k makes of the matrix.
+int dd_net_yolo_decoded(dd_net *net, float **boxes, float **conf, int **classes, int *rows) {
+    DD_REQUIRE(net && net->yolo_dec, DD_E_STATE, "dd_net_yolo_decoded: dd_net_yolo_decode is off");
+    if (boxes) *boxes = net->dec_boxes;
+    if (conf) *conf = net->dec_score;
+    if (classes) *classes = net->dec_cls;
+    if (rows) *rows = net->dec_anchors;
+    return DD_OK;
+}
+
+int dd_net_yolo_decoded_read(dd_net *net, int n, float *boxes_host, float *conf_host, int *classes_host) {
+    DD_REQUIRE(net && net->yolo_dec && n >= 0 && n <= net->max_batch, DD_E_STATE, "dd_net_yolo_decoded_read: decode is off or n out of range");
+    DD_DEVICE(net->ctx);
+    DD_HIP(hipStreamSynchronize(net->ctx->stream));
+    const size_t per = (size_t)n * net->dec_anchors;
+    if (boxes_host) DD_HIP(hipMemcpy(boxes_host, net->dec_boxes, per * 4 * sizeof(float), hipMemcpyDeviceToHost));
+    if (conf_host) DD_HIP(hipMemcpy(conf_host, net->dec_score, per * sizeof(float), hipMemcpyDeviceToHost));
+    if (classes_host) DD_HIP(hipMemcpy(classes_host, net->dec_cls, per * sizeof(int), hipMemcpyDeviceToHost));
+    return DD_OK;
+}
+
 
 // Device arrays the last forward decoded into: boxes f32 [n][n_anchors][4] (ymin, xmin, ymax, xmax), scores f32, classes
 // int32 (class id - 1), keys f32 (score, or -1 below the threshold) [n][n_anchors] -- what ssd_decode_k makes of the head matrix.
@@ -4276,6 +4417,17 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
                                         P.pad_t == 1 && P.pad_l == 1 && o[30] && !o[29] && i + 1 < net->n_ops && nimg >= 160 && !P.res && !P.out2 &&
                                         P.in == static_cast<const _Float16 *>(pair_b.out2);
                     if (!next_a && (rc = flush_pair()) != DD_OK) return rc;
+                }
+                if (P.epi == EPI_YOLO && net->yolo_dec && o[18] && !o[19]) {      // o[18] / o[31]: the per-anchor copy of weights / bias
+                    DD_REQUIRE(P.p[1] == net->dec_anchors, DD_E_ARG, "dd_net_forward: head of %d rows, decode set up for %d", P.p[1], net->dec_anchors);
+                    P.w = reinterpret_cast<const _Float16 *>(net->d_weights + (size_t)(uint32_t)o[18]);
+                    P.bias = reinterpret_cast<const float *>(net->d_weights + (size_t)(uint32_t)o[31]);
+                    P.zero = net->d_zero;
+                    P.dec_boxes = net->dec_boxes; P.dec_score = net->dec_score; P.dec_cls = net->dec_cls;
+                    rc = launch_yolo_head_dec(s, P);
+                    if (rc != DD_OK) return rc;
+                    net->op_launch[i] = OPK_YOLO_HEAD_DEC;
+                    break;
                 }
                 if (P.epi == EPI_SSD_HEAD && net->ssd_dec && o[18] && !o[19]) {   // o[18] / o[31]: the per-anchor copy of weights / bias
                     DD_REQUIRE(P.p[1] == net->dec_anchors, DD_E_ARG, "dd_net_forward: head of %d anchors, decode set up for %d", P.p[1], net->dec_anchors);

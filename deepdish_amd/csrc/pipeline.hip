@@ -22,6 +22,8 @@ int mog2_apply(dd_mog2 *m, hipStream_t s, const uint8_t *frames, double learning
 int mask_box_count(hipStream_t s, const uint8_t *mask, int H, int W, const int *d_boxes, const int *d_box_stream, int K, int *d_counts);
 int yolov5_decode(hipStream_t s, const float *raw, int n_rows, int n_cls, float thr, float img_w, float img_h, float *out_boxes,
                   float *out_scores, int *out_cls, int cap, int *out_n, int batch, void *scratch);
+int yolov5_select(hipStream_t s, const float *boxes4, const float *conf, const int *cls, int n_rows, float thr, float img_w, float img_h,
+                  float *out_boxes, float *out_scores, int *out_cls, int cap, int *out_n, int batch);
 size_t ssd_post_decoded_scratch_bytes(int n_anchors, int batch);
 int ssd_postprocess_decoded(hipStream_t s, const float *d_boxes, const float *d_score, const int *d_cls, const float *d_keys,
                             int n_anchors, int max_det, float score_thr, float iou_thr, float *boxes, float *classes, float *scores,
@@ -41,6 +43,8 @@ int tracker_read_host(dd_tracker *t, int which, int64_t *ints6_host, double *mea
 extern "C" int dd_net_max_batch(dd_net *net, int *out_host);
 extern "C" int dd_net_ssd_decode(dd_net *net, const float *anchors_host, int n_anchors, float score_thr, int enable);
 extern "C" int dd_net_ssd_decoded(dd_net *net, float **boxes, float **scores, int **classes, float **keys);
+extern "C" int dd_net_yolo_decode(dd_net *net, int enable);
+extern "C" int dd_net_yolo_decoded(dd_net *net, float **boxes, float **conf, int **classes, int *rows);
 extern "C" int dd_net_input_size(dd_net *net, int *h_host, int *w_host);
 
 namespace {
@@ -120,6 +124,7 @@ struct dd_pipeline {
     std::vector<std::string> tfl_labels;       // its label list: the label file's lines after the first, empty lines dropped (tflite.py:22, tflite_object_detector.py)
     bool det_late = true;                      // where the look-ahead detector run is queued (dd_pipeline_step2)
     bool ssd_dec = false;                      // SSD: the head layers decode in their epilogue (dd_net_ssd_decode)
+    bool yolo_dec = false;                     // YOLOv5: the Detect layers reduce their rows in their epilogue (dd_net_yolo_decode)
     size_t yolo_host_rows = 0;                 // YOLOv5: packed rows the first copy of a step brings to the host
     std::vector<size_t> ybase;
     PinBuf h_fin, h_nms, h_crop;
@@ -247,6 +252,12 @@ int dd_pipeline_create(dd_ctx *ctx, int n_streams, int frame_h, int frame_w, dd_
             if ((rc = p->h_fin.reserve(S * (MAX_DET * (4 * 8 + 4 + 8) + 4) + 256)) != DD_OK) return rc;
         } else {
             if ((rc = p->d_post.reserve(S * n_anchors * 8 + 256)) != DD_OK) return rc;              // per-row confidence + class
+            // yolov5.py:126-128 (cls *= obj, argmax, confidence) runs in the Detect layers' epilogues when the program carries their
+            // per-anchor weight copy: the [rows][85] matrix is never written (DD_YOLO_DEC=0: the separate yolo_conf_k pass, same bits)
+            if (p->det_kind == DET_YOLOV5) {
+                const char *e = getenv("DD_YOLO_DEC");
+                p->yolo_dec = !(e && atoi(e) == 0) && dd_net_yolo_decode(detector, 1) == DD_OK;
+            }
             // every row of the head may pass the threshold: yolov5.py:120-145 has no limit, so neither has this (device: per image
             // n_anchors rows of boxes f32x4, score, class + a count; then the same rows packed over the images)
             const size_t fin = S * ((size_t)n_anchors * 24 + 4) + 256;
@@ -387,6 +398,12 @@ int enqueue_detector(dd_pipeline *p, const uint8_t *frames) {
         const size_t cap = (size_t)p->n_anchors;
         float *yb = p->d_fin.as<float>(), *ys = yb + S * cap * 4;
         int *yc = reinterpret_cast<int *>(ys + S * cap), *yn = yc + S * cap;
+        if (p->yolo_dec) {                                       // :126-128 ran in the Detect layers' epilogues
+            float *b4 = nullptr, *cf = nullptr; int *cl = nullptr;
+            if ((rc = dd_net_yolo_decoded(p->det, &b4, &cf, &cl, nullptr)) != DD_OK) return rc;
+            if ((rc = ddk::yolov5_select(s, b4, cf, cl, p->n_anchors, (float)p->det_conf, (float)p->W, (float)p->H, yb, ys, yc,
+                                         p->n_anchors, yn, S)) != DD_OK) return rc;
+        } else
         if ((rc = ddk::yolov5_decode(s, static_cast<const float *>(raw), p->n_anchors, p->n_classes, (float)p->det_conf, (float)p->W,
                                      (float)p->H, yb, ys, yc, p->n_anchors, yn, S, p->d_post.p)) != DD_OK) return rc;
         // the passing rows of all streams packed behind one another; the host block is [S counts | pad to 64 B | rows x 24 B]: the

@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void yolo_conf_k(const float *__restrict__ raw
 
 // second half: ordered compaction of rows with conf >= thr (ascending row order, like np.where)
 __global__ __launch_bounds__(1024) void yolo_compact_k(const float *__restrict__ raw, const float *__restrict__ conf,
-                                                       const int *__restrict__ cls, int n_rows, int n_cls, float thr,
+                                                       const int *__restrict__ cls, int n_rows, int row_floats, float thr,
                                                        float img_w, float img_h, float *__restrict__ out_boxes,
                                                        float *__restrict__ out_scores, int *__restrict__ out_cls,
                                                        int cap, int *__restrict__ out_n) {
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(1024) void yolo_compact_k(const float *__restrict__
     __shared__ int base;
     {   // blockIdx.x = image of a batch: rows, per-row confidences and outputs of that image
         const size_t z = blockIdx.x;
-        raw += z * n_rows * (5 + n_cls); conf += z * n_rows; cls += z * n_rows;
+        raw += z * n_rows * row_floats; conf += z * n_rows; cls += z * n_rows;      // row_floats: 5 + classes (the matrix) or 4 (boxes only)
         out_boxes += z * cap * 4; out_scores += z * cap; out_cls += z * cap; out_n += z;
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(1024) void yolo_compact_k(const float *__restrict__
         for (int w = 0; w < wave; ++w) off += wave_cnt[w];
         const int pos = off + __popcll(b & ((1ull << lane) - 1ull));
         if (ok && pos < cap) {
-            const float *x = raw + (size_t)r * (5 + n_cls);
+            const float *x = raw + (size_t)r * row_floats;
             const float x1 = x[0] - x[2] / 2, y1 = x[1] - x[3] / 2, x2 = x[0] + x[2] / 2, y2 = x[1] + x[3] / 2;
             out_boxes[pos * 4 + 0] = (float)((double)x1 * (double)img_w);
             out_boxes[pos * 4 + 1] = (float)((double)y1 * (double)img_h);
@@ -369,7 +369,17 @@ int yolov5_decode(hipStream_t s, const float *raw, int n_rows, int n_cls, float 
     DD_REQUIRE(total < (1LL << 31), DD_E_CAPACITY, "yolov5_decode: %lld rows exceed 32-bit indexing", total);
     hipLaunchKernelGGL(yolo_conf_k, dim3((unsigned)std::min<long long>((total + 7) / 8, 256 * 32)), dim3(256), 0, s, raw, (int)total, n_cls, conf, cls);
     DD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(yolo_compact_k, dim3(batch), dim3(1024), 0, s, raw, conf, cls, n_rows, n_cls, thr, img_w, img_h, out_boxes,
+    hipLaunchKernelGGL(yolo_compact_k, dim3(batch), dim3(1024), 0, s, raw, conf, cls, n_rows, 5 + n_cls, thr, img_w, img_h, out_boxes,
+                       out_scores, out_cls, cap, out_n);
+    DD_LAUNCH_CHECK();
+    return DD_OK;
+}
+
+// The second half alone, on what the Detect heads wrote when they reduced their rows themselves (dd_net_yolo_decode): boxes f32
+// [batch][n_rows][4] (x, y, w, h), conf, cls [batch][n_rows].
+int yolov5_select(hipStream_t s, const float *boxes4, const float *conf, const int *cls, int n_rows, float thr, float img_w, float img_h,
+                  float *out_boxes, float *out_scores, int *out_cls, int cap, int *out_n, int batch) {
+    hipLaunchKernelGGL(yolo_compact_k, dim3(batch), dim3(1024), 0, s, boxes4, conf, cls, n_rows, 4, thr, img_w, img_h, out_boxes,
                        out_scores, out_cls, cap, out_n);
     DD_LAUNCH_CHECK();
     return DD_OK;

@@ -52,6 +52,20 @@ class Net:
         check(lib().dd_net_ssd_decoded_read(self._h, n, *[ptr(o) for o in out]), 'dd_net_ssd_decoded_read')
         return out
 
+    def yolo_decode(self, enable=True):
+        """YOLOv5 Detect heads reduce their rows to (box, confidence, class) in their epilogue (dd_net_yolo_decode): `read()` of the
+        head matrix then raises; `yolo_decoded()` returns what tools/yolov5.py:121-128 computes from it."""
+        check(lib().dd_net_yolo_decode(self._h, int(bool(enable))), 'dd_net_yolo_decode')
+        self._yolo_rows = int(self.program.meta['rows']) if enable else 0
+
+    def yolo_decoded(self, n=None):
+        """(boxes [n, R, 4] f32 xywh, conf [n, R] f32, classes [n, R] i32) of the last forward, on the host."""
+        n = self._last_n if n is None else n
+        R = self._yolo_rows
+        out = (np.zeros((n, R, 4), np.float32), np.zeros((n, R), np.float32), np.zeros((n, R), np.int32))
+        check(lib().dd_net_yolo_decoded_read(self._h, n, *[ptr(o) for o in out]), 'dd_net_yolo_decoded_read')
+        return out
+
     def forward(self, images, stream=None):
         """images: u8 [n, in_h, in_w, 3] torch cuda tensor (or numpy, uploaded).  Enqueues only."""
         if isinstance(images, np.ndarray):

@@ -188,6 +188,18 @@ class Program:
                 b96[an * 96:an * 96 + per] = bp[an * per:(an + 1) * per]
             kw_['aff_off'] = self.add_blob(w96)
             kw_['aux_off'] = self.add_blob(b96)
+        if epi == EPI_YOLO and (kh, kw, stride) == (1, 1, 1) and cin_pad % 64 == 0 and p[0] <= 96 and cout % p[0] == 0:
+            # second copy of the Detect weights, one anchor per 96 rows (x, y, w, h, objectness, C classes, zero rows): the layout of the
+            # kernel that reduces a row to (box, confidence, class) in its epilogue (csrc/nets.hip yolo_head_finish; dd_net_yolo_decode)
+            per, a_n = p[0], cout // p[0]
+            assert kpad == cin_pad
+            w96 = np.zeros((a_n * 96, kpad), dtype=np.float16)
+            b96 = np.zeros(a_n * 96, dtype=np.float32)
+            for an in range(a_n):
+                w96[an * 96:an * 96 + per] = wflat[an * per:(an + 1) * per]
+                b96[an * 96:an * 96 + per] = bp[an * per:(an + 1) * per]
+            kw_['aff_off'] = self.add_blob(w96)
+            kw_['aux_off'] = self.add_blob(b96)
         self._op(OP_CONV, src=src, dst=dst, res=res, dst2=dst2, **kw_)
         tile = '4,1,1,2' if cout_pad <= 32 else '2,2,2,2'
         rw = (kh, kw, stride, cin_pad, cout_pad, epi, pt, pl) == (3, 3, 1, 32, 32, EPI_F16, 1, 1)

@@ -28,7 +28,7 @@ def net_op_times(net):
 
 # dd_net_op_launches codes (include/deepdish_hip.h)
 OPK_FOLDED = 1
-OPK_NAMES = {2: 'conv3x3_pool_rows_k', 3: 'conv3x3_pool_rows_k<STEM>', 4: 'res_unit_rows_k', 5: 'ssd_front_k', 6: 'conv3x3_c64_rows_k', 7: 'conv3x3_s2_rows_k', 8: 'conv_ws_k', 9: 'conv_ws_dw_k', 10: 'dwpw_rows_k', 11: 'conv_glds_k<ssd_head_decode>', 12: 'res_pair_rows_k'}
+OPK_NAMES = {2: 'conv3x3_pool_rows_k', 3: 'conv3x3_pool_rows_k<STEM>', 4: 'res_unit_rows_k', 5: 'ssd_front_k', 6: 'conv3x3_c64_rows_k', 7: 'conv3x3_s2_rows_k', 8: 'conv_ws_k', 9: 'conv_ws_dw_k', 10: 'dwpw_rows_k', 11: 'conv_glds_k<ssd_head_decode>', 12: 'res_pair_rows_k', 13: 'conv_glds_k<yolo_head_decode>'}
 
 
 def net_op_launches(net):

@@ -285,6 +285,17 @@ int dd_net_ssd_decoded(dd_net *net, float **boxes_dev, float **scores_dev, int *
 /* the same arrays of the first n images of the last forward copied to host memory (any pointer may be NULL) */
 int dd_net_ssd_decoded_read(dd_net *net, int n, float *boxes_host, float *scores_host, int *classes_host, float *keys_host);
 
+/* YOLOv5 detector: tools/yolov5.py:126-128 (cls *= obj, np.argmax, confidence) inside the Detect layers' epilogues -- per row of the
+ * head the decoded box (x, y, w, h: the matrix's first four columns), the confidence and the class; the f32 [rows][5 + C] matrix
+ * (yolov5.py:109 `pred`) is then never written and dd_net_read of it is an error.  Needs a program compiled with the per-anchor
+ * copy of the Detect weights (deepdish_amd.nets.compile_yolov5s emits it).  enable = 0 switches back. */
+int dd_net_yolo_decode(dd_net *net, int enable);
+/* Device pointers to what the last forward's heads wrote: boxes f32 [n][rows][4], conf f32 [n][rows], classes i32 [n][rows]
+ * (a NaN product makes conf NaN and the class the first NaN's index, as np.argmax does); rows = rows per image. */
+int dd_net_yolo_decoded(dd_net *net, float **boxes, float **conf, int **classes, int *rows);
+/* The same, copied to the host for the first n images (any pointer may be NULL). */
+int dd_net_yolo_decoded_read(dd_net *net, int n, float *boxes_host, float *conf_host, int *classes_host);
+
 /* tools/ssd_mobilenet.py:111-150, SSDMobileNet.predict after its four get_tensor calls, for `batch` images at once:
  * NaN scrub (:111-116), score >= confidence (:119), reorder [1,0,3,2] and scale by (w,h,w,h) in f64 (:121-127),
  * per-class nms_boxes (:59-98, see dd_nms_ssd).  Inputs are the outputs of dd_ssd_postprocess (device):

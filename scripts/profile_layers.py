@@ -20,6 +20,8 @@ else:
 net = Net(prog, max_batch=batch)
 if kind == 'ssd' and os.environ.get('DD_SSD_DEC', '1') != '0':      # as the pipeline runs it: the heads decode in their epilogue
     net.ssd_decode(prog.meta['anchors'], 1e-8)
+if kind not in ('ssd', 'mars') and os.environ.get('DD_YOLO_DEC', '1') != '0':      # as the pipeline runs it: the Detect heads reduce their rows
+    net.yolo_decode(True)
 x = torch.randint(0, 256, (batch,) + shape + (3,), dtype=torch.uint8, device='cuda')
 check(lib().dd_net_profile(net._h, 1))
 acc = np.zeros(len(prog.ops))

@@ -188,3 +188,38 @@ def test_ssd_head_layers_decode_in_their_epilogue_with_the_same_bits(n, thr):
     fused.ssd_decode(anchors, thr, enable=False)
     fused.forward(x)
     np.testing.assert_array_equal(fused.read(), plain.read())
+
+
+@pytest.mark.parametrize('n', [2, 5])
+def test_yolo_heads_reduce_rows_in_their_epilogue(n):
+    """dd_net_yolo_decode: the Detect layers write (box, confidence, class) per row instead of the [rows][85] matrix.  Against the
+    matrix of the same forward with the switch off: boxes are its first four columns bit for bit, confidence and class what
+    tools/yolov5.py:126-128 computes from it (numpy, f32) -- incl. rows whose class products tie, and a NaN row."""
+    import torch
+    from deepdish_amd import nets
+    from deepdish_amd.engine import Net
+    wd = nets.synthetic_yolov5s_weights()
+    prog = nets.compile_yolov5s(wd)
+    net = Net(prog, max_batch=n)
+    rng = np.random.default_rng(3)
+    x = rng.integers(0, 256, (n, 640, 640, 3), dtype=np.uint8)
+    x[1] = 128                                                  # a flat frame: many equal rows
+    xd = torch.from_numpy(x).cuda()
+    torch.cuda.synchronize()
+    net.forward(xd)
+    raw = net.read()[:, :, 0, :] if net.read().ndim == 4 else net.read()
+    raw = np.asarray(raw, dtype=np.float32).reshape(n, -1, 85)
+    net.yolo_decode(True)
+    net.forward(xd)
+    boxes, conf, cls = net.yolo_decoded()
+    with pytest.raises(Exception):
+        net.read()
+    np.testing.assert_array_equal(boxes, raw[:, :, :4])
+    prod = raw[:, :, 5:] * raw[:, :, 4:5]                       # x[..., 5:] *= x[..., 4:5]
+    want_cls = np.argmax(prod, axis=-1)
+    want_conf = np.take_along_axis(prod, want_cls[..., None], axis=-1)[..., 0]
+    np.testing.assert_array_equal(cls, want_cls.astype(np.int32))
+    np.testing.assert_array_equal(conf, want_conf)
+    net.yolo_decode(False)
+    net.forward(xd)
+    np.testing.assert_array_equal(np.asarray(net.read(), dtype=np.float32).reshape(n, -1, 85), raw)
