@@ -907,8 +907,11 @@ constexpr int RW_FILL = 11;                                    // 16 patch pixel
 constexpr int RW_MAX_PATCH = RW_FILL * 64;
 constexpr int RW_MB = 4;                                       // pixel fragments in flight per wave
 
-template <int NCO, int TW, int ACT, bool POOL, int EF = -1>     // TW: tile width when known at compile time (tap offsets
+template <int NCO, int TW, int ACT, bool POOL, int EF = -1, bool S2D8 = false>     // TW: tile width when known at compile time (tap offsets
 __global__ __launch_bounds__(256, 2) void conv3x3_rw_k(const ConvP P, const int total_tiles) {   // become ds_read immediates), else 0
+    // S2D8: the input is the u8 frame [2 H][2 W][3] behind a space-to-depth-2 input op (YOLOv5's Focus) that was folded into this launch:
+    // the patch fill slices, normalises and zero-pads it itself (input_s2d_chunks_k's arithmetic), so neither the input kernel nor its
+    // 32-channel f16 tensor (6.5 MB per frame written and read back) exist.
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
     // Pixel fragments in flight per wave.  The pooled conv1_2 tile is 17 x 32 pixels = 34 fragments: in groups of 4 that is
     // 9 groups for 4 waves -- three rounds of which the last is a quarter full; groups of 3 give 12 groups = three full
@@ -940,22 +943,71 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rw_k(const ConvP P, const int 
     // is fetched into registers while the current one is multiplied.
     // Patch fill: a wave pass covers 16 consecutive patch pixels x 4 chunks; inside it each 8-lane group
     // takes 8 consecutive pixels of one chunk (the ds_write_b128 lane groups are 8 contiguous lanes).
-    const int fc = (lane >> 3) & 3, fpl = (lane & 7) + ((lane >> 5) << 3);
-    h8 v[RW_FILL];
+    // S2D8: only chunks 0 and 1 carry data (12 of 32 channels); a wave pass covers 32 patch pixels x 2 chunks, the planes of chunks
+    // 2 and 3 are zeroed once per block and never touched again
+    const int fc = S2D8 ? (lane >> 3) & 1 : (lane >> 3) & 3, fpl = S2D8 ? (lane & 7) + ((lane >> 4) << 3) : (lane & 7) + ((lane >> 5) << 3);
+    constexpr int PPP = S2D8 ? 32 : 16;                         // patch pixels per wave pass
+    constexpr int NFILL = S2D8 ? (RW_FILL + 1) / 2 : RW_FILL;
+    if constexpr (S2D8) {
+        const h8 z8 = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+        for (int i = tid; i < 2 * (plane >> 3); i += 256) *reinterpret_cast<h8 *>(lds + 2 * plane + i * 8) = z8;
+    }
+    h8 v[NFILL];
     auto fetch = [&](int t) {
         const int lt = (int)dd_xcd_remap((unsigned)t, (unsigned)total_tiles);
         const int n = lt / tiles_per_image, r = lt - n * tiles_per_image;
         const int ty = r / P.tiles_x, tx = r - ty * P.tiles_x;
         const int ys = ty * (POOL ? P.th - 1 : P.th) - P.pad_t, xs = tx * tw - P.pad_l;
         const _Float16 *img = P.in + (size_t)n * P.H * P.W * P.cs_in + P.coff_in + fc * 8;
+        const uint8_t *img8 = S2D8 ? P.src8 + (size_t)n * P.H * P.W * 12 : nullptr;        // frame n: [2 H][2 W][3] bytes
 #pragma unroll
-        for (int i = 0; i < RW_FILL; ++i) {
-            const int pix = (wave + 4 * i) * 16 + fpl;
+        for (int i = 0; i < NFILL; ++i) {
+            const int pix = (wave + 4 * i) * PPP + fpl;
             const int py = (int)((pix * rcp_pw) >> 16);
             const int y = ys + py, x = xs + pix - py * PW;
             const bool ok = pix < npix && y >= 0 && y < P.H && x >= 0 && x < P.W;      // else: a line of zeros, no branch
-            v[i] = *reinterpret_cast<const h8 *>(ok ? img + ((size_t)y * P.W + x) * P.cs_in : P.zero);
+            if constexpr (S2D8) {
+                // source pixels (2y, 2x), (2y, 2x + 1) are six adjacent bytes of row 2y, likewise in row 2y + 1: one unaligned 8-byte load
+                // per row (the last focus pixel of a frame would read two bytes past it: it takes its bytes one by one).  Raw bytes
+                // travel in the fill registers, the conversion happens at the LDS write.  Chunks 2 and 3 are the zero channels.
+                typedef unsigned u2u __attribute__((ext_vector_type(2), aligned(1)));
+                typedef unsigned u4t __attribute__((ext_vector_type(4)));
+                u4t raw = {0u, 0u, 0u, 0u};
+                if (ok) {
+                    const uint8_t *p0 = img8 + ((size_t)(2 * y) * (2 * P.W) + 2 * x) * 3, *p1 = p0 + (size_t)P.W * 6;
+                    if (y == P.H - 1 && x == P.W - 1) {
+                        raw[0] = (unsigned)p0[0] | ((unsigned)p0[1] << 8) | ((unsigned)p0[2] << 16) | ((unsigned)p0[3] << 24);
+                        raw[1] = (unsigned)p0[4] | ((unsigned)p0[5] << 8);
+                        raw[2] = (unsigned)p1[0] | ((unsigned)p1[1] << 8) | ((unsigned)p1[2] << 16) | ((unsigned)p1[3] << 24);
+                        raw[3] = (unsigned)p1[4] | ((unsigned)p1[5] << 8);
+                    } else {
+                        const u2u a = *reinterpret_cast<const u2u *>(p0), b = *reinterpret_cast<const u2u *>(p1);
+                        raw[0] = a[0]; raw[1] = a[1]; raw[2] = b[0]; raw[3] = b[1];
+                    }
+                    raw[1] |= 0x80000000u;                        // marks a live chunk (bits the six bytes do not use)
+                }
+                v[i] = __builtin_bit_cast(h8, raw);
+            } else {
+                v[i] = *reinterpret_cast<const h8 *>(ok ? img + ((size_t)y * P.W + x) * P.cs_in : P.zero);
+            }
         }
+    };
+    auto s2d_chunk = [&](const h8 &rawv) -> h8 {                  // chunk fc of a focus pixel from its six + six bytes
+        typedef unsigned u4t __attribute__((ext_vector_type(4)));
+        const u4t r = __builtin_bit_cast(u4t, rawv);
+        h8 o = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+        if (!(r[1] & 0x80000000u)) return o;
+        auto byte = [&](int row, int k) { return (float)((k < 4 ? r[2 * row] >> (8 * k) : r[2 * row + 1] >> (8 * (k - 4))) & 255u); };
+        auto cv = [&](float b) { return (_Float16)((b - P.in_mean) * P.in_scale); };
+        if (fc == 0) {                                           // (y0x0) rgb, (y1x0) rgb, (y0x1) rg
+            o[0] = cv(byte(0, 0)); o[1] = cv(byte(0, 1)); o[2] = cv(byte(0, 2));
+            o[3] = cv(byte(1, 0)); o[4] = cv(byte(1, 1)); o[5] = cv(byte(1, 2));
+            o[6] = cv(byte(0, 3)); o[7] = cv(byte(0, 4));
+        } else {                                                 // (y0x1) b, (y1x1) rgb, zeros
+            o[0] = cv(byte(0, 5));
+            o[1] = cv(byte(1, 3)); o[2] = cv(byte(1, 4)); o[3] = cv(byte(1, 5));
+        }
+        return o;
     };
 
     const int tile_px = P.th * tw;
@@ -964,9 +1016,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rw_k(const ConvP P, const int 
     fetch(t);
     for (;;) {
 #pragma unroll
-        for (int i = 0; i < RW_FILL; ++i) {
-            const int pix = (wave + 4 * i) * 16 + fpl;
-            if (pix < npix) *reinterpret_cast<h8 *>(lds + fc * plane + pix * 8) = v[i];
+        for (int i = 0; i < NFILL; ++i) {
+            const int pix = (wave + 4 * i) * PPP + fpl;
+            if (pix < npix) *reinterpret_cast<h8 *>(lds + fc * plane + pix * 8) = S2D8 ? s2d_chunk(v[i]) : v[i];
         }
         __syncthreads();
         const int lt = (int)dd_xcd_remap((unsigned)t, (unsigned)total_tiles);
@@ -3584,6 +3636,7 @@ int launch_conv3x3_rw(hipStream_t s, ConvP &P, int nimg, bool pool, int device) 
     }
     const int npix = (P.th + 2) * (P.tw + 2);
     DD_REQUIRE(npix <= RW_MAX_PATCH, DD_E_ARG, "conv3x3_rw: patch of %d pixels", npix);
+    DD_REQUIRE(pool || !P.src8 || (P.tw == 32 && P.act == ACT_SILU && !P.res && !P.out2), DD_E_ARG, "conv3x3_rw: an input op was folded into a launch that cannot take it");
     const size_t lds_bytes = (size_t)4 * ((npix * 16 + 255) & ~255) + (pool ? (size_t)P.th * P.tw * 32 * sizeof(_Float16) : 0);
     const int total = nimg * P.tiles_x * P.tiles_y;
     const int grid = std::min(total, 2 * 256);                   // persistent: 2 blocks per CU (register-bound), multiple of 8
@@ -3604,6 +3657,8 @@ int launch_conv3x3_rw(hipStream_t s, ConvP &P, int nimg, bool pool, int device) 
 #define DD_RW(TW_, ACT_, EF_) hipLaunchKernelGGL((conv3x3_rw_k<2, TW_, ACT_, false, EF_>), dim3((unsigned)grid), dim3(256), lds_bytes, s, P, total)
     const int ef = (!P.res && !P.out2) ? 0 : (P.res && P.out2) ? 1 : -1;
     if (P.tw == 32 && P.act == ACT_ELU && ef == 0) DD_RW(32, ACT_ELU, 0);
+    else if (P.tw == 32 && P.act == ACT_SILU && P.src8 && ef == 0)
+        hipLaunchKernelGGL((conv3x3_rw_k<2, 32, ACT_SILU, false, 0, true>), dim3((unsigned)grid), dim3(256), lds_bytes, s, P, total);
     else if (P.tw == 32 && P.act == ACT_SILU) DD_RW(32, ACT_SILU, -1);
     else if (P.tw == 15 && P.act == ACT_ELU && ef == 0) DD_RW(15, ACT_ELU, 0);
     else if (P.tw == 15 && P.act == ACT_NONE && ef == 1) DD_RW(15, ACT_NONE, 1);
@@ -4302,6 +4357,9 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
     net->op_launch.assign((size_t)net->n_ops, OPK_DEFAULT);
     ConvP stem_p;                                                 // a first layer waiting to be folded into the next op's launch
     bool stem_pending = false;
+    bool input_pending = false;                                   // a space-to-depth input op waiting to be folded into the 3x3 layer behind it
+    float input_mean = 0.f, input_scale = 1.f;
+    int input_op = -1;
     ConvP unit_a;                                                 // first 3x3 layer of a residual unit, likewise
     bool unit_pending = false;
     ConvP pw_p;                                                   // pointwise layer whose only reader is the next (depthwise) op
@@ -4322,6 +4380,7 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
         const int kind = o[0], src = o[1], dst = o[2], res = o[3], dst2 = o[4];
         const TensorDesc *ts = src >= 0 ? &net->tensors[src] : nullptr;
         const TensorDesc *td = dst >= 0 ? &net->tensors[dst] : nullptr;
+        DD_REQUIRE(!input_pending || (kind == OP_CONV && i == input_op + 1), DD_E_STATE, "dd_net_forward: input op %d was folded into an op that did not take it", input_op);
         if (pair_pending && kind != OP_CONV) { const int rc = flush_pair(); if (rc != DD_OK) return rc; }
         if (pw_pending && kind != OP_DWCONV) {
             pw_pending = false; net->op_launch[i - 1] = OPK_CONV_WS;
@@ -4342,6 +4401,16 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
             case OP_INPUT: {
                 const int s2d = o[5];
                 const int m = nimg * td->h * td->w;
+                if (s2d && o[30] && !o[6] && td->cs == 32 && !td->coff && i + 1 < net->n_ops && net->use_rw) {   // o[30]: only the next op reads it
+                    const int32_t *q = net->prog.data() + net->ops_off + (size_t)(i + 1) * OP_WORDS;
+                    static const bool off = getenv("DD_FOCUS_UNFUSED") && atoi(getenv("DD_FOCUS_UNFUSED")) != 0;
+                    if (!off && q[0] == OP_CONV && q[1] == dst && q[5] == 3 && q[6] == 3 && q[7] == 1 && q[8] == 1 && q[9] == 1 && q[10] == 32 &&
+                        q[12] == 32 && q[14] == ACT_SILU && q[15] == EPI_F16 && q[3] < 0 && q[4] < 0 && !q[29] && td->w % 32 == 0) {
+                        input_pending = true; input_mean = of[32]; input_scale = of[33]; input_op = i;
+                        net->op_launch[i] = OPK_FOLDED;
+                        break;
+                    }
+                }
                 if (s2d && td->cs >= 16 && td->cs % 8 == 0) {
                     const int cpp = td->cs / 8;
                     DD_REQUIRE((long long)m * cpp < (1ll << 31), DD_E_CAPACITY, "dd_net_forward: %d x %d input chunks", m, cpp);
@@ -4447,6 +4516,7 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
                 if (net->use_rw && P.kh == 3 && P.kw == 3 && P.stride == 1 && P.cin == 32 && P.cout_pad == 32 &&
                     P.epi == EPI_F16 && P.pad_t == 1 && P.pad_l == 1) {
                     // whole filter in registers, input patch staged once (see conv3x3_rw_k)
+                    if (input_pending) { input_pending = false; P.src8 = input; P.in_mean = input_mean; P.in_scale = input_scale; }
                     if (o[29]) { P.p[0] = td->h; P.p[1] = td->w; }      // fused 3x3/2 max pool: dst is the pooled tensor
                     if (stem_pending) {
                         stem_pending = false;

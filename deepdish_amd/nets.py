@@ -532,6 +532,7 @@ def compile_ssd_mobilenet(wd, in_size=300):
 YOLO_ANCHORS = [[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]]   # yolov5s.yaml:6-10
 YOLO_NC = 80
 FOCUS32 = os.environ.get('DD_YOLO_FOCUS32', '1') != '0'
+FOCUS_FUSE = os.environ.get('DD_YOLO_FOCUS_FUSE', '1') != '0'
 
 
 class _YoloNames:
@@ -617,6 +618,8 @@ def compile_yolov5s(wd, in_size=640):
     # layer of the network; DD_YOLO_FOCUS32=0 keeps the 16-channel form).
     if FOCUS32:
         x = P.input(swap_rb=False, s2d=True, c_pad=32)
+        if FOCUS_FUSE:
+            P.ops[-1][30] = 1                                                 # only the conv behind it reads the sliced tensor: the executor folds the slicing into its patch fill
         w, b = fold_conv_bn(wd, 'm0.focus')
         w32 = np.zeros((3, 3, 32, w.shape[3]), dtype=w.dtype)
         w32[:, :, :12] = w

@@ -355,3 +355,38 @@ def test_pointwise_plus_next_depthwise_in_one_launch_gives_the_same_bits():
         assert r.returncode == 0, r.stderr[-2000:]
         sums.append(re.search(r'sha (\S+)', r.stdout).group(1))
     assert sums[0] == sums[1], sums
+
+
+@pytest.mark.parametrize('n', [1, 5])
+def test_yolo_focus_folded_into_the_first_conv_gives_the_same_bits(n):
+    """YOLOv5s: the space-to-depth input op runs inside conv3x3_rw_k's patch fill (the u8 frame is sliced, normalised and
+    zero-padded on the way into LDS).  Same decoded rows as a program compiled without the fold flag -- incl. frames whose
+    last pixels differ (the fill reads the last focus pixel of a frame byte by byte) -- and the sliced tensor, which was never
+    written, cannot be read."""
+    import torch
+    from deepdish_amd import nets
+    from deepdish_amd.engine import Net
+    wd = nets.synthetic_yolov5s_weights()
+    rng = np.random.default_rng(11)
+    x = rng.integers(0, 256, (n, 640, 640, 3), dtype=np.uint8)
+    x[0, -2:, -2:] = (255, 0, 128)
+    xd = torch.from_numpy(x).cuda()
+    torch.cuda.synchronize()
+    outs = {}
+    for fuse in (True, False):
+        old = nets.FOCUS_FUSE
+        nets.FOCUS_FUSE = fuse
+        try:
+            prog = nets.compile_yolov5s(wd)
+        finally:
+            nets.FOCUS_FUSE = old
+        net = Net(prog, max_batch=n)
+        net.forward(xd)
+        outs[fuse] = net.read().copy()
+        focus_tensor = int(prog.ops[0][2])
+        if fuse:
+            with pytest.raises(Exception):
+                net.read(tensor=focus_tensor)
+        else:
+            net.read(tensor=focus_tensor)
+    np.testing.assert_array_equal(outs[True], outs[False])
