@@ -118,6 +118,12 @@ def lib():
         raise DeepDishHipError(
             'libdeepdish_hip.so is missing (%s): build it with `python -m deepdish_amd.build`; '
             'there is no CPU fallback' % LIB_PATH)
+    # torch first: its wheel carries its own libamdhip64, and a process that loads /opt/rocm's copy through this library BEFORE torch
+    # ends up with two HIP runtimes (seen: build() then smoke() in one process -> "no ROCm-capable device is detected")
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     l = ctypes.CDLL(LIB_PATH)
     for name, args in SIGNATURES.items():
         try:
