@@ -1,0 +1,49 @@
+"""GPU: the engine's A/B switches (README table) are read once per process, so each variant runs in its own interpreter;
+what they must have in common is the output -- the README's claim is "every variant gives the same bits"."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _sha(script, args, env_extra):
+    env = dict(os.environ)
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', script)] + [str(a) for a in args], capture_output=True, text=True,
+                       env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    m = re.search(r'sha ([0-9a-f]{16})', r.stdout)
+    assert m, r.stdout[-500:]
+    return m.group(1)
+
+
+def test_ssd_forward_switches_give_the_same_bits():
+    """SSD forward at 192 frames (weight-stationary layers on): the LDS-DMA ring, two K stages per barrier, register-staged fills,
+    64 channels per wave, no pointwise + depthwise fusion, no weight-stationary kernel at all, unfused first layers."""
+    base = _sha('time_forward.py', ['ssd', 192], {})
+    for env in ({'DD_WS_SPB': '2'}, {'DD_WSR': '1'}, {'DD_WSR': '2'}, {'DD_WS_DW_OFF': '1'}, {'DD_WS': '0'},
+                {'DD_SSD_FRONT_UNFUSED': '1', 'DD_DWPW_ROWS_OFF': '1'}):
+        assert _sha('time_forward.py', ['ssd', 192], env) == base, env
+
+
+def test_mars_forward_switches_give_the_same_bits():
+    """MARS forward at 1280 crops: pair kernel off, residual units unfused, stem unfused, row kernels off."""
+    base = _sha('time_forward.py', ['mars', 1280], {})
+    for env in ({'DD_RES_PAIR_OFF': '1'}, {'DD_RES_UNIT_UNFUSED': '1'}, {'DD_STEM_UNFUSED': '1'},
+                {'DD_C64_ROWS_OFF': '1', 'DD_S2_ROWS_OFF': '1'}, {'DD_POOL_TILED': '1'}):
+        assert _sha('time_forward.py', ['mars', 1280], env) == base, env
+
+
+def test_yolo_and_image_switches_give_the_same_bits():
+    """YOLOv5s forward at 3 frames with the Focus slicing as its own launch / as a 16-channel tensor; the batched Lanczos
+    stretch in two launches; (the crop kernel's two forms are compared through the pipeline tests' golden scenes)."""
+    base = _sha('time_forward.py', ['yolo', 3], {})
+    for env in ({'DD_FOCUS_UNFUSED': '1'}, {'DD_YOLO_FOCUS_FUSE': '0'}):
+        assert _sha('time_forward.py', ['yolo', 3], env) == base, env
+    base = _sha('time_resize.py', [24], {})
+    assert _sha('time_resize.py', [24], {'DD_LANCZOS_FUSED': '0'}) == base
