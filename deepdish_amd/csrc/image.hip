@@ -76,13 +76,16 @@ __global__ __launch_bounds__(256) void crop_resize_k(const uint8_t *__restrict__
 // scattered single bytes: 81 us per 7 680 crops, bound by the address path.  (A load that would run past its frame -- the last
 // two pixels of the last row -- falls back to bytes.)
 typedef unsigned u2u __attribute__((ext_vector_type(2), aligned(1)));
-__device__ __forceinline__ void crop_pair(const uint8_t *p, bool wide, uint32_t &lo, uint32_t &hi) {      // six bytes at p: lo = p[0..3], hi = p[4..5]
-    if (wide) {
+__device__ __forceinline__ void crop_pair(const uint8_t *p, const uint8_t *end, uint32_t &lo, uint32_t &hi) {      // six bytes at p: lo = p[0..3], hi = p[4..5]
+    if (p + 8 <= end) {
         const u2u v = *reinterpret_cast<const u2u *>(p);
         lo = v[0]; hi = v[1];
-    } else {
-        lo = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
-        hi = (uint32_t)p[4] | ((uint32_t)p[5] << 8);
+    } else {                                                      // the last pixels of a frame: byte by byte, nothing past `end`
+        uint32_t b[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) b[i] = p + i < end ? (uint32_t)p[i] : 0u;
+        lo = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+        hi = b[4] | (b[5] << 8);
     }
 }
 __device__ __forceinline__ int crop_byte(uint32_t lo, uint32_t hi, int i) { return (int)((i < 4 ? lo >> (8 * i) : hi >> (8 * (i - 4))) & 255u); }
@@ -108,8 +111,8 @@ __global__ __launch_bounds__(256) void crop_resize4_k(const uint8_t *__restrict_
         for (int i = 0; i < 4; ++i) {
             const uint8_t *p0 = r0 + (size_t)(2 * (dx0 + i)) * 3, *p1 = r1 + (size_t)(2 * (dx0 + i)) * 3;
             uint32_t l0, h0, l1, h1;
-            crop_pair(p0, p0 + 8 <= fend, l0, h0);
-            crop_pair(p1, p1 + 8 <= fend, l1, h1);
+            crop_pair(p0, fend, l0, h0);
+            crop_pair(p1, fend, l1, h1);
 #pragma unroll
             for (int c = 0; c < 3; ++c)
                 px[i][b.swap_rb ? 2 - c : c] = (uint8_t)((crop_byte(l0, h0, c) + crop_byte(l0, h0, c + 3) + crop_byte(l1, h1, c) + crop_byte(l1, h1, c + 3) + 2) >> 2);
@@ -126,8 +129,8 @@ __global__ __launch_bounds__(256) void crop_resize4_k(const uint8_t *__restrict_
             const int second = min(sx + 1, b.cw - 1) == sx ? 0 : 3;        // at the crop's right edge both taps are pixel sx
             const uint8_t *p0 = r0 + (size_t)sx * 3, *p1 = r1 + (size_t)sx * 3;
             uint32_t l0, h0, l1, h1;
-            crop_pair(p0, p0 + 8 <= fend, l0, h0);
-            crop_pair(p1, p1 + 8 <= fend, l1, h1);
+            crop_pair(p0, fend, l0, h0);
+            crop_pair(p1, fend, l1, h1);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const int a0 = crop_byte(l0, h0, c) * xa0 + (second ? crop_byte(l0, h0, c + 3) : crop_byte(l0, h0, c)) * xa1;      // scale 2^11
