@@ -97,3 +97,44 @@ def test_pointwise_plus_depthwise_launch_at_the_bench_batch_sizes(batch):
         fused.append('conv_ws_dw_k' in r.stdout)
     assert sums[0] == sums[1], sums
     assert fused[1] is False and (fused[0] or batch not in (256, 384)), (batch, fused)
+
+
+def test_yolo_launch_of_256_frames_is_frame_independent_and_matches_the_oracle():
+    """Config 3's launch shape (256 frames per detector launch: conv_ws_k on the 256/512-channel pointwise layers, the Focus
+    slicing inside conv3x3_rw_k, the Detect heads reducing their rows): frames 0, 1, n/2, n-1 give the boxes / confidences /
+    classes of their single-frame forwards bit for bit, and one of them those that tools/yolov5.py:121-128 computes from the
+    f32 restatement's rows (boxes and confidence within test_gpu_nets.py's per-element tolerance; the class wherever the
+    restatement's best two products are further apart than that tolerance)."""
+    import torch
+    from deepdish_amd import nets
+    from deepdish_amd.engine import Net
+    from deepdish_amd.profile import net_op_launches, OPK_NAMES
+    from oracle import nets_torch
+    n = 256
+    wd = nets.synthetic_yolov5s_weights(1234)
+    net = Net(nets.compile_yolov5s(wd), max_batch=n)
+    net.yolo_decode(True)
+    rng = np.random.default_rng(256)
+    x = rng.integers(0, 256, (n, 640, 640, 3), dtype=np.uint8)
+    x[1] = 0
+    xd = torch.from_numpy(x).cuda()
+    torch.cuda.synchronize()
+    net.forward(xd)
+    ran = {OPK_NAMES.get(int(c)) for c in net_op_launches(net)}
+    assert {'conv_ws_k', 'conv_glds_k<yolo_head_decode>'} <= ran, ran
+    boxes, conf, cls = net.yolo_decoded()
+    assert np.isfinite(boxes).all() and np.isfinite(conf).all()
+    for i in (0, 1, n // 2, n - 1):
+        net.forward(xd[i:i + 1])
+        b1, c1, k1 = net.yolo_decoded()
+        np.testing.assert_array_equal(b1[0], boxes[i], err_msg='frame %d boxes' % i)
+        np.testing.assert_array_equal(c1[0], conf[i], err_msg='frame %d confidence' % i)
+        np.testing.assert_array_equal(k1[0], cls[i], err_msg='frame %d class' % i)
+    want = nets_torch.yolov5s_forward(wd, x[n - 1:n], w16=True)[0]
+    assert _close(boxes[n - 1], want[:, :4], 2e-4, 1e-2) <= 1.0
+    prod = want[:, 5:] * want[:, 4:5]
+    order = np.sort(prod, axis=-1)
+    assert _close(conf[n - 1], order[:, -1], 2e-4, 2e-2) <= 1.0
+    clear = (order[:, -1] - order[:, -2]) > (4e-4 + 4e-2 * order[:, -1])
+    assert clear.mean() > 0.5
+    np.testing.assert_array_equal(cls[n - 1][clear], np.argmax(prod, axis=-1)[clear])
