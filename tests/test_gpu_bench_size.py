@@ -138,3 +138,25 @@ def test_yolo_launch_of_256_frames_is_frame_independent_and_matches_the_oracle()
     clear = (order[:, -1] - order[:, -2]) > (4e-4 + 4e-2 * order[:, -1])
     assert clear.mean() > 0.5
     np.testing.assert_array_equal(cls[n - 1][clear], np.argmax(prod, axis=-1)[clear])
+
+
+def test_lanczos_launch_of_384_frames_matches_pillow():
+    """The detector pre-resize of a whole worker group (384 frames of 640x480 -> 300x300 in one launch of lanczos_fused_k: 5 760
+    blocks, 15 per frame): frames 0, 1, 191, 383 equal Pillow's bytes."""
+    import torch
+    from PIL import Image
+    from deepdish_amd._lib import lib, check
+    from deepdish_amd.runtime import default_context, ptr
+    ctx = default_context()
+    n, H, W, h, w = 384, 480, 640, 300, 300
+    g = torch.Generator(device='cuda'); g.manual_seed(384)
+    src = torch.randint(0, 256, (n, H, W, 3), dtype=torch.uint8, device='cuda', generator=g)
+    dst = torch.empty((n, h, w, 3), dtype=torch.uint8, device='cuda')
+    torch.cuda.synchronize()
+    check(lib().dd_resize_lanczos_batch(ctx.handle, ptr(src), n, H, W, 3, 1, ptr(dst), h, w, None))
+    ctx.sync()
+    for i in (0, 1, 191, 383):
+        bgr = src[i].cpu().numpy()
+        rgba = np.dstack([bgr[..., ::-1], np.full((H, W, 1), 255, np.uint8)])
+        want = np.asarray(Image.fromarray(rgba, 'RGBA').convert('RGB').resize((w, h), Image.LANCZOS))
+        np.testing.assert_array_equal(dst[i].cpu().numpy(), want, err_msg='frame %d' % i)
