@@ -18,6 +18,7 @@
 #include <string>
 #include "common.h"
 #include "ssd_dev.h"
+#include "net_priv.h"
 
 namespace {
 
@@ -3422,43 +3423,10 @@ __global__ __launch_bounds__(256) void l2norm_k(const float *__restrict__ in, in
     }
 }
 
-struct TensorDesc { int buf, h, w, c, cs, coff, dtype, pad; };
 
 }  // namespace
 
-struct dd_net {
-    dd_ctx *ctx = nullptr;
-    int max_batch = 0;
-    std::vector<int32_t> prog;
-    std::vector<TensorDesc> tensors;
-    std::vector<int64_t> buf_elems;          // per image
-    std::vector<void *> bufs;
-    std::vector<int> buf_dtype;
-    int n_ops = 0, ops_off = 0;
-    char *d_weights = nullptr;
-    int64_t weight_bytes = 0;
-    int in_h = 0, in_w = 0, out_tensor = -1;
-    bool profile = false;
-    int last_batch = 0;
-    DevBuf slab;                             // split-K partial sums (sized for max_batch: see launch_conv)
-    // dd_net_ssd_decode: the SSD head ops decode in their epilogue into these per-anchor arrays ([max_batch][n_anchors] each)
-    bool ssd_dec = false, yolo_dec = false;                      // dd_net_yolo_decode: the Detect heads reduce their rows to (box, confidence, class); dec_anchors = rows per image
-    int dec_anchors = 0; float dec_thr = 0.f;
-    float *d_anchors = nullptr, *dec_boxes = nullptr, *dec_score = nullptr, *dec_keys = nullptr; int *dec_cls = nullptr;
-    bool slab_moved = false;                 // the slab was reallocated during the last eager forward: captured graphs hold a dead pointer
-    _Float16 *d_zero = nullptr;              // 256 bytes of zeros (padding taps of the direct-to-LDS fills)
-    bool use_glds = true;
-    bool use_rw = true;                      // DD_NO_RW=1: 3x3x32x32 layers fall back to the implicit-GEMM kernels (A/B measurements)
-    int tile_mode = 0;                       // DD_TILE_MODE=1 forces the 64 x 64 tile everywhere (A/B measurements)
-    std::vector<hipEvent_t> events;           // n_ops + 1 when profiling
-    std::vector<int32_t> op_launch;           // per op of the last forward: DD_OPK_* (which launch ran it)
-    // Latency mode (dd_net_use_graph): the launch train of one forward -- 20 to 75 short kernels at batch 1 -- captured
-    // once per (input pointer, batch) and replayed as one hipGraph launch; the first call of a key runs eagerly (it may
-    // still allocate split-K slabs and set function attributes), the second captures.
-    struct GraphEntry { int calls = 0; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
-    bool use_graph = false;
-    std::map<std::pair<const void *, int>, GraphEntry> graphs;
-};
+
 
 static void net_drop_graphs(dd_net *net) {
     for (auto &kv : net->graphs) {
@@ -4047,15 +4015,15 @@ int dd_net_create(dd_ctx *ctx, const int32_t *program_host, int n_words, const v
     n->in_w = program_host[5];
     n->out_tensor = program_host[6];
     const int32_t *p = program_host + 8;
-    for (int i = 0; i < nt; ++i, p += TENSOR_WORDS) n->tensors.push_back(TensorDesc{p[0], p[1], p[2], p[3], p[4], p[5], p[6], 0});
+    for (int i = 0; i < nt; ++i, p += TENSOR_WORDS) n->tensors.push_back(TensorDesc{p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]});   // p[7] = 1: uint8 tensor in the bordered 16-channel-plane layout (csrc/netsq.hip)
     DD_HIP(hipSetDevice(ctx->device));
     for (int i = 0; i < nb; ++i, p += 2) {
         n->buf_elems.push_back(p[0]);
-        n->buf_dtype.push_back(p[1]);
+        n->buf_dtype.push_back(p[1] & 0xff);
         void *d = nullptr;
-        const size_t bytes = (size_t)p[0] * max_batch * dtype_size(p[1]) + 256;
+        const size_t bytes = (size_t)p[0] * max_batch * dtype_size(p[1] & 0xff) + 256;
         DD_HIP(hipMalloc(&d, bytes));
-        DD_HIP(hipMemset(d, 0, bytes));
+        DD_HIP(hipMemset(d, (p[1] >> 8) & 0xff, bytes));       // uint8 tensors: the zero point, which their borders keep (nobody writes them)
         n->bufs.push_back(d);
     }
     n->n_ops = no;
@@ -4187,7 +4155,8 @@ int dd_net_read(dd_net *n, int tensor, int n_img, void *dst, int dst_on_device, 
                    "size and its output stayed on chip); run a smaller batch or a program compiled without the fusion flags", t, i);
     }
     hipStream_t s = dd_pick_stream(n->ctx, stream);
-    const size_t bytes = (size_t)n_img * d.h * d.w * d.cs * dtype_size(d.dtype);
+    const size_t bytes = d.pad ? (size_t)n_img * (d.h + 2) * (d.w + 2) * d.cs                     // bordered uint8 layout, as it lies
+                               : (size_t)n_img * d.h * d.w * d.cs * dtype_size(d.dtype);
     if (!bytes) return DD_OK;
     DD_HIP(hipMemcpyAsync(dst, n->bufs[d.buf], bytes, dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
     if (!dst_on_device) DD_HIP(hipStreamSynchronize(s));
@@ -4218,6 +4187,10 @@ int dd_net_ssd_decode(dd_net *net, const float *anchors_host, int n_anchors, flo
         if (o[0] == OP_CONV && o[15] == EPI_SSD_HEAD) {
             DD_REQUIRE(o[18] && o[21] == n_anchors && 4 + o[20] <= 96, DD_E_ARG,
                        "dd_net_ssd_decode: head op %d has no per-anchor weight copy, or %d anchors / %d classes do not fit", i, o[21], o[20]);
+            ++heads;
+        }
+        if (o[0] == 20) {                                      // OP_QSSD_DECODE (uint8 programs decode in an op of their own)
+            DD_REQUIRE(o[21] == n_anchors, DD_E_ARG, "dd_net_ssd_decode: the program decodes %d anchors, %d given", o[21], n_anchors);
             ++heads;
         }
     }
@@ -4717,8 +4690,12 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
                 DD_LAUNCH_CHECK();
                 break;
             }
-            default:
-                DD_REQUIRE(false, DD_E_ARG, "dd_net_forward: unknown op kind %d at %d", kind, i);
+            default: {
+                int handled = 0;
+                const int rc = netq_run_op(net, i, o, input, nimg, s, &handled);       // csrc/netsq.hip: the uint8 programs' ops
+                if (rc != DD_OK) return rc;
+                DD_REQUIRE(handled, DD_E_ARG, "dd_net_forward: unknown op kind %d at %d", kind, i);
+            }
         }
     }
     if (pair_pending) { const int rc = flush_pair(); if (rc != DD_OK) return rc; }

@@ -22,7 +22,7 @@ class Net:
         self._h = h
         t = program.tensors[program.out_tensor]
         self.out_shape = (t['h'], t['w'], t['cs'])
-        self.out_dtype = {nets.DT_F16: torch.float16, nets.DT_F32: torch.float32}[t['dtype']]
+        self.out_dtype = {nets.DT_F16: torch.float16, nets.DT_F32: torch.float32, nets.DT_U8: torch.uint8}[t['dtype']]
         self.weight_bytes = len(blob)
 
     def __del__(self):
@@ -40,6 +40,10 @@ class Net:
     def ssd_decode(self, anchors, score_thr, enable=True):
         """SSD detector: first stage of TFLite_Detection_PostProcess inside the head layers' epilogues (the head matrix is then
         never written); results via ssd_decoded()."""
+        if not enable:
+            check(lib().dd_net_ssd_decode(self._h, None, 0, 0.0, 0), 'dd_net_ssd_decode')
+            self._dec_anchors = 0
+            return
         a = np.ascontiguousarray(anchors, dtype=np.float32)
         check(lib().dd_net_ssd_decode(self._h, ptr(a), len(a), float(score_thr), int(bool(enable))), 'dd_net_ssd_decode')
         self._dec_anchors = len(a) if enable else 0
@@ -79,14 +83,11 @@ class Net:
     def read(self, n=None, tensor=-1, to_host=True):
         """Output rows of the last forward: [n, h*w, cs] (host numpy or a fresh device tensor)."""
         n = self._last_n if n is None else n
-        if tensor < 0:
-            shape, dt = self.out_shape, self.out_dtype
-        else:
-            t = self.program.tensors[tensor]
-            shape = (t['h'], t['w'], t['cs'])
-            dt = {nets.DT_F16: torch.float16, nets.DT_F32: torch.float32}[t['dtype']]
+        t = self.program.tensors[self.program.out_tensor if tensor < 0 else tensor]
+        shape = (t['h'] + 2, t['cs'] // 16, t['w'] + 2, 16) if t.get('q16') else (t['h'], t['w'], t['cs'])   # bordered uint8 layout: as it lies (netsq.unpack_q16)
+        dt = {nets.DT_F16: torch.float16, nets.DT_F32: torch.float32, nets.DT_U8: torch.uint8}[t['dtype']]
         if to_host:
-            out = np.zeros((n,) + shape, dtype=np.float16 if dt == torch.float16 else np.float32)
+            out = np.zeros((n,) + shape, dtype={torch.float16: np.float16, torch.float32: np.float32, torch.uint8: np.uint8}[dt])
             check(lib().dd_net_read(self._h, tensor, n, ptr(out), 0, None), 'dd_net_read')
             return out
         out = self.ctx.empty((n,) + shape, dt)

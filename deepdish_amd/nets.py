@@ -59,9 +59,18 @@ class Program:
         self.info = []          # per op: kernel symbol + algorithmic flops / bytes per image
 
     # ---- storage
-    def buffer(self, elems, dtype=DT_F16):
-        self.bufs.append((int(elems), dtype))
+    def buffer(self, elems, dtype=DT_F16, fill=0):
+        """fill: the byte every element of the buffer holds at engine creation (uint8 tensors: their zero point)."""
+        self.bufs.append((int(elems), dtype | (int(fill) & 0xff) << 8))
         return len(self.bufs) - 1
+
+    def qtensor(self, h, w, c, zp):
+        """uint8 activation tensor in the bordered 16-channel-plane layout of csrc/netsq.hip: [h + 2][c / 16][w + 2][16],
+        borders = the tensor's zero point (set once, never written)."""
+        assert c % 16 == 0 and 0 <= zp <= 255
+        buf = self.buffer((h + 2) * (w + 2) * c, DT_U8, fill=zp)
+        self.tensors.append(dict(buf=buf, h=h, w=w, c=c, cs=c, coff=0, dtype=DT_U8, q16=1, zp=int(zp)))
+        return len(self.tensors) - 1
 
     def tensor(self, h, w, c, cs=None, coff=0, buf=None, dtype=DT_F16):
         cs = rup(c, 8) if cs is None else cs
@@ -97,6 +106,12 @@ class Program:
                 w[20:20 + len(v)] = v
             elif k == 'f':
                 f[32:32 + len(v)] = v
+            elif k == 'raw':                      # {word index: int32} (uint8 programs, deepdish_amd/netsq.py)
+                for i, x in v.items():
+                    w[i] = x
+            elif k == 'rawf':
+                for i, x in v.items():
+                    f[i] = x
             else:
                 w[names[k]] = v
         self.ops.append(w)
@@ -314,7 +329,7 @@ class Program:
     def serialize(self):
         head = np.array([MAGIC, len(self.tensors), len(self.bufs), len(self.ops), self.in_h, self.in_w,
                          self.out_tensor, 0], dtype=np.int32)
-        tw = np.array([[t['buf'], t['h'], t['w'], t['c'], t['cs'], t['coff'], t['dtype'], 0] for t in self.tensors],
+        tw = np.array([[t['buf'], t['h'], t['w'], t['c'], t['cs'], t['coff'], t['dtype'], t.get('q16', 0)] for t in self.tensors],
                       dtype=np.int32).reshape(-1)
         bw = np.array(self.bufs, dtype=np.int32).reshape(-1)
         words = np.concatenate([head, tw, bw] + self.ops).astype(np.int32)

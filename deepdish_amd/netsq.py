@@ -1,0 +1,204 @@
+"""Compiler for uint8 models: QModel (deepdish_amd/quantize.py, or tools/tflite_reader.py from a .tflite) -> op program
+for csrc/netsq.hip.  The analogue of handing `ssdmobilenetv1.tflite` to `Interpreter(model_path=...)`
+(tools/ssd_mobilenet.py:35-38 upstream): the arithmetic is the file's own -- uint8 tensors, int32 accumulators, TFLite's
+fixed-point requantisation.
+
+Weight packing (see csrc/netsq.hip): w' = w - 128 as i8 in MFMA A-fragment order [16-row fragment][k step][lane][16 B];
+k step = (tap, 64-channel slice); `cbias[c] = bias[c] - za' * sum_k w'[c][k] + K za' zw'` with za' = za - 128,
+zw' = zw - 128; `zwc = 128 - zw` multiplies the device-side row sum of the operand bytes.
+"""
+import os
+import numpy as np
+
+from . import nets, quantize
+from .nets import Program, same_pad, DT_U8
+
+OP_QCONV0, OP_QCONV, OP_QDW, OP_QDWPW, OP_QSSD_DECODE = 16, 17, 18, 19, 20
+QEPI_Q16, QEPI_ROWS = 0, 1
+FEATURE_LAYERS = ['pw11', 'pw13', 'extra1_2', 'extra2_2', 'extra3_2', 'extra4_2']
+
+
+def _req_words(L):
+    m, shift = quantize.conv_multiplier(L)
+    if shift > 0:
+        raise ValueError('uint8 layer with a multiplier >= 1 (shift %d): not built' % shift)
+    lo, hi = quantize.activation_range(L)
+    linear = int(L['act'] == 'none')
+    if not linear and lo < L['out_zp']:
+        raise ValueError('activation clamp below the zero point')
+    return {32: m, 33: -shift, 36: lo, 37: hi, 40: int(L['out_zp']), 41: linear}
+
+
+def _cbias(L, w_i8_ck):
+    """w_i8_ck: [cout][K] int (w - 128) over the real taps."""
+    za, zw = int(L['in_zp']) - 128, int(L['w_zp']) - 128
+    k = w_i8_ck.shape[1]
+    return (L['bias'].astype(np.int64) - za * w_i8_ck.sum(axis=1) + k * za * zw).astype(np.int64)
+
+
+def pack_conv(L, epi, chan_map=None, cout_pad=None):
+    """-> (packed i8 [n_mfrag][ksteps][64][16], cbias int32 [cout_pad], kc_per_tap).  chan_map[i] = source channel of output row i
+    (or -1: a zero row)."""
+    w = L['w'].astype(np.int64) - 128                       # [kh][kw][cin][cout]
+    kh, kw, cin, cout = w.shape
+    if chan_map is None:
+        chan_map = np.arange(cout)
+    cout_pad = cout_pad or (len(chan_map) + 15) // 16 * 16
+    cmap = np.full(cout_pad, -1, np.int64)
+    cmap[:len(chan_map)] = chan_map
+    kcpt = (cin + 63) // 64
+    wk = np.zeros((cout_pad, kh * kw, kcpt * 64), np.int64)
+    src = np.transpose(w, (3, 0, 1, 2)).reshape(cout, kh * kw, cin)
+    valid = cmap >= 0
+    wk[valid, :, :cin] = src[cmap[valid]]
+    cb = np.zeros(cout_pad, np.int64)
+    cb[valid] = _cbias(L, src.reshape(cout, -1))[cmap[valid]]
+    assert np.abs(cb).max() < 2 ** 31
+    n_mfrag = cout_pad // 16
+    ksteps = kh * kw * kcpt
+    # rows: natural (ROWS) or fragment m of group mg holds row 4g + r = channel 64 mg + 16 g + 4 m + r (Q16)
+    if epi == QEPI_Q16:
+        assert cout_pad % 64 == 0
+        f = np.arange(n_mfrag)[:, None]
+        row = np.arange(16)[None, :]
+        chan = 64 * (f // 4) + 16 * (row // 4) + 4 * (f % 4) + (row % 4)
+    else:
+        chan = 16 * np.arange(n_mfrag)[:, None] + np.arange(16)[None, :]
+    wf = wk[chan]                                           # [n_mfrag][16 rows][taps][kcpt*64]
+    wf = wf.reshape(n_mfrag, 16, kh * kw, kcpt, 4, 16)       # ... [kc][fq][16 bytes]
+    packed = np.transpose(wf, (0, 2, 3, 4, 1, 5)).reshape(n_mfrag, ksteps, 64, 16)     # lane = fq * 16 + row
+    return packed.astype(np.int8), cb.astype(np.int32), kcpt
+
+
+def pack_conv0(L):
+    """First layer: one k step, k group dy = the nine (dx, channel) bytes of filter row dy; two fragments, row 4g + r of fragment m =
+    channel 8g + 4m + r."""
+    w = L['w'].astype(np.int64) - 128                       # [3][3][3][32]
+    assert w.shape == (3, 3, 3, 32)
+    src = np.transpose(w, (3, 0, 1, 2)).reshape(32, 3, 9)
+    wk = np.zeros((32, 4, 16), np.int64)
+    wk[:, :3, :9] = src
+    f = np.arange(2)[:, None]
+    row = np.arange(16)[None, :]
+    chan = 8 * (row // 4) + 4 * f + (row % 4)
+    wf = wk[chan]                                           # [2][16][4][16]
+    packed = np.transpose(wf, (0, 2, 1, 3)).reshape(2, 64, 16)
+    return packed.astype(np.int8), _cbias(L, src.reshape(32, 27)).astype(np.int32)
+
+
+def pack_dw(L):
+    w = L['w'].astype(np.int64) - int(L['w_zp'])            # [3][3][C]
+    c = w.shape[2]
+    cb = L['bias'].astype(np.int64) - int(L['in_zp']) * w.reshape(9, c).sum(axis=0)
+    return w.reshape(9, c).astype(np.int16), cb.astype(np.int32)
+
+
+def compile_ssd_mobilenet_quant(qm):
+    """u8 RGB [n,300,300,3] -> box encodings u8 [n,1917,4] and class logits u8 [n,1917,96] (91 used per row), both in the
+    tensors' own quantisation; dd_net_ssd_decode adds the post-process op's first stage (per-anchor arrays)."""
+    size = int(qm['input']['size'])
+    P = Program(size, size)
+    Ls = qm['layers']
+    anchors, maps = nets.ssd_anchors(size)
+    n_anchors = len(anchors)
+
+    def geom(t, k, stride):
+        d = P.T(t)
+        ho, pt = same_pad(d['h'], k, stride)
+        wo, pl = same_pad(d['w'], k, stride)
+        return ho, wo, pt, pl
+
+    def info(kernel, flops, nbytes, wbytes):
+        P.info[-1] = dict(kernel=kernel, flops=flops, bytes=nbytes, wbytes=wbytes)
+
+    # first layer
+    L = Ls['conv0']
+    ho, pt = same_pad(size, 3, L['stride'])
+    wo, pl = same_pad(size, 3, L['stride'])
+    x = P.qtensor(ho, wo, 32, L['out_zp'])
+    wp, cb = pack_conv0(L)
+    raw = _req_words(L)
+    raw.update({38: 128 - int(L['w_zp']), 39: int(L['in_zp'])})
+    P._op(OP_QCONV0, dst=x, kh=3, kw=3, stride=L['stride'], pad_t=pt, pad_l=pl, cin=3, cout=32, cout_pad=32,
+          w_off=P.add_blob(wp), b_off=P.add_blob(cb), ho=ho, wo=wo, raw=raw)
+    info('q_conv0_k', 2 * ho * wo * 27 * 32, 3 * size * size + ho * wo * 32, 27 * 32 + 4 * 32)
+
+    def conv(src, name, epi=QEPI_Q16, dst=None, chan_map=None, cout_pad=None, row_bytes=0, base_off=0, cout_store=0):
+        L = Ls[name]
+        kh = L['w'].shape[0]
+        ho, wo, pt, pl = geom(src, kh, L['stride'])
+        s = P.T(src)
+        assert s['zp'] == L['in_zp'] and L['w'].shape[2] == s['c'], name
+        wp, cb, kcpt = pack_conv(L, epi, chan_map, cout_pad)
+        if dst is None:
+            dst = P.qtensor(ho, wo, L['w'].shape[3], L['out_zp'])
+        raw = _req_words(L)
+        raw.update({38: 128 - int(L['w_zp']), 39: int(L['in_zp']), 42: row_bytes, 43: base_off, 44: cout_store})
+        P._op(OP_QCONV, src=src, dst=dst, kh=kh, kw=kh, stride=L['stride'], pad_t=pt, pad_l=pl, cin=s['c'], cout=L['w'].shape[3],
+              cout_pad=len(cb), kpad=kcpt, epi=epi, w_off=P.add_blob(wp), b_off=P.add_blob(cb), ho=ho, wo=wo, raw=raw)
+        cin, cout = L['w'].shape[2:]
+        info('q_conv_k', 2 * ho * wo * kh * kh * cin * cout, s['h'] * s['w'] * cin + ho * wo * cout, kh * kh * cin * cout + 4 * cout)
+        return dst
+
+    def dw(src, name):
+        L = Ls[name]
+        ho, wo, pt, pl = geom(src, 3, L['stride'])
+        s = P.T(src)
+        assert s['zp'] == L['in_zp'] and L['w'].shape[2] == s['c'], name
+        w16, cb = pack_dw(L)
+        dst = P.qtensor(ho, wo, s['c'], L['out_zp'])
+        P._op(OP_QDW, src=src, dst=dst, kh=3, kw=3, stride=L['stride'], pad_t=pt, pad_l=pl, cin=s['c'], cout=s['c'], cout_pad=s['c'],
+              w_off=P.add_blob(w16), b_off=P.add_blob(cb), ho=ho, wo=wo, raw=_req_words(L))
+        info('q_dw_k', 2 * ho * wo * 9 * s['c'], s['h'] * s['w'] * s['c'] + ho * wo * s['c'], 9 * s['c'] + 4 * s['c'])
+        return dst
+
+    feats = {}
+    for i in range(1, 14):
+        x = conv(dw(x, f'dw{i}'), f'pw{i}')
+        feats[f'pw{i}'] = x
+    for j in range(1, 5):
+        x = conv(conv(x, f'extra{j}_1'), f'extra{j}_2')
+        feats[f'extra{j}_2'] = x
+    n_cls = Ls['cls0']['w'].shape[3] // nets.SSD_ANCHORS_PER_MAP[0]
+    cls_row = (n_cls + 15) // 16 * 16                        # 91 -> 96 bytes per anchor
+    box_t = P.tensor(n_anchors, 1, 4, cs=4, dtype=DT_U8)
+    cls_t = P.tensor(n_anchors, 1, n_cls, cs=cls_row, dtype=DT_U8)
+    base = 0
+    for k, (fname, a) in enumerate(zip(FEATURE_LAYERS, nets.SSD_ANCHORS_PER_MAP)):
+        ft = feats[fname]
+        fm = P.T(ft)['h']
+        assert fm == maps[k]
+        for other in (f'box{k}', f'cls{k}'):
+            assert (Ls[other]['out_scale'], Ls[other]['out_zp']) == (Ls[other[:3] + '0']['out_scale'], Ls[other[:3] + '0']['out_zp']), \
+                'the six %s tensors are concatenated: they need one (scale, zero point)' % other[:3]
+        conv(ft, f'box{k}', epi=QEPI_ROWS, dst=box_t, row_bytes=4 * a, base_off=4 * base, cout_store=4 * a)
+        cmap = np.full(a * cls_row, -1, np.int64)
+        for an in range(a):
+            cmap[an * cls_row:an * cls_row + n_cls] = an * n_cls + np.arange(n_cls)
+        conv(ft, f'cls{k}', epi=QEPI_ROWS, dst=cls_t, chan_map=cmap, cout_pad=(a * cls_row + 15) // 16 * 16,
+             row_bytes=a * cls_row, base_off=cls_row * base, cout_store=a * cls_row)
+        base += fm * fm * a
+    assert base == n_anchors
+    Lb, Lc = Ls['box0'], Ls['cls0']
+    lut = quantize.logistic_table(Lc['out_scale'], Lc['out_zp'], qm['logistic']['out_scale'], qm['logistic']['out_zp'])
+    P._op(OP_QSSD_DECODE, src=box_t, res=cls_t, w_off=P.add_blob(lut), p=[n_cls, n_anchors],
+          rawf={32: float(Lb['out_scale']), 33: float(Lb['out_zp']), 34: float(qm['logistic']['out_scale']), 35: float(qm['logistic']['out_zp'])})
+    info('q_ssd_decode_k', 0, n_anchors * (4 + cls_row + 24), 256)
+    P.out_tensor = cls_t
+    P.meta = dict(kind='ssd_mobilenet_v1_uint8', anchors=anchors, n_classes=n_cls, box_tensor=box_t, cls_tensor=cls_t, cls_row=cls_row,
+                  feats=feats, quant=True)
+    return P
+
+
+def unpack_q16(raw, h, w, c):
+    """dd_net_read of a bordered tensor ([n][h + 2][c / 16][w + 2][16] bytes) -> u8 NHWC [n][h][w][c] (the interior)."""
+    n = raw.size // ((h + 2) * (w + 2) * c)
+    a = np.asarray(raw, dtype=np.uint8).reshape(n, h + 2, c // 16, w + 2, 16)[:, 1:-1, :, 1:-1, :]
+    return np.ascontiguousarray(np.transpose(a, (0, 1, 3, 2, 4)).reshape(n, h, w, c))
+
+
+def borders_q16(raw, h, w, c):
+    """The border bytes of a bordered tensor, flattened (tests: they must still hold the zero point after a forward)."""
+    n = raw.size // ((h + 2) * (w + 2) * c)
+    a = np.asarray(raw, dtype=np.uint8).reshape(n, h + 2, c // 16, w + 2, 16)
+    return np.concatenate([a[:, 0].reshape(-1), a[:, -1].reshape(-1), a[:, :, :, 0].reshape(-1), a[:, :, :, -1].reshape(-1)])

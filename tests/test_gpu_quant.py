@@ -1,0 +1,97 @@
+"""GPU: the uint8 SSD-MobileNet-v1 program (csrc/netsq.hip) against the integer restatement of TFLite's reference
+kernels (oracle/nets_quant.py).  Integer work: the bar is bit-exact, tensor by tensor, borders included.
+(Parity against the real ssdmobilenetv1.tflite is unpinned: blob and tflite_runtime absent.)"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CHECK = ['conv0', 'dw1', 'pw1', 'dw2', 'pw2', 'pw3', 'dw4', 'pw4', 'pw5', 'pw6', 'dw7', 'pw7', 'pw11', 'dw12', 'pw12', 'dw13', 'pw13',
+         'extra1_1', 'extra1_2', 'extra2_2', 'extra3_2', 'extra4_1', 'extra4_2']
+
+
+def _frames(n, seed):
+    from deepdish_amd import quantize
+    fr = quantize.calibration_frames(n, seed=seed)
+    rng = np.random.default_rng(seed)
+    if n > 1:
+        fr[1] = rng.integers(0, 256, fr[1].shape, dtype=np.uint8)      # white noise: every clamp and both signs of every rounding
+    return fr
+
+
+@pytest.fixture(scope='module', params=['asymmetric', 'symmetric'])
+def qnet(request):
+    from deepdish_amd import quantize, netsq
+    from deepdish_amd.engine import Net
+    qm = quantize.synthetic_ssd_quant_model(1234, symmetric_weights=request.param == 'symmetric')
+    prog = netsq.compile_ssd_mobilenet_quant(qm)
+    return qm, prog, Net(prog, max_batch=8)
+
+
+def _tensor_of(prog, name):
+    """Program tensor written by layer `name` (ops are emitted in the model's order)."""
+    from deepdish_amd import netsq
+    order = ['conv0']
+    for i in range(1, 14):
+        order += [f'dw{i}', f'pw{i}']
+    for j in range(1, 5):
+        order += [f'extra{j}_1', f'extra{j}_2']
+    ops = [o for o in prog.ops if o[0] in (netsq.OP_QCONV0, netsq.OP_QCONV, netsq.OP_QDW)]
+    return int(ops[order.index(name)][2])
+
+
+def test_every_layer_is_bit_exact(qnet):
+    from deepdish_amd import netsq
+    from oracle import nets_quant
+    qm, prog, net = qnet
+    fr = _frames(3, 11)
+    fr[2] = 0
+    net.forward(fr)
+    box_w, cls_w, kept = nets_quant.ssd_quant_forward(qm, fr, keep=CHECK)
+    for name in CHECK:
+        t = _tensor_of(prog, name)
+        d = prog.tensors[t]
+        raw = net.read(tensor=t)
+        got = netsq.unpack_q16(raw, d['h'], d['w'], d['c'])
+        assert got.shape == kept[name].shape, name
+        bad = int((got != kept[name]).sum())
+        assert bad == 0, '%s: %d of %d bytes differ (max |diff| %d)' % (name, bad, got.size, int(np.abs(got.astype(int) - kept[name]).max()))
+        assert (netsq.borders_q16(raw, d['h'], d['w'], d['c']) == d['zp']).all(), name + ': border overwritten'
+    box = net.read(tensor=prog.meta['box_tensor'])[:, :, 0, :]
+    cls = net.read(tensor=prog.meta['cls_tensor'])[:, :, 0, :prog.meta['n_classes']]
+    np.testing.assert_array_equal(box, box_w)
+    np.testing.assert_array_equal(cls, cls_w)
+    assert len(np.unique(cls)) > 100 and len(np.unique(box)) > 50          # not a degenerate comparison
+
+
+def test_results_do_not_depend_on_the_launch(qnet):
+    qm, prog, net = qnet
+    fr = _frames(5, 3)
+    net.forward(fr)
+    cls = net.read(tensor=prog.meta['cls_tensor']).copy()
+    box = net.read(tensor=prog.meta['box_tensor']).copy()
+    net.forward(fr[3:4])
+    np.testing.assert_array_equal(net.read(tensor=prog.meta['cls_tensor']), cls[3:4])
+    np.testing.assert_array_equal(net.read(tensor=prog.meta['box_tensor']), box[3:4])
+
+
+def test_decoded_arrays(qnet):
+    """dd_net_ssd_decode on a uint8 program: the post-process op's first stage from the quantised head tensors."""
+    from oracle import nets_quant
+    qm, prog, net = qnet
+    fr = _frames(2, 5)
+    net.ssd_decode(nets_quant.ssd_anchors(), 0.3)
+    try:
+        net.forward(fr)
+        boxes, score, cls, keys = net.ssd_decoded()
+        box_q = net.read(tensor=prog.meta['box_tensor'])[:, :, 0, :]
+        cls_q = net.read(tensor=prog.meta['cls_tensor'])[:, :, 0, :prog.meta['n_classes']]
+        for z in range(2):
+            wb, ws, wc, wk = nets_quant.ssd_quant_decode(qm, box_q[z], cls_q[z], nets_quant.ssd_anchors(), 0.3)
+            np.testing.assert_array_equal(score[z], ws)
+            np.testing.assert_array_equal(cls[z], wc)
+            np.testing.assert_array_equal(keys[z], wk)
+            np.testing.assert_allclose(boxes[z], wb, rtol=0, atol=2e-6)        # expf: device vs numpy, a few ulp of values <= 2
+        assert (keys >= 0).sum() > 10
+    finally:
+        net.ssd_decode(None, 0.0, enable=False)
