@@ -27,6 +27,7 @@
 // forms give z <= 0, which a ReLU-type clamp (lo >= zo) maps to the same byte; layers without activation (the SSD heads)
 // take the literal two-step form.  tests/test_quant_host.py checks both against the literal gemmlowp statements.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include "common.h"
 #include "ssd_dev.h"
@@ -37,6 +38,8 @@ namespace {
 typedef int i4v __attribute__((ext_vector_type(4)));
 typedef int i2v __attribute__((ext_vector_type(2)));
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
+typedef short s2v __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(4))) int cint;      // read-only data at a wave-uniform address: s_load
 
 enum { OP_QCONV0 = 16, OP_QCONV = 17, OP_QDW = 18, OP_QDWPW = 19, OP_QSSD_DECODE = 20 };
 enum { QEPI_Q16 = 0, QEPI_ROWS = 1 };
@@ -363,12 +366,587 @@ __global__ __launch_bounds__(256) void q_ssd_decode_k(const QDecP P) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ MobileNet block in one launch
+// depthwise 3x3 (stride 1 or 2) -> uint8 -> pointwise 1x1 -> uint8, one read of the block input, one write of its output.
+//
+// A block of NW = (COUT / 64) * WP waves walks a contiguous range of 64-pixel tiles (raster order inside a frame; the last tile of
+// a frame is partly filled).  Per tile:
+//   * rows: the bordered input rows the tile's 3x3 windows touch live in an LDS ring (slot = global row index % NR, a row =
+//     [CIN / 16][W + 2][16] bytes as it lies in HBM).  The rows the NEXT tile adds are requested into registers before the
+//     depthwise stage and written to the ring after it (the slots they replace are dead by then): the ring holds one tile's
+//     rows, not two, and the HBM latency hides behind the depthwise arithmetic.
+//   * depthwise stage (vector ALU): wave item = 64 pixels (lane = pixel) x one plane of 16 channels, so the nine taps are nine
+//     conflict-free ds_read_b128 and the filter is wave-uniform (scalar loads).  Two taps of one channel per v_dot2_i32_i16
+//     (v_perm_b32 builds the {tap, tap} operand; weights w - zw as int16 pairs): 5 + 5 instructions per output, then the
+//     requantisation; the 16 bytes go to the operand tile [plane][pixel][16] -- the MFMA B-fragment image -- as a' = a ^ 0x80,
+//     their sum (v_dot4_u32_u8) to the pixel's row sum.
+//   * pointwise stage (matrix): wave (wm, wp) keeps the A fragments of its 64 output channels for ALL of K in registers for the
+//     whole launch (512 x 64 bytes = 128 VGPRs at most), reads each pixel fragment's K slices once (ds_read_b128, conflict-free),
+//     accumulates from its cbias registers, adds zwc * rowsum, requantises and stores 16 bytes per lane (the host packed fragment
+//     m's row 4g + r with channel 64 wm + 16 g + 4 m + r: a lane holds one pixel's 16 channels of plane 4 wm + g).
+// Two barriers per tile.
+struct QDwpwP {
+    const uint8_t *in; int H, W;
+    int off_y, off_x, ho, wo, hw, tiles_per_frame;
+    uint8_t *out; int c16_out;
+    const int *dw_w;                 // [CIN][5]: int16 pairs (w_t - zw) of taps (0,1) (2,3) (4,5) (6,7) (8,-)
+    const int *dw_cb;                // [CIN]: bias - za * sum_t (w_t - zw)
+    const i4v *w;                    // [COUT / 64][4][KC][64 lanes]
+    const int *cbias;                // [COUT]
+    int zwc, NR;
+    unsigned rb_magic, hb_magic;     // floor(2^32 / row bytes) + 1; the same for half a row
+    unsigned long long *dbg;         // DD_Q_STAMPS=1: per wave, cycles spent in each part of the tile loop (diagnostic launches only)
+    QReq Rd, Rp;
+};
+
+constexpr int QT = 64;               // pixels per tile
+
+__device__ __forceinline__ int q_requant_relu(int x, int M, long long C, int sh32) {      // e >= 1: z = (x M + C) >> (32 + sh32)
+    const long long t = (long long)x * M + C;
+    return ((int)(t >> 32)) >> sh32;
+}
+__device__ __forceinline__ int q_clamp(int z, int lo, int hi) {                           // lo <= hi: one v_med3_i32 (min(max()) is two instructions)
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(z), "s"(lo), "v"(hi));     // one scalar operand per vector instruction (constant bus)
+    return r;
+}
+
+template <int CIN, int COUT, int WP, int STRIDE, int LPT, bool ROWSUM>
+__global__ __launch_bounds__((COUT / 64) * WP * 64) void q_dwpw_k(const QDwpwP P, const int n_tiles, const int tiles_per_block) {
+    constexpr int WM = COUT / 64, NW = WM * WP, NT = NW * 64;
+    constexpr int KC = (CIN + 63) / 64, CINP = KC * 64, C16 = CIN / 16;
+    constexpr int NITEMS = C16;                                     // depthwise wave items per tile (64 pixels x 16 channels each)
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int wm = wave / WP, wp = wave % WP;
+    const int RB = (P.W + 2) * CIN, PP = (P.W + 2) * 16;           // ring row / plane pitch (bytes)
+    uint8_t *ring = smem;
+    uint8_t *opnd = smem + (size_t)P.NR * RB;                       // [CINP / 16][QT][16]
+    int *rowsum = reinterpret_cast<int *>(opnd + QT * CINP);        // [2][QT]
+    unsigned *pixoff = reinterpret_cast<unsigned *>(rowsum + 2 * QT);   // [QT]
+
+    // the wave's pointwise filter and per-channel constants, once
+    i4v Wr[4][KC];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) Wr[m][kc] = P.w[((size_t)(wm * 4 + m) * KC + kc) * 64 + lane];
+    i4v cb[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) cb[m] = *reinterpret_cast<const i4v *>(P.cbias + 64 * wm + 16 * fq + 4 * m);
+    if (CIN < CINP) for (int i = tid; i < QT * CINP / 16; i += NT) reinterpret_cast<u4v *>(opnd)[i] = u4v{0, 0, 0, 0};   // k slots without channels
+    for (int i = tid; i < 2 * QT; i += NT) rowsum[i] = 0;
+
+    const int t_begin = blockIdx.x * tiles_per_block, t_end = min(n_tiles, t_begin + tiles_per_block);
+    if (t_begin >= t_end) return;
+    const int Md = P.Rd.M, shd = P.Rd.e - 1, Mp = P.Rp.M, shp = P.Rp.e - 1;
+    const long long Cd = P.Rd.C, Cp = P.Rp.C;
+    const int lod = P.Rd.lo, hid = P.Rd.hi, lop = P.Rp.lo, hip_ = P.Rp.hi;
+
+    auto tile_rows = [&](int t, int &n, int &q0, int &q1, int &ga, int &gb) {
+        n = t / P.tiles_per_frame;
+        q0 = (t - n * P.tiles_per_frame) * QT;
+        q1 = min(q0 + QT, P.hw) - 1;
+        const int y0 = q0 / P.wo, y1 = q1 / P.wo;
+        ga = n * (P.H + 2) + y0 * STRIDE + P.off_y;
+        gb = n * (P.H + 2) + y1 * STRIDE + P.off_y + 2;
+    };
+    int n, q0, q1, ga, gb;
+    tile_rows(t_begin, n, q0, q1, ga, gb);
+    {   // the first tile's rows, synchronously
+        const unsigned nb = (unsigned)(gb - ga + 1) * RB;
+        const uint8_t *src = P.in + (size_t)ga * RB;
+        for (unsigned idx = tid * 16u; idx < nb; idx += NT * 16u) {
+            const unsigned row = idx / (unsigned)RB, off = idx - row * RB;
+            *reinterpret_cast<u4v *>(ring + (size_t)((ga + row) % P.NR) * RB + off) = *reinterpret_cast<const u4v *>(src + idx);
+        }
+    }
+    int loaded_hi = gb;
+    __syncthreads();
+
+    unsigned long long st[6] = {0, 0, 0, 0, 0, 0}, tprev = P.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+#define Q_STAMP(k) do { if (P.dbg) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st[k] += now_ - tprev; tprev = now_; } } while (0)
+    for (int t = t_begin; t < t_end; ++t) {
+        // ---- which rows the next tile adds
+        int lo = 0; unsigned nb = 0;
+        int n2 = 0, q02 = 0, q12 = 0, ga2 = 0, gb2 = 0;
+        if (t + 1 < t_end) {
+            tile_rows(t + 1, n2, q02, q12, ga2, gb2);
+            lo = max(loaded_hi + 1, ga2);
+            nb = gb2 >= lo ? (unsigned)(gb2 - lo + 1) * RB : 0u;
+            loaded_hi = max(loaded_hi, gb2);
+        }
+        // ---- per-lane geometry of this tile
+        const int cur = t & 1;
+        if (tid < QT) {
+            const int q = q0 + tid;
+            unsigned po = 0xffffffffu;
+            if (q <= q1) {
+                const int y = q / P.wo, x = q - y * P.wo;
+                po = (unsigned)(((size_t)n * (P.ho + 2) + y + 1) * P.c16_out * ((P.wo + 2) * 16) + (size_t)(x + 1) * 16);
+            }
+            pixoff[tid] = po;
+        }
+        // ---- depthwise stage
+        {
+            const int q = min(q0 + lane, q1);
+            const int y = q / P.wo, x = q - y * P.wo;
+            const int g0 = n * (P.H + 2) + y * STRIDE + P.off_y;
+            const int s0 = g0 % P.NR, s1 = s0 + 1 == P.NR ? 0 : s0 + 1, s2 = s1 + 1 == P.NR ? 0 : s1 + 1;
+            const int col = (x * STRIDE + P.off_x) * 16;
+            const uint8_t *r0 = ring + (size_t)s0 * RB + col, *r1 = ring + (size_t)s1 * RB + col, *r2 = ring + (size_t)s2 * RB + col;
+            unsigned rs = 0;
+            // the filter of an item is wave-uniform: constant address space = scalar loads (hipcc otherwise loads it through the
+            // vector memory path, one dependent round trip per four taps: 25 of them per item)
+            const cint *dww = (const cint *)(const void *)P.dw_w, *dwc = (const cint *)(const void *)P.dw_cb;
+            for (int it = wave; it < NITEMS; it += NW) {
+                const int cg = __builtin_amdgcn_readfirstlane(it);
+                const int po = cg * PP;
+                u4v tap[9];
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    tap[dx] = *reinterpret_cast<const u4v *>(r0 + po + dx * 16);
+                    tap[3 + dx] = *reinterpret_cast<const u4v *>(r1 + po + dx * 16);
+                    tap[6 + dx] = *reinterpret_cast<const u4v *>(r2 + po + dx * 16);
+                }
+                u4v o;
+                int wq[2][20], wc[2][4];                                // filter pairs and constants of a channel quad (scalar registers), double-buffered
+                {
+                    const cint *a = dww + cg * 80, *b = dwc + cg * 16;
+#pragma unroll
+                    for (int k = 0; k < 20; ++k) wq[0][k] = a[k];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) wc[0][k] = b[k];
+                }
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    if (d < 3) {                                        // the next quad's filter is requested before this quad's arithmetic
+                        const cint *a = dww + cg * 80 + (d + 1) * 20, *b = dwc + cg * 16 + (d + 1) * 4;
+#pragma unroll
+                        for (int k = 0; k < 20; ++k) wq[(d + 1) & 1][k] = a[k];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) wc[(d + 1) & 1][k] = b[k];
+                    }
+                    unsigned packed = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const unsigned sel = 0x0c000c00u | (unsigned)j | ((unsigned)(4 + j) << 16);
+                        int acc = wc[d & 1][j];
+#pragma unroll
+                        for (int pr = 0; pr < 4; ++pr) {
+                            const unsigned pa = __builtin_amdgcn_perm(tap[2 * pr + 1][d], tap[2 * pr][d], sel);
+                            acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(s2v, pa), __builtin_bit_cast(s2v, wq[d & 1][j * 5 + pr]), acc, false);
+                        }
+                        {
+                            const unsigned pa = __builtin_amdgcn_perm(0u, tap[8][d], 0x0c0c0c00u | (unsigned)j);
+                            acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(s2v, pa), __builtin_bit_cast(s2v, wq[d & 1][j * 5 + 4]), acc, false);
+                        }
+                        const int z = q_clamp(q_requant_relu(acc, Md, Cd, shd), lod, hid);
+                        packed |= (unsigned)z << (8 * j);
+                    }
+                    o[d] = packed;
+                    if (ROWSUM) rs = __builtin_amdgcn_udot4(packed, 0x01010101u, rs, false);
+                }
+                o ^= 0x80808080u;
+                *reinterpret_cast<u4v *>(opnd + ((size_t)cg * QT + lane) * 16) = o;
+            }
+            if (ROWSUM) atomicAdd(&rowsum[cur * QT + lane], (int)rs);
+        }
+        Q_STAMP(0);
+        __syncthreads();                                             // A: operand tile, row sums and pixel offsets are complete; the ring is free
+        Q_STAMP(1);
+        // ---- request the next tile's rows (registers; they go to the ring when the matrix stage below is done: the slots they
+        // replace are dead since barrier A, and the HBM latency hides behind the MFMAs)
+        u4v pf[LPT];
+        if (nb) {                                                    // (uniform) every request goes out back to back: no lane predicate, the
+            const uint8_t *src = P.in + (size_t)lo * RB;             // pieces past the end re-read the last one and are dropped at the write
+#pragma unroll
+            for (int i = 0; i < LPT; ++i) pf[i] = *reinterpret_cast<const u4v *>(src + min((unsigned)(i * NT + tid) * 16u, nb - 16u));
+        }
+        if (tid < QT) rowsum[(cur ^ 1) * QT + tid] = 0;
+        // ---- pointwise stage
+        const int nf = (q1 - q0) / 16 + 1;
+        for (int f = wp; f < nf; f += WP) {
+            i4v acc[4];
+            const uint8_t *bp = opnd + ((size_t)fq * QT + 16 * f + fr) * 16;
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
+                const i4v b = *reinterpret_cast<const i4v *>(bp + (size_t)kc * 4 * QT * 16);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Wr[m][kc], b, kc == 0 ? cb[m] : acc[m], 0, 0, 0);
+            }
+            const int rsv = ROWSUM ? rowsum[cur * QT + 16 * f + fr] * P.zwc : 0;
+            const unsigned po = pixoff[16 * f + fr];
+            u4v o;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                unsigned packed = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int z = q_clamp(q_requant_relu(acc[m][r] + rsv, Mp, Cp, shp), lop, hip_);
+                    packed |= (unsigned)z << (8 * r);
+                }
+                o[m] = packed;
+            }
+            if (po != 0xffffffffu) *reinterpret_cast<u4v *>(P.out + po + (size_t)(4 * wm + fq) * ((P.wo + 2) * 16)) = o;
+        }
+        Q_STAMP(2);
+        if (nb) {
+            unsigned tid16 = (unsigned)tid * 16u;
+            asm volatile("" : "+v"(tid16));                          // keeps the eight (row, offset) pairs from being hoisted out of the tile loop (16 live registers: spills)
+            int slot0 = lo % P.NR;
+#pragma unroll
+            for (int i = 0; i < LPT; ++i) {
+                const unsigned idx = (unsigned)(i * NT) * 16u + tid16;
+                if (idx < nb) {
+                    const unsigned row = __umulhi(idx, P.rb_magic), off = idx - row * RB;      // idx / RB (exact: idx * RB < 2^32)
+                    int slot = slot0 + (int)row;
+                    slot = slot >= P.NR ? slot - P.NR : slot;
+                    slot = slot >= P.NR ? slot - P.NR : slot;
+                    *reinterpret_cast<u4v *>(ring + (size_t)slot * RB + off) = pf[i];
+                }
+            }
+        }
+        Q_STAMP(3);
+        __syncthreads();                                             // B: the operand tile is free, the ring holds the next tile's rows
+        Q_STAMP(4);
+        n = n2; q0 = q02; q1 = q12; ga = ga2; gb = gb2;
+    }
+#undef Q_STAMP
+    if (P.dbg && lane == 0) for (int k = 0; k < 5; ++k) P.dbg[((size_t)blockIdx.x * NW + wave) * 8 + k] = st[k];
+}
+
+// ---- q_dwpw_k with the two stages of consecutive tiles overlapped (the form that runs; DD_Q_TEAMS=0 keeps the one above).
+// The block's waves form two teams (the lower and the upper half of the wave numbers: with eight waves one of each per SIMD).
+// A tile step has two phases, one barrier each:
+//     phase 1   team A: matrix stage of tile t (its channels)          team B: depthwise stage of tile t + 1, planes [0, C16/2)
+//     phase 2   team B: matrix stage of tile t                         team A: depthwise stage of tile t + 1, planes [C16/2, C16)
+// so a SIMD always holds one wave issuing MFMAs and one issuing vector instructions (in q_dwpw_k every wave is in the same stage,
+// the matrix pipe idles during the depthwise stage and the vector ALUs during the matrix stage: 22 k cycles per tile where the
+// arithmetic needs 9 k).  The operand tile, the pixel offsets (x2) and the row sums (x3) are multi-buffered.  Ring rows: a row is
+// [lower planes | upper planes]; the lower halves of the rows tile t + 2 adds are requested in phase 1 and written in phase 2
+// (team B's depthwise stage, their last reader, is behind the barrier), the upper halves requested in phase 2 and written in
+// phase 1 of the next step -- still one tile's rows in the ring, no extra barrier.
+template <int CIN, int COUT, int WP, int STRIDE, int LPH, bool ROWSUM>
+__global__ __launch_bounds__((COUT / 64) * WP * 64) void q_dwpw2_k(const QDwpwP P, const int n_tiles, const int tiles_per_block) {
+    constexpr int WM = COUT / 64, NW = WM * WP, NT = NW * 64, NWT = NW / 2;
+    constexpr int KC = (CIN + 63) / 64, CINP = KC * 64, C16 = CIN / 16, CH = C16 / 2;
+    static_assert(NW % 2 == 0 && C16 % 2 == 0 && CH % NWT == 0 || NWT % CH == 0, "teams");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int wm = wave / WP, wp = wave % WP;
+    const int team = wave >= NWT, wt = wave - team * NWT;             // team 0 = A
+    const int RB = (P.W + 2) * CIN, PP = (P.W + 2) * 16, HB = RB / 2;
+    uint8_t *ring = smem;
+    uint8_t *opnd = smem + (size_t)P.NR * RB;                       // [2][CINP / 16][QT][16]
+    int *rowsum = reinterpret_cast<int *>(opnd + 2 * QT * CINP);    // [3][QT]
+    unsigned *pixoff = reinterpret_cast<unsigned *>(rowsum + 3 * QT);   // [2][QT]
+
+    i4v Wr[4][KC];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) Wr[m][kc] = P.w[((size_t)(wm * 4 + m) * KC + kc) * 64 + lane];
+    if (CIN < CINP) for (int i = tid; i < 2 * QT * CINP / 16; i += NT) reinterpret_cast<u4v *>(opnd)[i] = u4v{0, 0, 0, 0};
+    for (int i = tid; i < 3 * QT; i += NT) rowsum[i] = 0;
+
+    const int t_begin = blockIdx.x * tiles_per_block, t_end = min(n_tiles, t_begin + tiles_per_block);
+    if (t_begin >= t_end) return;
+    const int Md = P.Rd.M, shd = P.Rd.e - 1, Mp = P.Rp.M, shp = P.Rp.e - 1;
+    const long long Cd = P.Rd.C, Cp = P.Rp.C;
+    const int lod = P.Rd.lo, hid = P.Rd.hi, lop = P.Rp.lo, hip_ = P.Rp.hi;
+    const cint *dww = (const cint *)(const void *)P.dw_w, *dwc = (const cint *)(const void *)P.dw_cb;
+
+    auto tile_rows = [&](int t, int &n, int &q0, int &q1, int &ga, int &gb) {
+        n = t / P.tiles_per_frame;
+        q0 = (t - n * P.tiles_per_frame) * QT;
+        q1 = min(q0 + QT, P.hw) - 1;
+        const int y0 = q0 / P.wo, y1 = q1 / P.wo;
+        ga = n * (P.H + 2) + y0 * STRIDE + P.off_y;
+        gb = n * (P.H + 2) + y1 * STRIDE + P.off_y + 2;
+    };
+    auto slot_of = [&](int g) { return g % P.NR; };
+    // whole rows [lo, lo + nrows) into the ring, synchronously (start of the block's range only)
+    auto load_rows_sync = [&](int lo, int nrows) {
+        const unsigned nb = (unsigned)nrows * RB;
+        const uint8_t *src = P.in + (size_t)lo * RB;
+        for (unsigned idx = tid * 16u; idx < nb; idx += NT * 16u) {
+            const unsigned row = idx / (unsigned)RB, off = idx - row * RB;
+            *reinterpret_cast<u4v *>(ring + (size_t)slot_of(lo + (int)row) * RB + off) = *reinterpret_cast<const u4v *>(src + idx);
+        }
+    };
+    // ---- depthwise stage of one tile for planes [h * CH, (h + 1) * CH), by the calling team
+    auto dw_half = [&](int n, int q0, int q1, int h, int buf, int rsb) {
+        const int q = min(q0 + lane, q1);
+        const int y = q / P.wo, x = q - y * P.wo;
+        const int g0 = n * (P.H + 2) + y * STRIDE + P.off_y;
+        const int s0 = g0 % P.NR, s1 = s0 + 1 == P.NR ? 0 : s0 + 1, s2 = s1 + 1 == P.NR ? 0 : s1 + 1;
+        const int col = (x * STRIDE + P.off_x) * 16;
+        const uint8_t *r0 = ring + (size_t)s0 * RB + col, *r1 = ring + (size_t)s1 * RB + col, *r2 = ring + (size_t)s2 * RB + col;
+        uint8_t *ob = opnd + (size_t)buf * QT * CINP;
+        unsigned rs = 0;
+        for (int it = h * CH + wt; it < (h + 1) * CH; it += NWT) {
+            const int cg = __builtin_amdgcn_readfirstlane(it);
+            const int po = cg * PP;
+            u4v tap[9];
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                tap[dx] = *reinterpret_cast<const u4v *>(r0 + po + dx * 16);
+                tap[3 + dx] = *reinterpret_cast<const u4v *>(r1 + po + dx * 16);
+                tap[6 + dx] = *reinterpret_cast<const u4v *>(r2 + po + dx * 16);
+            }
+            u4v o;
+            int wq[2][20], wc[2][4];
+            {
+                const cint *a = dww + cg * 80, *b = dwc + cg * 16;
+#pragma unroll
+                for (int k = 0; k < 20; ++k) wq[0][k] = a[k];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) wc[0][k] = b[k];
+            }
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                if (d < 3) {
+                    const cint *a = dww + cg * 80 + (d + 1) * 20, *b = dwc + cg * 16 + (d + 1) * 4;
+#pragma unroll
+                    for (int k = 0; k < 20; ++k) wq[(d + 1) & 1][k] = a[k];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) wc[(d + 1) & 1][k] = b[k];
+                }
+                unsigned packed = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned sel = 0x0c000c00u | (unsigned)j | ((unsigned)(4 + j) << 16);
+                    int acc = wc[d & 1][j];
+#pragma unroll
+                    for (int pr = 0; pr < 4; ++pr) {
+                        const unsigned pa = __builtin_amdgcn_perm(tap[2 * pr + 1][d], tap[2 * pr][d], sel);
+                        acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(s2v, pa), __builtin_bit_cast(s2v, wq[d & 1][j * 5 + pr]), acc, false);
+                    }
+                    {
+                        const unsigned pa = __builtin_amdgcn_perm(0u, tap[8][d], 0x0c0c0c00u | (unsigned)j);
+                        acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(s2v, pa), __builtin_bit_cast(s2v, wq[d & 1][j * 5 + 4]), acc, false);
+                    }
+                    const int z = q_clamp(q_requant_relu(acc, Md, Cd, shd), lod, hid);
+                    packed |= (unsigned)z << (8 * j);
+                }
+                o[d] = packed;
+                if (ROWSUM) rs = __builtin_amdgcn_udot4(packed, 0x01010101u, rs, false);
+            }
+            o ^= 0x80808080u;
+            *reinterpret_cast<u4v *>(ob + ((size_t)cg * QT + lane) * 16) = o;
+        }
+        if (ROWSUM) atomicAdd(&rowsum[rsb * QT + lane], (int)rs);
+    };
+    auto pix_offsets = [&](int n, int q0, int q1, int buf, int idx) {       // idx in [0, QT)
+        const int q = q0 + idx;
+        unsigned po = 0xffffffffu;
+        if (q <= q1) {
+            const int y = q / P.wo, x = q - y * P.wo;
+            po = (unsigned)(((size_t)n * (P.ho + 2) + y + 1) * P.c16_out * ((P.wo + 2) * 16) + (size_t)(x + 1) * 16);
+        }
+        pixoff[buf * QT + idx] = po;
+    };
+    // ---- matrix stage of one tile for this wave's channels / fragments
+    auto matrix = [&](int q0, int q1, int buf, int rsb) {
+        i4v cb[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) cb[m] = *reinterpret_cast<const i4v *>(P.cbias + 64 * wm + 16 * fq + 4 * m);
+        const uint8_t *ob = opnd + (size_t)buf * QT * CINP;
+        const int nf = (q1 - q0) / 16 + 1;
+        for (int f = wp; f < nf; f += WP) {
+            i4v acc[4];
+            const uint8_t *bp = ob + ((size_t)fq * QT + 16 * f + fr) * 16;
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
+                const i4v b = *reinterpret_cast<const i4v *>(bp + (size_t)kc * 4 * QT * 16);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Wr[m][kc], b, kc == 0 ? cb[m] : acc[m], 0, 0, 0);
+            }
+            const int rsv = ROWSUM ? rowsum[rsb * QT + 16 * f + fr] * P.zwc : 0;
+            const unsigned po = pixoff[buf * QT + 16 * f + fr];
+            u4v o;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                unsigned packed = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int z = q_clamp(q_requant_relu(acc[m][r] + rsv, Mp, Cp, shp), lop, hip_);
+                    packed |= (unsigned)z << (8 * r);
+                }
+                o[m] = packed;
+            }
+            if (po != 0xffffffffu) *reinterpret_cast<u4v *>(P.out + po + (size_t)(4 * wm + fq) * ((P.wo + 2) * 16)) = o;
+        }
+    };
+    // half rows: pieces of the lower (half = 0) or upper plane halves of rows [lo, lo + nrows)
+    auto pf_request = [&](u4v (&pf)[LPH], int lo, int nrows, int half) {
+        if (nrows <= 0) return;
+        const unsigned nb = (unsigned)nrows * HB;
+#pragma unroll
+        for (int i = 0; i < LPH; ++i) {
+            const unsigned idx = min((unsigned)(i * NT + tid) * 16u, nb - 16u);
+            const unsigned row = __umulhi(idx, P.hb_magic), off = idx - row * HB;
+            pf[i] = *reinterpret_cast<const u4v *>(P.in + ((size_t)lo + row) * RB + (size_t)half * HB + off);
+        }
+    };
+    auto pf_write = [&](const u4v (&pf)[LPH], int lo, int nrows, int half) {
+        if (nrows <= 0) return;
+        const unsigned nb = (unsigned)nrows * HB;
+        unsigned tid16 = (unsigned)tid * 16u;
+        asm volatile("" : "+v"(tid16));
+        const int slot0 = lo % P.NR;
+#pragma unroll
+        for (int i = 0; i < LPH; ++i) {
+            const unsigned idx = (unsigned)(i * NT) * 16u + tid16;
+            if (idx < nb) {
+                const unsigned row = __umulhi(idx, P.hb_magic), off = idx - row * HB;
+                int slot = slot0 + (int)row;
+                slot = slot >= P.NR ? slot - P.NR : slot;
+                slot = slot >= P.NR ? slot - P.NR : slot;
+                *reinterpret_cast<u4v *>(ring + (size_t)slot * RB + (size_t)half * HB + off) = pf[i];
+            }
+        }
+    };
+
+    // ---- prologue: the first tile's rows and depthwise stage, the second tile's rows
+    int n, q0, q1, ga, gb;
+    tile_rows(t_begin, n, q0, q1, ga, gb);
+    load_rows_sync(ga, gb - ga + 1);
+    int loaded_hi = gb;
+    __syncthreads();
+    dw_half(n, q0, q1, team ? 0 : 1, t_begin & 1, t_begin % 3);
+    if (tid < QT) pix_offsets(n, q0, q1, t_begin & 1, tid);
+    int n1 = 0, q01 = 0, q11 = 0, ga1 = 0, gb1 = 0;                 // tile t + 1
+    __syncthreads();
+    if (t_begin + 1 < t_end) {
+        tile_rows(t_begin + 1, n1, q01, q11, ga1, gb1);
+        const int lo = max(loaded_hi + 1, ga1);
+        if (gb1 >= lo) load_rows_sync(lo, gb1 - lo + 1);
+        loaded_hi = max(loaded_hi, gb1);
+    }
+    __syncthreads();
+
+    u4v pfL[LPH], pfU[LPH];
+    int loU = 0, nrU = 0;                                           // upper halves requested in the previous step, to be written in this one
+    for (int t = t_begin; t < t_end; ++t) {
+        const bool has1 = t + 1 < t_end, has2 = t + 2 < t_end;
+        int n2 = 0, q02 = 0, q12 = 0, ga2 = 0, gb2 = 0, lo2 = 0, nr2 = 0;
+        if (has2) {
+            tile_rows(t + 2, n2, q02, q12, ga2, gb2);
+            lo2 = max(loaded_hi + 1, ga2);
+            nr2 = max(0, gb2 - lo2 + 1);
+            loaded_hi = max(loaded_hi, gb2);
+        }
+        const int b0 = t & 1, b1 = b0 ^ 1, r0i = t % 3, r1i = (t + 1) % 3, r2i = (t + 2) % 3;
+        // ---- phase 1
+        pf_request(pfL, lo2, nr2, 0);
+        pf_write(pfU, loU, nrU, 1);
+        if (!team) matrix(q0, q1, b0, r0i);
+        else {
+            if (has1) dw_half(n1, q01, q11, 0, b1, r1i);
+            if (wt == 0 && has1) pix_offsets(n1, q01, q11, b1, lane);
+            if (wt == 0) rowsum[r2i * QT + lane] = 0;
+        }
+        __syncthreads();
+        // ---- phase 2
+        pf_request(pfU, lo2, nr2, 1);
+        loU = lo2; nrU = nr2;
+        pf_write(pfL, lo2, nr2, 0);
+        if (team) matrix(q0, q1, b0, r0i);
+        else if (has1) dw_half(n1, q01, q11, 1, b1, r1i);
+        __syncthreads();
+        n = n1; q0 = q01; q1 = q11;
+        n1 = n2; q01 = q02; q11 = q12;
+    }
+}
+
 QReq make_req(const int32_t *o) {
     QReq R;
     R.M = o[32]; R.e = o[33];
     R.zo = o[40]; R.lo = o[36]; R.hi = o[37]; R.linear = o[41];
     R.C = (1ll << 30) + (R.e > 0 ? (1ll << (30 + R.e)) : 0) + ((long long)R.zo << (31 + R.e));
     return R;
+}
+
+
+// Ring rows and prefetch depth of q_dwpw_k for this geometry (tiles of one frame and the step into the next frame).
+void dwpw_plan(int H, int W, int ho, int wo, int stride, int off_y, int cin, int nt, int *NR, int *lpt) {
+    const int hw = ho * wo, tpf = dd_ceil_div(hw, QT), RB = (W + 2) * cin;
+    int span = 0, hi = 0, mx = 0;
+    for (int n = 0; n < 2; ++n)
+        for (int k = 0; k < tpf; ++k) {
+            const int q0 = k * QT, q1 = std::min(q0 + QT, hw) - 1;
+            const int ga = n * (H + 2) + (q0 / wo) * stride + off_y, gb = n * (H + 2) + (q1 / wo) * stride + off_y + 2;
+            span = std::max(span, gb - ga + 1);
+            if (n || k) { const int lo = std::max(hi + 1, ga); mx = std::max(mx, gb - lo + 1); }
+            hi = std::max(hi, gb);
+        }
+    *NR = span;
+    *lpt = (int)(((long long)mx * RB + (long long)nt * 16 - 1) / ((long long)nt * 16));
+}
+
+template <int CIN, int COUT, int WP, int STRIDE, int LPT>
+int launch_q_dwpw(hipStream_t s, QDwpwP &P, int nimg, int device, bool *ok) {
+    constexpr int NW = (COUT / 64) * WP, NT = NW * 64, CINP = (CIN + 63) / 64 * 64, LPH = (LPT + 1) / 2;
+    static const bool teams = !(getenv("DD_Q_TEAMS") && atoi(getenv("DD_Q_TEAMS")) == 0);      // A/B switch: 0 = every wave in the same stage (q_dwpw_k)
+    int lpt = 0;
+    dwpw_plan(P.H, P.W, P.ho, P.wo, STRIDE, P.off_y, CIN, NT, &P.NR, &lpt);
+    const int RB = (P.W + 2) * CIN;
+    const size_t lds = (size_t)P.NR * RB + (size_t)(teams ? 2 : 1) * QT * CINP + (teams ? 5 : 3) * QT * sizeof(int);
+    P.rb_magic = (unsigned)((1ull << 32) / (unsigned)RB) + 1u;
+    P.hb_magic = (unsigned)((1ull << 32) / (unsigned)(RB / 2)) + 1u;
+    *ok = lpt <= LPT && (lpt + 1) / 2 <= LPH && lds <= 160 * 1024 && (long long)LPT * NT * 16 * RB < (1ll << 32) && (LPT * NT * 16) / RB + 1 <= 2 * P.NR;
+    if (!*ok) return DD_OK;
+    const bool rsum = P.zwc != 0;
+    static DevOnce once;
+    const int rc = once.run(device, [&]() -> int {
+        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&q_dwpw2_k<CIN, COUT, WP, STRIDE, LPH, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&q_dwpw2_k<CIN, COUT, WP, STRIDE, LPH, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        return DD_OK;
+    });
+    if (rc != DD_OK) return rc;
+    static std::atomic<int> per_cu_cache[64];
+    int per_cu = per_cu_cache[device & 63].load(std::memory_order_relaxed);
+    if (per_cu == 0) {
+        int nb = 0;
+        if (teams) DD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&q_dwpw2_k<CIN, COUT, WP, STRIDE, LPH, true>), NT, lds));
+        else DD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, true>), NT, lds));
+        per_cu = std::max(1, std::min(8, nb));
+        per_cu_cache[device & 63].store(per_cu, std::memory_order_relaxed);
+    }
+    const int n_tiles = nimg * P.tiles_per_frame;
+    const int blocks = std::min(n_tiles, per_cu * 256);
+    const int tpb = dd_ceil_div(n_tiles, blocks);
+    const dim3 grid((unsigned)dd_ceil_div(n_tiles, tpb));
+    if (teams) {
+        if (rsum) hipLaunchKernelGGL((q_dwpw2_k<CIN, COUT, WP, STRIDE, LPH, true>), grid, dim3(NT), lds, s, P, n_tiles, tpb);
+        else hipLaunchKernelGGL((q_dwpw2_k<CIN, COUT, WP, STRIDE, LPH, false>), grid, dim3(NT), lds, s, P, n_tiles, tpb);
+        DD_LAUNCH_CHECK();
+        return DD_OK;
+    }
+    static const bool stamps = getenv("DD_Q_STAMPS") && atoi(getenv("DD_Q_STAMPS")) != 0;
+    const size_t n_st = (size_t)grid.x * NW * 8;
+    if (stamps) { DD_HIP(hipMalloc(&P.dbg, n_st * 8)); DD_HIP(hipMemsetAsync(P.dbg, 0, n_st * 8, s)); }
+    if (rsum) hipLaunchKernelGGL((q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, true>), grid, dim3(NT), lds, s, P, n_tiles, tpb);
+    else hipLaunchKernelGGL((q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, false>), grid, dim3(NT), lds, s, P, n_tiles, tpb);
+    DD_LAUNCH_CHECK();
+    if (stamps) {                                                   // diagnostic: where the waves of this launch spent their cycles
+        std::vector<unsigned long long> h(n_st);
+        DD_HIP(hipStreamSynchronize(s));
+        DD_HIP(hipMemcpy(h.data(), P.dbg, n_st * 8, hipMemcpyDeviceToHost));
+        DD_HIP(hipFree(P.dbg));
+        double sum[5] = {0, 0, 0, 0, 0};
+        for (size_t w = 0; w < n_st / 8; ++w) for (int k = 0; k < 5; ++k) sum[k] += (double)h[w * 8 + k];
+        const double nw = (double)(n_st / 8) * tpb;
+        fprintf(stderr, "q_dwpw_k<%d,%d,%d> %d tiles/block: cycles per wave and tile: depthwise %.0f  barrier A %.0f  matrix stage %.0f  ring write %.0f  barrier B %.0f\n",
+                CIN, COUT, STRIDE, tpb, sum[0] / nw, sum[1] / nw, sum[2] / nw, sum[3] / nw, sum[4] / nw);
+    }
+    return DD_OK;
 }
 
 }  // namespace
@@ -447,6 +1025,38 @@ int netq_run_op(dd_net *net, int i, const int32_t *o, const uint8_t *input, int 
             DD_REQUIRE(P.total < (1ll << 31) * 256, DD_E_CAPACITY, "dd_net_forward: uint8 depthwise %d: too many items", i);
             hipLaunchKernelGGL(q_dw_k, dim3((unsigned)((P.total + 255) / 256)), dim3(256), 0, s, P);
             DD_LAUNCH_CHECK();
+            return DD_OK;
+        }
+        case OP_QDWPW: {
+            QDwpwP P;
+            memset(&P, 0, sizeof(P));
+            DD_REQUIRE(ts->pad == 1 && td->pad == 1 && ts->cs % 16 == 0 && td->cs % 64 == 0, DD_E_ARG, "dd_net_forward: uint8 block %d: tensor layouts", i);
+            const int stride = o[7], cin = o[10], cout = o[11];
+            P.in = base(src); P.H = ts->h; P.W = ts->w;
+            P.off_y = 1 - o[8]; P.off_x = 1 - o[9]; P.ho = td->h; P.wo = td->w; P.hw = P.ho * P.wo; P.tiles_per_frame = dd_ceil_div(P.hw, QT);
+            P.out = base(dst); P.c16_out = td->cs / 16;
+            P.dw_w = reinterpret_cast<const int *>(W + (size_t)(uint32_t)o[20]);
+            P.dw_cb = reinterpret_cast<const int *>(W + (size_t)(uint32_t)o[21]);
+            P.w = reinterpret_cast<const i4v *>(W + (size_t)(uint32_t)o[16]);
+            P.cbias = reinterpret_cast<const int *>(W + (size_t)(uint32_t)o[17]);
+            P.zwc = o[38]; P.Rp = make_req(o);
+            { int32_t d[48] = {0}; d[32] = o[22]; d[33] = o[23]; d[36] = o[24]; d[37] = o[25]; d[40] = o[28]; P.Rd = make_req(d); }
+            DD_REQUIRE(cin == ts->cs && cout == td->cs && P.Rd.e >= 1 && P.Rp.e >= 1 && !P.Rd.linear && !P.Rp.linear && P.off_y >= 0 && P.off_x >= 0 &&
+                       (P.ho - 1) * stride + 2 + P.off_y <= P.H + 1 && (P.wo - 1) * stride + 2 + P.off_x <= P.W + 1, DD_E_ARG,
+                       "dd_net_forward: uint8 block %d: shapes / multipliers the fused kernel does not take", i);
+            DD_REQUIRE((double)nimg * (P.ho + 2) * (P.wo + 2) * td->cs < 4294967296.0, DD_E_CAPACITY, "dd_net_forward: uint8 block %d: output beyond 32-bit offsets", i);
+            bool ok = false;
+            int rc = DD_OK;
+            const int dev = net->ctx->device;
+            if (cin == 32 && cout == 64 && stride == 1) rc = launch_q_dwpw<32, 64, 2, 1, 8>(s, P, nimg, dev, &ok);
+            else if (cin == 64 && cout == 128 && stride == 2) rc = launch_q_dwpw<64, 128, 2, 2, 8>(s, P, nimg, dev, &ok);
+            else if (cin == 128 && cout == 128 && stride == 1) rc = launch_q_dwpw<128, 128, 2, 1, 8>(s, P, nimg, dev, &ok);
+            else if (cin == 128 && cout == 256 && stride == 2) rc = launch_q_dwpw<128, 256, 2, 2, 8>(s, P, nimg, dev, &ok);
+            else if (cin == 256 && cout == 256 && stride == 1) rc = launch_q_dwpw<256, 256, 2, 1, 6>(s, P, nimg, dev, &ok);
+            else if (cin == 256 && cout == 512 && stride == 2) rc = launch_q_dwpw<256, 512, 1, 2, 12>(s, P, nimg, dev, &ok);
+            else if (cin == 512 && cout == 512 && stride == 1) rc = launch_q_dwpw<512, 512, 1, 1, 8>(s, P, nimg, dev, &ok);
+            if (rc != DD_OK) return rc;
+            DD_REQUIRE(ok, DD_E_ARG, "dd_net_forward: uint8 block %d (%d -> %d, stride %d, %d x %d): no fused kernel for this shape -- compile the program with the two-op form", i, cin, cout, stride, P.H, P.W);
             return DD_OK;
         }
         case OP_QSSD_DECODE: {

@@ -15,6 +15,8 @@ from .nets import Program, same_pad, DT_U8
 
 OP_QCONV0, OP_QCONV, OP_QDW, OP_QDWPW, OP_QSSD_DECODE = 16, 17, 18, 19, 20
 QEPI_Q16, QEPI_ROWS = 0, 1
+FUSE_BLOCKS = os.environ.get('DD_Q_FUSE', '1') != '0'      # MobileNet blocks as one launch each (q_dwpw_k); 0: depthwise and pointwise ops
+FUSED_SHAPES = {(32, 64, 1), (64, 128, 2), (128, 128, 1), (128, 256, 2), (256, 256, 1), (256, 512, 2), (512, 512, 1)}
 FEATURE_LAYERS = ['pw11', 'pw13', 'extra1_2', 'extra2_2', 'extra3_2', 'extra4_2']
 
 
@@ -152,9 +154,38 @@ def compile_ssd_mobilenet_quant(qm):
         info('q_dw_k', 2 * ho * wo * 9 * s['c'], s['h'] * s['w'] * s['c'] + ho * wo * s['c'], 9 * s['c'] + 4 * s['c'])
         return dst
 
+    def dwpw(src, dname, pname):
+        """MobileNet block as one launch (csrc/netsq.hip q_dwpw_k) where a fused kernel exists for the shape, else two ops."""
+        Ld, Lp = Ls[dname], Ls[pname]
+        s = P.T(src)
+        cin, cout, stride = s['c'], Lp['w'].shape[3], Ld['stride']
+        ho, wo, pt, pl = geom(src, 3, stride)
+        if not FUSE_BLOCKS or (cin, cout, stride) not in FUSED_SHAPES or wo < 19:
+            return conv(dw(src, dname), pname)
+        assert s['zp'] == Ld['in_zp'] and Ld['out_zp'] == Lp['in_zp'] and Ld['w'].shape[2] == cin and Lp['w'].shape[2] == cin
+        w9 = (Ld['w'].astype(np.int64) - int(Ld['w_zp'])).reshape(9, cin)
+        pairs = np.zeros((cin, 10), np.int16)
+        pairs[:, :9] = w9.T
+        dcb = (Ld['bias'].astype(np.int64) - int(Ld['in_zp']) * w9.sum(axis=0)).astype(np.int32)
+        wp, cb, kcpt = pack_conv(Lp, QEPI_Q16)
+        zwc = 128 - int(Lp['w_zp'])
+        cb = (cb.astype(np.int64) - 128 * cin * zwc).astype(np.int64)       # the kernel's row sums are of the bytes themselves, not of a - 128
+        assert np.abs(cb).max() < 2 ** 31
+        rd, rp = _req_words(Ld), _req_words(Lp)
+        if rd[33] < 1 or rp[33] < 1:
+            return conv(dw(src, dname), pname)                             # a multiplier >= 0.5: the two-op form handles it
+        dst = P.qtensor(ho, wo, cout, Lp['out_zp'])
+        raw = dict(rp)
+        raw.update({38: zwc, 39: int(Lp['in_zp'])})
+        P._op(OP_QDWPW, src=src, dst=dst, kh=1, kw=1, stride=stride, pad_t=pt, pad_l=pl, cin=cin, cout=cout, cout_pad=cout, kpad=kcpt,
+              w_off=P.add_blob(wp), b_off=P.add_blob(cb.astype(np.int32)), ho=ho, wo=wo,
+              p=[P.add_blob(pairs.view(np.int32)), P.add_blob(dcb), rd[32], rd[33], rd[36], rd[37]], bk=rd[40], raw=raw)
+        info('q_dwpw_k', 2 * ho * wo * cin * (9 + cout), s['h'] * s['w'] * cin + ho * wo * cout, cin * (9 + cout) + 4 * (cin + cout))
+        return dst
+
     feats = {}
     for i in range(1, 14):
-        x = conv(dw(x, f'dw{i}'), f'pw{i}')
+        x = dwpw(x, f'dw{i}', f'pw{i}')
         feats[f'pw{i}'] = x
     for j in range(1, 5):
         x = conv(conv(x, f'extra{j}_1'), f'extra{j}_2')

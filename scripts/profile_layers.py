@@ -13,14 +13,17 @@ kind, batch = sys.argv[1], int(sys.argv[2])
 reps = 20
 if kind == 'ssd':
     prog = nets.compile_ssd_mobilenet(nets.synthetic_ssd_weights()); shape = (300, 300)
+elif kind in ('ssd_i8', 'ssd_i8_sym'):                                    # the uint8 model (csrc/netsq.hip); _sym: weight zero points at 128
+    from deepdish_amd import quantize, netsq
+    prog = netsq.compile_ssd_mobilenet_quant(quantize.synthetic_ssd_quant_model(symmetric_weights=kind.endswith('sym'))); shape = (300, 300)
 elif kind == 'mars':
     prog = nets.compile_mars(nets.synthetic_mars_weights()); shape = (64, 32)
 else:
     prog = nets.compile_yolov5s(nets.synthetic_yolov5s_weights()); shape = (640, 640)
 net = Net(prog, max_batch=batch)
-if kind == 'ssd' and os.environ.get('DD_SSD_DEC', '1') != '0':      # as the pipeline runs it: the heads decode in their epilogue
+if kind.startswith('ssd') and os.environ.get('DD_SSD_DEC', '1') != '0':      # as the pipeline runs it: the heads decode in their epilogue
     net.ssd_decode(prog.meta['anchors'], 1e-8)
-if kind not in ('ssd', 'mars') and os.environ.get('DD_YOLO_DEC', '1') != '0':      # as the pipeline runs it: the Detect heads reduce their rows
+if kind not in ('ssd', 'ssd_i8', 'ssd_i8_sym', 'mars') and os.environ.get('DD_YOLO_DEC', '1') != '0':      # as the pipeline runs it: the Detect heads reduce their rows
     net.yolo_decode(True)
 x = torch.randint(0, 256, (batch,) + shape + (3,), dtype=torch.uint8, device='cuda')
 check(lib().dd_net_profile(net._h, 1))
