@@ -8,17 +8,18 @@
 // with the contractions on v_mfma_i32_16x16x64_i8 and everything else in integer vector instructions.
 //
 // Layout of an activation tensor (H, W, C), C % 16 == 0, in HBM ("Q16"):
-//     u8 [n][H + 2][C / 16][W + 2][16]
+//     i8 [n][H + 2][C / 16][W + 2][16],   stored byte = a - 128 (= a ^ 0x80)
 // i.e. planes of 16 channels, every image row and plane carrying one border pixel on each side, one border row above and
-// below.  Border bytes hold the tensor's zero point from engine creation on (nobody writes them), so a 3x3 window never
-// needs a bounds test and a padded tap contributes (za - za) = 0 as TFLite's skipped tap does.  A 16-pixel MFMA operand
+// below.  Border bytes hold the tensor's zero point (minus 128) from engine creation on (nobody writes them), so a 3x3 window
+// never needs a bounds test and a padded tap contributes (za - za) = 0 as TFLite's skipped tap does.  A 16-pixel MFMA operand
 // fragment is 4 planes x 16 pixels x 16 bytes: every lane loads 16 contiguous bytes, 16 lanes 256 contiguous bytes.
 //
-// Signed operands: the matrix instruction multiplies i8.  a' = a - 128 and w' = w - 128 (one XOR per 4 bytes / done on the
-// host), za' = za - 128, zw' = zw - 128, and
+// Signed operands: the matrix instruction multiplies i8, hence the stored a' = a - 128 (the producer's epilogue XORs the packed
+// word: a quarter of an instruction per byte; consumers read operands as they lie) and w' = w - 128 (host).  With za' = za - 128,
+// zw' = zw - 128:
 //     sum (a - za)(w - zw) = sum a'w'  -  zw' * sum_k a'  -  za' * sum_k w'[c]  +  K za' zw'
 // The last two terms are per output channel (host: `cbias`); the second needs the row sum of the pixel's operand bytes
-// (v_dot4_i32_i8 on the fragments the MFMAs read) unless zw == 128.
+// (v_dot4_i32_i8) unless zw == 128.  The head tensors (plain rows, read by the decode) hold the bytes themselves.
 //
 // Requantisation: for multipliers < 1 (shift <= 0, e = -shift) the two roundings of MultiplyByQuantizedMultiplier,
 //     y = (x M + 2^30) >> 31 (SaturatingRoundingDoublingHighMul; the truncating division and its sign-dependent nudge are
@@ -128,8 +129,7 @@ __global__ __launch_bounds__(256) void q_conv_k(const QConvP P, const int n_item
                 i4v b[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    b[j] = *reinterpret_cast<const i4v *>(base[j] + off);
-                    b[j] ^= (int)0x80808080;
+                    b[j] = *reinterpret_cast<const i4v *>(base[j] + off);      // stored as a - 128: the MFMA operand as it lies
                     if (!kv) b[j] = i4v{0, 0, 0, 0};
                     if (ROWSUM) {
 #pragma unroll
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void q_conv_k(const QConvP P, const int n_item
                     unsigned wv = 0;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) wv |= (unsigned)q_requant(acc[m][j][r] + rs[j] + c[r], P.R) << (8 * r);
-                    o[m] = wv;
+                    o[m] = wv ^ 0x80808080u;
                 }
                 if (live[j]) {
                     uint8_t *dst = P.out + (((size_t)qn[j] * (P.Ho + 2) + qy[j] + 1) * P.c16_out + 4 * mg + fq) * PPo + (size_t)(qx[j] + 1) * 16;
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void q_conv0_k(const QConv0P P, const int n_fr
     if (live) {
         const size_t PPo = (size_t)(P.wo + 2) * 16;
         uint8_t *dst = P.out + (((size_t)n * (P.ho + 2) + y + 1) * 2 + (fq >> 1)) * PPo + (size_t)(x + 1) * 16 + (fq & 1) * 8;
-        *reinterpret_cast<uint2 *>(dst) = make_uint2(lo, hi);
+        *reinterpret_cast<uint2 *>(dst) = make_uint2(lo ^ 0x80808080u, hi ^ 0x80808080u);
     }
 }
 
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void q_dw_k(const QDwP P) {
             const u4v a = *reinterpret_cast<const u4v *>(src + (size_t)dy * RP + (size_t)dx * 16);
             const short *wt = P.w + (size_t)(dy * 3 + dx) * C + pl * 16;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] += (int)((a[i >> 2] >> (8 * (i & 3))) & 0xffu) * (int)wt[i];
+            for (int i = 0; i < 16; ++i) acc[i] += ((int)(a[i >> 2] << (24 - 8 * (i & 3))) >> 24) * (int)wt[i];      // the stored byte is a - 128, signed
         }
     u4v o;
 #pragma unroll
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void q_dw_k(const QDwP P) {
         unsigned wv = 0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) wv |= (unsigned)q_requant(acc[4 * d + r], P.R) << (8 * r);
-        o[d] = wv;
+        o[d] = wv ^ 0x80808080u;
     }
     uint8_t *dst = P.out + (((size_t)n * (P.ho + 2) + y + 1) * P.c16 + pl) * ((size_t)(P.wo + 2) * 16) + (size_t)(x + 1) * 16;
     *reinterpret_cast<u4v *>(dst) = o;
@@ -367,34 +367,44 @@ __global__ __launch_bounds__(256) void q_ssd_decode_k(const QDecP P) {
 }
 
 // ------------------------------------------------------------------------------------------------ MobileNet block in one launch
-// depthwise 3x3 (stride 1 or 2) -> uint8 -> pointwise 1x1 -> uint8, one read of the block input, one write of its output.
+// depthwise 3x3 (stride 1 or 2) -> uint8 -> pointwise 1x1 -> uint8: one read of the block input, one write of its output, BOTH
+// contractions on the matrix pipe.
+//
+// Why the depthwise stage is on MFMA too.  Measured (scripts/experiments/valu_rates.hip, profiles/r04_valu_rates.txt): v_perm_b32,
+// v_dot2c_i32_i16, v_mad_i64_i32 cost 4.2 cycles of a SIMD per wave instruction however many waves share it (v_add_u32: 2.6), and
+// a depthwise output on the vector ALU is 5 + 5 of them plus the requantisation: 53 cycles per 64 outputs -- the first form of this
+// kernel spent 9.9 k of its 22 k cycles per tile there at 69 % VALU issue, and overlapping that stage with the matrix stage of the
+// neighbouring tile (two wave teams) gained nothing: one wave per SIMD cannot issue faster than one instruction per 5 cycles
+// (profiles/r04_layers_ssd_i8_b384_valu_dw.txt, ..._teams_valu_dw.txt).  As a block-diagonal product the same stage is 6
+// v_mfma_i32_16x16x64_i8 per 16 pixels x 16 channels -- 24 matrix cycles per 64 outputs at 1/16 of the array's utilisation, still
+// less than half the vector cost, and no unpacking at all: a k slice = four taps x 16 channels = exactly the 16 bytes per lane the
+// bordered plane layout serves.
+//
+//   A operand (filter): lane (g, r) of k step ks holds tap 4 ks + g of channel r on the diagonal (byte r of its 16, zeros
+//     elsewhere); w - zw spans 9 bits, so it is split hi = clamp(w - zw, -128, 127), lo = rest and the two products share one
+//     accumulator.  Built in registers from six bytes per lane and plane (v_perm_b32 replicates, four masks select).
+//   B operand (pixels): lane (g, p) reads the 16 channel bytes of tap 4 ks + g at pixel p straight from the LDS row ring.
+//   accumulator: rows = channels, so a lane ends up with 4 consecutive channels of one pixel: requantise, pack, one
+//     ds_write_b32 into the pointwise stage's operand tile [plane][pixel][16]; v_dot4_i32_i8 of the packed word feeds the row sum.
 //
 // A block of NW = (COUT / 64) * WP waves walks a contiguous range of 64-pixel tiles (raster order inside a frame; the last tile of
-// a frame is partly filled).  Per tile:
-//   * rows: the bordered input rows the tile's 3x3 windows touch live in an LDS ring (slot = global row index % NR, a row =
-//     [CIN / 16][W + 2][16] bytes as it lies in HBM).  The rows the NEXT tile adds are requested into registers before the
-//     depthwise stage and written to the ring after it (the slots they replace are dead by then): the ring holds one tile's
-//     rows, not two, and the HBM latency hides behind the depthwise arithmetic.
-//   * depthwise stage (vector ALU): wave item = 64 pixels (lane = pixel) x one plane of 16 channels, so the nine taps are nine
-//     conflict-free ds_read_b128 and the filter is wave-uniform (scalar loads).  Two taps of one channel per v_dot2_i32_i16
-//     (v_perm_b32 builds the {tap, tap} operand; weights w - zw as int16 pairs): 5 + 5 instructions per output, then the
-//     requantisation; the 16 bytes go to the operand tile [plane][pixel][16] -- the MFMA B-fragment image -- as a' = a ^ 0x80,
-//     their sum (v_dot4_u32_u8) to the pixel's row sum.
-//   * pointwise stage (matrix): wave (wm, wp) keeps the A fragments of its 64 output channels for ALL of K in registers for the
-//     whole launch (512 x 64 bytes = 128 VGPRs at most), reads each pixel fragment's K slices once (ds_read_b128, conflict-free),
-//     accumulates from its cbias registers, adds zwc * rowsum, requantises and stores 16 bytes per lane (the host packed fragment
-//     m's row 4g + r with channel 64 wm + 16 g + 4 m + r: a lane holds one pixel's 16 channels of plane 4 wm + g).
+// a frame is partly filled).  Rows: the bordered input rows a tile's windows touch live in an LDS ring (slot = global row index
+// % NR, a row = [CIN / 16][W + 2][16] bytes as it lies in HBM); the rows the NEXT tile adds are requested into registers at the
+// start of the pointwise stage and written to the ring at its end (their slots are dead since barrier A): the ring holds one
+// tile's rows, the HBM latency hides behind the MFMAs.  Pointwise stage: wave (wm, wp) keeps the A fragments of its 64 output
+// channels for all of K in registers for the whole launch (<= 128 VGPRs), accumulates from its cbias registers, adds
+// zwc * rowsum, requantises, stores 16 bytes per lane (fragment m's row 4g + r was packed with channel 64 wm + 16 g + 4 m + r).
 // Two barriers per tile.
 struct QDwpwP {
     const uint8_t *in; int H, W;
     int off_y, off_x, ho, wo, hw, tiles_per_frame;
     uint8_t *out; int c16_out;
-    const int *dw_w;                 // [CIN][5]: int16 pairs (w_t - zw) of taps (0,1) (2,3) (4,5) (6,7) (8,-)
-    const int *dw_cb;                // [CIN]: bias - za * sum_t (w_t - zw)
+    const uint2 *dw_a;               // [CIN / 16][64 lanes]: .x bytes 0..2 = hi parts of the lane's tap in k steps 0..2, .y = lo parts
+    const int *dw_cb;                // [CIN]: bias - (za - 128) * sum_t (w_t - zw)
     const i4v *w;                    // [COUT / 64][4][KC][64 lanes]
     const int *cbias;                // [COUT]
     int zwc, NR;
-    unsigned rb_magic, hb_magic;     // floor(2^32 / row bytes) + 1; the same for half a row
+    unsigned rb_magic;               // floor(2^32 / row bytes) + 1
     unsigned long long *dbg;         // DD_Q_STAMPS=1: per wave, cycles spent in each part of the tile loop (diagnostic launches only)
     QReq Rd, Rp;
 };
@@ -415,7 +425,8 @@ template <int CIN, int COUT, int WP, int STRIDE, int LPT, bool ROWSUM>
 __global__ __launch_bounds__((COUT / 64) * WP * 64) void q_dwpw_k(const QDwpwP P, const int n_tiles, const int tiles_per_block) {
     constexpr int WM = COUT / 64, NW = WM * WP, NT = NW * 64;
     constexpr int KC = (CIN + 63) / 64, CINP = KC * 64, C16 = CIN / 16;
-    constexpr int NITEMS = C16;                                     // depthwise wave items per tile (64 pixels x 16 channels each)
+    constexpr int CGW = C16 / NW > 0 ? C16 / NW : 1;                // planes per wave in the depthwise stage (each with all four pixel fragments)
+    static_assert(C16 % NW == 0 || NW % C16 == 0, "planes over waves");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
@@ -424,7 +435,8 @@ __global__ __launch_bounds__((COUT / 64) * WP * 64) void q_dwpw_k(const QDwpwP P
     uint8_t *ring = smem;
     uint8_t *opnd = smem + (size_t)P.NR * RB;                       // [CINP / 16][QT][16]
     int *rowsum = reinterpret_cast<int *>(opnd + QT * CINP);        // [2][QT]
-    unsigned *pixoff = reinterpret_cast<unsigned *>(rowsum + 2 * QT);   // [QT]
+    unsigned *pixoff = reinterpret_cast<unsigned *>(rowsum + 2 * QT);   // [2][QT]
+    i4v *pinfo = reinterpret_cast<i4v *>(pixoff + 2 * QT);          // [2][QT]: ring offsets of the pixel's three window rows, column offset
 
     // the wave's pointwise filter and per-channel constants, once
     i4v Wr[4][KC];
@@ -437,6 +449,16 @@ __global__ __launch_bounds__((COUT / 64) * WP * 64) void q_dwpw_k(const QDwpwP P
     for (int m = 0; m < 4; ++m) cb[m] = *reinterpret_cast<const i4v *>(P.cbias + 64 * wm + 16 * fq + 4 * m);
     if (CIN < CINP) for (int i = tid; i < QT * CINP / 16; i += NT) reinterpret_cast<u4v *>(opnd)[i] = u4v{0, 0, 0, 0};   // k slots without channels
     for (int i = tid; i < 2 * QT; i += NT) rowsum[i] = 0;
+    // depthwise lane constants: which byte of the 16 is this lane's diagonal element; which window row / column its tap of k step ks is
+    unsigned dmask[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) dmask[d] = (fr >> 2) == d ? 0xffu << (8 * (fr & 3)) : 0u;
+    int tap_row[3], tap_dx[3];
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+        const int tp = min(4 * ks + fq, 8);                         // k slots past the ninth tap carry zero weights: any valid address will do
+        tap_row[ks] = tp / 3; tap_dx[ks] = (tp % 3) * 16;
+    }
 
     const int t_begin = blockIdx.x * tiles_per_block, t_end = min(n_tiles, t_begin + tiles_per_block);
     if (t_begin >= t_end) return;
@@ -452,6 +474,15 @@ __global__ __launch_bounds__((COUT / 64) * WP * 64) void q_dwpw_k(const QDwpwP P
         ga = n * (P.H + 2) + y0 * STRIDE + P.off_y;
         gb = n * (P.H + 2) + y1 * STRIDE + P.off_y + 2;
     };
+    auto geometry = [&](int n, int q0, int q1, int buf) {           // threads 0 .. QT - 1: where pixel tid of the tile reads and writes
+        const int q = q0 + tid;
+        const int qc = min(q, q1);
+        const int y = qc / P.wo, x = qc - y * P.wo;
+        const int g0 = n * (P.H + 2) + y * STRIDE + P.off_y;
+        const int s0 = g0 % P.NR, s1 = s0 + 1 == P.NR ? 0 : s0 + 1, s2 = s1 + 1 == P.NR ? 0 : s1 + 1;
+        pinfo[buf * QT + tid] = i4v{s0 * RB, s1 * RB, s2 * RB, (x * STRIDE + P.off_x) * 16};
+        pixoff[buf * QT + tid] = q <= q1 ? (unsigned)(((size_t)n * (P.ho + 2) + y + 1) * P.c16_out * ((P.wo + 2) * 16) + (size_t)(x + 1) * 16) : 0xffffffffu;
+    };
     int n, q0, q1, ga, gb;
     tile_rows(t_begin, n, q0, q1, ga, gb);
     {   // the first tile's rows, synchronously
@@ -462,6 +493,7 @@ __global__ __launch_bounds__((COUT / 64) * WP * 64) void q_dwpw_k(const QDwpwP P
             *reinterpret_cast<u4v *>(ring + (size_t)((ga + row) % P.NR) * RB + off) = *reinterpret_cast<const u4v *>(src + idx);
         }
     }
+    if (tid < QT) geometry(n, q0, q1, t_begin & 1);
     int loaded_hi = gb;
     __syncthreads();
 
@@ -477,94 +509,79 @@ __global__ __launch_bounds__((COUT / 64) * WP * 64) void q_dwpw_k(const QDwpwP P
             nb = gb2 >= lo ? (unsigned)(gb2 - lo + 1) * RB : 0u;
             loaded_hi = max(loaded_hi, gb2);
         }
-        // ---- per-lane geometry of this tile
         const int cur = t & 1;
-        if (tid < QT) {
-            const int q = q0 + tid;
-            unsigned po = 0xffffffffu;
-            if (q <= q1) {
-                const int y = q / P.wo, x = q - y * P.wo;
-                po = (unsigned)(((size_t)n * (P.ho + 2) + y + 1) * P.c16_out * ((P.wo + 2) * 16) + (size_t)(x + 1) * 16);
-            }
-            pixoff[tid] = po;
-        }
-        // ---- depthwise stage
+        // ---- depthwise stage: this wave's planes x the four pixel fragments
         {
-            const int q = min(q0 + lane, q1);
-            const int y = q / P.wo, x = q - y * P.wo;
-            const int g0 = n * (P.H + 2) + y * STRIDE + P.off_y;
-            const int s0 = g0 % P.NR, s1 = s0 + 1 == P.NR ? 0 : s0 + 1, s2 = s1 + 1 == P.NR ? 0 : s1 + 1;
-            const int col = (x * STRIDE + P.off_x) * 16;
-            const uint8_t *r0 = ring + (size_t)s0 * RB + col, *r1 = ring + (size_t)s1 * RB + col, *r2 = ring + (size_t)s2 * RB + col;
-            unsigned rs = 0;
-            // the filter of an item is wave-uniform: constant address space = scalar loads (hipcc otherwise loads it through the
-            // vector memory path, one dependent round trip per four taps: 25 of them per item)
-            const cint *dww = (const cint *)(const void *)P.dw_w, *dwc = (const cint *)(const void *)P.dw_cb;
-            for (int it = wave; it < NITEMS; it += NW) {
-                const int cg = __builtin_amdgcn_readfirstlane(it);
-                const int po = cg * PP;
-                u4v tap[9];
+            i4v pi[4];
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    tap[dx] = *reinterpret_cast<const u4v *>(r0 + po + dx * 16);
-                    tap[3 + dx] = *reinterpret_cast<const u4v *>(r1 + po + dx * 16);
-                    tap[6 + dx] = *reinterpret_cast<const u4v *>(r2 + po + dx * 16);
+            for (int f = 0; f < 4; ++f) pi[f] = pinfo[cur * QT + 16 * f + fr];
+            int rs[4] = {0, 0, 0, 0};
+            const int n_cg = C16 >= NW ? CGW : 1;
+            const int cg0 = C16 >= NW ? wave * CGW : wave % C16;
+            const bool work = C16 >= NW || wave < C16;               // more waves than planes: the surplus waves sit this stage out
+            for (int ci = 0; ci < n_cg && work; ++ci) {
+                const int cg = cg0 + ci;
+                const uint2 ab = P.dw_a[cg * 64 + lane];
+                const i4v cbv = *reinterpret_cast<const i4v *>(P.dw_cb + cg * 16 + 4 * fq);
+                i4v Ah[3], Al[3];
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) {
+                    const unsigned sel = 0x01010101u * (unsigned)ks;
+                    const unsigned rh = __builtin_amdgcn_perm(ab.x, ab.x, sel), rl = __builtin_amdgcn_perm(ab.y, ab.y, sel);
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) { Ah[ks][d] = (int)(rh & dmask[d]); Al[ks][d] = (int)(rl & dmask[d]); }
                 }
-                u4v o;
-                int wq[2][20], wc[2][4];                                // filter pairs and constants of a channel quad (scalar registers), double-buffered
-                {
-                    const cint *a = dww + cg * 80, *b = dwc + cg * 16;
+                const int pofs = cg * PP;
+                i4v acc[4];
 #pragma unroll
-                    for (int k = 0; k < 20; ++k) wq[0][k] = a[k];
+                for (int f = 0; f < 4; ++f) acc[f] = cbv;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) wc[0][k] = b[k];
-                }
+                for (int ks = 0; ks < 3; ++ks) {
+                    i4v b[4];
 #pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    if (d < 3) {                                        // the next quad's filter is requested before this quad's arithmetic
-                        const cint *a = dww + cg * 80 + (d + 1) * 20, *b = dwc + cg * 16 + (d + 1) * 4;
-#pragma unroll
-                        for (int k = 0; k < 20; ++k) wq[(d + 1) & 1][k] = a[k];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) wc[(d + 1) & 1][k] = b[k];
+                    for (int f = 0; f < 4; ++f) {
+                        const int ro = tap_row[ks] == 0 ? pi[f][0] : tap_row[ks] == 1 ? pi[f][1] : pi[f][2];
+                        b[f] = *reinterpret_cast<const i4v *>(ring + ro + pi[f][3] + tap_dx[ks] + pofs);
                     }
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Ah[ks], b[f], acc[f], 0, 0, 0);
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Al[ks], b[f], acc[f], 0, 0, 0);
+                }
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
                     unsigned packed = 0;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const unsigned sel = 0x0c000c00u | (unsigned)j | ((unsigned)(4 + j) << 16);
-                        int acc = wc[d & 1][j];
-#pragma unroll
-                        for (int pr = 0; pr < 4; ++pr) {
-                            const unsigned pa = __builtin_amdgcn_perm(tap[2 * pr + 1][d], tap[2 * pr][d], sel);
-                            acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(s2v, pa), __builtin_bit_cast(s2v, wq[d & 1][j * 5 + pr]), acc, false);
-                        }
-                        {
-                            const unsigned pa = __builtin_amdgcn_perm(0u, tap[8][d], 0x0c0c0c00u | (unsigned)j);
-                            acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(s2v, pa), __builtin_bit_cast(s2v, wq[d & 1][j * 5 + 4]), acc, false);
-                        }
-                        const int z = q_clamp(q_requant_relu(acc, Md, Cd, shd), lod, hid);
-                        packed |= (unsigned)z << (8 * j);
-                    }
-                    o[d] = packed;
-                    if (ROWSUM) rs = __builtin_amdgcn_udot4(packed, 0x01010101u, rs, false);
+                    for (int r = 0; r < 4; ++r) packed |= (unsigned)q_clamp(q_requant_relu(acc[f][r], Md, Cd, shd), lod, hid) << (8 * r);
+                    packed ^= 0x80808080u;
+                    if (ROWSUM) rs[f] = sdot4((int)packed, 0x01010101, rs[f]);
+                    *reinterpret_cast<unsigned *>(opnd + ((size_t)cg * QT + 16 * f + fr) * 16 + 4 * fq) = packed;
                 }
-                o ^= 0x80808080u;
-                *reinterpret_cast<u4v *>(opnd + ((size_t)cg * QT + lane) * 16) = o;
             }
-            if (ROWSUM) atomicAdd(&rowsum[cur * QT + lane], (int)rs);
+            if (ROWSUM && work) {
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    int v = rs[f];
+                    v += __shfl_xor(v, 16, 64);
+                    v += __shfl_xor(v, 32, 64);
+                    if (fq == 0) atomicAdd(&rowsum[cur * QT + 16 * f + fr], v);
+                }
+            }
         }
         Q_STAMP(0);
-        __syncthreads();                                             // A: operand tile, row sums and pixel offsets are complete; the ring is free
+        __syncthreads();                                             // A: operand tile and row sums are complete; the ring is free
         Q_STAMP(1);
-        // ---- request the next tile's rows (registers; they go to the ring when the matrix stage below is done: the slots they
-        // replace are dead since barrier A, and the HBM latency hides behind the MFMAs)
+        // ---- request the next tile's rows (registers; they go to the ring when the matrix stage below is done)
         u4v pf[LPT];
         if (nb) {                                                    // (uniform) every request goes out back to back: no lane predicate, the
             const uint8_t *src = P.in + (size_t)lo * RB;             // pieces past the end re-read the last one and are dropped at the write
 #pragma unroll
             for (int i = 0; i < LPT; ++i) pf[i] = *reinterpret_cast<const u4v *>(src + min((unsigned)(i * NT + tid) * 16u, nb - 16u));
         }
-        if (tid < QT) rowsum[(cur ^ 1) * QT + tid] = 0;
+        if (tid < QT) {
+            rowsum[(cur ^ 1) * QT + tid] = 0;
+            if (t + 1 < t_end) geometry(n2, q02, q12, cur ^ 1);
+        }
         // ---- pointwise stage
         const int nf = (q1 - q0) / 16 + 1;
         for (int f = wp; f < nf; f += WP) {
@@ -577,24 +594,21 @@ __global__ __launch_bounds__((COUT / 64) * WP * 64) void q_dwpw_k(const QDwpwP P
                 for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Wr[m][kc], b, kc == 0 ? cb[m] : acc[m], 0, 0, 0);
             }
             const int rsv = ROWSUM ? rowsum[cur * QT + 16 * f + fr] * P.zwc : 0;
-            const unsigned po = pixoff[16 * f + fr];
+            const unsigned po = pixoff[cur * QT + 16 * f + fr];
             u4v o;
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 unsigned packed = 0;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int z = q_clamp(q_requant_relu(acc[m][r] + rsv, Mp, Cp, shp), lop, hip_);
-                    packed |= (unsigned)z << (8 * r);
-                }
-                o[m] = packed;
+                for (int r = 0; r < 4; ++r) packed |= (unsigned)q_clamp(q_requant_relu(acc[m][r] + rsv, Mp, Cp, shp), lop, hip_) << (8 * r);
+                o[m] = packed ^ 0x80808080u;
             }
             if (po != 0xffffffffu) *reinterpret_cast<u4v *>(P.out + po + (size_t)(4 * wm + fq) * ((P.wo + 2) * 16)) = o;
         }
         Q_STAMP(2);
         if (nb) {
             unsigned tid16 = (unsigned)tid * 16u;
-            asm volatile("" : "+v"(tid16));                          // keeps the eight (row, offset) pairs from being hoisted out of the tile loop (16 live registers: spills)
+            asm volatile("" : "+v"(tid16));                          // keeps the (row, offset) pairs from being hoisted out of the tile loop (16 live registers: spills)
             int slot0 = lo % P.NR;
 #pragma unroll
             for (int i = 0; i < LPT; ++i) {
@@ -615,252 +629,6 @@ __global__ __launch_bounds__((COUT / 64) * WP * 64) void q_dwpw_k(const QDwpwP P
     }
 #undef Q_STAMP
     if (P.dbg && lane == 0) for (int k = 0; k < 5; ++k) P.dbg[((size_t)blockIdx.x * NW + wave) * 8 + k] = st[k];
-}
-
-// ---- q_dwpw_k with the two stages of consecutive tiles overlapped (the form that runs; DD_Q_TEAMS=0 keeps the one above).
-// The block's waves form two teams (the lower and the upper half of the wave numbers: with eight waves one of each per SIMD).
-// A tile step has two phases, one barrier each:
-//     phase 1   team A: matrix stage of tile t (its channels)          team B: depthwise stage of tile t + 1, planes [0, C16/2)
-//     phase 2   team B: matrix stage of tile t                         team A: depthwise stage of tile t + 1, planes [C16/2, C16)
-// so a SIMD always holds one wave issuing MFMAs and one issuing vector instructions (in q_dwpw_k every wave is in the same stage,
-// the matrix pipe idles during the depthwise stage and the vector ALUs during the matrix stage: 22 k cycles per tile where the
-// arithmetic needs 9 k).  The operand tile, the pixel offsets (x2) and the row sums (x3) are multi-buffered.  Ring rows: a row is
-// [lower planes | upper planes]; the lower halves of the rows tile t + 2 adds are requested in phase 1 and written in phase 2
-// (team B's depthwise stage, their last reader, is behind the barrier), the upper halves requested in phase 2 and written in
-// phase 1 of the next step -- still one tile's rows in the ring, no extra barrier.
-template <int CIN, int COUT, int WP, int STRIDE, int LPH, bool ROWSUM>
-__global__ __launch_bounds__((COUT / 64) * WP * 64) void q_dwpw2_k(const QDwpwP P, const int n_tiles, const int tiles_per_block) {
-    constexpr int WM = COUT / 64, NW = WM * WP, NT = NW * 64, NWT = NW / 2;
-    constexpr int KC = (CIN + 63) / 64, CINP = KC * 64, C16 = CIN / 16, CH = C16 / 2;
-    static_assert(NW % 2 == 0 && C16 % 2 == 0 && CH % NWT == 0 || NWT % CH == 0, "teams");
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int fr = lane & 15, fq = lane >> 4;
-    const int wm = wave / WP, wp = wave % WP;
-    const int team = wave >= NWT, wt = wave - team * NWT;             // team 0 = A
-    const int RB = (P.W + 2) * CIN, PP = (P.W + 2) * 16, HB = RB / 2;
-    uint8_t *ring = smem;
-    uint8_t *opnd = smem + (size_t)P.NR * RB;                       // [2][CINP / 16][QT][16]
-    int *rowsum = reinterpret_cast<int *>(opnd + 2 * QT * CINP);    // [3][QT]
-    unsigned *pixoff = reinterpret_cast<unsigned *>(rowsum + 3 * QT);   // [2][QT]
-
-    i4v Wr[4][KC];
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int kc = 0; kc < KC; ++kc) Wr[m][kc] = P.w[((size_t)(wm * 4 + m) * KC + kc) * 64 + lane];
-    if (CIN < CINP) for (int i = tid; i < 2 * QT * CINP / 16; i += NT) reinterpret_cast<u4v *>(opnd)[i] = u4v{0, 0, 0, 0};
-    for (int i = tid; i < 3 * QT; i += NT) rowsum[i] = 0;
-
-    const int t_begin = blockIdx.x * tiles_per_block, t_end = min(n_tiles, t_begin + tiles_per_block);
-    if (t_begin >= t_end) return;
-    const int Md = P.Rd.M, shd = P.Rd.e - 1, Mp = P.Rp.M, shp = P.Rp.e - 1;
-    const long long Cd = P.Rd.C, Cp = P.Rp.C;
-    const int lod = P.Rd.lo, hid = P.Rd.hi, lop = P.Rp.lo, hip_ = P.Rp.hi;
-    const cint *dww = (const cint *)(const void *)P.dw_w, *dwc = (const cint *)(const void *)P.dw_cb;
-
-    auto tile_rows = [&](int t, int &n, int &q0, int &q1, int &ga, int &gb) {
-        n = t / P.tiles_per_frame;
-        q0 = (t - n * P.tiles_per_frame) * QT;
-        q1 = min(q0 + QT, P.hw) - 1;
-        const int y0 = q0 / P.wo, y1 = q1 / P.wo;
-        ga = n * (P.H + 2) + y0 * STRIDE + P.off_y;
-        gb = n * (P.H + 2) + y1 * STRIDE + P.off_y + 2;
-    };
-    auto slot_of = [&](int g) { return g % P.NR; };
-    // whole rows [lo, lo + nrows) into the ring, synchronously (start of the block's range only)
-    auto load_rows_sync = [&](int lo, int nrows) {
-        const unsigned nb = (unsigned)nrows * RB;
-        const uint8_t *src = P.in + (size_t)lo * RB;
-        for (unsigned idx = tid * 16u; idx < nb; idx += NT * 16u) {
-            const unsigned row = idx / (unsigned)RB, off = idx - row * RB;
-            *reinterpret_cast<u4v *>(ring + (size_t)slot_of(lo + (int)row) * RB + off) = *reinterpret_cast<const u4v *>(src + idx);
-        }
-    };
-    // ---- depthwise stage of one tile for planes [h * CH, (h + 1) * CH), by the calling team
-    auto dw_half = [&](int n, int q0, int q1, int h, int buf, int rsb) {
-        const int q = min(q0 + lane, q1);
-        const int y = q / P.wo, x = q - y * P.wo;
-        const int g0 = n * (P.H + 2) + y * STRIDE + P.off_y;
-        const int s0 = g0 % P.NR, s1 = s0 + 1 == P.NR ? 0 : s0 + 1, s2 = s1 + 1 == P.NR ? 0 : s1 + 1;
-        const int col = (x * STRIDE + P.off_x) * 16;
-        const uint8_t *r0 = ring + (size_t)s0 * RB + col, *r1 = ring + (size_t)s1 * RB + col, *r2 = ring + (size_t)s2 * RB + col;
-        uint8_t *ob = opnd + (size_t)buf * QT * CINP;
-        unsigned rs = 0;
-        for (int it = h * CH + wt; it < (h + 1) * CH; it += NWT) {
-            const int cg = __builtin_amdgcn_readfirstlane(it);
-            const int po = cg * PP;
-            u4v tap[9];
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                tap[dx] = *reinterpret_cast<const u4v *>(r0 + po + dx * 16);
-                tap[3 + dx] = *reinterpret_cast<const u4v *>(r1 + po + dx * 16);
-                tap[6 + dx] = *reinterpret_cast<const u4v *>(r2 + po + dx * 16);
-            }
-            u4v o;
-            int wq[2][20], wc[2][4];
-            {
-                const cint *a = dww + cg * 80, *b = dwc + cg * 16;
-#pragma unroll
-                for (int k = 0; k < 20; ++k) wq[0][k] = a[k];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) wc[0][k] = b[k];
-            }
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                if (d < 3) {
-                    const cint *a = dww + cg * 80 + (d + 1) * 20, *b = dwc + cg * 16 + (d + 1) * 4;
-#pragma unroll
-                    for (int k = 0; k < 20; ++k) wq[(d + 1) & 1][k] = a[k];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) wc[(d + 1) & 1][k] = b[k];
-                }
-                unsigned packed = 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const unsigned sel = 0x0c000c00u | (unsigned)j | ((unsigned)(4 + j) << 16);
-                    int acc = wc[d & 1][j];
-#pragma unroll
-                    for (int pr = 0; pr < 4; ++pr) {
-                        const unsigned pa = __builtin_amdgcn_perm(tap[2 * pr + 1][d], tap[2 * pr][d], sel);
-                        acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(s2v, pa), __builtin_bit_cast(s2v, wq[d & 1][j * 5 + pr]), acc, false);
-                    }
-                    {
-                        const unsigned pa = __builtin_amdgcn_perm(0u, tap[8][d], 0x0c0c0c00u | (unsigned)j);
-                        acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(s2v, pa), __builtin_bit_cast(s2v, wq[d & 1][j * 5 + 4]), acc, false);
-                    }
-                    const int z = q_clamp(q_requant_relu(acc, Md, Cd, shd), lod, hid);
-                    packed |= (unsigned)z << (8 * j);
-                }
-                o[d] = packed;
-                if (ROWSUM) rs = __builtin_amdgcn_udot4(packed, 0x01010101u, rs, false);
-            }
-            o ^= 0x80808080u;
-            *reinterpret_cast<u4v *>(ob + ((size_t)cg * QT + lane) * 16) = o;
-        }
-        if (ROWSUM) atomicAdd(&rowsum[rsb * QT + lane], (int)rs);
-    };
-    auto pix_offsets = [&](int n, int q0, int q1, int buf, int idx) {       // idx in [0, QT)
-        const int q = q0 + idx;
-        unsigned po = 0xffffffffu;
-        if (q <= q1) {
-            const int y = q / P.wo, x = q - y * P.wo;
-            po = (unsigned)(((size_t)n * (P.ho + 2) + y + 1) * P.c16_out * ((P.wo + 2) * 16) + (size_t)(x + 1) * 16);
-        }
-        pixoff[buf * QT + idx] = po;
-    };
-    // ---- matrix stage of one tile for this wave's channels / fragments
-    auto matrix = [&](int q0, int q1, int buf, int rsb) {
-        i4v cb[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) cb[m] = *reinterpret_cast<const i4v *>(P.cbias + 64 * wm + 16 * fq + 4 * m);
-        const uint8_t *ob = opnd + (size_t)buf * QT * CINP;
-        const int nf = (q1 - q0) / 16 + 1;
-        for (int f = wp; f < nf; f += WP) {
-            i4v acc[4];
-            const uint8_t *bp = ob + ((size_t)fq * QT + 16 * f + fr) * 16;
-#pragma unroll
-            for (int kc = 0; kc < KC; ++kc) {
-                const i4v b = *reinterpret_cast<const i4v *>(bp + (size_t)kc * 4 * QT * 16);
-#pragma unroll
-                for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Wr[m][kc], b, kc == 0 ? cb[m] : acc[m], 0, 0, 0);
-            }
-            const int rsv = ROWSUM ? rowsum[rsb * QT + 16 * f + fr] * P.zwc : 0;
-            const unsigned po = pixoff[buf * QT + 16 * f + fr];
-            u4v o;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                unsigned packed = 0;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int z = q_clamp(q_requant_relu(acc[m][r] + rsv, Mp, Cp, shp), lop, hip_);
-                    packed |= (unsigned)z << (8 * r);
-                }
-                o[m] = packed;
-            }
-            if (po != 0xffffffffu) *reinterpret_cast<u4v *>(P.out + po + (size_t)(4 * wm + fq) * ((P.wo + 2) * 16)) = o;
-        }
-    };
-    // half rows: pieces of the lower (half = 0) or upper plane halves of rows [lo, lo + nrows)
-    auto pf_request = [&](u4v (&pf)[LPH], int lo, int nrows, int half) {
-        if (nrows <= 0) return;
-        const unsigned nb = (unsigned)nrows * HB;
-#pragma unroll
-        for (int i = 0; i < LPH; ++i) {
-            const unsigned idx = min((unsigned)(i * NT + tid) * 16u, nb - 16u);
-            const unsigned row = __umulhi(idx, P.hb_magic), off = idx - row * HB;
-            pf[i] = *reinterpret_cast<const u4v *>(P.in + ((size_t)lo + row) * RB + (size_t)half * HB + off);
-        }
-    };
-    auto pf_write = [&](const u4v (&pf)[LPH], int lo, int nrows, int half) {
-        if (nrows <= 0) return;
-        const unsigned nb = (unsigned)nrows * HB;
-        unsigned tid16 = (unsigned)tid * 16u;
-        asm volatile("" : "+v"(tid16));
-        const int slot0 = lo % P.NR;
-#pragma unroll
-        for (int i = 0; i < LPH; ++i) {
-            const unsigned idx = (unsigned)(i * NT) * 16u + tid16;
-            if (idx < nb) {
-                const unsigned row = __umulhi(idx, P.hb_magic), off = idx - row * HB;
-                int slot = slot0 + (int)row;
-                slot = slot >= P.NR ? slot - P.NR : slot;
-                slot = slot >= P.NR ? slot - P.NR : slot;
-                *reinterpret_cast<u4v *>(ring + (size_t)slot * RB + (size_t)half * HB + off) = pf[i];
-            }
-        }
-    };
-
-    // ---- prologue: the first tile's rows and depthwise stage, the second tile's rows
-    int n, q0, q1, ga, gb;
-    tile_rows(t_begin, n, q0, q1, ga, gb);
-    load_rows_sync(ga, gb - ga + 1);
-    int loaded_hi = gb;
-    __syncthreads();
-    dw_half(n, q0, q1, team ? 0 : 1, t_begin & 1, t_begin % 3);
-    if (tid < QT) pix_offsets(n, q0, q1, t_begin & 1, tid);
-    int n1 = 0, q01 = 0, q11 = 0, ga1 = 0, gb1 = 0;                 // tile t + 1
-    __syncthreads();
-    if (t_begin + 1 < t_end) {
-        tile_rows(t_begin + 1, n1, q01, q11, ga1, gb1);
-        const int lo = max(loaded_hi + 1, ga1);
-        if (gb1 >= lo) load_rows_sync(lo, gb1 - lo + 1);
-        loaded_hi = max(loaded_hi, gb1);
-    }
-    __syncthreads();
-
-    u4v pfL[LPH], pfU[LPH];
-    int loU = 0, nrU = 0;                                           // upper halves requested in the previous step, to be written in this one
-    for (int t = t_begin; t < t_end; ++t) {
-        const bool has1 = t + 1 < t_end, has2 = t + 2 < t_end;
-        int n2 = 0, q02 = 0, q12 = 0, ga2 = 0, gb2 = 0, lo2 = 0, nr2 = 0;
-        if (has2) {
-            tile_rows(t + 2, n2, q02, q12, ga2, gb2);
-            lo2 = max(loaded_hi + 1, ga2);
-            nr2 = max(0, gb2 - lo2 + 1);
-            loaded_hi = max(loaded_hi, gb2);
-        }
-        const int b0 = t & 1, b1 = b0 ^ 1, r0i = t % 3, r1i = (t + 1) % 3, r2i = (t + 2) % 3;
-        // ---- phase 1
-        pf_request(pfL, lo2, nr2, 0);
-        pf_write(pfU, loU, nrU, 1);
-        if (!team) matrix(q0, q1, b0, r0i);
-        else {
-            if (has1) dw_half(n1, q01, q11, 0, b1, r1i);
-            if (wt == 0 && has1) pix_offsets(n1, q01, q11, b1, lane);
-            if (wt == 0) rowsum[r2i * QT + lane] = 0;
-        }
-        __syncthreads();
-        // ---- phase 2
-        pf_request(pfU, lo2, nr2, 1);
-        loU = lo2; nrU = nr2;
-        pf_write(pfL, lo2, nr2, 0);
-        if (team) matrix(q0, q1, b0, r0i);
-        else if (has1) dw_half(n1, q01, q11, 1, b1, r1i);
-        __syncthreads();
-        n = n1; q0 = q01; q1 = q11;
-        n1 = n2; q01 = q02; q11 = q12;
-    }
 }
 
 QReq make_req(const int32_t *o) {
@@ -890,23 +658,19 @@ void dwpw_plan(int H, int W, int ho, int wo, int stride, int off_y, int cin, int
 
 template <int CIN, int COUT, int WP, int STRIDE, int LPT>
 int launch_q_dwpw(hipStream_t s, QDwpwP &P, int nimg, int device, bool *ok) {
-    constexpr int NW = (COUT / 64) * WP, NT = NW * 64, CINP = (CIN + 63) / 64 * 64, LPH = (LPT + 1) / 2;
-    static const bool teams = !(getenv("DD_Q_TEAMS") && atoi(getenv("DD_Q_TEAMS")) == 0);      // A/B switch: 0 = every wave in the same stage (q_dwpw_k)
+    constexpr int NW = (COUT / 64) * WP, NT = NW * 64, CINP = (CIN + 63) / 64 * 64;
     int lpt = 0;
     dwpw_plan(P.H, P.W, P.ho, P.wo, STRIDE, P.off_y, CIN, NT, &P.NR, &lpt);
     const int RB = (P.W + 2) * CIN;
-    const size_t lds = (size_t)P.NR * RB + (size_t)(teams ? 2 : 1) * QT * CINP + (teams ? 5 : 3) * QT * sizeof(int);
+    const size_t lds = (size_t)P.NR * RB + (size_t)QT * CINP + 4 * QT * sizeof(int) + 2 * QT * 16;
     P.rb_magic = (unsigned)((1ull << 32) / (unsigned)RB) + 1u;
-    P.hb_magic = (unsigned)((1ull << 32) / (unsigned)(RB / 2)) + 1u;
-    *ok = lpt <= LPT && (lpt + 1) / 2 <= LPH && lds <= 160 * 1024 && (long long)LPT * NT * 16 * RB < (1ll << 32) && (LPT * NT * 16) / RB + 1 <= 2 * P.NR;
+    *ok = lpt <= LPT && lds <= 160 * 1024 && (long long)LPT * NT * 16 * RB < (1ll << 32) && (LPT * NT * 16) / RB + 1 <= 2 * P.NR;
     if (!*ok) return DD_OK;
     const bool rsum = P.zwc != 0;
     static DevOnce once;
     const int rc = once.run(device, [&]() -> int {
         DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&q_dwpw2_k<CIN, COUT, WP, STRIDE, LPH, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&q_dwpw2_k<CIN, COUT, WP, STRIDE, LPH, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         return DD_OK;
     });
     if (rc != DD_OK) return rc;
@@ -914,8 +678,7 @@ int launch_q_dwpw(hipStream_t s, QDwpwP &P, int nimg, int device, bool *ok) {
     int per_cu = per_cu_cache[device & 63].load(std::memory_order_relaxed);
     if (per_cu == 0) {
         int nb = 0;
-        if (teams) DD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&q_dwpw2_k<CIN, COUT, WP, STRIDE, LPH, true>), NT, lds));
-        else DD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, true>), NT, lds));
+        DD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, true>), NT, lds));
         per_cu = std::max(1, std::min(8, nb));
         per_cu_cache[device & 63].store(per_cu, std::memory_order_relaxed);
     }
@@ -923,12 +686,6 @@ int launch_q_dwpw(hipStream_t s, QDwpwP &P, int nimg, int device, bool *ok) {
     const int blocks = std::min(n_tiles, per_cu * 256);
     const int tpb = dd_ceil_div(n_tiles, blocks);
     const dim3 grid((unsigned)dd_ceil_div(n_tiles, tpb));
-    if (teams) {
-        if (rsum) hipLaunchKernelGGL((q_dwpw2_k<CIN, COUT, WP, STRIDE, LPH, true>), grid, dim3(NT), lds, s, P, n_tiles, tpb);
-        else hipLaunchKernelGGL((q_dwpw2_k<CIN, COUT, WP, STRIDE, LPH, false>), grid, dim3(NT), lds, s, P, n_tiles, tpb);
-        DD_LAUNCH_CHECK();
-        return DD_OK;
-    }
     static const bool stamps = getenv("DD_Q_STAMPS") && atoi(getenv("DD_Q_STAMPS")) != 0;
     const size_t n_st = (size_t)grid.x * NW * 8;
     if (stamps) { DD_HIP(hipMalloc(&P.dbg, n_st * 8)); DD_HIP(hipMemsetAsync(P.dbg, 0, n_st * 8, s)); }
@@ -943,8 +700,8 @@ int launch_q_dwpw(hipStream_t s, QDwpwP &P, int nimg, int device, bool *ok) {
         double sum[5] = {0, 0, 0, 0, 0};
         for (size_t w = 0; w < n_st / 8; ++w) for (int k = 0; k < 5; ++k) sum[k] += (double)h[w * 8 + k];
         const double nw = (double)(n_st / 8) * tpb;
-        fprintf(stderr, "q_dwpw_k<%d,%d,%d> %d tiles/block: cycles per wave and tile: depthwise %.0f  barrier A %.0f  matrix stage %.0f  ring write %.0f  barrier B %.0f\n",
-                CIN, COUT, STRIDE, tpb, sum[0] / nw, sum[1] / nw, sum[2] / nw, sum[3] / nw, sum[4] / nw);
+        fprintf(stderr, "q_dwpw_k<%d,%d,%d> %d blocks/CU %d tiles/block: cycles per wave and tile: depthwise %.0f  barrier A %.0f  matrix stage %.0f  ring write %.0f  barrier B %.0f\n",
+                CIN, COUT, STRIDE, per_cu, tpb, sum[0] / nw, sum[1] / nw, sum[2] / nw, sum[3] / nw, sum[4] / nw);
     }
     return DD_OK;
 }
@@ -1035,7 +792,7 @@ int netq_run_op(dd_net *net, int i, const int32_t *o, const uint8_t *input, int 
             P.in = base(src); P.H = ts->h; P.W = ts->w;
             P.off_y = 1 - o[8]; P.off_x = 1 - o[9]; P.ho = td->h; P.wo = td->w; P.hw = P.ho * P.wo; P.tiles_per_frame = dd_ceil_div(P.hw, QT);
             P.out = base(dst); P.c16_out = td->cs / 16;
-            P.dw_w = reinterpret_cast<const int *>(W + (size_t)(uint32_t)o[20]);
+            P.dw_a = reinterpret_cast<const uint2 *>(W + (size_t)(uint32_t)o[20]);
             P.dw_cb = reinterpret_cast<const int *>(W + (size_t)(uint32_t)o[21]);
             P.w = reinterpret_cast<const i4v *>(W + (size_t)(uint32_t)o[16]);
             P.cbias = reinterpret_cast<const int *>(W + (size_t)(uint32_t)o[17]);

@@ -65,10 +65,10 @@ class Program:
         return len(self.bufs) - 1
 
     def qtensor(self, h, w, c, zp):
-        """uint8 activation tensor in the bordered 16-channel-plane layout of csrc/netsq.hip: [h + 2][c / 16][w + 2][16],
-        borders = the tensor's zero point (set once, never written)."""
+        """uint8 activation tensor in the bordered 16-channel-plane layout of csrc/netsq.hip: [h + 2][c / 16][w + 2][16] bytes
+        a - 128, borders = the tensor's zero point (set once, never written)."""
         assert c % 16 == 0 and 0 <= zp <= 255
-        buf = self.buffer((h + 2) * (w + 2) * c, DT_U8, fill=zp)
+        buf = self.buffer((h + 2) * (w + 2) * c, DT_U8, fill=zp ^ 0x80)      # stored bytes are a - 128 (MFMA operands as they lie)
         self.tensors.append(dict(buf=buf, h=h, w=w, c=c, cs=c, coff=0, dtype=DT_U8, q16=1, zp=int(zp)))
         return len(self.tensors) - 1
 

@@ -89,10 +89,32 @@ def pack_conv0(L):
 
 
 def pack_dw(L):
+    """Stand-alone depthwise op: int16 taps w - zw [9][C]; cbias = bias - (za - 128) * sum_t (w_t - zw) (the stored input bytes are a - 128)."""
     w = L['w'].astype(np.int64) - int(L['w_zp'])            # [3][3][C]
     c = w.shape[2]
-    cb = L['bias'].astype(np.int64) - int(L['in_zp']) * w.reshape(9, c).sum(axis=0)
+    cb = L['bias'].astype(np.int64) - (int(L['in_zp']) - 128) * w.reshape(9, c).sum(axis=0)
     return w.reshape(9, c).astype(np.int16), cb.astype(np.int32)
+
+
+def pack_dw_mfma(L):
+    """Fused block's depthwise stage on the matrix pipe (csrc/netsq.hip q_dwpw_k): per plane of 16 channels and lane (g, r) the six
+    bytes of the lane's diagonal element -- tap 4 ks + g of channel r for k steps ks = 0..2, split hi = clamp(w - zw, -128, 127),
+    lo = (w - zw) - hi -- as uint32 [C / 16][64][2].  None when a weight needs lo = 128 (w - zw = 255)."""
+    w9 = (L['w'].astype(np.int64) - int(L['w_zp'])).reshape(9, -1)       # [tap][C]
+    c = w9.shape[1]
+    hi = np.clip(w9, -128, 127)
+    lo = w9 - hi
+    if lo.max() > 127:
+        return None
+    tab = np.zeros((c // 16, 64, 2, 4), np.uint8)
+    for ks in range(3):
+        for g in range(4):
+            t = 4 * ks + g
+            if t < 9:
+                tab[:, g * 16:(g + 1) * 16, 0, ks] = (hi[t].reshape(c // 16, 16) & 0xff).astype(np.uint8)
+                tab[:, g * 16:(g + 1) * 16, 1, ks] = (lo[t].reshape(c // 16, 16) & 0xff).astype(np.uint8)
+    cb = L['bias'].astype(np.int64) - (int(L['in_zp']) - 128) * w9.sum(axis=0)
+    return tab.reshape(c // 16, 64, 8).view(np.uint32).reshape(c // 16, 64, 2), cb.astype(np.int32)
 
 
 def compile_ssd_mobilenet_quant(qm):
@@ -163,23 +185,19 @@ def compile_ssd_mobilenet_quant(qm):
         if not FUSE_BLOCKS or (cin, cout, stride) not in FUSED_SHAPES or wo < 19:
             return conv(dw(src, dname), pname)
         assert s['zp'] == Ld['in_zp'] and Ld['out_zp'] == Lp['in_zp'] and Ld['w'].shape[2] == cin and Lp['w'].shape[2] == cin
-        w9 = (Ld['w'].astype(np.int64) - int(Ld['w_zp'])).reshape(9, cin)
-        pairs = np.zeros((cin, 10), np.int16)
-        pairs[:, :9] = w9.T
-        dcb = (Ld['bias'].astype(np.int64) - int(Ld['in_zp']) * w9.sum(axis=0)).astype(np.int32)
+        packed_dw = pack_dw_mfma(Ld)
+        rd, rp = _req_words(Ld), _req_words(Lp)
+        if packed_dw is None or rd[33] < 1 or rp[33] < 1:
+            return conv(dw(src, dname), pname)                             # w - zw = 255, or a multiplier >= 0.5: the two-op form handles it
+        dwa, dcb = packed_dw
         wp, cb, kcpt = pack_conv(Lp, QEPI_Q16)
         zwc = 128 - int(Lp['w_zp'])
-        cb = (cb.astype(np.int64) - 128 * cin * zwc).astype(np.int64)       # the kernel's row sums are of the bytes themselves, not of a - 128
-        assert np.abs(cb).max() < 2 ** 31
-        rd, rp = _req_words(Ld), _req_words(Lp)
-        if rd[33] < 1 or rp[33] < 1:
-            return conv(dw(src, dname), pname)                             # a multiplier >= 0.5: the two-op form handles it
         dst = P.qtensor(ho, wo, cout, Lp['out_zp'])
         raw = dict(rp)
         raw.update({38: zwc, 39: int(Lp['in_zp'])})
         P._op(OP_QDWPW, src=src, dst=dst, kh=1, kw=1, stride=stride, pad_t=pt, pad_l=pl, cin=cin, cout=cout, cout_pad=cout, kpad=kcpt,
-              w_off=P.add_blob(wp), b_off=P.add_blob(cb.astype(np.int32)), ho=ho, wo=wo,
-              p=[P.add_blob(pairs.view(np.int32)), P.add_blob(dcb), rd[32], rd[33], rd[36], rd[37]], bk=rd[40], raw=raw)
+              w_off=P.add_blob(wp), b_off=P.add_blob(cb), ho=ho, wo=wo,
+              p=[P.add_blob(dwa), P.add_blob(dcb), rd[32], rd[33], rd[36], rd[37]], bk=rd[40], raw=raw)
         info('q_dwpw_k', 2 * ho * wo * cin * (9 + cout), s['h'] * s['w'] * cin + ho * wo * cout, cin * (9 + cout) + 4 * (cin + cout))
         return dst
 
@@ -224,12 +242,12 @@ def compile_ssd_mobilenet_quant(qm):
 def unpack_q16(raw, h, w, c):
     """dd_net_read of a bordered tensor ([n][h + 2][c / 16][w + 2][16] bytes) -> u8 NHWC [n][h][w][c] (the interior)."""
     n = raw.size // ((h + 2) * (w + 2) * c)
-    a = np.asarray(raw, dtype=np.uint8).reshape(n, h + 2, c // 16, w + 2, 16)[:, 1:-1, :, 1:-1, :]
+    a = np.asarray(raw, dtype=np.uint8).reshape(n, h + 2, c // 16, w + 2, 16)[:, 1:-1, :, 1:-1, :] ^ 0x80       # stored as a - 128
     return np.ascontiguousarray(np.transpose(a, (0, 1, 3, 2, 4)).reshape(n, h, w, c))
 
 
 def borders_q16(raw, h, w, c):
     """The border bytes of a bordered tensor, flattened (tests: they must still hold the zero point after a forward)."""
     n = raw.size // ((h + 2) * (w + 2) * c)
-    a = np.asarray(raw, dtype=np.uint8).reshape(n, h + 2, c // 16, w + 2, 16)
+    a = np.asarray(raw, dtype=np.uint8).reshape(n, h + 2, c // 16, w + 2, 16) ^ 0x80
     return np.concatenate([a[:, 0].reshape(-1), a[:, -1].reshape(-1), a[:, :, :, 0].reshape(-1), a[:, :, :, -1].reshape(-1)])
