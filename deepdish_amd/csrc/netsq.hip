@@ -91,9 +91,9 @@ struct QConvP {
     QReq R;
 };
 
-// One wave item = MQ 16-channel fragments x two 16-pixel fragments; operands straight from L2 / HBM in fragment shape (Q16 is
+// One wave item = MQ 16-channel fragments x NPF (2 or 4) 16-pixel fragments; operands straight from L2 / HBM in fragment shape (Q16 is
 // that shape), no LDS.  Small layers only (SSD extras and heads, 10x10 MobileNet blocks): the big ones run q_dwpw_k.
-template <int MQ, bool ROWSUM>
+template <int MQ, bool ROWSUM, int NPF, bool PIPE>
 __global__ __launch_bounds__(256) void q_conv_k(const QConvP P, const int n_items, const int n_mgroups) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 15, fq = lane >> 4;
@@ -101,11 +101,11 @@ __global__ __launch_bounds__(256) void q_conv_k(const QConvP P, const int n_item
     if (item >= n_items) return;                                   // whole waves leave; no barrier below
     const int mg = item % n_mgroups, pf = item / n_mgroups;
     const size_t PP = (size_t)(P.W + 2) * 16, RP = PP * P.c16_in;  // plane / row pitch of the source
-    const uint8_t *base[2];
-    int qn[2], qy[2], qx[2]; bool live[2];
+    const uint8_t *base[NPF];
+    int qn[NPF], qy[NPF], qx[NPF]; bool live[NPF];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        int q = pf * 32 + j * 16 + fr;
+    for (int j = 0; j < NPF; ++j) {
+        int q = pf * (16 * NPF) + j * 16 + fr;
         live[j] = q < P.m;
         q = min(q, P.m - 1);
         const int hw = P.ho * P.wo;
@@ -113,39 +113,78 @@ __global__ __launch_bounds__(256) void q_conv_k(const QConvP P, const int n_item
         qy[j] = r / P.wo; qx[j] = r - qy[j] * P.wo;
         base[j] = P.in + ((size_t)qn[j] * (P.H + 2) + qy[j] * P.stride + P.off_y) * RP + (size_t)(qx[j] * P.stride + P.off_x) * 16;
     }
-    i4v acc[MQ][2];
+    i4v acc[MQ][NPF];
 #pragma unroll
-    for (int m = 0; m < MQ; ++m) { acc[m][0] = i4v{0, 0, 0, 0}; acc[m][1] = acc[m][0]; }
-    int rs[2] = {0, 0};
+    for (int m = 0; m < MQ; ++m)
+#pragma unroll
+        for (int j = 0; j < NPF; ++j) acc[m][j] = i4v{0, 0, 0, 0};
+    int rs[NPF];
+#pragma unroll
+    for (int j = 0; j < NPF; ++j) rs[j] = 0;
     const int ksteps = P.kh * P.kw * P.kc_per_tap;
     const i4v *wp = P.w + ((size_t)mg * MQ * ksteps) * 64 + lane;
-    int ks = 0;
-    for (int dy = 0; dy < P.kh; ++dy)
-        for (int dx = 0; dx < P.kw; ++dx)
-            for (int kc = 0; kc < P.kc_per_tap; ++kc, ++ks) {
-                const int plane = 4 * kc + fq;
-                const bool kv = plane < P.c16_in;
-                const size_t off = (size_t)dy * RP + (size_t)dx * 16 + (size_t)min(plane, P.c16_in - 1) * PP;
-                i4v b[2];
+    // k step ks = (tap, 64-channel slice): the operands of step ks + 1 are requested before the MFMAs of step ks are issued (a step's
+    // loads followed by its own MFMAs left every step waiting out an L2 round trip: 36 of them in a 3x3 layer with 256 channels)
+    auto step_off = [&](int ks, bool &kv) -> size_t {
+        const int tap = ks / P.kc_per_tap, kc = ks - tap * P.kc_per_tap, dy = tap / P.kw, dx = tap - dy * P.kw;
+        const int plane = 4 * kc + fq;
+        kv = plane < P.c16_in;
+        return (size_t)dy * RP + (size_t)dx * 16 + (size_t)min(plane, P.c16_in - 1) * PP;
+    };
+    auto load_step = [&](int ks, i4v (&bb)[NPF], i4v (&aa)[MQ]) {
+        bool kv;
+        const size_t off = step_off(ks, kv);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    b[j] = *reinterpret_cast<const i4v *>(base[j] + off);      // stored as a - 128: the MFMA operand as it lies
-                    if (!kv) b[j] = i4v{0, 0, 0, 0};
-                    if (ROWSUM) {
+        for (int j = 0; j < NPF; ++j) {
+            bb[j] = *reinterpret_cast<const i4v *>(base[j] + off);      // stored as a - 128: the MFMA operand as it lies
+            if (!kv) bb[j] = i4v{0, 0, 0, 0};
+        }
 #pragma unroll
-                        for (int d = 0; d < 4; ++d) rs[j] = sdot4(b[j][d], 0x01010101, rs[j]);
-                    }
+        for (int m = 0; m < MQ; ++m) aa[m] = (mg * MQ + m) < P.n_mfrag ? wp[((size_t)m * ksteps + ks) * 64] : i4v{0, 0, 0, 0};
+    };
+    i4v b0[NPF], a0[MQ], b1[NPF], a1[MQ];
+    if constexpr (!PIPE) {                                          // launches with thousands of wave items per CU: the waves cover each other's round trips,
+        for (int ks = 0; ks < ksteps; ++ks) {                       // and the second operand set only costs occupancy (b13: 138 -> 155 us with it)
+            load_step(ks, b0, a0);
+#pragma unroll
+            for (int j = 0; j < NPF; ++j) {
+                if (ROWSUM) {
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) rs[j] = sdot4(b0[j][d], 0x01010101, rs[j]);
                 }
 #pragma unroll
-                for (int m = 0; m < MQ; ++m) {
-                    const i4v a = (mg * MQ + m) < P.n_mfrag ? wp[((size_t)m * ksteps + ks) * 64] : i4v{0, 0, 0, 0};
-                    acc[m][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b[0], acc[m][0], 0, 0, 0);
-                    acc[m][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b[1], acc[m][1], 0, 0, 0);
-                }
+                for (int m = 0; m < MQ; ++m) acc[m][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[m], b0[j], acc[m][j], 0, 0, 0);
             }
+        }
+    } else {
+    load_step(0, b0, a0);
+    for (int ks = 0; ks < ksteps; ks += 2) {
+        if (ks + 1 < ksteps) load_step(ks + 1, b1, a1);
+#pragma unroll
+        for (int j = 0; j < NPF; ++j) {
+            if (ROWSUM) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) rs[j] = sdot4(b0[j][d], 0x01010101, rs[j]);
+            }
+#pragma unroll
+            for (int m = 0; m < MQ; ++m) acc[m][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[m], b0[j], acc[m][j], 0, 0, 0);
+        }
+        if (ks + 1 >= ksteps) break;
+        if (ks + 2 < ksteps) load_step(ks + 2, b0, a0);
+#pragma unroll
+        for (int j = 0; j < NPF; ++j) {
+            if (ROWSUM) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) rs[j] = sdot4(b1[j][d], 0x01010101, rs[j]);
+            }
+#pragma unroll
+            for (int m = 0; m < MQ; ++m) acc[m][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[m], b1[j], acc[m][j], 0, 0, 0);
+        }
+    }
+    }
     if (ROWSUM) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NPF; ++j) {
             rs[j] += __shfl_xor(rs[j], 16, 64);
             rs[j] += __shfl_xor(rs[j], 32, 64);
             rs[j] *= P.zwc;
@@ -158,7 +197,7 @@ __global__ __launch_bounds__(256) void q_conv_k(const QConvP P, const int n_item
             const i4v c0 = cb[0], c1 = cb[1], c2 = cb[2], c3 = cb[3];
             const size_t PPo = (size_t)(P.Wo + 2) * 16;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < NPF; ++j) {
                 u4v o;
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
@@ -181,7 +220,7 @@ __global__ __launch_bounds__(256) void q_conv_k(const QConvP P, const int n_item
             if (ch >= P.cout_store) continue;
             const i4v c = *reinterpret_cast<const i4v *>(P.cbias + ch);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < NPF; ++j) {
                 unsigned wv = 0;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) wv |= (unsigned)q_requant(acc[m][j][r] + rs[j] + c[r], P.R) << (8 * r);
@@ -206,66 +245,74 @@ struct QConv0P {
 
 // 3x3 stride-2 conv over the 3 colour channels, 32 output channels: one MFMA k slice (3 filter rows x 9 bytes of an image row,
 // 37 zero slots) per 16 pixels, two fragments of 16 channels.  Taps outside the image read the input zero point.
+constexpr int C0F = 4;      // 16-pixel fragments per wave: twelve loads in flight per lane (one fragment per wave was bound by the HBM latency: 222 us per 384 frames)
 __global__ __launch_bounds__(256) void q_conv0_k(const QConv0P P, const int n_frags) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 15, fq = lane >> 4;
-    const int f = blockIdx.x * 4 + wave;
-    if (f >= n_frags) return;
-    int q = f * 16 + fr;
-    const bool live = q < P.m;
-    q = min(q, P.m - 1);
-    const int hw = P.ho * P.wo, n = q / hw, r0 = q - n * hw, y = r0 / P.wo, x = r0 - y * P.wo;
+    const int f0 = (blockIdx.x * 4 + wave) * C0F;
+    if (f0 >= n_frags) return;
     const unsigned zp4 = (unsigned)P.in_zp * 0x01010101u;
-    unsigned d[3] = {zp4, zp4, zp4};
-    const int row = y * P.stride + fq - P.pad_t, col = x * P.stride - P.pad_l;       // first of the three source pixels of this filter row
-    if (fq < 3 && row >= 0 && row < P.H) {
-        const long long a = ((long long)n * P.H + row) * P.W * 3 + (long long)col * 3;     // may be < 0 by up to 3 (col = -1): those bytes are replaced below
+    const int hw = P.ho * P.wo;
+    unsigned w[C0F][3]; int o_[C0F]; bool rowok[C0F], live[C0F]; int pn[C0F], py[C0F], px[C0F];
+#pragma unroll
+    for (int j = 0; j < C0F; ++j) {
+        int q = (f0 + j) * 16 + fr;
+        live[j] = q < P.m;
+        q = min(q, P.m - 1);
+        pn[j] = q / hw; const int r0 = q - pn[j] * hw; py[j] = r0 / P.wo; px[j] = r0 - py[j] * P.wo;
+        const int row = py[j] * P.stride + fq - P.pad_t, col = px[j] * P.stride - P.pad_l;      // first of the three source pixels of this filter row
+        rowok[j] = fq < 3 && row >= 0 && row < P.H;
+        const long long a = ((long long)pn[j] * P.H + (rowok[j] ? row : 0)) * P.W * 3 + (long long)col * 3;   // may be < 0 by up to 3 (col = -1): those bytes are replaced below
         const long long a4 = a & ~3ll;
-        const int o = (int)(a - a4);
-        unsigned w[3];
+        o_[j] = (int)(a - a4);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const long long ai = min(max(a4 + 4 * i, 0ll), P.total_bytes - 4);
-            w[i] = *reinterpret_cast<const unsigned *>(P.src + ai);
-        }
-        d[0] = __builtin_amdgcn_alignbyte(w[1], w[0], o);
-        d[1] = __builtin_amdgcn_alignbyte(w[2], w[1], o);
-        d[2] = __builtin_amdgcn_alignbyte(0u, w[2], o);
-        // columns outside the image: pixel i of the three covers bytes 3i .. 3i + 2
+        for (int i = 0; i < 3; ++i) w[j][i] = *reinterpret_cast<const unsigned *>(P.src + min(max(a4 + 4 * i, 0ll), P.total_bytes - 4));
+    }
+    const i4v wa = P.w[lane], wb = P.w[64 + lane];
+    // fragment m's row 4g + r was packed with channel 8g + 4m + r: this lane holds channels 8 fq .. 8 fq + 7
+    const i4v c0 = *reinterpret_cast<const i4v *>(P.cbias + 8 * fq), c1 = *reinterpret_cast<const i4v *>(P.cbias + 8 * fq + 4);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const bool in = col + i >= 0 && col + i < P.W;
-            if (!in) {
+    for (int j = 0; j < C0F; ++j) {
+        unsigned d[3] = {zp4, zp4, zp4};
+        if (rowok[j]) {
+            d[0] = __builtin_amdgcn_alignbyte(w[j][1], w[j][0], o_[j]);
+            d[1] = __builtin_amdgcn_alignbyte(w[j][2], w[j][1], o_[j]);
+            d[2] = __builtin_amdgcn_alignbyte(0u, w[j][2], o_[j]);
+            const int col = px[j] * P.stride - P.pad_l;
+            // columns outside the image: pixel i of the three covers bytes 3i .. 3i + 2
 #pragma unroll
-                for (int b = 3 * i; b < 3 * i + 3; ++b) {
-                    const unsigned msk = 0xffu << (8 * (b & 3));
-                    d[b >> 2] = (d[b >> 2] & ~msk) | (zp4 & msk);
+            for (int i = 0; i < 3; ++i) {
+                const bool in = col + i >= 0 && col + i < P.W;
+                if (!in) {
+#pragma unroll
+                    for (int b = 3 * i; b < 3 * i + 3; ++b) {
+                        const unsigned msk = 0xffu << (8 * (b & 3));
+                        d[b >> 2] = (d[b >> 2] & ~msk) | (zp4 & msk);
+                    }
                 }
             }
         }
-    }
-    i4v b;
-    b[0] = (int)(d[0] ^ 0x80808080u); b[1] = (int)(d[1] ^ 0x80808080u); b[2] = (int)((d[2] ^ 0x80u) & 0xffu); b[3] = 0;
-    if (fq == 3) b = i4v{0, 0, 0, 0};
-    int rs = sdot4(b[0], 0x01010101, sdot4(b[1], 0x01010101, sdot4(b[2], 0x01010101, 0)));
-    rs += __shfl_xor(rs, 16, 64);
-    rs += __shfl_xor(rs, 32, 64);
-    rs *= P.zwc;
-    i4v acc0 = {0, 0, 0, 0}, acc1 = acc0;
-    acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(P.w[lane], b, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(P.w[64 + lane], b, acc1, 0, 0, 0);
-    // fragment m's row 4g + r was packed with channel 8g + 4m + r: this lane holds channels 8 fq .. 8 fq + 7
-    const i4v c0 = *reinterpret_cast<const i4v *>(P.cbias + 8 * fq), c1 = *reinterpret_cast<const i4v *>(P.cbias + 8 * fq + 4);
-    unsigned lo = 0, hi = 0;
+        i4v b;
+        b[0] = (int)(d[0] ^ 0x80808080u); b[1] = (int)(d[1] ^ 0x80808080u); b[2] = (int)((d[2] ^ 0x80u) & 0xffu); b[3] = 0;
+        if (fq == 3) b = i4v{0, 0, 0, 0};
+        int rs = sdot4(b[0], 0x01010101, sdot4(b[1], 0x01010101, sdot4(b[2], 0x01010101, 0)));
+        rs += __shfl_xor(rs, 16, 64);
+        rs += __shfl_xor(rs, 32, 64);
+        rs *= P.zwc;
+        i4v acc0 = {0, 0, 0, 0}, acc1 = acc0;
+        acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa, b, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(wb, b, acc1, 0, 0, 0);
+        unsigned lo = 0, hi = 0;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        lo |= (unsigned)q_requant(acc0[r] + rs + c0[r], P.R) << (8 * r);
-        hi |= (unsigned)q_requant(acc1[r] + rs + c1[r], P.R) << (8 * r);
-    }
-    if (live) {
-        const size_t PPo = (size_t)(P.wo + 2) * 16;
-        uint8_t *dst = P.out + (((size_t)n * (P.ho + 2) + y + 1) * 2 + (fq >> 1)) * PPo + (size_t)(x + 1) * 16 + (fq & 1) * 8;
-        *reinterpret_cast<uint2 *>(dst) = make_uint2(lo ^ 0x80808080u, hi ^ 0x80808080u);
+        for (int r = 0; r < 4; ++r) {
+            lo |= (unsigned)q_requant(acc0[r] + rs + c0[r], P.R) << (8 * r);
+            hi |= (unsigned)q_requant(acc1[r] + rs + c1[r], P.R) << (8 * r);
+        }
+        if (live[j]) {
+            const size_t PPo = (size_t)(P.wo + 2) * 16;
+            uint8_t *dst = P.out + (((size_t)pn[j] * (P.ho + 2) + py[j] + 1) * 2 + (fq >> 1)) * PPo + (size_t)(px[j] + 1) * 16 + (fq & 1) * 8;
+            *reinterpret_cast<uint2 *>(dst) = make_uint2(lo ^ 0x80808080u, hi ^ 0x80808080u);
+        }
     }
 }
 
@@ -319,7 +366,7 @@ __global__ __launch_bounds__(256) void q_dw_k(const QDwP P) {
 
 // ------------------------------------------------------------------------------------------------ SSD decode
 // First stage of TFLite_Detection_PostProcess on the quantised head tensors (kernels/detection_postprocess.cc:
-// DequantizeBoxEncodings, DequantizeClassPredictions behind the graph's uint8 LOGISTIC): sixteen lanes per anchor sweep its
+// DequantizeBoxEncodings, DequantizeClassPredictions behind the graph's uint8 LOGISTIC): the lanes of an anchor sweep its
 // class bytes through the logistic table, a butterfly picks the best class (background skipped, lowest class on ties),
 // one lane decodes the box with csrc/ssd_dev.h's statements.
 struct QDecP {
@@ -332,20 +379,26 @@ struct QDecP {
 };
 
 __global__ __launch_bounds__(256) void q_ssd_decode_k(const QDecP P) {
+    // eight lanes per anchor: six of them take 16 class bytes each (one load), table look-ups from LDS, a three-step butterfly
     __shared__ uint8_t lut[256];
     lut[threadIdx.x] = P.lut[threadIdx.x];
     __syncthreads();
-    const int a = (blockIdx.x * 256 + threadIdx.x) >> 4, sub = threadIdx.x & 15;
+    const int a = (blockIdx.x * 256 + threadIdx.x) >> 3, sub = threadIdx.x & 7;
     const size_t z = blockIdx.y;
     const bool live = a < P.n_anchors;
     const uint8_t *c = P.cls + (z * P.n_anchors + (live ? a : 0)) * P.cls_stride;
     int best = -1, bi = 0x7fffffff;
-    for (int k = 1 + sub; k < P.n_classes; k += 16) {          // class 0 = background
-        const int v = lut[c[k]];
-        if (v > best) { best = v; bi = k - 1; }
+    if (sub * 16 < P.n_classes) {
+        const u4v v = *reinterpret_cast<const u4v *>(c + sub * 16);         // cls_stride is a multiple of 16: aligned, inside the row
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int k = sub * 16 + i;                                      // class 0 = background
+            const int q = lut[(v[i >> 2] >> (8 * (i & 3))) & 0xffu];
+            if (k >= 1 && k < P.n_classes && q > best) { best = q; bi = k - 1; }
+        }
     }
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) {
+    for (int o = 4; o > 0; o >>= 1) {
         const int ob = __shfl_xor(best, o, 64), oi = __shfl_xor(bi, o, 64);
         if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
     }
@@ -421,34 +474,34 @@ __device__ __forceinline__ int q_clamp(int z, int lo, int hi) {                 
     return r;
 }
 
-template <int CIN, int COUT, int WP, int STRIDE, int LPT, bool ROWSUM>
+template <int CIN, int COUT, int WP, int STRIDE, int LPT, bool ROWSUM, bool TEAMS>
 __global__ __launch_bounds__((COUT / 64) * WP * 64) void q_dwpw_k(const QDwpwP P, const int n_tiles, const int tiles_per_block) {
     constexpr int WM = COUT / 64, NW = WM * WP, NT = NW * 64;
     constexpr int KC = (CIN + 63) / 64, CINP = KC * 64, C16 = CIN / 16;
-    constexpr int CGW = C16 / NW > 0 ? C16 / NW : 1;                // planes per wave in the depthwise stage (each with all four pixel fragments)
+    constexpr int NOB = TEAMS ? 2 : 1, NRS = TEAMS ? 3 : 2;         // operand tiles, row-sum buffers
     static_assert(C16 % NW == 0 || NW % C16 == 0, "planes over waves");
+    static_assert(!TEAMS || (NW % 2 == 0 && C16 % NW == 0), "teams: every wave owns whole planes");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int wm = wave / WP, wp = wave % WP;
     const int RB = (P.W + 2) * CIN, PP = (P.W + 2) * 16;           // ring row / plane pitch (bytes)
     uint8_t *ring = smem;
-    uint8_t *opnd = smem + (size_t)P.NR * RB;                       // [CINP / 16][QT][16]
-    int *rowsum = reinterpret_cast<int *>(opnd + QT * CINP);        // [2][QT]
-    unsigned *pixoff = reinterpret_cast<unsigned *>(rowsum + 2 * QT);   // [2][QT]
+    uint8_t *opnd = smem + (size_t)P.NR * RB;                       // [NOB][CINP / 16][QT][16]
+    int *rowsum = reinterpret_cast<int *>(opnd + NOB * QT * CINP);  // [NRS][QT]
+    unsigned *pixoff = reinterpret_cast<unsigned *>(rowsum + NRS * QT);   // [2][QT]
     i4v *pinfo = reinterpret_cast<i4v *>(pixoff + 2 * QT);          // [2][QT]: ring offsets of the pixel's three window rows, column offset
+    int *cbl = reinterpret_cast<int *>(pinfo + 2 * QT);             // [COUT]: the pointwise layer's per-channel constants
 
-    // the wave's pointwise filter and per-channel constants, once
+    // the wave's pointwise filter, once
     i4v Wr[4][KC];
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) Wr[m][kc] = P.w[((size_t)(wm * 4 + m) * KC + kc) * 64 + lane];
-    i4v cb[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) cb[m] = *reinterpret_cast<const i4v *>(P.cbias + 64 * wm + 16 * fq + 4 * m);
-    if (CIN < CINP) for (int i = tid; i < QT * CINP / 16; i += NT) reinterpret_cast<u4v *>(opnd)[i] = u4v{0, 0, 0, 0};   // k slots without channels
-    for (int i = tid; i < 2 * QT; i += NT) rowsum[i] = 0;
+    for (int i = tid; i < COUT; i += NT) cbl[i] = P.cbias[i];
+    if (CIN < CINP) for (int i = tid; i < NOB * QT * CINP / 16; i += NT) reinterpret_cast<u4v *>(opnd)[i] = u4v{0, 0, 0, 0};   // k slots without channels
+    for (int i = tid; i < NRS * QT; i += NT) rowsum[i] = 0;
     // depthwise lane constants: which byte of the 16 is this lane's diagonal element; which window row / column its tap of k step ks is
     unsigned dmask[4];
 #pragma unroll
@@ -483,118 +536,101 @@ __global__ __launch_bounds__((COUT / 64) * WP * 64) void q_dwpw_k(const QDwpwP P
         pinfo[buf * QT + tid] = i4v{s0 * RB, s1 * RB, s2 * RB, (x * STRIDE + P.off_x) * 16};
         pixoff[buf * QT + tid] = q <= q1 ? (unsigned)(((size_t)n * (P.ho + 2) + y + 1) * P.c16_out * ((P.wo + 2) * 16) + (size_t)(x + 1) * 16) : 0xffffffffu;
     };
-    int n, q0, q1, ga, gb;
-    tile_rows(t_begin, n, q0, q1, ga, gb);
-    {   // the first tile's rows, synchronously
-        const unsigned nb = (unsigned)(gb - ga + 1) * RB;
-        const uint8_t *src = P.in + (size_t)ga * RB;
+    auto load_rows_sync = [&](int lo, int hi) {                     // whole rows [lo, hi] into the ring (start of the block's range only)
+        if (hi < lo) return;
+        const unsigned nb = (unsigned)(hi - lo + 1) * RB;
+        const uint8_t *src = P.in + (size_t)lo * RB;
         for (unsigned idx = tid * 16u; idx < nb; idx += NT * 16u) {
             const unsigned row = idx / (unsigned)RB, off = idx - row * RB;
-            *reinterpret_cast<u4v *>(ring + (size_t)((ga + row) % P.NR) * RB + off) = *reinterpret_cast<const u4v *>(src + idx);
+            *reinterpret_cast<u4v *>(ring + (size_t)((lo + row) % P.NR) * RB + off) = *reinterpret_cast<const u4v *>(src + idx);
         }
-    }
-    if (tid < QT) geometry(n, q0, q1, t_begin & 1);
-    int loaded_hi = gb;
-    __syncthreads();
-
-    unsigned long long st[6] = {0, 0, 0, 0, 0, 0}, tprev = P.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
-#define Q_STAMP(k) do { if (P.dbg) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st[k] += now_ - tprev; tprev = now_; } } while (0)
-    for (int t = t_begin; t < t_end; ++t) {
-        // ---- which rows the next tile adds
-        int lo = 0; unsigned nb = 0;
-        int n2 = 0, q02 = 0, q12 = 0, ga2 = 0, gb2 = 0;
-        if (t + 1 < t_end) {
-            tile_rows(t + 1, n2, q02, q12, ga2, gb2);
-            lo = max(loaded_hi + 1, ga2);
-            nb = gb2 >= lo ? (unsigned)(gb2 - lo + 1) * RB : 0u;
-            loaded_hi = max(loaded_hi, gb2);
+    };
+    // ---- depthwise stage: planes [cg0, cg0 + n_cg) x the four pixel fragments of the tile whose geometry is in buffer gbuf
+    auto dw_planes = [&](int cg0, int n_cg, int gbuf, int obuf, int rsb) {
+        int tapoff[3][4];                                            // ring offset of this lane's tap of k step ks at its pixel of fragment f (plane 0)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const i4v pi = pinfo[gbuf * QT + 16 * f + fr];
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) tapoff[ks][f] = (tap_row[ks] == 0 ? pi[0] : tap_row[ks] == 1 ? pi[1] : pi[2]) + pi[3] + tap_dx[ks];
         }
-        const int cur = t & 1;
-        // ---- depthwise stage: this wave's planes x the four pixel fragments
-        {
-            i4v pi[4];
+        int rs[4] = {0, 0, 0, 0};
+        uint8_t *ob = opnd + (size_t)obuf * QT * CINP;
+        for (int ci = 0; ci < n_cg; ++ci) {
+            const int cg = cg0 + ci;
+            const uint2 ab = P.dw_a[cg * 64 + lane];
+            const i4v cbv = *reinterpret_cast<const i4v *>(P.dw_cb + cg * 16 + 4 * fq);
+            const int pofs = cg * PP;
+            i4v acc[4];
 #pragma unroll
-            for (int f = 0; f < 4; ++f) pi[f] = pinfo[cur * QT + 16 * f + fr];
-            int rs[4] = {0, 0, 0, 0};
-            const int n_cg = C16 >= NW ? CGW : 1;
-            const int cg0 = C16 >= NW ? wave * CGW : wave % C16;
-            const bool work = C16 >= NW || wave < C16;               // more waves than planes: the surplus waves sit this stage out
-            for (int ci = 0; ci < n_cg && work; ++ci) {
-                const int cg = cg0 + ci;
-                const uint2 ab = P.dw_a[cg * 64 + lane];
-                const i4v cbv = *reinterpret_cast<const i4v *>(P.dw_cb + cg * 16 + 4 * fq);
-                i4v Ah[3], Al[3];
+            for (int f = 0; f < 4; ++f) acc[f] = cbv;
+            i4v b[2][4];
 #pragma unroll
-                for (int ks = 0; ks < 3; ++ks) {
-                    const unsigned sel = 0x01010101u * (unsigned)ks;
-                    const unsigned rh = __builtin_amdgcn_perm(ab.x, ab.x, sel), rl = __builtin_amdgcn_perm(ab.y, ab.y, sel);
+            for (int f = 0; f < 4; ++f) b[0][f] = *reinterpret_cast<const i4v *>(ring + tapoff[0][f] + pofs);
 #pragma unroll
-                    for (int d = 0; d < 4; ++d) { Ah[ks][d] = (int)(rh & dmask[d]); Al[ks][d] = (int)(rl & dmask[d]); }
-                }
-                const int pofs = cg * PP;
-                i4v acc[4];
+            for (int ks = 0; ks < 3; ++ks) {
+                const unsigned sel = 0x01010101u * (unsigned)ks;
+                const unsigned rh = __builtin_amdgcn_perm(ab.x, ab.x, sel), rl = __builtin_amdgcn_perm(ab.y, ab.y, sel);
+                i4v Ah, Al;
 #pragma unroll
-                for (int f = 0; f < 4; ++f) acc[f] = cbv;
+                for (int d = 0; d < 4; ++d) { Ah[d] = (int)(rh & dmask[d]); Al[d] = (int)(rl & dmask[d]); }
+                if (ks < 2) {                                        // the next k step's operands are on their way while this one multiplies
 #pragma unroll
-                for (int ks = 0; ks < 3; ++ks) {
-                    i4v b[4];
-#pragma unroll
-                    for (int f = 0; f < 4; ++f) {
-                        const int ro = tap_row[ks] == 0 ? pi[f][0] : tap_row[ks] == 1 ? pi[f][1] : pi[f][2];
-                        b[f] = *reinterpret_cast<const i4v *>(ring + ro + pi[f][3] + tap_dx[ks] + pofs);
-                    }
-#pragma unroll
-                    for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Ah[ks], b[f], acc[f], 0, 0, 0);
-#pragma unroll
-                    for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Al[ks], b[f], acc[f], 0, 0, 0);
+                    for (int f = 0; f < 4; ++f) b[(ks + 1) & 1][f] = *reinterpret_cast<const i4v *>(ring + tapoff[ks + 1][f] + pofs);
                 }
 #pragma unroll
-                for (int f = 0; f < 4; ++f) {
-                    unsigned packed = 0;
+                for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Ah, b[ks & 1][f], acc[f], 0, 0, 0);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) packed |= (unsigned)q_clamp(q_requant_relu(acc[f][r], Md, Cd, shd), lod, hid) << (8 * r);
-                    packed ^= 0x80808080u;
-                    if (ROWSUM) rs[f] = sdot4((int)packed, 0x01010101, rs[f]);
-                    *reinterpret_cast<unsigned *>(opnd + ((size_t)cg * QT + 16 * f + fr) * 16 + 4 * fq) = packed;
-                }
+                for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Al, b[ks & 1][f], acc[f], 0, 0, 0);
             }
-            if (ROWSUM && work) {
 #pragma unroll
-                for (int f = 0; f < 4; ++f) {
-                    int v = rs[f];
-                    v += __shfl_xor(v, 16, 64);
-                    v += __shfl_xor(v, 32, 64);
-                    if (fq == 0) atomicAdd(&rowsum[cur * QT + 16 * f + fr], v);
-                }
+            for (int f = 0; f < 4; ++f) {
+                unsigned packed = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) packed |= (unsigned)q_clamp(q_requant_relu(acc[f][r], Md, Cd, shd), lod, hid) << (8 * r);
+                packed ^= 0x80808080u;
+                if (ROWSUM) rs[f] = sdot4((int)packed, 0x01010101, rs[f]);
+                *reinterpret_cast<unsigned *>(ob + ((size_t)cg * QT + 16 * f + fr) * 16 + 4 * fq) = packed;
             }
         }
-        Q_STAMP(0);
-        __syncthreads();                                             // A: operand tile and row sums are complete; the ring is free
-        Q_STAMP(1);
-        // ---- request the next tile's rows (registers; they go to the ring when the matrix stage below is done)
-        u4v pf[LPT];
-        if (nb) {                                                    // (uniform) every request goes out back to back: no lane predicate, the
-            const uint8_t *src = P.in + (size_t)lo * RB;             // pieces past the end re-read the last one and are dropped at the write
+        if (ROWSUM && n_cg > 0) {
 #pragma unroll
-            for (int i = 0; i < LPT; ++i) pf[i] = *reinterpret_cast<const u4v *>(src + min((unsigned)(i * NT + tid) * 16u, nb - 16u));
+            for (int f = 0; f < 4; ++f) {
+                int v = rs[f];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                if (fq == 0) atomicAdd(&rowsum[rsb * QT + 16 * f + fr], v);
+            }
         }
-        if (tid < QT) {
-            rowsum[(cur ^ 1) * QT + tid] = 0;
-            if (t + 1 < t_end) geometry(n2, q02, q12, cur ^ 1);
-        }
-        // ---- pointwise stage
+    };
+    // ---- pointwise stage of this wave's channels / fragments
+    auto matrix = [&](int q0, int q1, int gbuf, int obuf, int rsb) {
+        const uint8_t *ob = opnd + (size_t)obuf * QT * CINP;
         const int nf = (q1 - q0) / 16 + 1;
+        // A lone ds_read -> s_waitcnt -> 4 MFMAs per K slice leaves the matrix pipe idle for the LDS latency eight times per fragment
+        // (2.2 k cycles per fragment measured, 0.5 k of MFMA): all K slices of a fragment are requested before its first MFMA, and the
+        // next fragment's as soon as this one's MFMAs are issued, so they land during the epilogue.
+        i4v b[KC];
+        if (wp < nf) {
+            const uint8_t *bp = ob + ((size_t)fq * QT + 16 * wp + fr) * 16;
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) b[kc] = *reinterpret_cast<const i4v *>(bp + (size_t)kc * 4 * QT * 16);
+        }
         for (int f = wp; f < nf; f += WP) {
             i4v acc[4];
-            const uint8_t *bp = opnd + ((size_t)fq * QT + 16 * f + fr) * 16;
 #pragma unroll
-            for (int kc = 0; kc < KC; ++kc) {
-                const i4v b = *reinterpret_cast<const i4v *>(bp + (size_t)kc * 4 * QT * 16);
+            for (int m = 0; m < 4; ++m) acc[m] = *reinterpret_cast<const i4v *>(cbl + 64 * wm + 16 * fq + 4 * m);
 #pragma unroll
-                for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Wr[m][kc], b, kc == 0 ? cb[m] : acc[m], 0, 0, 0);
+            for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Wr[m][kc], b[kc], acc[m], 0, 0, 0);
+            if (f + WP < nf) {
+                const uint8_t *bp = ob + ((size_t)fq * QT + 16 * (f + WP) + fr) * 16;
+#pragma unroll
+                for (int kc = 0; kc < KC; ++kc) b[kc] = *reinterpret_cast<const i4v *>(bp + (size_t)kc * 4 * QT * 16);
             }
-            const int rsv = ROWSUM ? rowsum[cur * QT + 16 * f + fr] * P.zwc : 0;
-            const unsigned po = pixoff[cur * QT + 16 * f + fr];
+            const int rsv = ROWSUM ? rowsum[rsb * QT + 16 * f + fr] * P.zwc : 0;
+            const unsigned po = pixoff[gbuf * QT + 16 * f + fr];
             u4v o;
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
@@ -605,27 +641,122 @@ __global__ __launch_bounds__((COUT / 64) * WP * 64) void q_dwpw_k(const QDwpwP P
             }
             if (po != 0xffffffffu) *reinterpret_cast<u4v *>(P.out + po + (size_t)(4 * wm + fq) * ((P.wo + 2) * 16)) = o;
         }
-        Q_STAMP(2);
-        if (nb) {
-            unsigned tid16 = (unsigned)tid * 16u;
-            asm volatile("" : "+v"(tid16));                          // keeps the (row, offset) pairs from being hoisted out of the tile loop (16 live registers: spills)
-            int slot0 = lo % P.NR;
+    };
+    auto pf_request = [&](u4v (&pf)[LPT], int lo, unsigned nb) {
+        if (!nb) return;                                             // (uniform) every request goes out back to back: no lane predicate, the
+        const uint8_t *src = P.in + (size_t)lo * RB;                 // pieces past the end re-read the last one and are dropped at the write
 #pragma unroll
-            for (int i = 0; i < LPT; ++i) {
-                const unsigned idx = (unsigned)(i * NT) * 16u + tid16;
-                if (idx < nb) {
-                    const unsigned row = __umulhi(idx, P.rb_magic), off = idx - row * RB;      // idx / RB (exact: idx * RB < 2^32)
-                    int slot = slot0 + (int)row;
-                    slot = slot >= P.NR ? slot - P.NR : slot;
-                    slot = slot >= P.NR ? slot - P.NR : slot;
-                    *reinterpret_cast<u4v *>(ring + (size_t)slot * RB + off) = pf[i];
-                }
+        for (int i = 0; i < LPT; ++i) pf[i] = *reinterpret_cast<const u4v *>(src + min((unsigned)(i * NT + tid) * 16u, nb - 16u));
+    };
+    auto pf_write = [&](const u4v (&pf)[LPT], int lo, unsigned nb) {
+        if (!nb) return;
+        unsigned tid16 = (unsigned)tid * 16u;
+        asm volatile("" : "+v"(tid16));                              // keeps the (row, offset) pairs from being hoisted out of the tile loop (16 live registers: spills)
+        const int slot0 = lo % P.NR;
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const unsigned idx = (unsigned)(i * NT) * 16u + tid16;
+            if (idx < nb) {
+                const unsigned row = __umulhi(idx, P.rb_magic), off = idx - row * RB;      // idx / RB (exact: idx * RB < 2^32)
+                int slot = slot0 + (int)row;
+                slot = slot >= P.NR ? slot - P.NR : slot;
+                slot = slot >= P.NR ? slot - P.NR : slot;
+                *reinterpret_cast<u4v *>(ring + (size_t)slot * RB + off) = pf[i];
             }
         }
-        Q_STAMP(3);
-        __syncthreads();                                             // B: the operand tile is free, the ring holds the next tile's rows
-        Q_STAMP(4);
-        n = n2; q0 = q02; q1 = q12; ga = ga2; gb = gb2;
+    };
+    // this wave's planes when every wave takes part in the depthwise stage
+    const int all_cg0 = C16 >= NW ? wave * (C16 / NW) : wave % C16, all_ncg = C16 >= NW ? C16 / NW : (wave < C16 ? 1 : 0);
+
+    int n, q0, q1, ga, gb;
+    tile_rows(t_begin, n, q0, q1, ga, gb);
+    load_rows_sync(ga, gb);
+    if (tid < QT) geometry(n, q0, q1, t_begin & 1);
+    int loaded_hi = gb;
+    __syncthreads();
+    unsigned long long st[6] = {0, 0, 0, 0, 0, 0}, tprev = P.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+#define Q_STAMP(k) do { if (P.dbg) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st[k] += now_ - tprev; tprev = now_; } } while (0)
+
+    if constexpr (!TEAMS) {
+        for (int t = t_begin; t < t_end; ++t) {
+            int lo = 0; unsigned nb = 0;
+            int n2 = 0, q02 = 0, q12 = 0, ga2 = 0, gb2 = 0;
+            if (t + 1 < t_end) {
+                tile_rows(t + 1, n2, q02, q12, ga2, gb2);
+                lo = max(loaded_hi + 1, ga2);
+                nb = gb2 >= lo ? (unsigned)(gb2 - lo + 1) * RB : 0u;
+                loaded_hi = max(loaded_hi, gb2);
+            }
+            const int cur = t & 1;
+            dw_planes(all_cg0, all_ncg, cur, 0, cur);
+            Q_STAMP(0);
+            __syncthreads();                                         // A: operand tile and row sums are complete; the ring is free
+            Q_STAMP(1);
+            u4v pf[LPT];
+            pf_request(pf, lo, nb);                                  // the next tile's rows: registers now, ring when the matrix stage is done
+            if (tid < QT) {
+                rowsum[(cur ^ 1) * QT + tid] = 0;
+                if (t + 1 < t_end) geometry(n2, q02, q12, cur ^ 1);
+            }
+            matrix(q0, q1, cur, 0, cur);
+            Q_STAMP(2);
+            pf_write(pf, lo, nb);
+            Q_STAMP(3);
+            __syncthreads();                                         // B: the operand tile is free, the ring holds the next tile's rows
+            Q_STAMP(4);
+            n = n2; q0 = q02; q1 = q12;
+        }
+    } else {
+        // Two teams (lower / upper half of the wave numbers: with eight waves one of each per SIMD), a tile step in two phases:
+        //     phase 1   team A: pointwise stage of tile t        team B: depthwise stage of tile t + 1, lower half of the planes
+        //     phase 2   team B: pointwise stage of tile t        team A: depthwise stage of tile t + 1, upper half of the planes
+        // so every SIMD always has one wave whose MFMAs are long dependent-free runs (pointwise) next to one that alternates short MFMA
+        // runs with vector work (depthwise, epilogues).  Then the rows tile t + 2 adds replace those tile t + 1 no longer needs.
+        constexpr int NWT = NW / 2, CGT = C16 / NW;                  // waves per team, planes per wave and phase
+        const int team = wave >= NWT, wt = wave - team * NWT;
+        dw_planes(all_cg0, all_ncg, t_begin & 1, t_begin & 1, t_begin % 3);          // the first tile's depthwise stage, all waves
+        int n1 = 0, q01 = 0, q11 = 0, ga1 = 0, gb1 = 0;
+        __syncthreads();
+        if (t_begin + 1 < t_end) {
+            tile_rows(t_begin + 1, n1, q01, q11, ga1, gb1);
+            load_rows_sync(max(loaded_hi + 1, ga1), gb1);
+            loaded_hi = max(loaded_hi, gb1);
+            if (tid < QT) geometry(n1, q01, q11, (t_begin + 1) & 1);
+        }
+        __syncthreads();
+        for (int t = t_begin; t < t_end; ++t) {
+            const bool has1 = t + 1 < t_end, has2 = t + 2 < t_end;
+            int n2 = 0, q02 = 0, q12 = 0, ga2 = 0, gb2 = 0, lo = 0; unsigned nb = 0;
+            if (has2) {
+                tile_rows(t + 2, n2, q02, q12, ga2, gb2);
+                lo = max(loaded_hi + 1, ga2);
+                nb = gb2 >= lo ? (unsigned)(gb2 - lo + 1) * RB : 0u;
+                loaded_hi = max(loaded_hi, gb2);
+            }
+            const int b0 = t & 1, b1 = b0 ^ 1, r0i = t % 3, r1i = (t + 1) % 3, r2i = (t + 2) % 3;
+            u4v pf[LPT];
+            // ---- phase 1
+            if (tid < QT) rowsum[r2i * QT + tid] = 0;
+            if (!team) matrix(q0, q1, b0, b0, r0i);
+            else if (has1) dw_planes(wt * CGT, CGT, b1, b1, r1i);
+            Q_STAMP(0);
+            __syncthreads();
+            Q_STAMP(1);
+            // ---- phase 2
+            pf_request(pf, lo, nb);
+            if (team) matrix(q0, q1, b0, b0, r0i);
+            else if (has1) dw_planes(C16 / 2 + wt * CGT, CGT, b1, b1, r1i);
+            Q_STAMP(2);
+            __syncthreads();
+            Q_STAMP(3);
+            // ---- the rows of tile t + 2, its geometry
+            pf_write(pf, lo, nb);
+            if (has2 && tid < QT) geometry(n2, q02, q12, b0);
+            __syncthreads();
+            Q_STAMP(4);
+            n = n1; q0 = q01; q1 = q11;
+            n1 = n2; q01 = q02; q11 = q12;
+        }
     }
 #undef Q_STAMP
     if (P.dbg && lane == 0) for (int k = 0; k < 5; ++k) P.dbg[((size_t)blockIdx.x * NW + wave) * 8 + k] = st[k];
@@ -656,21 +787,21 @@ void dwpw_plan(int H, int W, int ho, int wo, int stride, int off_y, int cin, int
     *lpt = (int)(((long long)mx * RB + (long long)nt * 16 - 1) / ((long long)nt * 16));
 }
 
-template <int CIN, int COUT, int WP, int STRIDE, int LPT>
+template <int CIN, int COUT, int WP, int STRIDE, int LPT, bool TEAMS>
 int launch_q_dwpw(hipStream_t s, QDwpwP &P, int nimg, int device, bool *ok) {
     constexpr int NW = (COUT / 64) * WP, NT = NW * 64, CINP = (CIN + 63) / 64 * 64;
     int lpt = 0;
     dwpw_plan(P.H, P.W, P.ho, P.wo, STRIDE, P.off_y, CIN, NT, &P.NR, &lpt);
     const int RB = (P.W + 2) * CIN;
-    const size_t lds = (size_t)P.NR * RB + (size_t)QT * CINP + 4 * QT * sizeof(int) + 2 * QT * 16;
+    const size_t lds = (size_t)P.NR * RB + (size_t)(TEAMS ? 2 : 1) * QT * CINP + (size_t)((TEAMS ? 3 : 2) + 2) * QT * sizeof(int) + 2 * QT * 16 + COUT * sizeof(int);
     P.rb_magic = (unsigned)((1ull << 32) / (unsigned)RB) + 1u;
     *ok = lpt <= LPT && lds <= 160 * 1024 && (long long)LPT * NT * 16 * RB < (1ll << 32) && (LPT * NT * 16) / RB + 1 <= 2 * P.NR;
     if (!*ok) return DD_OK;
     const bool rsum = P.zwc != 0;
     static DevOnce once;
     const int rc = once.run(device, [&]() -> int {
-        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, true, TEAMS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, false, TEAMS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         return DD_OK;
     });
     if (rc != DD_OK) return rc;
@@ -678,7 +809,7 @@ int launch_q_dwpw(hipStream_t s, QDwpwP &P, int nimg, int device, bool *ok) {
     int per_cu = per_cu_cache[device & 63].load(std::memory_order_relaxed);
     if (per_cu == 0) {
         int nb = 0;
-        DD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, true>), NT, lds));
+        DD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, true, TEAMS>), NT, lds));
         per_cu = std::max(1, std::min(8, nb));
         per_cu_cache[device & 63].store(per_cu, std::memory_order_relaxed);
     }
@@ -689,8 +820,8 @@ int launch_q_dwpw(hipStream_t s, QDwpwP &P, int nimg, int device, bool *ok) {
     static const bool stamps = getenv("DD_Q_STAMPS") && atoi(getenv("DD_Q_STAMPS")) != 0;
     const size_t n_st = (size_t)grid.x * NW * 8;
     if (stamps) { DD_HIP(hipMalloc(&P.dbg, n_st * 8)); DD_HIP(hipMemsetAsync(P.dbg, 0, n_st * 8, s)); }
-    if (rsum) hipLaunchKernelGGL((q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, true>), grid, dim3(NT), lds, s, P, n_tiles, tpb);
-    else hipLaunchKernelGGL((q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, false>), grid, dim3(NT), lds, s, P, n_tiles, tpb);
+    if (rsum) hipLaunchKernelGGL((q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, true, TEAMS>), grid, dim3(NT), lds, s, P, n_tiles, tpb);
+    else hipLaunchKernelGGL((q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, false, TEAMS>), grid, dim3(NT), lds, s, P, n_tiles, tpb);
     DD_LAUNCH_CHECK();
     if (stamps) {                                                   // diagnostic: where the waves of this launch spent their cycles
         std::vector<unsigned long long> h(n_st);
@@ -700,7 +831,8 @@ int launch_q_dwpw(hipStream_t s, QDwpwP &P, int nimg, int device, bool *ok) {
         double sum[5] = {0, 0, 0, 0, 0};
         for (size_t w = 0; w < n_st / 8; ++w) for (int k = 0; k < 5; ++k) sum[k] += (double)h[w * 8 + k];
         const double nw = (double)(n_st / 8) * tpb;
-        fprintf(stderr, "q_dwpw_k<%d,%d,%d> %d blocks/CU %d tiles/block: cycles per wave and tile: depthwise %.0f  barrier A %.0f  matrix stage %.0f  ring write %.0f  barrier B %.0f\n",
+        fprintf(stderr, TEAMS ? "q_dwpw_k<%d,%d,%d> teams, %d blocks/CU %d tiles/block: cycles per wave and tile: phase 1 %.0f  barrier %.0f  phase 2 %.0f  barrier %.0f  ring write + barrier %.0f\n"
+                              : "q_dwpw_k<%d,%d,%d> %d blocks/CU %d tiles/block: cycles per wave and tile: depthwise %.0f  barrier A %.0f  matrix stage %.0f  ring write %.0f  barrier B %.0f\n",
                 CIN, COUT, STRIDE, per_cu, tpb, sum[0] / nw, sum[1] / nw, sum[2] / nw, sum[3] / nw, sum[4] / nw);
     }
     return DD_OK;
@@ -729,7 +861,7 @@ int netq_run_op(dd_net *net, int i, const int32_t *o, const uint8_t *input, int 
             DD_REQUIRE(td->pad == 1 && td->cs == 32 && o[11] == 32 && (reinterpret_cast<uintptr_t>(input) & 3) == 0 && (P.total_bytes & 3) == 0 && !P.R.linear,
                        DD_E_ARG, "dd_net_forward: uint8 first layer: 32 channels into a bordered tensor from a 4-byte aligned batch");
             const int n_frags = dd_ceil_div(P.m, 16);
-            hipLaunchKernelGGL(q_conv0_k, dim3(dd_ceil_div(n_frags, 4)), dim3(256), 0, s, P, n_frags);
+            hipLaunchKernelGGL(q_conv0_k, dim3(dd_ceil_div(n_frags, 4 * C0F)), dim3(256), 0, s, P, n_frags);
             DD_LAUNCH_CHECK();
             return DD_OK;
         }
@@ -757,13 +889,19 @@ int netq_run_op(dd_net *net, int i, const int32_t *o, const uint8_t *input, int 
                 P.mq = std::min(4, P.n_mfrag);
             }
             const int n_mgroups = dd_ceil_div(P.n_mfrag, P.mq);
-            const long long n_items = (long long)n_mgroups * dd_ceil_div(P.m, 32);
+            static const int npf_env = getenv("DD_Q_NPF") ? atoi(getenv("DD_Q_NPF")) : 2;
+            const int npf = npf_env == 4 && P.m >= 8192 ? 4 : 2;      // pixel fragments per wave item (four measured slower on every layer: more registers, fewer waves)
+            const long long n_items = (long long)n_mgroups * dd_ceil_div(P.m, 16 * npf);
             DD_REQUIRE(n_items < (1ll << 31), DD_E_CAPACITY, "dd_net_forward: uint8 conv %d: %lld wave items", i, n_items);
             const dim3 grid((unsigned)((n_items + 3) / 4));
             const bool rsum = P.zwc != 0;
-#define DD_QC(MQ_) do { if (rsum) hipLaunchKernelGGL((q_conv_k<MQ_, true>), grid, dim3(256), 0, s, P, (int)n_items, n_mgroups); \
-                        else hipLaunchKernelGGL((q_conv_k<MQ_, false>), grid, dim3(256), 0, s, P, (int)n_items, n_mgroups); } while (0)
+            const bool pipe = n_items < 8192;
+#define DD_QC2(MQ_, R_) do { if (npf == 4) hipLaunchKernelGGL((q_conv_k<MQ_, R_, 4, false>), grid, dim3(256), 0, s, P, (int)n_items, n_mgroups); \
+                             else if (pipe) hipLaunchKernelGGL((q_conv_k<MQ_, R_, 2, true>), grid, dim3(256), 0, s, P, (int)n_items, n_mgroups); \
+                             else hipLaunchKernelGGL((q_conv_k<MQ_, R_, 2, false>), grid, dim3(256), 0, s, P, (int)n_items, n_mgroups); } while (0)
+#define DD_QC(MQ_) do { if (rsum) DD_QC2(MQ_, true); else DD_QC2(MQ_, false); } while (0)
             if (P.mq == 4) DD_QC(4); else if (P.mq == 3) DD_QC(3); else if (P.mq == 2) DD_QC(2); else DD_QC(1);
+#undef DD_QC2
 #undef DD_QC
             DD_LAUNCH_CHECK();
             return DD_OK;
@@ -805,13 +943,16 @@ int netq_run_op(dd_net *net, int i, const int32_t *o, const uint8_t *input, int 
             bool ok = false;
             int rc = DD_OK;
             const int dev = net->ctx->device;
-            if (cin == 32 && cout == 64 && stride == 1) rc = launch_q_dwpw<32, 64, 2, 1, 8>(s, P, nimg, dev, &ok);
-            else if (cin == 64 && cout == 128 && stride == 2) rc = launch_q_dwpw<64, 128, 2, 2, 8>(s, P, nimg, dev, &ok);
-            else if (cin == 128 && cout == 128 && stride == 1) rc = launch_q_dwpw<128, 128, 2, 1, 8>(s, P, nimg, dev, &ok);
-            else if (cin == 128 && cout == 256 && stride == 2) rc = launch_q_dwpw<128, 256, 2, 2, 8>(s, P, nimg, dev, &ok);
-            else if (cin == 256 && cout == 256 && stride == 1) rc = launch_q_dwpw<256, 256, 2, 1, 6>(s, P, nimg, dev, &ok);
-            else if (cin == 256 && cout == 512 && stride == 2) rc = launch_q_dwpw<256, 512, 1, 2, 12>(s, P, nimg, dev, &ok);
-            else if (cin == 512 && cout == 512 && stride == 1) rc = launch_q_dwpw<512, 512, 1, 1, 8>(s, P, nimg, dev, &ok);
+            static const int teams = getenv("DD_Q_TEAMS") ? atoi(getenv("DD_Q_TEAMS")) : 0;       // 1 = the two-team schedule (measured slower: profiles/r04_q_stamps.txt)
+#define DD_QB(CIN_, COUT_, WP_, S_, LPT_, T_) (T_ && teams ? launch_q_dwpw<CIN_, COUT_, WP_, S_, LPT_, T_>(s, P, nimg, dev, &ok) : launch_q_dwpw<CIN_, COUT_, WP_, S_, LPT_, false>(s, P, nimg, dev, &ok))
+            if (cin == 32 && cout == 64 && stride == 1) rc = DD_QB(32, 64, 2, 1, 8, false);
+            else if (cin == 64 && cout == 128 && stride == 2) rc = DD_QB(64, 128, 2, 2, 8, false);
+            else if (cin == 128 && cout == 128 && stride == 1) rc = DD_QB(128, 128, 2, 1, 8, false);
+            else if (cin == 128 && cout == 256 && stride == 2) rc = DD_QB(128, 256, 2, 2, 8, true);
+            else if (cin == 256 && cout == 256 && stride == 1) rc = DD_QB(256, 256, 2, 1, 6, true);
+            else if (cin == 256 && cout == 512 && stride == 2) rc = DD_QB(256, 512, 1, 2, 12, true);
+            else if (cin == 512 && cout == 512 && stride == 1) rc = DD_QB(512, 512, 1, 1, 8, true);
+#undef DD_QB
             if (rc != DD_OK) return rc;
             DD_REQUIRE(ok, DD_E_ARG, "dd_net_forward: uint8 block %d (%d -> %d, stride %d, %d x %d): no fused kernel for this shape -- compile the program with the two-op form", i, cin, cout, stride, P.H, P.W);
             return DD_OK;
@@ -828,7 +969,8 @@ int netq_run_op(dd_net *net, int i, const int32_t *o, const uint8_t *input, int 
             const float *of = reinterpret_cast<const float *>(o);
             P.box_scale = of[32]; P.box_zp = of[33]; P.sc_scale = of[34]; P.sc_zp = of[35]; P.thr = net->dec_thr;
             P.anchors = net->d_anchors; P.boxes = net->dec_boxes; P.score = net->dec_score; P.keys = net->dec_keys; P.cls_out = net->dec_cls;
-            hipLaunchKernelGGL(q_ssd_decode_k, dim3(dd_ceil_div(P.n_anchors * 16, 256), nimg), dim3(256), 0, s, P);
+            DD_REQUIRE(P.cls_stride % 16 == 0 && P.n_classes <= 128, DD_E_ARG, "dd_net_forward: uint8 decode: %d classes in rows of %d bytes", P.n_classes, P.cls_stride);
+            hipLaunchKernelGGL(q_ssd_decode_k, dim3(dd_ceil_div(P.n_anchors * 8, 256), nimg), dim3(256), 0, s, P);
             DD_LAUNCH_CHECK();
             return DD_OK;
         }
