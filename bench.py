@@ -33,6 +33,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 N_OBJ = 20
+DEFAULT_DETECTOR_DTYPE = 'i8'       # the reference's own detector arithmetic (its ssdmobilenetv1.tflite is uint8-quantised); --detector-dtype f16 = the float model
 CONFIGS = {
     2: dict(W=640, H=480, model='synthetic-ssd_mobilenet_v1', streams=1536, groups=4,
             workload='SSD-MobileNet-v1 (300x300) + MARS-64x32x3 + deep_sort on synthetic 640x480 BGR frames, '
@@ -58,6 +59,9 @@ def parse():
     ap.add_argument('--groups', type=int, default=None,
                     help='worker threads per GPU: the streams are split into this many pipelines, each with its own '
                          'HIP stream, so one group\'s host phases (LSAP, count line) overlap the other\'s kernels')
+    ap.add_argument('--detector-dtype', choices=('f16', 'i8'), default=DEFAULT_DETECTOR_DTYPE,
+                    help='SSD-MobileNet arithmetic (configs 2 and 5): i8 = the uint8-quantised model the reference ships '
+                         '(tools/ssd_mobilenet.py:102), integer kernels bit-exact against the TFLite restatement; f16 = the float model')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--ingest-host', action='store_true',
                     help='secondary figure (never the headline value): frames start in pinned host memory and cross PCIe '
@@ -350,7 +354,11 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.rehearse_cpu:
         return rehearse(args, rank, world, real_stdout)
-    cfg = CONFIGS[args.config]
+    cfg = dict(CONFIGS[args.config])
+    i8 = args.detector_dtype == 'i8' and 'mobilenet' in cfg['model']
+    if i8:                                                  # the uint8-quantised detector (deepdish_amd/quantize.py, csrc/netsq.hip)
+        cfg['model'] += '-uint8'
+        cfg['workload'] = cfg['workload'].replace('SSD-MobileNet-v1', 'SSD-MobileNet-v1 uint8-quantised')
     W, H = cfg['W'], cfg['H']
     gen_pool = start_gen_pool(world, args.streams)          # before anything touches the GPU
     G = max(1, min(args.groups, args.streams))
@@ -475,7 +483,7 @@ def main():
             'metric': 'end-to-end frames/sec (detect+encode+track) at %dx%d' % (W, H),
             'value': total_frames / dt, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'i8 (reference: uint8); encoder f16' if i8 else 'f16', 'data': 'synthetic',
             'config': {'workload': cfg['workload'], 'baseline_config': args.config,
                        'streams_per_gpu': args.streams, 'frames_per_step': args.streams * world,
                        'worker_threads_per_gpu': G,

@@ -6,10 +6,10 @@ import numpy as np
 
 from ._lib import lib, check, P
 from .runtime import default_context, ptr
-from . import nets
+from . import nets, netsq
 from .engine import Net
 from .pipeline import DEFAULT_LABELS, DEFAULT_YOLO_LABELS
-from .tools.weights_io import load_named_weights
+from .tools.weights_io import load_named_weights, load_ssd_model
 
 
 class _TrackerView:
@@ -59,8 +59,9 @@ class MultiStreamPipeline:
             self.det = Net(prog, max_batch=self.S, context=self.ctx)
             n_anchors, n_classes = prog.meta['rows'], prog.meta['n_classes']
         elif run_detector:
-            wd = load_named_weights(model, nets.synthetic_ssd_weights)
-            prog = nets.compile_ssd_mobilenet(wd)
+            kind, wd = load_ssd_model(model)                        # ('uint8', QModel): the reference's own arithmetic (csrc/netsq.hip)
+            prog = netsq.compile_ssd_mobilenet_quant(wd) if kind == 'uint8' else nets.compile_ssd_mobilenet(wd)
+            self.det_dtype = 'u8' if kind == 'uint8' else 'f16'
             self.det = Net(prog, max_batch=self.S, context=self.ctx)
             anchors = np.ascontiguousarray(prog.meta['anchors'], dtype=np.float32)
             n_anchors, n_classes = len(anchors), prog.meta['n_classes']

@@ -8,6 +8,7 @@ from .runtime import ptr
 
 PEAK_F16_TFLOPS = 2500.0       # MI355X_MICROARCH.md: Peak BF16/FP16 MFMA ~2.5 PF dense
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak BW 8.0 TB/s spec
+PEAK_I8_TOPS = 5000.0          # MI355X_MICROARCH.md: I8 MFMA = 2x the BF16 rate per clock
 
 
 def last_batch(net):
@@ -135,7 +136,13 @@ def dominant_kernel_roofline(pipes, step_group, args, reps=20):
     name, k = max(acc.items(), key=lambda kv: kv[1]['ms'])
     sec = k['ms'] * 1e-3
     avg_us = 1e3 * k['ms'] / max(k['launches'], 1e-9)
-    if name.startswith('conv') or name.startswith('res_unit'):
+    if name.startswith('q_'):
+        # uint8 detector: the fused MobileNet blocks move one read and one write of every block tensor and run both contractions on
+        # i8 MFMA; priced against HBM (the larger fraction), the matrix fraction next to it
+        achieved = k['bytes'] / sec / 1e9
+        out = dict(bound='hbm', achieved=achieved, peak=PEAK_HBM_GBS, unit='GB/s', frac=achieved / PEAK_HBM_GBS,
+                   mfma_i8=dict(achieved=k['flops'] / sec / 1e12, peak=PEAK_I8_TOPS, unit='TOP/s', frac=k['flops'] / sec / 1e12 / PEAK_I8_TOPS))
+    elif name.startswith('conv') or name.startswith('res_unit'):
         achieved = k['flops'] / sec / 1e12
         out = dict(bound='mfma', achieved=achieved, peak=PEAK_F16_TFLOPS, unit='TFLOP/s', frac=achieved / PEAK_F16_TFLOPS)
     else:

@@ -6,15 +6,16 @@ Device side: Lanczos stretch resize (csrc/image.hip) -> MobileNet-v1 SSD forward
 MFMA) -> anchor decode / sigmoid / fast NMS / top-10 (csrc/post.hip) -> per-class NMS
 (csrc/nms.hip mode 1).  Host side: the dozen-element list handling of predict / detect_image.
 """
+import ctypes
 import os
 import numpy as np
 import torch
 
 from .._lib import lib, check
 from ..runtime import default_context, ptr
-from .. import nets
+from .. import nets, netsq
 from ..engine import Net
-from .weights_io import load_named_weights
+from .weights_io import load_named_weights, load_ssd_model
 
 COCO_LABELS_FALLBACK = None
 
@@ -29,10 +30,13 @@ class SSDMobileNet:
         self.ctx = context or default_context()
         self.use_edgetpu = False
         self.num_threads = num_threads
-        wd = load_named_weights(model_path, nets.synthetic_ssd_weights)
+        kind, wd = load_ssd_model(model_path)       # ('uint8', QModel): a quantised model as the reference's own file is (ssd_mobilenet.py:102)
         self.weights = wd
-        prog = nets.compile_ssd_mobilenet(wd)
+        self.quantized = kind == 'uint8'
+        prog = netsq.compile_ssd_mobilenet_quant(wd) if self.quantized else nets.compile_ssd_mobilenet(wd)
         self.net = Net(prog, max_batch=max_batch, context=self.ctx)
+        if self.quantized:                           # integer heads: the post-process op's first stage reads the quantised tensors (csrc/netsq.hip)
+            self.net.ssd_decode(prog.meta['anchors'], 1e-8)
         self.height = self.width = prog.in_h
         self.anchors = prog.meta['anchors']
         self.n_classes = prog.meta['n_classes']
@@ -59,10 +63,17 @@ class SSDMobileNet:
     def invoke_device(self, resized_dev, read=True):
         """ssd_mobilenet.py:102-109: interpreter.invoke() and its four output tensors (read=False leaves them in HBM)."""
         self.net.forward(resized_dev)
-        raw = self.net.output_ptr()
-        check(lib().dd_ssd_postprocess(self.ctx.handle, raw, ptr(self._anchors_dev), len(self.anchors), self.n_classes,
-                                       self.MAX_DET, 1e-8, 0.6, ptr(self._boxes), ptr(self._classes),
-                                       ptr(self._scores), ptr(self._count), None), 'dd_ssd_postprocess')
+        if self.quantized:
+            P4 = [ctypes.c_void_p() for _ in range(4)]
+            check(lib().dd_net_ssd_decoded(self.net._h, *[ctypes.byref(q) for q in P4]), 'dd_net_ssd_decoded')
+            check(lib().dd_ssd_postprocess_decoded(self.ctx.handle, P4[0], P4[1], P4[2], P4[3], len(self.anchors), self.MAX_DET, 1e-8, 0.6,
+                                                   ptr(self._boxes), ptr(self._classes), ptr(self._scores), ptr(self._count), 1, None),
+                  'dd_ssd_postprocess_decoded')
+        else:
+            raw = self.net.output_ptr()
+            check(lib().dd_ssd_postprocess(self.ctx.handle, raw, ptr(self._anchors_dev), len(self.anchors), self.n_classes,
+                                           self.MAX_DET, 1e-8, 0.6, ptr(self._boxes), ptr(self._classes),
+                                           ptr(self._scores), ptr(self._count), None), 'dd_ssd_postprocess')
         if not read:
             return None
         self.ctx.sync()

@@ -5,6 +5,11 @@ build reads its own `.npz` of named f32 arrays (names as in deepdish_amd/nets.py
 the form `synthetic[:seed]...`, or any path when DEEPDISH_SYNTHETIC_WEIGHTS=1, yields seeded random
 weights of the right architecture (what tests and bench.py use).  Anything else is an error: there
 is no TFLite flatbuffer reader here yet.
+
+`load_ssd_model` is what the SSD-MobileNet plugins call: it returns ('uint8', QModel) for the reference's own kind
+of file -- a uint8-quantised model (tools/ssd_mobilenet.py:102 upstream; `synthetic...uint8` names build one from
+the seeded f32 weights with deepdish_amd/quantize.py, `...sym...` pins the weight zero points at 128) -- and
+('f32', named weights) otherwise.
 """
 import os
 import re
@@ -23,3 +28,17 @@ def load_named_weights(model_file, synthetic_fn):
     raise FileNotFoundError(
         '%s: cannot load model weights (%s). Supply an .npz of named arrays, or use a "synthetic[:seed]" '
         'model path / DEEPDISH_SYNTHETIC_WEIGHTS=1 for seeded random weights.' % (model_file, name))
+
+
+def load_ssd_model(model_file):
+    """-> ('uint8', QModel) | ('f32', {name: f32 array})."""
+    from .. import nets, quantize
+    name = str(model_file)
+    if name.endswith('.tflite') and os.path.exists(name):
+        from . import tflite_reader
+        return tflite_reader.load_ssd_mobilenet(name)
+    m = re.search(r'synthetic(?::|-seed)?(\d+)?', name)
+    if m and ('uint8' in name or 'quant' in name):
+        seed = int(m.group(1)) if m.group(1) else 1234
+        return 'uint8', quantize.synthetic_ssd_quant_model(seed, symmetric_weights='sym' in name)
+    return 'f32', load_named_weights(model_file, nets.synthetic_ssd_weights)
