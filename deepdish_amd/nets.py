@@ -338,7 +338,11 @@ class Program:
 
 # ------------------------------------------------------------------------------------------- folding
 def bn_affine(wd, scope):
-    """(scale, shift) of an inference batch-norm; gamma optional (slim default scale=False)."""
+    """(scale, shift) of an inference batch-norm; gamma optional (slim default scale=False).  A model that arrives with its batch
+    norms already folded (a .tflite file: tools/tflite_reader.py) has `<layer>/biases` instead: scale 1, shift = the bias."""
+    if scope + '/moving_variance' not in wd and scope.endswith('/bn') and scope[:-3] + '/biases' in wd:
+        b = wd[scope[:-3] + '/biases'].astype(np.float32)
+        return np.ones_like(b), b
     var, mean, beta = wd[scope + '/moving_variance'], wd[scope + '/moving_mean'], wd[scope + '/beta']
     gamma = wd.get(scope + '/gamma', np.ones_like(var))
     s = gamma / np.sqrt(var + BN_EPS)
@@ -506,6 +510,9 @@ def compile_ssd_mobilenet(wd, in_size=300):
     """u8 RGB [n,300,300,3] -> f32 [n,1917,4+91] raw box encodings + class logits."""
     P = Program(in_size, in_size)
     anchors, maps = ssd_anchors(in_size)
+    if 'anchors' in wd:                                     # a model file carries its own (the post-process op's third input)
+        assert wd['anchors'].shape == anchors.shape
+        anchors = np.ascontiguousarray(wd['anchors'], dtype=np.float32)
     n_anchors = len(anchors)
     ld = 4 + SSD_CLASSES
     w, b = fold_conv_bn(wd, 'conv0')

@@ -124,6 +124,9 @@ def compile_ssd_mobilenet_quant(qm):
     P = Program(size, size)
     Ls = qm['layers']
     anchors, maps = nets.ssd_anchors(size)
+    if qm.get('anchors') is not None:                       # a model file carries its own (the post-process op's third input)
+        assert qm['anchors'].shape == anchors.shape
+        anchors = np.ascontiguousarray(qm['anchors'], dtype=np.float32)
     n_anchors = len(anchors)
 
     def geom(t, k, stride):

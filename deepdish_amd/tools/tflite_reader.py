@@ -1,0 +1,232 @@
+"""Reads the model files the reference loads -- `.tflite` flatbuffers (tools/ssd_mobilenet.py:31-52 `Interpreter(model_path=...)`,
+tools/yolov5.py:71-79, tools/generate_detections.py:151-162) -- without TensorFlow: tensors, buffers, quantisation parameters and
+the operator list, from the public schema (tensorflow/lite/schema/schema.fbs; table slots below are its field order).
+
+`read(path)` gives the graph as plain Python objects.  `load_ssd_mobilenet(path)` recognises the SSD-MobileNet-v1 detector the
+reference ships (`detectors/mobilenet/ssdmobilenetv1.tflite`, absent from the tree: .MISSING_LARGE_BLOBS) by structure -- the
+`TFLite_Detection_PostProcess` custom op, its two CONCATENATION / RESHAPE / CONV_2D fans, the CONV_2D / DEPTHWISE_CONV_2D chain
+behind them -- and returns the model in the form deepdish_amd/netsq.py (uint8) or deepdish_amd/nets.py (float) compiles; the first
+operator that does not fit is named in the error.  None of the reference's blobs is here to try it on: the parser is exercised on
+files deepdish_amd/tools/tflite_writer.py produces from the same schema (tests/test_tflite_io.py).
+"""
+import numpy as np
+
+from . import flatbuf
+
+TENSOR_TYPES = {0: np.float32, 1: np.float16, 2: np.int32, 3: np.uint8, 4: np.int64, 6: np.bool_, 7: np.int16, 9: np.int8}
+# BuiltinOperator values (schema.fbs)
+OPS = {0: 'ADD', 1: 'AVERAGE_POOL_2D', 2: 'CONCATENATION', 3: 'CONV_2D', 4: 'DEPTHWISE_CONV_2D', 6: 'DEQUANTIZE', 9: 'FULLY_CONNECTED',
+       14: 'LOGISTIC', 17: 'MAX_POOL_2D', 18: 'MUL', 19: 'RELU', 21: 'RELU6', 22: 'RESHAPE', 23: 'RESIZE_BILINEAR', 25: 'SOFTMAX',
+       28: 'TANH', 32: 'CUSTOM', 34: 'PAD', 39: 'TRANSPOSE', 40: 'MEAN', 41: 'SUB', 42: 'DIV', 43: 'SQUEEZE', 45: 'STRIDED_SLICE',
+       47: 'EXP', 49: 'SPLIT', 53: 'CAST', 76: 'RSQRT', 83: 'PACK', 92: 'SQUARE', 97: 'RESIZE_NEAREST_NEIGHBOR', 111: 'ELU',
+       114: 'QUANTIZE', 117: 'HARD_SWISH'}
+PADDING = {0: 'SAME', 1: 'VALID'}
+ACTIVATION = {0: 'none', 1: 'relu', 2: 'relu_n1_to_1', 3: 'relu6', 4: 'tanh'}
+
+
+class Tensor:
+    def __init__(self, index, name, shape, dtype, data, scale, zero_point, quant_dim):
+        self.index, self.name, self.shape, self.dtype, self.data = index, name, shape, dtype, data
+        self.scale, self.zero_point, self.quant_dim = scale, zero_point, quant_dim
+
+    @property
+    def per_tensor(self):
+        return len(self.scale) == 1
+
+    def __repr__(self):
+        return 'Tensor(%d %r %s %s%s)' % (self.index, self.name, tuple(self.shape), np.dtype(self.dtype).name if self.dtype else '?',
+                                          ' const' if self.data is not None else '')
+
+
+class Op:
+    def __init__(self, index, kind, inputs, outputs, options, custom):
+        self.index, self.kind, self.inputs, self.outputs, self.options, self.custom = index, kind, inputs, outputs, options, custom
+
+    def __repr__(self):
+        return 'Op(%d %s %s -> %s %s)' % (self.index, self.kind, self.inputs, self.outputs, self.options)
+
+
+class Graph:
+    def __init__(self, tensors, ops, inputs, outputs, description):
+        self.tensors, self.ops, self.inputs, self.outputs, self.description = tensors, ops, inputs, outputs, description
+        self.producer = {o: op for op in ops for o in op.outputs}
+
+    def made_by(self, t):
+        return self.producer.get(t)
+
+
+def _options(kind, op_table):
+    t = op_table.table(4)                       # Operator.builtin_options (slot 3 is its union type)
+    if t is None:
+        return {}
+    if kind == 'CONV_2D':                       # Conv2DOptions: padding, stride_w, stride_h, fused_activation_function, dilation_w, dilation_h
+        return dict(padding=PADDING.get(t.scalar(0, 'i8'), '?'), stride_w=t.scalar(1, 'i32'), stride_h=t.scalar(2, 'i32'),
+                    act=ACTIVATION.get(t.scalar(3, 'i8'), '?'), dilation_w=t.scalar(4, 'i32', 1), dilation_h=t.scalar(5, 'i32', 1))
+    if kind == 'DEPTHWISE_CONV_2D':             # DepthwiseConv2DOptions: padding, stride_w, stride_h, depth_multiplier, fused_activation_function, dilations
+        return dict(padding=PADDING.get(t.scalar(0, 'i8'), '?'), stride_w=t.scalar(1, 'i32'), stride_h=t.scalar(2, 'i32'),
+                    depth_multiplier=t.scalar(3, 'i32'), act=ACTIVATION.get(t.scalar(4, 'i8'), '?'),
+                    dilation_w=t.scalar(5, 'i32', 1), dilation_h=t.scalar(6, 'i32', 1))
+    if kind == 'CONCATENATION':                 # ConcatenationOptions: axis, fused_activation_function
+        return dict(axis=t.scalar(0, 'i32'), act=ACTIVATION.get(t.scalar(1, 'i8'), '?'))
+    if kind == 'RESHAPE':                       # ReshapeOptions: new_shape
+        return dict(new_shape=t.scalars(0, 'i32'))
+    if kind in ('MAX_POOL_2D', 'AVERAGE_POOL_2D'):   # Pool2DOptions: padding, stride_w, stride_h, filter_width, filter_height, fused_activation_function
+        return dict(padding=PADDING.get(t.scalar(0, 'i8'), '?'), stride_w=t.scalar(1, 'i32'), stride_h=t.scalar(2, 'i32'),
+                    filter_w=t.scalar(3, 'i32'), filter_h=t.scalar(4, 'i32'), act=ACTIVATION.get(t.scalar(5, 'i8'), '?'))
+    if kind in ('ADD', 'MUL', 'SUB', 'DIV'):
+        return dict(act=ACTIVATION.get(t.scalar(0, 'i8'), '?'))
+    if kind == 'FULLY_CONNECTED':
+        return dict(act=ACTIVATION.get(t.scalar(0, 'i8'), '?'))
+    return {}
+
+
+def read(path_or_bytes):
+    buf = path_or_bytes if isinstance(path_or_bytes, (bytes, bytearray, memoryview)) else open(path_or_bytes, 'rb').read()
+    m = flatbuf.root(buf, b'TFL3')              # Model: version, operator_codes, subgraphs, description, buffers
+    if m.scalar(0, 'u32') != 3:
+        raise ValueError('TFLite schema version %d (expected 3)' % m.scalar(0, 'u32'))
+    codes = []
+    for c in m.tables(1):                       # OperatorCode: deprecated_builtin_code (i8), custom_code, version, builtin_code (i32)
+        b = max(c.scalar(3, 'i32'), c.scalar(0, 'i8'))
+        codes.append((OPS.get(b, 'BUILTIN_%d' % b), c.string(1)))
+    buffers = [b.scalars(0, 'u8') for b in m.tables(4)]         # Buffer.data
+    subs = m.tables(2)
+    if len(subs) != 1:
+        raise ValueError('%d subgraphs: control-flow models are not supported' % len(subs))
+    g = subs[0]                                 # SubGraph: tensors, inputs, outputs, operators, name
+    tensors = []
+    for i, t in enumerate(g.tables(0)):         # Tensor: shape, type, buffer, name, quantization
+        dt = TENSOR_TYPES.get(t.scalar(1, 'i8'))
+        shape = t.scalars(0, 'i32')
+        raw = buffers[t.scalar(2, 'u32')] if t.scalar(2, 'u32') < len(buffers) else b''
+        data = None
+        if len(raw) and dt is not None:
+            data = np.frombuffer(bytes(raw), dtype=dt).reshape(shape)
+        q = t.table(4)                          # QuantizationParameters: min, max, scale, zero_point, details_type, details, quantized_dimension
+        scale = np.array(q.scalars(2, 'f32'), np.float32) if q else np.zeros(0, np.float32)
+        zp = np.array(q.scalars(3, 'i64'), np.int64) if q else np.zeros(0, np.int64)
+        tensors.append(Tensor(i, t.string(3), shape, dt, data, scale, zp, q.scalar(6, 'i32') if q else 0))
+    ops = []
+    for i, o in enumerate(g.tables(3)):         # Operator: opcode_index, inputs, outputs, builtin_options_type, builtin_options, custom_options
+        kind, custom = codes[o.scalar(0, 'u32')]
+        opts = _options(kind, o)
+        if kind == 'CUSTOM':
+            raw = bytes(o.scalars(5, 'u8'))
+            opts = flatbuf.flex_map(raw) if raw else {}
+        ops.append(Op(i, kind, o.scalars(1, 'i32'), o.scalars(2, 'i32'), opts, custom))
+    return Graph(tensors, ops, g.scalars(1, 'i32'), g.scalars(2, 'i32'), m.string(3))
+
+
+# ------------------------------------------------------------------------------------------- SSD-MobileNet-v1
+class UnsupportedModel(ValueError):
+    pass
+
+
+def _need(cond, op, what):
+    if not cond:
+        raise UnsupportedModel('operator %s: %s' % (op, what))
+
+
+def _conv_layer(g, op):
+    """CONV_2D / DEPTHWISE_CONV_2D -> QModel layer dict (weights in HWIO / HWC as deepdish_amd/quantize.py has them)."""
+    _need(op.kind in ('CONV_2D', 'DEPTHWISE_CONV_2D'), op, 'expected a convolution here')
+    x, w, b = (g.tensors[i] for i in op.inputs[:3])
+    y = g.tensors[op.outputs[0]]
+    o = op.options
+    _need(o['padding'] == 'SAME' and o['stride_w'] == o['stride_h'] and o['dilation_w'] == 1 and o['dilation_h'] == 1, op, 'SAME padding, square stride, no dilation')
+    _need(o['act'] in ('none', 'relu6'), op, 'fused activation %s (NONE and RELU6 are built)' % o['act'])
+    _need(w.data is not None and b.data is not None, op, 'filter and bias must be constants')
+    if op.kind == 'CONV_2D':
+        wd = np.transpose(w.data, (1, 2, 3, 0))                     # OHWI -> HWIO
+        kind = 'conv'
+    else:
+        _need(o['depth_multiplier'] == 1 and w.data.shape[0] == 1, op, 'depth multiplier 1')
+        wd = w.data[0]                                               # [1, H, W, C] -> HWC
+        kind = 'dw'
+    L = dict(kind=kind, w=np.ascontiguousarray(wd), stride=int(o['stride_w']), act=o['act'])
+    if x.dtype == np.uint8:
+        _need(w.dtype == np.uint8 and b.dtype == np.int32 and y.dtype == np.uint8, op, 'uint8 activations need uint8 filters and int32 biases')
+        _need(x.per_tensor and w.per_tensor and y.per_tensor, op, 'per-channel quantisation is not built (per-tensor parameters only)')
+        L.update(w_scale=np.float32(w.scale[0]), w_zp=int(w.zero_point[0]), bias=b.data.astype(np.int32).reshape(-1),
+                 in_scale=np.float32(x.scale[0]), in_zp=int(x.zero_point[0]), out_scale=np.float32(y.scale[0]), out_zp=int(y.zero_point[0]))
+    else:
+        _need(x.dtype == np.float32, op, 'activations of type %s' % x.dtype)
+        L.update(w=L['w'].astype(np.float32), bias=b.data.astype(np.float32).reshape(-1))
+    return L, op.inputs[0]
+
+
+def load_ssd_mobilenet(path):
+    """-> ('uint8', QModel) or ('f32', named folded weights).  Structure walked backwards from the post-process op."""
+    g = read(path)
+    post = [op for op in g.ops if op.kind == 'CUSTOM']
+    if len(post) != 1 or post[0].custom != 'TFLite_Detection_PostProcess':
+        raise UnsupportedModel('%s: no TFLite_Detection_PostProcess op (operators: %s)' % (path, sorted({o.custom or o.kind for o in g.ops})))
+    post = post[0]
+    want = dict(y_scale=10.0, x_scale=10.0, h_scale=5.0, w_scale=5.0)
+    for k, v in want.items():
+        _need(abs(float(post.options.get(k, v)) - v) < 1e-6, post, '%s = %s (the decode is built for %s)' % (k, post.options.get(k), v))
+    anchors = g.tensors[post.inputs[2]]
+    _need(anchors.data is not None and anchors.data.ndim == 2 and anchors.data.shape[1] == 4, post, 'anchors must be a constant [n, 4]')
+    anc = anchors.data.astype(np.float32) if anchors.dtype != np.uint8 else (np.float32(anchors.scale[0]) * (anchors.data.astype(np.float32) - np.float32(anchors.zero_point[0])))
+
+    def fan(t, logistic):
+        """tensor -> the six head convolutions feeding it (through [LOGISTIC] CONCATENATION RESHAPE)."""
+        op = g.made_by(t)
+        logi = None
+        if logistic:
+            _need(op is not None and op.kind == 'LOGISTIC', op, 'class predictions must come from LOGISTIC')
+            logi = op
+            op = g.made_by(op.inputs[0])
+        _need(op is not None and op.kind == 'CONCATENATION', op, 'expected the CONCATENATION of the per-map predictions')
+        heads = []
+        for ti in op.inputs:
+            r = g.made_by(ti)
+            _need(r is not None and r.kind == 'RESHAPE', r, 'expected RESHAPE of a predictor output')
+            c = g.made_by(r.inputs[0])
+            _need(c is not None and c.kind == 'CONV_2D', c, 'expected the predictor CONV_2D')
+            heads.append(c)
+        return heads, logi
+
+    box_heads, _ = fan(post.inputs[0], False)
+    cls_heads, logi = fan(post.inputs[1], True)
+    _need(len(box_heads) == 6 and len(cls_heads) == 6, post, '%d / %d predictor maps (SSD-MobileNet-v1 has 6)' % (len(box_heads), len(cls_heads)))
+    layers, feats = {}, []
+    for k, (bh, ch) in enumerate(zip(box_heads, cls_heads)):
+        _need(bh.inputs[0] == ch.inputs[0], ch, 'box and class predictor %d read different feature maps' % k)
+        layers[f'box{k}'], _ = _conv_layer(g, bh)
+        layers[f'cls{k}'], _ = _conv_layer(g, ch)
+        feats.append(bh.inputs[0])
+    # the backbone: from the last feature map back to the graph input
+    chain, t = [], feats[-1]
+    while g.made_by(t) is not None:
+        op = g.made_by(t)
+        chain.append(op)
+        t = op.inputs[0]
+    _need(t in g.inputs, chain[-1] if chain else post, 'the backbone does not start at a graph input')
+    chain.reverse()
+    names = ['conv0'] + [n for i in range(1, 14) for n in (f'dw{i}', f'pw{i}')] + [f'extra{j}_{h}' for j in range(1, 5) for h in (1, 2)]
+    _need(len(chain) == len(names), chain[min(len(chain), len(names)) - 1], '%d backbone convolutions (SSD-MobileNet-v1 has %d)' % (len(chain), len(names)))
+    out_of = {}
+    for name, op in zip(names, chain):
+        layers[name], _ = _conv_layer(g, op)
+        _need(layers[name]['kind'] == ('dw' if name.startswith('dw') else 'conv'), op, 'expected %s for %s' % ('DEPTHWISE_CONV_2D' if name.startswith('dw') else 'CONV_2D', name))
+        out_of[op.outputs[0]] = name
+    want_feats = ['pw11', 'pw13', 'extra1_2', 'extra2_2', 'extra3_2', 'extra4_2']
+    _need([out_of.get(f) for f in feats] == want_feats, post, 'feature maps come from %s (expected %s)' % ([out_of.get(f) for f in feats], want_feats))
+    x = g.tensors[t]
+    _need(len(x.shape) == 4 and x.shape[1] == x.shape[2] and x.shape[3] == 3, chain[0], 'input %s (expected [1, s, s, 3])' % (x.shape,))
+    order = names + [n for k in range(6) for n in (f'box{k}', f'cls{k}')]
+    if x.dtype == np.uint8:
+        lt = g.tensors[logi.outputs[0]]
+        qm = dict(kind='ssd_mobilenet_v1_uint8', input=dict(scale=np.float32(x.scale[0]), zp=int(x.zero_point[0]), size=int(x.shape[1])),
+                  layers=layers, logistic=dict(out_scale=np.float32(lt.scale[0]), out_zp=int(lt.zero_point[0])), order=order, anchors=anc,
+                  post=dict(post.options), source=str(path))
+        return 'uint8', qm
+    wd = {}
+    for name in order:
+        L = layers[name]
+        w = L['w'] if L['kind'] == 'conv' else L['w'][:, :, :, None]
+        wd[name + '/weights'] = w.astype(np.float32)
+        wd[name + '/biases'] = L['bias']
+    wd['anchors'] = anc
+    return 'f32', wd

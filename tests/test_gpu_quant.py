@@ -127,3 +127,25 @@ def test_launch_of_384_frames_is_bit_exact():
     box_w, cls_w, _ = nets_quant.ssd_quant_forward(qm, base)
     for z in range(384):
         assert (box[z] == box_w[idx[z]]).all() and (cls[z] == cls_w[idx[z]]).all(), 'slot %d (frame %d)' % (z, idx[z])
+
+
+def test_plugin_loads_a_tflite_file(tmp_path):
+    """SSD_MOBILENET(model_file='....tflite') as deepdish.py:491-495 constructs it: a uint8 model written to disk in the interchange format
+    gives the detections of the same model handed over in memory."""
+    import os
+    from deepdish_amd import quantize
+    from deepdish_amd.tools import tflite_writer
+    from deepdish_amd.tools.ssd_mobilenet import SSD_MOBILENET
+    from deepdish_amd.pipeline import DEFAULT_LABELS
+    path = str(tmp_path / 'ssdmobilenetv1.tflite')
+    tflite_writer.write_ssd_mobilenet(quantize.synthetic_ssd_quant_model(1234), path)
+    a = SSD_MOBILENET(wanted_labels=['person', 'car', 'bicycle'], model_file=path, label_file=DEFAULT_LABELS, num_threads=4, edgetpu=False, score_threshold=0.0)
+    b = SSD_MOBILENET(wanted_labels=['person', 'car', 'bicycle'], model_file='synthetic-ssd_mobilenet_v1-uint8', label_file=DEFAULT_LABELS, score_threshold=0.0)
+    assert a.ssdm.quantized and b.ssdm.quantized and (a.width, a.height) == (300, 300)
+    rng = np.random.default_rng(3)
+    for _ in range(3):
+        img = rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)
+        ra, rb = a.detect_image(img), b.detect_image(img)
+        assert ra[1] == rb[1] and len(ra[0]) == len(rb[0])
+        np.testing.assert_array_equal(np.asarray(ra[0], np.float64), np.asarray(rb[0], np.float64))
+        np.testing.assert_array_equal(np.asarray(ra[2], np.float64), np.asarray(rb[2], np.float64))

@@ -1,0 +1,108 @@
+"""CPU: the .tflite reader (deepdish_amd/tools/tflite_reader.py) -- what makes `--model <file>.tflite` a drop-in
+(tools/ssd_mobilenet.py:31-52 upstream).  None of the reference's blobs is in the tree (.MISSING_LARGE_BLOBS): the reader is held
+to a committed fixture whose values are written down in scripts/make_tflite_fixture.py, and to round trips through the writer."""
+import os
+import numpy as np
+import pytest
+
+
+def test_committed_fixture_parses_to_the_written_values(golden_dir):
+    from deepdish_amd.tools import tflite_reader as R
+    g = R.read(os.path.join(golden_dir, 'tiny_quant_graph.tflite'))
+    assert g.description == 'tiny fixture' and g.inputs == [0] and [op.kind for op in g.ops] == ['CONV_2D', 'DEPTHWISE_CONV_2D', 'LOGISTIC', 'CUSTOM']
+    t = {x.name: x for x in g.tensors}
+    assert t['input'].shape == [1, 8, 8, 3] and t['input'].dtype == np.uint8 and t['input'].scale[0] == np.float32(0.0078125) and t['input'].zero_point[0] == 128
+    np.testing.assert_array_equal(t['conv/w'].data, (np.arange(108) % 251).astype(np.uint8).reshape(4, 3, 3, 3))
+    np.testing.assert_array_equal(t['conv/b'].data, np.array([-7, 0, 11, 123456], np.int32))
+    assert t['conv/w'].zero_point[0] == 131 and t['conv/w'].scale[0] == np.float32(0.02) and t['conv'].data is None
+    np.testing.assert_array_equal(t['dw/w'].data, (200 - np.arange(36)).astype(np.uint8).reshape(1, 3, 3, 4))
+    assert g.ops[0].options == dict(padding='SAME', stride_w=2, stride_h=2, act='relu6', dilation_w=1, dilation_h=1)
+    assert g.ops[1].options['depth_multiplier'] == 1 and g.ops[1].options['act'] == 'none' and g.ops[1].options['stride_w'] == 1
+    assert g.ops[3].custom == 'TFLite_Detection_PostProcess'
+    o = g.ops[3].options
+    assert o['max_detections'] == 10 and o['num_classes'] == 90 and o['use_regular_nms'] is False
+    assert o['y_scale'] == 10.0 and o['h_scale'] == 5.0 and abs(o['nms_iou_threshold'] - 0.6) < 1e-7
+    np.testing.assert_array_equal(t['anchors'].data, np.array([[0.5, 0.5, 0.1, 0.2], [0.25, 0.75, 1.0, 1.0]], np.float32))
+    assert g.made_by(t['scores'].index).kind == 'LOGISTIC'
+
+
+def test_a_graph_that_is_not_the_detector_is_refused_by_name(golden_dir):
+    from deepdish_amd.tools import tflite_reader as R
+    with pytest.raises(R.UnsupportedModel) as e:
+        R.load_ssd_mobilenet(os.path.join(golden_dir, 'tiny_quant_graph.tflite'))
+    assert 'CONCATENATION' in str(e.value) or 'LOGISTIC' in str(e.value)
+    with pytest.raises(ValueError):
+        R.read(b'\x10\x00\x00\x00XXXX' + bytes(64))             # wrong file identifier
+
+
+@pytest.fixture(scope='module')
+def qmodel():
+    from deepdish_amd import quantize
+    return quantize.synthetic_ssd_quant_model(1234)
+
+
+def test_uint8_detector_round_trip(tmp_path, qmodel):
+    """QModel -> .tflite -> QModel: every array and parameter, the anchors, and the compiled program are the same."""
+    from deepdish_amd import netsq, nets
+    from deepdish_amd.tools import tflite_writer, tflite_reader
+    from deepdish_amd.tools.weights_io import load_ssd_model
+    path = str(tmp_path / 'ssdmobilenetv1.tflite')
+    tflite_writer.write_ssd_mobilenet(qmodel, path)
+    kind, qm2 = load_ssd_model(path)                                # what SSD_MOBILENET(model_file=...) calls
+    assert kind == 'uint8' and qm2['input'] == qmodel['input'] and qm2['logistic'] == qmodel['logistic']
+    for name in qmodel['order']:
+        a, b = qmodel['layers'][name], qm2['layers'][name]
+        for k in ('w', 'bias'):
+            np.testing.assert_array_equal(a[k], b[k], err_msg=name)
+        for k in ('w_scale', 'w_zp', 'in_scale', 'in_zp', 'out_scale', 'out_zp', 'stride', 'act', 'kind'):
+            assert a[k] == b[k], (name, k)
+    np.testing.assert_array_equal(qm2['anchors'], nets.ssd_anchors(300)[0])
+    p1, p2 = netsq.compile_ssd_mobilenet_quant(qmodel), netsq.compile_ssd_mobilenet_quant(qm2)
+    assert bytes(p1.blob) == bytes(p2.blob) and (p1.serialize()[0] == p2.serialize()[0]).all()
+
+
+def test_float_detector_round_trip(tmp_path):
+    from deepdish_amd import nets, quantize
+    from deepdish_amd.tools import tflite_writer
+    from deepdish_amd.tools.weights_io import load_ssd_model
+    wd = nets.synthetic_ssd_weights(7)
+    folded = {}
+    for name, kind, w, b, stride, act in quantize.folded_ssd_layers(wd):
+        folded[name + '/weights'] = w if kind == 'conv' else w[:, :, :, None]
+        folded[name + '/biases'] = b
+    path = str(tmp_path / 'ssd_float.tflite')
+    tflite_writer.write_ssd_mobilenet(folded, path)
+    kind, wd2 = load_ssd_model(path)
+    assert kind == 'f32'
+    assert bytes(nets.compile_ssd_mobilenet(wd2).blob) == bytes(nets.compile_ssd_mobilenet(wd).blob)
+
+
+def test_unsupported_graphs_name_the_operator(tmp_path, qmodel):
+    """Per-channel filters and a missing predictor are errors that say where."""
+    import copy
+    from deepdish_amd.tools import tflite_writer, tflite_reader as R
+    W = tflite_writer.ssd_mobilenet_graph(qmodel)
+    t = next(x for x in W.tensors if x['name'] == 'pw3/weights')
+    t['scale'] = np.full(128, 0.01, np.float32); t['zero_point'] = np.zeros(128, np.int64)
+    p = str(tmp_path / 'perchannel.tflite')
+    open(p, 'wb').write(W.tobytes())
+    with pytest.raises(R.UnsupportedModel) as e:
+        R.load_ssd_mobilenet(p)
+    assert 'per-channel' in str(e.value) and 'CONV_2D' in str(e.value)
+    W = tflite_writer.ssd_mobilenet_graph(qmodel)
+    W.ops[-1]['custom_options'] = __import__('deepdish_amd.tools.flatbuf', fromlist=['x']).flex_build_map(dict(y_scale=8.0, x_scale=10.0, h_scale=5.0, w_scale=5.0))
+    p = str(tmp_path / 'scales.tflite')
+    open(p, 'wb').write(W.tobytes())
+    with pytest.raises(R.UnsupportedModel) as e:
+        R.load_ssd_mobilenet(p)
+    assert 'y_scale' in str(e.value)
+
+
+def test_other_model_files_fail_loudly(tmp_path):
+    from deepdish_amd.tools.weights_io import load_named_weights
+    from deepdish_amd import nets
+    p = tmp_path / 'mars-64x32x3.pb'
+    p.write_bytes(b'\0' * 16)
+    with pytest.raises(FileNotFoundError) as e:
+        load_named_weights(str(p), nets.synthetic_mars_weights)
+    assert 'frozen' in str(e.value) or '.pb' in str(e.value)
