@@ -196,7 +196,8 @@ def cpu_baseline(n_frames, W, H, config=2):
     yolo = config == 3
     wd_mars = nets.synthetic_mars_weights(1234)
     wd_det = nets.synthetic_yolov5s_weights(1234) if yolo else nets.synthetic_ssd_weights(1234)
-    anchors, _ = nets.ssd_anchors(300)
+    from oracle import nets_quant
+    anchors = nets_quant.ssd_anchors(300)                # the oracle's own generator (tests/test_quant_host.py holds the product's to it)
     yolo_labels = {i: l.strip() for i, l in enumerate(open(os.path.join(ROOT, 'deepdish_amd', 'assets', 'coco_classes.txt')))}
     per_seed, stage_pick = [], {}
     keep_for_parity = None

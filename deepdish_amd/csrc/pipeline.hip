@@ -14,6 +14,7 @@
 #include <string>
 #include "common.h"
 #include "hostpool.h"
+#include "host_phases.h"
 
 struct dd_tracker;
 struct dd_mog2;
@@ -82,27 +83,8 @@ struct StreamState {
     std::vector<double> means;
 };
 
-double cross2(double ax, double ay, double bx, double by) { return ax * by - ay * bx; }
-
-// tools/intersection.py:4-24
-bool seg_intersect(const double p[2], const double pr[2], const double q[2], const double qs[2]) {
-    const double eps = 2.220446049250313e-16;
-    const double rx = pr[0] - p[0], ry = pr[1] - p[1], sx = qs[0] - q[0], sy = qs[1] - q[1];
-    const double rxs = cross2(rx, ry, sx, sy);
-    const double mx = q[0] - p[0], my = q[1] - p[1];
-    const double qpxr = cross2(mx, my, rx, ry);
-    if (fabs(rxs) < eps) {
-        if (fabs(qpxr) >= eps) return false;
-        const double rr = rx * rx + ry * ry;
-        const double ex = rx / rr, ey = ry / rr;
-        double t0 = mx * ex + my * ey;
-        double t1 = t0 + sx * ex + sy * ey;
-        if (t0 > t1) std::swap(t0, t1);
-        return !(t1 < 0 || t0 > 1);
-    }
-    const double t = cross2(mx, my, sx, sy) / rxs, u = qpxr / rxs;
-    return 0.0 <= t && t <= 1.0 && 0.0 <= u && u <= 1.0;
-}
+using ddhost::cross2;
+using ddhost::seg_intersect;
 
 }  // namespace
 
@@ -560,15 +542,18 @@ int dd_pipeline_step2(dd_pipeline *p, const uint8_t *frames_in, const uint8_t *f
             for (int z = 0; z < S; ++z) ybase[z + 1] = ybase[z] + (size_t)std::min(yn[z], p->n_anchors);
             if (ybase[S] > p->yolo_host_rows) {                    // a busy step: fetch the rest (the detector stream is idle here) and
                 const size_t have = p->yolo_host_rows, total = ybase[S];      // make room for twice as many from now on
+                // ... but never more than the packed block holds (S * n_anchors rows): the first copy of every later step reads that many
+                const size_t grown = std::min(2 * total, (size_t)S * (size_t)p->n_anchors);
                 PinBuf bigger;
-                if ((rc = bigger.reserve(head + 2 * total * 24)) != DD_OK) return rc;
+                if ((rc = bigger.reserve(head + grown * 24)) != DD_OK) return rc;
                 memcpy(bigger.p, p->h_fin.p, head + have * 24);
-                DD_HIP(hipMemcpyAsync(bigger.as<char>() + head + have * 24, p->d_pack.as<char>() + have * 24, (total - have) * 24,
-                                      hipMemcpyDeviceToHost, p->det_stream));
-                DD_HIP(hipStreamSynchronize(p->det_stream));
+                hipError_t he = hipMemcpyAsync(bigger.as<char>() + head + have * 24, p->d_pack.as<char>() + have * 24, (total - have) * 24,
+                                               hipMemcpyDeviceToHost, p->det_stream);
+                if (he == hipSuccess) he = hipStreamSynchronize(p->det_stream);
+                if (he != hipSuccess) { bigger.release(); DD_HIP(he); }
                 p->h_fin.release();
                 p->h_fin = bigger;
-                p->yolo_host_rows = 2 * total;
+                p->yolo_host_rows = grown;
                 yn = p->h_fin.as<int>();
             }
             const float *rows = reinterpret_cast<const float *>(p->h_fin.as<char>() + head);
@@ -600,17 +585,23 @@ int dd_pipeline_step2(dd_pipeline *p, const uint8_t *frames_in, const uint8_t *f
                     q.boxes0.clear(); q.scores0.clear(); q.cls0.clear();
                     int order[MAX_DET], n = 0;
                     for (int i = 0; i < hn[z] && i < MAX_DET; ++i)
-                        if (hs[z * MAX_DET + i] >= (float)p->det_conf) order[n++] = i;
+                        if ((double)hs[z * MAX_DET + i] >= p->det_conf) order[n++] = i;      // np.float32 >= python float: compared in float64
                     std::stable_sort(order, order + n, [&](int a, int b) { return hs[z * MAX_DET + a] > hs[z * MAX_DET + b]; });
                     for (int k = 0; k < n; ++k) {
                         const int i = order[k], c = (int)hc[z * MAX_DET + i];
                         if (c < 0 || c >= (int)p->tfl_labels.size() || wanted_index(p, p->tfl_labels[c]) < 0) continue;
+                        // the class stored for the vote is resolved through class_name() = labels[c + label_offset]: the same line of the
+                        // label file only while no blank line precedes it -- store the index class_name() maps back to this very label
+                        int cs = -1;
+                        for (int li = p->label_offset; li < (int)p->labels.size() && cs < 0; ++li) if (p->labels[li] == p->tfl_labels[c]) cs = li - p->label_offset;
+                        if (cs < 0) continue;
                         const float *b = hb + ((size_t)z * MAX_DET + i) * 4;                          // ymin, xmin, ymax, xmax (normalised)
-                        const int top = (int)(b[0] * (float)p->H), left = (int)(b[1] * (float)p->W);
-                        const int bottom = (int)(b[2] * (float)p->H), right = (int)(b[3] * (float)p->W);
+                        // int(np.float32 * python int): the reference's pinned NumPy promotes the product to float64 (exact), then truncates
+                        const int top = (int)((double)b[0] * (double)p->H), left = (int)((double)b[1] * (double)p->W);
+                        const int bottom = (int)((double)b[2] * (double)p->H), right = (int)((double)b[3] * (double)p->W);
                         q.boxes0.insert(q.boxes0.end(), {(double)left, (double)top, (double)(right - left), (double)(bottom - top)});
                         q.scores0.push_back((double)hs[z * MAX_DET + i]);
-                        q.cls0.push_back(c);
+                        q.cls0.push_back(cs);
                     }
                 }
             });
@@ -654,20 +645,7 @@ int dd_pipeline_step2(dd_pipeline *p, const uint8_t *frames_in, const uint8_t *f
                 q.cls0.assign(inj_cls_host + a, inj_cls_host + b);
             }
             q.ib.clear(); q.is.clear(); q.ic.clear();
-            const int k0 = (int)q.scores0.size();
-            bool any_nan = false;
-            for (double v : q.boxes0) if (v != v) any_nan = true;
-            if (any_nan) continue;
-            for (int i = 0; i < k0; ++i) {
-                const double *b = q.boxes0.data() + (size_t)i * 4;
-                auto clipi = [](double v, double lo, double hi) { return (int64_t)(v < lo ? lo : (v > hi ? hi : v)); };
-                const int64_t x = clipi(b[0], 0, p->W), y = clipi(b[1], 0, p->H);
-                const int64_t w = clipi(b[2], 0, (double)(p->W - x)), h = clipi(b[3], 0, (double)(p->H - y));
-                if ((double)(w * h) > 0.9 * p->W * p->H) continue;
-                q.ib.insert(q.ib.end(), {x, y, w, h});
-                q.is.push_back(q.scores0[i]);
-                q.ic.push_back(q.cls0[i]);
-            }
+            ddhost::clean_boxes(q.boxes0, q.scores0, q.cls0, p->W, p->H, q.ib, q.is, q.ic);
         }
     });
     for (int z = 0; z < S; ++z) off[z + 1] = off[z] + (int)st[z].is.size();

@@ -554,7 +554,12 @@ int trackers_update_match(dd_tracker **ts, int S) {
         }
     });
     if (first_err.load() != DD_OK) {                               // (dd_last_error is per thread: restate it on the caller's)
-        dd_set_error("dd_tracker_update: track capacity %d of a stream exhausted", ts[0]->tcap);
+        // Every stream has already advanced its host state (tracks, free slots, ids) while no device update followed: the group's host
+        // mirrors and its device state now disagree -- the handle must be destroyed and recreated with a larger track_capacity.
+        int zbad = -1;
+        for (int z = 0; z < S && zbad < 0; ++z) if (ts[z]->free_slots.empty()) zbad = z;
+        dd_set_error("dd_tracker_update: track capacity %d exhausted (stream %d of %d in the group); the group's state is no longer consistent: "
+                     "recreate it with a larger track_capacity", zbad >= 0 ? ts[zbad]->tcap : ts[0]->tcap, zbad, S);
         return first_err.load();
     }
     for (int z = 0; z < S; ++z) {                                  // gallery placement: serial, stream order (track.py:140 features.append)

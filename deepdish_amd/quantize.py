@@ -207,7 +207,8 @@ def logistic_table(in_scale, in_zp, out_scale=np.float32(1.0 / 256.0), out_zp=0)
     input byte, rescaled, rounded half away from zero, clamped."""
     q = np.arange(256, dtype=np.float32)
     x = np.float32(in_scale) * (q - np.float32(in_zp))
-    y = np.float32(1.0) / (np.float32(1.0) + np.exp(-x, dtype=np.float32))
+    with np.errstate(over='ignore'):
+        y = np.float32(1.0) / (np.float32(1.0) + np.exp(-x, dtype=np.float32))
     r = y / np.float32(out_scale) + np.float32(out_zp)
     r = np.where(r >= 0, np.floor(r + np.float32(0.5)), np.ceil(r - np.float32(0.5)))
     return np.clip(r, 0, 255).astype(np.uint8)

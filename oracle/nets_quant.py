@@ -132,7 +132,8 @@ def logistic_table(in_scale, in_zp, out_scale=1.0 / 256.0, out_zp=0):
     tab = np.zeros(256, np.uint8)
     for q in range(256):
         x = np.float32(in_scale) * (np.float32(q) - np.float32(in_zp))
-        y = np.float32(1.0) / (np.float32(1.0) + np.float32(math.exp(-float(x))))
+        with np.errstate(over='ignore'):
+            y = np.float32(1.0) / (np.float32(1.0) + np.exp(-x))            # std::exp on a float: evaluated in f32
         r = float(y / np.float32(out_scale) + np.float32(out_zp))
         tab[q] = min(255, max(0, int(math.floor(r + 0.5)) if r >= 0 else int(math.ceil(r - 0.5))))
     return tab

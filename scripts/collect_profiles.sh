@@ -7,6 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
+export DD_BENCH_GEN_WORKERS=1      # every profiled run generates its frames in-process: no generator pool forked from a process the profiler's preloaded library may have initialised the GPU in
 PARTS=${*:-layers trace pmc sq}
 B="python3 $R/bench.py --groups 1 --streams 384 --steps 20 --warmup 5 --no-cpu-baseline"
 for part in $PARTS; do

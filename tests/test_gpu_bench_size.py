@@ -135,9 +135,12 @@ def test_yolo_launch_of_256_frames_is_frame_independent_and_matches_the_oracle()
     prod = want[:, 5:] * want[:, 4:5]
     order = np.sort(prod, axis=-1)
     assert _close(conf[n - 1], order[:, -1], 2e-4, 2e-2) <= 1.0
-    clear = (order[:, -1] - order[:, -2]) > (4e-4 + 4e-2 * order[:, -1])
-    assert clear.mean() > 0.5
+    # the class: on every row whose two best products are further apart than twice the stated tolerance of a product
+    # (2e-4 + 2e-2 * value each), and those rows must be >= 90 % of the rows that pass the detector's 0.25 threshold
+    clear = (order[:, -1] - order[:, -2]) > 2 * (2e-4 + 2e-2 * order[:, -1])
     np.testing.assert_array_equal(cls[n - 1][clear], np.argmax(prod, axis=-1)[clear])
+    passed = order[:, -1] >= 0.25
+    assert passed.sum() > 0 and clear[passed].mean() >= 0.9, (int(passed.sum()), float(clear[passed].mean()))
 
 
 def test_lanczos_launch_of_384_frames_matches_pillow():

@@ -51,7 +51,7 @@ def test_ssd_plugin_vs_oracle():
     from deepdish_amd.pipeline import make_detector, DEFAULT_LABELS
     from deepdish_amd import nets
     from deepdish_amd.synth import Scene
-    from oracle import nets_torch, deepsort_np
+    from oracle import nets_torch, nets_quant, deepsort_np
     det = make_detector('synthetic-ssd_mobilenet_v1.tflite', wanted_labels=[l.strip() for l in open(DEFAULT_LABELS)][1:])
     assert (det.width, det.height) == (300, 300) and det.labels[1] == 'person' and det.use_edgetpu is False
     frame = Scene(seed=3, n_obj=8).frame(0)
@@ -64,13 +64,13 @@ def test_ssd_plugin_vs_oracle():
     wd = det.ssdm.weights
     resized = np.asarray(img.convert('RGB').resize((300, 300), Image.LANCZOS))
     raw = nets_torch.ssd_forward(wd, resized[None], w16=True)[0]
-    ob, oc, osc, n = nets_torch.ssd_postprocess(raw, det.ssdm.anchors)
+    ob, oc, osc, n = nets_torch.ssd_postprocess(raw, nets_quant.ssd_anchors())          # the oracle's own anchor generator, not the product's
     out = det.ssdm.invoke_device(det.ssdm.prepare_image_device(torch.from_numpy(rgba).cuda(), 480, 640, 4))
     assert int(out[3]) == n == 10
     # (1) the post-process op by itself: the oracle's restatement applied to the HIP head tensor must pick the SAME ten
     # anchors -- classes identical row by row, boxes and scores equal to f32 rounding (expf vs numpy's exp)
     raw_hip = det.ssdm.net.read()[0, :, 0, :]
-    hb, hc, hs, hn = nets_torch.ssd_postprocess(raw_hip, det.ssdm.anchors)
+    hb, hc, hs, hn = nets_torch.ssd_postprocess(raw_hip, nets_quant.ssd_anchors())
     assert hn == 10
     np.testing.assert_array_equal(out[1], hc)
     np.testing.assert_allclose(out[0], hb, rtol=0, atol=2e-6)
@@ -96,7 +96,7 @@ def test_yolov5_plugin_vs_oracle():
     the threshold is found with the same class, box within 1e-2 (image-normalised) and confidence within 2e-2."""
     from deepdish_amd.pipeline import make_detector
     from deepdish_amd.synth import Scene
-    from oracle import nets_torch, image_np, detectors_np
+    from oracle import nets_torch, nets_quant, image_np, detectors_np
     det = make_detector('synthetic-yolov5s-fp16.tflite', wanted_labels=['person'])
     frame = Scene(seed=4, n_obj=8).frame(0)
     rgb = np.ascontiguousarray(frame[..., ::-1])
@@ -316,7 +316,7 @@ def test_tflite_plugin_vs_oracle():
     """a13: generic TFLite-Task adaptor = cv2 bilinear stretch + SSD forward + post-process + int() boxes."""
     from deepdish_amd.pipeline import make_detector, DEFAULT_LABELS
     from deepdish_amd.synth import Scene
-    from oracle import nets_torch, image_np
+    from oracle import nets_torch, nets_quant, image_np
     names = [l.strip() for l in open(DEFAULT_LABELS)]
     wanted = sorted(set(names) - {'???'})
     det = make_detector('synthetic-efficientdet_lite0.tflite', wanted_labels=wanted)
@@ -325,7 +325,7 @@ def test_tflite_plugin_vs_oracle():
     boxes, labels, scores = det.detect_image(rgb)
     resized = image_np.resize_linear_u8(rgb, 300, 300)
     raw = nets_torch.ssd_forward(det.detector.weights, resized[None], w16=True)[0]
-    ob, oc, osc, n = nets_torch.ssd_postprocess(raw, det.detector._anchors)
+    ob, oc, osc, n = nets_torch.ssd_postprocess(raw, nets_quant.ssd_anchors())
     want = []
     for i in range(n):
         if osc[i] >= 0.5:
