@@ -92,7 +92,7 @@ def pmc_traffic(kernel, streams):
     None when no summary exists for this stream count -- bench.py cannot run the profiler on itself."""
     import json, os
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles')
-    path = next((p for p in (os.path.join(root, 'r%02d_pmc_traffic_s%d.json' % (r, streams)) for r in (3, 2, 1)) if os.path.exists(p)), None)
+    path = next((p for p in (os.path.join(root, 'r%02d_pmc_traffic_s%d.json' % (r, streams)) for r in (4, 3, 2, 1)) if os.path.exists(p)), None)
     if path is None:                       # the newest round's summary for this stream count, if one was collected
         return None
     keys = [part.replace(',', ', ') for part in kernel.split('+')]

@@ -15,7 +15,7 @@ case $part in
 tests)
     (cd $R && timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/gputests.log 2>&1; echo "rc=$?" >> $O/gputests.log; tail -3 $O/gputests.log) ;;
 layers)
-    for kb in "ssd 384" "ssd 192" "mars 7680" "mars 3840" "yolo 128"; do set -- $kb
+    for kb in "ssd_i8 384" "ssd_i8_sym 384" "ssd 384" "mars 7680" "yolo 128"; do set -- $kb
         python3 $R/scripts/profile_layers.py $1 $2 > $O/layers_$1_b$2.txt 2>&1; tail -1 $O/layers_$1_b$2.txt; done ;;
 trace)
     DD_BENCH_NO_LOOKAHEAD=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_g1 -- python3 $R/bench.py --groups 1 --streams 384 --steps 60 --warmup 5 --no-cpu-baseline > $O/bench_groups1_s384.json 2> $O/kt_g1.err
