@@ -68,6 +68,32 @@ __device__ __forceinline__ int q_requant(int x, const QReq &R) {
     return min(max(z, R.lo), R.hi);
 }
 
+__device__ __forceinline__ int q_requant_relu(int x, int M, long long C, int sh32) {      // e >= 1: z = (x M + C) >> (32 + sh32)
+    const long long t = (long long)x * M + C;
+    return ((int)(t >> 32)) >> sh32;
+}
+__device__ __forceinline__ int q_clamp(int z, int lo, int hi) {                           // lo <= hi: one v_med3_i32 (min(max()) is two instructions)
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(z), "s"(lo), "v"(hi));     // one scalar operand per vector instruction (constant bus)
+    return r;
+}
+
+// Four requantised values -> four bytes.  SAT (the layer's clamp is the whole byte range, as ReLU6 at scale 6/255 makes it): saturating
+// packs do clamp and pack in 5 instructions (v_cvt_pk_i16_i32 x2, v_sat_pk_u8_i16 x2, v_lshl_or_b32) instead of 4 v_med3 + 3 v_lshl_or.
+template <bool SAT>
+__device__ __forceinline__ unsigned q_pack4(int z0, int z1, int z2, int z3, int lo, int hi) {
+    if constexpr (SAT) {
+        unsigned p01, p23, q01, q23;
+        asm("v_cvt_pk_i16_i32 %0, %1, %2" : "=v"(p01) : "v"(z0), "v"(z1));
+        asm("v_cvt_pk_i16_i32 %0, %1, %2" : "=v"(p23) : "v"(z2), "v"(z3));
+        asm("v_sat_pk_u8_i16 %0, %1" : "=v"(q01) : "v"(p01));
+        asm("v_sat_pk_u8_i16 %0, %1" : "=v"(q23) : "v"(p23));
+        return (q23 << 16) | (q01 & 0xffffu);
+    } else {
+        return (unsigned)q_clamp(z0, lo, hi) | (unsigned)q_clamp(z1, lo, hi) << 8 | (unsigned)q_clamp(z2, lo, hi) << 16 | (unsigned)q_clamp(z3, lo, hi) << 24;
+    }
+}
+
 __device__ __forceinline__ int sdot4(int a, int b, int c) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_sdot4(a, b, c, false);
@@ -269,6 +295,8 @@ __global__ __launch_bounds__(256) void q_conv0_k(const QConv0P P, const int n_fr
         for (int i = 0; i < 3; ++i) w[j][i] = *reinterpret_cast<const unsigned *>(P.src + min(max(a4 + 4 * i, 0ll), P.total_bytes - 4));
     }
     const i4v wa = P.w[lane], wb = P.w[64 + lane];
+    const int M0 = P.R.M, sh0 = P.R.e - 1, lo0 = P.R.lo, hi0 = P.R.hi;
+    const long long C0 = P.R.C;
     // fragment m's row 4g + r was packed with channel 8g + 4m + r: this lane holds channels 8 fq .. 8 fq + 7
     const i4v c0 = *reinterpret_cast<const i4v *>(P.cbias + 8 * fq), c1 = *reinterpret_cast<const i4v *>(P.cbias + 8 * fq + 4);
 #pragma unroll
@@ -279,7 +307,8 @@ __global__ __launch_bounds__(256) void q_conv0_k(const QConv0P P, const int n_fr
             d[1] = __builtin_amdgcn_alignbyte(w[j][2], w[j][1], o_[j]);
             d[2] = __builtin_amdgcn_alignbyte(0u, w[j][2], o_[j]);
             const int col = px[j] * P.stride - P.pad_l;
-            // columns outside the image: pixel i of the three covers bytes 3i .. 3i + 2
+            // columns outside the image: pixel i of the three covers bytes 3i .. 3i + 2 (only the waves at the left / right edge run this)
+            if (__builtin_amdgcn_ballot_w64(col < 0 || col + 2 >= P.W) != 0ull)
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const bool in = col + i >= 0 && col + i < P.W;
@@ -305,8 +334,8 @@ __global__ __launch_bounds__(256) void q_conv0_k(const QConv0P P, const int n_fr
         unsigned lo = 0, hi = 0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            lo |= (unsigned)q_requant(acc0[r] + rs + c0[r], P.R) << (8 * r);
-            hi |= (unsigned)q_requant(acc1[r] + rs + c1[r], P.R) << (8 * r);
+            lo |= (unsigned)q_clamp(q_requant_relu(acc0[r] + rs + c0[r], M0, C0, sh0), lo0, hi0) << (8 * r);
+            hi |= (unsigned)q_clamp(q_requant_relu(acc1[r] + rs + c1[r], M0, C0, sh0), lo0, hi0) << (8 * r);
         }
         if (live[j]) {
             const size_t PPo = (size_t)(P.wo + 2) * 16;
@@ -464,19 +493,13 @@ struct QDwpwP {
 
 constexpr int QT = 64;               // pixels per tile
 
-__device__ __forceinline__ int q_requant_relu(int x, int M, long long C, int sh32) {      // e >= 1: z = (x M + C) >> (32 + sh32)
-    const long long t = (long long)x * M + C;
-    return ((int)(t >> 32)) >> sh32;
-}
-__device__ __forceinline__ int q_clamp(int z, int lo, int hi) {                           // lo <= hi: one v_med3_i32 (min(max()) is two instructions)
-    int r;
-    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(z), "s"(lo), "v"(hi));     // one scalar operand per vector instruction (constant bus)
-    return r;
-}
-
-template <int CIN, int COUT, int WP, int STRIDE, int LPT, bool ROWSUM, bool TEAMS>
-__global__ __launch_bounds__((COUT / 64) * WP * 64) void q_dwpw_k(const QDwpwP P, const int n_tiles, const int tiles_per_block) {
-    constexpr int WM = COUT / 64, NW = WM * WP, NT = NW * 64;
+// MW = 16-channel fragments of the pointwise filter per wave: 4 (64 channels, <= 128 VGPRs of filter, 256-register waves, two per SIMD) or
+// 2 (32 channels, <= 64 VGPRs, 128-register waves, four per SIMD: twice the waves to cover each other's LDS / MFMA / requantisation chains).
+template <int CIN, int COUT, int WP, int STRIDE, int LPT, bool ROWSUM, bool TEAMS, int MW = 4, bool SAT = false>
+__global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64) void q_dwpw_k(const QDwpwP P, const int n_tiles, const int tiles_per_block) {
+    constexpr int WM = COUT / (16 * MW), NW = WM * WP, NT = NW * 64;
+    constexpr int FB = MW == 4 ? 4 : 2;                               // pixel fragments the depthwise stage keeps in flight (registers)
+    static_assert(MW == 4 || MW == 2, "fragments per wave");
     constexpr int KC = (CIN + 63) / 64, CINP = KC * 64, C16 = CIN / 16;
     constexpr int NOB = TEAMS ? 2 : 1, NRS = TEAMS ? 3 : 2;         // operand tiles, row-sum buffers
     static_assert(C16 % NW == 0 || NW % C16 == 0, "planes over waves");
@@ -494,11 +517,13 @@ __global__ __launch_bounds__((COUT / 64) * WP * 64) void q_dwpw_k(const QDwpwP P
     int *cbl = reinterpret_cast<int *>(pinfo + 2 * QT);             // [COUT]: the pointwise layer's per-channel constants
 
     // the wave's pointwise filter, once
-    i4v Wr[4][KC];
+    // wave wm's fragments: MW consecutive ones of the host's 4-fragment groups (fragment 4 mg + m holds channels 64 mg + 16 g + 4 m + r)
+    i4v Wr[MW][KC];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < MW; ++m)
 #pragma unroll
-        for (int kc = 0; kc < KC; ++kc) Wr[m][kc] = P.w[((size_t)(wm * 4 + m) * KC + kc) * 64 + lane];
+        for (int kc = 0; kc < KC; ++kc) Wr[m][kc] = P.w[((size_t)(wm * MW + m) * KC + kc) * 64 + lane];
+    const int mg = (wm * MW) / 4, m0 = (wm * MW) % 4;               // the 64-channel group and the first fragment inside it
     for (int i = tid; i < COUT; i += NT) cbl[i] = P.cbias[i];
     if (CIN < CINP) for (int i = tid; i < NOB * QT * CINP / 16; i += NT) reinterpret_cast<u4v *>(opnd)[i] = u4v{0, 0, 0, 0};   // k slots without channels
     for (int i = tid; i < NRS * QT; i += NT) rowsum[i] = 0;
@@ -547,50 +572,66 @@ __global__ __launch_bounds__((COUT / 64) * WP * 64) void q_dwpw_k(const QDwpwP P
     };
     // ---- depthwise stage: planes [cg0, cg0 + n_cg) x the four pixel fragments of the tile whose geometry is in buffer gbuf
     auto dw_planes = [&](int cg0, int n_cg, int gbuf, int obuf, int rsb) {
-        int tapoff[3][4];                                            // ring offset of this lane's tap of k step ks at its pixel of fragment f (plane 0)
-#pragma unroll
-        for (int f = 0; f < 4; ++f) {
-            const i4v pi = pinfo[gbuf * QT + 16 * f + fr];
-#pragma unroll
-            for (int ks = 0; ks < 3; ++ks) tapoff[ks][f] = (tap_row[ks] == 0 ? pi[0] : tap_row[ks] == 1 ? pi[1] : pi[2]) + pi[3] + tap_dx[ks];
-        }
         int rs[4] = {0, 0, 0, 0};
         uint8_t *ob = opnd + (size_t)obuf * QT * CINP;
+        int tapoff_all[3][4];                                        // (all four fragments in flight: once per tile, not once per plane)
+        if constexpr (FB == 4) {
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const i4v pi = pinfo[gbuf * QT + 16 * f + fr];
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) tapoff_all[ks][f] = (tap_row[ks] == 0 ? pi[0] : tap_row[ks] == 1 ? pi[1] : pi[2]) + pi[3] + tap_dx[ks];
+            }
+        }
         for (int ci = 0; ci < n_cg; ++ci) {
             const int cg = cg0 + ci;
             const uint2 ab = P.dw_a[cg * 64 + lane];
             const i4v cbv = *reinterpret_cast<const i4v *>(P.dw_cb + cg * 16 + 4 * fq);
             const int pofs = cg * PP;
-            i4v acc[4];
 #pragma unroll
-            for (int f = 0; f < 4; ++f) acc[f] = cbv;
-            i4v b[2][4];
+            for (int f0 = 0; f0 < 4; f0 += FB) {
+                int tapoff[3][FB];                                   // ring offset of this lane's tap of k step ks at its pixel of fragment f0 + f (plane 0)
 #pragma unroll
-            for (int f = 0; f < 4; ++f) b[0][f] = *reinterpret_cast<const i4v *>(ring + tapoff[0][f] + pofs);
+                for (int f = 0; f < FB; ++f) {
+                    if constexpr (FB == 4) {
 #pragma unroll
-            for (int ks = 0; ks < 3; ++ks) {
-                const unsigned sel = 0x01010101u * (unsigned)ks;
-                const unsigned rh = __builtin_amdgcn_perm(ab.x, ab.x, sel), rl = __builtin_amdgcn_perm(ab.y, ab.y, sel);
-                i4v Ah, Al;
+                        for (int ks = 0; ks < 3; ++ks) tapoff[ks][f] = tapoff_all[ks][f];
+                    } else {
+                        const i4v pi = pinfo[gbuf * QT + 16 * (f0 + f) + fr];
 #pragma unroll
-                for (int d = 0; d < 4; ++d) { Ah[d] = (int)(rh & dmask[d]); Al[d] = (int)(rl & dmask[d]); }
-                if (ks < 2) {                                        // the next k step's operands are on their way while this one multiplies
+                        for (int ks = 0; ks < 3; ++ks) tapoff[ks][f] = (tap_row[ks] == 0 ? pi[0] : tap_row[ks] == 1 ? pi[1] : pi[2]) + pi[3] + tap_dx[ks];
+                    }
+                }
+                i4v acc[FB];
 #pragma unroll
-                    for (int f = 0; f < 4; ++f) b[(ks + 1) & 1][f] = *reinterpret_cast<const i4v *>(ring + tapoff[ks + 1][f] + pofs);
+                for (int f = 0; f < FB; ++f) acc[f] = cbv;
+                i4v b[2][FB];
+#pragma unroll
+                for (int f = 0; f < FB; ++f) b[0][f] = *reinterpret_cast<const i4v *>(ring + tapoff[0][f] + pofs);
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) {
+                    const unsigned sel = 0x01010101u * (unsigned)ks;
+                    const unsigned rh = __builtin_amdgcn_perm(ab.x, ab.x, sel), rl = __builtin_amdgcn_perm(ab.y, ab.y, sel);
+                    i4v Ah, Al;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) { Ah[d] = (int)(rh & dmask[d]); Al[d] = (int)(rl & dmask[d]); }
+                    if (ks < 2) {                                    // the next k step's operands are on their way while this one multiplies
+#pragma unroll
+                        for (int f = 0; f < FB; ++f) b[(ks + 1) & 1][f] = *reinterpret_cast<const i4v *>(ring + tapoff[ks + 1][f] + pofs);
+                    }
+#pragma unroll
+                    for (int f = 0; f < FB; ++f) acc[f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Ah, b[ks & 1][f], acc[f], 0, 0, 0);
+#pragma unroll
+                    for (int f = 0; f < FB; ++f) acc[f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Al, b[ks & 1][f], acc[f], 0, 0, 0);
                 }
 #pragma unroll
-                for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Ah, b[ks & 1][f], acc[f], 0, 0, 0);
-#pragma unroll
-                for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Al, b[ks & 1][f], acc[f], 0, 0, 0);
-            }
-#pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                unsigned packed = 0;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) packed |= (unsigned)q_clamp(q_requant_relu(acc[f][r], Md, Cd, shd), lod, hid) << (8 * r);
-                packed ^= 0x80808080u;
-                if (ROWSUM) rs[f] = sdot4((int)packed, 0x01010101, rs[f]);
-                *reinterpret_cast<unsigned *>(ob + ((size_t)cg * QT + 16 * f + fr) * 16 + 4 * fq) = packed;
+                for (int f = 0; f < FB; ++f) {
+                    unsigned packed = q_pack4<SAT>(q_requant_relu(acc[f][0], Md, Cd, shd), q_requant_relu(acc[f][1], Md, Cd, shd),
+                                                   q_requant_relu(acc[f][2], Md, Cd, shd), q_requant_relu(acc[f][3], Md, Cd, shd), lod, hid);
+                    packed ^= 0x80808080u;
+                    if (ROWSUM) rs[f0 + f] = sdot4((int)packed, 0x01010101, rs[f0 + f]);
+                    *reinterpret_cast<unsigned *>(ob + ((size_t)cg * QT + 16 * (f0 + f) + fr) * 16 + 4 * fq) = packed;
+                }
             }
         }
         if (ROWSUM && n_cg > 0) {
@@ -610,43 +651,58 @@ __global__ __launch_bounds__((COUT / 64) * WP * 64) void q_dwpw_k(const QDwpwP P
         // A lone ds_read -> s_waitcnt -> 4 MFMAs per K slice leaves the matrix pipe idle for the LDS latency eight times per fragment
         // (2.2 k cycles per fragment measured, 0.5 k of MFMA): all K slices of a fragment are requested before its first MFMA, and the
         // next fragment's as soon as this one's MFMAs are issued, so they land during the epilogue.
-        i4v b[KC];
+        constexpr int KB = KC < 4 ? KC : 4;                             // K slices requested at a time (all eight of a 512-channel layer cost 32 registers: the prefetch
+                                                                        // registers then spill, and a spilled HBM load is waited for on the spot)
+        i4v b[KB];
         if (wp < nf) {
             const uint8_t *bp = ob + ((size_t)fq * QT + 16 * wp + fr) * 16;
 #pragma unroll
-            for (int kc = 0; kc < KC; ++kc) b[kc] = *reinterpret_cast<const i4v *>(bp + (size_t)kc * 4 * QT * 16);
+            for (int kc = 0; kc < KB; ++kc) b[kc] = *reinterpret_cast<const i4v *>(bp + (size_t)kc * 4 * QT * 16);
         }
         for (int f = wp; f < nf; f += WP) {
-            i4v acc[4];
+            i4v acc[MW];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) acc[m] = *reinterpret_cast<const i4v *>(cbl + 64 * wm + 16 * fq + 4 * m);
+            for (int m = 0; m < MW; ++m) acc[m] = *reinterpret_cast<const i4v *>(cbl + 64 * mg + 16 * fq + 4 * (m0 + m));
+            const uint8_t *bp = ob + ((size_t)fq * QT + 16 * f + fr) * 16;
 #pragma unroll
-            for (int kc = 0; kc < KC; ++kc)
+            for (int k0 = 0; k0 < KC; k0 += KB) {
 #pragma unroll
-                for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Wr[m][kc], b[kc], acc[m], 0, 0, 0);
+                for (int kc = 0; kc < KB; ++kc)
+#pragma unroll
+                    for (int m = 0; m < MW; ++m) acc[m] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Wr[m][k0 + kc], b[kc], acc[m], 0, 0, 0);
+                if (k0 + KB < KC) {
+#pragma unroll
+                    for (int kc = 0; kc < KB; ++kc) b[kc] = *reinterpret_cast<const i4v *>(bp + (size_t)(k0 + KB + kc) * 4 * QT * 16);
+                }
+            }
             if (f + WP < nf) {
-                const uint8_t *bp = ob + ((size_t)fq * QT + 16 * (f + WP) + fr) * 16;
+                const uint8_t *bn = ob + ((size_t)fq * QT + 16 * (f + WP) + fr) * 16;
 #pragma unroll
-                for (int kc = 0; kc < KC; ++kc) b[kc] = *reinterpret_cast<const i4v *>(bp + (size_t)kc * 4 * QT * 16);
+                for (int kc = 0; kc < KB; ++kc) b[kc] = *reinterpret_cast<const i4v *>(bn + (size_t)kc * 4 * QT * 16);
             }
             const int rsv = ROWSUM ? rowsum[rsb * QT + 16 * f + fr] * P.zwc : 0;
             const unsigned po = pixoff[gbuf * QT + 16 * f + fr];
-            u4v o;
+            unsigned o[MW];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                unsigned packed = 0;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) packed |= (unsigned)q_clamp(q_requant_relu(acc[m][r] + rsv, Mp, Cp, shp), lop, hip_) << (8 * r);
-                o[m] = packed ^ 0x80808080u;
+            for (int m = 0; m < MW; ++m) {
+                o[m] = 0x80808080u ^ q_pack4<SAT>(q_requant_relu(acc[m][0] + rsv, Mp, Cp, shp), q_requant_relu(acc[m][1] + rsv, Mp, Cp, shp),
+                                                    q_requant_relu(acc[m][2] + rsv, Mp, Cp, shp), q_requant_relu(acc[m][3] + rsv, Mp, Cp, shp), lop, hip_);
             }
-            if (po != 0xffffffffu) *reinterpret_cast<u4v *>(P.out + po + (size_t)(4 * wm + fq) * ((P.wo + 2) * 16)) = o;
+            if (po != 0xffffffffu) {
+                uint8_t *dst = P.out + po + (size_t)(4 * mg + fq) * ((P.wo + 2) * 16) + 4 * m0;
+                if constexpr (MW == 4) *reinterpret_cast<u4v *>(dst) = u4v{o[0], o[1], o[2], o[3]};
+                else *reinterpret_cast<uint2 *>(dst) = make_uint2(o[0], o[1]);
+            }
         }
     };
     auto pf_request = [&](u4v (&pf)[LPT], int lo, unsigned nb) {
         if (!nb) return;                                             // (uniform) every request goes out back to back: no lane predicate, the
         const uint8_t *src = P.in + (size_t)lo * RB;                 // pieces past the end re-read the last one and are dropped at the write
 #pragma unroll
-        for (int i = 0; i < LPT; ++i) pf[i] = *reinterpret_cast<const u4v *>(src + min((unsigned)(i * NT + tid) * 16u, nb - 16u));
+        for (int i = 0; i < LPT; ++i) {
+            if ((unsigned)(i * NT) * 16u < nb)                       // (uniform; no `break`: that leaves a rolled loop and the array in scratch) most tiles add a fraction of the worst case
+                pf[i] = *reinterpret_cast<const u4v *>(src + min((unsigned)(i * NT + tid) * 16u, nb - 16u));
+        }
     };
     auto pf_write = [&](const u4v (&pf)[LPT], int lo, unsigned nb) {
         if (!nb) return;
@@ -656,7 +712,7 @@ __global__ __launch_bounds__((COUT / 64) * WP * 64) void q_dwpw_k(const QDwpwP P
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
             const unsigned idx = (unsigned)(i * NT) * 16u + tid16;
-            if (idx < nb) {
+            if ((unsigned)(i * NT) * 16u < nb && idx < nb) {
                 const unsigned row = __umulhi(idx, P.rb_magic), off = idx - row * RB;      // idx / RB (exact: idx * RB < 2^32)
                 int slot = slot0 + (int)row;
                 slot = slot >= P.NR ? slot - P.NR : slot;
@@ -787,9 +843,9 @@ void dwpw_plan(int H, int W, int ho, int wo, int stride, int off_y, int cin, int
     *lpt = (int)(((long long)mx * RB + (long long)nt * 16 - 1) / ((long long)nt * 16));
 }
 
-template <int CIN, int COUT, int WP, int STRIDE, int LPT, bool TEAMS>
+template <int CIN, int COUT, int WP, int STRIDE, int LPT, bool TEAMS, int MW = 4>
 int launch_q_dwpw(hipStream_t s, QDwpwP &P, int nimg, int device, bool *ok) {
-    constexpr int NW = (COUT / 64) * WP, NT = NW * 64, CINP = (CIN + 63) / 64 * 64;
+    constexpr int NW = (COUT / (16 * MW)) * WP, NT = NW * 64, CINP = (CIN + 63) / 64 * 64;
     int lpt = 0;
     dwpw_plan(P.H, P.W, P.ho, P.wo, STRIDE, P.off_y, CIN, NT, &P.NR, &lpt);
     const int RB = (P.W + 2) * CIN;
@@ -798,10 +854,17 @@ int launch_q_dwpw(hipStream_t s, QDwpwP &P, int nimg, int device, bool *ok) {
     *ok = lpt <= LPT && lds <= 160 * 1024 && (long long)LPT * NT * 16 * RB < (1ll << 32) && (LPT * NT * 16) / RB + 1 <= 2 * P.NR;
     if (!*ok) return DD_OK;
     const bool rsum = P.zwc != 0;
+    const bool sat = P.Rd.lo == 0 && P.Rd.hi == 255 && P.Rp.lo == 0 && P.Rp.hi == 255;       // both clamps are the byte range: saturating packs
+    auto kfn = [&]() -> const void * {
+        if (rsum) return sat ? reinterpret_cast<const void *>(&q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, true, TEAMS, MW, true>) : reinterpret_cast<const void *>(&q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, true, TEAMS, MW, false>);
+        return sat ? reinterpret_cast<const void *>(&q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, false, TEAMS, MW, true>) : reinterpret_cast<const void *>(&q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, false, TEAMS, MW, false>);
+    };
     static DevOnce once;
     const int rc = once.run(device, [&]() -> int {
-        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, true, TEAMS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, false, TEAMS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, true, TEAMS, MW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, true, TEAMS, MW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, false, TEAMS, MW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, false, TEAMS, MW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         return DD_OK;
     });
     if (rc != DD_OK) return rc;
@@ -809,7 +872,7 @@ int launch_q_dwpw(hipStream_t s, QDwpwP &P, int nimg, int device, bool *ok) {
     int per_cu = per_cu_cache[device & 63].load(std::memory_order_relaxed);
     if (per_cu == 0) {
         int nb = 0;
-        DD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, true, TEAMS>), NT, lds));
+        DD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kfn(), NT, lds));
         per_cu = std::max(1, std::min(8, nb));
         per_cu_cache[device & 63].store(per_cu, std::memory_order_relaxed);
     }
@@ -820,8 +883,10 @@ int launch_q_dwpw(hipStream_t s, QDwpwP &P, int nimg, int device, bool *ok) {
     static const bool stamps = getenv("DD_Q_STAMPS") && atoi(getenv("DD_Q_STAMPS")) != 0;
     const size_t n_st = (size_t)grid.x * NW * 8;
     if (stamps) { DD_HIP(hipMalloc(&P.dbg, n_st * 8)); DD_HIP(hipMemsetAsync(P.dbg, 0, n_st * 8, s)); }
-    if (rsum) hipLaunchKernelGGL((q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, true, TEAMS>), grid, dim3(NT), lds, s, P, n_tiles, tpb);
-    else hipLaunchKernelGGL((q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, false, TEAMS>), grid, dim3(NT), lds, s, P, n_tiles, tpb);
+    if (rsum && sat) hipLaunchKernelGGL((q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, true, TEAMS, MW, true>), grid, dim3(NT), lds, s, P, n_tiles, tpb);
+    else if (rsum) hipLaunchKernelGGL((q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, true, TEAMS, MW, false>), grid, dim3(NT), lds, s, P, n_tiles, tpb);
+    else if (sat) hipLaunchKernelGGL((q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, false, TEAMS, MW, true>), grid, dim3(NT), lds, s, P, n_tiles, tpb);
+    else hipLaunchKernelGGL((q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, false, TEAMS, MW, false>), grid, dim3(NT), lds, s, P, n_tiles, tpb);
     DD_LAUNCH_CHECK();
     if (stamps) {                                                   // diagnostic: where the waves of this launch spent their cycles
         std::vector<unsigned long long> h(n_st);
@@ -858,7 +923,7 @@ int netq_run_op(dd_net *net, int i, const int32_t *o, const uint8_t *input, int 
             P.w = reinterpret_cast<const i4v *>(W + (size_t)(uint32_t)o[16]);
             P.cbias = reinterpret_cast<const int *>(W + (size_t)(uint32_t)o[17]);
             P.out = base(dst); P.in_zp = o[39]; P.zwc = o[38]; P.R = make_req(o);
-            DD_REQUIRE(td->pad == 1 && td->cs == 32 && o[11] == 32 && (reinterpret_cast<uintptr_t>(input) & 3) == 0 && (P.total_bytes & 3) == 0 && !P.R.linear,
+            DD_REQUIRE(td->pad == 1 && td->cs == 32 && o[11] == 32 && (reinterpret_cast<uintptr_t>(input) & 3) == 0 && (P.total_bytes & 3) == 0 && !P.R.linear && P.R.e >= 1,
                        DD_E_ARG, "dd_net_forward: uint8 first layer: 32 channels into a bordered tensor from a 4-byte aligned batch");
             const int n_frags = dd_ceil_div(P.m, 16);
             hipLaunchKernelGGL(q_conv0_k, dim3(dd_ceil_div(n_frags, 4 * C0F)), dim3(256), 0, s, P, n_frags);
@@ -943,6 +1008,7 @@ int netq_run_op(dd_net *net, int i, const int32_t *o, const uint8_t *input, int 
             bool ok = false;
             int rc = DD_OK;
             const int dev = net->ctx->device;
+            static const int mw = getenv("DD_Q_MW") ? atoi(getenv("DD_Q_MW")) : 4;               // 19x19 blocks: 4 = eight waves of 64 channels; 2 = sixteen of 32 (four per SIMD; measured slower: 131 vs 89 us, the stages are issue-bound, not latency-bound)
             static const int teams = getenv("DD_Q_TEAMS") ? atoi(getenv("DD_Q_TEAMS")) : 0;       // 1 = the two-team schedule (measured slower: profiles/r04_q_stamps.txt)
 #define DD_QB(CIN_, COUT_, WP_, S_, LPT_, T_) (T_ && teams ? launch_q_dwpw<CIN_, COUT_, WP_, S_, LPT_, T_>(s, P, nimg, dev, &ok) : launch_q_dwpw<CIN_, COUT_, WP_, S_, LPT_, false>(s, P, nimg, dev, &ok))
             if (cin == 32 && cout == 64 && stride == 1) rc = DD_QB(32, 64, 2, 1, 8, false);
@@ -950,8 +1016,8 @@ int netq_run_op(dd_net *net, int i, const int32_t *o, const uint8_t *input, int 
             else if (cin == 128 && cout == 128 && stride == 1) rc = DD_QB(128, 128, 2, 1, 8, false);
             else if (cin == 128 && cout == 256 && stride == 2) rc = DD_QB(128, 256, 2, 2, 8, true);
             else if (cin == 256 && cout == 256 && stride == 1) rc = DD_QB(256, 256, 2, 1, 6, true);
-            else if (cin == 256 && cout == 512 && stride == 2) rc = DD_QB(256, 512, 1, 2, 12, true);
-            else if (cin == 512 && cout == 512 && stride == 1) rc = DD_QB(512, 512, 1, 1, 8, true);
+            else if (cin == 256 && cout == 512 && stride == 2) rc = mw == 2 ? launch_q_dwpw<256, 512, 1, 2, 6, false, 2>(s, P, nimg, dev, &ok) : DD_QB(256, 512, 1, 2, 12, true);
+            else if (cin == 512 && cout == 512 && stride == 1) rc = mw == 2 ? launch_q_dwpw<512, 512, 1, 1, 4, false, 2>(s, P, nimg, dev, &ok) : DD_QB(512, 512, 1, 1, 8, true);
 #undef DD_QB
             if (rc != DD_OK) return rc;
             DD_REQUIRE(ok, DD_E_ARG, "dd_net_forward: uint8 block %d (%d -> %d, stride %d, %d x %d): no fused kernel for this shape -- compile the program with the two-op form", i, cin, cout, stride, P.H, P.W);
