@@ -87,7 +87,20 @@ def config4():
     ints = np.zeros((n.value, 6), dtype=np.int64); check(lib().dd_tracker_read(h, 0, ptr(ints), None, None))
     same_abi = [(int(r[0]), int(r[1])) for r in ints] == [(t.track_id, t.state) for t in otrk.tracks]
     lib().dd_tracker_destroy(h)
-    return dict(config=4, what='tracker only, 256 targets, frames 30-59',
+    # SURVEY.md 8(d), algorithmic bytes per frame at T = D = 256 (the gallery is unbounded, deepdish.py:515: a track holds one sample per
+    # frame it was matched in, so G = 256 x (frame + 1); frames 30-59 -> 11 648 rows on average)
+    T = D = 256
+    G = 256 * 45.5
+    by = dict(kalman_predict=T * 1152, gating=T * 576 + D * 32 + T * D * 8, cosine=(G + D) * 512 + T * D * 8, iou=(T + D) * 32 + T * D * 8,
+              kalman_update=min(T, D) * 1152)
+    total_b, flops = sum(by.values()), 2 * G * D * 128
+    ms = 1e3 * t_abi / 30
+    roof = dict(bound='latency', algorithmic_bytes_per_frame=by, algorithmic_bytes_total=total_b, cosine_flops=flops,
+                achieved_GBps=total_b / (ms * 1e-3) / 1e9, frac_of_8TBps=total_b / (ms * 1e-3) / 8e12,
+                cosine_TFLOPs=flops / (ms * 1e-3) / 1e12,
+                note='one stream: five dependent launches and two host round trips per frame (LSAP on the host); the bytes are 1e-3 of what the GPU '
+                     'moves in that time -- the headline batches 384 such trackers per launch instead (csrc/tracker.hip)')
+    return dict(config=4, what='tracker only, 256 targets, frames 30-59', roofline=roof,
                 hip_c_abi_ms_per_frame=1e3 * t_abi / 30,
                 hip_python_objects_ms_per_frame=1e3 * t_gpu / 30, cpu_oracle_ms_per_frame=1e3 * t_cpu / 30, tracks=len(trk.tracks),
                 identical_ids_and_states=bool(same and same_abi))
@@ -119,5 +132,5 @@ def config5(S):
 
 
 if __name__ == '__main__':
-    for fn in (config3, config4, lambda: config5(1), lambda: config5(8), lambda: config5(64)):
+    for fn in (config4, lambda: config5(1), lambda: config5(8)):
         print(json.dumps(fn()), flush=True)
