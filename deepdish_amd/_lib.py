@@ -67,6 +67,8 @@ SIGNATURES = {
     'dd_mog2_apply': [P, P, c_double, P, P, P],
     'dd_mask_box_count': [P, P, c_int, c_int, c_int, P, P, c_int, P, P],
     'dd_net_create': [P, P, c_int, P, c_int64, c_int, POINTER(P)],
+    'dd_net_create_shared': [P, P, c_int, P, c_int64, c_int, POINTER(P)],
+    'dd_net_activation_bytes': [P, POINTER(c_int64)],
     'dd_net_destroy': [P],
     'dd_net_forward': [P, P, c_int, P],
     'dd_net_output': [P, c_int, POINTER(P), POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int),

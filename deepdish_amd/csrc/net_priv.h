@@ -16,6 +16,8 @@ struct dd_net {
     std::vector<void *> bufs;
     std::vector<int> buf_dtype;
     int n_ops = 0, ops_off = 0;
+    void *arena = nullptr;                   // dd_net_create_shared: one allocation, the buffers are offsets into it
+    int64_t arena_bytes = 0;
     char *d_weights = nullptr;
     int64_t weight_bytes = 0;
     int in_h = 0, in_w = 0, out_tensor = -1;

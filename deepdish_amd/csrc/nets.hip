@@ -4000,8 +4000,26 @@ extern "C" {
 // Program layout (int32 words): [magic 'DDN1'][n_tensors][n_bufs][n_ops][in_h][in_w][out_tensor][rsvd]
 // then n_tensors * 8 words (buf,h,w,c,cs,coff,dtype,0), n_bufs * 2 words (elements per image, dtype),
 // n_ops * 48 words.  See deepdish_amd/nets.py (Program.serialize) for the field order.
+static int net_create(dd_ctx *ctx, const int32_t *program_host, int n_words, const void *weights_host,
+                      int64_t n_weight_bytes, int max_batch, dd_net **out, bool share);
+
 int dd_net_create(dd_ctx *ctx, const int32_t *program_host, int n_words, const void *weights_host,
                   int64_t n_weight_bytes, int max_batch, dd_net **out) {
+    return net_create(ctx, program_host, n_words, weights_host, n_weight_bytes, max_batch, out, false);
+}
+
+// The same engine with its activation buffers overlaid by lifetime: a buffer is live from the first op that writes it to the last op
+// that reads it (the output tensor: to the end), and buffers whose lifetimes do not meet share device memory (first fit, in op
+// order).  For the engines a pipeline drives -- nobody reads an intermediate tensor after the forward (dd_net_read of anything but
+// the output is DD_E_STATE) -- and for f16 programs only: the uint8 programs' bordered tensors keep their zero-point borders
+// precisely because nothing else is ever written there.
+int dd_net_create_shared(dd_ctx *ctx, const int32_t *program_host, int n_words, const void *weights_host,
+                         int64_t n_weight_bytes, int max_batch, dd_net **out) {
+    return net_create(ctx, program_host, n_words, weights_host, n_weight_bytes, max_batch, out, true);
+}
+
+static int net_create(dd_ctx *ctx, const int32_t *program_host, int n_words, const void *weights_host,
+                      int64_t n_weight_bytes, int max_batch, dd_net **out, bool share) {
     DD_REQUIRE(ctx && program_host && weights_host && out && max_batch > 0 && n_words >= 8, DD_E_ARG,
                "dd_net_create: bad argument");
     DD_REQUIRE(program_host[0] == 0x314E4444, DD_E_ARG, "dd_net_create: bad program magic");
@@ -4017,6 +4035,73 @@ int dd_net_create(dd_ctx *ctx, const int32_t *program_host, int n_words, const v
     const int32_t *p = program_host + 8;
     for (int i = 0; i < nt; ++i, p += TENSOR_WORDS) n->tensors.push_back(TensorDesc{p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]});   // p[7] = 1: uint8 tensor in the bordered 16-channel-plane layout (csrc/netsq.hip)
     DD_HIP(hipSetDevice(ctx->device));
+    if (share) {
+        // lifetimes from the op list (it follows the buffer table): [first writer, last reader]; -1 = never written (the input of a view-only chain)
+        const int32_t *ops = p + (size_t)nb * 2;
+        std::vector<int> first(nb, -1), last(nb, -1);
+        auto touch = [&](int t, int i, bool write) {
+            if (t < 0 || t >= nt) return;
+            const int b = n->tensors[t].buf;
+            if (write && first[b] < 0) first[b] = i;
+            if (first[b] < 0) first[b] = i;
+            last[b] = std::max(last[b], i);
+        };
+        for (int i = 0; i < no; ++i) {
+            const int32_t *o = ops + (size_t)i * OP_WORDS;
+            DD_REQUIRE(o[0] < 16, DD_E_ARG, "dd_net_create_shared: uint8 programs keep one buffer per tensor (their borders are set once)");
+            touch(o[1], i, false); touch(o[3], i, false); touch(o[2], i, true); touch(o[4], i, true);
+        }
+        if (n->out_tensor >= 0) last[n->tensors[n->out_tensor].buf] = no;
+        // An op flagged "only the next op reads my output" (word 30) may run inside that op's launch -- a first layer folded into the
+        // pooled layer behind it, a residual unit held back until its second layer, a pair of units until the fourth -- so every buffer
+        // touched anywhere in such a chain of ops is live over the whole chain.
+        std::vector<int> gs(no), ge(no);
+        for (int i = 0; i < no;) {
+            int j = i;
+            while (j + 1 < no && (ops + (size_t)j * OP_WORDS)[30] != 0) ++j;
+            for (int k = i; k <= j; ++k) { gs[k] = i; ge[k] = j; }
+            i = j + 1;
+        }
+        std::fill(first.begin(), first.end(), -1);
+        std::fill(last.begin(), last.end(), -1);
+        auto touch2 = [&](int t, int i) {
+            if (t < 0 || t >= nt) return;
+            const int b = n->tensors[t].buf;
+            first[b] = first[b] < 0 ? gs[i] : std::min(first[b], gs[i]);
+            last[b] = std::max(last[b], ge[i]);
+        };
+        for (int i = 0; i < no; ++i) {
+            const int32_t *o = ops + (size_t)i * OP_WORDS;
+            touch2(o[1], i); touch2(o[2], i); touch2(o[3], i); touch2(o[4], i);
+        }
+        if (n->out_tensor >= 0) last[n->tensors[n->out_tensor].buf] = no;
+        std::vector<size_t> bytes(nb), off(nb, 0);
+        size_t arena = 0;
+        std::vector<int> order(nb);
+        for (int b = 0; b < nb; ++b) { order[b] = b; bytes[b] = ((size_t)p[2 * b] * max_batch * dtype_size(p[2 * b + 1] & 0xff) + 256 + 255) & ~(size_t)255; }
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return first[a] < first[b]; });
+        std::vector<int> placed;
+        for (int b : order) {
+            if (first[b] < 0) { first[b] = 0; last[b] = no; }      // untouched by any op: keep it apart for the whole forward
+            size_t at = 0;
+            for (bool moved = true; moved;) {                      // lowest offset that overlaps no placed buffer alive at the same time
+                moved = false;
+                for (int q : placed)
+                    if (!(last[q] < first[b] || last[b] < first[q]) && at < off[q] + bytes[q] && off[q] < at + bytes[b]) { at = off[q] + bytes[q]; moved = true; }
+            }
+            off[b] = at;
+            arena = std::max(arena, at + bytes[b]);
+            placed.push_back(b);
+        }
+        DD_HIP(hipMalloc(&n->arena, arena));
+        DD_HIP(hipMemset(n->arena, 0, arena));
+        n->arena_bytes = (int64_t)arena;
+        for (int i = 0; i < nb; ++i, p += 2) {
+            n->buf_elems.push_back(p[0]);
+            n->buf_dtype.push_back(p[1] & 0xff);
+            n->bufs.push_back(static_cast<char *>(n->arena) + off[i]);
+        }
+    } else
     for (int i = 0; i < nb; ++i, p += 2) {
         n->buf_elems.push_back(p[0]);
         n->buf_dtype.push_back(p[1] & 0xff);
@@ -4053,7 +4138,8 @@ int dd_net_create(dd_ctx *ctx, const int32_t *program_host, int n_words, const v
 
 int dd_net_destroy(dd_net *n) {
     if (!n) return DD_OK;
-    for (void *b : n->bufs) (void)hipFree(b);
+    if (n->arena) (void)hipFree(n->arena);
+    else for (void *b : n->bufs) (void)hipFree(b);
     for (hipEvent_t e : n->events) (void)hipEventDestroy(e);
     net_drop_graphs(n);
     n->slab.release();
@@ -4061,6 +4147,15 @@ int dd_net_destroy(dd_net *n) {
     (void)hipFree(n->d_weights);
     for (void *q : {(void *)n->d_anchors, (void *)n->dec_boxes, (void *)n->dec_score, (void *)n->dec_keys, (void *)n->dec_cls}) (void)hipFree(q);
     delete n;
+    return DD_OK;
+}
+
+int dd_net_activation_bytes(dd_net *n, int64_t *out_host) {
+    DD_REQUIRE(n && out_host, DD_E_ARG, "dd_net_activation_bytes: NULL argument");
+    if (n->arena) { *out_host = n->arena_bytes; return DD_OK; }
+    int64_t tot = 0;
+    for (size_t i = 0; i < n->bufs.size(); ++i) tot += n->buf_elems[i] * n->max_batch * (int64_t)dtype_size(n->buf_dtype[i]) + 256;
+    *out_host = tot;
     return DD_OK;
 }
 
@@ -4138,6 +4233,8 @@ int dd_net_read(dd_net *n, int tensor, int n_img, void *dst, int dst_on_device, 
     const int t = tensor < 0 ? n->out_tensor : tensor;
     DD_REQUIRE(t >= 0 && t < (int)n->tensors.size(), DD_E_ARG, "dd_net_read: tensor %d out of range", t);
     const TensorDesc &d = n->tensors[t];
+    DD_REQUIRE(!n->arena || t == n->out_tensor, DD_E_STATE, "dd_net_read: tensor %d of an engine whose buffers share memory by lifetime "
+               "(dd_net_create_shared): only the output tensor outlives the forward", t);
     DD_REQUIRE(d.coff == 0, DD_E_ARG, "dd_net_read: tensor %d is a channel slice", t);
     // A tensor whose producing op ran inside the NEXT op's launch in the last forward (conv1_1 in conv3x3_pool_rows_k<STEM>,
     // conv0 in ssd_front_k, the first layer of a residual unit, a pointwise layer in conv_ws_dw_k; batch dependent) was

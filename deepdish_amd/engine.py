@@ -9,7 +9,8 @@ from . import nets
 
 
 class Net:
-    def __init__(self, program, max_batch, context=None):
+    def __init__(self, program, max_batch, context=None, shared=False):
+        """shared=True: activation buffers overlaid by lifetime (dd_net_create_shared): only the output tensor can be read back."""
         self.ctx = context or default_context()
         self.program = program
         self.max_batch = int(max_batch)
@@ -17,8 +18,8 @@ class Net:
         self._words = words
         blob_arr = np.frombuffer(blob, dtype=np.uint8)
         h = P()
-        check(lib().dd_net_create(self.ctx.handle, ptr(words), len(words), ptr(blob_arr), len(blob),
-                                  self.max_batch, ctypes.byref(h)), 'dd_net_create')
+        create = lib().dd_net_create_shared if shared else lib().dd_net_create
+        check(create(self.ctx.handle, ptr(words), len(words), ptr(blob_arr), len(blob), self.max_batch, ctypes.byref(h)), 'dd_net_create')
         self._h = h
         t = program.tensors[program.out_tensor]
         self.out_shape = (t['h'], t['w'], t['cs'])
@@ -32,6 +33,11 @@ class Net:
                 self._h = None
         except Exception:
             pass
+
+    def activation_bytes(self):
+        v = ctypes.c_int64()
+        check(lib().dd_net_activation_bytes(self._h, ctypes.byref(v)), 'dd_net_activation_bytes')
+        return v.value
 
     def use_graph(self, enable=True):
         """Latency mode: replay each (input buffer, batch) forward as one hipGraph launch."""

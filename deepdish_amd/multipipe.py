@@ -2,6 +2,7 @@
 frame each per step, device work batched across streams.  Mirrors `pipeline.HotPath` (one stream,
 reference-shaped Python objects) but keeps the per-frame orchestration in C++."""
 import ctypes
+import os
 import numpy as np
 
 from ._lib import lib, check, P
@@ -67,10 +68,11 @@ class MultiStreamPipeline:
             n_anchors, n_classes = len(anchors), prog.meta['n_classes']
         wd = load_named_weights(encoder_model, nets.synthetic_mars_weights)
         self.enc_weights = wd
-        self.enc = Net(nets.compile_mars(wd), max_batch=encoder_max_batch or max(64, 32 * self.S), context=self.ctx)
+        # the pipeline never reads an intermediate encoder tensor: its activation buffers share memory by lifetime (6.2 -> ~2 GB at 12 288 crops)
+        self.enc = Net(nets.compile_mars(wd), max_batch=encoder_max_batch or max(64, 32 * self.S), context=self.ctx,
+                       shared=os.environ.get('DD_NET_SHARED', '1') != '0')
         # latency mode: with a handful of streams a forward is a train of 20-75 kernels of a few microseconds each;
         # replaying it as one hipGraph takes the per-launch host cost out of the frame latency (DD_GRAPH=0/1 overrides)
-        import os
         if graph is None:
             graph = self.S <= 4 if os.environ.get('DD_GRAPH') is None else os.environ['DD_GRAPH'] == '1'
         self.graph = bool(graph)

@@ -233,6 +233,14 @@ int dd_mask_box_count(dd_ctx *ctx, const uint8_t *mask, int n_streams, int heigh
  * analogue of the reference's .tflite file; the word layout is documented in csrc/nets.hip. */
 int dd_net_create(dd_ctx *ctx, const int32_t *program_host, int n_words, const void *weights_host,
                   int64_t n_weight_bytes, int max_batch, dd_net **out);
+/* The same engine with its activation buffers overlaid by lifetime (a buffer is live from its first writer to its last reader; the
+ * output tensor to the end): what a pipeline that never reads intermediate tensors wants -- the reference's interpreter keeps one
+ * arena per model too (tflite_runtime: `interpreter.allocate_tensors()`, tools/ssd_mobilenet.py:38).  f16 programs only; dd_net_read
+ * of anything but the output tensor is DD_E_STATE. */
+int dd_net_create_shared(dd_ctx *ctx, const int32_t *program_host, int n_words, const void *weights_host,
+                         int64_t n_weight_bytes, int max_batch, dd_net **out);
+/* device bytes of the engine's activation buffers (one number: the arena, or the sum of the per-tensor buffers) */
+int dd_net_activation_bytes(dd_net *net, int64_t *out_host);
 int dd_net_destroy(dd_net *net);
 /* input u8 [n][in_h][in_w][3]; results stay in the net's own device tensors (dd_net_output). */
 int dd_net_forward(dd_net *net, const uint8_t *input, int n, void *stream);

@@ -110,3 +110,22 @@ def test_yolov5s_forward_vs_oracle():
     # per element of the decoded rows (xywh normalised, objectness, class scores in (0, 1)); measured: rtol 1e-2 alone
     # covers every element but a handful near zero (atol 2.1e-6)
     _assert_close('yolov5s rows vs f32 restatement, f16-rounded weights', got, want, atol=2e-4, rtol=1e-2)
+
+
+def test_shared_activation_buffers_give_the_same_features():
+    """dd_net_create_shared (buffers overlaid by lifetime, what the pipeline's encoder uses): same bits as one buffer per tensor at every
+    launch shape the fusion rules distinguish, a third of the memory, and intermediate tensors are refused."""
+    from deepdish_amd import nets
+    from deepdish_amd.engine import Net
+    from deepdish_amd._lib import DeepDishHipError
+    wd = nets.synthetic_mars_weights(1234)
+    prog = nets.compile_mars(wd)
+    plain, shared = Net(prog, max_batch=2200), Net(prog, max_batch=2200, shared=True)
+    assert shared.activation_bytes() < 0.45 * plain.activation_bytes(), (shared.activation_bytes(), plain.activation_bytes())
+    rng = np.random.default_rng(4)
+    for n in (1, 37, 200, 600, 1100, 2200):
+        x = rng.integers(0, 256, (n, 64, 32, 3), dtype=np.uint8)
+        plain.forward(x); shared.forward(x)
+        np.testing.assert_array_equal(shared.read(), plain.read(), err_msg='%d crops' % n)
+    with pytest.raises(DeepDishHipError):
+        shared.read(tensor=prog.meta['tensors']['pool1'])
