@@ -393,6 +393,74 @@ __global__ __launch_bounds__(256) void q_dw_k(const QDwP P) {
     *reinterpret_cast<u4v *>(dst) = o;
 }
 
+// The same layer on the matrix pipe (block-diagonal product, see q_dwpw_k): one wave item = one plane of 16 channels x four 16-pixel
+// fragments, operands straight from the bordered planes in HBM / L2 (16 bytes per lane and tap group), the filter's six operand
+// registers built once per item.  32 + 55 us -> for the two 10x10 layers of the SSD backbone that q_dwpw_k's ring does not fit.
+struct QDwmP {
+    const uint8_t *in; int H, W, c16;
+    int stride, off_y, off_x, ho, wo, m;
+    const uint2 *dw_a; const int *dw_cb;
+    uint8_t *out;
+    QReq R;
+};
+
+template <bool SAT>
+__global__ __launch_bounds__(256) void q_dwm_k(const QDwmP P, const int n_items) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= n_items) return;
+    const int cg = item % P.c16, fg = item / P.c16;                 // planes fastest: the waves of a block read the same pixels' other planes
+    const size_t PP = (size_t)(P.W + 2) * 16, RP = PP * P.c16, PPo = (size_t)(P.wo + 2) * 16;
+    const uint2 ab = P.dw_a[cg * 64 + lane];
+    const i4v cbv = *reinterpret_cast<const i4v *>(P.dw_cb + cg * 16 + 4 * fq);
+    unsigned dmask[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) dmask[d] = (fr >> 2) == d ? 0xffu << (8 * (fr & 3)) : 0u;
+    const uint8_t *src[4]; uint8_t *dst[4]; bool live[4];
+    const int hw = P.ho * P.wo;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        int q = (fg * 4 + f) * 16 + fr;
+        live[f] = q < P.m;
+        q = min(q, P.m - 1);
+        const int n = q / hw, r = q - n * hw, y = r / P.wo, x = r - y * P.wo;
+        src[f] = P.in + ((size_t)n * (P.H + 2) + y * P.stride + P.off_y) * RP + (size_t)cg * PP + (size_t)(x * P.stride + P.off_x) * 16;
+        dst[f] = P.out + (((size_t)n * (P.ho + 2) + y + 1) * P.c16 + cg) * PPo + (size_t)(x + 1) * 16 + 4 * fq;
+    }
+    i4v acc[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) acc[f] = cbv;
+    i4v b[3][4];
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+        const int tp = min(4 * ks + fq, 8);
+        const size_t to = (size_t)(tp / 3) * RP + (size_t)(tp % 3) * 16;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) b[ks][f] = *reinterpret_cast<const i4v *>(src[f] + to);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+        const unsigned sel = 0x01010101u * (unsigned)ks;
+        const unsigned rh = __builtin_amdgcn_perm(ab.x, ab.x, sel), rl = __builtin_amdgcn_perm(ab.y, ab.y, sel);
+        i4v Ah, Al;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) { Ah[d] = (int)(rh & dmask[d]); Al[d] = (int)(rl & dmask[d]); }
+#pragma unroll
+        for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Ah, b[ks][f], acc[f], 0, 0, 0);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Al, b[ks][f], acc[f], 0, 0, 0);
+    }
+    const int M = P.R.M, sh = P.R.e - 1, lo = P.R.lo, hi = P.R.hi;
+    const long long C = P.R.C;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const unsigned packed = 0x80808080u ^ q_pack4<SAT>(q_requant_relu(acc[f][0], M, C, sh), q_requant_relu(acc[f][1], M, C, sh),
+                                                             q_requant_relu(acc[f][2], M, C, sh), q_requant_relu(acc[f][3], M, C, sh), lo, hi);
+        if (live[f]) *reinterpret_cast<unsigned *>(dst[f]) = packed;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ SSD decode
 // First stage of TFLite_Detection_PostProcess on the quantised head tensors (kernels/detection_postprocess.cc:
 // DequantizeBoxEncodings, DequantizeClassPredictions behind the graph's uint8 LOGISTIC): the lanes of an anchor sweep its
@@ -487,6 +555,7 @@ struct QDwpwP {
     const int *cbias;                // [COUT]
     int zwc, NR;
     unsigned rb_magic;               // floor(2^32 / row bytes) + 1
+    unsigned wo_magic, nr_magic, tpf_magic;   // the same for the output width, the ring size, the tiles per frame (exact for every value divided here)
     unsigned long long *dbg;         // DD_Q_STAMPS=1: per wave, cycles spent in each part of the tile loop (diagnostic launches only)
     QReq Rd, Rp;
 };
@@ -544,20 +613,22 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64) void q_dwpw_k(const Q
     const long long Cd = P.Rd.C, Cp = P.Rp.C;
     const int lod = P.Rd.lo, hid = P.Rd.hi, lop = P.Rp.lo, hip_ = P.Rp.hi;
 
+    // (divisions by the layer's constants as multiply-high: a hardware-less integer division is ~40 scalar or ~25 vector instructions, and
+    // a tile step had ten of them -- 320 scalar instructions per tile and wave in the 32-channel block)
     auto tile_rows = [&](int t, int &n, int &q0, int &q1, int &ga, int &gb) {
-        n = t / P.tiles_per_frame;
+        n = (int)__umulhi((unsigned)t, P.tpf_magic);
         q0 = (t - n * P.tiles_per_frame) * QT;
         q1 = min(q0 + QT, P.hw) - 1;
-        const int y0 = q0 / P.wo, y1 = q1 / P.wo;
+        const int y0 = (int)__umulhi((unsigned)q0, P.wo_magic), y1 = (int)__umulhi((unsigned)q1, P.wo_magic);
         ga = n * (P.H + 2) + y0 * STRIDE + P.off_y;
         gb = n * (P.H + 2) + y1 * STRIDE + P.off_y + 2;
     };
     auto geometry = [&](int n, int q0, int q1, int buf) {           // threads 0 .. QT - 1: where pixel tid of the tile reads and writes
         const int q = q0 + tid;
         const int qc = min(q, q1);
-        const int y = qc / P.wo, x = qc - y * P.wo;
+        const int y = (int)__umulhi((unsigned)qc, P.wo_magic), x = qc - y * P.wo;
         const int g0 = n * (P.H + 2) + y * STRIDE + P.off_y;
-        const int s0 = g0 % P.NR, s1 = s0 + 1 == P.NR ? 0 : s0 + 1, s2 = s1 + 1 == P.NR ? 0 : s1 + 1;
+        const int s0 = g0 - (int)__umulhi((unsigned)g0, P.nr_magic) * P.NR, s1 = s0 + 1 == P.NR ? 0 : s0 + 1, s2 = s1 + 1 == P.NR ? 0 : s1 + 1;
         pinfo[buf * QT + tid] = i4v{s0 * RB, s1 * RB, s2 * RB, (x * STRIDE + P.off_x) * 16};
         pixoff[buf * QT + tid] = q <= q1 ? (unsigned)(((size_t)n * (P.ho + 2) + y + 1) * P.c16_out * ((P.wo + 2) * 16) + (size_t)(x + 1) * 16) : 0xffffffffu;
     };
@@ -708,7 +779,7 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64) void q_dwpw_k(const Q
         if (!nb) return;
         unsigned tid16 = (unsigned)tid * 16u;
         asm volatile("" : "+v"(tid16));                              // keeps the (row, offset) pairs from being hoisted out of the tile loop (16 live registers: spills)
-        const int slot0 = lo % P.NR;
+        const int slot0 = lo - (int)__umulhi((unsigned)lo, P.nr_magic) * P.NR;
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
             const unsigned idx = (unsigned)(i * NT) * 16u + tid16;
@@ -851,7 +922,11 @@ int launch_q_dwpw(hipStream_t s, QDwpwP &P, int nimg, int device, bool *ok) {
     const int RB = (P.W + 2) * CIN;
     const size_t lds = (size_t)P.NR * RB + (size_t)(TEAMS ? 2 : 1) * QT * CINP + (size_t)((TEAMS ? 3 : 2) + 2) * QT * sizeof(int) + 2 * QT * 16 + COUT * sizeof(int);
     P.rb_magic = (unsigned)((1ull << 32) / (unsigned)RB) + 1u;
-    *ok = lpt <= LPT && lds <= 160 * 1024 && (long long)LPT * NT * 16 * RB < (1ll << 32) && (LPT * NT * 16) / RB + 1 <= 2 * P.NR;
+    P.wo_magic = (unsigned)((1ull << 32) / (unsigned)P.wo) + 1u;
+    P.nr_magic = (unsigned)((1ull << 32) / (unsigned)P.NR) + 1u;
+    P.tpf_magic = (unsigned)((1ull << 32) / (unsigned)P.tiles_per_frame) + 1u;
+    *ok = (long long)nimg * P.tiles_per_frame * P.tiles_per_frame < (1ll << 32) && (long long)P.hw * P.wo < (1ll << 32) &&
+          (long long)(nimg + 1) * (P.H + 2) * P.NR < (1ll << 32) && lpt <= LPT && lds <= 160 * 1024 && (long long)LPT * NT * 16 * RB < (1ll << 32) && (LPT * NT * 16) / RB + 1 <= 2 * P.NR;
     if (!*ok) return DD_OK;
     const bool rsum = P.zwc != 0;
     const bool sat = P.Rd.lo == 0 && P.Rd.hi == 255 && P.Rp.lo == 0 && P.Rp.hi == 255;       // both clamps are the byte range: saturating packs
@@ -954,8 +1029,12 @@ int netq_run_op(dd_net *net, int i, const int32_t *o, const uint8_t *input, int 
                 P.mq = std::min(4, P.n_mfrag);
             }
             const int n_mgroups = dd_ceil_div(P.n_mfrag, P.mq);
-            static const int npf_env = getenv("DD_Q_NPF") ? atoi(getenv("DD_Q_NPF")) : 2;
-            const int npf = npf_env == 4 && P.m >= 8192 ? 4 : 2;      // pixel fragments per wave item (four measured slower on every layer: more registers, fewer waves)
+            // Pixel fragments per wave item.  Two by default; four (half the weight fetches per MFMA, twice the registers) where the launch has
+            // few wave items anyway and pixels enough -- measured per layer at 384 frames: extras 48 -> 38, 63 -> 39 us, 5x5 class predictor
+            // 23 -> 16 us, but 53 -> 65, 86 -> 95, 68 -> 78 us on the layers with 19 k+ items (b12 / b13 pointwise, 19x19 class predictor).
+            const long long items2 = (long long)n_mgroups * dd_ceil_div(P.m, 32);
+            static const int npf_env = getenv("DD_Q_NPF") ? atoi(getenv("DD_Q_NPF")) : 0;
+            const int npf = npf_env ? npf_env : (items2 < 8192 && P.m >= 2048 ? 4 : 2);
             const long long n_items = (long long)n_mgroups * dd_ceil_div(P.m, 16 * npf);
             DD_REQUIRE(n_items < (1ll << 31), DD_E_CAPACITY, "dd_net_forward: uint8 conv %d: %lld wave items", i, n_items);
             const dim3 grid((unsigned)((n_items + 3) / 4));
@@ -983,6 +1062,20 @@ int netq_run_op(dd_net *net, int i, const int32_t *o, const uint8_t *input, int 
             DD_REQUIRE(P.off_y >= 0 && P.off_x >= 0 && (P.ho - 1) * P.stride + 2 + P.off_y <= P.H + 1 && (P.wo - 1) * P.stride + 2 + P.off_x <= P.W + 1 && !P.R.linear,
                        DD_E_ARG, "dd_net_forward: uint8 depthwise %d reaches outside the one-pixel border", i);
             DD_REQUIRE(P.total < (1ll << 31) * 256, DD_E_CAPACITY, "dd_net_forward: uint8 depthwise %d: too many items", i);
+            static const bool no_mfma = getenv("DD_Q_DW_VALU") && atoi(getenv("DD_Q_DW_VALU")) != 0;       // A/B switch: the vector-ALU form
+            if (o[20] && P.R.e >= 1 && !no_mfma) {                  // o[20], o[21]: the block-diagonal operand table and its constants (netsq.pack_dw_mfma)
+                QDwmP Q;
+                Q.in = P.in; Q.H = P.H; Q.W = P.W; Q.c16 = P.c16; Q.stride = P.stride; Q.off_y = P.off_y; Q.off_x = P.off_x; Q.ho = P.ho; Q.wo = P.wo;
+                Q.m = nimg * P.ho * P.wo; Q.out = P.out; Q.R = P.R;
+                Q.dw_a = reinterpret_cast<const uint2 *>(W + (size_t)(uint32_t)o[20]);
+                Q.dw_cb = reinterpret_cast<const int *>(W + (size_t)(uint32_t)o[21]);
+                const long long n_items = (long long)P.c16 * dd_ceil_div(Q.m, 64);
+                DD_REQUIRE(n_items < (1ll << 31), DD_E_CAPACITY, "dd_net_forward: uint8 depthwise %d: %lld wave items", i, n_items);
+                if (P.R.lo == 0 && P.R.hi == 255) hipLaunchKernelGGL((q_dwm_k<true>), dim3((unsigned)((n_items + 3) / 4)), dim3(256), 0, s, Q, (int)n_items);
+                else hipLaunchKernelGGL((q_dwm_k<false>), dim3((unsigned)((n_items + 3) / 4)), dim3(256), 0, s, Q, (int)n_items);
+                DD_LAUNCH_CHECK();
+                return DD_OK;
+            }
             hipLaunchKernelGGL(q_dw_k, dim3((unsigned)((P.total + 255) / 256)), dim3(256), 0, s, P);
             DD_LAUNCH_CHECK();
             return DD_OK;

@@ -174,8 +174,10 @@ def compile_ssd_mobilenet_quant(qm):
         assert s['zp'] == L['in_zp'] and L['w'].shape[2] == s['c'], name
         w16, cb = pack_dw(L)
         dst = P.qtensor(ho, wo, s['c'], L['out_zp'])
+        mf = pack_dw_mfma(L)                                    # the matrix-pipe form's operand table (None: a weight needs w - zw = 255)
         P._op(OP_QDW, src=src, dst=dst, kh=3, kw=3, stride=L['stride'], pad_t=pt, pad_l=pl, cin=s['c'], cout=s['c'], cout_pad=s['c'],
-              w_off=P.add_blob(w16), b_off=P.add_blob(cb), ho=ho, wo=wo, raw=_req_words(L))
+              w_off=P.add_blob(w16), b_off=P.add_blob(cb), ho=ho, wo=wo, raw=_req_words(L),
+              p=[P.add_blob(mf[0]), P.add_blob(mf[1])] if mf is not None else [0, 0])
         info('q_dw_k', 2 * ho * wo * 9 * s['c'], s['h'] * s['w'] * s['c'] + ho * wo * s['c'], 9 * s['c'] + 4 * s['c'])
         return dst
 
