@@ -280,12 +280,20 @@ __global__ __launch_bounds__(256) void q_conv0_k(const QConv0P P, const int n_fr
     const unsigned zp4 = (unsigned)P.in_zp * 0x01010101u;
     const int hw = P.ho * P.wo;
     unsigned w[C0F][3]; int o_[C0F]; bool rowok[C0F], live[C0F]; int pn[C0F], py[C0F], px[C0F];
+    // the lane's pixel of the first fragment by division (once), of the following ones by stepping 16 pixels along the raster
+    int qn, qy, qx;
+    {
+        const int q = min(f0 * 16 + fr, P.m - 1);
+        qn = q / hw; const int r0 = q - qn * hw; qy = r0 / P.wo; qx = r0 - qy * P.wo;
+    }
 #pragma unroll
     for (int j = 0; j < C0F; ++j) {
-        int q = (f0 + j) * 16 + fr;
+        const int q = (f0 + j) * 16 + fr;
         live[j] = q < P.m;
-        q = min(q, P.m - 1);
-        pn[j] = q / hw; const int r0 = q - pn[j] * hw; py[j] = r0 / P.wo; px[j] = r0 - py[j] * P.wo;
+        pn[j] = qn; py[j] = qy; px[j] = qx;
+        qx += 16;                                                   // (wo >= 16: at most one row step per fragment)
+        if (qx >= P.wo) { qx -= P.wo; if (++qy == P.ho) { qy = 0; ++qn; } }
+        if (!live[j]) { pn[j] = 0; py[j] = 0; px[j] = 0; }
         const int row = py[j] * P.stride + fq - P.pad_t, col = px[j] * P.stride - P.pad_l;      // first of the three source pixels of this filter row
         rowok[j] = fq < 3 && row >= 0 && row < P.H;
         const long long a = ((long long)pn[j] * P.H + (rowok[j] ? row : 0)) * P.W * 3 + (long long)col * 3;   // may be < 0 by up to 3 (col = -1): those bytes are replaced below
@@ -998,6 +1006,7 @@ int netq_run_op(dd_net *net, int i, const int32_t *o, const uint8_t *input, int 
             P.w = reinterpret_cast<const i4v *>(W + (size_t)(uint32_t)o[16]);
             P.cbias = reinterpret_cast<const int *>(W + (size_t)(uint32_t)o[17]);
             P.out = base(dst); P.in_zp = o[39]; P.zwc = o[38]; P.R = make_req(o);
+            DD_REQUIRE(td->w >= 16, DD_E_ARG, "dd_net_forward: uint8 first layer: output narrower than a fragment");
             DD_REQUIRE(td->pad == 1 && td->cs == 32 && o[11] == 32 && (reinterpret_cast<uintptr_t>(input) & 3) == 0 && (P.total_bytes & 3) == 0 && !P.R.linear && P.R.e >= 1,
                        DD_E_ARG, "dd_net_forward: uint8 first layer: 32 channels into a bordered tensor from a 4-byte aligned batch");
             const int n_frags = dd_ceil_div(P.m, 16);
