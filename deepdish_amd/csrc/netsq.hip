@@ -560,6 +560,7 @@ struct QDwpwP {
     const uint2 *dw_a;               // [CIN / 16][64 lanes]: .x bytes 0..2 = hi parts of the lane's tap in k steps 0..2, .y = lo parts
     const int *dw_cb;                // [CIN]: bias - (za - 128) * sum_t (w_t - zw)
     const i4v *w;                    // [COUT / 64][4][KC][64 lanes]
+    const i4v *w2;                   // HL: the second filter (see below), same layout
     const int *cbias;                // [COUT]
     int zwc, NR;
     unsigned rb_magic;               // floor(2^32 / row bytes) + 1
@@ -572,11 +573,15 @@ constexpr int QT = 64;               // pixels per tile
 
 // MW = 16-channel fragments of the pointwise filter per wave: 4 (64 channels, <= 128 VGPRs of filter, 256-register waves, two per SIMD) or
 // 2 (32 channels, <= 64 VGPRs, 128-register waves, four per SIMD: twice the waves to cover each other's LDS / MFMA / requantisation chains).
-template <int CIN, int COUT, int WP, int STRIDE, int LPT, bool ROWSUM, bool TEAMS, int MW = 4, bool SAT = false>
+// HL: the pointwise filter as w - zw split into hi = clamp(w - zw, -128, 127) and lo = rest, two MFMAs per fragment and k slice on one
+// accumulator instead of one MFMA plus the zwc * rowsum correction: for the layers with few input channels the matrix pipe has the time
+// (16 -> 32 MFMAs per tile in block 1) and the row-sum machinery (dot products, cross-lane sums, LDS atomics, an add per output) goes.
+template <int CIN, int COUT, int WP, int STRIDE, int LPT, bool ROWSUM, bool TEAMS, int MW = 4, bool SAT = false, bool HL = false>
 __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64) void q_dwpw_k(const QDwpwP P, const int n_tiles, const int tiles_per_block) {
     constexpr int WM = COUT / (16 * MW), NW = WM * WP, NT = NW * 64;
     constexpr int FB = MW == 4 ? 4 : 2;                               // pixel fragments the depthwise stage keeps in flight (registers)
     static_assert(MW == 4 || MW == 2, "fragments per wave");
+    static_assert(!(HL && ROWSUM), "the split filter needs no row sums");
     constexpr int KC = (CIN + 63) / 64, CINP = KC * 64, C16 = CIN / 16;
     constexpr int NOB = TEAMS ? 2 : 1, NRS = TEAMS ? 3 : 2;         // operand tiles, row-sum buffers
     static_assert(C16 % NW == 0 || NW % C16 == 0, "planes over waves");
@@ -601,6 +606,13 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64) void q_dwpw_k(const Q
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) Wr[m][kc] = P.w[((size_t)(wm * MW + m) * KC + kc) * 64 + lane];
     const int mg = (wm * MW) / 4, m0 = (wm * MW) % 4;               // the 64-channel group and the first fragment inside it
+    i4v Wl[HL ? MW : 1][HL ? KC : 1];
+    if constexpr (HL) {
+#pragma unroll
+        for (int m = 0; m < MW; ++m)
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) Wl[m][kc] = P.w2[((size_t)(wm * MW + m) * KC + kc) * 64 + lane];
+    }
     for (int i = tid; i < COUT; i += NT) cbl[i] = P.cbias[i];
     if (CIN < CINP) for (int i = tid; i < NOB * QT * CINP / 16; i += NT) reinterpret_cast<u4v *>(opnd)[i] = u4v{0, 0, 0, 0};   // k slots without channels
     for (int i = tid; i < NRS * QT; i += NT) rowsum[i] = 0;
@@ -748,7 +760,10 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64) void q_dwpw_k(const Q
 #pragma unroll
                 for (int kc = 0; kc < KB; ++kc)
 #pragma unroll
-                    for (int m = 0; m < MW; ++m) acc[m] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Wr[m][k0 + kc], b[kc], acc[m], 0, 0, 0);
+                    for (int m = 0; m < MW; ++m) {
+                        acc[m] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Wr[m][k0 + kc], b[kc], acc[m], 0, 0, 0);
+                        if constexpr (HL) acc[m] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Wl[m][k0 + kc], b[kc], acc[m], 0, 0, 0);
+                    }
                 if (k0 + KB < KC) {
 #pragma unroll
                     for (int kc = 0; kc < KB; ++kc) b[kc] = *reinterpret_cast<const i4v *>(bp + (size_t)(k0 + KB + kc) * 4 * QT * 16);
@@ -936,20 +951,23 @@ int launch_q_dwpw(hipStream_t s, QDwpwP &P, int nimg, int device, bool *ok) {
     *ok = (long long)nimg * P.tiles_per_frame * P.tiles_per_frame < (1ll << 32) && (long long)P.hw * P.wo < (1ll << 32) &&
           (long long)(nimg + 1) * (P.H + 2) * P.NR < (1ll << 32) && lpt <= LPT && lds <= 160 * 1024 && (long long)LPT * NT * 16 * RB < (1ll << 32) && (LPT * NT * 16) / RB + 1 <= 2 * P.NR;
     if (!*ok) return DD_OK;
-    const bool rsum = P.zwc != 0;
+    const bool hl = P.w2 != nullptr;                                  // the compiler packed a split filter (small CIN): no row sums
+    const bool rsum = P.zwc != 0 && !hl;
     const bool sat = P.Rd.lo == 0 && P.Rd.hi == 255 && P.Rp.lo == 0 && P.Rp.hi == 255;       // both clamps are the byte range: saturating packs
-    auto kfn = [&]() -> const void * {
-        if (rsum) return sat ? reinterpret_cast<const void *>(&q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, true, TEAMS, MW, true>) : reinterpret_cast<const void *>(&q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, true, TEAMS, MW, false>);
-        return sat ? reinterpret_cast<const void *>(&q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, false, TEAMS, MW, true>) : reinterpret_cast<const void *>(&q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, false, TEAMS, MW, false>);
-    };
+#define DD_QK(R_, S_, H_) q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, R_, TEAMS, MW, S_, H_>
+    void (*kern)(const QDwpwP, const int, const int) =
+        hl ? (sat ? &DD_QK(false, true, true) : &DD_QK(false, false, true))
+           : rsum ? (sat ? &DD_QK(true, true, false) : &DD_QK(true, false, false)) : (sat ? &DD_QK(false, true, false) : &DD_QK(false, false, false));
+    auto kfn = [&]() -> const void * { return reinterpret_cast<const void *>(kern); };
     static DevOnce once;
     const int rc = once.run(device, [&]() -> int {
-        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, true, TEAMS, MW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, true, TEAMS, MW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, false, TEAMS, MW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, false, TEAMS, MW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        for (const void *f : {reinterpret_cast<const void *>(&DD_QK(false, true, true)), reinterpret_cast<const void *>(&DD_QK(false, false, true)),
+                              reinterpret_cast<const void *>(&DD_QK(true, true, false)), reinterpret_cast<const void *>(&DD_QK(true, false, false)),
+                              reinterpret_cast<const void *>(&DD_QK(false, true, false)), reinterpret_cast<const void *>(&DD_QK(false, false, false))})
+            DD_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         return DD_OK;
     });
+#undef DD_QK
     if (rc != DD_OK) return rc;
     static std::atomic<int> per_cu_cache[64];
     int per_cu = per_cu_cache[device & 63].load(std::memory_order_relaxed);
@@ -966,10 +984,7 @@ int launch_q_dwpw(hipStream_t s, QDwpwP &P, int nimg, int device, bool *ok) {
     static const bool stamps = getenv("DD_Q_STAMPS") && atoi(getenv("DD_Q_STAMPS")) != 0;
     const size_t n_st = (size_t)grid.x * NW * 8;
     if (stamps) { DD_HIP(hipMalloc(&P.dbg, n_st * 8)); DD_HIP(hipMemsetAsync(P.dbg, 0, n_st * 8, s)); }
-    if (rsum && sat) hipLaunchKernelGGL((q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, true, TEAMS, MW, true>), grid, dim3(NT), lds, s, P, n_tiles, tpb);
-    else if (rsum) hipLaunchKernelGGL((q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, true, TEAMS, MW, false>), grid, dim3(NT), lds, s, P, n_tiles, tpb);
-    else if (sat) hipLaunchKernelGGL((q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, false, TEAMS, MW, true>), grid, dim3(NT), lds, s, P, n_tiles, tpb);
-    else hipLaunchKernelGGL((q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, false, TEAMS, MW, false>), grid, dim3(NT), lds, s, P, n_tiles, tpb);
+    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, P, n_tiles, tpb);
     DD_LAUNCH_CHECK();
     if (stamps) {                                                   // diagnostic: where the waves of this launch spent their cycles
         std::vector<unsigned long long> h(n_st);
@@ -1100,6 +1115,7 @@ int netq_run_op(dd_net *net, int i, const int32_t *o, const uint8_t *input, int 
             P.dw_a = reinterpret_cast<const uint2 *>(W + (size_t)(uint32_t)o[20]);
             P.dw_cb = reinterpret_cast<const int *>(W + (size_t)(uint32_t)o[21]);
             P.w = reinterpret_cast<const i4v *>(W + (size_t)(uint32_t)o[16]);
+            P.w2 = o[18] ? reinterpret_cast<const i4v *>(W + (size_t)(uint32_t)o[18]) : nullptr;       // o[18]: the lo part of a split pointwise filter
             P.cbias = reinterpret_cast<const int *>(W + (size_t)(uint32_t)o[17]);
             P.zwc = o[38]; P.Rp = make_req(o);
             { int32_t d[48] = {0}; d[32] = o[22]; d[33] = o[23]; d[36] = o[24]; d[37] = o[25]; d[40] = o[28]; P.Rd = make_req(d); }
