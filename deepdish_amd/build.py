@@ -22,6 +22,11 @@ COMMON = ['--offload-arch=' + ARCH, '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno
 STRICT_FP = {'kalman.hip', 'cost.hip', 'nms.hip', 'tracker.hip', 'lsap.cpp', 'pyset.cpp', 'api.hip', 'image.hip', 'pipeline.hip', 'mog2.hip', 'post.hip'}
 
 
+# Per-file code generation flags.  netsq.hip: MFMA results in ordinary VGPRs -- its kernels are bound by vector-instruction issue and every
+# accumulator parked in an AGPR costs a v_accvgpr_read before the requantisation (3144 of them in the file's kernels without the flag).
+EXTRA = {'netsq.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form']} if os.environ.get('DD_NO_VGPR_FORM') != '1' else {}
+
+
 def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(('.hip', '.cpp')))
 
@@ -36,9 +41,9 @@ def _compile(src, force, hmt):
     obj = os.path.join(OBJ, src + '.o')
     path = os.path.join(CSRC, src)
     if (not force and os.path.exists(obj)
-            and os.path.getmtime(obj) >= max(os.path.getmtime(path), hmt)):
+            and os.path.getmtime(obj) >= max(os.path.getmtime(path), hmt, os.path.getmtime(__file__))):
         return obj, False
-    cmd = [HIPCC] + COMMON + (['-ffp-contract=off'] if src in STRICT_FP else []) + ['-x', 'hip', '-c', path, '-o', obj]
+    cmd = [HIPCC] + COMMON + (['-ffp-contract=off'] if src in STRICT_FP else []) + EXTRA.get(src, []) + ['-x', 'hip', '-c', path, '-o', obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError('hipcc failed for %s:\n%s\n%s' % (src, r.stdout, r.stderr))

@@ -44,7 +44,6 @@ typedef const __attribute__((address_space(4))) int cint;      // read-only data
 
 enum { OP_QCONV0 = 16, OP_QCONV = 17, OP_QDW = 18, OP_QDWPW = 19, OP_QSSD_DECODE = 20 };
 enum { QEPI_Q16 = 0, QEPI_ROWS = 1 };
-constexpr int OP_WORDS = 48;
 
 struct QReq {            // requantisation of one layer (per-tensor parameters)
     int M;               // quantized multiplier, [2^30, 2^31)
@@ -79,7 +78,7 @@ __device__ __forceinline__ int q_clamp(int z, int lo, int hi) {                 
 }
 
 // Four requantised values -> four bytes.  SAT (the layer's clamp is the whole byte range, as ReLU6 at scale 6/255 makes it): saturating
-// packs do clamp and pack in 5 instructions (v_cvt_pk_i16_i32 x2, v_sat_pk_u8_i16 x2, v_lshl_or_b32) instead of 4 v_med3 + 3 v_lshl_or.
+// packs do clamp and pack in 5 instructions (v_cvt_pk_i16_i32 x2, v_sat_pk_u8_i16 x2, v_perm_b32) instead of 4 v_med3 + 3 v_lshl_or.
 template <bool SAT>
 __device__ __forceinline__ unsigned q_pack4(int z0, int z1, int z2, int z3, int lo, int hi) {
     if constexpr (SAT) {
@@ -88,7 +87,7 @@ __device__ __forceinline__ unsigned q_pack4(int z0, int z1, int z2, int z3, int 
         asm("v_cvt_pk_i16_i32 %0, %1, %2" : "=v"(p23) : "v"(z2), "v"(z3));
         asm("v_sat_pk_u8_i16 %0, %1" : "=v"(q01) : "v"(p01));
         asm("v_sat_pk_u8_i16 %0, %1" : "=v"(q23) : "v"(p23));
-        return (q23 << 16) | (q01 & 0xffffu);
+        return __builtin_amdgcn_perm(q23, q01, 0x05040100u);                  // bytes 0, 1 of each
     } else {
         return (unsigned)q_clamp(z0, lo, hi) | (unsigned)q_clamp(z1, lo, hi) << 8 | (unsigned)q_clamp(z2, lo, hi) << 16 | (unsigned)q_clamp(z3, lo, hi) << 24;
     }
@@ -558,45 +557,49 @@ struct QDwpwP {
     int off_y, off_x, ho, wo, hw, tiles_per_frame;
     uint8_t *out; int c16_out;
     const uint2 *dw_a;               // [CIN / 16][64 lanes]: .x bytes 0..2 = hi parts of the lane's tap in k steps 0..2, .y = lo parts
-    const int *dw_cb;                // [CIN]: bias - (za - 128) * sum_t (w_t - zw)
+    const long long *dw_cq;          // [CIN]: (bias - (za - 128) * sum_t (w_t - zw)) * M + C: the depthwise requantisation's 64-bit addend per channel
     const i4v *w;                    // [COUT / 64][4][KC][64 lanes]
     const i4v *w2;                   // HL: the second filter (see below), same layout
     const int *cbias;                // [COUT]
+    const long long *cq;             // [COUT]: cbias * M + C (the pointwise requantisation's addend per channel; used when no row sums are)
     int zwc, NR;
-    unsigned rb_magic;               // floor(2^32 / row bytes) + 1
-    unsigned wo_magic, nr_magic, tpf_magic;   // the same for the output width, the ring size, the tiles per frame (exact for every value divided here)
+    unsigned wo_magic, nr_magic, tpf_magic;   // floor(2^32 / d) + 1 for the output width, the ring size, the tiles per frame (exact for every value divided here)
     unsigned long long *dbg;         // DD_Q_STAMPS=1: per wave, cycles spent in each part of the tile loop (diagnostic launches only)
     QReq Rd, Rp;
 };
 
 constexpr int QT = 64;               // pixels per tile
 
+// The tile loop is bound by vector-instruction issue (423 vector instructions per wave and tile in the 32-channel block against 28 MFMAs:
+// scripts/experiments/isa_mix.py), so everything that does not depend on the tile stays in registers where they are to be had:
+//   * per-channel requantisation addends (bias * M + C, 64 bits, computed by the host): accumulators start at zero (free: the first MFMA
+//     takes the literal) and v_mad_i64_i32 adds the channel's constant -- no accumulator initialisation, no bias add;
+//   * KEEP (<= 2 planes per wave): the depthwise A operands, built once per launch instead of per plane and tile (30 instructions each);
+//   * FOLDP (no row sums, K <= 256): the pointwise addends, 32 registers.
 // MW = 16-channel fragments of the pointwise filter per wave: 4 (64 channels, <= 128 VGPRs of filter, 256-register waves, two per SIMD) or
-// 2 (32 channels, <= 64 VGPRs, 128-register waves, four per SIMD: twice the waves to cover each other's LDS / MFMA / requantisation chains).
+// 2 (32 channels, 128-register waves, four per SIMD -- measured slower, 131 vs 89 us on the 512-channel block: issue-bound, not latency-bound).
 // HL: the pointwise filter as w - zw split into hi = clamp(w - zw, -128, 127) and lo = rest, two MFMAs per fragment and k slice on one
 // accumulator instead of one MFMA plus the zwc * rowsum correction: for the layers with few input channels the matrix pipe has the time
-// (16 -> 32 MFMAs per tile in block 1) and the row-sum machinery (dot products, cross-lane sums, LDS atomics, an add per output) goes.
-template <int CIN, int COUT, int WP, int STRIDE, int LPT, bool ROWSUM, bool TEAMS, int MW = 4, bool SAT = false, bool HL = false>
-__global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64) void q_dwpw_k(const QDwpwP P, const int n_tiles, const int tiles_per_block) {
+// and the row-sum machinery (dot products, cross-lane sums, LDS atomics, an add per output) goes.
+template <int CIN, int COUT, int WP, int STRIDE, int LPT, bool ROWSUM, int MW = 4, bool SAT = false, bool HL = false>
+__global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64, 2) void q_dwpw_k(const QDwpwP P, const int n_tiles, const int tiles_per_block) {
     constexpr int WM = COUT / (16 * MW), NW = WM * WP, NT = NW * 64;
-    constexpr int FB = MW == 4 ? 4 : 2;                               // pixel fragments the depthwise stage keeps in flight (registers)
     static_assert(MW == 4 || MW == 2, "fragments per wave");
     static_assert(!(HL && ROWSUM), "the split filter needs no row sums");
     constexpr int KC = (CIN + 63) / 64, CINP = KC * 64, C16 = CIN / 16;
-    constexpr int NOB = TEAMS ? 2 : 1, NRS = TEAMS ? 3 : 2;         // operand tiles, row-sum buffers
-    static_assert(C16 % NW == 0 || NW % C16 == 0, "planes over waves");
-    static_assert(!TEAMS || (NW % 2 == 0 && C16 % NW == 0), "teams: every wave owns whole planes");
+    static_assert(C16 % NW == 0, "planes over waves");
+    constexpr int CPW = C16 / NW;                                     // depthwise planes per wave
+    constexpr bool KEEP = CPW <= 2, FOLDP = !ROWSUM && KC <= 4;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (the wave number in a scalar register)
     const int fr = lane & 15, fq = lane >> 4;
     const int wm = wave / WP, wp = wave % WP;
     const int RB = (P.W + 2) * CIN, PP = (P.W + 2) * 16;           // ring row / plane pitch (bytes)
-    uint8_t *ring = smem;
-    uint8_t *opnd = smem + (size_t)P.NR * RB;                       // [NOB][CINP / 16][QT][16]
-    int *rowsum = reinterpret_cast<int *>(opnd + NOB * QT * CINP);  // [NRS][QT]
-    unsigned *pixoff = reinterpret_cast<unsigned *>(rowsum + NRS * QT);   // [2][QT]
-    i4v *pinfo = reinterpret_cast<i4v *>(pixoff + 2 * QT);          // [2][QT]: ring offsets of the pixel's three window rows, column offset
-    int *cbl = reinterpret_cast<int *>(pinfo + 2 * QT);             // [COUT]: the pointwise layer's per-channel constants
+    uint8_t *opnd = smem;                                           // [CINP / 16][QT][16]
+    int *rowsum = reinterpret_cast<int *>(opnd + QT * CINP);        // [2][QT]
+    i4v *pinfo = reinterpret_cast<i4v *>(rowsum + 2 * QT);          // [2][QT]: ring offsets of the pixel's window (rows 0..2, first column), offset of its output
+    int *cbl = reinterpret_cast<int *>(pinfo + 2 * QT);             // [COUT]: the pointwise layer's per-channel constants (!FOLDP)
+    uint8_t *ring = reinterpret_cast<uint8_t *>(cbl + COUT);        // [NR][RB], last (>= 4 KB of other data below it: see pf_issue)
 
     // the wave's pointwise filter, once
     // wave wm's fragments: MW consecutive ones of the host's 4-fragment groups (fragment 4 mg + m holds channels 64 mg + 16 g + 4 m + r)
@@ -613,25 +616,53 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64) void q_dwpw_k(const Q
 #pragma unroll
             for (int kc = 0; kc < KC; ++kc) Wl[m][kc] = P.w2[((size_t)(wm * MW + m) * KC + kc) * 64 + lane];
     }
-    for (int i = tid; i < COUT; i += NT) cbl[i] = P.cbias[i];
-    if (CIN < CINP) for (int i = tid; i < NOB * QT * CINP / 16; i += NT) reinterpret_cast<u4v *>(opnd)[i] = u4v{0, 0, 0, 0};   // k slots without channels
-    for (int i = tid; i < NRS * QT; i += NT) rowsum[i] = 0;
-    // depthwise lane constants: which byte of the 16 is this lane's diagonal element; which window row / column its tap of k step ks is
+    long long CP[FOLDP ? MW : 1][4];
+    if constexpr (FOLDP) {
+#pragma unroll
+        for (int m = 0; m < MW; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) CP[m][r] = P.cq[64 * mg + 16 * fq + 4 * (m0 + m) + r];
+    } else {
+        for (int i = tid; i < COUT; i += NT) cbl[i] = P.cbias[i];
+    }
+    if (CIN < CINP) for (int i = tid; i < QT * CINP / 16; i += NT) reinterpret_cast<u4v *>(opnd)[i] = u4v{0, 0, 0, 0};   // k slots without channels
+    for (int i = tid; i < 2 * QT; i += NT) rowsum[i] = 0;
+    // depthwise lane constants: which byte of the 16 is this lane's diagonal element; which window column its tap of k step ks is
+    // (k step 0: taps 0..3 = row 0 columns 0..2, row 1 column 0; step 1: taps 4..7 = row 1 columns 1, 2, row 2 columns 0, 1; step 2: tap 8 =
+    // row 2 column 2, and the k slots past it carry zero weights: any valid address will do)
     unsigned dmask[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d) dmask[d] = (fr >> 2) == d ? 0xffu << (8 * (fr & 3)) : 0u;
-    int tap_row[3], tap_dx[3];
+    int tap_dx[3];
 #pragma unroll
-    for (int ks = 0; ks < 3; ++ks) {
-        const int tp = min(4 * ks + fq, 8);                         // k slots past the ninth tap carry zero weights: any valid address will do
-        tap_row[ks] = tp / 3; tap_dx[ks] = (tp % 3) * 16;
+    for (int ks = 0; ks < 3; ++ks) tap_dx[ks] = (min(4 * ks + fq, 8) % 3) * 16;
+    const bool row_up0 = fq == 3, row_up1 = fq >= 2;                // the lane's tap of k step 0 / 1 lies in the later of the step's two rows
+    auto build_a = [&](int cg, i4v (&Ah)[3], i4v (&Al)[3], long long (&Cq)[4]) {
+        const uint2 ab = P.dw_a[cg * 64 + lane];
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            const unsigned sel = 0x01010101u * (unsigned)ks;
+            const unsigned rh = __builtin_amdgcn_perm(ab.x, ab.x, sel), rl = __builtin_amdgcn_perm(ab.y, ab.y, sel);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) { Ah[ks][d] = (int)(rh & dmask[d]); Al[ks][d] = (int)(rl & dmask[d]); }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Cq[r] = P.dw_cq[cg * 16 + 4 * fq + r];
+    };
+    i4v KAh[KEEP ? CPW : 1][3], KAl[KEEP ? CPW : 1][3];
+    long long KCq[KEEP ? CPW : 1][4];
+    if constexpr (KEEP) {
+#pragma unroll
+        for (int ci = 0; ci < CPW; ++ci) build_a(wave * CPW + ci, KAh[ci], KAl[ci], KCq[ci]);
     }
 
     const int t_begin = blockIdx.x * tiles_per_block, t_end = min(n_tiles, t_begin + tiles_per_block);
     if (t_begin >= t_end) return;
     const int Md = P.Rd.M, shd = P.Rd.e - 1, Mp = P.Rp.M, shp = P.Rp.e - 1;
-    const long long Cd = P.Rd.C, Cp = P.Rp.C;
+    const long long Cp = P.Rp.C;
     const int lod = P.Rd.lo, hid = P.Rd.hi, lop = P.Rp.lo, hip_ = P.Rp.hi;
+    const int out_row = P.c16_out * ((P.wo + 2) * 16);               // bytes of one bordered output row (all planes)
+    const unsigned ring_bytes = (unsigned)P.NR * (unsigned)RB;
 
     // (divisions by the layer's constants as multiply-high: a hardware-less integer division is ~40 scalar or ~25 vector instructions, and
     // a tile step had ten of them -- 320 scalar instructions per tile and wave in the 32-channel block)
@@ -643,14 +674,20 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64) void q_dwpw_k(const Q
         ga = n * (P.H + 2) + y0 * STRIDE + P.off_y;
         gb = n * (P.H + 2) + y1 * STRIDE + P.off_y + 2;
     };
-    auto geometry = [&](int n, int q0, int q1, int buf) {           // threads 0 .. QT - 1: where pixel tid of the tile reads and writes
+    // threads 0 .. QT - 1: where pixel tid of the tile reads and writes.  One wave's work on every tile's critical path: the row's ring slot
+    // from the tile's first (a scalar division) plus the rows in between, 24-bit multiplies (the host checked the ranges).
+    auto geometry = [&](int n, int q0, int q1, int ga, int buf) {
         const int q = q0 + tid;
         const int qc = min(q, q1);
-        const int y = (int)__umulhi((unsigned)qc, P.wo_magic), x = qc - y * P.wo;
-        const int g0 = n * (P.H + 2) + y * STRIDE + P.off_y;
-        const int s0 = g0 - (int)__umulhi((unsigned)g0, P.nr_magic) * P.NR, s1 = s0 + 1 == P.NR ? 0 : s0 + 1, s2 = s1 + 1 == P.NR ? 0 : s1 + 1;
-        pinfo[buf * QT + tid] = i4v{s0 * RB, s1 * RB, s2 * RB, (x * STRIDE + P.off_x) * 16};
-        pixoff[buf * QT + tid] = q <= q1 ? (unsigned)(((size_t)n * (P.ho + 2) + y + 1) * P.c16_out * ((P.wo + 2) * 16) + (size_t)(x + 1) * 16) : 0xffffffffu;
+        const int y = (int)__umulhi((unsigned)qc, P.wo_magic), x = qc - __mul24(y, P.wo);
+        const int y0 = (int)__umulhi((unsigned)q0, P.wo_magic);
+        const int sa = ga - (int)__umulhi((unsigned)ga, P.nr_magic) * P.NR;
+        int s0 = sa + (y - y0) * STRIDE;
+        s0 = s0 >= P.NR ? s0 - P.NR : s0;
+        const int s1 = s0 + 1 == P.NR ? 0 : s0 + 1, s2 = s1 + 1 == P.NR ? 0 : s1 + 1;
+        const int col = (x * STRIDE + P.off_x) * 16;
+        const unsigned po = q <= q1 ? (unsigned)__mul24(n * (P.ho + 2) + y + 1, out_row) + (unsigned)(x + 1) * 16u : 0xffffffffu;
+        pinfo[buf * QT + tid] = i4v{__mul24(s0, RB) + col, __mul24(s1, RB) + col, __mul24(s2, RB) + col, (int)po};
     };
     auto load_rows_sync = [&](int lo, int hi) {                     // whole rows [lo, hi] into the ring (start of the block's range only)
         if (hi < lo) return;
@@ -661,71 +698,69 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64) void q_dwpw_k(const Q
             *reinterpret_cast<u4v *>(ring + (size_t)((lo + row) % P.NR) * RB + off) = *reinterpret_cast<const u4v *>(src + idx);
         }
     };
-    // ---- depthwise stage: planes [cg0, cg0 + n_cg) x the four pixel fragments of the tile whose geometry is in buffer gbuf
-    auto dw_planes = [&](int cg0, int n_cg, int gbuf, int obuf, int rsb) {
+    // ---- depthwise stage: this wave's planes x the four pixel fragments of the tile whose geometry is in buffer gbuf
+    auto dw_planes = [&](int gbuf, int rsb) {
         int rs[4] = {0, 0, 0, 0};
-        uint8_t *ob = opnd + (size_t)obuf * QT * CINP;
-        int tapoff_all[3][4];                                        // (all four fragments in flight: once per tile, not once per plane)
-        if constexpr (FB == 4) {
+        int tapoff[3][4];                                            // ring offset of this lane's tap of k step ks at its pixel of fragment f (plane 0)
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                const i4v pi = pinfo[gbuf * QT + 16 * f + fr];
-#pragma unroll
-                for (int ks = 0; ks < 3; ++ks) tapoff_all[ks][f] = (tap_row[ks] == 0 ? pi[0] : tap_row[ks] == 1 ? pi[1] : pi[2]) + pi[3] + tap_dx[ks];
-            }
+        for (int f = 0; f < 4; ++f) {
+            const i4v pi = pinfo[gbuf * QT + 16 * f + fr];
+            tapoff[0][f] = (row_up0 ? pi[1] : pi[0]) + tap_dx[0];
+            tapoff[1][f] = (row_up1 ? pi[2] : pi[1]) + tap_dx[1];
+            tapoff[2][f] = pi[2] + tap_dx[2];
         }
-        for (int ci = 0; ci < n_cg; ++ci) {
-            const int cg = cg0 + ci;
-            const uint2 ab = P.dw_a[cg * 64 + lane];
-            const i4v cbv = *reinterpret_cast<const i4v *>(P.dw_cb + cg * 16 + 4 * fq);
+        auto plane = [&](int cg, int ci) {                           // (ci: a literal after unrolling when KEEP)
             const int pofs = cg * PP;
+            uint2 ab = make_uint2(0u, 0u);
+            if constexpr (!KEEP) ab = P.dw_a[cg * 64 + lane];
+            i4v acc[4];
 #pragma unroll
-            for (int f0 = 0; f0 < 4; f0 += FB) {
-                int tapoff[3][FB];                                   // ring offset of this lane's tap of k step ks at its pixel of fragment f0 + f (plane 0)
+            for (int f = 0; f < 4; ++f) acc[f] = i4v{0, 0, 0, 0};
+            i4v b[2][4];
 #pragma unroll
-                for (int f = 0; f < FB; ++f) {
-                    if constexpr (FB == 4) {
+            for (int f = 0; f < 4; ++f) b[0][f] = *reinterpret_cast<const i4v *>(ring + tapoff[0][f] + pofs);
 #pragma unroll
-                        for (int ks = 0; ks < 3; ++ks) tapoff[ks][f] = tapoff_all[ks][f];
-                    } else {
-                        const i4v pi = pinfo[gbuf * QT + 16 * (f0 + f) + fr];
-#pragma unroll
-                        for (int ks = 0; ks < 3; ++ks) tapoff[ks][f] = (tap_row[ks] == 0 ? pi[0] : tap_row[ks] == 1 ? pi[1] : pi[2]) + pi[3] + tap_dx[ks];
-                    }
-                }
-                i4v acc[FB];
-#pragma unroll
-                for (int f = 0; f < FB; ++f) acc[f] = cbv;
-                i4v b[2][FB];
-#pragma unroll
-                for (int f = 0; f < FB; ++f) b[0][f] = *reinterpret_cast<const i4v *>(ring + tapoff[0][f] + pofs);
-#pragma unroll
-                for (int ks = 0; ks < 3; ++ks) {
+            for (int ks = 0; ks < 3; ++ks) {
+                i4v Ah, Al;
+                if constexpr (KEEP) { Ah = KAh[ci][ks]; Al = KAl[ci][ks]; }
+                else {
                     const unsigned sel = 0x01010101u * (unsigned)ks;
                     const unsigned rh = __builtin_amdgcn_perm(ab.x, ab.x, sel), rl = __builtin_amdgcn_perm(ab.y, ab.y, sel);
-                    i4v Ah, Al;
 #pragma unroll
                     for (int d = 0; d < 4; ++d) { Ah[d] = (int)(rh & dmask[d]); Al[d] = (int)(rl & dmask[d]); }
-                    if (ks < 2) {                                    // the next k step's operands are on their way while this one multiplies
+                }
+                if (ks < 2) {                                        // the next k step's operands are on their way while this one multiplies
 #pragma unroll
-                        for (int f = 0; f < FB; ++f) b[(ks + 1) & 1][f] = *reinterpret_cast<const i4v *>(ring + tapoff[ks + 1][f] + pofs);
-                    }
-#pragma unroll
-                    for (int f = 0; f < FB; ++f) acc[f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Ah, b[ks & 1][f], acc[f], 0, 0, 0);
-#pragma unroll
-                    for (int f = 0; f < FB; ++f) acc[f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Al, b[ks & 1][f], acc[f], 0, 0, 0);
+                    for (int f = 0; f < 4; ++f) b[(ks + 1) & 1][f] = *reinterpret_cast<const i4v *>(ring + tapoff[ks + 1][f] + pofs);
                 }
 #pragma unroll
-                for (int f = 0; f < FB; ++f) {
-                    unsigned packed = q_pack4<SAT>(q_requant_relu(acc[f][0], Md, Cd, shd), q_requant_relu(acc[f][1], Md, Cd, shd),
-                                                   q_requant_relu(acc[f][2], Md, Cd, shd), q_requant_relu(acc[f][3], Md, Cd, shd), lod, hid);
-                    packed ^= 0x80808080u;
-                    if (ROWSUM) rs[f0 + f] = sdot4((int)packed, 0x01010101, rs[f0 + f]);
-                    *reinterpret_cast<unsigned *>(ob + ((size_t)cg * QT + 16 * (f0 + f) + fr) * 16 + 4 * fq) = packed;
-                }
+                for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Ah, b[ks & 1][f], acc[f], 0, 0, 0);
+#pragma unroll
+                for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Al, b[ks & 1][f], acc[f], 0, 0, 0);
             }
+            long long Cq[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if constexpr (KEEP) Cq[r] = KCq[ci][r];
+                else Cq[r] = P.dw_cq[cg * 16 + 4 * fq + r];
+            }
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                unsigned packed = q_pack4<SAT>(q_requant_relu(acc[f][0], Md, Cq[0], shd), q_requant_relu(acc[f][1], Md, Cq[1], shd),
+                                               q_requant_relu(acc[f][2], Md, Cq[2], shd), q_requant_relu(acc[f][3], Md, Cq[3], shd), lod, hid);
+                packed ^= 0x80808080u;
+                if (ROWSUM) rs[f] = sdot4((int)packed, 0x01010101, rs[f]);
+                *reinterpret_cast<unsigned *>(opnd + ((size_t)cg * QT + 16 * f + fr) * 16 + 4 * fq) = packed;
+            }
+        };
+        if constexpr (KEEP) {
+#pragma unroll
+            for (int ci = 0; ci < CPW; ++ci) plane(wave * CPW + ci, ci);
+        } else {
+#pragma unroll 1
+            for (int ci = 0; ci < CPW; ++ci) plane(wave * CPW + ci, ci);
         }
-        if (ROWSUM && n_cg > 0) {
+        if (ROWSUM) {
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
                 int v = rs[f];
@@ -735,9 +770,38 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64) void q_dwpw_k(const Q
             }
         }
     };
+    // The rows the next tile adds go from HBM straight into the ring (LDS-DMA, global_load_lds_dwordx4: no registers -- a register-staged
+    // prefetch held 32 per lane through the matrix stage and pushed the 512-channel block into scratch, where one reload after the requests
+    // waits for all of them -- no ds_write pass, no per-lane ring addresses).  Rows lo .. lie one after the other in HBM and, but for the wrap,
+    // in the ring (slot = row % NR, pitch RB): byte idx of the request goes to ring byte (slot(lo) * RB + idx) mod ring size.  One
+    // wave-instruction moves 1 KB lane-linearly to a wave-uniform LDS base; a piece that straddles the end of the ring is issued twice with
+    // complementary lane masks (the second base lies below the ring: the operand tile is there, the addresses the active lanes form are not).
+    auto pf_issue = [&](int lo, unsigned nb) {
+        if (!nb) return;
+        const uint8_t *src = P.in + (size_t)lo * RB;
+        const unsigned base = (unsigned)(lo - (int)__umulhi((unsigned)lo, P.nr_magic) * P.NR) * (unsigned)RB;
+        typedef const __attribute__((address_space(1))) void *gptr_t;
+        typedef __attribute__((address_space(3))) void *lptr_t;
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const unsigned cb = (unsigned)(i * NW + wave) * 1024u;  // (wave-uniform) this wave's piece of the request
+            if (cb < nb) {
+                unsigned a = base + cb;
+                a = a >= ring_bytes ? a - ring_bytes : a;
+                const unsigned idx = cb + (unsigned)lane * 16u;
+                const uint8_t *g = src + idx;
+                if (a + 1024u <= ring_bytes) {
+                    if (idx < nb) __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(ring + a), 16, 0, 0);
+                } else {
+                    const bool first = a + (unsigned)lane * 16u < ring_bytes;
+                    if (idx < nb && first) __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(ring + a), 16, 0, 0);
+                    if (idx < nb && !first) __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(ring + (int)(a - ring_bytes)), 16, 0, 0);
+                }
+            }
+        }
+    };
     // ---- pointwise stage of this wave's channels / fragments
-    auto matrix = [&](int q0, int q1, int gbuf, int obuf, int rsb) {
-        const uint8_t *ob = opnd + (size_t)obuf * QT * CINP;
+    auto matrix = [&](int q0, int q1, int gbuf, int rsb) {
         const int nf = (q1 - q0) / 16 + 1;
         // A lone ds_read -> s_waitcnt -> 4 MFMAs per K slice leaves the matrix pipe idle for the LDS latency eight times per fragment
         // (2.2 k cycles per fragment measured, 0.5 k of MFMA): all K slices of a fragment are requested before its first MFMA, and the
@@ -746,15 +810,18 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64) void q_dwpw_k(const Q
                                                                         // registers then spill, and a spilled HBM load is waited for on the spot)
         i4v b[KB];
         if (wp < nf) {
-            const uint8_t *bp = ob + ((size_t)fq * QT + 16 * wp + fr) * 16;
+            const uint8_t *bp = opnd + ((size_t)fq * QT + 16 * wp + fr) * 16;
 #pragma unroll
             for (int kc = 0; kc < KB; ++kc) b[kc] = *reinterpret_cast<const i4v *>(bp + (size_t)kc * 4 * QT * 16);
         }
         for (int f = wp; f < nf; f += WP) {
             i4v acc[MW];
 #pragma unroll
-            for (int m = 0; m < MW; ++m) acc[m] = *reinterpret_cast<const i4v *>(cbl + 64 * mg + 16 * fq + 4 * (m0 + m));
-            const uint8_t *bp = ob + ((size_t)fq * QT + 16 * f + fr) * 16;
+            for (int m = 0; m < MW; ++m) {
+                if constexpr (FOLDP) acc[m] = i4v{0, 0, 0, 0};
+                else acc[m] = *reinterpret_cast<const i4v *>(cbl + 64 * mg + 16 * fq + 4 * (m0 + m));
+            }
+            const uint8_t *bp = opnd + ((size_t)fq * QT + 16 * f + fr) * 16;
 #pragma unroll
             for (int k0 = 0; k0 < KC; k0 += KB) {
 #pragma unroll
@@ -770,17 +837,21 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64) void q_dwpw_k(const Q
                 }
             }
             if (f + WP < nf) {
-                const uint8_t *bn = ob + ((size_t)fq * QT + 16 * (f + WP) + fr) * 16;
+                const uint8_t *bn = opnd + ((size_t)fq * QT + 16 * (f + WP) + fr) * 16;
 #pragma unroll
                 for (int kc = 0; kc < KB; ++kc) b[kc] = *reinterpret_cast<const i4v *>(bn + (size_t)kc * 4 * QT * 16);
             }
             const int rsv = ROWSUM ? rowsum[rsb * QT + 16 * f + fr] * P.zwc : 0;
-            const unsigned po = pixoff[gbuf * QT + 16 * f + fr];
+            const unsigned po = (unsigned)pinfo[gbuf * QT + 16 * f + fr][3];
             unsigned o[MW];
 #pragma unroll
             for (int m = 0; m < MW; ++m) {
-                o[m] = 0x80808080u ^ q_pack4<SAT>(q_requant_relu(acc[m][0] + rsv, Mp, Cp, shp), q_requant_relu(acc[m][1] + rsv, Mp, Cp, shp),
-                                                    q_requant_relu(acc[m][2] + rsv, Mp, Cp, shp), q_requant_relu(acc[m][3] + rsv, Mp, Cp, shp), lop, hip_);
+                if constexpr (FOLDP)
+                    o[m] = 0x80808080u ^ q_pack4<SAT>(q_requant_relu(acc[m][0], Mp, CP[m][0], shp), q_requant_relu(acc[m][1], Mp, CP[m][1], shp),
+                                                        q_requant_relu(acc[m][2], Mp, CP[m][2], shp), q_requant_relu(acc[m][3], Mp, CP[m][3], shp), lop, hip_);
+                else
+                    o[m] = 0x80808080u ^ q_pack4<SAT>(q_requant_relu(acc[m][0] + rsv, Mp, Cp, shp), q_requant_relu(acc[m][1] + rsv, Mp, Cp, shp),
+                                                        q_requant_relu(acc[m][2] + rsv, Mp, Cp, shp), q_requant_relu(acc[m][3] + rsv, Mp, Cp, shp), lop, hip_);
             }
             if (po != 0xffffffffu) {
                 uint8_t *dst = P.out + po + (size_t)(4 * mg + fq) * ((P.wo + 2) * 16) + 4 * m0;
@@ -789,124 +860,41 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64) void q_dwpw_k(const Q
             }
         }
     };
-    auto pf_request = [&](u4v (&pf)[LPT], int lo, unsigned nb) {
-        if (!nb) return;                                             // (uniform) every request goes out back to back: no lane predicate, the
-        const uint8_t *src = P.in + (size_t)lo * RB;                 // pieces past the end re-read the last one and are dropped at the write
-#pragma unroll
-        for (int i = 0; i < LPT; ++i) {
-            if ((unsigned)(i * NT) * 16u < nb)                       // (uniform; no `break`: that leaves a rolled loop and the array in scratch) most tiles add a fraction of the worst case
-                pf[i] = *reinterpret_cast<const u4v *>(src + min((unsigned)(i * NT + tid) * 16u, nb - 16u));
-        }
-    };
-    auto pf_write = [&](const u4v (&pf)[LPT], int lo, unsigned nb) {
-        if (!nb) return;
-        unsigned tid16 = (unsigned)tid * 16u;
-        asm volatile("" : "+v"(tid16));                              // keeps the (row, offset) pairs from being hoisted out of the tile loop (16 live registers: spills)
-        const int slot0 = lo - (int)__umulhi((unsigned)lo, P.nr_magic) * P.NR;
-#pragma unroll
-        for (int i = 0; i < LPT; ++i) {
-            const unsigned idx = (unsigned)(i * NT) * 16u + tid16;
-            if ((unsigned)(i * NT) * 16u < nb && idx < nb) {
-                const unsigned row = __umulhi(idx, P.rb_magic), off = idx - row * RB;      // idx / RB (exact: idx * RB < 2^32)
-                int slot = slot0 + (int)row;
-                slot = slot >= P.NR ? slot - P.NR : slot;
-                slot = slot >= P.NR ? slot - P.NR : slot;
-                *reinterpret_cast<u4v *>(ring + (size_t)slot * RB + off) = pf[i];
-            }
-        }
-    };
-    // this wave's planes when every wave takes part in the depthwise stage
-    const int all_cg0 = C16 >= NW ? wave * (C16 / NW) : wave % C16, all_ncg = C16 >= NW ? C16 / NW : (wave < C16 ? 1 : 0);
-
     int n, q0, q1, ga, gb;
     tile_rows(t_begin, n, q0, q1, ga, gb);
     load_rows_sync(ga, gb);
-    if (tid < QT) geometry(n, q0, q1, t_begin & 1);
+    if (tid < QT) geometry(n, q0, q1, ga, t_begin & 1);
     int loaded_hi = gb;
     __syncthreads();
     unsigned long long st[6] = {0, 0, 0, 0, 0, 0}, tprev = P.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
 #define Q_STAMP(k) do { if (P.dbg) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st[k] += now_ - tprev; tprev = now_; } } while (0)
 
-    if constexpr (!TEAMS) {
-        for (int t = t_begin; t < t_end; ++t) {
-            int lo = 0; unsigned nb = 0;
-            int n2 = 0, q02 = 0, q12 = 0, ga2 = 0, gb2 = 0;
-            if (t + 1 < t_end) {
-                tile_rows(t + 1, n2, q02, q12, ga2, gb2);
-                lo = max(loaded_hi + 1, ga2);
-                nb = gb2 >= lo ? (unsigned)(gb2 - lo + 1) * RB : 0u;
-                loaded_hi = max(loaded_hi, gb2);
-            }
-            const int cur = t & 1;
-            dw_planes(all_cg0, all_ncg, cur, 0, cur);
-            Q_STAMP(0);
-            __syncthreads();                                         // A: operand tile and row sums are complete; the ring is free
-            Q_STAMP(1);
-            u4v pf[LPT];
-            pf_request(pf, lo, nb);                                  // the next tile's rows: registers now, ring when the matrix stage is done
-            if (tid < QT) {
-                rowsum[(cur ^ 1) * QT + tid] = 0;
-                if (t + 1 < t_end) geometry(n2, q02, q12, cur ^ 1);
-            }
-            matrix(q0, q1, cur, 0, cur);
-            Q_STAMP(2);
-            pf_write(pf, lo, nb);
-            Q_STAMP(3);
-            __syncthreads();                                         // B: the operand tile is free, the ring holds the next tile's rows
-            Q_STAMP(4);
-            n = n2; q0 = q02; q1 = q12;
+    for (int t = t_begin; t < t_end; ++t) {
+        int lo = 0; unsigned nb = 0;
+        int n2 = 0, q02 = 0, q12 = 0, ga2 = 0, gb2 = 0;
+        if (t + 1 < t_end) {
+            tile_rows(t + 1, n2, q02, q12, ga2, gb2);
+            lo = max(loaded_hi + 1, ga2);
+            nb = gb2 >= lo ? (unsigned)(gb2 - lo + 1) * RB : 0u;
+            loaded_hi = max(loaded_hi, gb2);
         }
-    } else {
-        // Two teams (lower / upper half of the wave numbers: with eight waves one of each per SIMD), a tile step in two phases:
-        //     phase 1   team A: pointwise stage of tile t        team B: depthwise stage of tile t + 1, lower half of the planes
-        //     phase 2   team B: pointwise stage of tile t        team A: depthwise stage of tile t + 1, upper half of the planes
-        // so every SIMD always has one wave whose MFMAs are long dependent-free runs (pointwise) next to one that alternates short MFMA
-        // runs with vector work (depthwise, epilogues).  Then the rows tile t + 2 adds replace those tile t + 1 no longer needs.
-        constexpr int NWT = NW / 2, CGT = C16 / NW;                  // waves per team, planes per wave and phase
-        const int team = wave >= NWT, wt = wave - team * NWT;
-        dw_planes(all_cg0, all_ncg, t_begin & 1, t_begin & 1, t_begin % 3);          // the first tile's depthwise stage, all waves
-        int n1 = 0, q01 = 0, q11 = 0, ga1 = 0, gb1 = 0;
-        __syncthreads();
-        if (t_begin + 1 < t_end) {
-            tile_rows(t_begin + 1, n1, q01, q11, ga1, gb1);
-            load_rows_sync(max(loaded_hi + 1, ga1), gb1);
-            loaded_hi = max(loaded_hi, gb1);
-            if (tid < QT) geometry(n1, q01, q11, (t_begin + 1) & 1);
+        const int cur = t & 1;
+        dw_planes(cur, cur);
+        Q_STAMP(0);
+        __syncthreads();                                         // A: operand tile and row sums are complete; the ring is free
+        Q_STAMP(1);
+        pf_issue(lo, nb);                                        // the next tile's rows: on their way into the ring while the matrix stage runs
+        if (tid < QT) {
+            if (ROWSUM) rowsum[(cur ^ 1) * QT + tid] = 0;
+            if (t + 1 < t_end) geometry(n2, q02, q12, ga2, cur ^ 1);
         }
-        __syncthreads();
-        for (int t = t_begin; t < t_end; ++t) {
-            const bool has1 = t + 1 < t_end, has2 = t + 2 < t_end;
-            int n2 = 0, q02 = 0, q12 = 0, ga2 = 0, gb2 = 0, lo = 0; unsigned nb = 0;
-            if (has2) {
-                tile_rows(t + 2, n2, q02, q12, ga2, gb2);
-                lo = max(loaded_hi + 1, ga2);
-                nb = gb2 >= lo ? (unsigned)(gb2 - lo + 1) * RB : 0u;
-                loaded_hi = max(loaded_hi, gb2);
-            }
-            const int b0 = t & 1, b1 = b0 ^ 1, r0i = t % 3, r1i = (t + 1) % 3, r2i = (t + 2) % 3;
-            u4v pf[LPT];
-            // ---- phase 1
-            if (tid < QT) rowsum[r2i * QT + tid] = 0;
-            if (!team) matrix(q0, q1, b0, b0, r0i);
-            else if (has1) dw_planes(wt * CGT, CGT, b1, b1, r1i);
-            Q_STAMP(0);
-            __syncthreads();
-            Q_STAMP(1);
-            // ---- phase 2
-            pf_request(pf, lo, nb);
-            if (team) matrix(q0, q1, b0, b0, r0i);
-            else if (has1) dw_planes(C16 / 2 + wt * CGT, CGT, b1, b1, r1i);
-            Q_STAMP(2);
-            __syncthreads();
-            Q_STAMP(3);
-            // ---- the rows of tile t + 2, its geometry
-            pf_write(pf, lo, nb);
-            if (has2 && tid < QT) geometry(n2, q02, q12, b0);
-            __syncthreads();
-            Q_STAMP(4);
-            n = n1; q0 = q01; q1 = q11;
-            n1 = n2; q01 = q02; q11 = q12;
-        }
+        matrix(q0, q1, cur, cur);
+        Q_STAMP(2);
+        __builtin_amdgcn_s_waitcnt(0x0f70);                      // vmcnt(0): this wave's pieces of the ring have landed (stamped apart from the barrier)
+        Q_STAMP(3);
+        __syncthreads();                                         // B: the operand tile is free, the ring holds the next tile's rows (every wave waited for its pieces)
+        Q_STAMP(4);
+        n = n2; q0 = q02; q1 = q12;
     }
 #undef Q_STAMP
     if (P.dbg && lane == 0) for (int k = 0; k < 5; ++k) P.dbg[((size_t)blockIdx.x * NW + wave) * 8 + k] = st[k];
@@ -937,28 +925,30 @@ void dwpw_plan(int H, int W, int ho, int wo, int stride, int off_y, int cin, int
     *lpt = (int)(((long long)mx * RB + (long long)nt * 16 - 1) / ((long long)nt * 16));
 }
 
-template <int CIN, int COUT, int WP, int STRIDE, int LPT, bool TEAMS, int MW = 4>
+template <int CIN, int COUT, int WP, int STRIDE, int LPT, int MW = 4>
 int launch_q_dwpw(hipStream_t s, QDwpwP &P, int nimg, int device, bool *ok) {
     constexpr int NW = (COUT / (16 * MW)) * WP, NT = NW * 64, CINP = (CIN + 63) / 64 * 64;
     int lpt = 0;
     dwpw_plan(P.H, P.W, P.ho, P.wo, STRIDE, P.off_y, CIN, NT, &P.NR, &lpt);
     const int RB = (P.W + 2) * CIN;
-    const size_t lds = (size_t)P.NR * RB + (size_t)(TEAMS ? 2 : 1) * QT * CINP + (size_t)((TEAMS ? 3 : 2) + 2) * QT * sizeof(int) + 2 * QT * 16 + COUT * sizeof(int);
-    P.rb_magic = (unsigned)((1ull << 32) / (unsigned)RB) + 1u;
+    const size_t lds = (size_t)P.NR * RB + (size_t)QT * CINP + (size_t)2 * QT * sizeof(int) + 2 * QT * 16 + COUT * sizeof(int);
     P.wo_magic = (unsigned)((1ull << 32) / (unsigned)P.wo) + 1u;
     P.nr_magic = (unsigned)((1ull << 32) / (unsigned)P.NR) + 1u;
     P.tpf_magic = (unsigned)((1ull << 32) / (unsigned)P.tiles_per_frame) + 1u;
+    const long long lim24 = 1ll << 23;                              // the kernel's 24-bit multiplies
     *ok = (long long)nimg * P.tiles_per_frame * P.tiles_per_frame < (1ll << 32) && (long long)P.hw * P.wo < (1ll << 32) &&
-          (long long)(nimg + 1) * (P.H + 2) * P.NR < (1ll << 32) && lpt <= LPT && lds <= 160 * 1024 && (long long)LPT * NT * 16 * RB < (1ll << 32) && (LPT * NT * 16) / RB + 1 <= 2 * P.NR;
+          (long long)(nimg + 1) * (P.H + 2) * P.NR < (1ll << 32) && lpt <= LPT && lds <= 160 * 1024 && (long long)LPT * NT * 16 + (long long)P.NR * RB < (1ll << 32) &&
+          RB < lim24 && (long long)P.c16_out * (P.wo + 2) * 16 < lim24 && (long long)(nimg + 1) * (P.ho + 2) < lim24 && P.hw < lim24;
     if (!*ok) return DD_OK;
-    const bool hl = P.w2 != nullptr;                                  // the compiler packed a split filter (small CIN): no row sums
+    constexpr bool CAN_HL = CIN <= 128;                                // split pointwise filters are packed for the narrow blocks only
+    const bool hl = P.w2 != nullptr;
+    if (hl && !CAN_HL) { *ok = false; return DD_OK; }
     const bool rsum = P.zwc != 0 && !hl;
     const bool sat = P.Rd.lo == 0 && P.Rd.hi == 255 && P.Rp.lo == 0 && P.Rp.hi == 255;       // both clamps are the byte range: saturating packs
-#define DD_QK(R_, S_, H_) q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, R_, TEAMS, MW, S_, H_>
+#define DD_QK(R_, S_, H_) q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, R_, MW, S_, (H_) && CAN_HL>
     void (*kern)(const QDwpwP, const int, const int) =
         hl ? (sat ? &DD_QK(false, true, true) : &DD_QK(false, false, true))
            : rsum ? (sat ? &DD_QK(true, true, false) : &DD_QK(true, false, false)) : (sat ? &DD_QK(false, true, false) : &DD_QK(false, false, false));
-    auto kfn = [&]() -> const void * { return reinterpret_cast<const void *>(kern); };
     static DevOnce once;
     const int rc = once.run(device, [&]() -> int {
         for (const void *f : {reinterpret_cast<const void *>(&DD_QK(false, true, true)), reinterpret_cast<const void *>(&DD_QK(false, false, true)),
@@ -973,7 +963,7 @@ int launch_q_dwpw(hipStream_t s, QDwpwP &P, int nimg, int device, bool *ok) {
     int per_cu = per_cu_cache[device & 63].load(std::memory_order_relaxed);
     if (per_cu == 0) {
         int nb = 0;
-        DD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kfn(), NT, lds));
+        DD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern), NT, lds));
         per_cu = std::max(1, std::min(8, nb));
         per_cu_cache[device & 63].store(per_cu, std::memory_order_relaxed);
     }
@@ -994,8 +984,7 @@ int launch_q_dwpw(hipStream_t s, QDwpwP &P, int nimg, int device, bool *ok) {
         double sum[5] = {0, 0, 0, 0, 0};
         for (size_t w = 0; w < n_st / 8; ++w) for (int k = 0; k < 5; ++k) sum[k] += (double)h[w * 8 + k];
         const double nw = (double)(n_st / 8) * tpb;
-        fprintf(stderr, TEAMS ? "q_dwpw_k<%d,%d,%d> teams, %d blocks/CU %d tiles/block: cycles per wave and tile: phase 1 %.0f  barrier %.0f  phase 2 %.0f  barrier %.0f  ring write + barrier %.0f\n"
-                              : "q_dwpw_k<%d,%d,%d> %d blocks/CU %d tiles/block: cycles per wave and tile: depthwise %.0f  barrier A %.0f  matrix stage %.0f  ring write %.0f  barrier B %.0f\n",
+        fprintf(stderr, "q_dwpw_k<%d,%d,%d> %d blocks/CU %d tiles/block: cycles per wave and tile: depthwise %.0f  barrier A %.0f  matrix stage %.0f  ring write %.0f  barrier B %.0f\n",
                 CIN, COUT, STRIDE, per_cu, tpb, sum[0] / nw, sum[1] / nw, sum[2] / nw, sum[3] / nw, sum[4] / nw);
     }
     return DD_OK;
@@ -1113,12 +1102,14 @@ int netq_run_op(dd_net *net, int i, const int32_t *o, const uint8_t *input, int 
             P.off_y = 1 - o[8]; P.off_x = 1 - o[9]; P.ho = td->h; P.wo = td->w; P.hw = P.ho * P.wo; P.tiles_per_frame = dd_ceil_div(P.hw, QT);
             P.out = base(dst); P.c16_out = td->cs / 16;
             P.dw_a = reinterpret_cast<const uint2 *>(W + (size_t)(uint32_t)o[20]);
-            P.dw_cb = reinterpret_cast<const int *>(W + (size_t)(uint32_t)o[21]);
+            P.dw_cq = reinterpret_cast<const long long *>(W + (size_t)(uint32_t)o[45]);      // o[21] (the 32-bit constants) serves the two-op form only
+            P.cq = reinterpret_cast<const long long *>(W + (size_t)(uint32_t)o[46]);
             P.w = reinterpret_cast<const i4v *>(W + (size_t)(uint32_t)o[16]);
             P.w2 = o[18] ? reinterpret_cast<const i4v *>(W + (size_t)(uint32_t)o[18]) : nullptr;       // o[18]: the lo part of a split pointwise filter
             P.cbias = reinterpret_cast<const int *>(W + (size_t)(uint32_t)o[17]);
             P.zwc = o[38]; P.Rp = make_req(o);
             { int32_t d[48] = {0}; d[32] = o[22]; d[33] = o[23]; d[36] = o[24]; d[37] = o[25]; d[40] = o[28]; P.Rd = make_req(d); }
+            DD_REQUIRE(o[45] != 0 && o[46] != 0, DD_E_ARG, "dd_net_forward: uint8 block %d: the program carries no folded requantisation constants (compiled by an older netsq.py?)", i);
             DD_REQUIRE(cin == ts->cs && cout == td->cs && P.Rd.e >= 1 && P.Rp.e >= 1 && !P.Rd.linear && !P.Rp.linear && P.off_y >= 0 && P.off_x >= 0 &&
                        (P.ho - 1) * stride + 2 + P.off_y <= P.H + 1 && (P.wo - 1) * stride + 2 + P.off_x <= P.W + 1, DD_E_ARG,
                        "dd_net_forward: uint8 block %d: shapes / multipliers the fused kernel does not take", i);
@@ -1126,16 +1117,14 @@ int netq_run_op(dd_net *net, int i, const int32_t *o, const uint8_t *input, int 
             bool ok = false;
             int rc = DD_OK;
             const int dev = net->ctx->device;
-            static const int mw = getenv("DD_Q_MW") ? atoi(getenv("DD_Q_MW")) : 4;               // 19x19 blocks: 4 = eight waves of 64 channels; 2 = sixteen of 32 (four per SIMD; measured slower: 131 vs 89 us, the stages are issue-bound, not latency-bound)
-            static const int teams = getenv("DD_Q_TEAMS") ? atoi(getenv("DD_Q_TEAMS")) : 0;       // 1 = the two-team schedule (measured slower: profiles/r04_q_stamps.txt)
-#define DD_QB(CIN_, COUT_, WP_, S_, LPT_, T_) (T_ && teams ? launch_q_dwpw<CIN_, COUT_, WP_, S_, LPT_, T_>(s, P, nimg, dev, &ok) : launch_q_dwpw<CIN_, COUT_, WP_, S_, LPT_, false>(s, P, nimg, dev, &ok))
-            if (cin == 32 && cout == 64 && stride == 1) rc = DD_QB(32, 64, 2, 1, 8, false);
-            else if (cin == 64 && cout == 128 && stride == 2) rc = DD_QB(64, 128, 2, 2, 8, false);
-            else if (cin == 128 && cout == 128 && stride == 1) rc = DD_QB(128, 128, 2, 1, 8, false);
-            else if (cin == 128 && cout == 256 && stride == 2) rc = DD_QB(128, 256, 2, 2, 8, true);
-            else if (cin == 256 && cout == 256 && stride == 1) rc = DD_QB(256, 256, 2, 1, 6, true);
-            else if (cin == 256 && cout == 512 && stride == 2) rc = mw == 2 ? launch_q_dwpw<256, 512, 1, 2, 6, false, 2>(s, P, nimg, dev, &ok) : DD_QB(256, 512, 1, 2, 12, true);
-            else if (cin == 512 && cout == 512 && stride == 1) rc = mw == 2 ? launch_q_dwpw<512, 512, 1, 1, 4, false, 2>(s, P, nimg, dev, &ok) : DD_QB(512, 512, 1, 1, 8, true);
+#define DD_QB(CIN_, COUT_, WP_, S_, LPT_) launch_q_dwpw<CIN_, COUT_, WP_, S_, LPT_>(s, P, nimg, dev, &ok)
+            if (cin == 32 && cout == 64 && stride == 1) rc = DD_QB(32, 64, 2, 1, 8);
+            else if (cin == 64 && cout == 128 && stride == 2) rc = DD_QB(64, 128, 2, 2, 8);
+            else if (cin == 128 && cout == 128 && stride == 1) rc = DD_QB(128, 128, 2, 1, 8);
+            else if (cin == 128 && cout == 256 && stride == 2) rc = DD_QB(128, 256, 2, 2, 8);
+            else if (cin == 256 && cout == 256 && stride == 1) rc = DD_QB(256, 256, 2, 1, 6);
+            else if (cin == 256 && cout == 512 && stride == 2) rc = DD_QB(256, 512, 1, 2, 12);
+            else if (cin == 512 && cout == 512 && stride == 1) rc = DD_QB(512, 512, 1, 1, 8);
 #undef DD_QB
             if (rc != DD_OK) return rc;
             DD_REQUIRE(ok, DD_E_ARG, "dd_net_forward: uint8 block %d (%d -> %d, stride %d, %d x %d): no fused kernel for this shape -- compile the program with the two-op form", i, cin, cout, stride, P.H, P.W);

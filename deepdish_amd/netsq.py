@@ -34,6 +34,16 @@ def _req_words(L):
     return {32: m, 33: -shift, 36: lo, 37: hi, 40: int(L['out_zp']), 41: linear}
 
 
+def folded_addends(cb, rw):
+    """Per-channel 64-bit addend of the ReLU-type requantisation z = ((acc + cb) M + C) >> (31 + e)  ->  (acc M + [cb M + C]) >> (31 + e),
+    C = 2^30 + 2^(30+e) + (zo << (31+e)) (csrc/netsq.hip make_req): accumulators start at zero and v_mad_i64_i32 adds the channel's constant."""
+    m, e, zo = int(rw[32]), int(rw[33]), int(rw[40])
+    c = (1 << 30) + ((1 << (30 + e)) if e > 0 else 0) + (zo << (31 + e))
+    out = [int(v) * m + c for v in np.asarray(cb).reshape(-1)]
+    assert all(-(1 << 62) < v < (1 << 62) for v in out)
+    return np.array(out, dtype=np.int64)
+
+
 def _cbias(L, w_i8_ck):
     """w_i8_ck: [cout][K] int (w - 128) over the real taps."""
     za, zw = int(L['in_zp']) - 128, int(L['w_zp']) - 128
@@ -213,7 +223,7 @@ def compile_ssd_mobilenet_quant(qm):
                 zwc = 0
         dst = P.qtensor(ho, wo, cout, Lp['out_zp'])
         raw = dict(rp)
-        raw.update({38: zwc, 39: int(Lp['in_zp'])})
+        raw.update({38: zwc, 39: int(Lp['in_zp']), 45: P.add_blob(folded_addends(dcb, rd)), 46: P.add_blob(folded_addends(cb, rp))})
         P._op(OP_QDWPW, src=src, dst=dst, kh=1, kw=1, stride=stride, pad_t=pt, pad_l=pl, cin=cin, cout=cout, cout_pad=cout, kpad=kcpt,
               w_off=P.add_blob(wp), b_off=P.add_blob(cb), aff_off=w_lo, ho=ho, wo=wo,
               p=[P.add_blob(dwa), P.add_blob(dcb), rd[32], rd[33], rd[36], rd[37]], bk=rd[40], raw=raw)
