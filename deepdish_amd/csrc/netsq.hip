@@ -599,7 +599,9 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64, 2) void q_dwpw_k(cons
     int *rowsum = reinterpret_cast<int *>(opnd + QT * CINP);        // [2][QT]
     i4v *pinfo = reinterpret_cast<i4v *>(rowsum + 2 * QT);          // [2][QT]: ring offsets of the pixel's window (rows 0..2, first column), offset of its output
     int *cbl = reinterpret_cast<int *>(pinfo + 2 * QT);             // [COUT]: the pointwise layer's per-channel constants (!FOLDP)
-    uint8_t *ring = reinterpret_cast<uint8_t *>(cbl + COUT);        // [NR][RB], last (>= 4 KB of other data below it: see pf_issue)
+    uint2 *dwa_l = reinterpret_cast<uint2 *>(cbl + COUT);           // !KEEP: the depthwise tables in LDS ([C16][64] operand bytes, [CIN] addends): a global
+    long long *dwq_l = reinterpret_cast<long long *>(dwa_l + (KEEP ? 0 : C16 * 64));     // load at the head of every plane is ~500 cycles before its first use
+    uint8_t *ring = reinterpret_cast<uint8_t *>(dwq_l + (KEEP ? 0 : CIN));   // [NR][RB], last (>= 4 KB of other data below it: see pf_issue)
 
     // the wave's pointwise filter, once
     // wave wm's fragments: MW consecutive ones of the host's 4-fragment groups (fragment 4 mg + m holds channels 64 mg + 16 g + 4 m + r)
@@ -624,6 +626,10 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64, 2) void q_dwpw_k(cons
             for (int r = 0; r < 4; ++r) CP[m][r] = P.cq[64 * mg + 16 * fq + 4 * (m0 + m) + r];
     } else {
         for (int i = tid; i < COUT; i += NT) cbl[i] = P.cbias[i];
+    }
+    if constexpr (!KEEP) {
+        for (int i = tid; i < C16 * 64; i += NT) dwa_l[i] = P.dw_a[i];
+        for (int i = tid; i < CIN; i += NT) dwq_l[i] = P.dw_cq[i];
     }
     if (CIN < CINP) for (int i = tid; i < QT * CINP / 16; i += NT) reinterpret_cast<u4v *>(opnd)[i] = u4v{0, 0, 0, 0};   // k slots without channels
     for (int i = tid; i < 2 * QT; i += NT) rowsum[i] = 0;
@@ -712,7 +718,7 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64, 2) void q_dwpw_k(cons
         auto plane = [&](int cg, int ci) {                           // (ci: a literal after unrolling when KEEP)
             const int pofs = cg * PP;
             uint2 ab = make_uint2(0u, 0u);
-            if constexpr (!KEEP) ab = P.dw_a[cg * 64 + lane];
+            if constexpr (!KEEP) ab = dwa_l[cg * 64 + lane];
             i4v acc[4];
 #pragma unroll
             for (int f = 0; f < 4; ++f) acc[f] = i4v{0, 0, 0, 0};
@@ -742,7 +748,7 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64, 2) void q_dwpw_k(cons
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if constexpr (KEEP) Cq[r] = KCq[ci][r];
-                else Cq[r] = P.dw_cq[cg * 16 + 4 * fq + r];
+                else Cq[r] = dwq_l[cg * 16 + 4 * fq + r];
             }
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
@@ -931,7 +937,8 @@ int launch_q_dwpw(hipStream_t s, QDwpwP &P, int nimg, int device, bool *ok) {
     int lpt = 0;
     dwpw_plan(P.H, P.W, P.ho, P.wo, STRIDE, P.off_y, CIN, NT, &P.NR, &lpt);
     const int RB = (P.W + 2) * CIN;
-    const size_t lds = (size_t)P.NR * RB + (size_t)QT * CINP + (size_t)2 * QT * sizeof(int) + 2 * QT * 16 + COUT * sizeof(int);
+    constexpr bool KEEP = (CIN / 16) / NW <= 2;                       // (as in the kernel) else the depthwise tables take LDS
+    const size_t lds = (size_t)P.NR * RB + (size_t)QT * CINP + (size_t)2 * QT * sizeof(int) + 2 * QT * 16 + COUT * sizeof(int) + (KEEP ? 0 : (CIN / 16) * 64 * 8 + CIN * 8);
     P.wo_magic = (unsigned)((1ull << 32) / (unsigned)P.wo) + 1u;
     P.nr_magic = (unsigned)((1ull << 32) / (unsigned)P.NR) + 1u;
     P.tpf_magic = (unsigned)((1ull << 32) / (unsigned)P.tiles_per_frame) + 1u;
