@@ -93,6 +93,29 @@ __device__ __forceinline__ unsigned q_pack4(int z0, int z1, int z2, int z3, int 
     }
 }
 
+// Four accumulators -> four requantised bytes (ReLU-type layers, e >= 1): z = (x M + C) >> (32 + sh), clamped.  SAT: 0 = the layer's own clamp
+// (v_med3), 1 = the clamp is the byte range: saturating packs, 2 = that and sh <= 7: the shift moves behind the first pack, where one
+// v_pk_ashrrev_i16 serves two values -- exact, because the high word saturated to 16 bits still shifts to >= 255 (32767 >> 7) or below 0
+// exactly when the unsaturated one does.  14 -> 12 instructions per four values; these kernels are bound by instruction issue.
+template <int SAT>
+__device__ __forceinline__ unsigned q_requant_pack4(int x0, int x1, int x2, int x3, int M, long long C0, long long C1, long long C2, long long C3, int sh32, int lo, int hi) {
+    if constexpr (SAT == 2) {
+        const int h0 = (int)(((long long)x0 * M + C0) >> 32), h1 = (int)(((long long)x1 * M + C1) >> 32);
+        const int h2 = (int)(((long long)x2 * M + C2) >> 32), h3 = (int)(((long long)x3 * M + C3) >> 32);
+        const unsigned shpk = (unsigned)sh32 | (unsigned)sh32 << 16;
+        unsigned p01, p23, q01, q23;
+        asm("v_cvt_pk_i16_i32 %0, %1, %2" : "=v"(p01) : "v"(h0), "v"(h1));
+        asm("v_cvt_pk_i16_i32 %0, %1, %2" : "=v"(p23) : "v"(h2), "v"(h3));
+        asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(p01) : "s"(shpk), "v"(p01));
+        asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(p23) : "s"(shpk), "v"(p23));
+        asm("v_sat_pk_u8_i16 %0, %1" : "=v"(q01) : "v"(p01));
+        asm("v_sat_pk_u8_i16 %0, %1" : "=v"(q23) : "v"(p23));
+        return __builtin_amdgcn_perm(q23, q01, 0x05040100u);
+    } else {
+        return q_pack4<SAT == 1>(q_requant_relu(x0, M, C0, sh32), q_requant_relu(x1, M, C1, sh32), q_requant_relu(x2, M, C2, sh32), q_requant_relu(x3, M, C3, sh32), lo, hi);
+    }
+}
+
 __device__ __forceinline__ int sdot4(int a, int b, int c) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_sdot4(a, b, c, false);
@@ -581,7 +604,7 @@ constexpr int QT = 64;               // pixels per tile
 // HL: the pointwise filter as w - zw split into hi = clamp(w - zw, -128, 127) and lo = rest, two MFMAs per fragment and k slice on one
 // accumulator instead of one MFMA plus the zwc * rowsum correction: for the layers with few input channels the matrix pipe has the time
 // and the row-sum machinery (dot products, cross-lane sums, LDS atomics, an add per output) goes.
-template <int CIN, int COUT, int WP, int STRIDE, int LPT, bool ROWSUM, int MW = 4, bool SAT = false, bool HL = false>
+template <int CIN, int COUT, int WP, int STRIDE, int LPT, bool ROWSUM, int MW = 4, int SAT = 0, bool HL = false>
 __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64, 2) void q_dwpw_k(const QDwpwP P, const int n_tiles, const int tiles_per_block) {
     constexpr int WM = COUT / (16 * MW), NW = WM * WP, NT = NW * 64;
     static_assert(MW == 4 || MW == 2, "fragments per wave");
@@ -752,8 +775,7 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64, 2) void q_dwpw_k(cons
             }
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
-                unsigned packed = q_pack4<SAT>(q_requant_relu(acc[f][0], Md, Cq[0], shd), q_requant_relu(acc[f][1], Md, Cq[1], shd),
-                                               q_requant_relu(acc[f][2], Md, Cq[2], shd), q_requant_relu(acc[f][3], Md, Cq[3], shd), lod, hid);
+                unsigned packed = q_requant_pack4<SAT>(acc[f][0], acc[f][1], acc[f][2], acc[f][3], Md, Cq[0], Cq[1], Cq[2], Cq[3], shd, lod, hid);
                 packed ^= 0x80808080u;
                 if (ROWSUM) rs[f] = sdot4((int)packed, 0x01010101, rs[f]);
                 *reinterpret_cast<unsigned *>(opnd + ((size_t)cg * QT + 16 * f + fr) * 16 + 4 * fq) = packed;
@@ -853,11 +875,9 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64, 2) void q_dwpw_k(cons
 #pragma unroll
             for (int m = 0; m < MW; ++m) {
                 if constexpr (FOLDP)
-                    o[m] = 0x80808080u ^ q_pack4<SAT>(q_requant_relu(acc[m][0], Mp, CP[m][0], shp), q_requant_relu(acc[m][1], Mp, CP[m][1], shp),
-                                                        q_requant_relu(acc[m][2], Mp, CP[m][2], shp), q_requant_relu(acc[m][3], Mp, CP[m][3], shp), lop, hip_);
+                    o[m] = 0x80808080u ^ q_requant_pack4<SAT>(acc[m][0], acc[m][1], acc[m][2], acc[m][3], Mp, CP[m][0], CP[m][1], CP[m][2], CP[m][3], shp, lop, hip_);
                 else
-                    o[m] = 0x80808080u ^ q_pack4<SAT>(q_requant_relu(acc[m][0] + rsv, Mp, Cp, shp), q_requant_relu(acc[m][1] + rsv, Mp, Cp, shp),
-                                                        q_requant_relu(acc[m][2] + rsv, Mp, Cp, shp), q_requant_relu(acc[m][3] + rsv, Mp, Cp, shp), lop, hip_);
+                    o[m] = 0x80808080u ^ q_requant_pack4<SAT>(acc[m][0] + rsv, acc[m][1] + rsv, acc[m][2] + rsv, acc[m][3] + rsv, Mp, Cp, Cp, Cp, Cp, shp, lop, hip_);
             }
             if (po != 0xffffffffu) {
                 uint8_t *dst = P.out + po + (size_t)(4 * mg + fq) * ((P.wo + 2) * 16) + 4 * m0;
@@ -951,19 +971,20 @@ int launch_q_dwpw(hipStream_t s, QDwpwP &P, int nimg, int device, bool *ok) {
     const bool hl = P.w2 != nullptr;
     if (hl && !CAN_HL) { *ok = false; return DD_OK; }
     const bool rsum = P.zwc != 0 && !hl;
-    const bool sat = P.Rd.lo == 0 && P.Rd.hi == 255 && P.Rp.lo == 0 && P.Rp.hi == 255;       // both clamps are the byte range: saturating packs
+    // both clamps are the byte range: saturating packs (1); both shifts <= 8 as well: the packed 16-bit shift (2)
+    const int sat = P.Rd.lo == 0 && P.Rd.hi == 255 && P.Rp.lo == 0 && P.Rp.hi == 255 ? (P.Rd.e <= 8 && P.Rp.e <= 8 ? 2 : 1) : 0;
 #define DD_QK(R_, S_, H_) q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, R_, MW, S_, (H_) && CAN_HL>
-    void (*kern)(const QDwpwP, const int, const int) =
-        hl ? (sat ? &DD_QK(false, true, true) : &DD_QK(false, false, true))
-           : rsum ? (sat ? &DD_QK(true, true, false) : &DD_QK(true, false, false)) : (sat ? &DD_QK(false, true, false) : &DD_QK(false, false, false));
+#define DD_QS(R_, H_) (sat == 2 ? &DD_QK(R_, 2, H_) : sat == 1 ? &DD_QK(R_, 1, H_) : &DD_QK(R_, 0, H_))
+    void (*kern)(const QDwpwP, const int, const int) = hl ? DD_QS(false, true) : rsum ? DD_QS(true, false) : DD_QS(false, false);
     static DevOnce once;
     const int rc = once.run(device, [&]() -> int {
-        for (const void *f : {reinterpret_cast<const void *>(&DD_QK(false, true, true)), reinterpret_cast<const void *>(&DD_QK(false, false, true)),
-                              reinterpret_cast<const void *>(&DD_QK(true, true, false)), reinterpret_cast<const void *>(&DD_QK(true, false, false)),
-                              reinterpret_cast<const void *>(&DD_QK(false, true, false)), reinterpret_cast<const void *>(&DD_QK(false, false, false))})
+        for (const void *f : {reinterpret_cast<const void *>(&DD_QK(false, 0, true)), reinterpret_cast<const void *>(&DD_QK(false, 1, true)), reinterpret_cast<const void *>(&DD_QK(false, 2, true)),
+                              reinterpret_cast<const void *>(&DD_QK(true, 0, false)), reinterpret_cast<const void *>(&DD_QK(true, 1, false)), reinterpret_cast<const void *>(&DD_QK(true, 2, false)),
+                              reinterpret_cast<const void *>(&DD_QK(false, 0, false)), reinterpret_cast<const void *>(&DD_QK(false, 1, false)), reinterpret_cast<const void *>(&DD_QK(false, 2, false))})
             DD_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         return DD_OK;
     });
+#undef DD_QS
 #undef DD_QK
     if (rc != DD_OK) return rc;
     static std::atomic<int> per_cu_cache[64];
