@@ -286,14 +286,18 @@ struct QConv0P {
     const uint8_t *src; int H, W; long long total_bytes;      // u8 [n][H][W][3]
     int stride, pad_t, pad_l, ho, wo, m;
     const i4v *w;                                             // [2 fragments][lane]: k group dy holds the 9 bytes (dx, channel) of filter row dy
-    const int *cbias;                                         // [32]
-    uint8_t *out; int in_zp, zwc;
+    const i4v *w2;                                            // HL: the lo part of the split filter (w - zw = hi + lo), same layout
+    const long long *cq;                                      // [32]: cbias * M + C, the requantisation's addend per channel
+    uint8_t *out; long long out_bytes; int in_zp, zwc;
     QReq R;
 };
 
 // 3x3 stride-2 conv over the 3 colour channels, 32 output channels: one MFMA k slice (3 filter rows x 9 bytes of an image row,
 // 37 zero slots) per 16 pixels, two fragments of 16 channels.  Taps outside the image read the input zero point.
+// Bound by vector-instruction issue (177 per fragment against 2 MFMAs): the filter split hi + lo (HL: four MFMAs, no row sum of the window),
+// per-channel 64-bit addends, saturating packs (q_requant_pack4), 32-bit addresses.
 constexpr int C0F = 4;      // 16-pixel fragments per wave: twelve loads in flight per lane (one fragment per wave was bound by the HBM latency: 222 us per 384 frames)
+template <bool HL, int SAT>
 __global__ __launch_bounds__(256) void q_conv0_k(const QConv0P P, const int n_frags) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 15, fq = lane >> 4;
@@ -301,44 +305,52 @@ __global__ __launch_bounds__(256) void q_conv0_k(const QConv0P P, const int n_fr
     if (f0 >= n_frags) return;
     const unsigned zp4 = (unsigned)P.in_zp * 0x01010101u;
     const int hw = P.ho * P.wo;
-    unsigned w[C0F][3]; int o_[C0F]; bool rowok[C0F], live[C0F]; int pn[C0F], py[C0F], px[C0F];
+    // Range-checked buffer accesses: a window that starts before the batch (column -1 of the first row) or ends past it reads zeros instead of
+    // faulting -- those bytes are replaced by the zero point below anyway -- and a pixel past the last one stores nothing; no clamps, no
+    // 64-bit address arithmetic (the host checked that both tensors stay below 2^31 / 2^32 bytes).
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(P.src), 0, (int)P.total_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdst = __builtin_amdgcn_make_buffer_rsrc(P.out, 0, (int)P.out_bytes, 0x00020000);
+    unsigned w[C0F][3]; int o_[C0F]; bool rowok[C0F]; int px[C0F]; unsigned so[C0F];
     // the lane's pixel of the first fragment by division (once), of the following ones by stepping 16 pixels along the raster
     int qn, qy, qx;
     {
-        const int q = min(f0 * 16 + fr, P.m - 1);
+        const int q = f0 * 16 + fr;
         qn = q / hw; const int r0 = q - qn * hw; qy = r0 / P.wo; qx = r0 - qy * P.wo;
     }
+    const int PPo = (P.wo + 2) * 16;
 #pragma unroll
     for (int j = 0; j < C0F; ++j) {
-        const int q = (f0 + j) * 16 + fr;
-        live[j] = q < P.m;
-        pn[j] = qn; py[j] = qy; px[j] = qx;
+        px[j] = qx;
+        const int row = qy * P.stride + fq - P.pad_t, col = qx * P.stride - P.pad_l;      // first of the three source pixels of this filter row
+        rowok[j] = fq < 3 && row >= 0 && row < P.H;
+        const int a = ((qn * P.H + row) * P.W + col) * 3;      // (< 0 or past the end only for rows / pixels whose bytes are not used)
+        const int a4 = a & ~3;
+        o_[j] = a - a4;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) w[j][i] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, a4 + 4 * i, 0, 0);
+        // a pixel past the end of the batch: an offset outside the tensor (the store is dropped)
+        so[j] = (f0 + j) * 16 + fr < P.m ? (unsigned)((((qn * (P.ho + 2) + qy + 1) * 2 + (fq >> 1)) * PPo) + (qx + 1) * 16 + (fq & 1) * 8) : 0xfffffff0u;
         qx += 16;                                                   // (wo >= 16: at most one row step per fragment)
         if (qx >= P.wo) { qx -= P.wo; if (++qy == P.ho) { qy = 0; ++qn; } }
-        if (!live[j]) { pn[j] = 0; py[j] = 0; px[j] = 0; }
-        const int row = py[j] * P.stride + fq - P.pad_t, col = px[j] * P.stride - P.pad_l;      // first of the three source pixels of this filter row
-        rowok[j] = fq < 3 && row >= 0 && row < P.H;
-        const long long a = ((long long)pn[j] * P.H + (rowok[j] ? row : 0)) * P.W * 3 + (long long)col * 3;   // may be < 0 by up to 3 (col = -1): those bytes are replaced below
-        const long long a4 = a & ~3ll;
-        o_[j] = (int)(a - a4);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) w[j][i] = *reinterpret_cast<const unsigned *>(P.src + min(max(a4 + 4 * i, 0ll), P.total_bytes - 4));
     }
     const i4v wa = P.w[lane], wb = P.w[64 + lane];
+    i4v wal = {0, 0, 0, 0}, wbl = wal;
+    if constexpr (HL) { wal = P.w2[lane]; wbl = P.w2[64 + lane]; }
     const int M0 = P.R.M, sh0 = P.R.e - 1, lo0 = P.R.lo, hi0 = P.R.hi;
-    const long long C0 = P.R.C;
     // fragment m's row 4g + r was packed with channel 8g + 4m + r: this lane holds channels 8 fq .. 8 fq + 7
-    const i4v c0 = *reinterpret_cast<const i4v *>(P.cbias + 8 * fq), c1 = *reinterpret_cast<const i4v *>(P.cbias + 8 * fq + 4);
+    long long CQ[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) CQ[r] = P.cq[8 * fq + r];
 #pragma unroll
     for (int j = 0; j < C0F; ++j) {
-        unsigned d[3] = {zp4, zp4, zp4};
-        if (rowok[j]) {
-            d[0] = __builtin_amdgcn_alignbyte(w[j][1], w[j][0], o_[j]);
-            d[1] = __builtin_amdgcn_alignbyte(w[j][2], w[j][1], o_[j]);
-            d[2] = __builtin_amdgcn_alignbyte(0u, w[j][2], o_[j]);
-            const int col = px[j] * P.stride - P.pad_l;
-            // columns outside the image: pixel i of the three covers bytes 3i .. 3i + 2 (only the waves at the left / right edge run this)
-            if (__builtin_amdgcn_ballot_w64(col < 0 || col + 2 >= P.W) != 0ull)
+        unsigned d[3];
+        d[0] = __builtin_amdgcn_alignbyte(w[j][1], w[j][0], o_[j]);
+        d[1] = __builtin_amdgcn_alignbyte(w[j][2], w[j][1], o_[j]);
+        d[2] = __builtin_amdgcn_alignbyte(0u, w[j][2], o_[j]);
+        if (!rowok[j]) { d[0] = zp4; d[1] = zp4; d[2] = zp4; }
+        const int col = px[j] * P.stride - P.pad_l;
+        // columns outside the image: pixel i of the three covers bytes 3i .. 3i + 2 (only the waves at the left / right edge run this)
+        if (__builtin_amdgcn_ballot_w64(col < 0 || col + 2 >= P.W) != 0ull) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const bool in = col + i >= 0 && col + i < P.W;
@@ -351,27 +363,28 @@ __global__ __launch_bounds__(256) void q_conv0_k(const QConv0P P, const int n_fr
                 }
             }
         }
+        // (bytes 9 .. 15 of a k group and the whole of group 3 meet zero weights: what they hold does not matter -- except to the row sum)
         i4v b;
-        b[0] = (int)(d[0] ^ 0x80808080u); b[1] = (int)(d[1] ^ 0x80808080u); b[2] = (int)((d[2] ^ 0x80u) & 0xffu); b[3] = 0;
-        if (fq == 3) b = i4v{0, 0, 0, 0};
-        int rs = sdot4(b[0], 0x01010101, sdot4(b[1], 0x01010101, sdot4(b[2], 0x01010101, 0)));
-        rs += __shfl_xor(rs, 16, 64);
-        rs += __shfl_xor(rs, 32, 64);
-        rs *= P.zwc;
+        b[0] = (int)(d[0] ^ 0x80808080u); b[1] = (int)(d[1] ^ 0x80808080u); b[2] = (int)(d[2] ^ 0x80808080u); b[3] = 0;
+        int rs = 0;
+        if constexpr (!HL) {
+            if (fq == 3) { b[0] = 0; b[1] = 0; b[2] = 0; }
+            rs = sdot4(b[0], 0x01010101, sdot4(b[1], 0x01010101, sdot4(b[2] & 0xff, 0x01010101, 0)));
+            rs += __shfl_xor(rs, 16, 64);
+            rs += __shfl_xor(rs, 32, 64);
+            rs *= P.zwc;
+        }
         i4v acc0 = {0, 0, 0, 0}, acc1 = acc0;
         acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa, b, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(wb, b, acc1, 0, 0, 0);
-        unsigned lo = 0, hi = 0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            lo |= (unsigned)q_clamp(q_requant_relu(acc0[r] + rs + c0[r], M0, C0, sh0), lo0, hi0) << (8 * r);
-            hi |= (unsigned)q_clamp(q_requant_relu(acc1[r] + rs + c1[r], M0, C0, sh0), lo0, hi0) << (8 * r);
+        if constexpr (HL) {
+            acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(wal, b, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(wbl, b, acc1, 0, 0, 0);
         }
-        if (live[j]) {
-            const size_t PPo = (size_t)(P.wo + 2) * 16;
-            uint8_t *dst = P.out + (((size_t)pn[j] * (P.ho + 2) + py[j] + 1) * 2 + (fq >> 1)) * PPo + (size_t)(px[j] + 1) * 16 + (fq & 1) * 8;
-            *reinterpret_cast<uint2 *>(dst) = make_uint2(lo ^ 0x80808080u, hi ^ 0x80808080u);
-        }
+        const unsigned lo = q_requant_pack4<SAT>(acc0[0] + rs, acc0[1] + rs, acc0[2] + rs, acc0[3] + rs, M0, CQ[0], CQ[1], CQ[2], CQ[3], sh0, lo0, hi0);
+        const unsigned hi = q_requant_pack4<SAT>(acc1[0] + rs, acc1[1] + rs, acc1[2] + rs, acc1[3] + rs, M0, CQ[4], CQ[5], CQ[6], CQ[7], sh0, lo0, hi0);
+        typedef unsigned u2v __attribute__((ext_vector_type(2)));
+        __builtin_amdgcn_raw_buffer_store_b64(u2v{lo ^ 0x80808080u, hi ^ 0x80808080u}, rdst, (int)so[j], 0, 0);
     }
 }
 
@@ -1036,13 +1049,22 @@ int netq_run_op(dd_net *net, int i, const int32_t *o, const uint8_t *input, int 
             P.src = input; P.H = net->in_h; P.W = net->in_w; P.total_bytes = (long long)nimg * P.H * P.W * 3;
             P.stride = o[7]; P.pad_t = o[8]; P.pad_l = o[9]; P.ho = td->h; P.wo = td->w; P.m = nimg * P.ho * P.wo;
             P.w = reinterpret_cast<const i4v *>(W + (size_t)(uint32_t)o[16]);
-            P.cbias = reinterpret_cast<const int *>(W + (size_t)(uint32_t)o[17]);
+            P.w2 = o[18] ? reinterpret_cast<const i4v *>(W + (size_t)(uint32_t)o[18]) : nullptr;
+            P.cq = reinterpret_cast<const long long *>(W + (size_t)(uint32_t)o[46]);
             P.out = base(dst); P.in_zp = o[39]; P.zwc = o[38]; P.R = make_req(o);
+            P.out_bytes = (long long)nimg * (P.ho + 2) * 2 * (P.wo + 2) * 16;
             DD_REQUIRE(td->w >= 16, DD_E_ARG, "dd_net_forward: uint8 first layer: output narrower than a fragment");
             DD_REQUIRE(td->pad == 1 && td->cs == 32 && o[11] == 32 && (reinterpret_cast<uintptr_t>(input) & 3) == 0 && (P.total_bytes & 3) == 0 && !P.R.linear && P.R.e >= 1,
                        DD_E_ARG, "dd_net_forward: uint8 first layer: 32 channels into a bordered tensor from a 4-byte aligned batch");
             const int n_frags = dd_ceil_div(P.m, 16);
-            hipLaunchKernelGGL(q_conv0_k, dim3(dd_ceil_div(n_frags, 4 * C0F)), dim3(256), 0, s, P, n_frags);
+            DD_REQUIRE(o[46] != 0 && P.total_bytes < (1ll << 31) - 16 && P.out_bytes < (1ll << 31) - 16, DD_E_ARG, "dd_net_forward: uint8 first layer: no folded requantisation constants in the program, or a batch beyond 31-bit offsets");
+            const int sat0 = P.R.lo == 0 && P.R.hi == 255 ? (P.R.e <= 8 ? 2 : 1) : 0;
+            const dim3 grid0(dd_ceil_div(n_frags, 4 * C0F));
+#define DD_Q0(H_) do { if (sat0 == 2) hipLaunchKernelGGL((q_conv0_k<H_, 2>), grid0, dim3(256), 0, s, P, n_frags); \
+                       else if (sat0 == 1) hipLaunchKernelGGL((q_conv0_k<H_, 1>), grid0, dim3(256), 0, s, P, n_frags); \
+                       else hipLaunchKernelGGL((q_conv0_k<H_, 0>), grid0, dim3(256), 0, s, P, n_frags); } while (0)
+            if (P.w2) DD_Q0(true); else DD_Q0(false);
+#undef DD_Q0
             DD_LAUNCH_CHECK();
             return DD_OK;
         }

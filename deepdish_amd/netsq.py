@@ -87,18 +87,24 @@ def pack_conv(L, epi, chan_map=None, cout_pad=None):
 
 def pack_conv0(L):
     """First layer: one k step, k group dy = the nine (dx, channel) bytes of filter row dy; two fragments, row 4g + r of fragment m =
-    channel 8g + 4m + r."""
-    w = L['w'].astype(np.int64) - 128                       # [3][3][3][32]
+    channel 8g + 4m + r.  -> (filter bytes, lo part or None, cbias): the filter is split w - zw = hi + lo (two MFMAs on one accumulator, no
+    row sum of the window) unless zw = 128 already or a weight needs lo = 128."""
+    def frags(w333o):                                       # [3][3][3][32] int -> [2][64][16] int8
+        src = np.transpose(w333o, (3, 0, 1, 2)).reshape(32, 3, 9)
+        wk = np.zeros((32, 4, 16), np.int64)
+        wk[:, :3, :9] = src
+        f = np.arange(2)[:, None]
+        row = np.arange(16)[None, :]
+        chan = 8 * (row // 4) + 4 * f + (row % 4)
+        return np.transpose(wk[chan], (0, 2, 1, 3)).reshape(2, 64, 16).astype(np.int8)    # wk[chan]: [2][16][4][16]
+    w = L['w'].astype(np.int64)
     assert w.shape == (3, 3, 3, 32)
-    src = np.transpose(w, (3, 0, 1, 2)).reshape(32, 3, 9)
-    wk = np.zeros((32, 4, 16), np.int64)
-    wk[:, :3, :9] = src
-    f = np.arange(2)[:, None]
-    row = np.arange(16)[None, :]
-    chan = 8 * (row // 4) + 4 * f + (row % 4)
-    wf = wk[chan]                                           # [2][16][4][16]
-    packed = np.transpose(wf, (0, 2, 1, 3)).reshape(2, 64, 16)
-    return packed.astype(np.int8), _cbias(L, src.reshape(32, 27)).astype(np.int32)
+    x = w - int(L['w_zp'])
+    hi = np.clip(x, -128, 127)
+    if int(L['w_zp']) != 128 and (x - hi).max() <= 127:
+        cb = L['bias'].astype(np.int64) + (128 - int(L['in_zp'])) * x.reshape(27, 32).sum(axis=0)
+        return frags(hi), frags(x - hi), cb.astype(np.int32)
+    return frags(w - 128), None, _cbias(L, np.transpose(w - 128, (3, 0, 1, 2)).reshape(32, 27)).astype(np.int32)
 
 
 def pack_dw(L):
@@ -156,11 +162,12 @@ def compile_ssd_mobilenet_quant(qm):
     ho, pt = same_pad(size, 3, L['stride'])
     wo, pl = same_pad(size, 3, L['stride'])
     x = P.qtensor(ho, wo, 32, L['out_zp'])
-    wp, cb = pack_conv0(L)
+    wp, wl, cb = pack_conv0(L)
     raw = _req_words(L)
-    raw.update({38: 128 - int(L['w_zp']), 39: int(L['in_zp'])})
+    P.add_blob(np.zeros(16, np.uint8))                      # (offset 0 means "absent" in the op words)
+    raw.update({38: 0 if wl is not None else 128 - int(L['w_zp']), 39: int(L['in_zp']), 46: P.add_blob(folded_addends(cb, raw))})
     P._op(OP_QCONV0, dst=x, kh=3, kw=3, stride=L['stride'], pad_t=pt, pad_l=pl, cin=3, cout=32, cout_pad=32,
-          w_off=P.add_blob(wp), b_off=P.add_blob(cb), ho=ho, wo=wo, raw=raw)
+          w_off=P.add_blob(wp), b_off=P.add_blob(cb), aff_off=P.add_blob(wl) if wl is not None else 0, ho=ho, wo=wo, raw=raw)
     info('q_conv0_k', 2 * ho * wo * 27 * 32, 3 * size * size + ho * wo * 32, 27 * 32 + 4 * 32)
 
     def conv(src, name, epi=QEPI_Q16, dst=None, chan_map=None, cout_pad=None, row_bytes=0, base_off=0, cout_store=0):
