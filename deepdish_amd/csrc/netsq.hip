@@ -618,7 +618,7 @@ constexpr int QT = 64;               // pixels per tile
 // accumulator instead of one MFMA plus the zwc * rowsum correction: for the layers with few input channels the matrix pipe has the time
 // and the row-sum machinery (dot products, cross-lane sums, LDS atomics, an add per output) goes.
 template <int CIN, int COUT, int WP, int STRIDE, int LPT, bool ROWSUM, int MW = 4, int SAT = 0, bool HL = false>
-__global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64, 2) void q_dwpw_k(const QDwpwP P, const int n_tiles, const int tiles_per_block) {
+__global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64, (COUT / (16 * MW)) * WP <= 2 ? 3 : 2) void q_dwpw_k(const QDwpwP P, const int n_tiles, const int tiles_per_block) {
     constexpr int WM = COUT / (16 * MW), NW = WM * WP, NT = NW * 64;
     static_assert(MW == 4 || MW == 2, "fragments per wave");
     static_assert(!(HL && ROWSUM), "the split filter needs no row sums");
@@ -929,9 +929,21 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64, 2) void q_dwpw_k(cons
         }
         matrix(q0, q1, cur, cur);
         Q_STAMP(2);
-        __builtin_amdgcn_s_waitcnt(0x0f70);                      // vmcnt(0): this wave's pieces of the ring have landed (stamped apart from the barrier)
+        // This wave's pieces of the ring have landed: they were requested BEFORE the matrix stage's output stores and the vector-memory counter
+        // retires in issue order, so the wait leaves as many operations outstanding as the wave stored fragments -- vmcnt(0) here also waited
+        // for the stores' write acknowledgements (0.8 k cycles per tile in the 32-channel block).  The barrier is the bare instruction:
+        // __syncthreads() would drain the counter again.
+        {
+            const int nf_t = (q1 - q0) / 16 + 1, ns = nf_t > wp ? (nf_t - wp + WP - 1) / WP : 0;     // (wave-uniform) fragments this wave stored
+            if (ns >= 4) __builtin_amdgcn_s_waitcnt(0x0f74);
+            else if (ns == 3) __builtin_amdgcn_s_waitcnt(0x0f73);
+            else if (ns == 2) __builtin_amdgcn_s_waitcnt(0x0f72);
+            else if (ns == 1) __builtin_amdgcn_s_waitcnt(0x0f71);
+            else __builtin_amdgcn_s_waitcnt(0x0f70);
+        }
         Q_STAMP(3);
-        __syncthreads();                                         // B: the operand tile is free, the ring holds the next tile's rows (every wave waited for its pieces)
+        __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0): this wave's LDS traffic is done
+        __builtin_amdgcn_s_barrier();                            // B: the operand tile is free, the ring holds the next tile's rows (every wave waited for its pieces)
         Q_STAMP(4);
         n = n2; q0 = q02; q1 = q12;
     }
