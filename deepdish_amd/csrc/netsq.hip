@@ -817,12 +817,21 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64, (COUT / (16 * MW)) * 
     // in the ring (slot = row % NR, pitch RB): byte idx of the request goes to ring byte (slot(lo) * RB + idx) mod ring size.  One
     // wave-instruction moves 1 KB lane-linearly to a wave-uniform LDS base; a piece that straddles the end of the ring is issued twice with
     // complementary lane masks (the second base lies below the ring: the operand tile is there, the addresses the active lanes form are not).
-    auto pf_issue = [&](int lo, unsigned nb) {
-        if (!nb) return;
+    // The statement is assembly, not the builtin: hipcc would make every later ds_read that may alias an LDS-DMA in flight wait for it
+    // (s_waitcnt vmcnt(0) at the head of the depthwise stage), and the rows requested BEFORE that stage -- into slots the current tile no
+    // longer reads, see the tile loop -- are to stay in flight through it.  The waits are this kernel's own, at barrier B.  (M0, the
+    // destination base, is the compiler's register: saved and restored in the statement that uses it.)
+    auto glds16 = [&](const uint8_t *g, const uint8_t *l) {
+        unsigned keep;
+        const unsigned dst = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)l;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+    };
+    auto pf_issue = [&](int lo, int hi) {                            // rows [lo, hi]
+        if (hi < lo) return;
+        const unsigned nb = (unsigned)(hi - lo + 1) * (unsigned)RB;
         const uint8_t *src = P.in + (size_t)lo * RB;
         const unsigned base = (unsigned)(lo - (int)__umulhi((unsigned)lo, P.nr_magic) * P.NR) * (unsigned)RB;
-        typedef const __attribute__((address_space(1))) void *gptr_t;
-        typedef __attribute__((address_space(3))) void *lptr_t;
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
             const unsigned cb = (unsigned)(i * NW + wave) * 1024u;  // (wave-uniform) this wave's piece of the request
@@ -832,11 +841,11 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64, (COUT / (16 * MW)) * 
                 const unsigned idx = cb + (unsigned)lane * 16u;
                 const uint8_t *g = src + idx;
                 if (a + 1024u <= ring_bytes) {
-                    if (idx < nb) __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(ring + a), 16, 0, 0);
+                    if (idx < nb) glds16(g, ring + a);
                 } else {
                     const bool first = a + (unsigned)lane * 16u < ring_bytes;
-                    if (idx < nb && first) __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(ring + a), 16, 0, 0);
-                    if (idx < nb && !first) __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(ring + (int)(a - ring_bytes)), 16, 0, 0);
+                    if (idx < nb && first) glds16(g, ring + a);
+                    if (idx < nb && !first) glds16(g, ring + (int)(a - ring_bytes));
                 }
             }
         }
@@ -909,20 +918,28 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64, (COUT / (16 * MW)) * 
 #define Q_STAMP(k) do { if (P.dbg) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st[k] += now_ - tprev; tprev = now_; } } while (0)
 
     for (int t = t_begin; t < t_end; ++t) {
-        int lo = 0; unsigned nb = 0;
+        // The rows tile t + 1 adds.  Those whose ring slot holds a row BELOW this tile's first one (the ring is P.NR >= the largest span of one
+        // tile; the launcher adds rows where LDS allows) are requested now and fly through both stages; the others wait for barrier A, when
+        // the depthwise stage has read the rows they replace.  One tile's worth of requests in flight during the matrix stage only left HBM
+        // idle half of the time.  (Measured: neutral -- with the stores or the requests removed the stride-2 blocks run in 124 / 132 us against 208 with
+        // both: they move their 829 MB at the 4.0-4.2 TB/s every streaming kernel of this network reaches, extra ring rows (DD_Q_EXTRA) change nothing.)
+        int lo = 0, hi = -1, e_hi = -1;
         int n2 = 0, q02 = 0, q12 = 0, ga2 = 0, gb2 = 0;
         if (t + 1 < t_end) {
             tile_rows(t + 1, n2, q02, q12, ga2, gb2);
             lo = max(loaded_hi + 1, ga2);
-            nb = gb2 >= lo ? (unsigned)(gb2 - lo + 1) * RB : 0u;
+            hi = gb2;
+            e_hi = min(hi, ga + P.NR - 1);
             loaded_hi = max(loaded_hi, gb2);
         }
+        pf_issue(lo, e_hi);
         const int cur = t & 1;
         dw_planes(cur, cur);
         Q_STAMP(0);
-        __syncthreads();                                         // A: operand tile and row sums are complete; the ring is free
+        __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0): this wave's part of the operand tile and of the row sums is written
+        __builtin_amdgcn_s_barrier();                            // A: operand tile and row sums are complete; the ring is free (bare: requests stay in flight)
         Q_STAMP(1);
-        pf_issue(lo, nb);                                        // the next tile's rows: on their way into the ring while the matrix stage runs
+        pf_issue(max(lo, e_hi + 1), hi);                         // the rest of the next tile's rows
         if (tid < QT) {
             if (ROWSUM) rowsum[(cur ^ 1) * QT + tid] = 0;
             if (t + 1 < t_end) geometry(n2, q02, q12, ga2, cur ^ 1);
@@ -945,7 +962,7 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64, (COUT / (16 * MW)) * 
         __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0): this wave's LDS traffic is done
         __builtin_amdgcn_s_barrier();                            // B: the operand tile is free, the ring holds the next tile's rows (every wave waited for its pieces)
         Q_STAMP(4);
-        n = n2; q0 = q02; q1 = q12;
+        n = n2; q0 = q02; q1 = q12; ga = ga2;
     }
 #undef Q_STAMP
     if (P.dbg && lane == 0) for (int k = 0; k < 5; ++k) P.dbg[((size_t)blockIdx.x * NW + wave) * 8 + k] = st[k];
@@ -976,11 +993,13 @@ void dwpw_plan(int H, int W, int ho, int wo, int stride, int off_y, int cin, int
     *lpt = (int)(((long long)mx * RB + (long long)nt * 16 - 1) / ((long long)nt * 16));
 }
 
-template <int CIN, int COUT, int WP, int STRIDE, int LPT, int MW = 4>
+template <int CIN, int COUT, int WP, int STRIDE, int LPT, int EXTRA = 0, int MW = 4>
 int launch_q_dwpw(hipStream_t s, QDwpwP &P, int nimg, int device, bool *ok) {
     constexpr int NW = (COUT / (16 * MW)) * WP, NT = NW * 64, CINP = (CIN + 63) / 64 * 64;
     int lpt = 0;
     dwpw_plan(P.H, P.W, P.ho, P.wo, STRIDE, P.off_y, CIN, NT, &P.NR, &lpt);
+    static const int extra_env = getenv("DD_Q_EXTRA") ? atoi(getenv("DD_Q_EXTRA")) : -1;
+    P.NR += extra_env >= 0 ? extra_env : EXTRA;                   // ring rows beyond one tile's span: the next tile's rows can be requested a stage earlier
     const int RB = (P.W + 2) * CIN;
     constexpr bool KEEP = (CIN / 16) / NW <= 2;                       // (as in the kernel) else the depthwise tables take LDS
     const size_t lds = (size_t)P.NR * RB + (size_t)QT * CINP + (size_t)2 * QT * sizeof(int) + 2 * QT * 16 + COUT * sizeof(int) + (KEEP ? 0 : (CIN / 16) * 64 * 8 + CIN * 8);
