@@ -116,6 +116,27 @@ __device__ __forceinline__ unsigned q_requant_pack4(int x0, int x1, int x2, int 
     }
 }
 
+// The same for a layer without activation (the SSD heads), clamp = the byte range, e >= 1: the literal two roundings
+//     y = (x M + 2^30) >> 31,   z = ((y + 2^(e-1) + (y >> 31)) >> e) + zo  =  (y + [2^(e-1) + (zo << e)] + (y >> 31)) >> e
+// with the bias in the 64-bit addend (C = cbias * M + 2^30 per channel) and the clamp in the saturating packs: 5 instructions per value
+// + 5 per four (q_requant's statement of the same arithmetic: 11 per value).
+__device__ __forceinline__ unsigned q_requant_linear_pack4(int x0, int x1, int x2, int x3, int M, long long C0, long long C1, long long C2, long long C3, int e, int k1) {
+    int z[4];
+    const int x[4] = {x0, x1, x2, x3};
+    const long long C[4] = {C0, C1, C2, C3};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int y = (int)(((long long)x[i] * M + C[i]) >> 31);
+        z[i] = (y + k1 + (y >> 31)) >> e;
+    }
+    unsigned p01, p23, q01, q23;
+    asm("v_cvt_pk_i16_i32 %0, %1, %2" : "=v"(p01) : "v"(z[0]), "v"(z[1]));
+    asm("v_cvt_pk_i16_i32 %0, %1, %2" : "=v"(p23) : "v"(z[2]), "v"(z[3]));
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(q01) : "v"(p01));
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(q23) : "v"(p23));
+    return __builtin_amdgcn_perm(q23, q01, 0x05040100u);
+}
+
 __device__ __forceinline__ int sdot4(int a, int b, int c) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_sdot4(a, b, c, false);
@@ -1062,6 +1083,217 @@ int launch_q_dwpw(hipStream_t s, QDwpwP &P, int nimg, int device, bool *ok) {
     return DD_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ pointwise layer, filter in registers
+// 1x1 stride-1 layers with 512 or 1024 input channels after block 11 (b12 / b13 pointwise, the first extra layer, the two big class
+// predictors: 245 of the tail's 285 GFLOP).  q_conv_k reads both operands of every MFMA from L2 in fragment shape -- 8 KB per 16 MFMAs and
+// wave, the L1 path's 64 B per cycle and CU bound it at a quarter of the matrix rate (0.6-0.9 POP/s measured).  Here, as in q_dwpw_k's
+// matrix stage (3.2 POP/s while it runs), a wave keeps the A fragments of its MW * 16 output channels for all of K in registers (128 VGPRs:
+// MW = 4 at K = 512, MW = 2 at K = 1024) and the pixels come through LDS: tiles of 64 pixels as the B-fragment image [plane][pixel][16],
+// filled by LDS-DMA with per-lane source addresses (lane = pixel, one wave instruction = one plane of the tile = 1 KB; the bordered layout
+// makes a pixel's 16 channels of a plane one aligned 16-byte piece), two tiles deep, ONE barrier per tile.  Row sums (zw != 128) come off
+// the matrix pipe as well: an A fragment of ones accumulates sum_k b into every row of a fifth accumulator, whose column is the lane's pixel.
+struct QPwsP {
+    const uint8_t *in; int H, W, c16_in;          // Q16 source; the layer's output has the same H x W
+    int hw, m;                                    // H * W, images * H * W
+    const i4v *w;                                 // [n_mfrag][K / 64][64 lanes]
+    const int *cbias;                             // [16 * n_mfrag]
+    const long long *cq;                          // [16 * n_mfrag]: cbias * M + C (Q16 epilogue)
+    int n_mfrag, frags_per_group;                 // fragments in all; per block (= waves * MW)
+    uint8_t *out; int c16_out;                    // QEPI_Q16
+    long long img_bytes_out; int row_bytes, base_off, cout_store;   // QEPI_ROWS
+    int zwc, tiles_per_block;
+    unsigned hw_magic, w_magic;
+    QReq R;
+};
+
+template <int K, int MW, int EPI, bool ROWSUM, int SAT>
+__global__ __launch_bounds__(512, 2) void q_pws_k(const QPwsP P, const int n_tiles) {
+    constexpr int KC = K / 64, C16 = K / 16;
+    static_assert(MW * KC * 4 <= 128, "the wave's filter is 128 registers at most");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *opnd = smem;                                            // [2][C16][QT][16]
+    unsigned *psrc = reinterpret_cast<unsigned *>(smem + 2 * QT * K);   // [4][QT]: the pixel's offset in the source (plane 0)
+    unsigned *pdst = psrc + 4 * QT;                                  // [4][QT]: its offset in the destination, ~0 past the end
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), NW = blockDim.x >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int frag0 = blockIdx.y * P.frags_per_group + wave * MW;     // this wave's first fragment
+    const unsigned PP = (unsigned)(P.W + 2) * 16u;
+
+    i4v Wr[MW][KC];
+#pragma unroll
+    for (int m = 0; m < MW; ++m)
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) Wr[m][kc] = frag0 + m < P.n_mfrag ? P.w[((size_t)(frag0 + m) * KC + kc) * 64 + lane] : i4v{0, 0, 0, 0};
+    const int M = P.R.M, sh = P.R.e - 1, lo = P.R.lo, hi = P.R.hi;
+    // Q16: fragment 4 mg + m holds channels 64 mg + 16 g + 4 m + r (MW = 2: the wave's pair is half of such a group)
+    const int mg = frag0 / 4, m0 = frag0 % 4;
+    // per-channel 64-bit addends (Q16: cbias * M + C of the ReLU form, channel order of the fragment rows; ROWS: cbias * M + 2^30, natural order)
+    long long CQ[MW][4];
+#pragma unroll
+    for (int m = 0; m < MW; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ch = EPI == QEPI_Q16 ? 64 * mg + 16 * fq + 4 * (m0 + m) + r : 16 * (frag0 + m) + 4 * fq + r;
+            CQ[m][r] = frag0 + m < P.n_mfrag ? P.cq[ch] : 0ll;
+        }
+    const int e_lin = P.R.e, k1_lin = (1 << (P.R.e - 1)) + (P.R.zo << P.R.e);
+    int n_store_m = 0;                                               // ROWS: fragments of this wave that store anything
+#pragma unroll
+    for (int m = 0; m < MW; ++m) n_store_m += 16 * (frag0 + m) < P.cout_store ? 1 : 0;
+    const i4v ones = {0x01010101, 0x01010101, 0x01010101, 0x01010101};
+
+    const int t_begin = blockIdx.x * P.tiles_per_block, t_end = min(n_tiles, t_begin + P.tiles_per_block);
+    if (t_begin >= t_end) return;
+    auto geometry = [&](int t) {                                     // threads 0 .. QT - 1
+        const int q = t * QT + tid, qc = min(q, P.m - 1);
+        const int n = (int)__umulhi((unsigned)qc, P.hw_magic), r = qc - n * P.hw;
+        const int y = (int)__umulhi((unsigned)r, P.w_magic), x = r - y * P.W;
+        const unsigned row = (unsigned)(n * (P.H + 2) + y + 1);
+        psrc[(t & 3) * QT + tid] = row * (unsigned)P.c16_in * PP + (unsigned)(x + 1) * 16u;
+        unsigned d;
+        if constexpr (EPI == QEPI_Q16) d = row * (unsigned)P.c16_out * PP + (unsigned)(x + 1) * 16u;
+        else d = (unsigned)((long long)n * P.img_bytes_out) + (unsigned)P.base_off + (unsigned)r * (unsigned)P.row_bytes;
+        pdst[(t & 3) * QT + tid] = q < P.m ? d : 0xffffffffu;
+    };
+    auto fill = [&](int t) {                                         // tile t's bytes on their way: plane c of the tile = one wave instruction
+        const uint8_t *src = P.in + psrc[(t & 3) * QT + lane];
+        uint8_t *dst = opnd + (size_t)(t & 1) * QT * K;
+        for (int c = wave; c < C16; c += NW) {
+            unsigned keep;
+            const unsigned l = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)(dst + (size_t)c * QT * 16);
+            const uint8_t *g = src + (size_t)c * PP;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(g), "s"(l) : "memory");
+        }
+    };
+
+    if (tid < QT) { geometry(t_begin); if (t_begin + 1 < t_end) geometry(t_begin + 1); }
+    __syncthreads();
+    fill(t_begin);
+    int ns_prev = 0;                                                 // vector stores this wave issued since its last fill
+    for (int t = t_begin; t < t_end; ++t) {
+        // tile t has landed (this wave's planes: they were requested before the stores counted in ns_prev; the counter retires in order)
+        switch (ns_prev) {
+#define DD_VMCNT(N_) case N_: __builtin_amdgcn_s_waitcnt(0x0f70 | ((N_) & 15) | (((N_) >> 4) << 14)); break;
+            DD_VMCNT(1) DD_VMCNT(2) DD_VMCNT(3) DD_VMCNT(4) DD_VMCNT(5) DD_VMCNT(6) DD_VMCNT(7) DD_VMCNT(8)
+            DD_VMCNT(9) DD_VMCNT(10) DD_VMCNT(11) DD_VMCNT(12) DD_VMCNT(13) DD_VMCNT(14) DD_VMCNT(15) DD_VMCNT(16)
+#undef DD_VMCNT
+            default: __builtin_amdgcn_s_waitcnt(0x0f70);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                          // (and this wave's LDS reads of tile t - 1, its geometry writes)
+        __builtin_amdgcn_s_barrier();                                // every wave's planes of tile t are in; tile t - 1's buffer is free
+        if (t + 1 < t_end) fill(t + 1);
+        if (t + 2 < t_end && tid < QT) geometry(t + 2);
+        const uint8_t *ob = opnd + (size_t)(t & 1) * QT * K;
+        const int nf = (min((t + 1) * QT, P.m) - t * QT + 15) / 16;
+        constexpr int KB = KC < 4 ? KC : 4;
+        i4v b[KB];
+        {
+            const uint8_t *bp = ob + ((size_t)fq * QT + fr) * 16;
+#pragma unroll
+            for (int kc = 0; kc < KB; ++kc) b[kc] = *reinterpret_cast<const i4v *>(bp + (size_t)kc * 4 * QT * 16);
+        }
+        ns_prev = 0;
+        for (int f = 0; f < nf; ++f) {
+            i4v acc[MW], ars = {0, 0, 0, 0};
+#pragma unroll
+            for (int m = 0; m < MW; ++m) acc[m] = i4v{0, 0, 0, 0};
+            const uint8_t *bp = ob + ((size_t)fq * QT + 16 * f + fr) * 16;
+#pragma unroll
+            for (int k0 = 0; k0 < KC; k0 += KB) {
+#pragma unroll
+                for (int kc = 0; kc < KB; ++kc) {
+#pragma unroll
+                    for (int m = 0; m < MW; ++m) acc[m] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Wr[m][k0 + kc], b[kc], acc[m], 0, 0, 0);
+                    if constexpr (ROWSUM) ars = __builtin_amdgcn_mfma_i32_16x16x64_i8(ones, b[kc], ars, 0, 0, 0);
+                }
+                if (k0 + KB < KC) {
+#pragma unroll
+                    for (int kc = 0; kc < KB; ++kc) b[kc] = *reinterpret_cast<const i4v *>(bp + (size_t)(k0 + KB + kc) * 4 * QT * 16);
+                }
+            }
+            if (f + 1 < nf) {
+                const uint8_t *bn = ob + ((size_t)fq * QT + 16 * (f + 1) + fr) * 16;
+#pragma unroll
+                for (int kc = 0; kc < KB; ++kc) b[kc] = *reinterpret_cast<const i4v *>(bn + (size_t)kc * 4 * QT * 16);
+            }
+            const int rsv = ROWSUM ? ars[0] * P.zwc : 0;
+            const unsigned po = pdst[(t & 3) * QT + 16 * f + fr];
+            if constexpr (EPI == QEPI_Q16) {
+                unsigned o[MW];
+#pragma unroll
+                for (int m = 0; m < MW; ++m)
+                    o[m] = 0x80808080u ^ q_requant_pack4<SAT>(acc[m][0] + rsv, acc[m][1] + rsv, acc[m][2] + rsv, acc[m][3] + rsv, M, CQ[m][0], CQ[m][1], CQ[m][2], CQ[m][3], sh, lo, hi);
+                if (po != 0xffffffffu && frag0 < P.n_mfrag) {
+                    uint8_t *dst = P.out + po + (size_t)(4 * mg + fq) * PP + 4 * m0;
+                    if constexpr (MW == 4) *reinterpret_cast<u4v *>(dst) = u4v{o[0], o[1], o[2], o[3]};
+                    else *reinterpret_cast<uint2 *>(dst) = make_uint2(o[0], o[1]);
+                }
+                if (frag0 < P.n_mfrag) ++ns_prev;
+            } else {
+#pragma unroll
+                for (int m = 0; m < MW; ++m) {
+                    const int ch = 16 * (frag0 + m) + 4 * fq;
+                    if (ch >= P.cout_store) continue;
+                    const unsigned wv = q_requant_linear_pack4(acc[m][0] + rsv, acc[m][1] + rsv, acc[m][2] + rsv, acc[m][3] + rsv, M, CQ[m][0], CQ[m][1], CQ[m][2], CQ[m][3], e_lin, k1_lin);
+                    if (po != 0xffffffffu) *reinterpret_cast<unsigned *>(P.out + po + ch) = wv;
+                }
+                ns_prev += n_store_m;
+            }
+        }
+    }
+}
+
+// Shapes q_pws_k takes; *ok = false leaves the layer to q_conv_k.
+template <int K, int MW>
+int launch_q_pws(hipStream_t s, QPwsP &P, int nimg, int device, bool *ok) {
+    const int n_tiles = dd_ceil_div(P.m, QT);
+    const int waves = std::min(8, dd_ceil_div(P.n_mfrag, MW));         // per block; the fragments split evenly over the groups
+    const int groups = dd_ceil_div(P.n_mfrag, waves * MW);
+    const int wpb = dd_ceil_div(dd_ceil_div(P.n_mfrag, groups), MW);  // waves per block
+    P.frags_per_group = wpb * MW;
+    const size_t lds = (size_t)2 * QT * K + 8 * QT * sizeof(unsigned);
+    const int blocks_x = std::max(1, std::min(n_tiles, 256 / groups));
+    P.tiles_per_block = dd_ceil_div(n_tiles, blocks_x);
+    P.hw_magic = (unsigned)((1ull << 32) / (unsigned)P.hw) + 1u;
+    P.w_magic = (unsigned)((1ull << 32) / (unsigned)P.W) + 1u;
+    const long long in_bytes = (long long)nimg * (P.H + 2) * P.c16_in * (P.W + 2) * 16;
+    const long long out_bytes = P.img_bytes_out ? (long long)nimg * P.img_bytes_out : (long long)nimg * (P.H + 2) * P.c16_out * (P.W + 2) * 16;
+    *ok = in_bytes < (1ll << 32) && out_bytes < (1ll << 32) && (long long)P.m * P.hw < (1ll << 32) && (long long)P.hw * P.W < (1ll << 32) && P.zwc >= -128 && P.zwc <= 128 &&
+          lds <= 160 * 1024 && wpb >= 1 && wpb <= 8;
+    if (!*ok) return DD_OK;
+    const bool rsum = P.zwc != 0;
+    const bool rows = P.img_bytes_out != 0;
+    if (rows && !(P.R.linear && P.R.e >= 1 && P.R.e <= 30 && P.R.lo == 0 && P.R.hi == 255 && std::abs(P.R.zo) < 256)) { *ok = false; return DD_OK; }
+    const int sat = !rows && P.R.lo == 0 && P.R.hi == 255 ? (P.R.e <= 8 ? 2 : 1) : 0;
+    void (*kern)(const QPwsP, const int) = nullptr;
+#define DD_PW(E_, R_, S_) q_pws_k<K, MW, E_, R_, S_>
+    if (rows) kern = rsum ? &DD_PW(QEPI_ROWS, true, 0) : &DD_PW(QEPI_ROWS, false, 0);
+    else if constexpr (MW != 3) {
+        if (sat == 2) kern = rsum ? &DD_PW(QEPI_Q16, true, 2) : &DD_PW(QEPI_Q16, false, 2);
+        else if (sat == 1) kern = rsum ? &DD_PW(QEPI_Q16, true, 1) : &DD_PW(QEPI_Q16, false, 1);
+        else kern = rsum ? &DD_PW(QEPI_Q16, true, 0) : &DD_PW(QEPI_Q16, false, 0);
+    }
+    if (!kern) { *ok = false; return DD_OK; }
+    static DevOnce once;
+    const int rc = once.run(device, [&]() -> int {
+        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&DD_PW(QEPI_ROWS, true, 0)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&DD_PW(QEPI_ROWS, false, 0)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if constexpr (MW != 3) {
+            for (const void *f : {reinterpret_cast<const void *>(&DD_PW(QEPI_Q16, true, 2)), reinterpret_cast<const void *>(&DD_PW(QEPI_Q16, false, 2)),
+                                  reinterpret_cast<const void *>(&DD_PW(QEPI_Q16, true, 1)), reinterpret_cast<const void *>(&DD_PW(QEPI_Q16, false, 1)),
+                                  reinterpret_cast<const void *>(&DD_PW(QEPI_Q16, true, 0)), reinterpret_cast<const void *>(&DD_PW(QEPI_Q16, false, 0))})
+                DD_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        }
+        return DD_OK;
+    });
+#undef DD_PW
+    if (rc != DD_OK) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)dd_ceil_div(n_tiles, P.tiles_per_block), (unsigned)groups), dim3((unsigned)wpb * 64), lds, s, P, n_tiles);
+    DD_LAUNCH_CHECK();
+    return DD_OK;
+}
+
 }  // namespace
 
 int netq_prepare(dd_net *) { return DD_OK; }
@@ -1121,6 +1353,23 @@ int netq_run_op(dd_net *net, int i, const int32_t *o, const uint8_t *input, int 
                 DD_REQUIRE(!td->pad && P.row_bytes % 4 == 0 && P.base_off % 4 == 0 && P.cout_store % 4 == 0 && P.cout_store <= P.row_bytes &&
                            (long long)P.base_off + (long long)P.ho * P.wo * P.row_bytes <= P.img_bytes_out, DD_E_ARG, "dd_net_forward: uint8 conv %d: row output geometry", i);
                 P.mq = std::min(4, P.n_mfrag);
+            }
+            // 1x1 stride-1 layers with 512 / 1024 input channels and pixels enough: the filter in registers, the pixels through LDS (q_pws_k)
+            static const int pws_env = getenv("DD_Q_PWS") ? atoi(getenv("DD_Q_PWS")) : 1;
+            if (pws_env && P.kh == 1 && P.kw == 1 && P.stride == 1 && P.off_y == 1 && P.off_x == 1 && (ts->cs == 512 || ts->cs == 1024) && P.m >= 8192 && P.n_mfrag >= 8 &&
+                o[46] != 0 && (P.epi == QEPI_ROWS || (!P.R.linear && P.R.e >= 1))) {
+                QPwsP Q;
+                memset(&Q, 0, sizeof(Q));
+                Q.in = P.in; Q.H = P.H; Q.W = P.W; Q.c16_in = P.c16_in; Q.hw = P.ho * P.wo; Q.m = P.m;
+                Q.w = P.w; Q.cbias = P.cbias; Q.cq = reinterpret_cast<const long long *>(W + (size_t)(uint32_t)o[46]);
+                Q.n_mfrag = P.n_mfrag; Q.out = P.out; Q.c16_out = P.c16_out; Q.zwc = P.zwc; Q.R = P.R;
+                if (P.epi == QEPI_ROWS) { Q.img_bytes_out = P.img_bytes_out; Q.row_bytes = P.row_bytes; Q.base_off = P.base_off; Q.cout_store = P.cout_store; }
+                bool ok = false;
+                // (the 19x19 class predictor has 18 fragments: six waves of three load the SIMDs 6 / 6 / 3 / 3, five of four 8 / 4 / 4 / 2)
+                const int rc = ts->cs == 512 ? (P.epi == QEPI_ROWS && P.n_mfrag % 3 == 0 && P.n_mfrag % 4 != 0 ? launch_q_pws<512, 3>(s, Q, nimg, net->ctx->device, &ok) : launch_q_pws<512, 4>(s, Q, nimg, net->ctx->device, &ok))
+                                             : launch_q_pws<1024, 2>(s, Q, nimg, net->ctx->device, &ok);
+                if (rc != DD_OK) return rc;
+                if (ok) return DD_OK;
             }
             const int n_mgroups = dd_ceil_div(P.n_mfrag, P.mq);
             // Pixel fragments per wave item.  Two by default; four (half the weight fetches per MFMA, twice the registers) where the launch has

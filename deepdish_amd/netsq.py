@@ -181,6 +181,8 @@ def compile_ssd_mobilenet_quant(qm):
             dst = P.qtensor(ho, wo, L['w'].shape[3], L['out_zp'])
         raw = _req_words(L)
         raw.update({38: 128 - int(L['w_zp']), 39: int(L['in_zp']), 42: row_bytes, 43: base_off, 44: cout_store})
+        # the per-channel 64-bit requantisation addends (q_pws_k): cbias * M + C of the ReLU form, or + 2^30 (the first rounding) without activation
+        raw[46] = P.add_blob(folded_addends(cb, raw) if not raw[41] else np.array([int(v) * int(raw[32]) + (1 << 30) for v in cb], dtype=np.int64))
         P._op(OP_QCONV, src=src, dst=dst, kh=kh, kw=kh, stride=L['stride'], pad_t=pt, pad_l=pl, cin=s['c'], cout=L['w'].shape[3],
               cout_pad=len(cb), kpad=kcpt, epi=epi, w_off=P.add_blob(wp), b_off=P.add_blob(cb), ho=ho, wo=wo, raw=raw)
         cin, cout = L['w'].shape[2:]
