@@ -1114,6 +1114,7 @@ __global__ __launch_bounds__(512, 2) void q_pws_k(const QPwsP P, const int n_til
     uint8_t *opnd = smem;                                            // [2][C16][QT][16]
     unsigned *psrc = reinterpret_cast<unsigned *>(smem + 2 * QT * K);   // [4][QT]: the pixel's offset in the source (plane 0)
     unsigned *pdst = psrc + 4 * QT;                                  // [4][QT]: its offset in the destination, ~0 past the end
+    int *rowsum = reinterpret_cast<int *>(pdst + 4 * QT);            // [3][QT]: sum over k of the pixel's operand bytes (ROWSUM)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), NW = blockDim.x >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int frag0 = blockIdx.y * P.frags_per_group + wave * MW;     // this wave's first fragment
@@ -1140,7 +1141,6 @@ __global__ __launch_bounds__(512, 2) void q_pws_k(const QPwsP P, const int n_til
     int n_store_m = 0;                                               // ROWS: fragments of this wave that store anything
 #pragma unroll
     for (int m = 0; m < MW; ++m) n_store_m += 16 * (frag0 + m) < P.cout_store ? 1 : 0;
-    const i4v ones = {0x01010101, 0x01010101, 0x01010101, 0x01010101};
 
     const int t_begin = blockIdx.x * P.tiles_per_block, t_end = min(n_tiles, t_begin + P.tiles_per_block);
     if (t_begin >= t_end) return;
@@ -1160,30 +1160,50 @@ __global__ __launch_bounds__(512, 2) void q_pws_k(const QPwsP P, const int n_til
         uint8_t *dst = opnd + (size_t)(t & 1) * QT * K;
         for (int c = wave; c < C16; c += NW) {
             unsigned keep;
-            const unsigned l = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)(dst + (size_t)c * QT * 16);
+            const unsigned l = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)(dst + (size_t)c * QT * 16));   // (wave-uniform: say so)
             const uint8_t *g = src + (size_t)c * PP;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(g), "s"(l) : "memory");
         }
     };
 
-    if (tid < QT) { geometry(t_begin); if (t_begin + 1 < t_end) geometry(t_begin + 1); }
-    __syncthreads();
-    fill(t_begin);
-    int ns_prev = 0;                                                 // vector stores this wave issued since its last fill
-    for (int t = t_begin; t < t_end; ++t) {
-        // tile t has landed (this wave's planes: they were requested before the stores counted in ns_prev; the counter retires in order)
-        switch (ns_prev) {
+    // Row sums: every wave adds up the planes IT requested (64 pixels x 16 bytes each: lane = pixel) once its own requests have landed --
+    // no barrier needed for that -- and adds the partial sums into the tile's slot of a three-slot ring (zeroed two tiles ahead, read one
+    // barrier later).  An A fragment of ones on the matrix pipe gave the same numbers for 25 % (K = 512) / 50 % (K = 1024) more MFMAs.
+    auto own_rowsum = [&](int t, int slot) {
+        const uint8_t *ob = opnd + (size_t)(t & 1) * QT * K;
+        int a = 0;
+        for (int c = wave; c < C16; c += NW) {
+            const i4v v = *reinterpret_cast<const i4v *>(ob + ((size_t)c * QT + lane) * 16);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) a = sdot4(v[d], 0x01010101, a);
+        }
+        atomicAdd(&rowsum[slot * QT + lane], a);
+    };
+    auto wait_landed = [&](int ns) {                                 // this wave's requests have landed: they precede its last ns stores, the counter retires in order
+        switch (ns) {
 #define DD_VMCNT(N_) case N_: __builtin_amdgcn_s_waitcnt(0x0f70 | ((N_) & 15) | (((N_) >> 4) << 14)); break;
             DD_VMCNT(1) DD_VMCNT(2) DD_VMCNT(3) DD_VMCNT(4) DD_VMCNT(5) DD_VMCNT(6) DD_VMCNT(7) DD_VMCNT(8)
             DD_VMCNT(9) DD_VMCNT(10) DD_VMCNT(11) DD_VMCNT(12) DD_VMCNT(13) DD_VMCNT(14) DD_VMCNT(15) DD_VMCNT(16)
 #undef DD_VMCNT
             default: __builtin_amdgcn_s_waitcnt(0x0f70);
         }
+    };
+    if (tid < QT) { geometry(t_begin); if (t_begin + 1 < t_end) geometry(t_begin + 1); }
+    for (int i = tid; i < 3 * QT; i += blockDim.x) rowsum[i] = 0;
+    __syncthreads();
+    fill(t_begin);
+    wait_landed(0);
+    int slot = 0;                                                    // (t - t_begin) % 3
+    if constexpr (ROWSUM) own_rowsum(t_begin, 0);
+    int ns_prev = 0;                                                 // vector stores this wave issued since its last fill
+    for (int t = t_begin; t < t_end; ++t) {
         __builtin_amdgcn_s_waitcnt(0xc07f);                          // (and this wave's LDS reads of tile t - 1, its geometry writes)
         __builtin_amdgcn_s_barrier();                                // every wave's planes of tile t are in; tile t - 1's buffer is free
         if (t + 1 < t_end) fill(t + 1);
         if (t + 2 < t_end && tid < QT) geometry(t + 2);
+        const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot1 == 2 ? 0 : slot1 + 1;
+        if (ROWSUM && tid < QT) rowsum[slot2 * QT + tid] = 0;
         const uint8_t *ob = opnd + (size_t)(t & 1) * QT * K;
         const int nf = (min((t + 1) * QT, P.m) - t * QT + 15) / 16;
         constexpr int KB = KC < 4 ? KC : 4;
@@ -1195,7 +1215,7 @@ __global__ __launch_bounds__(512, 2) void q_pws_k(const QPwsP P, const int n_til
         }
         ns_prev = 0;
         for (int f = 0; f < nf; ++f) {
-            i4v acc[MW], ars = {0, 0, 0, 0};
+            i4v acc[MW];
 #pragma unroll
             for (int m = 0; m < MW; ++m) acc[m] = i4v{0, 0, 0, 0};
             const uint8_t *bp = ob + ((size_t)fq * QT + 16 * f + fr) * 16;
@@ -1205,7 +1225,6 @@ __global__ __launch_bounds__(512, 2) void q_pws_k(const QPwsP P, const int n_til
                 for (int kc = 0; kc < KB; ++kc) {
 #pragma unroll
                     for (int m = 0; m < MW; ++m) acc[m] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Wr[m][k0 + kc], b[kc], acc[m], 0, 0, 0);
-                    if constexpr (ROWSUM) ars = __builtin_amdgcn_mfma_i32_16x16x64_i8(ones, b[kc], ars, 0, 0, 0);
                 }
                 if (k0 + KB < KC) {
 #pragma unroll
@@ -1217,7 +1236,7 @@ __global__ __launch_bounds__(512, 2) void q_pws_k(const QPwsP P, const int n_til
 #pragma unroll
                 for (int kc = 0; kc < KB; ++kc) b[kc] = *reinterpret_cast<const i4v *>(bn + (size_t)kc * 4 * QT * 16);
             }
-            const int rsv = ROWSUM ? ars[0] * P.zwc : 0;
+            const int rsv = ROWSUM ? rowsum[slot * QT + 16 * f + fr] * P.zwc : 0;
             const unsigned po = pdst[(t & 3) * QT + 16 * f + fr];
             if constexpr (EPI == QEPI_Q16) {
                 unsigned o[MW];
@@ -1241,6 +1260,11 @@ __global__ __launch_bounds__(512, 2) void q_pws_k(const QPwsP P, const int n_til
                 ns_prev += n_store_m;
             }
         }
+        if (t + 1 < t_end) {
+            wait_landed(ns_prev);                                    // tile t + 1: this wave's planes are in
+            if constexpr (ROWSUM) own_rowsum(t + 1, slot1);
+        }
+        slot = slot1;
     }
 }
 
@@ -1252,7 +1276,7 @@ int launch_q_pws(hipStream_t s, QPwsP &P, int nimg, int device, bool *ok) {
     const int groups = dd_ceil_div(P.n_mfrag, waves * MW);
     const int wpb = dd_ceil_div(dd_ceil_div(P.n_mfrag, groups), MW);  // waves per block
     P.frags_per_group = wpb * MW;
-    const size_t lds = (size_t)2 * QT * K + 8 * QT * sizeof(unsigned);
+    const size_t lds = (size_t)2 * QT * K + 11 * QT * sizeof(unsigned);
     const int blocks_x = std::max(1, std::min(n_tiles, 256 / groups));
     P.tiles_per_block = dd_ceil_div(n_tiles, blocks_x);
     P.hw_magic = (unsigned)((1ull << 32) / (unsigned)P.hw) + 1u;
