@@ -1104,6 +1104,11 @@ struct QPwsP {
     int zwc, tiles_per_block;
     unsigned hw_magic, w_magic;
     QReq R;
+    // QEPI_ROWS, two predictors on one feature map in one launch (the SSD's class and box layers read the same pixels): fragments
+    // [n_frag_a, n_mfrag) belong to the second one, with its own requantisation, weight zero point and destination rows
+    int n_frag_a;                                 // 0: one layer
+    uint8_t *out_b; long long img_bytes_b; int row_bytes_b, base_off_b, cout_store_b, zwc_b;
+    QReq Rb;
 };
 
 template <int K, int MW, int EPI, bool ROWSUM, int SAT>
@@ -1115,6 +1120,7 @@ __global__ __launch_bounds__(512, 2) void q_pws_k(const QPwsP P, const int n_til
     unsigned *psrc = reinterpret_cast<unsigned *>(smem + 2 * QT * K);   // [4][QT]: the pixel's offset in the source (plane 0)
     unsigned *pdst = psrc + 4 * QT;                                  // [4][QT]: its offset in the destination, ~0 past the end
     int *rowsum = reinterpret_cast<int *>(pdst + 4 * QT);            // [3][QT]: sum over k of the pixel's operand bytes (ROWSUM)
+    unsigned *pdstb = reinterpret_cast<unsigned *>(rowsum + 3 * QT); // [4][QT]: the second predictor's destination offsets
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), NW = blockDim.x >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int frag0 = blockIdx.y * P.frags_per_group + wave * MW;     // this wave's first fragment
@@ -1137,10 +1143,18 @@ __global__ __launch_bounds__(512, 2) void q_pws_k(const QPwsP P, const int n_til
             const int ch = EPI == QEPI_Q16 ? 64 * mg + 16 * fq + 4 * (m0 + m) + r : 16 * (frag0 + m) + 4 * fq + r;
             CQ[m][r] = frag0 + m < P.n_mfrag ? P.cq[ch] : 0ll;
         }
-    const int e_lin = P.R.e, k1_lin = (1 << (P.R.e - 1)) + (P.R.zo << P.R.e);
-    int n_store_m = 0;                                               // ROWS: fragments of this wave that store anything
+    // ROWS: which predictor fragment m belongs to (wave-uniform), its first channel, its constants
+    const int nfa = EPI == QEPI_ROWS && P.n_frag_a ? P.n_frag_a : P.n_mfrag;
+    bool hb[MW]; int chm[MW], Mm[MW], em[MW], k1m[MW], zwm[MW];
+    int n_store_m = 0;                                               // fragments of this wave that store anything
 #pragma unroll
-    for (int m = 0; m < MW; ++m) n_store_m += 16 * (frag0 + m) < P.cout_store ? 1 : 0;
+    for (int m = 0; m < MW; ++m) {
+        hb[m] = frag0 + m >= nfa;
+        chm[m] = 16 * (frag0 + m - (hb[m] ? nfa : 0));
+        const QReq &Rm = hb[m] ? P.Rb : P.R;
+        Mm[m] = Rm.M; em[m] = Rm.e; k1m[m] = (1 << (Rm.e - 1)) + (Rm.zo << Rm.e); zwm[m] = hb[m] ? P.zwc_b : P.zwc;
+        n_store_m += frag0 + m < P.n_mfrag && chm[m] < (hb[m] ? P.cout_store_b : P.cout_store) ? 1 : 0;
+    }
 
     const int t_begin = blockIdx.x * P.tiles_per_block, t_end = min(n_tiles, t_begin + P.tiles_per_block);
     if (t_begin >= t_end) return;
@@ -1154,6 +1168,7 @@ __global__ __launch_bounds__(512, 2) void q_pws_k(const QPwsP P, const int n_til
         if constexpr (EPI == QEPI_Q16) d = row * (unsigned)P.c16_out * PP + (unsigned)(x + 1) * 16u;
         else d = (unsigned)((long long)n * P.img_bytes_out) + (unsigned)P.base_off + (unsigned)r * (unsigned)P.row_bytes;
         pdst[(t & 3) * QT + tid] = q < P.m ? d : 0xffffffffu;
+        if (EPI == QEPI_ROWS && P.n_frag_a) pdstb[(t & 3) * QT + tid] = q < P.m ? (unsigned)((long long)n * P.img_bytes_b) + (unsigned)P.base_off_b + (unsigned)r * (unsigned)P.row_bytes_b : 0xffffffffu;
     };
     auto fill = [&](int t) {                                         // tile t's bytes on their way: plane c of the tile = one wave instruction
         const uint8_t *src = P.in + psrc[(t & 3) * QT + lane];
@@ -1250,12 +1265,16 @@ __global__ __launch_bounds__(512, 2) void q_pws_k(const QPwsP P, const int n_til
                 }
                 if (frag0 < P.n_mfrag) ++ns_prev;
             } else {
+                const int rs0 = ROWSUM ? rowsum[slot * QT + 16 * f + fr] : 0;
+                const unsigned pob = P.n_frag_a ? pdstb[(t & 3) * QT + 16 * f + fr] : 0xffffffffu;
 #pragma unroll
                 for (int m = 0; m < MW; ++m) {
-                    const int ch = 16 * (frag0 + m) + 4 * fq;
-                    if (ch >= P.cout_store) continue;
-                    const unsigned wv = q_requant_linear_pack4(acc[m][0] + rsv, acc[m][1] + rsv, acc[m][2] + rsv, acc[m][3] + rsv, M, CQ[m][0], CQ[m][1], CQ[m][2], CQ[m][3], e_lin, k1_lin);
-                    if (po != 0xffffffffu) *reinterpret_cast<unsigned *>(P.out + po + ch) = wv;
+                    const int ch = chm[m] + 4 * fq;
+                    if (frag0 + m >= P.n_mfrag || ch >= (hb[m] ? P.cout_store_b : P.cout_store)) continue;
+                    const int rv = rs0 * zwm[m];
+                    const unsigned wv = q_requant_linear_pack4(acc[m][0] + rv, acc[m][1] + rv, acc[m][2] + rv, acc[m][3] + rv, Mm[m], CQ[m][0], CQ[m][1], CQ[m][2], CQ[m][3], em[m], k1m[m]);
+                    const unsigned pm = hb[m] ? pob : po;
+                    if (pm != 0xffffffffu) *reinterpret_cast<unsigned *>((hb[m] ? P.out_b : P.out) + pm + ch) = wv;
                 }
                 ns_prev += n_store_m;
             }
@@ -1276,7 +1295,7 @@ int launch_q_pws(hipStream_t s, QPwsP &P, int nimg, int device, bool *ok) {
     const int groups = dd_ceil_div(P.n_mfrag, waves * MW);
     const int wpb = dd_ceil_div(dd_ceil_div(P.n_mfrag, groups), MW);  // waves per block
     P.frags_per_group = wpb * MW;
-    const size_t lds = (size_t)2 * QT * K + 11 * QT * sizeof(unsigned);
+    const size_t lds = (size_t)2 * QT * K + 15 * QT * sizeof(unsigned);
     const int blocks_x = std::max(1, std::min(n_tiles, 256 / groups));
     P.tiles_per_block = dd_ceil_div(n_tiles, blocks_x);
     P.hw_magic = (unsigned)((1ull << 32) / (unsigned)P.hw) + 1u;
@@ -1286,8 +1305,10 @@ int launch_q_pws(hipStream_t s, QPwsP &P, int nimg, int device, bool *ok) {
     *ok = in_bytes < (1ll << 32) && out_bytes < (1ll << 32) && (long long)P.m * P.hw < (1ll << 32) && (long long)P.hw * P.W < (1ll << 32) && P.zwc >= -128 && P.zwc <= 128 &&
           lds <= 160 * 1024 && wpb >= 1 && wpb <= 8;
     if (!*ok) return DD_OK;
-    const bool rsum = P.zwc != 0;
+    const bool rsum = P.zwc != 0 || (P.n_frag_a && P.zwc_b != 0);
     const bool rows = P.img_bytes_out != 0;
+    if (P.n_frag_a && !(P.Rb.linear && P.Rb.e >= 1 && P.Rb.e <= 30 && P.Rb.lo == 0 && P.Rb.hi == 255 && std::abs(P.Rb.zo) < 256 && P.zwc_b >= -128 && P.zwc_b <= 128 &&
+                        (long long)nimg * P.img_bytes_b < (1ll << 32))) { *ok = false; return DD_OK; }
     if (rows && !(P.R.linear && P.R.e >= 1 && P.R.e <= 30 && P.R.lo == 0 && P.R.hi == 255 && std::abs(P.R.zo) < 256)) { *ok = false; return DD_OK; }
     const int sat = !rows && P.R.lo == 0 && P.R.hi == 255 ? (P.R.e <= 8 ? 2 : 1) : 0;
     void (*kern)(const QPwsP, const int) = nullptr;
@@ -1366,6 +1387,14 @@ int netq_run_op(dd_net *net, int i, const int32_t *o, const uint8_t *input, int 
             P.cbias = reinterpret_cast<const int *>(W + (size_t)(uint32_t)o[17]);
             P.kc_per_tap = o[13]; P.n_mfrag = o[12] / 16; P.epi = o[15];
             P.out = base(dst); P.zwc = o[38]; P.R = make_req(o);
+            const int n_frag_a = o[14];                              // > 0: two predictors in one op (fragments [0, n_frag_a) the first: netsq.py conv_heads)
+            QReq Rb = P.R;
+            if (n_frag_a) {
+                int32_t d[48] = {0}; d[32] = o[20]; d[33] = o[21]; d[40] = o[22]; d[36] = 0; d[37] = 255; d[41] = o[41]; Rb = make_req(d);
+                DD_REQUIRE(o[4] >= 0 && P.epi == QEPI_ROWS && n_frag_a < P.n_mfrag && !net->tensors[o[4]].pad && o[23] % 4 == 0 && o[24] % 4 == 0 && o[25] % 4 == 0 && o[25] <= o[23] &&
+                           (long long)o[24] + (long long)P.ho * P.wo * o[23] <= (long long)net->tensors[o[4]].h * net->tensors[o[4]].w * net->tensors[o[4]].cs, DD_E_ARG,
+                           "dd_net_forward: uint8 conv %d: second predictor's row geometry", i);
+            }
             DD_REQUIRE(P.off_y >= 0 && P.off_x >= 0 && (P.ho - 1) * P.stride + P.kh - 1 + P.off_y <= P.H + 1 && (P.wo - 1) * P.stride + P.kw - 1 + P.off_x <= P.W + 1,
                        DD_E_ARG, "dd_net_forward: uint8 conv %d reaches outside the one-pixel border", i);
             if (P.epi == QEPI_Q16) {
@@ -1388,34 +1417,53 @@ int netq_run_op(dd_net *net, int i, const int32_t *o, const uint8_t *input, int 
                 Q.w = P.w; Q.cbias = P.cbias; Q.cq = reinterpret_cast<const long long *>(W + (size_t)(uint32_t)o[46]);
                 Q.n_mfrag = P.n_mfrag; Q.out = P.out; Q.c16_out = P.c16_out; Q.zwc = P.zwc; Q.R = P.R;
                 if (P.epi == QEPI_ROWS) { Q.img_bytes_out = P.img_bytes_out; Q.row_bytes = P.row_bytes; Q.base_off = P.base_off; Q.cout_store = P.cout_store; }
+                if (n_frag_a) {
+                    const TensorDesc *tb = &net->tensors[o[4]];
+                    Q.n_frag_a = n_frag_a; Q.out_b = base(o[4]); Q.img_bytes_b = (long long)tb->h * tb->w * tb->cs; Q.row_bytes_b = o[23]; Q.base_off_b = o[24]; Q.cout_store_b = o[25];
+                    Q.zwc_b = o[28]; Q.Rb = Rb;
+                }
                 bool ok = false;
                 // (the 19x19 class predictor has 18 fragments: six waves of three load the SIMDs 6 / 6 / 3 / 3, five of four 8 / 4 / 4 / 2)
-                const int rc = ts->cs == 512 ? (P.epi == QEPI_ROWS && P.n_mfrag % 3 == 0 && P.n_mfrag % 4 != 0 ? launch_q_pws<512, 3>(s, Q, nimg, net->ctx->device, &ok) : launch_q_pws<512, 4>(s, Q, nimg, net->ctx->device, &ok))
+                const int rc = ts->cs == 512 ? (P.epi == QEPI_ROWS && (P.n_mfrag + 2) / 3 <= 8 && P.n_mfrag % 4 != 0 ? launch_q_pws<512, 3>(s, Q, nimg, net->ctx->device, &ok) : launch_q_pws<512, 4>(s, Q, nimg, net->ctx->device, &ok))
                                              : launch_q_pws<1024, 2>(s, Q, nimg, net->ctx->device, &ok);
                 if (rc != DD_OK) return rc;
                 if (ok) return DD_OK;
             }
-            const int n_mgroups = dd_ceil_div(P.n_mfrag, P.mq);
-            // Pixel fragments per wave item.  Two by default; four (half the weight fetches per MFMA, twice the registers) where the launch has
-            // few wave items anyway and pixels enough -- measured per layer at 384 frames: extras 48 -> 38, 63 -> 39 us, 5x5 class predictor
-            // 23 -> 16 us, but 53 -> 65, 86 -> 95, 68 -> 78 us on the layers with 19 k+ items (b12 / b13 pointwise, 19x19 class predictor).
-            const long long items2 = (long long)n_mgroups * dd_ceil_div(P.m, 32);
-            static const int npf_env = getenv("DD_Q_NPF") ? atoi(getenv("DD_Q_NPF")) : 0;
-            const int npf = npf_env ? npf_env : (items2 < 8192 && P.m >= 2048 ? 4 : 2);
-            const long long n_items = (long long)n_mgroups * dd_ceil_div(P.m, 16 * npf);
-            DD_REQUIRE(n_items < (1ll << 31), DD_E_CAPACITY, "dd_net_forward: uint8 conv %d: %lld wave items", i, n_items);
-            const dim3 grid((unsigned)((n_items + 3) / 4));
-            const bool rsum = P.zwc != 0;
-            const bool pipe = n_items < 8192;
+            auto run_generic = [&](QConvP &P) -> int {
+                const int n_mgroups = dd_ceil_div(P.n_mfrag, P.mq);
+                // Pixel fragments per wave item.  Two by default; four (half the weight fetches per MFMA, twice the registers) where the launch has
+                // few wave items anyway and pixels enough -- measured per layer at 384 frames: extras 48 -> 38, 63 -> 39 us, 5x5 class predictor
+                // 23 -> 16 us, but 53 -> 65, 86 -> 95, 68 -> 78 us on the layers with 19 k+ items (b12 / b13 pointwise, 19x19 class predictor).
+                const long long items2 = (long long)n_mgroups * dd_ceil_div(P.m, 32);
+                static const int npf_env = getenv("DD_Q_NPF") ? atoi(getenv("DD_Q_NPF")) : 0;
+                const int npf = npf_env ? npf_env : (items2 < 8192 && P.m >= 2048 ? 4 : 2);
+                const long long n_items = (long long)n_mgroups * dd_ceil_div(P.m, 16 * npf);
+                DD_REQUIRE(n_items < (1ll << 31), DD_E_CAPACITY, "dd_net_forward: uint8 conv %d: %lld wave items", i, n_items);
+                const dim3 grid((unsigned)((n_items + 3) / 4));
+                const bool rsum = P.zwc != 0;
+                const bool pipe = n_items < 8192;
 #define DD_QC2(MQ_, R_) do { if (npf == 4) hipLaunchKernelGGL((q_conv_k<MQ_, R_, 4, false>), grid, dim3(256), 0, s, P, (int)n_items, n_mgroups); \
-                             else if (pipe) hipLaunchKernelGGL((q_conv_k<MQ_, R_, 2, true>), grid, dim3(256), 0, s, P, (int)n_items, n_mgroups); \
-                             else hipLaunchKernelGGL((q_conv_k<MQ_, R_, 2, false>), grid, dim3(256), 0, s, P, (int)n_items, n_mgroups); } while (0)
+                                 else if (pipe) hipLaunchKernelGGL((q_conv_k<MQ_, R_, 2, true>), grid, dim3(256), 0, s, P, (int)n_items, n_mgroups); \
+                                 else hipLaunchKernelGGL((q_conv_k<MQ_, R_, 2, false>), grid, dim3(256), 0, s, P, (int)n_items, n_mgroups); } while (0)
 #define DD_QC(MQ_) do { if (rsum) DD_QC2(MQ_, true); else DD_QC2(MQ_, false); } while (0)
-            if (P.mq == 4) DD_QC(4); else if (P.mq == 3) DD_QC(3); else if (P.mq == 2) DD_QC(2); else DD_QC(1);
+                if (P.mq == 4) DD_QC(4); else if (P.mq == 3) DD_QC(3); else if (P.mq == 2) DD_QC(2); else DD_QC(1);
 #undef DD_QC2
 #undef DD_QC
-            DD_LAUNCH_CHECK();
-            return DD_OK;
+                DD_LAUNCH_CHECK();
+                return DD_OK;
+            };
+            if (n_frag_a == 0) return run_generic(P);
+            // two predictors, small batch: one launch each (the second one's fragments, constants and destination follow the first one's)
+            QConvP P2 = P;
+            P.n_mfrag = n_frag_a; P.mq = std::min(4, P.n_mfrag);
+            int rc2 = run_generic(P);
+            if (rc2 != DD_OK) return rc2;
+            const TensorDesc *tb = &net->tensors[o[4]];
+            P2.w = P.w + (size_t)n_frag_a * (P.kh * P.kw * P.kc_per_tap) * 64; P2.cbias = P.cbias + 16 * n_frag_a;
+            P2.n_mfrag -= n_frag_a; P2.mq = std::min(4, P2.n_mfrag);
+            P2.out = base(o[4]); P2.img_bytes_out = (long long)tb->h * tb->w * tb->cs; P2.row_bytes = o[23]; P2.base_off = o[24]; P2.cout_store = o[25];
+            P2.zwc = o[28]; P2.R = Rb;
+            return run_generic(P2);
         }
         case OP_QDW: {
             QDwP P;

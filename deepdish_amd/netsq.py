@@ -19,6 +19,7 @@ FUSE_BLOCKS = os.environ.get('DD_Q_FUSE', '1') != '0'      # MobileNet blocks as
 SPLIT_PW = os.environ.get('DD_Q_SPLIT_PW', '1') != '0'      # pointwise filters of the blocks with <= SPLIT_PW_MAX_CIN input channels as hi + lo parts (no row sums)
 SPLIT_PW_MAX_CIN = int(os.environ.get('DD_Q_SPLIT_PW_MAX_CIN', '128'))
 SPLIT_PW_MIN_CIN = int(os.environ.get('DD_Q_SPLIT_PW_MIN_CIN', '64'))       # block 1 (32 channels) measured slower split: 308 vs 294 us
+MERGE_HEADS = os.environ.get('DD_Q_MERGE_HEADS', '1') != '0'  # class + box predictor of a feature map with 512 / 1024 channels as one op
 FUSED_SHAPES = {(32, 64, 1), (64, 128, 2), (128, 128, 1), (128, 256, 2), (256, 256, 1), (256, 512, 2), (512, 512, 1)}
 FEATURE_LAYERS = ['pw11', 'pw13', 'extra1_2', 'extra2_2', 'extra3_2', 'extra4_2']
 
@@ -189,6 +190,29 @@ def compile_ssd_mobilenet_quant(qm):
         info('q_conv_k', 2 * ho * wo * kh * kh * cin * cout, s['h'] * s['w'] * cin + ho * wo * cout, kh * kh * cin * cout + 4 * cout)
         return dst
 
+    def conv_heads(src, cname, bname, cls_args, box_args):
+        """The class and box predictors of one feature map as ONE op (they read the same pixels; csrc/netsq.hip q_pws_k stores both, small
+        batches run two launches of q_conv_k): fragments of the class layer first, then the box layer's; its parameters in words 20..25, 28."""
+        Lc, Lb = Ls[cname], Ls[bname]
+        s = P.T(src)
+        ho, wo, pt, pl = geom(src, 1, 1)
+        assert s['zp'] == Lc['in_zp'] == Lb['in_zp'] and Lc['w'].shape[:3] == Lb['w'].shape[:3] == (1, 1, s['c'])
+        wc, cbc, kcpt = pack_conv(Lc, QEPI_ROWS, cls_args['chan_map'], cls_args['cout_pad'])
+        wb, cbb, _ = pack_conv(Lb, QEPI_ROWS, None, None)
+        rc, rb = _req_words(Lc), _req_words(Lb)
+        assert rc[41] and rb[41]
+        lin = lambda cb, r: np.array([int(v) * int(r[32]) + (1 << 30) for v in cb], dtype=np.int64)
+        raw = dict(rc)
+        raw.update({38: 128 - int(Lc['w_zp']), 39: int(Lc['in_zp']), 42: cls_args['row_bytes'], 43: cls_args['base_off'], 44: cls_args['cout_store'],
+                    46: P.add_blob(np.concatenate([lin(cbc, rc), lin(cbb, rb)])),
+                    20: rb[32], 21: rb[33], 22: rb[40], 23: box_args['row_bytes'], 24: box_args['base_off'], 25: box_args['cout_store'], 28: 128 - int(Lb['w_zp'])})
+        P._op(OP_QCONV, src=src, dst=cls_args['dst'], dst2=box_args['dst'], kh=1, kw=1, stride=1, pad_t=pt, pad_l=pl, cin=s['c'], cout=Lc['w'].shape[3] + Lb['w'].shape[3],
+              cout_pad=len(cbc) + len(cbb), kpad=kcpt, act=len(cbc) // 16, epi=QEPI_ROWS, w_off=P.add_blob(np.concatenate([wc, wb])), b_off=P.add_blob(np.concatenate([cbc, cbb])),
+              ho=ho, wo=wo, raw=raw)
+        cin = s['c']
+        cout = Lc['w'].shape[3] + Lb['w'].shape[3]
+        info('q_pws_k (two predictors)', 2 * ho * wo * cin * cout, s['h'] * s['w'] * cin + ho * wo * cout, cin * cout + 4 * cout)
+
     def dw(src, name):
         L = Ls[name]
         ho, wo, pt, pl = geom(src, 3, L['stride'])
@@ -258,12 +282,16 @@ def compile_ssd_mobilenet_quant(qm):
         for other in (f'box{k}', f'cls{k}'):
             assert (Ls[other]['out_scale'], Ls[other]['out_zp']) == (Ls[other[:3] + '0']['out_scale'], Ls[other[:3] + '0']['out_zp']), \
                 'the six %s tensors are concatenated: they need one (scale, zero point)' % other[:3]
-        conv(ft, f'box{k}', epi=QEPI_ROWS, dst=box_t, row_bytes=4 * a, base_off=4 * base, cout_store=4 * a)
         cmap = np.full(a * cls_row, -1, np.int64)
         for an in range(a):
             cmap[an * cls_row:an * cls_row + n_cls] = an * n_cls + np.arange(n_cls)
-        conv(ft, f'cls{k}', epi=QEPI_ROWS, dst=cls_t, chan_map=cmap, cout_pad=(a * cls_row + 15) // 16 * 16,
-             row_bytes=a * cls_row, base_off=cls_row * base, cout_store=a * cls_row)
+        box_args = dict(dst=box_t, row_bytes=4 * a, base_off=4 * base, cout_store=4 * a)
+        cls_args = dict(dst=cls_t, chan_map=cmap, cout_pad=(a * cls_row + 15) // 16 * 16, row_bytes=a * cls_row, base_off=cls_row * base, cout_store=a * cls_row)
+        if MERGE_HEADS and P.T(ft)['c'] in (512, 1024):
+            conv_heads(ft, f'cls{k}', f'box{k}', cls_args, box_args)
+        else:
+            conv(ft, f'box{k}', epi=QEPI_ROWS, **box_args)
+            conv(ft, f'cls{k}', epi=QEPI_ROWS, **cls_args)
         base += fm * fm * a
     assert base == n_anchors
     Lb, Lc = Ls['box0'], Ls['cls0']
