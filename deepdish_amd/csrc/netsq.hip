@@ -638,24 +638,29 @@ constexpr int QT = 64;               // pixels per tile
 // HL: the pointwise filter as w - zw split into hi = clamp(w - zw, -128, 127) and lo = rest, two MFMAs per fragment and k slice on one
 // accumulator instead of one MFMA plus the zwc * rowsum correction: for the layers with few input channels the matrix pipe has the time
 // and the row-sum machinery (dot products, cross-lane sums, LDS atomics, an add per output) goes.
-template <int CIN, int COUT, int WP, int STRIDE, int LPT, bool ROWSUM, int MW = 4, int SAT = 0, bool HL = false>
-__global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64, (COUT / (16 * MW)) * WP <= 2 ? 3 : 2) void q_dwpw_k(const QDwpwP P, const int n_tiles, const int tiles_per_block) {
+template <int CIN, int COUT, int WP, int STRIDE, int LPT, bool ROWSUM, int MW = 4, int SAT = 0, bool HL = false, int QTT = QT>
+__global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64, (COUT / (16 * MW)) * WP <= 2 ? 3 : QTT > 64 ? 4 : 2) void q_dwpw_k(const QDwpwP P, const int n_tiles, const int tiles_per_block) {
     constexpr int WM = COUT / (16 * MW), NW = WM * WP, NT = NW * 64;
     static_assert(MW == 4 || MW == 2, "fragments per wave");
     static_assert(!(HL && ROWSUM), "the split filter needs no row sums");
     constexpr int KC = (CIN + 63) / 64, CINP = KC * 64, C16 = CIN / 16;
-    static_assert(C16 % NW == 0, "planes over waves");
-    constexpr int CPW = C16 / NW;                                     // depthwise planes per wave
+    // depthwise work units: (plane, four 16-pixel fragments); a tile of QTT pixels has QTT / 64 fragment quads per plane.  QTT = 128 with four
+    // waves (block 1: 2 planes x 2 quads) does per wave and tile what QTT = 64 does with two, in 33 instead of 26.5 KB of LDS per block: 16 waves
+    // per CU instead of 12, and that block's time goes as 1 / waves (533 / 443 / 338 / 282 / 243 us at 2..6 blocks of two waves per CU).
+    constexpr int FPT = QTT / 16, UNITS = C16 * (FPT / 4);
+    static_assert(QTT % 64 == 0 && UNITS % NW == 0, "depthwise units over waves");
+    constexpr int CPW = UNITS / NW;                                   // units per wave
+    static_assert(FPT == 4 || CPW == 1, "several units per wave: one fragment quad only");
     constexpr bool KEEP = CPW <= 2, FOLDP = !ROWSUM && KC <= 4;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (the wave number in a scalar register)
     const int fr = lane & 15, fq = lane >> 4;
     const int wm = wave / WP, wp = wave % WP;
     const int RB = (P.W + 2) * CIN, PP = (P.W + 2) * 16;           // ring row / plane pitch (bytes)
-    uint8_t *opnd = smem;                                           // [CINP / 16][QT][16]
-    int *rowsum = reinterpret_cast<int *>(opnd + QT * CINP);        // [2][QT]
-    i4v *pinfo = reinterpret_cast<i4v *>(rowsum + 2 * QT);          // [2][QT]: ring offsets of the pixel's window (rows 0..2, first column), offset of its output
-    int *cbl = reinterpret_cast<int *>(pinfo + 2 * QT);             // [COUT]: the pointwise layer's per-channel constants (!FOLDP)
+    uint8_t *opnd = smem;                                           // [CINP / 16][QTT][16]
+    int *rowsum = reinterpret_cast<int *>(opnd + QTT * CINP);        // [2][QTT]
+    i4v *pinfo = reinterpret_cast<i4v *>(rowsum + 2 * QTT);          // [2][QTT]: ring offsets of the pixel's window (rows 0..2, first column), offset of its output
+    int *cbl = reinterpret_cast<int *>(pinfo + 2 * QTT);             // [COUT]: the pointwise layer's per-channel constants (!FOLDP)
     uint2 *dwa_l = reinterpret_cast<uint2 *>(cbl + COUT);           // !KEEP: the depthwise tables in LDS ([C16][64] operand bytes, [CIN] addends): a global
     long long *dwq_l = reinterpret_cast<long long *>(dwa_l + (KEEP ? 0 : C16 * 64));     // load at the head of every plane is ~500 cycles before its first use
     uint8_t *ring = reinterpret_cast<uint8_t *>(dwq_l + (KEEP ? 0 : CIN));   // [NR][RB], last (>= 4 KB of other data below it: see pf_issue)
@@ -688,8 +693,8 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64, (COUT / (16 * MW)) * 
         for (int i = tid; i < C16 * 64; i += NT) dwa_l[i] = P.dw_a[i];
         for (int i = tid; i < CIN; i += NT) dwq_l[i] = P.dw_cq[i];
     }
-    if (CIN < CINP) for (int i = tid; i < QT * CINP / 16; i += NT) reinterpret_cast<u4v *>(opnd)[i] = u4v{0, 0, 0, 0};   // k slots without channels
-    for (int i = tid; i < 2 * QT; i += NT) rowsum[i] = 0;
+    if (CIN < CINP) for (int i = tid; i < QTT * CINP / 16; i += NT) reinterpret_cast<u4v *>(opnd)[i] = u4v{0, 0, 0, 0};   // k slots without channels
+    for (int i = tid; i < 2 * QTT; i += NT) rowsum[i] = 0;
     // depthwise lane constants: which byte of the 16 is this lane's diagonal element; which window column its tap of k step ks is
     // (k step 0: taps 0..3 = row 0 columns 0..2, row 1 column 0; step 1: taps 4..7 = row 1 columns 1, 2, row 2 columns 0, 1; step 2: tap 8 =
     // row 2 column 2, and the k slots past it carry zero weights: any valid address will do)
@@ -716,7 +721,7 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64, (COUT / (16 * MW)) * 
     long long KCq[KEEP ? CPW : 1][4];
     if constexpr (KEEP) {
 #pragma unroll
-        for (int ci = 0; ci < CPW; ++ci) build_a(wave * CPW + ci, KAh[ci], KAl[ci], KCq[ci]);
+        for (int ci = 0; ci < CPW; ++ci) build_a((wave * CPW + ci) % C16, KAh[ci], KAl[ci], KCq[ci]);
     }
 
     const int t_begin = blockIdx.x * tiles_per_block, t_end = min(n_tiles, t_begin + tiles_per_block);
@@ -731,13 +736,13 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64, (COUT / (16 * MW)) * 
     // a tile step had ten of them -- 320 scalar instructions per tile and wave in the 32-channel block)
     auto tile_rows = [&](int t, int &n, int &q0, int &q1, int &ga, int &gb) {
         n = (int)__umulhi((unsigned)t, P.tpf_magic);
-        q0 = (t - n * P.tiles_per_frame) * QT;
-        q1 = min(q0 + QT, P.hw) - 1;
+        q0 = (t - n * P.tiles_per_frame) * QTT;
+        q1 = min(q0 + QTT, P.hw) - 1;
         const int y0 = (int)__umulhi((unsigned)q0, P.wo_magic), y1 = (int)__umulhi((unsigned)q1, P.wo_magic);
         ga = n * (P.H + 2) + y0 * STRIDE + P.off_y;
         gb = n * (P.H + 2) + y1 * STRIDE + P.off_y + 2;
     };
-    // threads 0 .. QT - 1: where pixel tid of the tile reads and writes.  One wave's work on every tile's critical path: the row's ring slot
+    // threads 0 .. QTT - 1: where pixel tid of the tile reads and writes.  One wave's work on every tile's critical path: the row's ring slot
     // from the tile's first (a scalar division) plus the rows in between, 24-bit multiplies (the host checked the ranges).
     auto geometry = [&](int n, int q0, int q1, int ga, int buf) {
         const int q = q0 + tid;
@@ -750,7 +755,7 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64, (COUT / (16 * MW)) * 
         const int s1 = s0 + 1 == P.NR ? 0 : s0 + 1, s2 = s1 + 1 == P.NR ? 0 : s1 + 1;
         const int col = (x * STRIDE + P.off_x) * 16;
         const unsigned po = q <= q1 ? (unsigned)__mul24(n * (P.ho + 2) + y + 1, out_row) + (unsigned)(x + 1) * 16u : 0xffffffffu;
-        pinfo[buf * QT + tid] = i4v{__mul24(s0, RB) + col, __mul24(s1, RB) + col, __mul24(s2, RB) + col, (int)po};
+        pinfo[buf * QTT + tid] = i4v{__mul24(s0, RB) + col, __mul24(s1, RB) + col, __mul24(s2, RB) + col, (int)po};
     };
     auto load_rows_sync = [&](int lo, int hi) {                     // whole rows [lo, hi] into the ring (start of the block's range only)
         if (hi < lo) return;
@@ -765,54 +770,62 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64, (COUT / (16 * MW)) * 
     auto dw_planes = [&](int gbuf, int rsb) {
         int rs[4] = {0, 0, 0, 0};
         int tapoff[3][4];                                            // ring offset of this lane's tap of k step ks at its pixel of fragment f (plane 0)
+        const int fb = 4 * ((wave * CPW) / C16);                       // the wave's fragment quad (one per wave: see the assertion)
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
-            const i4v pi = pinfo[gbuf * QT + 16 * f + fr];
+            const i4v pi = pinfo[gbuf * QTT + 16 * (fb + f) + fr];
             tapoff[0][f] = (row_up0 ? pi[1] : pi[0]) + tap_dx[0];
             tapoff[1][f] = (row_up1 ? pi[2] : pi[1]) + tap_dx[1];
             tapoff[2][f] = pi[2] + tap_dx[2];
         }
-        auto plane = [&](int cg, int ci) {                           // (ci: a literal after unrolling when KEEP)
+        auto plane = [&](int unit, int ci) {                         // (ci: a literal after unrolling when KEEP)
+            const int cg = unit % C16;
             const int pofs = cg * PP;
             uint2 ab = make_uint2(0u, 0u);
             if constexpr (!KEEP) ab = dwa_l[cg * 64 + lane];
-            i4v acc[4];
-#pragma unroll
-            for (int f = 0; f < 4; ++f) acc[f] = i4v{0, 0, 0, 0};
-            i4v b[2][4];
-#pragma unroll
-            for (int f = 0; f < 4; ++f) b[0][f] = *reinterpret_cast<const i4v *>(ring + tapoff[0][f] + pofs);
-#pragma unroll
-            for (int ks = 0; ks < 3; ++ks) {
-                i4v Ah, Al;
-                if constexpr (KEEP) { Ah = KAh[ci][ks]; Al = KAl[ci][ks]; }
-                else {
-                    const unsigned sel = 0x01010101u * (unsigned)ks;
-                    const unsigned rh = __builtin_amdgcn_perm(ab.x, ab.x, sel), rl = __builtin_amdgcn_perm(ab.y, ab.y, sel);
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) { Ah[d] = (int)(rh & dmask[d]); Al[d] = (int)(rl & dmask[d]); }
-                }
-                if (ks < 2) {                                        // the next k step's operands are on their way while this one multiplies
-#pragma unroll
-                    for (int f = 0; f < 4; ++f) b[(ks + 1) & 1][f] = *reinterpret_cast<const i4v *>(ring + tapoff[ks + 1][f] + pofs);
-                }
-#pragma unroll
-                for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Ah, b[ks & 1][f], acc[f], 0, 0, 0);
-#pragma unroll
-                for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Al, b[ks & 1][f], acc[f], 0, 0, 0);
-            }
             long long Cq[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if constexpr (KEEP) Cq[r] = KCq[ci][r];
                 else Cq[r] = dwq_l[cg * 16 + 4 * fq + r];
             }
+            // FB fragments in flight: all four, or two at a time where the block runs four waves per SIMD on 128 registers each (their
+            // operand double buffer is 16 registers instead of 32; the other waves cover the shorter chains)
+            constexpr int FB = QTT > 64 ? 2 : 4;
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                unsigned packed = q_requant_pack4<SAT>(acc[f][0], acc[f][1], acc[f][2], acc[f][3], Md, Cq[0], Cq[1], Cq[2], Cq[3], shd, lod, hid);
-                packed ^= 0x80808080u;
-                if (ROWSUM) rs[f] = sdot4((int)packed, 0x01010101, rs[f]);
-                *reinterpret_cast<unsigned *>(opnd + ((size_t)cg * QT + 16 * f + fr) * 16 + 4 * fq) = packed;
+            for (int f0 = 0; f0 < 4; f0 += FB) {
+                i4v acc[FB];
+#pragma unroll
+                for (int f = 0; f < FB; ++f) acc[f] = i4v{0, 0, 0, 0};
+                i4v b[2][FB];
+#pragma unroll
+                for (int f = 0; f < FB; ++f) b[0][f] = *reinterpret_cast<const i4v *>(ring + tapoff[0][f0 + f] + pofs);
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) {
+                    i4v Ah, Al;
+                    if constexpr (KEEP) { Ah = KAh[ci][ks]; Al = KAl[ci][ks]; }
+                    else {
+                        const unsigned sel = 0x01010101u * (unsigned)ks;
+                        const unsigned rh = __builtin_amdgcn_perm(ab.x, ab.x, sel), rl = __builtin_amdgcn_perm(ab.y, ab.y, sel);
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) { Ah[d] = (int)(rh & dmask[d]); Al[d] = (int)(rl & dmask[d]); }
+                    }
+                    if (ks < 2) {                                    // the next k step's operands are on their way while this one multiplies
+#pragma unroll
+                        for (int f = 0; f < FB; ++f) b[(ks + 1) & 1][f] = *reinterpret_cast<const i4v *>(ring + tapoff[ks + 1][f0 + f] + pofs);
+                    }
+#pragma unroll
+                    for (int f = 0; f < FB; ++f) acc[f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Ah, b[ks & 1][f], acc[f], 0, 0, 0);
+#pragma unroll
+                    for (int f = 0; f < FB; ++f) acc[f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Al, b[ks & 1][f], acc[f], 0, 0, 0);
+                }
+#pragma unroll
+                for (int f = 0; f < FB; ++f) {
+                    unsigned packed = q_requant_pack4<SAT>(acc[f][0], acc[f][1], acc[f][2], acc[f][3], Md, Cq[0], Cq[1], Cq[2], Cq[3], shd, lod, hid);
+                    packed ^= 0x80808080u;
+                    if (ROWSUM) rs[f0 + f] = sdot4((int)packed, 0x01010101, rs[f0 + f]);
+                    *reinterpret_cast<unsigned *>(opnd + ((size_t)cg * QTT + 16 * (fb + f0 + f) + fr) * 16 + 4 * fq) = packed;
+                }
             }
         };
         if constexpr (KEEP) {
@@ -828,7 +841,7 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64, (COUT / (16 * MW)) * 
                 int v = rs[f];
                 v += __shfl_xor(v, 16, 64);
                 v += __shfl_xor(v, 32, 64);
-                if (fq == 0) atomicAdd(&rowsum[rsb * QT + 16 * f + fr], v);
+                if (fq == 0) atomicAdd(&rowsum[rsb * QTT + 16 * (fb + f) + fr], v);
             }
         }
     };
@@ -881,9 +894,9 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64, (COUT / (16 * MW)) * 
                                                                         // registers then spill, and a spilled HBM load is waited for on the spot)
         i4v b[KB];
         if (wp < nf) {
-            const uint8_t *bp = opnd + ((size_t)fq * QT + 16 * wp + fr) * 16;
+            const uint8_t *bp = opnd + ((size_t)fq * QTT + 16 * wp + fr) * 16;
 #pragma unroll
-            for (int kc = 0; kc < KB; ++kc) b[kc] = *reinterpret_cast<const i4v *>(bp + (size_t)kc * 4 * QT * 16);
+            for (int kc = 0; kc < KB; ++kc) b[kc] = *reinterpret_cast<const i4v *>(bp + (size_t)kc * 4 * QTT * 16);
         }
         for (int f = wp; f < nf; f += WP) {
             i4v acc[MW];
@@ -892,7 +905,7 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64, (COUT / (16 * MW)) * 
                 if constexpr (FOLDP) acc[m] = i4v{0, 0, 0, 0};
                 else acc[m] = *reinterpret_cast<const i4v *>(cbl + 64 * mg + 16 * fq + 4 * (m0 + m));
             }
-            const uint8_t *bp = opnd + ((size_t)fq * QT + 16 * f + fr) * 16;
+            const uint8_t *bp = opnd + ((size_t)fq * QTT + 16 * f + fr) * 16;
 #pragma unroll
             for (int k0 = 0; k0 < KC; k0 += KB) {
 #pragma unroll
@@ -904,16 +917,16 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64, (COUT / (16 * MW)) * 
                     }
                 if (k0 + KB < KC) {
 #pragma unroll
-                    for (int kc = 0; kc < KB; ++kc) b[kc] = *reinterpret_cast<const i4v *>(bp + (size_t)(k0 + KB + kc) * 4 * QT * 16);
+                    for (int kc = 0; kc < KB; ++kc) b[kc] = *reinterpret_cast<const i4v *>(bp + (size_t)(k0 + KB + kc) * 4 * QTT * 16);
                 }
             }
             if (f + WP < nf) {
-                const uint8_t *bn = opnd + ((size_t)fq * QT + 16 * (f + WP) + fr) * 16;
+                const uint8_t *bn = opnd + ((size_t)fq * QTT + 16 * (f + WP) + fr) * 16;
 #pragma unroll
-                for (int kc = 0; kc < KB; ++kc) b[kc] = *reinterpret_cast<const i4v *>(bn + (size_t)kc * 4 * QT * 16);
+                for (int kc = 0; kc < KB; ++kc) b[kc] = *reinterpret_cast<const i4v *>(bn + (size_t)kc * 4 * QTT * 16);
             }
-            const int rsv = ROWSUM ? rowsum[rsb * QT + 16 * f + fr] * P.zwc : 0;
-            const unsigned po = (unsigned)pinfo[gbuf * QT + 16 * f + fr][3];
+            const int rsv = ROWSUM ? rowsum[rsb * QTT + 16 * f + fr] * P.zwc : 0;
+            const unsigned po = (unsigned)pinfo[gbuf * QTT + 16 * f + fr][3];
             unsigned o[MW];
 #pragma unroll
             for (int m = 0; m < MW; ++m) {
@@ -932,7 +945,7 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64, (COUT / (16 * MW)) * 
     int n, q0, q1, ga, gb;
     tile_rows(t_begin, n, q0, q1, ga, gb);
     load_rows_sync(ga, gb);
-    if (tid < QT) geometry(n, q0, q1, ga, t_begin & 1);
+    if (tid < QTT) geometry(n, q0, q1, ga, t_begin & 1);
     int loaded_hi = gb;
     __syncthreads();
     unsigned long long st[6] = {0, 0, 0, 0, 0, 0}, tprev = P.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -961,8 +974,8 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64, (COUT / (16 * MW)) * 
         __builtin_amdgcn_s_barrier();                            // A: operand tile and row sums are complete; the ring is free (bare: requests stay in flight)
         Q_STAMP(1);
         pf_issue(max(lo, e_hi + 1), hi);                         // the rest of the next tile's rows
-        if (tid < QT) {
-            if (ROWSUM) rowsum[(cur ^ 1) * QT + tid] = 0;
+        if (tid < QTT) {
+            if (ROWSUM) rowsum[(cur ^ 1) * QTT + tid] = 0;
             if (t + 1 < t_end) geometry(n2, q02, q12, ga2, cur ^ 1);
         }
         matrix(q0, q1, cur, cur);
@@ -999,12 +1012,12 @@ QReq make_req(const int32_t *o) {
 
 
 // Ring rows and prefetch depth of q_dwpw_k for this geometry (tiles of one frame and the step into the next frame).
-void dwpw_plan(int H, int W, int ho, int wo, int stride, int off_y, int cin, int nt, int *NR, int *lpt) {
-    const int hw = ho * wo, tpf = dd_ceil_div(hw, QT), RB = (W + 2) * cin;
+void dwpw_plan(int H, int W, int ho, int wo, int stride, int off_y, int cin, int nt, int qt, int *NR, int *lpt) {
+    const int hw = ho * wo, tpf = dd_ceil_div(hw, qt), RB = (W + 2) * cin;
     int span = 0, hi = 0, mx = 0;
     for (int n = 0; n < 2; ++n)
         for (int k = 0; k < tpf; ++k) {
-            const int q0 = k * QT, q1 = std::min(q0 + QT, hw) - 1;
+            const int q0 = k * qt, q1 = std::min(q0 + qt, hw) - 1;
             const int ga = n * (H + 2) + (q0 / wo) * stride + off_y, gb = n * (H + 2) + (q1 / wo) * stride + off_y + 2;
             span = std::max(span, gb - ga + 1);
             if (n || k) { const int lo = std::max(hi + 1, ga); mx = std::max(mx, gb - lo + 1); }
@@ -1014,16 +1027,17 @@ void dwpw_plan(int H, int W, int ho, int wo, int stride, int off_y, int cin, int
     *lpt = (int)(((long long)mx * RB + (long long)nt * 16 - 1) / ((long long)nt * 16));
 }
 
-template <int CIN, int COUT, int WP, int STRIDE, int LPT, int EXTRA = 0, int MW = 4>
+template <int CIN, int COUT, int WP, int STRIDE, int LPT, int EXTRA = 0, int MW = 4, int QTT = QT>
 int launch_q_dwpw(hipStream_t s, QDwpwP &P, int nimg, int device, bool *ok) {
     constexpr int NW = (COUT / (16 * MW)) * WP, NT = NW * 64, CINP = (CIN + 63) / 64 * 64;
     int lpt = 0;
-    dwpw_plan(P.H, P.W, P.ho, P.wo, STRIDE, P.off_y, CIN, NT, &P.NR, &lpt);
+    P.tiles_per_frame = dd_ceil_div(P.hw, QTT);
+    dwpw_plan(P.H, P.W, P.ho, P.wo, STRIDE, P.off_y, CIN, NT, QTT, &P.NR, &lpt);
     static const int extra_env = getenv("DD_Q_EXTRA") ? atoi(getenv("DD_Q_EXTRA")) : -1;
     P.NR += extra_env >= 0 ? extra_env : EXTRA;                   // ring rows beyond one tile's span: the next tile's rows can be requested a stage earlier
     const int RB = (P.W + 2) * CIN;
-    constexpr bool KEEP = (CIN / 16) / NW <= 2;                       // (as in the kernel) else the depthwise tables take LDS
-    const size_t lds = (size_t)P.NR * RB + (size_t)QT * CINP + (size_t)2 * QT * sizeof(int) + 2 * QT * 16 + COUT * sizeof(int) + (KEEP ? 0 : (CIN / 16) * 64 * 8 + CIN * 8);
+    constexpr bool KEEP = ((CIN / 16) * (QTT / 64)) / NW <= 2;        // (as in the kernel) else the depthwise tables take LDS
+    const size_t lds = (size_t)P.NR * RB + (size_t)QTT * CINP + (size_t)2 * QTT * sizeof(int) + 2 * QTT * 16 + COUT * sizeof(int) + (KEEP ? 0 : (CIN / 16) * 64 * 8 + CIN * 8);
     P.wo_magic = (unsigned)((1ull << 32) / (unsigned)P.wo) + 1u;
     P.nr_magic = (unsigned)((1ull << 32) / (unsigned)P.NR) + 1u;
     P.tpf_magic = (unsigned)((1ull << 32) / (unsigned)P.tiles_per_frame) + 1u;
@@ -1038,7 +1052,7 @@ int launch_q_dwpw(hipStream_t s, QDwpwP &P, int nimg, int device, bool *ok) {
     const bool rsum = P.zwc != 0 && !hl;
     // both clamps are the byte range: saturating packs (1); both shifts <= 8 as well: the packed 16-bit shift (2)
     const int sat = P.Rd.lo == 0 && P.Rd.hi == 255 && P.Rp.lo == 0 && P.Rp.hi == 255 ? (P.Rd.e <= 8 && P.Rp.e <= 8 ? 2 : 1) : 0;
-#define DD_QK(R_, S_, H_) q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, R_, MW, S_, (H_) && CAN_HL>
+#define DD_QK(R_, S_, H_) q_dwpw_k<CIN, COUT, WP, STRIDE, LPT, R_, MW, S_, (H_) && CAN_HL, QTT>
 #define DD_QS(R_, H_) (sat == 2 ? &DD_QK(R_, 2, H_) : sat == 1 ? &DD_QK(R_, 1, H_) : &DD_QK(R_, 0, H_))
     void (*kern)(const QDwpwP, const int, const int) = hl ? DD_QS(false, true) : rsum ? DD_QS(true, false) : DD_QS(false, false);
     static DevOnce once;
@@ -1060,6 +1074,8 @@ int launch_q_dwpw(hipStream_t s, QDwpwP &P, int nimg, int device, bool *ok) {
         per_cu = std::max(1, std::min(8, nb));
         per_cu_cache[device & 63].store(per_cu, std::memory_order_relaxed);
     }
+    static const int per_cu_env = getenv("DD_Q_PER_CU") ? atoi(getenv("DD_Q_PER_CU")) : 0;     // experiment: fewer blocks per CU than fit
+    if (per_cu_env > 0) per_cu = std::min(per_cu, per_cu_env);
     const int n_tiles = nimg * P.tiles_per_frame;
     const int blocks = std::min(n_tiles, per_cu * 256);
     const int tpb = dd_ceil_div(n_tiles, blocks);
@@ -1520,7 +1536,8 @@ int netq_run_op(dd_net *net, int i, const int32_t *o, const uint8_t *input, int 
             int rc = DD_OK;
             const int dev = net->ctx->device;
 #define DD_QB(CIN_, COUT_, WP_, S_, LPT_) launch_q_dwpw<CIN_, COUT_, WP_, S_, LPT_>(s, P, nimg, dev, &ok)
-            if (cin == 32 && cout == 64 && stride == 1) rc = DD_QB(32, 64, 2, 1, 8);
+            static const int qt128 = getenv("DD_Q_QT128") ? atoi(getenv("DD_Q_QT128")) : 1;   // block 1: 128-pixel tiles, four waves (0: 64-pixel tiles, two waves)
+            if (cin == 32 && cout == 64 && stride == 1) rc = qt128 ? launch_q_dwpw<32, 64, 4, 1, 6, 0, 4, 128>(s, P, nimg, dev, &ok) : DD_QB(32, 64, 2, 1, 8);
             else if (cin == 64 && cout == 128 && stride == 2) rc = DD_QB(64, 128, 2, 2, 8);
             else if (cin == 128 && cout == 128 && stride == 1) rc = DD_QB(128, 128, 2, 1, 8);
             else if (cin == 128 && cout == 256 && stride == 2) rc = DD_QB(128, 256, 2, 2, 8);
