@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Whole-forward device time of a network (HIP events on the launch stream), no per-op instrumentation.
-Usage: python scripts/time_forward.py ssd|mars|yolo BATCH [kernels]   (kernels: also print which special launches ran)"""
+Usage: python scripts/time_forward.py ssd|ssd_i8|mars|yolo BATCH [kernels]   (kernels: also print which special launches ran)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -11,6 +11,9 @@ from deepdish_amd._lib import lib, check
 kind, batch = sys.argv[1], int(sys.argv[2])
 if kind == 'ssd':
     prog = nets.compile_ssd_mobilenet(nets.synthetic_ssd_weights()); shape = (300, 300)
+elif kind == 'ssd_i8':
+    from deepdish_amd import quantize, netsq
+    prog = netsq.compile_ssd_mobilenet_quant(quantize.synthetic_ssd_quant_model()); shape = (300, 300)
 elif kind == 'mars':
     prog = nets.compile_mars(nets.synthetic_mars_weights()); shape = (64, 32)
 else:
@@ -30,6 +33,8 @@ for r in range(reps):
 net.ctx.sync()
 us = np.array([ev[r].elapsed_time(ev[r + 1]) * 1e3 for r in range(reps)])
 ref = net.read().copy()
+if kind == 'ssd_i8':                                       # the class rows are the output tensor; the box rows belong to the digest too
+    ref = np.concatenate([np.asarray(ref).reshape(-1), np.asarray(net.read(tensor=prog.meta['box_tensor'])).reshape(-1)])
 import hashlib
 print(f'{kind} batch {batch}: mean {us.mean():.1f} us  min {us.min():.1f} us  checksum {float(np.abs(ref).sum()):.6e}  sha {hashlib.sha256(np.ascontiguousarray(ref).tobytes()).hexdigest()[:16]}')
 if len(sys.argv) > 3 and sys.argv[3] == 'kernels':

@@ -31,6 +31,15 @@ def test_ssd_forward_switches_give_the_same_bits():
         assert _sha('time_forward.py', ['ssd', 192], env) == base, env
 
 
+def test_uint8_ssd_forward_switches_give_the_same_bits():
+    """uint8 SSD forward at 96 frames (every fused path on): generic conv instead of the register-filter pointwise kernel, predictors as
+    separate ops, 64-pixel tiles in block 1, blocks as depthwise + pointwise ops, no split pointwise filters, the depthwise layers on the
+    vector ALU."""
+    base = _sha('time_forward.py', ['ssd_i8', 96], {})
+    for env in ({'DD_Q_PWS': '0'}, {'DD_Q_MERGE_HEADS': '0'}, {'DD_Q_QT128': '0'}, {'DD_Q_FUSE': '0'}, {'DD_Q_SPLIT_PW': '0'}, {'DD_Q_DW_VALU': '1'}):
+        assert _sha('time_forward.py', ['ssd_i8', 96], env) == base, env
+
+
 def test_mars_forward_switches_give_the_same_bits():
     """MARS forward at 1280 crops: pair kernel off, residual units unfused, stem unfused, row kernels off."""
     base = _sha('time_forward.py', ['mars', 1280], {})
