@@ -162,12 +162,15 @@ struct QConvP {
 
 // One wave item = MQ 16-channel fragments x NPF (2 or 4) 16-pixel fragments; operands straight from L2 / HBM in fragment shape (Q16 is
 // that shape), no LDS.  Small layers only (SSD extras and heads, 10x10 MobileNet blocks): the big ones run q_dwpw_k.
-template <int MQ, bool ROWSUM, int NPF, bool PIPE>
+// SPLIT = 3 (3x3 layers with few wave items: the SSD extras): the block is ONE item, wave w sums the k steps of filter row w, the partial
+// accumulators meet in LDS and wave 0 runs the epilogue -- three times the waves to cover the L2 round trips of a 36-step chain
+// (the 10x10 -> 5x5 extra layer has 1 200 items for 1 024 SIMDs).  Integer sums: the same bits in any order.
+template <int MQ, bool ROWSUM, int NPF, bool PIPE, int SPLIT = 1>
 __global__ __launch_bounds__(256) void q_conv_k(const QConvP P, const int n_items, const int n_mgroups) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 15, fq = lane >> 4;
-    const int item = blockIdx.x * 4 + wave;
-    if (item >= n_items) return;                                   // whole waves leave; no barrier below
+    const int item = SPLIT > 1 ? blockIdx.x : blockIdx.x * 4 + wave;
+    if (item >= n_items) return;                                   // whole waves (SPLIT: whole blocks) leave
     const int mg = item % n_mgroups, pf = item / n_mgroups;
     const size_t PP = (size_t)(P.W + 2) * 16, RP = PP * P.c16_in;  // plane / row pitch of the source
     const uint8_t *base[NPF];
@@ -191,6 +194,7 @@ __global__ __launch_bounds__(256) void q_conv_k(const QConvP P, const int n_item
 #pragma unroll
     for (int j = 0; j < NPF; ++j) rs[j] = 0;
     const int ksteps = P.kh * P.kw * P.kc_per_tap;
+    const int ks_lo = SPLIT > 1 ? wave * (ksteps / SPLIT) : 0, ks_hi = SPLIT > 1 ? ks_lo + ksteps / SPLIT : ksteps;     // this wave's k steps
     const i4v *wp = P.w + ((size_t)mg * MQ * ksteps) * 64 + lane;
     // k step ks = (tap, 64-channel slice): the operands of step ks + 1 are requested before the MFMAs of step ks are issued (a step's
     // loads followed by its own MFMAs left every step waiting out an L2 round trip: 36 of them in a 3x3 layer with 256 channels)
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(256) void q_conv_k(const QConvP P, const int n_item
     };
     i4v b0[NPF], a0[MQ], b1[NPF], a1[MQ];
     if constexpr (!PIPE) {                                          // launches with thousands of wave items per CU: the waves cover each other's round trips,
-        for (int ks = 0; ks < ksteps; ++ks) {                       // and the second operand set only costs occupancy (b13: 138 -> 155 us with it)
+        for (int ks = ks_lo; ks < ks_hi; ++ks) {                    // and the second operand set only costs occupancy (b13: 138 -> 155 us with it)
             load_step(ks, b0, a0);
 #pragma unroll
             for (int j = 0; j < NPF; ++j) {
@@ -226,9 +230,9 @@ __global__ __launch_bounds__(256) void q_conv_k(const QConvP P, const int n_item
             }
         }
     } else {
-    load_step(0, b0, a0);
-    for (int ks = 0; ks < ksteps; ks += 2) {
-        if (ks + 1 < ksteps) load_step(ks + 1, b1, a1);
+    load_step(ks_lo, b0, a0);
+    for (int ks = ks_lo; ks < ks_hi; ks += 2) {
+        if (ks + 1 < ks_hi) load_step(ks + 1, b1, a1);
 #pragma unroll
         for (int j = 0; j < NPF; ++j) {
             if (ROWSUM) {
@@ -238,8 +242,8 @@ __global__ __launch_bounds__(256) void q_conv_k(const QConvP P, const int n_item
 #pragma unroll
             for (int m = 0; m < MQ; ++m) acc[m][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[m], b0[j], acc[m][j], 0, 0, 0);
         }
-        if (ks + 1 >= ksteps) break;
-        if (ks + 2 < ksteps) load_step(ks + 2, b0, a0);
+        if (ks + 1 >= ks_hi) break;
+        if (ks + 2 < ks_hi) load_step(ks + 2, b0, a0);
 #pragma unroll
         for (int j = 0; j < NPF; ++j) {
             if (ROWSUM) {
@@ -250,6 +254,32 @@ __global__ __launch_bounds__(256) void q_conv_k(const QConvP P, const int n_item
             for (int m = 0; m < MQ; ++m) acc[m][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[m], b1[j], acc[m][j], 0, 0, 0);
         }
     }
+    }
+    if constexpr (SPLIT > 1) {
+        __shared__ int xch[SPLIT - 1][MQ * NPF * 4 + NPF][64];
+        if (wave > 0) {
+#pragma unroll
+            for (int m = 0; m < MQ; ++m)
+#pragma unroll
+                for (int j = 0; j < NPF; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xch[wave - 1][(m * NPF + j) * 4 + r][lane] = acc[m][j][r];
+#pragma unroll
+            for (int j = 0; j < NPF; ++j) xch[wave - 1][MQ * NPF * 4 + j][lane] = rs[j];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int w = 0; w < SPLIT - 1; ++w) {
+#pragma unroll
+            for (int m = 0; m < MQ; ++m)
+#pragma unroll
+                for (int j = 0; j < NPF; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[m][j][r] += xch[w][(m * NPF + j) * 4 + r][lane];
+#pragma unroll
+            for (int j = 0; j < NPF; ++j) rs[j] += xch[w][MQ * NPF * 4 + j][lane];
+        }
     }
     if (ROWSUM) {
 #pragma unroll
@@ -1455,12 +1485,16 @@ int netq_run_op(dd_net *net, int i, const int32_t *o, const uint8_t *input, int 
                 const int npf = npf_env ? npf_env : (items2 < 8192 && P.m >= 2048 ? 4 : 2);
                 const long long n_items = (long long)n_mgroups * dd_ceil_div(P.m, 16 * npf);
                 DD_REQUIRE(n_items < (1ll << 31), DD_E_CAPACITY, "dd_net_forward: uint8 conv %d: %lld wave items", i, n_items);
-                const dim3 grid((unsigned)((n_items + 3) / 4));
                 const bool rsum = P.zwc != 0;
                 const bool pipe = n_items < 8192;
-#define DD_QC2(MQ_, R_) do { if (npf == 4) hipLaunchKernelGGL((q_conv_k<MQ_, R_, 4, false>), grid, dim3(256), 0, s, P, (int)n_items, n_mgroups); \
-                                 else if (pipe) hipLaunchKernelGGL((q_conv_k<MQ_, R_, 2, true>), grid, dim3(256), 0, s, P, (int)n_items, n_mgroups); \
-                                 else hipLaunchKernelGGL((q_conv_k<MQ_, R_, 2, false>), grid, dim3(256), 0, s, P, (int)n_items, n_mgroups); } while (0)
+                static const int split_env = getenv("DD_Q_SPLITK") ? atoi(getenv("DD_Q_SPLITK")) : 1;
+                const bool split = split_env && P.kh * P.kw == 9 && n_items < 1024;       // (3x3: the k steps divide by the three filter rows; at 1 200 items the split costs: 40 -> 51 us)
+                const dim3 grid(split ? (unsigned)n_items : (unsigned)((n_items + 3) / 4)), block(split ? 192 : 256);
+#define DD_QC2(MQ_, R_) do { if (npf == 4 && split) hipLaunchKernelGGL((q_conv_k<MQ_, R_, 4, false, 3>), grid, block, 0, s, P, (int)n_items, n_mgroups); \
+                             else if (npf == 4) hipLaunchKernelGGL((q_conv_k<MQ_, R_, 4, false>), grid, block, 0, s, P, (int)n_items, n_mgroups); \
+                             else if (split) hipLaunchKernelGGL((q_conv_k<MQ_, R_, 2, true, 3>), grid, block, 0, s, P, (int)n_items, n_mgroups); \
+                             else if (pipe) hipLaunchKernelGGL((q_conv_k<MQ_, R_, 2, true>), grid, block, 0, s, P, (int)n_items, n_mgroups); \
+                             else hipLaunchKernelGGL((q_conv_k<MQ_, R_, 2, false>), grid, block, 0, s, P, (int)n_items, n_mgroups); } while (0)
 #define DD_QC(MQ_) do { if (rsum) DD_QC2(MQ_, true); else DD_QC2(MQ_, false); } while (0)
                 if (P.mq == 4) DD_QC(4); else if (P.mq == 3) DD_QC(3); else if (P.mq == 2) DD_QC(2); else DD_QC(1);
 #undef DD_QC2
