@@ -555,6 +555,7 @@ YOLO_ANCHORS = [[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 1
 YOLO_NC = 80
 FOCUS32 = os.environ.get('DD_YOLO_FOCUS32', '1') != '0'
 FOCUS_FUSE = os.environ.get('DD_YOLO_FOCUS_FUSE', '1') != '0'
+YOLO_C3_MERGE = os.environ.get('DD_YOLO_C3_MERGE', '1') != '0'      # C3 blocks: cv1 || cv2 as one layer into the concat tensor, bottlenecks in place (0: the round-3 program)
 
 
 class _YoloNames:
@@ -625,6 +626,18 @@ def compile_yolov5s(wd, in_size=640):
         s = P.T(src)
         cat = P.tensor(s['h'], s['w'], 2 * c_)
         left, right = P.view(cat, 0, c_), P.view(cat, c_, c_)
+        if YOLO_C3_MERGE and n > 0:
+            # cv1 || cv2 read the same tensor: ONE 1x1 layer with both filters writes [cv1 | cv2] straight into the concat tensor (one read of the
+            # block input instead of two: 629 + 629 -> 839 MB at 160x160 and 128 frames), and the bottlenecks run IN PLACE on its left half --
+            # their 3x3 layer reads the separate 1x1 output, the epilogue reads the residual element it is about to overwrite
+            w1, b1 = fold_conv_bn(wd, name + '.cv1')
+            w2, b2 = fold_conv_bn(wd, name + '.cv2')
+            P.conv(src, np.concatenate([w1, w2], axis=3), np.concatenate([b1, b2]), pad=0, act=ACT_SILU, dst=cat)
+            for i in range(n):
+                h = cv(f'{name}.m{i}.cv1', left)
+                w, b = fold_conv_bn(wd, f'{name}.m{i}.cv2')
+                P.conv(h, w, b, pad=1, act=ACT_SILU, res=left if shortcut else -1, dst=left)
+            return cv(name + '.cv3', cat, dst=dst)
         y = cv(name + '.cv1', src, dst=left if n == 0 else None)
         for i in range(n):
             h = cv(f'{name}.m{i}.cv1', y)

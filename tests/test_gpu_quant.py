@@ -109,23 +109,26 @@ def test_decoded_arrays(qnet):
         net.ssd_decode(None, 0.0, enable=False)
 
 
-def test_launch_of_384_frames_is_bit_exact():
-    """The bench's launch shape (one worker group = 384 frames per forward): picked slots against the integer oracle, every
-    other slot against the slot that holds the same frame (persistent blocks, tiles that straddle frames, the last tile of a frame)."""
+@pytest.mark.parametrize('n_frames, symmetric', [(384, False), (91, False), (91, True), (23, False)])
+def test_launch_of_many_frames_is_bit_exact(n_frames, symmetric):
+    """The bench's launch shape (one worker group = 384 frames per forward) and odd ones: picked slots against the integer oracle, every
+    other slot against the slot that holds the same frame (persistent blocks, tiles that straddle frames, the last tile of a frame).
+    91 frames: the register-filter pointwise kernel (from 8 192 pixels per launch) with a partly filled last tile on every map it takes,
+    merged predictors included; 23 frames: the same layers on the generic kernel, the 19x19 predictors still merged (8 303 pixels)."""
     from deepdish_amd import quantize, netsq
     from deepdish_amd.engine import Net
     from oracle import nets_quant
-    qm = quantize.synthetic_ssd_quant_model(1234)
+    qm = quantize.synthetic_ssd_quant_model(1234, symmetric_weights=symmetric)
     prog = netsq.compile_ssd_mobilenet_quant(qm)
-    net = Net(prog, max_batch=384)
+    net = Net(prog, max_batch=n_frames)
     base = _frames(4, 21)
-    idx = np.arange(384) % 4
-    idx[[0, 1, 190, 383]] = [3, 2, 1, 0]
+    idx = np.arange(n_frames) % 4
+    idx[[0, 1, n_frames // 2, n_frames - 1]] = [3, 2, 1, 0]
     net.forward(base[idx])
     box = net.read(tensor=prog.meta['box_tensor'])[:, :, 0, :]
     cls = net.read(tensor=prog.meta['cls_tensor'])[:, :, 0, :prog.meta['n_classes']]
     box_w, cls_w, _ = nets_quant.ssd_quant_forward(qm, base)
-    for z in range(384):
+    for z in range(n_frames):
         assert (box[z] == box_w[idx[z]]).all() and (cls[z] == cls_w[idx[z]]).all(), 'slot %d (frame %d)' % (z, idx[z])
 
 
