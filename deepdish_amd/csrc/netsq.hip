@@ -681,7 +681,7 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64, (COUT / (16 * MW)) * 
     static_assert(QTT % 64 == 0 && UNITS % NW == 0, "depthwise units over waves");
     constexpr int CPW = UNITS / NW;                                   // units per wave
     static_assert(FPT == 4 || CPW == 1, "several units per wave: one fragment quad only");
-    constexpr bool KEEP = CPW <= 2, FOLDP = !ROWSUM && KC <= 4;
+    constexpr bool KEEP = CPW <= 2, FOLDP = !ROWSUM && KC <= 4 && QTT == 64;      // (128-pixel tiles run on 128 registers: the 32 of the folded addends are not to be had)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (the wave number in a scalar register)
     const int fr = lane & 15, fq = lane >> 4;
@@ -799,15 +799,21 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64, (COUT / (16 * MW)) * 
     // ---- depthwise stage: this wave's planes x the four pixel fragments of the tile whose geometry is in buffer gbuf
     auto dw_planes = [&](int gbuf, int rsb) {
         int rs[4] = {0, 0, 0, 0};
+        constexpr int FB = QTT > 64 ? 2 : 4;                           // fragments in flight (see below)
+        constexpr bool TAP_ONCE = FB == 4;                             // the ring offsets of all four fragments up front (shared by the wave's planes), or per pass
         int tapoff[3][4];                                            // ring offset of this lane's tap of k step ks at its pixel of fragment f (plane 0)
         const int fb = 4 * ((wave * CPW) / C16);                       // the wave's fragment quad (one per wave: see the assertion)
+        auto taps = [&](int f0, int nfr) {
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
-            const i4v pi = pinfo[gbuf * QTT + 16 * (fb + f) + fr];
-            tapoff[0][f] = (row_up0 ? pi[1] : pi[0]) + tap_dx[0];
-            tapoff[1][f] = (row_up1 ? pi[2] : pi[1]) + tap_dx[1];
-            tapoff[2][f] = pi[2] + tap_dx[2];
-        }
+            for (int f = 0; f < 4; ++f) {
+                if (f < f0 || f >= f0 + nfr) continue;
+                const i4v pi = pinfo[gbuf * QTT + 16 * (fb + f) + fr];
+                tapoff[0][f] = (row_up0 ? pi[1] : pi[0]) + tap_dx[0];
+                tapoff[1][f] = (row_up1 ? pi[2] : pi[1]) + tap_dx[1];
+                tapoff[2][f] = pi[2] + tap_dx[2];
+            }
+        };
+        if constexpr (TAP_ONCE) taps(0, 4);
         auto plane = [&](int unit, int ci) {                         // (ci: a literal after unrolling when KEEP)
             const int cg = unit % C16;
             const int pofs = cg * PP;
@@ -821,9 +827,9 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64, (COUT / (16 * MW)) * 
             }
             // FB fragments in flight: all four, or two at a time where the block runs four waves per SIMD on 128 registers each (their
             // operand double buffer is 16 registers instead of 32; the other waves cover the shorter chains)
-            constexpr int FB = QTT > 64 ? 2 : 4;
 #pragma unroll
             for (int f0 = 0; f0 < 4; f0 += FB) {
+                if constexpr (!TAP_ONCE) taps(f0, FB);
                 i4v acc[FB];
 #pragma unroll
                 for (int f = 0; f < FB; ++f) acc[f] = i4v{0, 0, 0, 0};
