@@ -3317,6 +3317,49 @@ __global__ __launch_bounds__(256) void maxpool_k(const PoolP P) {
     *reinterpret_cast<h8 *>(P.out + (size_t)m * P.cs_out + P.coff_out + g * 8) = o;
 }
 
+// A cascade of N stride-1 k x k max pools (YOLOv5's SPP: 5, 9 and 13 as three 5 x 5 pools of each other) in ONE launch: a block holds the
+// H x W plane of one image and 8-channel group in LDS, pools it separably (row maxima, then column maxima: 2 k instead of k^2 taps), writes
+// the result into channel slice i of the destination and pools that again.  Three maxpool_k launches re-read their input from HBM at
+// 1.1 TB/s (47 us each at 128 frames); max of f16 values is exact either way: the same bits.
+constexpr int PC_GROUPS = 4;       // 8-channel groups per block: a pixel's 64 bytes are one sector of the NHWC row (one group alone would fetch four times its bytes)
+__global__ __launch_bounds__(256) void pool_cascade_k(const PoolP P, const int n_casc) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 pl[];
+    const int gblocks = (P.c >> 3) / PC_GROUPS, hw = P.H * P.W, items = hw * PC_GROUPS;
+    const int n = blockIdx.x / gblocks, g0 = (blockIdx.x - n * gblocks) * PC_GROUPS;
+    h8 *a = reinterpret_cast<h8 *>(pl), *b = a + items;            // [pixel][group]
+    for (int it = threadIdx.x; it < items; it += 256) {
+        const int p = it / PC_GROUPS, gs = it - p * PC_GROUPS;
+        a[it] = *reinterpret_cast<const h8 *>(P.in + ((size_t)n * hw + p) * P.cs_in + P.coff_in + (g0 + gs) * 8);
+    }
+    __syncthreads();
+    const int rad = P.k / 2;
+    const float inv_w = 1.f / (float)P.W;
+    auto row_of = [&](int p) { return (int)(((float)p + 0.5f) * inv_w); };      // p / W (exact: p < 4096)
+    for (int i = 0; i < n_casc; ++i) {
+        for (int it = threadIdx.x; it < items; it += 256) {         // row maxima (v_pk_max_f16: four instructions per tap)
+            const int p = it / PC_GROUPS, y = row_of(p), x = p - y * P.W;
+            h8 m = a[it];
+            for (int d = -rad; d <= rad; ++d) {
+                if (d == 0 || x + d < 0 || x + d >= P.W) continue;
+                m = __builtin_elementwise_max(m, a[it + d * PC_GROUPS]);
+            }
+            b[it] = m;
+        }
+        __syncthreads();
+        for (int it = threadIdx.x; it < items; it += 256) {         // column maxima of those
+            const int p = it / PC_GROUPS, gs = it - p * PC_GROUPS, y = row_of(p);
+            h8 m = b[it];
+            for (int d = -rad; d <= rad; ++d) {
+                if (d == 0 || y + d < 0 || y + d >= P.H) continue;
+                m = __builtin_elementwise_max(m, b[it + d * P.W * PC_GROUPS]);
+            }
+            a[it] = m;
+            *reinterpret_cast<h8 *>(P.out + ((size_t)n * hw + p) * P.cs_out + P.coff_out + i * P.c + (g0 + gs) * 8) = m;
+        }
+        __syncthreads();
+    }
+}
+
 // nearest x2 upsample into a (possibly wider) destination channel slice
 __global__ __launch_bounds__(256) void upsample2_k(const _Float16 *__restrict__ in, int H, int W, int cs_in, int coff_in,
                                                    int c, int m_out, _Float16 *__restrict__ out, int cs_out, int coff_out) {
@@ -4764,6 +4807,14 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
                 P.k = o[5]; P.stride = o[7]; P.pad = o[8]; P.ho = td->h; P.wo = td->w; P.c = o[12];
                 P.m = nimg * td->h * td->w;
                 P.out = reinterpret_cast<_Float16 *>(base(dst)); P.cs_out = td->cs; P.coff_out = td->coff;
+                if (o[6] > 1) {                                  // a cascade of o[6] stride-1 pools into consecutive channel slices (nets.py pool_cascade)
+                    const size_t lds = (size_t)2 * ts->h * ts->w * 16 * PC_GROUPS;
+                    DD_REQUIRE(P.stride == 1 && P.pad == P.k / 2 && (P.k & 1) && td->h == ts->h && td->w == ts->w && lds <= 64 * 1024 && P.coff_out + o[6] * P.c <= td->cs + td->coff &&
+                               (P.c >> 3) % PC_GROUPS == 0 && (long long)nimg * (P.c >> 3) < (1LL << 31), DD_E_ARG, "dd_net_forward: pool cascade %d: shape", i);
+                    hipLaunchKernelGGL(pool_cascade_k, dim3((unsigned)(nimg * ((P.c >> 3) / PC_GROUPS))), dim3(256), lds, s, P, o[6]);
+                    DD_LAUNCH_CHECK();
+                    break;
+                }
                 const long long total = (long long)P.m * (P.c >> 3);
                 DD_REQUIRE(total < (1LL << 31), DD_E_CAPACITY, "dd_net_forward: pooling layer of %lld items exceeds 32-bit indexing", total);
                 hipLaunchKernelGGL(maxpool_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, P);

@@ -297,6 +297,14 @@ class Program:
         self.info[-1] = dict(kernel='maxpool_k', flops=0, bytes=2 * s['c'] * (s['h'] * s['w'] + ho * wo), wbytes=0)
         return dst
 
+    def pool_cascade(self, src, k, n, dst_first):
+        """n stride-1 k x k max pools of each other in one launch (csrc/nets.hip pool_cascade_k): result i goes to the channel slice i * c behind
+        dst_first (a view of the concat tensor: YOLOv5's SPP)."""
+        s = self.T(src)
+        self._op(OP_MAXPOOL, src=src, dst=dst_first, kh=k, kw=n, stride=1, pad_t=k // 2, cout_pad=rup(s['c'], 8))
+        self.info[-1] = dict(kernel='pool_cascade_k', flops=0, bytes=2 * s['c'] * s['h'] * s['w'] * (1 + n), wbytes=0)
+        return dst_first
+
     def upsample2(self, src, dst):
         s = self.T(src)
         self._op(OP_UPSAMPLE, src=src, dst=dst, cout_pad=rup(s['c'], 8))
@@ -555,6 +563,7 @@ YOLO_ANCHORS = [[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 1
 YOLO_NC = 80
 FOCUS32 = os.environ.get('DD_YOLO_FOCUS32', '1') != '0'
 FOCUS_FUSE = os.environ.get('DD_YOLO_FOCUS_FUSE', '1') != '0'
+YOLO_SPP_FUSE = os.environ.get('DD_YOLO_SPP_FUSE', '1') != '0'      # SPP's three pools as one launch (same bits)
 YOLO_C3_MERGE = os.environ.get('DD_YOLO_C3_MERGE', '1') != '0'      # C3 blocks: cv1 || cv2 as one layer into the concat tensor, bottlenecks in place (0: the round-3 program)
 
 
@@ -676,11 +685,14 @@ def compile_yolov5s(wd, in_size=640):
     s = P.T(x)
     spp = P.tensor(s['h'], s['w'], 1024)                                    # [x | mp5 | mp9 | mp13]
     x = cv('m8.cv1', x, dst=P.view(spp, 0, 256))
-    src = x
-    for i, k in enumerate((5, 9, 13)):
-        # 5x5, 9x9 and 13x13 stride-1 max pools of x as a cascade of 5x5 pools (a max over a window of windows; taps outside the map
-        # are skipped, so the borders agree too): the same values with 75 taps per output instead of 275
-        src = P.maxpool(src, 5, 1, 2, dst=P.view(spp, 256 * (i + 1), 256))
+    # 5x5, 9x9 and 13x13 stride-1 max pools of x as a cascade of 5x5 pools (a max over a window of windows; taps outside the map
+    # are skipped, so the borders agree too): the same values with 75 taps per output instead of 275 -- and all three in one launch
+    if YOLO_SPP_FUSE:
+        P.pool_cascade(x, 5, 3, P.view(spp, 256, 256))
+    else:
+        src = x
+        for i, k in enumerate((5, 9, 13)):
+            src = P.maxpool(src, 5, 1, 2, dst=P.view(spp, 256 * (i + 1), 256))
     x = cv('m8.cv2', spp)
     x = c3('m9', x, 512, 1, False)
     cat23 = P.tensor(s['h'], s['w'], 512)                                   # [m21 | m10]
