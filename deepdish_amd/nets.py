@@ -348,6 +348,8 @@ class Program:
 def bn_affine(wd, scope):
     """(scale, shift) of an inference batch-norm; gamma optional (slim default scale=False).  A model that arrives with its batch
     norms already folded (a .tflite file: tools/tflite_reader.py) has `<layer>/biases` instead: scale 1, shift = the bias."""
+    if scope + '/scale' in wd:                                # a stand-alone batch norm as a .tflite file carries it: MUL + ADD constants
+        return wd[scope + '/scale'].astype(np.float32), wd[scope + '/shift'].astype(np.float32)
     if scope + '/moving_variance' not in wd and scope.endswith('/bn') and scope[:-3] + '/biases' in wd:
         b = wd[scope[:-3] + '/biases'].astype(np.float32)
         return np.ones_like(b), b
@@ -407,7 +409,7 @@ def compile_mars(wd, in_h=64, in_w=32):
     """tools/freeze_model.py:88-157 as an op program; input u8 BGR [n,64,32,3] -> f32 [n,128]."""
     P = Program(in_h, in_w)
     w, b = fold_conv_bn(wd, 'conv1_1')
-    x = c11 = P.stem(w, b, 1, ACT_ELU, swap_rb=True)                           # :175-177 BGR -> RGB, :101-105
+    x = c11 = P.stem(w, b, 1, ACT_ELU, swap_rb=bool(wd.get('__swap_rb__', True)))   # :175-177 BGR -> RGB, :101-105 (a .tflite graph says whether it reverses the channels)
     if Program.STEM_POOL_FUSE:       # conv1_1 is read by conv1_2 only: with >= 160 crops both run as one launch
         P.ops[-1][30] = 1            # (conv3x3_pool_rows_k<STEM>) and the conv1_1 tensor is not written
     w, b = fold_conv_bn(wd, 'conv1_2'); x = pool = P.conv(x, w, b, act=ACT_ELU, pool=True)   # :106-110 + :116 VALID pool

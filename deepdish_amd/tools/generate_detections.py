@@ -13,7 +13,7 @@ from .._lib import lib, check
 from ..runtime import default_context, ptr
 from .. import nets
 from ..engine import Net
-from .weights_io import load_named_weights
+from .weights_io import load_named_weights, load_mars_weights
 
 
 def crop_patches_device(ctx, frame_dev, H, W, boxes_int64, ph, pw):
@@ -50,7 +50,7 @@ class MarsImageEncoder(object):
 
     def __init__(self, model_filename, num_threads=1, max_batch=256, context=None):
         self.ctx = context or default_context()
-        wd = load_named_weights(model_filename, nets.synthetic_mars_weights)
+        wd = load_mars_weights(model_filename)                   # .tflite (generate_detections.py:151-162), .npz of named arrays, or synthetic[:seed]
         self.weights = wd
         self.net = Net(nets.compile_mars(wd), max_batch=max_batch, context=self.ctx)
         self.image_shape = (64, 32, 3)

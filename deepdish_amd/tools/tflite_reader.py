@@ -18,8 +18,8 @@ TENSOR_TYPES = {0: np.float32, 1: np.float16, 2: np.int32, 3: np.uint8, 4: np.in
 OPS = {0: 'ADD', 1: 'AVERAGE_POOL_2D', 2: 'CONCATENATION', 3: 'CONV_2D', 4: 'DEPTHWISE_CONV_2D', 6: 'DEQUANTIZE', 9: 'FULLY_CONNECTED',
        14: 'LOGISTIC', 17: 'MAX_POOL_2D', 18: 'MUL', 19: 'RELU', 21: 'RELU6', 22: 'RESHAPE', 23: 'RESIZE_BILINEAR', 25: 'SOFTMAX',
        28: 'TANH', 32: 'CUSTOM', 34: 'PAD', 39: 'TRANSPOSE', 40: 'MEAN', 41: 'SUB', 42: 'DIV', 43: 'SQUEEZE', 45: 'STRIDED_SLICE',
-       47: 'EXP', 49: 'SPLIT', 53: 'CAST', 76: 'RSQRT', 83: 'PACK', 92: 'SQUARE', 97: 'RESIZE_NEAREST_NEIGHBOR', 111: 'ELU',
-       114: 'QUANTIZE', 117: 'HARD_SWISH'}
+       47: 'EXP', 49: 'SPLIT', 53: 'CAST', 55: 'MAXIMUM', 74: 'SUM', 75: 'SQRT', 76: 'RSQRT', 83: 'PACK', 92: 'SQUARE', 97: 'RESIZE_NEAREST_NEIGHBOR',
+       105: 'REVERSE_V2', 11: 'L2_NORMALIZATION', 111: 'ELU', 114: 'QUANTIZE', 117: 'HARD_SWISH'}
 PADDING = {0: 'SAME', 1: 'VALID'}
 ACTIVATION = {0: 'none', 1: 'relu', 2: 'relu_n1_to_1', 3: 'relu6', 4: 'tanh'}
 
@@ -77,6 +77,8 @@ def _options(kind, op_table):
         return dict(act=ACTIVATION.get(t.scalar(0, 'i8'), '?'))
     if kind == 'FULLY_CONNECTED':
         return dict(act=ACTIVATION.get(t.scalar(0, 'i8'), '?'))
+    if kind == 'STRIDED_SLICE':                 # StridedSliceOptions: begin_mask, end_mask, ellipsis_mask, new_axis_mask, shrink_axis_mask
+        return dict(begin_mask=t.scalar(0, 'i32'), end_mask=t.scalar(1, 'i32'))
     return {}
 
 
@@ -230,3 +232,120 @@ def load_ssd_mobilenet(path):
         wd[name + '/biases'] = L['bias']
     wd['anchors'] = anc
     return 'f32', wd
+
+
+# ------------------------------------------------------------------------------------------- MARS encoder
+MARS_BLOCKS = [('conv2_1', 32, False, True), ('conv2_3', 32, False, False), ('conv3_1', 64, True, False),
+               ('conv3_3', 64, False, False), ('conv4_1', 128, True, False), ('conv4_3', 128, False, False)]
+
+
+def load_mars(path):
+    """`mars-64x32x3.tflite` (tools/generate_detections.py:151-177 upstream: float32 patches in, [n, 128] features out) -> the named float
+    weights deepdish_amd/nets.compile_mars takes, batch norms folded as the converter leaves them.
+
+    The file is absent from the reference tree, so the operator pattern is the one a TFLite conversion of tools/freeze_model.py's graph
+    gives as far as that can be told without it: every slim.conv2d / fully_connected with a normalizer arrives as CONV_2D /
+    FULLY_CONNECTED with the batch norm in filter and bias, followed by ELU; a block's leading batch norm (create_link, :17-21) as MUL +
+    ADD with constant operands; the skip as ADD of two activations; pool1 as a 3x3 stride-2 VALID MAX_POOL_2D; the projection as a 1x1
+    stride-2 CONV_2D; "ball" as MUL + ADD behind fc1's ELU; the unit-length tail (:153-156) in any spelling out of SQUARE / MUL / SUM / ADD /
+    SQRT / RSQRT / MAXIMUM / DIV / L2_NORMALIZATION.  A channel reversal in front (REVERSE_V2, or STRIDED_SLICE with a negative stride: the
+    frozen graph's BGR -> RGB, :175-177) sets `__swap_rb__`; without one the first layer takes the channels as they come.  Layers are
+    recognised by order, kernel size and channel counts; anything else raises UnsupportedModel naming the operator."""
+    g = read(path)
+    _need(len(g.inputs) == 1, g.ops[0], '%d graph inputs' % len(g.inputs))
+    x = g.tensors[g.inputs[0]]
+    _need(len(x.shape) == 4 and tuple(x.shape[1:]) == (64, 32, 3), g.ops[0], 'input %s (the encoder takes [n, 64, 32, 3] patches)' % (tuple(x.shape),))
+    const = lambda i: g.tensors[i].data if i >= 0 else None
+    convs, affines, pools, fc, flip, pending, n_skip = [], [], 0, None, False, None, 0
+    for op in g.ops:
+        k = op.kind
+        if k in ('CAST', 'DEQUANTIZE', 'RESHAPE', 'SQUEEZE', 'ELU'):
+            continue
+        if k == 'REVERSE_V2':
+            ax = const(op.inputs[1])
+            _need(fc is None and not convs and ax is not None and [int(v) % 4 for v in np.asarray(ax).reshape(-1)] == [3], op, 'only a reversal of the channel axis of the input is understood')
+            flip = True
+            continue
+        if k == 'STRIDED_SLICE':
+            st = const(op.inputs[3])
+            _need(fc is None and not convs and st is not None and list(np.asarray(st).reshape(-1)[:-1]) == [1] * (len(np.asarray(st).reshape(-1)) - 1) and int(np.asarray(st).reshape(-1)[-1]) == -1, op,
+                  'only a stride -1 slice of the channel axis of the input (BGR -> RGB) is understood')
+            flip = True
+            continue
+        if k == 'CONV_2D':
+            _need(fc is None, op, 'convolution behind the fully connected layer')
+            xi, w = g.tensors[op.inputs[0]], g.tensors[op.inputs[1]]
+            b = const(op.inputs[2]) if len(op.inputs) > 2 else None
+            o = op.options
+            _need(w.data is not None and xi.dtype == np.float32 and w.dtype == np.float32, op, 'float32 activations and constant float32 filters (a quantised encoder is not built)')
+            _need(o['padding'] == 'SAME' and o['stride_w'] == o['stride_h'] and o['act'] == 'none' and o['dilation_w'] == 1 and o['dilation_h'] == 1, op, 'SAME padding, square stride, no fused activation')
+            wt = np.ascontiguousarray(np.transpose(w.data, (1, 2, 3, 0))).astype(np.float32)     # OHWI -> HWIO
+            convs.append(dict(op=op, w=wt, b=np.zeros(wt.shape[3], np.float32) if b is None else np.asarray(b, np.float32).reshape(-1), stride=int(o['stride_w'])))
+            continue
+        if k == 'MAX_POOL_2D':
+            o = op.options
+            _need((o['filter_w'], o['filter_h'], o['stride_w'], o['stride_h'], o['padding']) == (3, 3, 2, 2, 'VALID') and len(convs) == 2, op, 'pool1 is 3x3 stride 2 VALID behind conv1_2')
+            pools += 1
+            continue
+        if k == 'FULLY_CONNECTED':
+            w, b = const(op.inputs[1]), const(op.inputs[2]) if len(op.inputs) > 2 else None
+            _need(fc is None and w is not None and w.ndim == 2 and w.dtype == np.float32 and op.options.get('act', 'none') == 'none', op, 'one float32 fully connected layer with constant weights')
+            fc = dict(op=op, w=np.ascontiguousarray(w.T).astype(np.float32), b=np.zeros(w.shape[0], np.float32) if b is None else np.asarray(b, np.float32).reshape(-1))
+            continue
+        if k in ('MUL', 'ADD'):
+            cs = [const(i) for i in op.inputs[:2]]
+            vec = [c for c in cs if c is not None and c.size > 1]
+            if vec and len([c for c in cs if c is None]) == 1:                      # activation (*|+) per-channel constant: one half of a batch norm
+                act_in = op.inputs[0] if cs[0] is None else op.inputs[1]
+                v = np.asarray(vec[0], np.float32).reshape(-1)
+                if k == 'MUL':
+                    _need(pending is None, op, 'two scalings in a row')
+                    pending = (v, op.outputs[0])
+                else:
+                    _need(pending is not None and pending[1] == act_in and len(pending[0]) == len(v), op, 'a per-channel ADD that does not follow its MUL (batch norm as scale, then shift)')
+                    affines.append((pending[0], v))
+                    pending = None
+                continue
+            if k == 'ADD' and cs[0] is None and cs[1] is None and fc is None:       # the skip connection
+                n_skip += 1
+                continue
+            _need(fc is not None, op, 'an element-wise %s that is neither a batch norm nor a skip connection' % k)
+            continue                                                                 # (unit-length tail: x * x, + 1e-8, x * rsqrt)
+        if k in ('SQUARE', 'SUM', 'SQRT', 'RSQRT', 'DIV', 'MAXIMUM', 'L2_NORMALIZATION'):
+            _need(fc is not None, op, '%s in front of the fully connected layer' % k)
+            continue
+        _need(False, op, 'not part of the MARS encoder graph as this reader knows it')
+    last = g.ops[-1]
+    _need(pending is None, last, 'a per-channel MUL without its ADD')
+    _need(len(convs) == 16 and len(affines) == 6 and pools == 1 and fc is not None and n_skip == 6, last,
+          '%d convolutions, %d stand-alone batch norms, %d pools, %d skip additions, %s fully connected layer (MARS: 16, 6, 1, 6, one)' % (len(convs), len(affines), pools, n_skip, 'a' if fc else 'no'))
+    wd = {'__swap_rb__': flip}
+
+    def take(name, c, kk, cin, cout, stride, what):
+        _need(c['w'].shape == (kk, kk, cin, cout) and c['stride'] == stride, c['op'], '%s: filter %s stride %d (expected %dx%d %d -> %d stride %d)' % (what, c['w'].shape, c['stride'], kk, kk, cin, cout, stride))
+        wd[name + '/weights'], wd[name + '/biases'] = c['w'], c['b']
+
+    it = iter(convs)
+    take('conv1_1', next(it), 3, 3, 32, 1, 'conv1_1')
+    take('conv1_2', next(it), 3, 32, 32, 1, 'conv1_2')
+    cin = 32
+    for name, c, inc, first in MARS_BLOCKS:
+        blk = [next(it) for _ in range(3 if inc else 2)]
+        proj = [b for b in blk if b['w'].shape[0] == 1]
+        main = [b for b in blk if b['w'].shape[0] == 3]
+        _need(len(proj) == (1 if inc else 0) and len(main) == 2, blk[0]['op'], 'block %s: %d 3x3 and %d 1x1 convolutions' % (name, len(main), len(proj)))
+        take(name + '/1', main[0], 3, cin, c, 2 if inc else 1, name + '/1')
+        take(name + '/2', main[1], 3, c, c, 1, name + '/2')
+        if inc:
+            take(name + '/projection', proj[0], 1, cin, c, 2, name + '/projection')
+            _need(not np.any(proj[0]['b']), proj[0]['op'], 'the projection has no bias (freeze_model.py:30-36)')
+            del wd[name + '/projection/biases']
+        cin = c
+    order = [b[0] + '/bn' for b in MARS_BLOCKS if not b[3]] + ['ball']
+    for name, (sc, sh) in zip(order, affines):
+        want = 128 if name == 'ball' else dict((b[0] + '/bn', p[1]) for b, p in zip(MARS_BLOCKS[1:], MARS_BLOCKS[:-1]))[name]
+        _need(len(sc) == want, last, 'batch norm %s has %d channels (expected %d)' % (name, len(sc), want))
+        wd[name + '/scale'], wd[name + '/shift'] = sc, sh
+    _need(fc['w'].shape == (4096, 128), fc['op'], 'fc1 weights %s (expected 4096 -> 128)' % (fc['w'].shape,))
+    wd['fc1/weights'], wd['fc1/biases'] = fc['w'], fc['b']
+    return wd

@@ -9,8 +9,10 @@ from . import flatbuf
 from .. import nets
 
 TYPE_CODE = {np.dtype(np.float32): 0, np.dtype(np.float16): 1, np.dtype(np.int32): 2, np.dtype(np.uint8): 3, np.dtype(np.int64): 4, np.dtype(np.int8): 9}
-OP_CODE = {'CONCATENATION': 2, 'CONV_2D': 3, 'DEPTHWISE_CONV_2D': 4, 'LOGISTIC': 14, 'RESHAPE': 22, 'CUSTOM': 32, 'MAX_POOL_2D': 17, 'ADD': 0}
-OPTIONS_TYPE = {'CONV_2D': 1, 'DEPTHWISE_CONV_2D': 2, 'CONCATENATION': 10, 'RESHAPE': 17}
+OP_CODE = {'CONCATENATION': 2, 'CONV_2D': 3, 'DEPTHWISE_CONV_2D': 4, 'LOGISTIC': 14, 'RESHAPE': 22, 'CUSTOM': 32, 'MAX_POOL_2D': 17, 'ADD': 0,
+           'MUL': 18, 'FULLY_CONNECTED': 9, 'ELU': 111, 'REVERSE_V2': 105, 'SUM': 74, 'SQRT': 75, 'DIV': 42}
+OPTIONS_TYPE = {'CONV_2D': 1, 'DEPTHWISE_CONV_2D': 2, 'CONCATENATION': 10, 'RESHAPE': 17, 'MAX_POOL_2D': 5, 'FULLY_CONNECTED': 8, 'ADD': 11, 'MUL': 21,
+                'DIV': 29, 'SUM': 27}
 ACT = {'none': 0, 'relu': 1, 'relu6': 3}
 
 
@@ -46,6 +48,12 @@ class GraphWriter:
             return b.table({0: ('i32', o['axis']), 1: ('i8', 0)})
         if kind == 'RESHAPE':
             return b.table({0: ('offset', b.scalars(o['new_shape'], 'i32'))})
+        if kind == 'MAX_POOL_2D':                 # Pool2DOptions: padding (1 = VALID), strides, filter, activation
+            return b.table({0: ('i8', 1 if o.get('padding', 'VALID') == 'VALID' else 0), 1: ('i32', o['stride']), 2: ('i32', o['stride']), 3: ('i32', o['k']), 4: ('i32', o['k']), 5: ('i8', 0)})
+        if kind in ('ADD', 'MUL', 'DIV', 'FULLY_CONNECTED'):
+            return b.table({0: ('i8', 0), 1: ('i8', 0)})      # (a second field so that the table is not empty: fused activation NONE)
+        if kind == 'SUM':                         # ReducerOptions: keep_dims
+            return b.table({0: ('bool', True), 1: ('i8', 0)})
         return 0
 
     def tobytes(self):
@@ -156,6 +164,96 @@ def ssd_mobilenet_graph(model, anchors=None):
                                                     num_classes=n_cls - 1, y_scale=10.0, x_scale=10.0, h_scale=5.0, w_scale=5.0, use_regular_nms=False)))
     W.outputs = outs
     return W
+
+
+def mars_graph(wd, reverse_channels=True):
+    """Named float weights of the MARS encoder (deepdish_amd/nets.synthetic_mars_weights or the arrays of an .npz; batch norms raw or folded)
+    -> GraphWriter of the graph as tools/tflite_reader.load_mars documents it: channel reversal, CONV_2D with the batch norm in filter and
+    bias + ELU, block batch norms as MUL + ADD, skip ADDs, pool1, FULLY_CONNECTED, "ball", the unit-length tail as MUL / SUM / ADD / SQRT / DIV."""
+    W = GraphWriter('MARS 64x32x3 encoder (float), written by deepdish_amd')
+    f32 = np.float32
+    x = W.tensor('images', [1, 64, 32, 3], f32)
+    W.inputs = [x]
+    cnt = [0]
+
+    def T(shape, name=None):
+        cnt[0] += 1
+        return W.tensor(name or 't%d' % cnt[0], shape, f32)
+
+    def const(name, arr, dtype=f32):
+        a = np.ascontiguousarray(arr, dtype=dtype)
+        return W.tensor(name, list(a.shape), dtype, a)
+
+    def conv(name, src, hw, w_hwio, bias, stride):
+        h, w_ = hw
+        ho, wo = -(-h // stride), -(-w_ // stride)
+        cout = w_hwio.shape[3]
+        fw = const(name + '/weights', np.transpose(w_hwio, (3, 0, 1, 2)))
+        ins = [src, fw] + ([const(name + '/bias', bias)] if bias is not None else [-1])
+        out = T([1, ho, wo, cout], name)
+        W.op('CONV_2D', ins, [out], dict(stride=stride, act='none'))
+        return out, (ho, wo)
+
+    def elu(src, shape):
+        out = T(shape)
+        W.op('ELU', [src], [out])
+        return out
+
+    def affine(name, src, shape, sc, sh):
+        m = T(shape)
+        W.op('MUL', [src, const(name + '/scale', sc)], [m])
+        a = T(shape)
+        W.op('ADD', [m, const(name + '/shift', sh)], [a])
+        return a
+
+    rev = x
+    if reverse_channels:                                               # the frozen graph's BGR -> RGB (tools/freeze_model.py:175-177)
+        rev = T([1, 64, 32, 3])
+        W.op('REVERSE_V2', [x, const('axis', [3], np.int32)], [rev])
+    hw = (64, 32)
+    w, b = nets.fold_conv_bn(wd, 'conv1_1'); t, hw = conv('conv1_1', rev, hw, w, b, 1); t = elu(t, [1, hw[0], hw[1], 32])
+    w, b = nets.fold_conv_bn(wd, 'conv1_2'); t, hw = conv('conv1_2', t, hw, w, b, 1); t = elu(t, [1, hw[0], hw[1], 32])
+    hw = ((hw[0] - 3) // 2 + 1, (hw[1] - 3) // 2 + 1)
+    p = T([1, hw[0], hw[1], 32], 'pool1')
+    W.op('MAX_POOL_2D', [t], [p], dict(k=3, stride=2, padding='VALID'))
+    raw, cin = p, 32
+    for name, c, inc, first in nets.MARS_BLOCKS:
+        pre = raw
+        if not first:
+            sc, sh = nets.bn_affine(wd, name + '/bn')
+            pre = elu(affine(name + '/bn', raw, [1, hw[0], hw[1], cin], sc, sh), [1, hw[0], hw[1], cin])
+        w, b = nets.fold_conv_bn(wd, name + '/1')
+        h1, hw2 = conv(name + '/1', pre, hw, w, b, 2 if inc else 1)
+        h1 = elu(h1, [1, hw2[0], hw2[1], c])
+        h2, _ = conv(name + '/2', h1, hw2, wd[name + '/2/weights'], wd[name + '/2/biases'], 1)
+        skip = raw
+        if inc:
+            skip, _ = conv(name + '/projection', raw, hw, wd[name + '/projection/weights'], None, 2)
+        out = T([1, hw2[0], hw2[1], c], name + '/add')
+        W.op('ADD', [skip, h2], [out])
+        raw, hw, cin = out, hw2, c
+    flat = T([1, hw[0] * hw[1] * cin])
+    W.op('RESHAPE', [raw], [flat], dict(new_shape=[1, hw[0] * hw[1] * cin]))
+    w, b = nets.fold_conv_bn(wd, 'fc1', 'fc1/bn')                       # [4096, 128]
+    fc = T([1, 128], 'fc1')
+    W.op('FULLY_CONNECTED', [flat, const('fc1/weights', np.ascontiguousarray(w.T)), const('fc1/bias', b)], [fc])
+    f = elu(fc, [1, 128])
+    sc, sh = nets.bn_affine(wd, 'ball')
+    f = affine('ball', f, [1, 128], sc, sh)
+    sq = T([1, 128]); W.op('MUL', [f, f], [sq])
+    sm = T([1, 1]); W.op('SUM', [sq, const('sum_axis', [1], np.int32)], [sm])
+    ep = T([1, 1]); W.op('ADD', [sm, const('eps', [1e-8])], [ep])
+    nr = T([1, 1]); W.op('SQRT', [ep], [nr])
+    out = T([1, 128], 'features'); W.op('DIV', [f, nr], [out])
+    W.outputs = [out]
+    return W
+
+
+def write_mars(wd, path, reverse_channels=True):
+    data = mars_graph(wd, reverse_channels).tobytes()
+    with open(path, 'wb') as f:
+        f.write(data)
+    return len(data)
 
 
 def write_ssd_mobilenet(model, path, anchors=None):

@@ -4,7 +4,8 @@ The reference loads `.tflite` / `.pb` blobs (all absent from its tree, .MISSING_
 build reads its own `.npz` of named f32 arrays (names as in deepdish_amd/nets.py).  A model path of
 the form `synthetic[:seed]...`, or any path when DEEPDISH_SYNTHETIC_WEIGHTS=1, yields seeded random
 weights of the right architecture (what tests and bench.py use).  SSD-MobileNet `.tflite` files (uint8 or
-float) are read by tools/tflite_reader.py; other graphs and frozen `.pb` files are an explicit error.
+float) and MARS encoder `.tflite` files (float) are read by tools/tflite_reader.py; other graphs and frozen `.pb`
+files are an explicit error.
 
 `load_ssd_model` is what the SSD-MobileNet plugins call: it returns ('uint8', QModel) for the reference's own kind
 of file -- a uint8-quantised model (tools/ssd_mobilenet.py:102 upstream; `synthetic...uint8` names build one from
@@ -28,13 +29,24 @@ def load_named_weights(model_file, synthetic_fn):
     hint = ''
     if name.endswith('.tflite'):
         hint = (' A .tflite file is parsed by deepdish_amd/tools/tflite_reader.py (tensors, buffers, quantisation, operators); only the '
-                'SSD-MobileNet-v1 detector graph is mapped onto a program so far (tools/weights_io.load_ssd_model) -- the MARS encoder and '
-                'YOLOv5 graphs are not.')
+                'SSD-MobileNet-v1 detector (tools/weights_io.load_ssd_model) and the MARS encoder (load_mars_weights) graphs are mapped onto programs '
+                'so far -- YOLOv5 graphs are not.')
     elif name.endswith('.pb'):
         hint = ' A frozen TensorFlow graph (.pb, tools/generate_detections.py:118-148 upstream) is not read here: convert it offline to an .npz of the named arrays.'
     raise FileNotFoundError(
         '%s: cannot load model weights (%s). Supply an .npz of named arrays, or use a "synthetic[:seed]" '
         'model path / DEEPDISH_SYNTHETIC_WEIGHTS=1 for seeded random weights.%s' % (model_file, name, hint))
+
+
+def load_mars_weights(model_file):
+    """What the encoder constructors call: a `.tflite` file on disk goes through tools/tflite_reader.load_mars (the reference's
+    `mars-64x32x3.tflite`, generate_detections.py:151-162), anything else through load_named_weights."""
+    from .. import nets
+    name = str(model_file)
+    if name.endswith('.tflite') and os.path.exists(name):
+        from . import tflite_reader
+        return tflite_reader.load_mars(name)
+    return load_named_weights(model_file, nets.synthetic_mars_weights)
 
 
 def load_ssd_model(model_file):

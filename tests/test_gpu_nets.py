@@ -129,3 +129,25 @@ def test_shared_activation_buffers_give_the_same_features():
         np.testing.assert_array_equal(shared.read(), plain.read(), err_msg='%d crops' % n)
     with pytest.raises(DeepDishHipError):
         shared.read(tensor=prog.meta['tensors']['pool1'])
+
+
+def test_box_encoder_loads_a_tflite_file(tmp_path):
+    """create_box_encoder('.../mars-64x32x3.tflite') as deepdish.py:505-510 constructs it: the encoder written to disk in the interchange
+    format gives, bit for bit, the features of the same weights handed over as named arrays (tools/tflite_reader.load_mars)."""
+    import numpy as np
+    from deepdish_amd import nets
+    from deepdish_amd.tools import tflite_writer
+    from deepdish_amd.tools.generate_detections import create_box_encoder, MarsImageEncoder
+    wd = nets.synthetic_mars_weights(4321)
+    path = str(tmp_path / 'mars-64x32x3.tflite')
+    tflite_writer.write_mars(wd, path)
+    enc = create_box_encoder(path, batch_size=32)
+    rng = np.random.default_rng(5)
+    frame = rng.integers(0, 256, (240, 320, 3), dtype=np.uint8)
+    boxes = [[10, 20, 40, 90], [100, 50, 60, 120], [200, 30, 50, 100]]
+    got = enc(frame, boxes)
+    assert got.shape == (3, 128) and np.allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-3)
+    np.savez(str(tmp_path / 'mars.npz'), **wd)
+    ref = create_box_encoder(str(tmp_path / 'mars.npz'), batch_size=32)
+    want = ref(frame, boxes)
+    np.testing.assert_array_equal(got, want)

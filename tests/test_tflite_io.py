@@ -106,3 +106,55 @@ def test_other_model_files_fail_loudly(tmp_path):
     with pytest.raises(FileNotFoundError) as e:
         load_named_weights(str(p), nets.synthetic_mars_weights)
     assert 'frozen' in str(e.value) or '.pb' in str(e.value)
+
+
+def test_mars_encoder_round_trip(tmp_path):
+    """create_box_encoder('.../mars-64x32x3.tflite') (generate_detections.py:151-162 upstream): named weights -> file -> named weights
+    gives the same program bytes as the weights handed over in memory -- batch norms folded where the converter folds them, the block
+    batch norms as scale / shift, the fully connected layer transposed back, the channel reversal noticed."""
+    from deepdish_amd import nets
+    from deepdish_amd.tools import tflite_reader as R, tflite_writer as Wr
+    from deepdish_amd.tools.weights_io import load_mars_weights
+    wd = nets.synthetic_mars_weights(11)
+    p = str(tmp_path / 'mars-64x32x3.tflite')
+    Wr.write_mars(wd, p)
+    g = R.read(p)
+    kinds = [op.kind for op in g.ops]
+    assert kinds[0] == 'REVERSE_V2' and kinds.count('CONV_2D') == 16 and kinds.count('ELU') == 2 + 6 + 5 + 1 and kinds[-1] == 'DIV'
+    got = load_mars_weights(p)
+    assert got['__swap_rb__'] is True and got['fc1/weights'].shape == (4096, 128) and 'conv3_1/projection/biases' not in got
+    a, b = nets.compile_mars(wd), nets.compile_mars(got)
+    assert bytes(a.blob) == bytes(b.blob) and all((x == y).all() for x, y in zip(a.ops, b.ops))
+    # a file without the reversal: the first layer takes the channels as they come
+    Wr.write_mars(wd, p, reverse_channels=False)
+    got = R.load_mars(p)
+    assert got['__swap_rb__'] is False
+    c = nets.compile_mars(got)
+    assert bytes(c.blob) != bytes(a.blob)
+
+
+def test_mars_reader_refuses_other_graphs_by_name(tmp_path, golden_dir):
+    from deepdish_amd import nets
+    from deepdish_amd.tools import tflite_reader as R, tflite_writer as Wr
+    with pytest.raises(R.UnsupportedModel) as e:              # the detector fixture is no encoder
+        R.load_mars(os.path.join(golden_dir, 'tiny_quant_graph.tflite'))
+    assert '64, 32, 3' in str(e.value) or 'input' in str(e.value)
+    wd = nets.synthetic_mars_weights(3)
+    W = Wr.mars_graph(wd)
+    # an operator the encoder does not have, in the middle of the graph
+    i = next(k for k, o in enumerate(W.ops) if o['kind'] == 'MAX_POOL_2D')
+    t = W.ops[i]['outputs'][0]
+    extra = W.tensor('squashed', W.tensors[t]['shape'], np.float32)
+    W.ops.insert(i + 1, dict(code=W._code('LOGISTIC'), kind='LOGISTIC', inputs=[t], outputs=[extra], options={}, custom_options=None))
+    p = str(tmp_path / 'odd.tflite')
+    open(p, 'wb').write(W.tobytes())
+    with pytest.raises(R.UnsupportedModel) as e:
+        R.load_mars(p)
+    assert 'LOGISTIC' in str(e.value)
+    # a block short: the counts are named
+    W = Wr.mars_graph(wd)
+    W.ops = [o for o in W.ops if not (o['kind'] == 'CONV_2D' and W.tensors[o['outputs'][0]]['name'] == 'conv4_3/2')]
+    open(p, 'wb').write(W.tobytes())
+    with pytest.raises(R.UnsupportedModel) as e:
+        R.load_mars(p)
+    assert '15 convolutions' in str(e.value)
