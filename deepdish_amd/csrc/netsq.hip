@@ -650,6 +650,7 @@ struct QDwpwP {
     const int *cbias;                // [COUT]
     const long long *cq;             // [COUT]: cbias * M + C (the pointwise requantisation's addend per channel; used when no row sums are)
     int zwc, NR;
+    int dup;                         // CIN = 32 only: the depthwise outputs are written to k slots 32..63 as well (see the kernel)
     unsigned wo_magic, nr_magic, tpf_magic;   // floor(2^32 / d) + 1 for the output width, the ring size, the tiles per frame (exact for every value divided here)
     unsigned long long *dbg;         // DD_Q_STAMPS=1: per wave, cycles spent in each part of the tile loop (diagnostic launches only)
     QReq Rd, Rp;
@@ -665,6 +666,8 @@ constexpr int QT = 64;               // pixels per tile
 //   * FOLDP (no row sums, K <= 256): the pointwise addends, 32 registers.
 // MW = 16-channel fragments of the pointwise filter per wave: 4 (64 channels, <= 128 VGPRs of filter, 256-register waves, two per SIMD) or
 // 2 (32 channels, 128-register waves, four per SIMD -- measured slower, 131 vs 89 us on the 512-channel block: issue-bound, not latency-bound).
+// P.dup (CIN = 32: half of the 64-byte k slice is free): the depthwise stage writes its bytes into BOTH halves and the host packs hi into the
+// filter's first 32 k slots, lo into the other 32 -- the split filter in ONE MFMA per fragment, no row sums, no second filter registers.
 // HL: the pointwise filter as w - zw split into hi = clamp(w - zw, -128, 127) and lo = rest, two MFMAs per fragment and k slice on one
 // accumulator instead of one MFMA plus the zwc * rowsum correction: for the layers with few input channels the matrix pipe has the time
 // and the row-sum machinery (dot products, cross-lane sums, LDS atomics, an add per output) goes.
@@ -861,6 +864,9 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64, (COUT / (16 * MW)) * 
                     packed ^= 0x80808080u;
                     if (ROWSUM) rs[f0 + f] = sdot4((int)packed, 0x01010101, rs[f0 + f]);
                     *reinterpret_cast<unsigned *>(opnd + ((size_t)cg * QTT + 16 * (fb + f0 + f) + fr) * 16 + 4 * fq) = packed;
+                    if constexpr (2 * CIN == CINP && !ROWSUM && !HL) {   // (32 channels in a 64-byte k slice) the same bytes again in the slice's other half
+                        if (P.dup) *reinterpret_cast<unsigned *>(opnd + ((size_t)(cg + C16) * QTT + 16 * (fb + f0 + f) + fr) * 16 + 4 * fq) = packed;
+                    }
                 }
             }
         };
@@ -1565,8 +1571,9 @@ int netq_run_op(dd_net *net, int i, const int32_t *o, const uint8_t *input, int 
             P.w = reinterpret_cast<const i4v *>(W + (size_t)(uint32_t)o[16]);
             P.w2 = o[18] ? reinterpret_cast<const i4v *>(W + (size_t)(uint32_t)o[18]) : nullptr;       // o[18]: the lo part of a split pointwise filter
             P.cbias = reinterpret_cast<const int *>(W + (size_t)(uint32_t)o[17]);
-            P.zwc = o[38]; P.Rp = make_req(o);
+            P.zwc = o[38]; P.Rp = make_req(o); P.dup = o[47];
             { int32_t d[48] = {0}; d[32] = o[22]; d[33] = o[23]; d[36] = o[24]; d[37] = o[25]; d[40] = o[28]; P.Rd = make_req(d); }
+            DD_REQUIRE(!P.dup || (cin == 32 && P.zwc == 0 && !P.w2), DD_E_ARG, "dd_net_forward: uint8 block %d: duplicated operand bytes are for 32 input channels", i);
             DD_REQUIRE(o[45] != 0 && o[46] != 0, DD_E_ARG, "dd_net_forward: uint8 block %d: the program carries no folded requantisation constants (compiled by an older netsq.py?)", i);
             DD_REQUIRE(cin == ts->cs && cout == td->cs && P.Rd.e >= 1 && P.Rp.e >= 1 && !P.Rd.linear && !P.Rp.linear && P.off_y >= 0 && P.off_x >= 0 &&
                        (P.ho - 1) * stride + 2 + P.off_y <= P.H + 1 && (P.wo - 1) * stride + 2 + P.off_x <= P.W + 1, DD_E_ARG,

@@ -19,6 +19,7 @@ FUSE_BLOCKS = os.environ.get('DD_Q_FUSE', '1') != '0'      # MobileNet blocks as
 SPLIT_PW = os.environ.get('DD_Q_SPLIT_PW', '1') != '0'      # pointwise filters of the blocks with <= SPLIT_PW_MAX_CIN input channels as hi + lo parts (no row sums)
 SPLIT_PW_MAX_CIN = int(os.environ.get('DD_Q_SPLIT_PW_MAX_CIN', '128'))
 SPLIT_PW_MIN_CIN = int(os.environ.get('DD_Q_SPLIT_PW_MIN_CIN', '64'))       # block 1 (32 channels) measured slower split: 308 vs 294 us
+DUP32 = os.environ.get('DD_Q_DUP32', '1') != '0'              # block 1: split pointwise filter through the free half of the k slice
 MERGE_HEADS = os.environ.get('DD_Q_MERGE_HEADS', '1') != '0'  # class + box predictor of a feature map with 512 / 1024 channels as one op
 FUSED_SHAPES = {(32, 64, 1), (64, 128, 2), (128, 128, 1), (128, 256, 2), (256, 256, 1), (256, 512, 2), (512, 512, 1)}
 FEATURE_LAYERS = ['pw11', 'pw13', 'extra1_2', 'extra2_2', 'extra3_2', 'extra4_2']
@@ -246,6 +247,16 @@ def compile_ssd_mobilenet_quant(qm):
         wp, cb, kcpt = pack_conv(Lp, QEPI_Q16)
         zwc = 128 - int(Lp['w_zp'])
         w_lo = 0
+        dup = 0
+        if DUP32 and cin == 32 and zwc != 0:
+            # 32 channels fill half of the 64-byte k slice: the kernel writes the depthwise bytes into both halves, the filter's halves are the
+            # hi and lo parts of w - zw -- the split filter in one MFMA, no activation row sums (block 1: 304 -> ~225 vector instructions per tile)
+            x = Lp['w'].astype(np.int64) - int(Lp['w_zp'])
+            hi = np.clip(x, -128, 127)
+            if (x - hi).max() <= 127:
+                wp, _, kcpt = pack_conv(dict(Lp, w=np.concatenate([hi + 128, x - hi + 128], axis=2).astype(np.int64)), QEPI_Q16)
+                cb = (Lp['bias'].astype(np.int64) + (128 - int(Lp['in_zp'])) * x.reshape(cin, cout).sum(axis=0)).astype(np.int32)
+                zwc, dup = 0, 1
         if SPLIT_PW and SPLIT_PW_MIN_CIN <= cin <= SPLIT_PW_MAX_CIN and zwc != 0:
             # few input channels: the filter as (w - zw) = hi + lo, two MFMAs per k slice instead of one plus the row-sum correction
             x = Lp['w'].astype(np.int64) - int(Lp['w_zp'])
@@ -258,7 +269,7 @@ def compile_ssd_mobilenet_quant(qm):
                 zwc = 0
         dst = P.qtensor(ho, wo, cout, Lp['out_zp'])
         raw = dict(rp)
-        raw.update({38: zwc, 39: int(Lp['in_zp']), 45: P.add_blob(folded_addends(dcb, rd)), 46: P.add_blob(folded_addends(cb, rp))})
+        raw.update({38: zwc, 39: int(Lp['in_zp']), 45: P.add_blob(folded_addends(dcb, rd)), 46: P.add_blob(folded_addends(cb, rp)), 47: dup})
         P._op(OP_QDWPW, src=src, dst=dst, kh=1, kw=1, stride=stride, pad_t=pt, pad_l=pl, cin=cin, cout=cout, cout_pad=cout, kpad=kcpt,
               w_off=P.add_blob(wp), b_off=P.add_blob(cb), aff_off=w_lo, ho=ho, wo=wo,
               p=[P.add_blob(dwa), P.add_blob(dcb), rd[32], rd[33], rd[36], rd[37]], bk=rd[40], raw=raw)
