@@ -1494,7 +1494,10 @@ int netq_run_op(dd_net *net, int i, const int32_t *o, const uint8_t *input, int 
                 // 23 -> 16 us, but 53 -> 65, 86 -> 95, 68 -> 78 us on the layers with 19 k+ items (b12 / b13 pointwise, 19x19 class predictor).
                 const long long items2 = (long long)n_mgroups * dd_ceil_div(P.m, 32);
                 static const int npf_env = getenv("DD_Q_NPF") ? atoi(getenv("DD_Q_NPF")) : 0;
-                const int npf = npf_env ? npf_env : (items2 < 8192 && P.m >= 2048 ? 4 : 2);
+                // (end of round: with the register-filter kernel on the big 1x1 layers and the k split on the small 3x3 ones, two fragments win or tie on
+                // every layer left here -- 87 -> 78 us over the eleven small layers; the rule used to be four below 8 192 items)
+                const int npf = npf_env ? npf_env : 2;
+                (void)items2;
                 const long long n_items = (long long)n_mgroups * dd_ceil_div(P.m, 16 * npf);
                 DD_REQUIRE(n_items < (1ll << 31), DD_E_CAPACITY, "dd_net_forward: uint8 conv %d: %lld wave items", i, n_items);
                 const bool rsum = P.zwc != 0;
