@@ -495,6 +495,7 @@ struct QDwmP {
     int stride, off_y, off_x, ho, wo, m;
     const uint2 *dw_a; const int *dw_cb;
     uint8_t *out;
+    unsigned hw_magic, wo_magic, c16_magic;   // floor(2^32 / d) + 1; hw_magic = 0: the pixel index times hw does not fit 32 bits (large maps: plain divisions)
     QReq R;
 };
 
@@ -504,8 +505,8 @@ __global__ __launch_bounds__(256) void q_dwm_k(const QDwmP P, const int n_items)
     const int fr = lane & 15, fq = lane >> 4;
     const int item = blockIdx.x * 4 + wave;
     if (item >= n_items) return;
-    const int cg = item % P.c16, fg = item / P.c16;                 // planes fastest: the waves of a block read the same pixels' other planes
-    const size_t PP = (size_t)(P.W + 2) * 16, RP = PP * P.c16, PPo = (size_t)(P.wo + 2) * 16;
+    const int fg = (int)__umulhi((unsigned)item, P.c16_magic), cg = item - fg * P.c16;   // planes fastest: the waves of a block read the same pixels' other planes
+    const unsigned PP = (unsigned)(P.W + 2) * 16u, RP = PP * (unsigned)P.c16, PPo = (unsigned)(P.wo + 2) * 16u;    // (32-bit offsets: the launcher checks the tensor sizes)
     const uint2 ab = P.dw_a[cg * 64 + lane];
     const i4v cbv = *reinterpret_cast<const i4v *>(P.dw_cb + cg * 16 + 4 * fq);
     unsigned dmask[4];
@@ -518,9 +519,13 @@ __global__ __launch_bounds__(256) void q_dwm_k(const QDwmP P, const int n_items)
         int q = (fg * 4 + f) * 16 + fr;
         live[f] = q < P.m;
         q = min(q, P.m - 1);
-        const int n = q / hw, r = q - n * hw, y = r / P.wo, x = r - y * P.wo;
-        src[f] = P.in + ((size_t)n * (P.H + 2) + y * P.stride + P.off_y) * RP + (size_t)cg * PP + (size_t)(x * P.stride + P.off_x) * 16;
-        dst[f] = P.out + (((size_t)n * (P.ho + 2) + y + 1) * P.c16 + cg) * PPo + (size_t)(x + 1) * 16 + 4 * fq;
+        // (a division without the hardware's help is ~25 vector instructions, and a wave item had eight of them around its 24 MFMAs)
+        int n, y;
+        if (P.hw_magic) { n = (int)__umulhi((unsigned)q, P.hw_magic); y = (int)__umulhi((unsigned)(q - n * hw), P.wo_magic); }
+        else { n = q / hw; y = (q - n * hw) / P.wo; }
+        const int r = q - n * hw, x = r - y * P.wo;
+        src[f] = P.in + (size_t)((unsigned)(n * (P.H + 2) + y * P.stride + P.off_y) * RP + (unsigned)cg * PP + (unsigned)(x * P.stride + P.off_x) * 16u);
+        dst[f] = P.out + (size_t)((unsigned)((n * (P.ho + 2) + y + 1) * P.c16 + cg) * PPo + (unsigned)(x + 1) * 16u + 4u * (unsigned)fq);
     }
     i4v acc[4];
 #pragma unroll
@@ -529,7 +534,7 @@ __global__ __launch_bounds__(256) void q_dwm_k(const QDwmP P, const int n_items)
 #pragma unroll
     for (int ks = 0; ks < 3; ++ks) {
         const int tp = min(4 * ks + fq, 8);
-        const size_t to = (size_t)(tp / 3) * RP + (size_t)(tp % 3) * 16;
+        const unsigned to = (unsigned)(tp / 3) * RP + (unsigned)(tp % 3) * 16u;
 #pragma unroll
         for (int f = 0; f < 4; ++f) b[ks][f] = *reinterpret_cast<const i4v *>(src[f] + to);
     }
@@ -1551,6 +1556,10 @@ int netq_run_op(dd_net *net, int i, const int32_t *o, const uint8_t *input, int 
                 Q.dw_cb = reinterpret_cast<const int *>(W + (size_t)(uint32_t)o[21]);
                 const long long n_items = (long long)P.c16 * dd_ceil_div(Q.m, 64);
                 DD_REQUIRE(n_items < (1ll << 31), DD_E_CAPACITY, "dd_net_forward: uint8 depthwise %d: %lld wave items", i, n_items);
+                Q.hw_magic = (unsigned)((1ull << 32) / (unsigned)(P.ho * P.wo)) + 1u; Q.wo_magic = (unsigned)((1ull << 32) / (unsigned)P.wo) + 1u; Q.c16_magic = (unsigned)((1ull << 32) / (unsigned)P.c16) + 1u;
+                if ((long long)Q.m * (P.ho * P.wo) >= (1ll << 32)) Q.hw_magic = 0;
+                DD_REQUIRE(n_items * P.c16 < (1ll << 32) && (long long)(nimg + 1) * (P.H + 2) * P.c16 * (P.W + 2) * 16 < (1ll << 32) &&
+                           (long long)(nimg + 1) * (P.ho + 2) * P.c16 * (P.wo + 2) * 16 < (1ll << 32), DD_E_CAPACITY, "dd_net_forward: uint8 depthwise %d: beyond 32-bit offsets", i);
                 if (P.R.lo == 0 && P.R.hi == 255) hipLaunchKernelGGL((q_dwm_k<true>), dim3((unsigned)((n_items + 3) / 4)), dim3(256), 0, s, Q, (int)n_items);
                 else hipLaunchKernelGGL((q_dwm_k<false>), dim3((unsigned)((n_items + 3) / 4)), dim3(256), 0, s, Q, (int)n_items);
                 DD_LAUNCH_CHECK();
