@@ -157,6 +157,7 @@ struct QConvP {
     int Ho, Wo, c16_out;                          // QEPI_Q16: destination geometry (Ho == ho, Wo == wo)
     long long img_bytes_out; int row_bytes, base_off, cout_store;   // QEPI_ROWS: plain [pixel][row_bytes] rows at base_off of each image
     int zwc;                                      // 128 - zw
+    unsigned hw_magic, wo_magic;                  // floor(2^32 / d) + 1 for ho * wo and wo; hw_magic = 0: not exact for this launch (plain divisions)
     QReq R;
 };
 
@@ -181,8 +182,10 @@ __global__ __launch_bounds__(256) void q_conv_k(const QConvP P, const int n_item
         live[j] = q < P.m;
         q = min(q, P.m - 1);
         const int hw = P.ho * P.wo;
-        qn[j] = q / hw; const int r = q - qn[j] * hw;
-        qy[j] = r / P.wo; qx[j] = r - qy[j] * P.wo;
+        int r;                                                      // (a division without the hardware's help is ~25 vector instructions: 100 per item, next to as few as 32 MFMAs)
+        if (P.hw_magic) { qn[j] = (int)__umulhi((unsigned)q, P.hw_magic); r = q - qn[j] * hw; qy[j] = (int)__umulhi((unsigned)r, P.wo_magic); }
+        else { qn[j] = q / hw; r = q - qn[j] * hw; qy[j] = r / P.wo; }
+        qx[j] = r - qy[j] * P.wo;
         base[j] = P.in + ((size_t)qn[j] * (P.H + 2) + qy[j] * P.stride + P.off_y) * RP + (size_t)(qx[j] * P.stride + P.off_x) * 16;
     }
     i4v acc[MQ][NPF];
@@ -505,7 +508,7 @@ __global__ __launch_bounds__(256) void q_dwm_k(const QDwmP P, const int n_items)
     const int fr = lane & 15, fq = lane >> 4;
     const int item = blockIdx.x * 4 + wave;
     if (item >= n_items) return;
-    const int fg = (int)__umulhi((unsigned)item, P.c16_magic), cg = item - fg * P.c16;   // planes fastest: the waves of a block read the same pixels' other planes
+    const int fg = P.hw_magic ? (int)__umulhi((unsigned)item, P.c16_magic) : item / P.c16, cg = item - fg * P.c16;   // planes fastest: the waves of a block read the same pixels' other planes
     const unsigned PP = (unsigned)(P.W + 2) * 16u, RP = PP * (unsigned)P.c16, PPo = (unsigned)(P.wo + 2) * 16u;    // (32-bit offsets: the launcher checks the tensor sizes)
     const uint2 ab = P.dw_a[cg * 64 + lane];
     const i4v cbv = *reinterpret_cast<const i4v *>(P.dw_cb + cg * 16 + 4 * fq);
@@ -1493,6 +1496,8 @@ int netq_run_op(dd_net *net, int i, const int32_t *o, const uint8_t *input, int 
                 if (ok) return DD_OK;
             }
             auto run_generic = [&](QConvP &P) -> int {
+                P.hw_magic = P.wo > 1 && (long long)P.m * (P.ho * P.wo) < (1ll << 32) ? (unsigned)((1ull << 32) / (unsigned)(P.ho * P.wo)) + 1u : 0u;   // (a divisor of 1 has no 32-bit magic)
+                P.wo_magic = (unsigned)((1ull << 32) / (unsigned)P.wo) + 1u;
                 const int n_mgroups = dd_ceil_div(P.n_mfrag, P.mq);
                 // Pixel fragments per wave item.  Two by default; four (half the weight fetches per MFMA, twice the registers) where the launch has
                 // few wave items anyway and pixels enough -- measured per layer at 384 frames: extras 48 -> 38, 63 -> 39 us, 5x5 class predictor
@@ -1557,7 +1562,7 @@ int netq_run_op(dd_net *net, int i, const int32_t *o, const uint8_t *input, int 
                 const long long n_items = (long long)P.c16 * dd_ceil_div(Q.m, 64);
                 DD_REQUIRE(n_items < (1ll << 31), DD_E_CAPACITY, "dd_net_forward: uint8 depthwise %d: %lld wave items", i, n_items);
                 Q.hw_magic = (unsigned)((1ull << 32) / (unsigned)(P.ho * P.wo)) + 1u; Q.wo_magic = (unsigned)((1ull << 32) / (unsigned)P.wo) + 1u; Q.c16_magic = (unsigned)((1ull << 32) / (unsigned)P.c16) + 1u;
-                if ((long long)Q.m * (P.ho * P.wo) >= (1ll << 32)) Q.hw_magic = 0;
+                if ((long long)Q.m * (P.ho * P.wo) >= (1ll << 32) || P.wo < 2 || P.c16 < 2) Q.hw_magic = 0;       // (a divisor of 1 has no 32-bit magic)
                 DD_REQUIRE(n_items * P.c16 < (1ll << 32) && (long long)(nimg + 1) * (P.H + 2) * P.c16 * (P.W + 2) * 16 < (1ll << 32) &&
                            (long long)(nimg + 1) * (P.ho + 2) * P.c16 * (P.wo + 2) * 16 < (1ll << 32), DD_E_CAPACITY, "dd_net_forward: uint8 depthwise %d: beyond 32-bit offsets", i);
                 if (P.R.lo == 0 && P.R.hi == 255) hipLaunchKernelGGL((q_dwm_k<true>), dim3((unsigned)((n_items + 3) / 4)), dim3(256), 0, s, Q, (int)n_items);
