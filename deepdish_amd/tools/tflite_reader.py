@@ -255,7 +255,17 @@ def load_mars(path):
     _need(len(g.inputs) == 1, g.ops[0], '%d graph inputs' % len(g.inputs))
     x = g.tensors[g.inputs[0]]
     _need(len(x.shape) == 4 and tuple(x.shape[1:]) == (64, 32, 3), g.ops[0], 'input %s (the encoder takes [n, 64, 32, 3] patches)' % (tuple(x.shape),))
-    const = lambda i: g.tensors[i].data if i >= 0 else None
+    def const(i):
+        """Constant data of tensor i, also through a DEQUANTIZE of a constant (float16 weight files keep their filters that way)."""
+        if i < 0:
+            return None
+        t = g.tensors[i]
+        if t.data is not None:
+            return t.data
+        op = g.made_by(i)
+        if op is not None and op.kind == 'DEQUANTIZE' and g.tensors[op.inputs[0]].data is not None and g.tensors[op.inputs[0]].dtype == np.float16:
+            return g.tensors[op.inputs[0]].data.astype(np.float32)
+        return None
     convs, affines, pools, fc, flip, pending, n_skip = [], [], 0, None, False, None, 0
     for op in g.ops:
         k = op.kind
@@ -274,10 +284,11 @@ def load_mars(path):
             continue
         if k == 'CONV_2D':
             _need(fc is None, op, 'convolution behind the fully connected layer')
-            xi, w = g.tensors[op.inputs[0]], g.tensors[op.inputs[1]]
+            xi, wdata = g.tensors[op.inputs[0]], const(op.inputs[1])
             b = const(op.inputs[2]) if len(op.inputs) > 2 else None
             o = op.options
-            _need(w.data is not None and xi.dtype == np.float32 and w.dtype == np.float32, op, 'float32 activations and constant float32 filters (a quantised encoder is not built)')
+            _need(wdata is not None and xi.dtype == np.float32 and wdata.dtype == np.float32, op, 'float32 activations and constant float32 (or float16 behind DEQUANTIZE) filters: a quantised encoder is not built')
+            w = type('W', (), dict(data=wdata))
             _need(o['padding'] == 'SAME' and o['stride_w'] == o['stride_h'] and o['act'] == 'none' and o['dilation_w'] == 1 and o['dilation_h'] == 1, op, 'SAME padding, square stride, no fused activation')
             wt = np.ascontiguousarray(np.transpose(w.data, (1, 2, 3, 0))).astype(np.float32)     # OHWI -> HWIO
             convs.append(dict(op=op, w=wt, b=np.zeros(wt.shape[3], np.float32) if b is None else np.asarray(b, np.float32).reshape(-1), stride=int(o['stride_w'])))

@@ -9,7 +9,7 @@ from . import flatbuf
 from .. import nets
 
 TYPE_CODE = {np.dtype(np.float32): 0, np.dtype(np.float16): 1, np.dtype(np.int32): 2, np.dtype(np.uint8): 3, np.dtype(np.int64): 4, np.dtype(np.int8): 9}
-OP_CODE = {'CONCATENATION': 2, 'CONV_2D': 3, 'DEPTHWISE_CONV_2D': 4, 'LOGISTIC': 14, 'RESHAPE': 22, 'CUSTOM': 32, 'MAX_POOL_2D': 17, 'ADD': 0,
+OP_CODE = {'DEQUANTIZE': 6, 'CONCATENATION': 2, 'CONV_2D': 3, 'DEPTHWISE_CONV_2D': 4, 'LOGISTIC': 14, 'RESHAPE': 22, 'CUSTOM': 32, 'MAX_POOL_2D': 17, 'ADD': 0,
            'MUL': 18, 'FULLY_CONNECTED': 9, 'ELU': 111, 'REVERSE_V2': 105, 'SUM': 74, 'SQRT': 75, 'DIV': 42}
 OPTIONS_TYPE = {'CONV_2D': 1, 'DEPTHWISE_CONV_2D': 2, 'CONCATENATION': 10, 'RESHAPE': 17, 'MAX_POOL_2D': 5, 'FULLY_CONNECTED': 8, 'ADD': 11, 'MUL': 21,
                 'DIV': 29, 'SUM': 27}
@@ -166,7 +166,7 @@ def ssd_mobilenet_graph(model, anchors=None):
     return W
 
 
-def mars_graph(wd, reverse_channels=True):
+def mars_graph(wd, reverse_channels=True, half_weights=False):
     """Named float weights of the MARS encoder (deepdish_amd/nets.synthetic_mars_weights or the arrays of an .npz; batch norms raw or folded)
     -> GraphWriter of the graph as tools/tflite_reader.load_mars documents it: channel reversal, CONV_2D with the batch norm in filter and
     bias + ELU, block batch norms as MUL + ADD, skip ADDs, pool1, FULLY_CONNECTED, "ball", the unit-length tail as MUL / SUM / ADD / SQRT / DIV."""
@@ -188,7 +188,12 @@ def mars_graph(wd, reverse_channels=True):
         h, w_ = hw
         ho, wo = -(-h // stride), -(-w_ // stride)
         cout = w_hwio.shape[3]
-        fw = const(name + '/weights', np.transpose(w_hwio, (3, 0, 1, 2)))
+        if half_weights:                                                # a float16 weight file: the filter behind a DEQUANTIZE
+            hw_ = const(name + '/weights_f16', np.transpose(w_hwio, (3, 0, 1, 2)), np.float16)
+            fw = T(list(np.transpose(w_hwio, (3, 0, 1, 2)).shape), name + '/weights')
+            W.op('DEQUANTIZE', [hw_], [fw])
+        else:
+            fw = const(name + '/weights', np.transpose(w_hwio, (3, 0, 1, 2)))
         ins = [src, fw] + ([const(name + '/bias', bias)] if bias is not None else [-1])
         out = T([1, ho, wo, cout], name)
         W.op('CONV_2D', ins, [out], dict(stride=stride, act='none'))
@@ -249,8 +254,8 @@ def mars_graph(wd, reverse_channels=True):
     return W
 
 
-def write_mars(wd, path, reverse_channels=True):
-    data = mars_graph(wd, reverse_channels).tobytes()
+def write_mars(wd, path, reverse_channels=True, half_weights=False):
+    data = mars_graph(wd, reverse_channels, half_weights).tobytes()
     with open(path, 'wb') as f:
         f.write(data)
     return len(data)

@@ -131,6 +131,12 @@ def test_mars_encoder_round_trip(tmp_path):
     assert got['__swap_rb__'] is False
     c = nets.compile_mars(got)
     assert bytes(c.blob) != bytes(a.blob)
+    # a float16 weight file (filters behind DEQUANTIZE): the filters come back rounded to half precision, everything else as written
+    Wr.write_mars(wd, p, half_weights=True)
+    got = R.load_mars(p)
+    w, _ = nets.fold_conv_bn(wd, 'conv4_1/1')
+    np.testing.assert_array_equal(got['conv4_1/1/weights'], w.astype(np.float16).astype(np.float32))
+    np.testing.assert_array_equal(got['ball/scale'], nets.bn_affine(wd, 'ball')[0])
 
 
 def test_mars_reader_refuses_other_graphs_by_name(tmp_path, golden_dir):
