@@ -19,6 +19,7 @@
 #include "common.h"
 #include "ssd_dev.h"
 #include "net_priv.h"
+#include "mars_tail.h"
 
 namespace {
 
@@ -30,7 +31,7 @@ enum { OP_INPUT = 1, OP_CONV = 2, OP_DWCONV = 3, OP_MAXPOOL = 4, OP_UPSAMPLE = 5
 enum { ACT_NONE = 0, ACT_RELU6 = 1, ACT_ELU = 2, ACT_SILU = 3, ACT_RELU = 4, ACT_SIGMOID = 5 };
 enum { EPI_F16 = 0, EPI_F32 = 1, EPI_SSD_HEAD = 2, EPI_YOLO = 3 };
 // dd_net_op_launches: 0 = the op's own kernel, 1 = no launch (folded into the next op's), else the fused / special kernel
-enum { OPK_DEFAULT = 0, OPK_FOLDED = 1, OPK_POOL_ROWS = 2, OPK_POOL_ROWS_STEM = 3, OPK_RES_UNIT = 4, OPK_SSD_FRONT = 5, OPK_C64_ROWS = 6, OPK_S2_ROWS = 7, OPK_CONV_WS = 8, OPK_WS_DW = 9, OPK_DWPW_ROWS = 10, OPK_SSD_HEAD_DEC = 11, OPK_RES_PAIR = 12, OPK_YOLO_HEAD_DEC = 13 };
+enum { OPK_DEFAULT = 0, OPK_FOLDED = 1, OPK_POOL_ROWS = 2, OPK_POOL_ROWS_STEM = 3, OPK_RES_UNIT = 4, OPK_SSD_FRONT = 5, OPK_C64_ROWS = 6, OPK_S2_ROWS = 7, OPK_CONV_WS = 8, OPK_WS_DW = 9, OPK_DWPW_ROWS = 10, OPK_SSD_HEAD_DEC = 11, OPK_RES_PAIR = 12, OPK_YOLO_HEAD_DEC = 13, OPK_MARS_WS = 14, OPK_FOLDED_PREV = 15 };
 enum { DT_F16 = 0, DT_F32 = 1, DT_U8 = 2 };
 
 constexpr int OP_WORDS = 48;       // int32 words per op record (see deepdish_amd/nets.py)
@@ -4036,6 +4037,43 @@ int launch_dwpw_big(hipStream_t s, ConvP &P, int device, int nimg) {
     return DD_OK;
 }
 
+
+// MARS conv4_x on the crop-resident weight-stationary kernels (csrc/mars_tail.hip).  They run at EVERY batch size (their K halves
+// meet at the end: not conv_glds_k's summation order), so a crop's feature does not depend on the launch shape.  DD_MARS_WS=0: off.
+bool mars_ws_on() {
+    static const bool on = !(getenv("DD_MARS_WS") && atoi(getenv("DD_MARS_WS")) == 0);
+    return on;
+}
+bool mars_ws_s1_eligible(const ConvP &P) {
+    return mars_ws_on() && P.kh == 3 && P.kw == 3 && P.stride == 1 && P.pad_t == 1 && P.pad_l == 1 && P.H == 8 && P.W == 4 && P.ho == 8 && P.wo == 4 &&
+           P.cin == 128 && P.cout == 128 && P.cout_pad == 128 && P.kpad >= 1152 && P.epi == EPI_F16 && P.cs_in % 8 == 0 && P.coff_in % 8 == 0 &&
+           P.cs_out % 8 == 0 && P.coff_out % 8 == 0 &&
+           ((P.act == ACT_ELU && !P.res && !P.out2) || (P.act == ACT_NONE && P.res && P.cs_res % 8 == 0 && P.coff_res % 8 == 0 && (!P.out2 || (P.cs_out2 % 8 == 0 && P.coff_out2 % 8 == 0))));
+}
+bool mars_ws_s2_eligible(const ConvP &P) {                        // the 3x3 stride-2 layer of a widening block; the caller checks the projection behind it
+    return mars_ws_on() && P.kh == 3 && P.kw == 3 && P.stride == 2 && P.pad_t == 0 && P.pad_l == 0 && P.H == 16 && P.W == 8 && P.ho == 8 && P.wo == 4 &&
+           P.cin == 64 && P.cout == 128 && P.cout_pad == 128 && P.kpad >= 576 && P.epi == EPI_F16 && P.act == ACT_ELU && !P.res && !P.out2 &&
+           P.cs_in % 8 == 0 && P.coff_in % 8 == 0 && P.cs_out % 8 == 0 && P.coff_out % 8 == 0;
+}
+bool mars_proj_follows(const dd_net *net, int i, const ConvP &P) {   // op i + 1: 1x1 stride 2, 64 -> 128, no activation, same map as op i's input
+    const int32_t *q = net->prog.data() + net->ops_off + (size_t)(i + 1) * OP_WORDS;
+    if (q[0] != OP_CONV || q[5] != 1 || q[6] != 1 || q[7] != 2 || q[8] != 0 || q[9] != 0 || q[10] != 64 || q[11] != 128 || q[12] != 128 ||
+        q[14] != ACT_NONE || q[15] != EPI_F16 || q[3] >= 0 || q[4] >= 0 || q[13] < 64 || q[1] < 0 || q[2] < 0) return false;
+    const TensorDesc &qs = net->tensors[q[1]], &qd = net->tensors[q[2]];
+    return qs.h == 16 && qs.w == 8 && qd.h == 8 && qd.w == 4 && qs.cs % 8 == 0 && qs.coff % 8 == 0 && qd.cs % 8 == 0 && qd.coff % 8 == 0 && qd.dtype == DT_F16;
+}
+MarsWsP mars_ws_params(const ConvP &P, int nimg) {
+    MarsWsP Q;
+    memset(&Q, 0, sizeof(Q));
+    Q.in = P.in; Q.cs_in = P.cs_in; Q.coff_in = P.coff_in;
+    Q.w = P.w; Q.kpad = P.kpad; Q.bias = P.bias;
+    Q.res = P.res; Q.cs_res = P.cs_res; Q.coff_res = P.coff_res;
+    Q.out = static_cast<_Float16 *>(P.out); Q.cs_out = P.cs_out; Q.coff_out = P.coff_out;
+    Q.out2 = P.out2; Q.cs_out2 = P.cs_out2; Q.coff_out2 = P.coff_out2; Q.aff2 = P.aff2; Q.cout_pad = P.cout_pad;
+    Q.zero = P.zero; Q.n_img = nimg;
+    return Q;
+}
+
 }  // namespace
 
 extern "C" {
@@ -4045,6 +4083,7 @@ extern "C" {
 // n_ops * 48 words.  See deepdish_amd/nets.py (Program.serialize) for the field order.
 static int net_create(dd_ctx *ctx, const int32_t *program_host, int n_words, const void *weights_host,
                       int64_t n_weight_bytes, int max_batch, dd_net **out, bool share);
+int dd_net_destroy(dd_net *n);
 
 int dd_net_create(dd_ctx *ctx, const int32_t *program_host, int n_words, const void *weights_host,
                   int64_t n_weight_bytes, int max_batch, dd_net **out) {
@@ -4069,6 +4108,7 @@ static int net_create(dd_ctx *ctx, const int32_t *program_host, int n_words, con
     const int nt = program_host[1], nb = program_host[2], no = program_host[3];
     DD_REQUIRE(n_words == 8 + nt * TENSOR_WORDS + nb * 2 + no * OP_WORDS, DD_E_ARG, "dd_net_create: program size mismatch");
     dd_net *n = new dd_net();
+    struct Guard { dd_net *n; ~Guard() { if (n) (void)dd_net_destroy(n); } } guard{n};      // every early return below frees what was built so far
     n->ctx = ctx;
     n->max_batch = max_batch;
     n->prog.assign(program_host, program_host + n_words);
@@ -4082,19 +4122,9 @@ static int net_create(dd_ctx *ctx, const int32_t *program_host, int n_words, con
         // lifetimes from the op list (it follows the buffer table): [first writer, last reader]; -1 = never written (the input of a view-only chain)
         const int32_t *ops = p + (size_t)nb * 2;
         std::vector<int> first(nb, -1), last(nb, -1);
-        auto touch = [&](int t, int i, bool write) {
-            if (t < 0 || t >= nt) return;
-            const int b = n->tensors[t].buf;
-            if (write && first[b] < 0) first[b] = i;
-            if (first[b] < 0) first[b] = i;
-            last[b] = std::max(last[b], i);
-        };
-        for (int i = 0; i < no; ++i) {
-            const int32_t *o = ops + (size_t)i * OP_WORDS;
-            DD_REQUIRE(o[0] < 16, DD_E_ARG, "dd_net_create_shared: uint8 programs keep one buffer per tensor (their borders are set once)");
-            touch(o[1], i, false); touch(o[3], i, false); touch(o[2], i, true); touch(o[4], i, true);
-        }
-        if (n->out_tensor >= 0) last[n->tensors[n->out_tensor].buf] = no;
+        for (int t = 0; t < nt; ++t) DD_REQUIRE(n->tensors[t].buf >= 0 && n->tensors[t].buf < nb, DD_E_ARG, "dd_net_create_shared: tensor %d names buffer %d of %d", t, n->tensors[t].buf, nb);
+        for (int i = 0; i < no; ++i)
+            DD_REQUIRE((ops + (size_t)i * OP_WORDS)[0] < 16, DD_E_ARG, "dd_net_create_shared: uint8 programs keep one buffer per tensor (their borders are set once)");
         // An op flagged "only the next op reads my output" (word 30) may run inside that op's launch -- a first layer folded into the
         // pooled layer behind it, a residual unit held back until its second layer, a pair of units until the fourth -- so every buffer
         // touched anywhere in such a chain of ops is live over the whole chain.
@@ -4105,8 +4135,6 @@ static int net_create(dd_ctx *ctx, const int32_t *program_host, int n_words, con
             for (int k = i; k <= j; ++k) { gs[k] = i; ge[k] = j; }
             i = j + 1;
         }
-        std::fill(first.begin(), first.end(), -1);
-        std::fill(last.begin(), last.end(), -1);
         auto touch2 = [&](int t, int i) {
             if (t < 0 || t >= nt) return;
             const int b = n->tensors[t].buf;
@@ -4175,6 +4203,7 @@ static int net_create(dd_ctx *ctx, const int32_t *program_host, int n_words, con
     n->tile_mode = getenv("DD_TILE_MODE") ? atoi(getenv("DD_TILE_MODE")) : 0;
     DD_HIP(hipMalloc(&n->d_weights, (size_t)n_weight_bytes + 256));
     DD_HIP(hipMemcpy(n->d_weights, weights_host, (size_t)n_weight_bytes, hipMemcpyHostToDevice));
+    guard.n = nullptr;
     *out = n;
     return DD_OK;
 }
@@ -4477,6 +4506,7 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
     bool unit_pending = false;
     ConvP pw_p;                                                   // pointwise layer whose only reader is the next (depthwise) op
     bool pw_pending = false;
+    bool proj_done = false;                                       // the previous op's launch also ran this op (a 1x1 stride-2 projection)
     ConvP pair_a, pair_b;                                         // a whole residual unit held back: it may run with the next unit (res_pair_rows_k)
     bool pair_pending = false;
     int pair_op = -1;
@@ -4536,6 +4566,7 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
                 break;
             }
             case OP_CONV: {
+                if (proj_done) { proj_done = false; net->op_launch[i] = OPK_FOLDED_PREV; break; }
                 ConvP P;
                 memset(&P, 0, sizeof(P));
                 P.in = reinterpret_cast<const _Float16 *>(base(src)); P.H = ts->h; P.W = ts->w; P.cs_in = ts->cs;
@@ -4650,6 +4681,22 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
                     }
                     if (o[29] && pool_rows_fusable(P, nimg)) net->op_launch[i] = P.src8 ? OPK_POOL_ROWS_STEM : OPK_POOL_ROWS;
                     rc = launch_conv3x3_rw(s, P, nimg, o[29] != 0, net->ctx->device);
+                } else if (mars_ws_s1_eligible(P)) {
+                    const MarsWsP Q = mars_ws_params(P, nimg);
+                    net->op_launch[i] = OPK_MARS_WS;
+                    rc = mars_ws128_launch(s, net->ctx->device, Q, P.res ? MARS_WS_S1_RES : MARS_WS_S1, P.act, P.out2 != nullptr);
+                } else if (o[30] == 3 && i + 1 < net->n_ops && mars_ws_s2_eligible(P) && mars_proj_follows(net, i, P)) {
+                    // 3x3 stride-2 layer of a widening residual block + the 1x1 stride-2 projection of the block's raw input (the next op): one launch
+                    const int32_t *q = net->prog.data() + net->ops_off + (size_t)(i + 1) * OP_WORDS;
+                    const TensorDesc &qs = net->tensors[q[1]], &qd = net->tensors[q[2]];
+                    MarsWsP Q = mars_ws_params(P, nimg);
+                    Q.in2 = reinterpret_cast<const _Float16 *>(base(q[1])); Q.cs_in2 = qs.cs; Q.coff_in2 = qs.coff;
+                    Q.w2 = reinterpret_cast<const _Float16 *>(net->d_weights + (size_t)(uint32_t)q[16]); Q.kpad2 = q[13];
+                    Q.bias2 = reinterpret_cast<const float *>(net->d_weights + (size_t)(uint32_t)q[17]);
+                    Q.out2 = reinterpret_cast<_Float16 *>(base(q[2])); Q.cs_out2 = qd.cs; Q.coff_out2 = qd.coff;
+                    net->op_launch[i] = OPK_MARS_WS;
+                    rc = mars_ws128_launch(s, net->ctx->device, Q, MARS_WS_S2_PROJ, P.act, false);
+                    proj_done = true;
                 } else if (s2_rows_eligible(P, nimg, net->max_batch)) {
                     net->op_launch[i] = OPK_S2_ROWS;
                     rc = launch_conv3x3_s2_rows(s, P, nimg, net->ctx->device);

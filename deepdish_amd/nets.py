@@ -46,6 +46,7 @@ class Program:
     STEM_POOL_FUSE = os.environ.get('DD_STEM_POOL_FUSE', '1') != '0'   # MARS conv1_1 folded into conv1_2's launch
     RES_UNIT_FUSE = os.environ.get('DD_RES_UNIT_FUSE', '1') != '0'     # MARS conv2_x: both 3x3 layers of a residual unit in one launch
     RES_PAIR_FUSE = os.environ.get('DD_RES_PAIR_FUSE', '1') != '0'     # ... and the two units of the stage in one launch (res_pair_rows_k)
+    PROJ_FUSE = os.environ.get('DD_PROJ_FUSE', '1') != '0'             # MARS widening blocks: 3x3 stride-2 layer + 1x1 stride-2 projection in one launch
     SSD_FRONT_FUSE = os.environ.get('DD_SSD_FRONT_FUSE', '1') != '0'   # SSD conv0 + MobileNet block 1 in one launch
     PW_DW_FUSE = os.environ.get('DD_PW_DW_FUSE', '1') != '0'           # MobileNet: pointwise layer + the next block's depthwise layer in one launch
 
@@ -421,6 +422,8 @@ def compile_mars(wd, in_h=64, in_w=32):
         if Program.RES_UNIT_FUSE and not inc and c == 32:
             P.ops[-1][30] = 1        # h1 is read by conv "2" only: both layers of the unit run as one launch (res_unit_rows_k)
         if inc:
+            if Program.PROJ_FUSE:
+                P.ops[-1][30] = 3        # the next op is this block's 1x1 stride-2 projection of `raw`: both may run as one launch (csrc/mars_tail.hip)
             skip = P.conv(raw, wd[name + '/projection/weights'], np.zeros(c, np.float32), stride=2)   # :30-36
         else:
             skip = raw

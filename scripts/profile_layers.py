@@ -7,7 +7,7 @@ import numpy as np, torch
 from deepdish_amd import nets
 from deepdish_amd.engine import Net
 from deepdish_amd._lib import lib, check
-from deepdish_amd.profile import net_op_times, net_op_launches, OPK_NAMES, OPK_FOLDED
+from deepdish_amd.profile import net_op_times, net_op_launches, OPK_NAMES, OPK_FOLDED, OPK_FOLDED_PREV
 
 kind, batch = sys.argv[1], int(sys.argv[2])
 reps = 20
@@ -39,6 +39,6 @@ codes = net_op_launches(net)
 for i, (ms, info, op) in enumerate(zip(acc, prog.info, prog.ops)):
     fl, by = info['flops'] * batch, info['bytes'] * batch + info.get('wbytes', 0)
     tot += ms
-    kname = '(in the next launch)' if codes[i] == OPK_FOLDED else OPK_NAMES.get(int(codes[i]), info['kernel'])
+    kname = '(in the next launch)' if codes[i] == OPK_FOLDED else '(in the previous launch)' if codes[i] == OPK_FOLDED_PREV else OPK_NAMES.get(int(codes[i]), info['kernel'])
     print(f'{i:3d} {kname:26s} {ms*1e3:8.1f}us {fl/1e9:8.3f} {by/1e6:8.2f} {fl/ms/1e9 if ms else 0:8.1f} {by/ms/1e6 if ms else 0:8.1f}  k={op[5]}x{op[6]} s={op[7]} cin={op[10]} cout={op[11]} hw={op[26]}x{op[27]}')
 print('total ms', tot, 'GFLOP', sum(i['flops'] for i in prog.info) * batch / 1e9)
