@@ -19,6 +19,7 @@
 //             stride 2 pads only below / right); the lanes of output column 3 mask the right tap;
 //   projection (1x1 stride 2 of the block's raw input): [8 planes][8 rows][4 columns] of the even pixels.
 #include "mars_tail.h"
+#include <vector>
 
 namespace {
 
@@ -44,9 +45,17 @@ __device__ __forceinline__ void lds_fill16(const _Float16 *g, char *lds_wave_bas
 // channels 8 fq .. 8 fq + 7 in acc[0][0..3], acc[1][0..3] (the order conv_glds_k stores plain f16 outputs in)
 __device__ __forceinline__ int frag_row(int a, int fr) { return (fr >> 2) * 8 + (a & 1) * 4 + (fr & 3); }
 
+// -DDD_MARS_STAMPS (scripts/experiments/mars_stamps.sh; never in the product build): s_memtime stamps per step and wave, summed per phase
+#ifdef DD_MARS_STAMPS
+__device__ unsigned long long dd_mars_stamps[256 * 8 * 8];
+#define DD_STAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[k] += t_ - st_last; st_last = t_; } while (0)
+#else
+#define DD_STAMP(k) do { } while (0)
+#endif
+
 constexpr int WS_LEAD = 2, WS_NB = WS_LEAD + 2, WS_NBR = WS_LEAD + 3;
 constexpr int ws_tile_bytes(int mode) { return mode == MARS_WS_S2_PROJ ? 17 * 68 * 16 : 10 * 72 * 16; }
-constexpr int ws_zero_bytes(int mode) { return mode == MARS_WS_S2_PROJ ? 0 : 7424; }          // largest stride-1 tap offset + 16, rounded up
+constexpr int ws_zero_bytes(int mode) { return mode == MARS_WS_S2_PROJ ? 0 : 7680; }          // 256 (a lane's bank phase) + largest stride-1 tap offset + 16, rounded up
 constexpr int WS_RES_BYTES = 8 * 72 * 16, WS_PRJ_BYTES = 4096;
 constexpr int ws_xw_bytes(int mode) { return mode == MARS_WS_S2_PROJ ? 4096 : 2048; }
 constexpr int ws_off_tiles(int mode) { return ws_zero_bytes(mode); }
@@ -111,33 +120,39 @@ __global__ __launch_bounds__(512, 2) void mars_ws128_k(const MarsWsP P) {
     const int n0 = blockIdx.x, nstep = gridDim.x;
     const int Kc = (P.n_img - n0 + nstep - 1) / nstep;            // crops of this workgroup: n0 + c * nstep
 
-    // ---- LDS-DMA of crop ci (past the last crop: zero lines, so that every step issues the same number of operations)
+    // ---- LDS-DMA of the next crop (dq): running per-lane source pointers, advanced by a wave-uniform stride.  Past the last crop the
+    // pointers stay on it: the same bytes go once more into a tile slot nobody reads, and every step issues the same number of operations.
     int dq = 0, dq_slot = 0, dq_rslot = 0;
-    unsigned dma_off[2], dma_off2;
+    const _Float16 *src_a, *src_b, *src_c;                        // stride 1: input row, residual row, -; stride 2: input rows w and w + 8, projection piece
+    size_t step_a, step_b, step_c;
     if constexpr (!S2) {
-        dma_off[0] = (unsigned)((wave * 4 + (lane & 3)) * P.cs_in + P.coff_in + (lane >> 2) * 8);
-        dma_off[1] = (unsigned)((wave * 4 + (lane & 3)) * P.cs_res + P.coff_res + (lane >> 2) * 8);
-        dma_off2 = 0;
+        src_a = P.in + (size_t)n0 * 32 * P.cs_in + ((wave * 4 + (lane & 3)) * P.cs_in + P.coff_in + (lane >> 2) * 8);
+        src_b = RES ? P.res + (size_t)n0 * 32 * P.cs_res + ((wave * 4 + (lane & 3)) * P.cs_res + P.coff_res + (lane >> 2) * 8) : P.zero;
+        src_c = P.zero;
+        step_a = (size_t)nstep * 32 * P.cs_in; step_b = (size_t)nstep * 32 * P.cs_res; step_c = 0;
     } else {
         const int par = lane >> 5, pl = (lane >> 2) & 7, col = 2 * (lane & 3) + par;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) dma_off[h] = (unsigned)(((wave + 8 * h) * 8 + col) * P.cs_in + P.coff_in + pl * 8);
+        src_a = P.in + (size_t)n0 * 128 * P.cs_in + ((wave * 8 + col) * P.cs_in + P.coff_in + pl * 8);
+        src_b = src_a + (size_t)64 * P.cs_in;
         const int ch = (wave & 3) * 64 + lane;                    // chunk of the projection tile: [plane][row][column]
-        dma_off2 = (unsigned)((2 * ((ch >> 2) & 7) * 8 + 2 * (ch & 3)) * P.cs_in2 + P.coff_in2 + (ch >> 5) * 8);
+        src_c = P.in2 + (size_t)n0 * 128 * P.cs_in2 + ((2 * ((ch >> 2) & 7) * 8 + 2 * (ch & 3)) * P.cs_in2 + P.coff_in2 + (ch >> 5) * 8);
+        step_a = step_b = (size_t)nstep * 128 * P.cs_in; step_c = (size_t)nstep * 128 * P.cs_in2;
     }
     auto issue = [&]() {
-        const bool ok = dq < Kc;
-        const size_t n = (size_t)(n0 + dq * nstep);
         char *T = smem + OFF_T + dq_slot * TILE_B;
         if constexpr (!S2) {
-            lds_fill16(ok ? P.in + n * 32 * P.cs_in + dma_off[0] : P.zero, T + (wave + 1) * 72 * 16);
-            if constexpr (RES) lds_fill16(ok ? P.res + n * 32 * P.cs_res + dma_off[1] : P.zero, smem + OFF_A + dq_rslot * WS_RES_BYTES + wave * 72 * 16);
+            lds_fill16(src_a, T + (wave + 1) * 72 * 16);
+            if constexpr (RES) lds_fill16(src_b, smem + OFF_A + dq_rslot * WS_RES_BYTES + wave * 72 * 16);
         } else {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) lds_fill16(ok ? P.in + n * 128 * P.cs_in + dma_off[h] : P.zero, T + (wave + 8 * h) * 68 * 16);
-            lds_fill16(ok ? P.in2 + n * 128 * P.cs_in2 + dma_off2 : P.zero, smem + OFF_A + dq_slot * WS_PRJ_BYTES + (wave & 3) * 1024);
+            lds_fill16(src_a, T + wave * 68 * 16);
+            lds_fill16(src_b, T + (wave + 8) * 68 * 16);
+            lds_fill16(src_c, smem + OFF_A + dq_slot * WS_PRJ_BYTES + (wave & 3) * 1024);
         }
         ++dq;
+        const bool more = dq < Kc;
+        src_a += more ? step_a : 0;
+        if constexpr (RES || S2) src_b += more ? step_b : 0;
+        if constexpr (S2) src_c += more ? step_c : 0;
         dq_slot = dq_slot + 1 == NB ? 0 : dq_slot + 1;
         dq_rslot = dq_rslot + 1 == NBR ? 0 : dq_rslot + 1;
     };
@@ -193,98 +208,129 @@ __global__ __launch_bounds__(512, 2) void mars_ws128_k(const MarsWsP P) {
         }
     };
 
+#ifdef DD_MARS_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+    const unsigned long long st_begin = st_last;
+#endif
+    static_assert(LEAD == 2, "the counted waits below are written for two crops of look-ahead");
     for (int ci = 0; ci < LEAD; ++ci) issue();
+    DD_STAMP(0);                                                  // prologue DMAs
+    // Step c in two phases, the two K halves in antiphase: phase 1 -- half 0 multiplies crop c while half 1 requests crop c + 2 and
+    // finishes crop c - 1; phase 2 -- the roles swap.  Every SIMD holds one wave of each half, so its matrix pipe is fed by one wave
+    // while the other issues the vector, LDS and memory work of its epilogue: run alike (both multiply, then both finish) the waves of
+    // a SIMD contend for the pipe and then leave it idle (stamps: 4 250 cycles per step for 2 304 of matrix work).
     for (int c = 0; c <= Kc; ++c) {
-        issue();                                                  // crop c + LEAD
 #if defined(__HIP_DEVICE_COMPILE__)
-        // crop c's own DMAs have landed: everything younger may still fly -- the DMAs of the LEAD crops behind it and the stores of the
-        // epilogues since (steps c - LEAD .. c - 1; step 0 has none)
-        if (c < LEAD) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(LEAD * N_DMA) : "memory");
-        else if (c == LEAD) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(LEAD * N_DMA + (LEAD - 1) * N_ST) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(LEAD * (N_DMA + N_ST)) : "memory");
-        __builtin_amdgcn_s_barrier();                             // ... and everybody else's; crop c - 1's partial sums too
+        // Barrier 1: crop c's tile is complete.  This wave requested its piece two non-multiplying phases ago; younger and allowed to fly:
+        // the stores of that phase's epilogue, the requests for crop c + 1 and the stores of the epilogue after them.
+        if (kh == 0 || c == 0) {                                  // half 1 waited at the end of its phase 1 (below): its compute phase ends at this barrier
+            if (c <= 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(N_DMA) : "memory");
+            else if (c == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(N_DMA + N_ST) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(N_DMA + 2 * N_ST) : "memory");
+        } else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        DD_STAMP(2);
+        __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
 #endif
-        if (c > 0) epilogue(c - 1);
-        if (c < Kc) {
+        DD_STAMP(3);
+        auto compute = [&](f4 (&kp)[S2 ? 4 : 2]) {
             const unsigned tb = (unsigned)(OFF_T + slot * TILE_B) + lo;
             f4 acc[2][2] = {{f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}}, {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}}};
             if constexpr (!S2) {
                 // tile row of map row y is y + 1, so tap dy of output row 4 p + yy reads tile row 4 p + yy + dy; the column of tap dx
                 // is x + dx - 1: the lanes of x = 0 (dx = 0) and x = 3 (dx = 2) read the zero region, at the same immediate offsets
-                const unsigned bs[3] = {x == 0 ? 0u : tb - 16u, tb, x == 3 ? 0u : tb + 16u};
-                h8 X[2][4];
-                auto rd = [&](int t, h8 (&xv)[4]) {
-                    const int dy = t / 3, dx = t - dy * 3;
-#pragma unroll
-                    for (int p = 0; p < 2; ++p)
-#pragma unroll
-                        for (int ks = 0; ks < 2; ++ks)
-                            xv[p * 2 + ks] = *reinterpret_cast<const h8 *>(smem + bs[dx] + ((4 * p + dy) * 72 + ks * 16) * 16);
-                };
-                rd(0, X[0]);
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    h8 (&xv)[4] = X[t & 1];
+                // (at the bank phase of the address they replace -- addr mod 256 -- so that a read stays conflict free: with all of them
+                // on one zero chunk, six taps of nine took two LDS passes per lane group and the LDS, not the matrix pipe, set the pace)
+                const unsigned bs[3] = {x == 0 ? ((tb - 16u) & 255u) : tb - 16u, tb, x == 3 ? ((tb + 16u) & 255u) : tb + 16u};
+                // 18 units of (tap, pixel fragment): two fragment reads (the tap's two k slices) feed four MFMAs.  Four rotating operand
+                // sets, three units (six reads) in flight.  The reads are inline assembly with hand-counted waits: hipcc waits for a
+                // ds_read result with lgkmcnt(0) -- for every read in flight, however many are younger -- which made the look-ahead
+                // one unit deep whatever the source said (stamps: 1 690 cycles per crop and wave for 1 152 cycles of matrix work).
+                h8 X[4][2];
 #if defined(__HIP_DEVICE_COMPILE__)
-                    asm volatile("" : "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3]));      // tap t has arrived before tap t + 1 is requested
-                    __builtin_amdgcn_sched_barrier(0);
+#define DD_RD(u_) do { constexpr int t_ = (u_) >> 1, p_ = (u_) & 1, dy_ = t_ / 3, dx_ = t_ - dy_ * 3;                                      \
+                       asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"                                       \
+                                    : "=&v"(X[(u_) & 3][0]), "=&v"(X[(u_) & 3][1]) : "v"(bs[dx_]), "n"(((4 * p_ + dy_) * 72) * 16), "n"(((4 * p_ + dy_) * 72 + 16) * 16) : "memory"); } while (0)
+#define DD_UNIT(u_) do { if constexpr ((u_) + 3 < 18) DD_RD(((u_) + 3) % 18);                                                            \
+                         asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(X[(u_) & 3][0]), "+v"(X[(u_) & 3][1]) : "n"((u_) + 3 < 18 ? 6 : 2 * (17 - (u_))));          \
+                         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int a = 0; a < 2; ++a)                  \
+                             acc[(u_) & 1][a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[(u_) >> 1][ks][a], X[(u_) & 3][ks], acc[(u_) & 1][a], 0, 0, 0); } while (0)
+                DD_RD(0); DD_RD(1); DD_RD(2);
+                DD_UNIT(0); DD_UNIT(1); DD_UNIT(2); DD_UNIT(3); DD_UNIT(4); DD_UNIT(5); DD_UNIT(6); DD_UNIT(7); DD_UNIT(8);
+                DD_UNIT(9); DD_UNIT(10); DD_UNIT(11); DD_UNIT(12); DD_UNIT(13); DD_UNIT(14); DD_UNIT(15); DD_UNIT(16); DD_UNIT(17);
+#undef DD_UNIT
+#undef DD_RD
 #endif
-                    if (t + 1 < 9) rd(t + 1, X[(t + 1) & 1]);
-#if defined(__HIP_DEVICE_COMPILE__)
-                    __builtin_amdgcn_sched_barrier(0);
-#endif
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                        for (int p = 0; p < 2; ++p)
-#pragma unroll
-                            for (int a = 0; a < 2; ++a)
-                                acc[p][a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[t][ks][a], xv[p * 2 + ks], acc[p][a], 0, 0, 0);
-#if defined(__HIP_DEVICE_COMPILE__)
-                    __builtin_amdgcn_sched_barrier(0);
-#endif
-                }
             } else {
                 // output pixel (4 p + yy, x) reads input rows 8 p + 2 yy + dy and columns 2 x + dx: even columns for dx = 0 / 2 (index x,
                 // x + 1), odd ones for dx = 1; column 8 does not exist: the lanes of x = 3 zero their dx = 2 operands
                 f4 accp[2][2] = {{f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}}, {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}}};
-                h8 X[9][2], XP[2];
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int dy = t / 3, dx = t - dy * 3;
-#pragma unroll
-                    for (int p = 0; p < 2; ++p)
-                        X[t][p] = *reinterpret_cast<const h8 *>(smem + tb + ((8 * p + dy) * 68 + (dx == 1 ? 32 : 0) + (dx == 2 ? 1 : 0)) * 16);
-                }
-#pragma unroll
-                for (int p = 0; p < 2; ++p) XP[p] = *reinterpret_cast<const h8 *>(smem + OFF_A + slot * WS_PRJ_BYTES + lo_prj + p * 16 * 16);
+                // 20 units: (tap, pixel fragment) x 18, then the projection's two fragments; one read feeds two MFMAs; four rotating
+                // operand registers, three reads in flight, hand-counted waits (see the stride-1 form)
+                h8 X[4];
+                const unsigned pb = (unsigned)(OFF_A + slot * WS_PRJ_BYTES) + lo_prj;
                 const h8 hz = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-#pragma unroll
-                    for (int p = 0; p < 2; ++p) {
-                        const h8 xv = (t % 3 == 2 && x == 3) ? hz : X[t][p];
-#pragma unroll
-                        for (int a = 0; a < 2; ++a) acc[p][a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[t][0][a], xv, acc[p][a], 0, 0, 0);
-                    }
-                }
-#pragma unroll
-                for (int p = 0; p < 2; ++p)
-#pragma unroll
-                    for (int a = 0; a < 2; ++a) accp[p][a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wp[a], XP[p], accp[p][a], 0, 0, 0);
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DD_RD(u_) do { if constexpr ((u_) < 18) { constexpr int t_ = (u_) >> 1, p_ = (u_) & 1, dy_ = t_ / 3, dx_ = t_ - dy_ * 3;                    \
+                           asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(X[(u_) & 3]) : "v"(tb), "n"(((8 * p_ + dy_) * 68 + (dx_ == 1 ? 32 : 0) + (dx_ == 2 ? 1 : 0)) * 16) : "memory"); } \
+                       else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(X[(u_) & 3]) : "v"(pb), "n"(((u_) - 18) * 256) : "memory"); } while (0)
+#define DD_UNIT(u_) do { if constexpr ((u_) + 3 < 20) DD_RD(((u_) + 3) % 20);                                                            \
+                         asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(X[(u_) & 3]) : "n"((u_) + 3 < 20 ? 3 : 19 - (u_)));               \
+                         if constexpr ((u_) < 18) { const h8 xv_ = (((u_) >> 1) % 3 == 2 && x == 3) ? hz : X[(u_) & 3];                    \
+                             _Pragma("unroll") for (int a = 0; a < 2; ++a) acc[(u_) & 1][a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[(u_) >> 1][0][a], xv_, acc[(u_) & 1][a], 0, 0, 0); } \
+                         else { _Pragma("unroll") for (int a = 0; a < 2; ++a) accp[(u_) - 18][a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wp[a], X[(u_) & 3], accp[(u_) - 18][a], 0, 0, 0); } } while (0)
+                DD_RD(0); DD_RD(1); DD_RD(2);
+                DD_UNIT(0); DD_UNIT(1); DD_UNIT(2); DD_UNIT(3); DD_UNIT(4); DD_UNIT(5); DD_UNIT(6); DD_UNIT(7); DD_UNIT(8); DD_UNIT(9);
+                DD_UNIT(10); DD_UNIT(11); DD_UNIT(12); DD_UNIT(13); DD_UNIT(14); DD_UNIT(15); DD_UNIT(16); DD_UNIT(17); DD_UNIT(18); DD_UNIT(19);
+#undef DD_UNIT
+#undef DD_RD
+#endif
                 char *Xm = smem + OFF_X + ((c & 1) * 8 + wave) * XW_B + lane * 16;
                 *reinterpret_cast<f4 *>(Xm + 2048) = kh ? accp[0][0] : accp[1][0];
                 *reinterpret_cast<f4 *>(Xm + 3072) = kh ? accp[0][1] : accp[1][1];
-                keep[2] = kh ? accp[1][0] : accp[0][0];
-                keep[3] = kh ? accp[1][1] : accp[0][1];
+                kp[2] = kh ? accp[1][0] : accp[0][0];
+                kp[3] = kh ? accp[1][1] : accp[0][1];
             }
             // hand the other fragment's partial sums to the partner, keep this wave's own
             char *Xm = smem + OFF_X + ((c & 1) * 8 + wave) * XW_B + lane * 16;
             *reinterpret_cast<f4 *>(Xm) = kh ? acc[0][0] : acc[1][0];
             *reinterpret_cast<f4 *>(Xm + 1024) = kh ? acc[0][1] : acc[1][1];
-            keep[0] = kh ? acc[1][0] : acc[0][0];
-            keep[1] = kh ? acc[1][1] : acc[0][1];
+            kp[0] = kh ? acc[1][0] : acc[0][0];
+            kp[1] = kh ? acc[1][1] : acc[0][1];
+        };
+        if (kh == 0) {
+            f4 kn[S2 ? 4 : 2];
+            if (c < Kc) compute(kn);
+            DD_STAMP(5);
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                         // barrier 2: the halves swap roles (half 0's partial sums of crop c are out)
+            asm volatile("" ::: "memory");
+#endif
+            DD_STAMP(3);
+            issue();                                              // crop c + 2
+            DD_STAMP(1);
+            if (c > 0) epilogue(c - 1);
+            DD_STAMP(4);
+#pragma unroll
+            for (int i = 0; i < (S2 ? 4 : 2); ++i) keep[i] = kn[i];
+        } else {
+            issue();
+            DD_STAMP(1);
+            if (c > 0) epilogue(c - 1);
+            DD_STAMP(4);
+#if defined(__HIP_DEVICE_COMPILE__)
+            // this wave's piece of crop c + 1 (requested one step ago) has landed: nothing of it is waited for behind the multiplications.
+            // Younger, as at barrier 1: the stores of that phase's epilogue, the requests of this phase and the stores of this epilogue
+            if (c == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(N_DMA) : "memory");
+            else if (c == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(N_DMA + N_ST) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(N_DMA + 2 * N_ST) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+#endif
+            DD_STAMP(3);
+            if (c < Kc) compute(keep);
+            DD_STAMP(5);
         }
         slot = slot + 1 == NB ? 0 : slot + 1;
         rslot_prev = rslot;
@@ -292,6 +338,14 @@ __global__ __launch_bounds__(512, 2) void mars_ws128_k(const MarsWsP P) {
     }
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the look-ahead DMAs past the last crop
+#endif
+#ifdef DD_MARS_STAMPS
+    if (lane == 0) {
+        unsigned long long *d = dd_mars_stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
+        for (int k = 0; k < 6; ++k) d[k] = st_acc[k];
+        d[6] = __builtin_amdgcn_s_memtime() - st_begin;
+        d[7] = (unsigned long long)Kc;
+    }
 #endif
 }
 
@@ -308,6 +362,25 @@ int launch_one(hipStream_t s, int device, const MarsWsP &P) {
     const int grid = P.n_img < 256 ? P.n_img : 256;               // one workgroup per CU, each the whole filter
     hipLaunchKernelGGL((mars_ws128_k<MODE, ACT, OUT2>), dim3(grid), dim3(512), lds, s, P);
     DD_LAUNCH_CHECK();
+#ifdef DD_MARS_STAMPS
+    {
+        static std::vector<unsigned long long> h(256 * 8 * 8);
+        DD_HIP(hipStreamSynchronize(s));
+        DD_HIP(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(dd_mars_stamps), h.size() * 8));
+        // per K half: mean cycles per step of each phase over the workgroups' waves
+        for (int half = 0; half < 2; ++half) {
+            double a[7] = {0, 0, 0, 0, 0, 0, 0};
+            int nw = 0;
+            for (int b = 0; b < grid; ++b)
+                for (int w = half * 4; w < half * 4 + 4; ++w, ++nw) {
+                    const unsigned long long *d = h.data() + ((size_t)b * 8 + w) * 8;
+                    for (int k = 0; k < 7; ++k) a[k] += (double)d[k] / (double)(k == 0 || k == 6 ? 1 : d[7] + 1);
+                }
+            fprintf(stderr, "mars_ws128_k<%d,%d,%d> K half %d: prologue DMAs %.0f | per step: issue %.0f, wait %.0f, barrier %.0f, epilogue %.0f, compute %.0f | loop total %.0f cycles, %d steps\n",
+                    MODE, ACT, (int)OUT2, half, a[0] / nw, a[1] / nw, a[2] / nw, a[3] / nw, a[4] / nw, a[5] / nw, a[6] / nw, (int)h[7] + 1);
+        }
+    }
+#endif
     return DD_OK;
 }
 
