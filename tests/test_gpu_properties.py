@@ -67,8 +67,9 @@ def test_mars_first_layers_give_the_same_bits_in_every_launch_shape(n):
         net2 = Net(nets.compile_mars(wd), max_batch=n)
     finally:
         nets.Program.STEM_POOL_FUSE, nets.Program.RES_UNIT_FUSE = old
-    assert net2.program.ops[0][30] == 0 and not any(op[30] for op in net2.program.ops)
-    assert [int(op[30]) for op in net.program.ops if op[30]] == [1, 1, 2, 1]      # conv1_1, conv2_1/1, conv2_1/2 (pair), conv2_3/1
+    assert net2.program.ops[0][30] == 0 and not any(op[30] in (1, 2) for op in net2.program.ops)
+    # conv1_1, conv2_1/1, conv2_1/2 (pair), conv2_3/1; 3 = the stride-2 layers of conv3_1 / conv4_1, whose projection may share their launch
+    assert [int(op[30]) for op in net.program.ops if op[30]] == [1, 1, 2, 1, 3, 3]
     from deepdish_amd.profile import net_op_launches
     net.forward(x)
     assert (12 in [int(c) for c in net_op_launches(net)]) == (n >= 1024)         # 12 = res_pair_rows_k
