@@ -96,6 +96,7 @@ SIGNATURES = {
                            c_double, c_int, c_int, P, c_int, c_int, POINTER(P)],
     'dd_pipeline_destroy': [P],
     'dd_pipeline_detector_adaptor': [P, c_int],
+    'dd_pipeline_ssd_options': [P, c_int, c_float, c_float],
     'dd_pipeline_step': [P, P, P, P, P, P],
     'dd_pipeline_step2': [P, P, P, P, P, P, P],
     'dd_pipeline_background_subtraction': [P, c_double, c_int],

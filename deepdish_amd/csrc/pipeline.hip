@@ -50,8 +50,8 @@ extern "C" int dd_net_input_size(dd_net *net, int *h_host, int *w_host);
 
 namespace {
 
-constexpr int MAX_DET = 10;              // N_max of the stock SSD post-process op
-constexpr float SSD_SCORE_THR = 1e-8f, SSD_IOU_THR = 0.6f;    // its score / NMS thresholds
+constexpr int MAX_DET_DEFAULT = 10, MAX_DET_CAP = 64;          // max_detections of the stock SSD post-process op; what csrc/post.hip takes
+constexpr float SSD_SCORE_THR = 1e-8f, SSD_IOU_THR = 0.6f;    // its score / NMS thresholds (dd_pipeline_ssd_options: the model file's own)
 constexpr int YOLO_HOST_ROWS = 128;      // YOLOv5 rows per stream the first device-to-host copy of a step has room for (the rest, if any, follows)
 enum { DET_SSD = 0, DET_YOLOV5 = 1, DET_TFLITE = 2 };
 enum { CONFIRMED = 2, DELETED = 3 };
@@ -96,6 +96,7 @@ struct dd_pipeline {
     int label_offset = 1;                      // class id c is line c + label_offset of the label file (SSD 1, YOLOv5 0)
     float *d_anchors = nullptr;
     double nms_overlap = 0.6, det_conf = 0.5;
+    int max_det = MAX_DET_DEFAULT; float ssd_score_thr = SSD_SCORE_THR, ssd_iou_thr = SSD_IOU_THR;   // TFLite_Detection_PostProcess options (dd_pipeline_ssd_options)
     double line[4] = {0, 0, 0, 0};
     std::vector<std::string> labels;           // label file lines (index = class id + 1, ssd_mobilenet.py:142-147)
     std::vector<std::string> wanted;
@@ -229,9 +230,10 @@ int dd_pipeline_create(dd_ctx *ctx, int n_streams, int frame_h, int frame_w, dd_
             const char *e = getenv("DD_SSD_DEC");
             p->ssd_dec = !(e && atoi(e) == 0);
             if (p->ssd_dec && (rc = dd_net_ssd_decode(detector, anchors_host, n_anchors, SSD_SCORE_THR, 1)) != DD_OK) return rc;
-            if ((rc = p->d_det.reserve(S * MAX_DET * 6 * sizeof(float) + S * sizeof(int) + 256)) != DD_OK) return rc;
-            if ((rc = p->d_fin.reserve(S * (MAX_DET * (4 * 8 + 4 + 8) + 4) + 256)) != DD_OK) return rc;
-            if ((rc = p->h_fin.reserve(S * (MAX_DET * (4 * 8 + 4 + 8) + 4) + 256)) != DD_OK) return rc;
+            // sized for the largest max_detections the post-process kernels take: dd_pipeline_ssd_options may raise it before the first step
+            if ((rc = p->d_det.reserve(S * MAX_DET_CAP * 6 * sizeof(float) + S * sizeof(int) + 256)) != DD_OK) return rc;
+            if ((rc = p->d_fin.reserve(S * (MAX_DET_CAP * (4 * 8 + 4 + 8) + 4) + 256)) != DD_OK) return rc;
+            if ((rc = p->h_fin.reserve(S * (MAX_DET_CAP * (4 * 8 + 4 + 8) + 4) + 256)) != DD_OK) return rc;
         } else {
             if ((rc = p->d_post.reserve(S * n_anchors * 8 + 256)) != DD_OK) return rc;              // per-row confidence + class
             // yolov5.py:126-128 (cls *= obj, argmax, confidence) runs in the Detect layers' epilogues when the program carries their
@@ -283,6 +285,24 @@ int dd_pipeline_destroy(dd_pipeline *p) {
 // tools/ssd_mobilenet.py (the default of a pipeline created with anchors: Pillow Lanczos stretch, predict tail with per-class
 // nms_boxes), 2 = the generic TFLite-Task adaptor (tools/tflite.py + tools/tflite_object_detector.py: cv2 bilinear stretch of
 // the RGB frame, the post-process op's rows with score >= 0.5, int() corners, sorted by score).  Call before the first step.
+// TFLite_Detection_PostProcess runs with the options the model file states (the interpreter at tools/ssd_mobilenet.py:100-109 upstream does):
+// max_detections rows per frame, nms_score_threshold, nms_iou_threshold -- the stock export's 10 / 1e-8 / 0.6 until this is called.
+int dd_pipeline_ssd_options(dd_pipeline *p, int max_detections, float nms_score_threshold, float nms_iou_threshold) {
+    DD_REQUIRE(p && p->det && p->det_kind != DET_YOLOV5, DD_E_ARG, "dd_pipeline_ssd_options: needs a pipeline with an SSD-type detector");
+    DD_REQUIRE(max_detections >= 1 && max_detections <= MAX_DET_CAP && nms_iou_threshold > 0.f && nms_iou_threshold <= 1.f, DD_E_ARG,
+               "dd_pipeline_ssd_options: max_detections %d (1 .. %d), nms_iou_threshold %g (0 < t <= 1)", max_detections, MAX_DET_CAP, (double)nms_iou_threshold);
+    DD_REQUIRE(p->steps == 0 && !p->det_pending, DD_E_STATE, "dd_pipeline_ssd_options: call before the first step");
+    DD_DEVICE(p->ctx);
+    if (p->ssd_dec && nms_score_threshold != p->ssd_score_thr) {   // the head layers' decode epilogue carries the score threshold
+        std::vector<float> anchors((size_t)p->n_anchors * 4);
+        DD_HIP(hipMemcpy(anchors.data(), p->d_anchors, anchors.size() * sizeof(float), hipMemcpyDeviceToHost));
+        const int rc = dd_net_ssd_decode(p->det, anchors.data(), p->n_anchors, nms_score_threshold, 1);
+        if (rc != DD_OK) return rc;
+    }
+    p->max_det = max_detections; p->ssd_score_thr = nms_score_threshold; p->ssd_iou_thr = nms_iou_threshold;
+    return DD_OK;
+}
+
 int dd_pipeline_detector_adaptor(dd_pipeline *p, int adaptor) {
     DD_REQUIRE(p && p->det && p->det_kind != DET_YOLOV5 && (adaptor == DET_SSD || adaptor == DET_TFLITE), DD_E_ARG,
                "dd_pipeline_detector_adaptor: needs a pipeline with an SSD-type detector; adaptor 0 (ssd_mobilenet) or 2 (tflite)");
@@ -363,7 +383,7 @@ namespace {
 // detector stream; det_done fires when the host block is complete.
 int enqueue_detector(dd_pipeline *p, const uint8_t *frames) {
     hipStream_t s = p->det_stream;
-    const int S = p->S;
+    const int S = p->S, MAX_DET = p->max_det;
     int rc;
     // order after whatever the caller has queued on the main stream so far (e.g. the ingest ring's wait for the
     // upload of these frames)
@@ -404,10 +424,10 @@ int enqueue_detector(dd_pipeline *p, const uint8_t *frames) {
         float *eb = nullptr, *es = nullptr, *ek = nullptr;
         int *ec = nullptr;
         if ((rc = dd_net_ssd_decoded(p->det, &eb, &es, &ec, &ek)) != DD_OK) return rc;
-        if ((rc = ddk::ssd_postprocess_decoded(s, eb, es, ec, ek, p->n_anchors, MAX_DET, SSD_SCORE_THR, SSD_IOU_THR, db, dc, ds, dn, S,
+        if ((rc = ddk::ssd_postprocess_decoded(s, eb, es, ec, ek, p->n_anchors, MAX_DET, p->ssd_score_thr, p->ssd_iou_thr, db, dc, ds, dn, S,
                                                p->d_post.p, p->d_post.cap)) != DD_OK) return rc;
     } else if ((rc = ddk::ssd_postprocess(s, static_cast<const float *>(raw), p->d_anchors, p->n_anchors, p->n_classes, MAX_DET,
-                                          SSD_SCORE_THR, SSD_IOU_THR, db, dc, ds, dn, S, p->d_post.p, p->d_post.cap)) != DD_OK) return rc;
+                                          p->ssd_score_thr, p->ssd_iou_thr, db, dc, ds, dn, S, p->d_post.p, p->d_post.cap)) != DD_OK) return rc;
     if (p->det_kind == DET_TFLITE) {                           // the generic adaptor's tail is a few integer truncations: on the host (step2)
         const size_t dbytes = (size_t)S * MAX_DET * 6 * sizeof(float) + (size_t)S * sizeof(int);
         DD_HIP(hipMemcpyAsync(p->h_fin.p, p->d_det.p, dbytes, hipMemcpyDeviceToHost, s));
@@ -516,7 +536,7 @@ int dd_pipeline_step2(dd_pipeline *p, const uint8_t *frames_in, const uint8_t *f
     DD_DEVICE(p->ctx);
     const uint8_t *frames = frames_in;
     hipStream_t s = p->ctx->stream;
-    const int S = p->S;
+    const int S = p->S, MAX_DET = p->max_det;
     int rc;
     const double t0 = now_s();
     if ((rc = ddk::trackers_predict(p->trks.data(), S)) != DD_OK) return rc;            // deepdish.py:1028
@@ -583,7 +603,7 @@ int dd_pipeline_step2(dd_pipeline *p, const uint8_t *frames_in, const uint8_t *f
                 for (int z = z0; z < z1; ++z) {
                     StreamState &q = st[z];
                     q.boxes0.clear(); q.scores0.clear(); q.cls0.clear();
-                    int order[MAX_DET], n = 0;
+                    int order[MAX_DET_CAP], n = 0;
                     for (int i = 0; i < hn[z] && i < MAX_DET; ++i)
                         if ((double)hs[z * MAX_DET + i] >= p->det_conf) order[n++] = i;      // np.float32 >= python float: compared in float64
                     std::stable_sort(order, order + n, [&](int a, int b) { return hs[z * MAX_DET + a] > hs[z * MAX_DET + b]; });

@@ -94,16 +94,16 @@ __global__ void ssd_gather_k(const int *__restrict__ keep, const int *__restrict
     if (i == 0) *out_count = __popcll(b);
 }
 
-// tools/ssd_mobilenet.py:111-150 (SSDMobileNet.predict after the four get_tensor calls) on the <= 16 rows the
+// tools/ssd_mobilenet.py:111-150 (SSDMobileNet.predict after the four get_tensor calls) on the <= 64 rows the
 // post-process op returns, one wave per image (lane 0 does the O(100) work): NaN scrub, score >= confidence,
 // reorder + scale to pixels (f64), per-class nms_boxes with its own overlap formula (:59-98: +1 on the intersection
 // extents only, areas without it, survivors ovr <= thr).  Classes are emitted in ascending id -- the reference
 // walks a Python set; the order is irrelevant downstream (deep_sort's NMS re-sorts by score) -- and inside a
 // class in pick order (descending score), exactly as nms_boxes returns them.
-constexpr int FIN_MAX = 16;
-// One wave per image, lane i = row i of the op's output (N <= 16 rows): the greedy loops run on wave reductions and
-// broadcasts -- class by class in ascending id, inside a class the best remaining score first (lowest row on ties, as the
-// reference's strict `>` scan), every other row of the class tested against it in parallel.  (One lane walking all of it
+constexpr int FIN_MAX = 64;                // one lane per row of the op's output (max_detections of the model file)
+// One wave per image, lane i = row i of the op's output (N <= 64 rows): the greedy loops run on wave reductions and
+// broadcasts -- class by class in ascending id, inside a class the best remaining score first (HIGHEST row on ties: the reference
+// reverses an ascending argsort, :73, which its NumPy 1.19 computes stably for <= 16 rows), every other row of the class tested against it in parallel.  (One lane walking all of it
 // alone took 83 us per 384-image launch: a chain of dependent loads and branches.)  Same f64 expressions, same order of the
 // emitted rows.
 __device__ __forceinline__ double shfl_f64(double v, int src) {
@@ -145,14 +145,14 @@ __global__ __launch_bounds__(64) void ssd_finish_k(const float *__restrict__ box
         bool cand = !done && cl == cmin;
         for (;;) {                                                        // greedy by descending score within the class
             float bs = cand ? sc : -__builtin_inff();
-            int bi = cand ? i : 64;
+            int bi = cand ? i : -1;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
                 const float os = __shfl_xor(bs, o, 64);
                 const int oi = __shfl_xor(bi, o, 64);
-                if (os > bs || (os == bs && oi < bi)) { bs = os; bi = oi; }
+                if (os > bs || (os == bs && oi > bi)) { bs = os; bi = oi; }      // equal scores: the higher row first (s.argsort()[::-1] of a stable sort)
             }
-            if (bi >= 64) break;
+            if (bi < 0) break;
             if (i == bi) {
                 out_boxes[n * 4 + 0] = x1; out_boxes[n * 4 + 1] = y1; out_boxes[n * 4 + 2] = x2; out_boxes[n * 4 + 3] = y2;
                 out_cls[n] = cmin;

@@ -10,7 +10,7 @@ from .runtime import default_context, ptr
 from . import nets, netsq
 from .engine import Net
 from .pipeline import DEFAULT_LABELS, DEFAULT_YOLO_LABELS
-from .tools.weights_io import load_named_weights, load_ssd_model
+from .tools.weights_io import load_named_weights, load_ssd_model, load_mars_weights, ssd_post_options
 
 
 class _TrackerView:
@@ -66,7 +66,8 @@ class MultiStreamPipeline:
             self.det = Net(prog, max_batch=self.S, context=self.ctx)
             anchors = np.ascontiguousarray(prog.meta['anchors'], dtype=np.float32)
             n_anchors, n_classes = len(anchors), prog.meta['n_classes']
-        wd = load_named_weights(encoder_model, nets.synthetic_mars_weights)
+            ssd_post = ssd_post_options(wd)                         # the post-process op's options as the model file states them
+        wd = load_mars_weights(encoder_model)                       # a mars .tflite file on disk goes through tools/tflite_reader.load_mars
         self.enc_weights = wd
         # the pipeline never reads an intermediate encoder tensor: its activation buffers share memory by lifetime (6.2 -> ~2 GB at 12 288 crops)
         self.enc = Net(nets.compile_mars(wd), max_batch=encoder_max_batch or max(64, 32 * self.S), context=self.ctx,
@@ -91,6 +92,9 @@ class MultiStreamPipeline:
                                        int(max_age), int(n_init), ptr(self.line), int(track_capacity),
                                        int(gallery_capacity), ctypes.byref(h)), 'dd_pipeline_create')
         self._h = h
+        if self.det is not None and self.kind != 'yolov5':
+            check(lib().dd_pipeline_ssd_options(self._h, int(ssd_post['max_detections']), float(ssd_post['nms_score_threshold']),
+                                                float(ssd_post['nms_iou_threshold'])), 'dd_pipeline_ssd_options')
         if self.kind == 'tflite' and self.det is not None:          # tools/tflite.py's adaptor instead of tools/ssd_mobilenet.py's
             check(lib().dd_pipeline_detector_adaptor(self._h, 2), 'dd_pipeline_detector_adaptor')
         off = 0 if self.kind == 'yolov5' else 1                     # yolov5.py:134 labels[idx]; ssd_mobilenet.py:142-147 labels[idx + 1]

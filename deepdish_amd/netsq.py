@@ -138,6 +138,14 @@ def pack_dw_mfma(L):
     return tab.reshape(c // 16, 64, 8).view(np.uint32).reshape(c // 16, 64, 2), cb.astype(np.int32)
 
 
+def _model_need(cond, what):
+    """A property of the MODEL (as opposed to an internal invariant): raised as tools.tflite_reader.UnsupportedModel, never an assert
+    (python -O strips those, and a file that misses one would run with wrong arithmetic)."""
+    if not cond:
+        from .tools.tflite_reader import UnsupportedModel
+        raise UnsupportedModel('uint8 SSD-MobileNet-v1: %s' % what)
+
+
 def compile_ssd_mobilenet_quant(qm):
     """u8 RGB [n,300,300,3] -> box encodings u8 [n,1917,4] and class logits u8 [n,1917,96] (91 used per row), both in the
     tensors' own quantisation; dd_net_ssd_decode adds the post-process op's first stage (per-anchor arrays)."""
@@ -146,7 +154,7 @@ def compile_ssd_mobilenet_quant(qm):
     Ls = qm['layers']
     anchors, maps = nets.ssd_anchors(size)
     if qm.get('anchors') is not None:                       # a model file carries its own (the post-process op's third input)
-        assert qm['anchors'].shape == anchors.shape
+        _model_need(tuple(qm['anchors'].shape) == tuple(anchors.shape), 'anchors %s (this input size gives %s)' % (tuple(qm['anchors'].shape), tuple(anchors.shape)))
         anchors = np.ascontiguousarray(qm['anchors'], dtype=np.float32)
     n_anchors = len(anchors)
 
@@ -177,7 +185,7 @@ def compile_ssd_mobilenet_quant(qm):
         kh = L['w'].shape[0]
         ho, wo, pt, pl = geom(src, kh, L['stride'])
         s = P.T(src)
-        assert s['zp'] == L['in_zp'] and L['w'].shape[2] == s['c'], name
+        _model_need(s['zp'] == L['in_zp'] and L['w'].shape[2] == s['c'], '%s: input zero point %s / channels %s, its producer writes %s / %s' % (name, L['in_zp'], L['w'].shape[2], s['zp'], s['c']))
         wp, cb, kcpt = pack_conv(L, epi, chan_map, cout_pad)
         if dst is None:
             dst = P.qtensor(ho, wo, L['w'].shape[3], L['out_zp'])
@@ -199,11 +207,11 @@ def compile_ssd_mobilenet_quant(qm):
         Lc, Lb = Ls[cname], Ls[bname]
         s = P.T(src)
         ho, wo, pt, pl = geom(src, 1, 1)
-        assert s['zp'] == Lc['in_zp'] == Lb['in_zp'] and Lc['w'].shape[:3] == Lb['w'].shape[:3] == (1, 1, s['c'])
+        _model_need(s['zp'] == Lc['in_zp'] == Lb['in_zp'] and Lc['w'].shape[:3] == Lb['w'].shape[:3] == (1, 1, s['c']), '%s / %s: 1x1 predictors on one feature map with one input zero point' % (cname, bname))
         wc, cbc, kcpt = pack_conv(Lc, QEPI_ROWS, cls_args['chan_map'], cls_args['cout_pad'])
         wb, cbb, _ = pack_conv(Lb, QEPI_ROWS, None, None)
         rc, rb = _req_words(Lc), _req_words(Lb)
-        assert rc[41] and rb[41]
+        _model_need(rc[41] and rb[41], '%s / %s: predictors carry no activation' % (cname, bname))
         lin = lambda cb, r: np.array([int(v) * int(r[32]) + (1 << 30) for v in cb], dtype=np.int64)
         raw = dict(rc)
         raw.update({38: 128 - int(Lc['w_zp']), 39: int(Lc['in_zp']), 42: cls_args['row_bytes'], 43: cls_args['base_off'], 44: cls_args['cout_store'],
@@ -220,7 +228,7 @@ def compile_ssd_mobilenet_quant(qm):
         L = Ls[name]
         ho, wo, pt, pl = geom(src, 3, L['stride'])
         s = P.T(src)
-        assert s['zp'] == L['in_zp'] and L['w'].shape[2] == s['c'], name
+        _model_need(s['zp'] == L['in_zp'] and L['w'].shape[2] == s['c'], '%s: input zero point %s / channels %s, its producer writes %s / %s' % (name, L['in_zp'], L['w'].shape[2], s['zp'], s['c']))
         w16, cb = pack_dw(L)
         dst = P.qtensor(ho, wo, s['c'], L['out_zp'])
         mf = pack_dw_mfma(L)                                    # the matrix-pipe form's operand table (None: a weight needs w - zw = 255)
@@ -238,7 +246,7 @@ def compile_ssd_mobilenet_quant(qm):
         ho, wo, pt, pl = geom(src, 3, stride)
         if not FUSE_BLOCKS or (cin, cout, stride) not in FUSED_SHAPES or wo < 19:
             return conv(dw(src, dname), pname)
-        assert s['zp'] == Ld['in_zp'] and Ld['out_zp'] == Lp['in_zp'] and Ld['w'].shape[2] == cin and Lp['w'].shape[2] == cin
+        _model_need(s['zp'] == Ld['in_zp'] and Ld['out_zp'] == Lp['in_zp'] and Ld['w'].shape[2] == cin and Lp['w'].shape[2] == cin, '%s / %s: zero points and channel counts along the block do not agree' % (dname, pname))
         packed_dw = pack_dw_mfma(Ld)
         rd, rp = _req_words(Ld), _req_words(Lp)
         if packed_dw is None or rd[33] < 1 or rp[33] < 1:
@@ -291,10 +299,10 @@ def compile_ssd_mobilenet_quant(qm):
     for k, (fname, a) in enumerate(zip(FEATURE_LAYERS, nets.SSD_ANCHORS_PER_MAP)):
         ft = feats[fname]
         fm = P.T(ft)['h']
-        assert fm == maps[k]
+        _model_need(fm == maps[k], 'feature map %d is %dx%d (the anchors are laid out for %d)' % (k, fm, fm, maps[k]))
         for other in (f'box{k}', f'cls{k}'):
-            assert (Ls[other]['out_scale'], Ls[other]['out_zp']) == (Ls[other[:3] + '0']['out_scale'], Ls[other[:3] + '0']['out_zp']), \
-                'the six %s tensors are concatenated: they need one (scale, zero point)' % other[:3]
+            _model_need((Ls[other]['out_scale'], Ls[other]['out_zp']) == (Ls[other[:3] + '0']['out_scale'], Ls[other[:3] + '0']['out_zp']),
+                        'the six %s tensors are concatenated: they need one (scale, zero point)' % other[:3])
         cmap = np.full(a * cls_row, -1, np.int64)
         for an in range(a):
             cmap[an * cls_row:an * cls_row + n_cls] = an * n_cls + np.arange(n_cls)
@@ -306,7 +314,7 @@ def compile_ssd_mobilenet_quant(qm):
             conv(ft, f'box{k}', epi=QEPI_ROWS, **box_args)
             conv(ft, f'cls{k}', epi=QEPI_ROWS, **cls_args)
         base += fm * fm * a
-    assert base == n_anchors
+    _model_need(base == n_anchors, '%d anchors for predictors that emit %d rows' % (n_anchors, base))
     Lb, Lc = Ls['box0'], Ls['cls0']
     lut = quantize.logistic_table(Lc['out_scale'], Lc['out_zp'], qm['logistic']['out_scale'], qm['logistic']['out_zp'])
     P._op(OP_QSSD_DECODE, src=box_t, res=cls_t, w_off=P.add_blob(lut), p=[n_cls, n_anchors],

@@ -178,7 +178,7 @@ def quantize_multiplier(real):
     if real == 0.0:
         return 0, 0
     q, shift = np.frexp(real)
-    q_fixed = int(np.round(q * (1 << 31)))
+    q_fixed = int(np.floor(q * (1 << 31) + 0.5))          # TfLiteRound rounds halves away from zero (np.round: to even); q > 0
     if q_fixed == (1 << 31):
         q_fixed //= 2
         shift += 1

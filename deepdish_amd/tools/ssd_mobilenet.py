@@ -15,13 +15,13 @@ from .._lib import lib, check
 from ..runtime import default_context, ptr
 from .. import nets, netsq
 from ..engine import Net
-from .weights_io import load_named_weights, load_ssd_model
+from .weights_io import load_named_weights, load_ssd_model, ssd_post_options
 
 COCO_LABELS_FALLBACK = None
 
 
 class SSDMobileNet:
-    MAX_DET = 10
+    MAX_DET = 10                                  # the stock export's max_detections; an instance takes its model file's
 
     def __init__(self, model_path, label_path, num_threads=None, edgetpu=False, libedgetpu=None,
                  score_threshold=0.5, context=None, max_batch=1):
@@ -33,10 +33,15 @@ class SSDMobileNet:
         kind, wd = load_ssd_model(model_path)       # ('uint8', QModel): a quantised model as the reference's own file is (ssd_mobilenet.py:102)
         self.weights = wd
         self.quantized = kind == 'uint8'
+        # the post-process op runs with the options its file states (the interpreter at ssd_mobilenet.py:100-109 does): a model that does
+        # not come from a file takes the stock export's 10 / 1e-8 / 0.6
+        post = ssd_post_options(wd)
+        self.MAX_DET = int(post['max_detections'])
+        self.nms_score_threshold, self.nms_iou_threshold = float(post['nms_score_threshold']), float(post['nms_iou_threshold'])
         prog = netsq.compile_ssd_mobilenet_quant(wd) if self.quantized else nets.compile_ssd_mobilenet(wd)
         self.net = Net(prog, max_batch=max_batch, context=self.ctx)
         if self.quantized:                           # integer heads: the post-process op's first stage reads the quantised tensors (csrc/netsq.hip)
-            self.net.ssd_decode(prog.meta['anchors'], 1e-8)
+            self.net.ssd_decode(prog.meta['anchors'], self.nms_score_threshold)
         self.height = self.width = prog.in_h
         self.anchors = prog.meta['anchors']
         self.n_classes = prog.meta['n_classes']
@@ -66,13 +71,14 @@ class SSDMobileNet:
         if self.quantized:
             P4 = [ctypes.c_void_p() for _ in range(4)]
             check(lib().dd_net_ssd_decoded(self.net._h, *[ctypes.byref(q) for q in P4]), 'dd_net_ssd_decoded')
-            check(lib().dd_ssd_postprocess_decoded(self.ctx.handle, P4[0], P4[1], P4[2], P4[3], len(self.anchors), self.MAX_DET, 1e-8, 0.6,
+            check(lib().dd_ssd_postprocess_decoded(self.ctx.handle, P4[0], P4[1], P4[2], P4[3], len(self.anchors), self.MAX_DET,
+                                                   self.nms_score_threshold, self.nms_iou_threshold,
                                                    ptr(self._boxes), ptr(self._classes), ptr(self._scores), ptr(self._count), 1, None),
                   'dd_ssd_postprocess_decoded')
         else:
             raw = self.net.output_ptr()
             check(lib().dd_ssd_postprocess(self.ctx.handle, raw, ptr(self._anchors_dev), len(self.anchors), self.n_classes,
-                                           self.MAX_DET, 1e-8, 0.6, ptr(self._boxes), ptr(self._classes),
+                                           self.MAX_DET, self.nms_score_threshold, self.nms_iou_threshold, ptr(self._boxes), ptr(self._classes),
                                            ptr(self._scores), ptr(self._count), None), 'dd_ssd_postprocess')
         if not read:
             return None

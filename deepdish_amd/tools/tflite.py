@@ -14,7 +14,7 @@ from .._lib import lib, check
 from ..runtime import default_context, ptr
 from .. import nets
 from ..engine import Net
-from .weights_io import load_named_weights
+from .weights_io import load_named_weights, load_ssd_model, ssd_post_options
 
 
 class ObjectDetectorOptions(NamedTuple):
@@ -52,8 +52,13 @@ class ObjectDetector:
         if options.enable_edgetpu:
             raise OSError("Coral EdgeTPU delegates do not exist on MI355X")
         self.ctx = context or default_context()
-        wd = load_named_weights(model_path, nets.synthetic_ssd_weights)
+        kind, wd = load_ssd_model(model_path)                 # an SSD-MobileNet .tflite file goes through tools/tflite_reader.py
+        if kind != 'f32':
+            raise ValueError('%s: the generic TFLite adaptor is built for float models (a uint8 SSD-MobileNet runs behind tools/ssd_mobilenet.py)' % model_path)
         self.weights = wd
+        post = ssd_post_options(wd)                           # the post-process op's own options (its file's, else the stock export's)
+        self.MAX_DET = int(post['max_detections'])
+        self._score_thr, self._iou_thr = float(post['nms_score_threshold']), float(post['nms_iou_threshold'])
         prog = nets.compile_ssd_mobilenet(wd)                 # float model: (x - 127.5) / 127.5 in the input op
         self._mean = self._std = 127.5                        # tflite_object_detector.py:124-131 defaults
         self.net = Net(prog, max_batch=1, context=self.ctx)
@@ -82,7 +87,7 @@ class ObjectDetector:
                                        ptr(self._resized), h, w, None), 'dd_resize_bilinear')      # :211 cv2.resize
         self.net.forward(self._resized)
         check(lib().dd_ssd_postprocess(self.ctx.handle, self.net.output_ptr(), ptr(self._anchors_dev), len(self._anchors),
-                                       self._n_classes, self.MAX_DET, 1e-8, 0.6, ptr(self._boxes), ptr(self._classes),
+                                       self._n_classes, self.MAX_DET, self._score_thr, self._iou_thr, ptr(self._boxes), ptr(self._classes),
                                        ptr(self._scores), ptr(self._count), None), 'dd_ssd_postprocess')
         self.ctx.sync()
         return self._postprocess(self._boxes.cpu().numpy(), self._classes.cpu().numpy(), self._scores.cpu().numpy(),

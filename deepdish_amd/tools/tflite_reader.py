@@ -157,6 +157,31 @@ def _conv_layer(g, op):
     return L, op.inputs[0]
 
 
+# TFLite_Detection_PostProcess options this build runs (tools/ssd_mobilenet.py:100-109 upstream: the interpreter applies whatever the file
+# says).  Passed on: max_detections, nms_score_threshold, nms_iou_threshold (SSDMobileNet, dd_pipeline_ssd_options).  Checked: the four
+# box-coder scales the decode is built for must be PRESENT and equal 10 / 10 / 5 / 5; max_classes_per_detection 1; the fast
+# (class-agnostic) NMS -- `use_regular_nms` true selects a per-class NMS with `detections_per_class`, which is not built: refused by name.
+SSD_POST_DEFAULTS = dict(max_detections=10, nms_score_threshold=1e-8, nms_iou_threshold=0.6)
+MAX_DETECTIONS_BUILT = 64                                          # csrc/post.hip: one wave lane per row of the op's output
+
+
+def ssd_post_options(post):
+    o = post.options
+    for k, v in dict(y_scale=10.0, x_scale=10.0, h_scale=5.0, w_scale=5.0).items():
+        _need(k in o, post, 'option %s is missing (the box decode needs the coder scales stated)' % k)
+        _need(abs(float(o[k]) - v) < 1e-6, post, '%s = %s (the decode is built for %s)' % (k, o[k], v))
+    for k in ('max_detections', 'nms_score_threshold', 'nms_iou_threshold', 'num_classes'):
+        _need(k in o, post, 'option %s is missing' % k)
+    _need(not bool(o.get('use_regular_nms', False)), post, 'use_regular_nms = true (per-class NMS with detections_per_class = %s): only the fast '
+          'class-agnostic NMS is built' % o.get('detections_per_class', 100))
+    _need(int(o.get('max_classes_per_detection', 1)) == 1, post, 'max_classes_per_detection = %s (one class per detection is built)' % o.get('max_classes_per_detection'))
+    md = int(o['max_detections'])
+    _need(1 <= md <= MAX_DETECTIONS_BUILT, post, 'max_detections = %d (1 .. %d are built)' % (md, MAX_DETECTIONS_BUILT))
+    iou, thr = float(o['nms_iou_threshold']), float(o['nms_score_threshold'])
+    _need(0.0 < iou <= 1.0, post, 'nms_iou_threshold = %s' % iou)            # the op itself rejects values outside (0, 1]
+    return dict(max_detections=md, nms_score_threshold=thr, nms_iou_threshold=iou, num_classes=int(o['num_classes']))
+
+
 def load_ssd_mobilenet(path):
     """-> ('uint8', QModel) or ('f32', named folded weights).  Structure walked backwards from the post-process op."""
     g = read(path)
@@ -164,9 +189,7 @@ def load_ssd_mobilenet(path):
     if len(post) != 1 or post[0].custom != 'TFLite_Detection_PostProcess':
         raise UnsupportedModel('%s: no TFLite_Detection_PostProcess op (operators: %s)' % (path, sorted({o.custom or o.kind for o in g.ops})))
     post = post[0]
-    want = dict(y_scale=10.0, x_scale=10.0, h_scale=5.0, w_scale=5.0)
-    for k, v in want.items():
-        _need(abs(float(post.options.get(k, v)) - v) < 1e-6, post, '%s = %s (the decode is built for %s)' % (k, post.options.get(k), v))
+    popts = ssd_post_options(post)
     anchors = g.tensors[post.inputs[2]]
     _need(anchors.data is not None and anchors.data.ndim == 2 and anchors.data.shape[1] == 4, post, 'anchors must be a constant [n, 4]')
     anc = anchors.data.astype(np.float32) if anchors.dtype != np.uint8 else (np.float32(anchors.scale[0]) * (anchors.data.astype(np.float32) - np.float32(anchors.zero_point[0])))
@@ -218,11 +241,14 @@ def load_ssd_mobilenet(path):
     x = g.tensors[t]
     _need(len(x.shape) == 4 and x.shape[1] == x.shape[2] and x.shape[3] == 3, chain[0], 'input %s (expected [1, s, s, 3])' % (x.shape,))
     order = names + [n for k in range(6) for n in (f'box{k}', f'cls{k}')]
+    per_anchor = layers['cls0']['w'].shape[3] // 3                      # the lowest map has three anchors per cell
+    _need(popts['num_classes'] + 1 == per_anchor, post, 'num_classes = %d, but the class predictors emit %d values per anchor (classes + background)'
+          % (popts['num_classes'], per_anchor))
     if x.dtype == np.uint8:
         lt = g.tensors[logi.outputs[0]]
         qm = dict(kind='ssd_mobilenet_v1_uint8', input=dict(scale=np.float32(x.scale[0]), zp=int(x.zero_point[0]), size=int(x.shape[1])),
                   layers=layers, logistic=dict(out_scale=np.float32(lt.scale[0]), out_zp=int(lt.zero_point[0])), order=order, anchors=anc,
-                  post=dict(post.options), source=str(path))
+                  post=popts, source=str(path))
         return 'uint8', qm
     wd = {}
     for name in order:
@@ -231,6 +257,7 @@ def load_ssd_mobilenet(path):
         wd[name + '/weights'] = w.astype(np.float32)
         wd[name + '/biases'] = L['bias']
     wd['anchors'] = anc
+    wd['__post__'] = popts                                            # not an array: nets.compile_ssd_mobilenet ignores it, the plugins read it
     return 'f32', wd
 
 

@@ -93,7 +93,7 @@ class GraphWriter:
         return b.finish(model, b'TFL3')
 
 
-def ssd_mobilenet_graph(model, anchors=None):
+def ssd_mobilenet_graph(model, anchors=None, post=None):
     """QModel (uint8) or named float weights (folded: name/weights, name/biases) -> GraphWriter of the SSD-MobileNet-v1 graph as the
     TF Object Detection API exports it: backbone, predictor convolutions, RESHAPE / CONCATENATION fans, LOGISTIC, post-process op."""
     quant = isinstance(model, dict) and model.get('kind') == 'ssd_mobilenet_v1_uint8'
@@ -158,10 +158,16 @@ def ssd_mobilenet_graph(model, anchors=None):
                    *(qp(model['logistic']['out_scale'], model['logistic']['out_zp']) if quant else (None, None)))
     W.op('LOGISTIC', [ccat], [sig])
     anc = W.tensor('anchors', [n_anchors, 4], np.float32, np.asarray(anchors, np.float32))
-    outs = [W.tensor('TFLite_Detection_PostProcess' + (':%d' % i if i else ''), s, np.float32) for i, s in enumerate(([1, 10, 4], [1, 10], [1, 10], [1]))]
-    W.op('CUSTOM', [bcat, sig, anc], outs, custom='TFLite_Detection_PostProcess',
-         custom_options=flatbuf.flex_build_map(dict(max_detections=10, max_classes_per_detection=1, nms_score_threshold=1e-8, nms_iou_threshold=0.6,
-                                                    num_classes=n_cls - 1, y_scale=10.0, x_scale=10.0, h_scale=5.0, w_scale=5.0, use_regular_nms=False)))
+    opts = dict(max_detections=10, max_classes_per_detection=1, nms_score_threshold=1e-8, nms_iou_threshold=0.6,
+                num_classes=n_cls - 1, y_scale=10.0, x_scale=10.0, h_scale=5.0, w_scale=5.0, use_regular_nms=False)
+    for k, v in (post or {}).items():                      # overrides; None drops the key (a file that does not state it)
+        if v is None:
+            opts.pop(k, None)
+        else:
+            opts[k] = v
+    nd = int(opts.get('max_detections', 10))
+    outs = [W.tensor('TFLite_Detection_PostProcess' + (':%d' % i if i else ''), s, np.float32) for i, s in enumerate(([1, nd, 4], [1, nd], [1, nd], [1]))]
+    W.op('CUSTOM', [bcat, sig, anc], outs, custom='TFLite_Detection_PostProcess', custom_options=flatbuf.flex_build_map(opts))
     W.outputs = outs
     return W
 
@@ -261,8 +267,9 @@ def write_mars(wd, path, reverse_channels=True, half_weights=False):
     return len(data)
 
 
-def write_ssd_mobilenet(model, path, anchors=None):
-    data = ssd_mobilenet_graph(model, anchors).tobytes()
+def write_ssd_mobilenet(model, path, anchors=None, post=None):
+    """post: overrides of the TFLite_Detection_PostProcess options ({name: value}; None drops the key)."""
+    data = ssd_mobilenet_graph(model, anchors, post=post).tobytes()
     with open(path, 'wb') as f:
         f.write(data)
     return len(data)

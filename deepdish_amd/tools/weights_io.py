@@ -61,3 +61,15 @@ def load_ssd_model(model_file):
         seed = int(m.group(1)) if m.group(1) else 1234
         return 'uint8', quantize.synthetic_ssd_quant_model(seed, symmetric_weights='sym' in name)
     return 'f32', load_named_weights(model_file, nets.synthetic_ssd_weights)
+
+
+def ssd_post_options(model):
+    """TFLite_Detection_PostProcess options of a model load_ssd_model returned: what its .tflite file states (tools/tflite_reader.
+    ssd_post_options has validated them), else the stock SSD-MobileNet-v1 export's (max_detections 10, nms_score_threshold 1e-8,
+    nms_iou_threshold 0.6 -- the values synthetic models and .npz weights run with)."""
+    from .tflite_reader import SSD_POST_DEFAULTS
+    post = dict(SSD_POST_DEFAULTS)
+    src = model.get('post') if isinstance(model, dict) and model.get('kind') == 'ssd_mobilenet_v1_uint8' else model.get('__post__') if isinstance(model, dict) else None
+    if src:
+        post.update({k: src[k] for k in SSD_POST_DEFAULTS if k in src})
+    return post

@@ -347,6 +347,10 @@ int dd_pipeline_destroy(dd_pipeline *p);
  * (tools/tflite.py:9-41 over tools/tflite_object_detector.py:180-295: cv2.resize INTER_LINEAR of the RGB frame, rows of the
  * post-process op with score >= 0.5, int() of the scaled corners, sorted by score).  Before the first step. */
 int dd_pipeline_detector_adaptor(dd_pipeline *p, int adaptor);
+/* Options of the TFLite_Detection_PostProcess op inside an SSD-type model file, which the reference's interpreter applies as the file
+ * states them (tools/ssd_mobilenet.py:100-109: invoke() + the four output tensors of max_detections rows): rows per frame (<= 64),
+ * nms_score_threshold, nms_iou_threshold (fast class-agnostic NMS).  Defaults: the stock export's 10 / 1e-8 / 0.6.  Before the first step. */
+int dd_pipeline_ssd_options(dd_pipeline *p, int max_detections, float nms_score_threshold, float nms_iou_threshold);
 /* frames: device u8 [n_streams][H][W][3] BGR.  inj_*: optional detections that REPLACE the detector's
  * output (it still runs): tlwh f64 rows, scores, class ids; stream s owns rows
  * [inj_offsets[s], inj_offsets[s+1]).  Blocks until the step is complete. */

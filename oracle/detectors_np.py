@@ -32,7 +32,11 @@ def ssd_nms_boxes(boxes, labels, scores, iou_threshold):
         left, top = b[:, 0], b[:, 1]
         wid, hei = b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]             # :69-70
         area = wid * hei                                            # :72
-        alive = [int(v) for v in s.argsort()[::-1]]                 # :73 descending score
+        # :73 descending score.  Equal scores (common with a uint8 model: scores are multiples of 1/256): the reference's own NumPy (1.19,
+        # Dockerfile.rpi-armv7:29-30) sorts the <= 16 rows of a class by insertion -- stably -- so the reversal puts the HIGHER row first;
+        # NumPy 2.x on an AVX-512 host uses an unstable vector sort for the same call and orders ties arbitrarily.  Restated as the
+        # reference's environment computes it.
+        alive = [int(v) for v in s.argsort(kind='stable')[::-1]]
         keep = []
         while alive:
             i = alive.pop(0)

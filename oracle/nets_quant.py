@@ -56,7 +56,7 @@ def quantize_multiplier(real):
     if real == 0.0:
         return 0, 0
     q, shift = math.frexp(real)
-    qf = int(round(q * (1 << 31)))               # TfLiteRound
+    qf = int(math.floor(q * (1 << 31) + 0.5))    # TfLiteRound = std::round: halves away from zero (q > 0 here), not Python's half-to-even
     if qf == (1 << 31):
         qf //= 2
         shift += 1

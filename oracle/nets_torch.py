@@ -156,6 +156,18 @@ def ssd_postprocess(raw, anchors, max_det=10, score_thr=1e-8, iou_thr=0.6):
     sc = (f(1) / (f(1) + np.exp(-raw[:, 5:]))).astype(np.float32)        # class 0 = background
     best_c = sc.argmax(axis=1)
     best = sc[np.arange(len(sc)), best_c]
+    return ssd_postprocess_decoded(boxes, best, best_c, max_det, score_thr, iou_thr)
+
+
+def ssd_postprocess_decoded(boxes, best, best_c, max_det=10, score_thr=1e-8, iou_thr=0.6):
+    """Second stage of the op (`use_regular_nms` false: NonMaxSuppressionMultiClassFastHelper) on per-anchor decoded boxes, best scores
+    and best classes -- what ssd_postprocess computes in f32 and what oracle/nets_quant.ssd_quant_decode computes from a uint8
+    model's head tensors: candidates with score >= nms_score_threshold by descending score, greedy suppression at IoU >
+    nms_iou_threshold, the first max_detections survivors."""
+    f = np.float32
+    boxes = np.asarray(boxes, dtype=np.float32)
+    best = np.asarray(best, dtype=np.float32)
+    best_c = np.asarray(best_c)
     cand = np.nonzero(best >= f(score_thr))[0]
     order = cand[np.lexsort((-cand, -best[cand]))]                       # score desc, ties: higher index first
     area = (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])
