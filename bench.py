@@ -266,7 +266,10 @@ def cpu_baseline(n_frames, W, H, config=2):
     used = max(s['threads_used'] for s in stages.values())
     base = dict(value=value, unit='frames/s', cores=used, kind='port',
                 sample='3 seeds x %d frames of the same %dx%d / ~20-detection workload (median), oracle path: Pillow Lanczos + '
-                       'torch-CPU f32 %s and MARS + numpy deep_sort; per stage the faster of %s threads'
+                       'torch-CPU f32 %s and MARS + numpy deep_sort; per stage the faster of %s threads.  NOTE: a float32 CPU detector '
+                       'beside a uint8 GPU detector -- the integer restatement of the reference\'s uint8 TFLite arithmetic (oracle/nets_quant.py) '
+                       'is a checker (~2 s per frame in numpy), not a CPU implementation, and tflite_runtime is absent; the reference\'s own '
+                       'uint8 CPU path would be faster than this f32 forward.  A reported baseline, not the target.'
                        % (n_frames, W, H, 'YOLOv5s' if yolo else 'SSD-MobileNet-v1', ' / '.join(map(str, settings))),
                 per_seed=[round(v, 2) for v in per_seed], stages=stages,
                 host=dict(cpu_model=_cpu_model(), logical_cores=ncores))
@@ -296,8 +299,59 @@ def gpu_sample_check(sc, n_frames, oracle_counts, oracle_table, device, W, H, mo
         if counts != oracle_counts or table != oracle_table:
             bad.append(z)
     counts0 = [int(v) for v in np.asarray(all_counts[0]).reshape(-1)]
-    return dict(frames=n_frames + 2, streams=streams, counts_hip=counts0, counts_oracle=oracle_counts,
-                identical=not bad, streams_that_differ=bad[:8])
+    out = dict(frames=n_frames + 2, streams=streams, counts_hip=counts0, counts_oracle=oracle_counts,
+               identical=not bad, streams_that_differ=bad[:8])
+    if 'uint8' in model or 'quant' in model:
+        try:
+            del mp1
+            torch.cuda.empty_cache()
+            out['detector'] = detector_sample_check(model, sc, device, W, H, streams)
+        except Exception as e:
+            out['detector'] = dict(error=repr(e))
+    return out
+
+
+def detector_sample_check(model, sc, device, W, H, streams):
+    """One step of a pipeline of the same launch shape WITHOUT injected detections, every label wanted (random weights rarely say
+    'person'): the uint8 detector's own host block (what detect_image returns,
+    tools/ssd_mobilenet.py:198-213) against the oracle chain for that frame -- Pillow Lanczos -> oracle/nets_quant.py (TFLite's integer
+    arithmetic) -> the post-process op (oracle/nets_torch.py) -> predict()'s tail and detect_image()'s filter (oracle/detectors_np.py).
+    Every stream slot holds the same frame, so every slot must hold the same rows."""
+    import torch
+    from PIL import Image
+    from oracle import nets_quant, nets_torch, detectors_np
+    from deepdish_amd.tools.weights_io import load_ssd_model, ssd_post_options
+    from deepdish_amd.pipeline import DEFAULT_LABELS
+    from deepdish_amd.multipipe import MultiStreamPipeline
+    labels = {i: l.strip() for i, l in enumerate(open(DEFAULT_LABELS))}
+    wanted = sorted({l for l in labels.values() if l and l != '???'})
+    mp1 = MultiStreamPipeline(streams, model=model, input_size=(W, H), wanted_labels=wanted)
+    f = 1
+    frame = sc.frame(f)
+    mp1.step(torch.from_numpy(frame[None]).to(device).expand(streams, H, W, 3).contiguous())
+    kind, qm = load_ssd_model(model)
+    post = ssd_post_options(qm)
+    rgba = np.dstack([frame[..., ::-1], np.full((H, W, 1), 255, np.uint8)])
+    resized = np.asarray(Image.fromarray(rgba, 'RGBA').convert('RGB').resize((300, 300), Image.LANCZOS))
+    box_q, cls_q, _ = nets_quant.ssd_quant_forward(qm, resized[None])
+    b, s_, c, _ = nets_quant.ssd_quant_decode(qm, box_q[0], cls_q[0], nets_quant.ssd_anchors(300), post['nms_score_threshold'])
+    op = nets_torch.ssd_postprocess_decoded(b, s_, c, post['max_detections'], post['nms_score_threshold'], post['nms_iou_threshold'])
+    boxes, names, scores = detectors_np.ssd_predict_tail(list(op), labels, original_image_size=(W, H))
+    wb, wl, ws = detectors_np.ssd_detect_filter(boxes, names, scores, mp1.wanted, 0.5)
+    want = sorted((l, float(s), tuple(float(v) for v in bb)) for bb, l, s in zip(wb, wl, ws))
+    bad, worst = [], 0.0
+    for z in range(streams):
+        gb, gl, gs = mp1.detections(z)
+        got = sorted((l, float(s), tuple(float(v) for v in bb)) for bb, l, s in zip(gb, gl, gs))
+        ok = len(got) == len(want) and all(g[0] == w[0] and g[1] == w[1] for g, w in zip(got, want))
+        if ok and want:
+            d = max(abs(a - b) for g, w in zip(got, want) for a, b in zip(g[2], w[2]))
+            worst = max(worst, d)
+            ok = d <= 2e-6 * max(W, H) * 2                # decoded corners: expf vs numpy's exp, scaled to pixels (tlwh: two corners)
+        if not ok:
+            bad.append(z)
+    return dict(frame=f, streams=streams, rows_oracle=len(want), identical=not bad, streams_that_differ=bad[:8], max_box_abs_diff_px=worst,
+                chain='Pillow Lanczos -> nets_quant.ssd_quant_forward -> ssd_quant_decode -> nets_torch.ssd_postprocess_decoded -> detectors_np tail')
 
 
 # ------------------------------------------------------------------------------------------------ rehearsal
@@ -491,7 +545,11 @@ def main():
                        'parallelism': 'independent streams, %d per GPU in %d worker groups' % (args.streams, G),
                        'weights': 'seeded synthetic (seed 1234)'},
             'counts_pos_neg_int_del': [int(v) for v in np.asarray(counts).reshape(-1)],
-            'stage_ms_per_step': {k: round(v, 4) for k, v in stage_ms.items() if k != 'steps'},
+            # GPU milliseconds per step of ONE worker group (HIP events on the streams the kernels run on; the reference's timer names,
+            # deepdish.py:975-981,1018-1021,1031-1032), `host` = the step's wall time outside its waits for the GPU.  The groups share the
+            # GPU and objd runs a frame ahead beside the other stages: the stages need not add up to `wall`, nor `wall` to ms_per_step.
+            'stage_ms_per_step': {k: (round(v, 4) if not isinstance(v, dict) else {a: round(b, 4) for a, b in v.items()})
+                                  for k, v in stage_ms.items() if k != 'steps'},
         }
         if args.streams == 1:
             out['latency_ms_per_frame'] = 1e3 * dt / args.steps        # the reference's own operating point: one stream

@@ -113,6 +113,14 @@ struct dd_pipeline {
     PinBuf h_fin, h_nms, h_crop;
     int crop_cap = 0;
     double t_det = 0, t_nms = 0, t_enc = 0, t_trk = 0;    // host wall seconds per stage, accumulated
+    // GPU time per stage (dd_pipeline_stage_gpu_ms): HIP events on the streams the kernels run on -- the detector chain on its own stream
+    // (Lanczos .. host copy; read when the step consumes it), and on the main stream the pairs 0 predict, 1 NMS, 2 crops + encoder,
+    // 3 association, 4 Kalman update / gallery, 5 track management -- read lazily (at the next step or by the getter) so that no step
+    // waits for anything it did not wait for before.  host = the step's wall time outside its waits for the GPU.
+    hipEvent_t ev_det[2] = {nullptr, nullptr}, ev_main[12] = {};
+    bool ev_pair[6] = {false, false, false, false, false, false}, ev_pending = false;
+    double g_det = 0, g_nms = 0, g_enc = 0, g_trk = 0, g_host = 0, g_wall = 0;     // milliseconds, accumulated
+    double step_wait = 0;                                                          // seconds of this step spent in stream / event waits
     long long steps = 0;
     // The detector has its own stream: like the reference, which keeps one detector call and one encoder call
     // in flight on different frames (deepdish.py:935,985,1008), the detector of frame t+1 can be queued while
@@ -133,6 +141,7 @@ struct dd_pipeline {
 };
 
 namespace {
+int flush_stage_events(dd_pipeline *p);
 
 int wanted_index(const dd_pipeline *p, const std::string &name) {
     for (size_t i = 0; i < p->wanted.size(); ++i) if (p->wanted[i] == name) return (int)i;
@@ -218,6 +227,7 @@ int dd_pipeline_create(dd_ctx *ctx, int n_streams, int frame_h, int frame_w, dd_
         }
         DD_HIP(hipEventCreateWithFlags(&p->det_done, hipEventDisableTiming));
         DD_HIP(hipEventCreateWithFlags(&p->main_mark, hipEventDisableTiming));
+        for (hipEvent_t &e : p->ev_det) DD_HIP(hipEventCreate(&e));
         const size_t S = n_streams;
         if ((rc = p->d_resized.reserve(S * p->det_in * p->det_in_w * 3)) != DD_OK) return rc;
         if ((rc = p->d_tmp.reserve(S * frame_h * p->det_in_w * 3 + 64)) != DD_OK) return rc;
@@ -262,12 +272,15 @@ int dd_pipeline_create(dd_ctx *ctx, int n_streams, int frame_h, int frame_w, dd_
         p->st[z].trk = p->trks[z];
         p->st[z].counts.assign(p->wanted.size() * 4, 0);
     }
+    for (hipEvent_t &e : p->ev_main) DD_HIP(hipEventCreate(&e));
     *out = p;
     return DD_OK;
 }
 
 int dd_pipeline_destroy(dd_pipeline *p) {
     if (!p) return DD_OK;
+    for (hipEvent_t e : p->ev_det) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : p->ev_main) if (e) (void)hipEventDestroy(e);
     if (p->det_stream) { (void)hipStreamSynchronize(p->det_stream); (void)hipStreamDestroy(p->det_stream); }
     if (p->det_done) (void)hipEventDestroy(p->det_done);
     if (p->main_mark) (void)hipEventDestroy(p->main_mark);
@@ -368,6 +381,28 @@ int dd_pipeline_counts(dd_pipeline *p, int64_t *counts_host) {
     return DD_OK;
 }
 
+int dd_pipeline_stage_gpu_ms(dd_pipeline *p, double *out6_host, long long *steps_host) {
+    DD_REQUIRE(p && out6_host, DD_E_ARG, "dd_pipeline_stage_gpu_ms: NULL argument");
+    DD_DEVICE(p->ctx);
+    const int rc = flush_stage_events(p);
+    if (rc != DD_OK) return rc;
+    out6_host[0] = p->g_det; out6_host[1] = p->g_nms; out6_host[2] = p->g_enc; out6_host[3] = p->g_trk; out6_host[4] = p->g_host; out6_host[5] = p->g_wall;
+    if (steps_host) *steps_host = p->steps;
+    return DD_OK;
+}
+
+int dd_pipeline_detections(dd_pipeline *p, int stream, double *boxes_host, double *scores_host, int *classes_host, int cap, int *n_host) {
+    DD_REQUIRE(p && n_host && stream >= 0 && stream < p->S && cap >= 0, DD_E_ARG, "dd_pipeline_detections: bad argument");
+    const StreamState &q = p->st[stream];
+    const int n = (int)q.scores0.size();
+    *n_host = n;
+    DD_REQUIRE(n <= cap || (!boxes_host && !scores_host && !classes_host), DD_E_CAPACITY, "dd_pipeline_detections: %d rows, room for %d", n, cap);
+    if (boxes_host) memcpy(boxes_host, q.boxes0.data(), (size_t)n * 4 * sizeof(double));
+    if (scores_host) memcpy(scores_host, q.scores0.data(), (size_t)n * sizeof(double));
+    if (classes_host) memcpy(classes_host, q.cls0.data(), (size_t)n * sizeof(int));
+    return DD_OK;
+}
+
 int dd_pipeline_stage_seconds(dd_pipeline *p, double *out4_host, long long *steps_host) {
     DD_REQUIRE(p && out4_host, DD_E_ARG, "dd_pipeline_stage_seconds: NULL argument");
     out4_host[0] = p->t_det; out4_host[1] = p->t_nms; out4_host[2] = p->t_enc; out4_host[3] = p->t_trk;
@@ -381,6 +416,25 @@ namespace {
 
 // resize -> forward -> post-process -> adaptor tail -> pinned host block, all streams at once, on the
 // detector stream; det_done fires when the host block is complete.
+// Stage events of the previous step -> the accumulated GPU milliseconds (they completed long ago unless the caller asks right after a step).
+int flush_stage_events(dd_pipeline *p) {
+    if (!p->ev_pending) return DD_OK;
+    p->ev_pending = false;
+    double *into[6] = {&p->g_trk, &p->g_nms, &p->g_enc, &p->g_trk, &p->g_trk, &p->g_trk};
+    for (int k = 0; k < 6; ++k) {
+        if (!p->ev_pair[k]) continue;
+        p->ev_pair[k] = false;
+        float ms = 0.f;
+        DD_HIP(hipEventSynchronize(p->ev_main[2 * k + 1]));
+        DD_HIP(hipEventElapsedTime(&ms, p->ev_main[2 * k], p->ev_main[2 * k + 1]));
+        *into[k] += (double)ms;
+    }
+    return DD_OK;
+}
+#define DD_STAGE_BEGIN(k) DD_HIP(hipEventRecord(p->ev_main[2 * (k)], s))
+#define DD_STAGE_END(k) do { DD_HIP(hipEventRecord(p->ev_main[2 * (k) + 1], s)); p->ev_pair[k] = true; } while (0)
+#define DD_TIMED_WAIT(expr) do { const double w0_ = now_s(); DD_HIP(expr); p->step_wait += now_s() - w0_; } while (0)
+
 int enqueue_detector(dd_pipeline *p, const uint8_t *frames) {
     hipStream_t s = p->det_stream;
     const int S = p->S, MAX_DET = p->max_det;
@@ -389,6 +443,7 @@ int enqueue_detector(dd_pipeline *p, const uint8_t *frames) {
     // upload of these frames)
     DD_HIP(hipEventRecord(p->main_mark, p->ctx->stream));
     DD_HIP(hipStreamWaitEvent(s, p->main_mark, 0));
+    DD_HIP(hipEventRecord(p->ev_det[0], s));
     if (p->det_kind == DET_TFLITE) {                           // tflite_object_detector.py:207-211: cv2.resize (INTER_LINEAR) of the RGB frame
         if ((rc = ddk::crop_resize(s, frames, p->H, p->W, p->d_tfl_boxes.p, S, p->det_in, p->det_in_w, p->d_resized.as<uint8_t>())) != DD_OK) return rc;
     } else if ((rc = ddk::resize_lanczos(s, p->ctx->device, frames, p->H, p->W, 3, 1, p->d_resized.as<uint8_t>(), p->det_in,
@@ -414,6 +469,7 @@ int enqueue_detector(dd_pipeline *p, const uint8_t *frames) {
         const size_t head = ((size_t)S * 4 + 63) / 64 * 64;
         DD_HIP(hipMemcpyAsync(p->h_fin.p, yn, (size_t)S * 4, hipMemcpyDeviceToHost, s));
         DD_HIP(hipMemcpyAsync(p->h_fin.as<char>() + head, p->d_pack.p, p->yolo_host_rows * 24, hipMemcpyDeviceToHost, s));
+        DD_HIP(hipEventRecord(p->ev_det[1], s));
         DD_HIP(hipEventRecord(p->det_done, s));
         p->det_pending = frames;
         return DD_OK;
@@ -431,6 +487,7 @@ int enqueue_detector(dd_pipeline *p, const uint8_t *frames) {
     if (p->det_kind == DET_TFLITE) {                           // the generic adaptor's tail is a few integer truncations: on the host (step2)
         const size_t dbytes = (size_t)S * MAX_DET * 6 * sizeof(float) + (size_t)S * sizeof(int);
         DD_HIP(hipMemcpyAsync(p->h_fin.p, p->d_det.p, dbytes, hipMemcpyDeviceToHost, s));
+        DD_HIP(hipEventRecord(p->ev_det[1], s));
         DD_HIP(hipEventRecord(p->det_done, s));
         p->det_pending = frames;
         return DD_OK;
@@ -441,6 +498,7 @@ int enqueue_detector(dd_pipeline *p, const uint8_t *frames) {
         return rc;                                                                                    // :111-150
     const size_t fbytes = (size_t)S * (MAX_DET * (4 * 8 + 8 + 4) + 4);
     DD_HIP(hipMemcpyAsync(p->h_fin.p, p->d_fin.p, fbytes, hipMemcpyDeviceToHost, s));
+    DD_HIP(hipEventRecord(p->ev_det[1], s));
     DD_HIP(hipEventRecord(p->det_done, s));
     p->det_pending = frames;
     return DD_OK;
@@ -538,8 +596,12 @@ int dd_pipeline_step2(dd_pipeline *p, const uint8_t *frames_in, const uint8_t *f
     hipStream_t s = p->ctx->stream;
     const int S = p->S, MAX_DET = p->max_det;
     int rc;
+    if ((rc = flush_stage_events(p)) != DD_OK) return rc;
     const double t0 = now_s();
+    p->step_wait = 0;
+    DD_STAGE_BEGIN(0);
     if ((rc = ddk::trackers_predict(p->trks.data(), S)) != DD_OK) return rc;            // deepdish.py:1028
+    DD_STAGE_END(0);
     if (p->mog2) {                                                                      // :920-924
         if ((rc = ddk::mog2_apply(p->mog2, s, frames_in, -1.0, p->d_mask.as<uint8_t>(),
                                   p->bg_masking ? p->d_masked.as<uint8_t>() : nullptr)) != DD_OK) return rc;
@@ -552,8 +614,13 @@ int dd_pipeline_step2(dd_pipeline *p, const uint8_t *frames_in, const uint8_t *f
     std::vector<StreamState> &st = p->st;
     if (p->det) {
         if (p->det_pending != frames && (rc = enqueue_detector(p, frames)) != DD_OK) return rc;       // not queued ahead: run it now
-        DD_HIP(hipEventSynchronize(p->det_done));                                                      // round trip 1
+        DD_TIMED_WAIT(hipEventSynchronize(p->det_done));                                               // round trip 1
         p->det_pending = nullptr;
+        {   // the detector chain of these frames on its stream: resize, forward, post-process, adaptor tail, host copy
+            float ms = 0.f;
+            DD_HIP(hipEventElapsedTime(&ms, p->ev_det[0], p->ev_det[1]));
+            p->g_det += (double)ms;
+        }
         if (p->det_kind == DET_YOLOV5) {
             const size_t head = ((size_t)S * 4 + 63) / 64 * 64;
             const int *yn = p->h_fin.as<int>();
@@ -683,7 +750,7 @@ int dd_pipeline_step2(dd_pipeline *p, const uint8_t *frames_in, const uint8_t *f
         DD_HIP(hipMemcpyAsync(dm, hm, in_bytes, hipMemcpyHostToDevice, s));
         if ((rc = ddk::mask_box_count(s, p->d_mask.as<uint8_t>(), p->H, p->W, dm, dm + (size_t)K0 * 4, K0, dm + (size_t)K0 * 5)) != DD_OK) return rc;
         DD_HIP(hipMemcpyAsync(hm + (size_t)K0 * 5, dm + (size_t)K0 * 5, (size_t)K0 * sizeof(int), hipMemcpyDeviceToHost, s));
-        DD_HIP(hipStreamSynchronize(s));                                                               // extra round trip
+        DD_TIMED_WAIT(hipStreamSynchronize(s));                                                        // extra round trip
         const int *cnt = hm + (size_t)K0 * 5;
         std::vector<int> off0 = off;
         for (int z = 0; z < S; ++z) {
@@ -719,6 +786,7 @@ int dd_pipeline_step2(dd_pipeline *p, const uint8_t *frames_in, const uint8_t *f
         });
         memcpy(ho, off.data(), (size_t)(S + 1) * sizeof(int));
         char *d = p->d_nms.as<char>();
+        DD_STAGE_BEGIN(1);
         DD_HIP(hipMemcpyAsync(d, hb, in_bytes, hipMemcpyHostToDevice, s));
         const double *dbx = reinterpret_cast<const double *>(d), *dk = dbx + (size_t)K * 4;
         const int *doff = reinterpret_cast<const int *>(dk + K);
@@ -735,7 +803,8 @@ int dd_pipeline_step2(dd_pipeline *p, const uint8_t *frames_in, const uint8_t *f
         }
         int *hidx = reinterpret_cast<int *>(p->h_nms.as<char>() + ((in_bytes + 63) / 64) * 64);
         DD_HIP(hipMemcpyAsync(hidx, didx, out_bytes, hipMemcpyDeviceToHost, s));
-        DD_HIP(hipStreamSynchronize(s));                                                               // round trip 2
+        DD_STAGE_END(1);
+        DD_TIMED_WAIT(hipStreamSynchronize(s));                                                        // round trip 2
         const int *hnk = hidx + K;
         for (int z = 0; z < S; ++z) st[z].keep.assign(hidx + off[z], hidx + off[z] + hnk[z]);
     } else {
@@ -772,6 +841,7 @@ int dd_pipeline_step2(dd_pipeline *p, const uint8_t *frames_in, const uint8_t *f
                 }
             }
         });
+        DD_STAGE_BEGIN(2);
         DD_HIP(hipMemcpyAsync(p->d_crop.p, hc, (size_t)D * 32, hipMemcpyHostToDevice, s));
         if ((rc = ddk::crop_resize(s, frames, p->H, p->W, p->d_crop.p, D, 64, 32, p->d_patches.as<uint8_t>())) != DD_OK) return rc;
         for (int a = 0; a < D; a += p->enc_batch) {
@@ -779,29 +849,38 @@ int dd_pipeline_step2(dd_pipeline *p, const uint8_t *frames_in, const uint8_t *f
             if ((rc = dd_net_forward(p->enc, p->d_patches.as<uint8_t>() + (size_t)a * 64 * 32 * 3, n, s)) != DD_OK) return rc;
             if ((rc = dd_net_read(p->enc, -1, n, p->d_feats.as<float>() + (size_t)a * 128, 1, s)) != DD_OK) return rc;
         }
+        DD_STAGE_END(2);
     } else {
         for (auto &q : st) { q.det_cls.clear(); q.det_conf.clear(); }
     }
     const double t3 = now_s();
 
     // ---------------- deep_sort update, phase-split so all streams share two round trips (:1029)
+    DD_STAGE_BEGIN(3);
     if ((rc = ddk::trackers_update_begin(p->trks.data(), S, tlwh.data(), D ? p->d_feats.as<float>() : nullptr, 1,
                                          doff.data())) != DD_OK) return rc;
+    DD_STAGE_END(3);
     // Look-ahead, late form (default): the detector run of the next frames is queued HERE, behind this step's NMS / crops / encoder /
     // association kernels (enqueue_detector orders the detector stream after what the main stream holds so far).  Queued at the
     // consume point instead (DD_DET_LATE=0) it shares the GPU with the encoder from the start, the chain the host waits for takes
     // twice as long, and then the GPU idles through the host's matching / count-line tail: one worker group ran 6.3 ms per
     // 384-frame step for 5.0 ms of kernels.  Here the chain runs alone, and the detector fills the tail.
     if (p->det && frames_next && p->det_late && (rc = enqueue_detector(p, frames_next)) != DD_OK) return rc;
-    DD_HIP(hipStreamSynchronize(s));                                                                   // round trip 3
+    DD_TIMED_WAIT(hipStreamSynchronize(s));                                                            // round trip 3
+    DD_STAGE_BEGIN(4);
     if ((rc = ddk::trackers_update_match(p->trks.data(), S)) != DD_OK) return rc;
-    DD_HIP(hipStreamSynchronize(s));                                                                   // round trip 4
+    DD_STAGE_END(4);
+    DD_TIMED_WAIT(hipStreamSynchronize(s));                                                            // round trip 4
+    DD_STAGE_BEGIN(5);
     if ((rc = ddk::trackers_update_end(p->trks.data(), S)) != DD_OK) return rc;
+    DD_STAGE_END(5);
     ddk::parallel_for(S, GRAIN, [&](int z0, int z1) {
         for (int z = z0; z < z1; ++z) count_line_one_stream(p, st[z]);
     });
     const double t4 = now_s();
     p->t_det += t1 - t0; p->t_nms += t2 - t1; p->t_enc += t3 - t2; p->t_trk += t4 - t3;
+    p->g_wall += 1e3 * (t4 - t0); p->g_host += 1e3 * ((t4 - t0) - p->step_wait);
+    p->ev_pending = true;
     p->steps += 1;
     return DD_OK;
 }

@@ -45,6 +45,7 @@ class MultiStreamPipeline:
         self.S = int(n_streams)
         self.W, self.H = input_size
         self.wanted = list(wanted_labels)
+        self.model_name = str(model)
         # the reference picks the detector plugin by a substring of --model (deepdish.py:482-502)
         self.kind = ('yolov5' if 'yolov5' in model else None if ('yolo' in model or 'saved_model' in model) else
                      'ssd_mobilenet' if 'mobilenet' in model else 'tflite' if 'tflite' in model else None)
@@ -156,8 +157,27 @@ class MultiStreamPipeline:
         return _TrackerView(h)
 
     def stage_ms(self):
-        t = np.zeros(4, dtype=np.float64)
+        """Per step: the stages' GPU milliseconds under the reference's timer names (deepdish.py:975-981 objd, :1018-1021 feat, :1031-1032
+        trak; nms = the deep_sort NMS of :995), measured with HIP events on the streams the kernels run on, `host` = the step's wall time
+        outside its waits for the GPU, `wall` = the step.  objd runs on the detector stream, one frame ahead beside the other stages, so
+        the stages do not add up to `wall`.  `host_wall` = the old host-side stopwatch per program section (NOT per-stage GPU time: its
+        `trak` contains the wait for the encoder kernels)."""
+        g = np.zeros(6, dtype=np.float64)
         n = ctypes.c_longlong()
+        check(lib().dd_pipeline_stage_gpu_ms(self._h, ptr(g), ctypes.byref(n)), 'dd_pipeline_stage_gpu_ms')
+        t = np.zeros(4, dtype=np.float64)
         check(lib().dd_pipeline_stage_seconds(self._h, ptr(t), ctypes.byref(n)), 'dd_pipeline_stage_seconds')
         k = max(1, n.value)
-        return dict(objd=1e3 * t[0] / k, nms=1e3 * t[1] / k, feat=1e3 * t[2] / k, trak=1e3 * t[3] / k, steps=n.value)
+        return dict(objd=g[0] / k, nms=g[1] / k, feat=g[2] / k, trak=g[3] / k, host=g[4] / k, wall=g[5] / k, steps=n.value,
+                    host_wall=dict(objd=1e3 * t[0] / k, nms=1e3 * t[1] / k, feat=1e3 * t[2] / k, trak=1e3 * t[3] / k))
+
+    def detections(self, stream):
+        """The detector adaptor's output for one stream in the last step: what the reference's detect_image(...) returns
+        (tools/ssd_mobilenet.py:198-213) -- (boxes tlwh f64 [n, 4], label names, scores f64 [n])."""
+        n = ctypes.c_int()
+        check(lib().dd_pipeline_detections(self._h, int(stream), None, None, None, 0, ctypes.byref(n)), 'dd_pipeline_detections')
+        b, sc, cl = np.zeros((n.value, 4), np.float64), np.zeros(n.value, np.float64), np.zeros(n.value, np.int32)
+        if n.value:
+            check(lib().dd_pipeline_detections(self._h, int(stream), ptr(b), ptr(sc), ptr(cl), n.value, ctypes.byref(n)), 'dd_pipeline_detections')
+        off = 0 if self.kind == 'yolov5' else 1
+        return b, [self.label_lines[int(c) + off] for c in cl], sc

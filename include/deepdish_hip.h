@@ -378,6 +378,16 @@ int dd_pipeline_counts(dd_pipeline *p, int64_t *counts_host);
 int dd_pipeline_tracker(dd_pipeline *p, int stream, dd_tracker **out);
 /* accumulated host wall time per stage (objd, nms, feat, trak as in deepdish.py's TimingInfo labels) */
 int dd_pipeline_stage_seconds(dd_pipeline *p, double *out4_host, long long *steps_host);
+/* GPU time per stage, as the reference names its per-frame timers (deepdish.py:975-981 objd, :1018-1021 feat, :1031-1032 trak; nms is the
+ * deep_sort NMS of :995): milliseconds between HIP events recorded on the streams the stage's kernels run on, summed over the steps so far --
+ * out6 = {objd (resize, detector forward, post-process, adaptor tail, host copy; on the detector stream), nms, feat (crops + encoder), trak
+ * (Kalman predict, association, update, track management kernels), host (the steps' wall time outside their waits for the GPU: adaptor
+ * filter, box hygiene, LSAP, count line), wall}. */
+int dd_pipeline_stage_gpu_ms(dd_pipeline *p, double *out6_host, long long *steps_host);
+/* What the detector adaptor returned for one stream in the last step -- the reference's object_detector.detect_image(...) result
+ * (deepdish.py:935,985; tools/ssd_mobilenet.py:198-213): tlwh rows (f64), scores, class ids (index into the label file minus the
+ * adaptor's label offset); with injected detections, those.  cap rows of room; n_host always gets the row count. */
+int dd_pipeline_detections(dd_pipeline *p, int stream, double *boxes_host, double *scores_host, int *classes_host, int cap, int *n_host);
 
 /* ---------------------------------------------------------------- multi-GPU
  * Sum of the per-stream count vectors (pos, neg, int, del per label; deepdish.py:1141-1145).

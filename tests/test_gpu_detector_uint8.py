@@ -179,3 +179,26 @@ def test_pipeline_loads_a_mars_tflite_file(tmp_path):
         a.step(fr, a.pack_injected([one])); b.step(fr, b.pack_injected([one]))
         np.testing.assert_array_equal(a.tracker(0).table()[0], b.tracker(0).table()[0])
     assert len(a.tracker(0).table()[0]) > 0
+
+
+def test_stage_gpu_ms_and_detections_getter():
+    """dd_pipeline_stage_gpu_ms: every stage has GPU time, the host share and the wall time are consistent; dd_pipeline_detections returns
+    the injected rows when detections are injected and the adaptor's own rows otherwise."""
+    from deepdish_amd.multipipe import MultiStreamPipeline
+    from deepdish_amd.synth import Scene
+    sc = Scene(seed=4, n_obj=6, n_frames=5)
+    wanted = sorted({l for l in _labels().values() if l and l != '???'})
+    mp = MultiStreamPipeline(2, model=MODEL, wanted_labels=wanted)
+    for f in range(4):
+        boxes, scores, _, _ = sc.detections(f)
+        one = ([tuple(int(v) for v in bb) for bb in boxes], ['person'] * len(boxes), [float(x) for x in scores])
+        fr = torch.from_numpy(sc.frame(f)).cuda()
+        mp.step(torch.stack([fr, fr]), mp.pack_injected([one, one]))
+        b, l, s_ = mp.detections(1)
+        assert l == ['person'] * len(boxes) and np.allclose(b, np.array(one[0], dtype=np.float64)) and np.allclose(s_, one[2])
+    t = mp.stage_ms()
+    assert t['steps'] == 4 and all(t[k] > 0 for k in ('objd', 'nms', 'feat', 'trak', 'host', 'wall'))
+    assert t['host'] < t['wall'] and t['feat'] < t['wall'] and t['objd'] < 4 * t['wall']
+    mp.step(torch.stack([fr, fr]))                                      # no injection: the detector's own rows, the same for both slots
+    a, b = mp.detections(0), mp.detections(1)
+    assert a[1] == b[1] and np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2])
