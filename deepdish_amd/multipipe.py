@@ -70,6 +70,8 @@ class MultiStreamPipeline:
             ssd_post = ssd_post_options(wd)                         # the post-process op's options as the model file states them
         wd = load_mars_weights(encoder_model)                       # a mars .tflite file on disk goes through tools/tflite_reader.load_mars
         self.enc_weights = wd
+        if tuple(wd.get('__in_hw__', (64, 32))) != (64, 32):
+            raise ValueError('%s takes %s crops: the batched pipeline is built for the 64 x 32 encoder (mars-64x32x3, deepdish.py:505-510)' % (encoder_model, wd['__in_hw__']))
         # the pipeline never reads an intermediate encoder tensor: its activation buffers share memory by lifetime (6.2 -> ~2 GB at 12 288 crops)
         self.enc = Net(nets.compile_mars(wd), max_batch=encoder_max_batch or max(64, 32 * self.S), context=self.ctx,
                        shared=os.environ.get('DD_NET_SHARED', '1') != '0')

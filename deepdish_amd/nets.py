@@ -413,7 +413,12 @@ def compile_mars(wd, in_h=64, in_w=32):
     x = c11 = P.stem(w, b, 1, ACT_ELU, swap_rb=bool(wd.get('__swap_rb__', True)))   # :175-177 BGR -> RGB, :101-105 (a .tflite graph says whether it reverses the channels)
     if Program.STEM_POOL_FUSE:       # conv1_1 is read by conv1_2 only: with >= 160 crops both run as one launch
         P.ops[-1][30] = 1            # (conv3x3_pool_rows_k<STEM>) and the conv1_1 tensor is not written
-    w, b = fold_conv_bn(wd, 'conv1_2'); x = pool = P.conv(x, w, b, act=ACT_ELU, pool=True)   # :106-110 + :116 VALID pool
+    w, b = fold_conv_bn(wd, 'conv1_2')
+    if in_w == 32:
+        x = pool = P.conv(x, w, b, act=ACT_ELU, pool=True)                     # :106-110 + :116 VALID pool, one launch (the fused kernel is 32 wide)
+    else:                                                                      # other crop sizes (mars-small128.pb: 128 x 64): pool as its own op
+        P.ops[-1][30] = 0
+        x = pool = P.maxpool(P.conv(x, w, b, act=ACT_ELU), 3, 2, 0)
     raw, pre = x, x                  # raw = block input (skip path), pre = what conv "1" reads
     for i, (name, c, inc, first) in enumerate(MARS_BLOCKS):
         stride = 2 if inc else 1

@@ -52,14 +52,16 @@ class MarsImageEncoder(object):
         self.ctx = context or default_context()
         wd = load_mars_weights(model_filename)                   # .tflite (generate_detections.py:151-162), .npz of named arrays, or synthetic[:seed]
         self.weights = wd
-        self.net = Net(nets.compile_mars(wd), max_batch=max_batch, context=self.ctx)
-        self.image_shape = (64, 32, 3)
-        self.height, self.width = 64, 32
+        # a frozen graph states its crop size in the `images` placeholder (generate_detections.py:141-142; mars-small128.pb: 128 x 64),
+        # the .tflite encoder the reference ships takes 64 x 32 (mars-64x32x3)
+        self.height, self.width = (int(v) for v in wd.get('__in_hw__', (64, 32)))
+        self.net = Net(nets.compile_mars(wd, self.height, self.width), max_batch=max_batch, context=self.ctx)
+        self.image_shape = (self.height, self.width, 3)
         self.feature_dim = 128
         self.max_batch_size = max_batch
 
     def encode_device(self, patches_dev):
-        """u8 [n,64,32,3] on device -> f32 [n,128] on device."""
+        """u8 [n, height, width, 3] on device -> f32 [n,128] on device."""
         n = int(patches_dev.shape[0])
         out = self.ctx.empty((n, 128), torch.float32)
         for s in range(0, n, self.max_batch_size):

@@ -4,8 +4,8 @@ The reference loads `.tflite` / `.pb` blobs (all absent from its tree, .MISSING_
 build reads its own `.npz` of named f32 arrays (names as in deepdish_amd/nets.py).  A model path of
 the form `synthetic[:seed]...`, or any path when DEEPDISH_SYNTHETIC_WEIGHTS=1, yields seeded random
 weights of the right architecture (what tests and bench.py use).  SSD-MobileNet `.tflite` files (uint8 or
-float) and MARS encoder `.tflite` files (float) are read by tools/tflite_reader.py; other graphs and frozen `.pb`
-files are an explicit error.
+float), MARS encoder `.tflite` files (float) and YOLOv5s `.tflite` files are read by tools/tflite_reader.py, frozen MARS `.pb` graphs by
+tools/graphdef.py; other graphs are an explicit error.
 
 `load_ssd_model` is what the SSD-MobileNet plugins call: it returns ('uint8', QModel) for the reference's own kind
 of file -- a uint8-quantised model (tools/ssd_mobilenet.py:102 upstream; `synthetic...uint8` names build one from
@@ -32,7 +32,7 @@ def load_named_weights(model_file, synthetic_fn):
                 'SSD-MobileNet-v1 detector (tools/weights_io.load_ssd_model) and the MARS encoder (load_mars_weights) graphs are mapped onto programs '
                 'so far -- YOLOv5 graphs are not.')
     elif name.endswith('.pb'):
-        hint = ' A frozen TensorFlow graph (.pb, tools/generate_detections.py:118-148 upstream) is not read here: convert it offline to an .npz of the named arrays.'
+        hint = ' Frozen TensorFlow graphs (.pb) are read for the MARS encoder only (tools/graphdef.py, tools/generate_detections.py:118-148 upstream).'
     raise FileNotFoundError(
         '%s: cannot load model weights (%s). Supply an .npz of named arrays, or use a "synthetic[:seed]" '
         'model path / DEEPDISH_SYNTHETIC_WEIGHTS=1 for seeded random weights.%s' % (model_file, name, hint))
@@ -46,6 +46,9 @@ def load_mars_weights(model_file):
     if name.endswith('.tflite') and os.path.exists(name):
         from . import tflite_reader
         return tflite_reader.load_mars(name)
+    if name.endswith('.pb') and os.path.exists(name):            # a frozen graph (generate_detections.py:118-148,187-189: ImageEncoder)
+        from . import graphdef
+        return graphdef.load_mars(name)[0]                       # '__in_hw__' carries the crop size its placeholder states
     return load_named_weights(model_file, nets.synthetic_mars_weights)
 
 

@@ -151,3 +151,35 @@ def test_box_encoder_loads_a_tflite_file(tmp_path):
     ref = create_box_encoder(str(tmp_path / 'mars.npz'), batch_size=32)
     want = ref(frame, boxes)
     np.testing.assert_array_equal(got, want)
+
+
+def test_create_box_encoder_reads_a_frozen_graph(tmp_path):
+    """create_box_encoder('<file>.pb') (the `else` branch of generate_detections.py:182-189 upstream: ImageEncoder on a frozen graph): the
+    64 x 32 encoder written as a GraphDef gives, bit for bit, the features of the same weights handed over as named arrays; a 128 x 64
+    graph (mars-small128, freeze_model.py:200-201) takes 128 x 64 crops and agrees with the f32 restatement within the encoder's tolerance."""
+    from deepdish_amd import nets
+    from deepdish_amd.tools import graphdef
+    from deepdish_amd.tools.generate_detections import create_box_encoder
+    from oracle import nets_torch
+    rng = np.random.default_rng(5)
+    frame = rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    boxes = [[30, 40, 60, 140], [300, 100, 80, 200], [500, 20, 50, 90]]
+    wd = nets.synthetic_mars_weights(4321)
+    path = str(tmp_path / 'mars-64x32x3.pb')
+    graphdef.write_mars(wd, path, in_hw=(64, 32))
+    np.savez(str(tmp_path / 'mars.npz'), **wd)
+    enc, ref = create_box_encoder(path, batch_size=32), create_box_encoder(str(tmp_path / 'mars.npz'), batch_size=32)
+    assert (enc.image_encoder.height, enc.image_encoder.width) == (64, 32)
+    np.testing.assert_array_equal(enc(frame, boxes), ref(frame, boxes))
+    wd['fc1/weights'] = (rng.standard_normal((16 * 8 * 128, 128)) * np.sqrt(2.0 / 16384)).astype(np.float32)
+    path = str(tmp_path / 'mars-small128.pb')
+    graphdef.write_mars(wd, path, in_hw=(128, 64))
+    enc = create_box_encoder(path, batch_size=32)
+    assert enc.image_encoder.image_shape == (128, 64, 3)
+    from oracle import image_np
+    patches = np.stack([image_np.extract_image_patch(frame, np.array(b), (128, 64)) for b in boxes])
+    want = nets_torch.mars_forward(wd, patches)
+    got = enc(frame, boxes)
+    assert got.shape == (3, 128)
+    np.testing.assert_allclose(got, want, rtol=0, atol=5e-3)
+    assert (1.0 - (got * want).sum(axis=1)).max() < 5e-4
