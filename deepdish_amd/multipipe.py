@@ -10,7 +10,7 @@ from .runtime import default_context, ptr
 from . import nets, netsq
 from .engine import Net
 from .pipeline import DEFAULT_LABELS, DEFAULT_YOLO_LABELS
-from .tools.weights_io import load_named_weights, load_ssd_model, load_mars_weights, ssd_post_options
+from .tools.weights_io import load_named_weights, load_ssd_model, load_mars_weights, load_yolov5_weights, ssd_post_options
 
 
 class _TrackerView:
@@ -56,8 +56,8 @@ class MultiStreamPipeline:
         self.det = None
         anchors, n_anchors, n_classes = None, 0, 0
         if run_detector and self.kind == 'yolov5':
-            wd = load_named_weights(model, nets.synthetic_yolov5s_weights)
-            prog = nets.compile_yolov5s(wd)
+            wd = load_yolov5_weights(model)                        # a yolov5s .tflite file on disk goes through tools/tflite_reader.load_yolov5s
+            prog = nets.compile_yolov5s(wd, int(wd.get('__in_size__', 640)))
             self.det = Net(prog, max_batch=self.S, context=self.ctx)
             n_anchors, n_classes = prog.meta['rows'], prog.meta['n_classes']
         elif run_detector:

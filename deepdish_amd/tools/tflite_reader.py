@@ -387,3 +387,252 @@ def load_mars(path):
     _need(fc['w'].shape == (4096, 128), fc['op'], 'fc1 weights %s (expected 4096 -> 128)' % (fc['w'].shape,))
     wd['fc1/weights'], wd['fc1/biases'] = fc['w'], fc['b']
     return wd
+
+
+# ------------------------------------------------------------------------------------------- YOLOv5s
+YOLO_ANCHORS = [[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]]     # detectors/yolov5/yolov5s.yaml:7-10
+
+
+class _Eval:
+    """Evaluates the shape-shuffling / element-wise corner of the operator set in numpy: used to CHECK what a model file's Focus slicing and
+    Detect tail compute (whatever spelling the exporter chose) against the arithmetic csrc/nets.hip runs in their place, on probe tensors."""
+    KINDS = ('STRIDED_SLICE', 'CONCATENATION', 'RESHAPE', 'TRANSPOSE', 'LOGISTIC', 'MUL', 'ADD', 'SUB', 'DIV', 'SQUARE', 'DEQUANTIZE')
+
+    def __init__(self, g):
+        self.g, self.vals = g, {}
+
+    def value(self, t):
+        if t in self.vals:
+            return self.vals[t]
+        ten = self.g.tensors[t]
+        if ten.data is not None:
+            return np.asarray(ten.data)
+        op = self.g.made_by(t)
+        _need(op is not None, self.g.ops[0], 'tensor %s has no producer and no data' % ten.name)
+        _need(op.kind in self.KINDS, op, 'not an operator the Focus / Detect check evaluates (%s)' % ', '.join(self.KINDS))
+        a = [self.value(i) for i in op.inputs]
+        k = op.kind
+        if k == 'DEQUANTIZE':
+            v = a[0].astype(np.float32)
+        elif k == 'LOGISTIC':
+            v = (1.0 / (1.0 + np.exp(-a[0].astype(np.float64)))).astype(np.float32)
+        elif k in ('MUL', 'ADD', 'SUB', 'DIV'):
+            _need(op.options.get('act', 'none') == 'none', op, 'fused activation')
+            x, y = a[0].astype(np.float32), a[1].astype(np.float32)
+            v = x * y if k == 'MUL' else x + y if k == 'ADD' else x - y if k == 'SUB' else x / y
+        elif k == 'SQUARE':
+            v = a[0] * a[0]
+        elif k == 'CONCATENATION':
+            v = np.concatenate(a, axis=op.options['axis'])
+        elif k == 'RESHAPE':
+            shape = [int(s) for s in (a[1].reshape(-1) if len(a) > 1 else op.options['new_shape'])]
+            v = a[0].reshape(shape)
+        elif k == 'TRANSPOSE':
+            v = np.transpose(a[0], [int(p) for p in a[1].reshape(-1)])
+        else:                                                       # STRIDED_SLICE (no ellipsis / new-axis / shrink masks: the reader reads none)
+            begin, end, strides = ([int(p) for p in q.reshape(-1)] for q in a[1:4])
+            bm, em = op.options.get('begin_mask', 0), op.options.get('end_mask', 0)
+            idx = tuple(slice(None if bm >> d & 1 else begin[d], None if em >> d & 1 else end[d], strides[d]) for d in range(a[0].ndim))
+            v = a[0][idx]
+        self.vals[t] = v
+        return v
+
+
+def load_yolov5s(path):
+    """`detectors/yolov5/yolov5s-fp16.tflite` (tools/yolov5.py:68-79 upstream: float32 [1, s, s, 3] pixels 0..255 in, [1, rows, 85] out) -> the
+    named weights deepdish_amd/nets.compile_yolov5s takes (batch norms folded as the converter leaves them: `<layer>/weights` + `<layer>/biases`).
+
+    The graph is walked BACKWARDS from its output along detectors/yolov5/yolov5s.yaml:12-48 (depth 0.33, width 0.50): Detect's three branches,
+    then C3 / Conv / Concat / Upsample / SPP / Focus, every tensor reached by two routes (the backbone maps the head concatenates) checked to be
+    the same one.  A Conv is [PAD +] CONV_2D (float, or float16 filters behind DEQUANTIZE) + SiLU spelt LOGISTIC x MUL; a Bottleneck's skip an ADD;
+    SPP three SAME stride-1 MAX_POOL_2D of 5 / 9 / 13; Upsample a 2x RESIZE_NEAREST_NEIGHBOR.  What the Focus slicing and each Detect tail
+    COMPUTE is not matched by spelling but evaluated in numpy on probe tensors and held to the arithmetic the kernels implement (slice order
+    (0,0) (1,0) (0,1) (1,1); sigmoid, (2 s - 0.5 + grid) stride / size, (2 s)^2 anchor / size, rows anchor-major).  The file is absent from the
+    reference tree (.MISSING_LARGE_BLOBS): exercised on files tflite_writer.write_yolov5s lays out like the YOLOv5 TensorFlow export; anything
+    else raises UnsupportedModel naming the operator -- a HARD_SWISH (older exports), an int8 file, a per-class NMS tail, another width."""
+    g = read(path)
+    _need(len(g.inputs) == 1 and len(g.outputs) == 1, g.ops[0], '%d inputs / %d outputs' % (len(g.inputs), len(g.outputs)))
+    x_in = g.tensors[g.inputs[0]]
+    _need(x_in.dtype == np.float32, g.ops[0], 'input of type %s (the int8 file, tools/yolov5.py:61,102-104, is not built: float / fp16-weight files are)'
+          % (np.dtype(x_in.dtype).name if x_in.dtype else '?'))
+    _need(len(x_in.shape) == 4 and x_in.shape[1] == x_in.shape[2] and x_in.shape[3] == 3 and x_in.shape[1] % 32 == 0, g.ops[0], 'input %s (expected [1, s, s, 3], s a multiple of 32)' % (x_in.shape,))
+    size = int(x_in.shape[1])
+    out_t = g.tensors[g.outputs[0]]
+    wd, seen = {}, {}
+
+    def const(i):
+        if i < 0:
+            return None
+        t = g.tensors[i]
+        if t.data is not None:
+            return np.asarray(t.data)
+        op = g.made_by(i)
+        if op is not None and op.kind == 'DEQUANTIZE' and g.tensors[op.inputs[0]].data is not None:
+            return np.asarray(g.tensors[op.inputs[0]].data).astype(np.float32)
+        return None
+
+    def raw_conv(name, op, k, s):
+        """CONV_2D `op` -> (weights HWIO, bias, the tensor it reads through an optional PAD); k, s as the yaml says."""
+        _need(op is not None and op.kind == 'CONV_2D', op or g.ops[0], 'expected the CONV_2D of %s' % name)
+        w, b = const(op.inputs[1]), const(op.inputs[2]) if len(op.inputs) > 2 else None
+        _need(w is not None and b is not None and w.dtype == np.float32, op, '%s: float filter and bias constants' % name)
+        o = op.options
+        _need(w.shape[1] == w.shape[2] == k and o['stride_w'] == o['stride_h'] == s and o['dilation_w'] == 1 and o['act'] == 'none', op,
+              '%s: %dx%d stride %d filter (yolov5s.yaml wants %dx%d stride %d, no fused activation)' % (name, w.shape[1], w.shape[2], o['stride_w'], k, k, s))
+        src = op.inputs[0]
+        if s == 1:
+            _need(o['padding'] == 'SAME', op, '%s: stride-1 convolutions are SAME' % name)
+        else:                                                       # the kernels pad k // 2 on every side (autopad): ZeroPadding2D + VALID in the export
+            pad = g.made_by(src)
+            _need(o['padding'] == 'VALID' and pad is not None and pad.kind == 'PAD', op, '%s: a stride-2 layer must be PAD + VALID CONV_2D (SAME pads one side only)' % name)
+            pv = const(pad.inputs[1])
+            _need(pv is not None and [int(v) for v in pv.reshape(-1)] == [0, 0, k // 2, k // 2, k // 2, k // 2, 0, 0], pad, '%s: paddings %s' % (name, None if pv is None else pv.tolist()))
+            src = pad.inputs[0]
+        return np.transpose(w, (1, 2, 3, 0)).astype(np.float32), b.astype(np.float32).reshape(-1), src
+
+    def conv(name, t, k=1, s=1):
+        """t = output of an activated Conv (yaml `Conv`: conv + bn + SiLU) -> the tensor it reads."""
+        if name in seen:
+            _need(seen[name][0] == t, g.made_by(t) or g.ops[0], '%s is reached by two routes that disagree' % name)
+            return seen[name][1]
+        op = g.made_by(t)
+        _need(op is not None, g.ops[0], '%s: no producer' % name)
+        _need(op.kind != 'HARD_SWISH', op, '%s: Hardswish activation (an older export): the kernels implement SiLU' % name)
+        _need(op.kind == 'MUL' and len(op.inputs) == 2, op, '%s: expected SiLU spelt x * LOGISTIC(x)' % name)
+        a, b = op.inputs
+        la, lb = g.made_by(a), g.made_by(b)
+        if lb is not None and lb.kind == 'LOGISTIC' and lb.inputs[0] == a:
+            pre = a
+        elif la is not None and la.kind == 'LOGISTIC' and la.inputs[0] == b:
+            pre = b
+        else:
+            _need(False, op, '%s: expected SiLU spelt x * LOGISTIC(x)' % name)
+        w, bias, src = raw_conv(name, g.made_by(pre), k, s)
+        wd[name + '/weights'], wd[name + '/biases'] = w, bias
+        seen[name] = (t, src)
+        return src
+
+    def cat_inputs(t, n, what):
+        op = g.made_by(t)
+        _need(op is not None and op.kind == 'CONCATENATION' and len(op.inputs) == n and op.options['axis'] in (3, -1), op or g.ops[0], 'expected the channel CONCATENATION of %s' % what)
+        return list(op.inputs)
+
+    def c3(name, t, n, shortcut):
+        cat = conv(name + '.cv3', t)
+        y, z = cat_inputs(cat, 2, name)
+        src2 = conv(name + '.cv2', z)
+        for i in reversed(range(n)):
+            if shortcut:
+                add = g.made_by(y)
+                _need(add is not None and add.kind == 'ADD' and len(add.inputs) == 2, add or g.ops[0], '%s.m%d: expected the shortcut ADD' % (name, i))
+                # one operand is the bottleneck's input, the other its cv2 output (which leads back to that input)
+                ok = False
+                for skip, branch in (add.inputs, add.inputs[::-1]):
+                    m = g.made_by(branch)
+                    if m is None or m.kind != 'MUL':
+                        continue
+                    mark = (dict(wd), dict(seen))
+                    try:
+                        h = conv('%s.m%d.cv2' % (name, i), branch, 3)
+                        if conv('%s.m%d.cv1' % (name, i), h) == skip:
+                            ok = True
+                            break
+                    except UnsupportedModel:
+                        pass
+                    wd.clear(); wd.update(mark[0]); seen.clear(); seen.update(mark[1])
+                _need(ok, add, '%s.m%d: the ADD does not join a bottleneck with its input' % (name, i))
+                y = skip
+            else:
+                y = conv('%s.m%d.cv1' % (name, i), conv('%s.m%d.cv2' % (name, i), y, 3))
+        src1 = conv(name + '.cv1', y)
+        _need(src1 == src2, g.made_by(t), '%s: cv1 and cv2 read different tensors' % name)
+        return src1
+
+    def upsample(t, what):
+        op = g.made_by(t)
+        _need(op is not None and op.kind == 'RESIZE_NEAREST_NEIGHBOR', op or g.ops[0], 'expected the 2x nearest-neighbour upsample of %s' % what)
+        sz = const(op.inputs[1])
+        src = g.tensors[op.inputs[0]]
+        _need(sz is not None and [int(v) for v in sz.reshape(-1)] == [2 * src.shape[1], 2 * src.shape[2]], op, 'upsample of %s to %s (2x is built)' % (src.shape, None if sz is None else sz.tolist()))
+        return op.inputs[0]
+
+    # ---- Detect: three branches concatenated along the rows
+    _need(len(out_t.shape) == 3 and out_t.shape[2] > 5, g.ops[-1], 'output %s (expected [1, rows, 5 + classes])' % (out_t.shape,))
+    no = int(out_t.shape[2])
+    top = g.made_by(out_t.index)
+    _need(top is not None and top.kind == 'CONCATENATION' and len(top.inputs) == 3 and top.options['axis'] == 1, top or g.ops[-1],
+          'expected the CONCATENATION of the three Detect layers along the rows (a file with NMS inside, or another head, is not built)')
+    feats = []
+    for i, z in enumerate(top.inputs):
+        # back along the first operands to the 1x1 CONV_2D with 3 * (5 + classes) outputs
+        t, hops, head = z, 0, None
+        while hops < 64:
+            op = g.made_by(t)
+            _need(op is not None, top, 'Detect branch %d does not start at a convolution' % i)
+            if op.kind == 'CONV_2D':
+                head = op
+                break
+            t = op.inputs[0]
+            if op.kind == 'CONCATENATION':                         # [xy, wh, rest]: any of them leads back
+                t = op.inputs[0]
+            hops += 1
+        _need(head is not None, top, 'Detect branch %d: no convolution within 64 operators' % i)
+        w, b, src = raw_conv('detect%d' % i, head, 1, 1)
+        _need(w.shape[3] == 3 * no, head, 'detect%d: %d output channels (3 anchors x %d)' % (i, w.shape[3], no))
+        hw = int(g.tensors[head.outputs[0]].shape[1])
+        _need(size % hw == 0 and g.tensors[head.outputs[0]].shape[2] == hw, head, 'detect%d: %s map' % (i, g.tensors[head.outputs[0]].shape))
+        stride = size // hw
+        # what the tail computes, on a probe: csrc/nets.hip's Detect epilogue restated (conv_epilogue, EPI_YOLO)
+        rng = np.random.default_rng(100 + i)
+        probe = rng.standard_normal((1, hw, hw, 3 * no)).astype(np.float32) * 2.0
+        ev = _Eval(g)
+        ev.vals[head.outputs[0]] = probe
+        got = ev.value(z)
+        s = 1.0 / (1.0 + np.exp(-probe.astype(np.float64).reshape(hw * hw, 3, no)))
+        gy, gx = np.meshgrid(np.arange(hw), np.arange(hw), indexing='ij')
+        grid = np.stack([gx, gy], axis=-1).reshape(hw * hw, 1, 2)
+        anc = np.array(YOLO_ANCHORS[i], np.float64).reshape(1, 3, 2)
+        want = s.copy()
+        want[..., 0:2] = (s[..., 0:2] * 2 - 0.5 + grid) * stride / size
+        want[..., 2:4] = (s[..., 2:4] * 2) ** 2 * anc / size
+        want = np.transpose(want, (1, 0, 2)).reshape(1, 3 * hw * hw, no)           # rows anchor-major inside a layer
+        _need(got.shape == want.shape and np.allclose(got, want, rtol=1e-4, atol=1e-5), head,
+              'detect%d: the operators behind this convolution do not compute the YOLOv5 box decode with anchors %s at stride %d' % (i, YOLO_ANCHORS[i], stride))
+        wd['detect%d/weights' % i], wd['detect%d/biases' % i] = w, b
+        feats.append(src)
+    p3, p4, p5 = feats
+    # ---- head and backbone, backwards (yolov5s.yaml:27-47, then :14-24)
+    m21, m10 = cat_inputs(c3('m23', p5, 1, False), 2, 'm22')
+    _need(conv('m21', m21, 3, 2) == p4, g.made_by(m21), 'm21 does not read the P4 output')
+    m18, m14 = cat_inputs(c3('m20', p4, 1, False), 2, 'm19')
+    _need(conv('m18', m18, 3, 2) == p3, g.made_by(m18), 'm18 does not read the P3 output')
+    u14, x4 = cat_inputs(c3('m17', p3, 1, False), 2, 'm16')
+    _need(upsample(u14, 'm14') == m14, g.made_by(u14), 'the P3 concatenation does not take the upsampled m14')
+    u10, x6 = cat_inputs(c3('m13', conv('m14', m14), 1, False), 2, 'm12')
+    _need(upsample(u10, 'm10') == m10, g.made_by(u10), 'the P4 concatenation does not take the upsampled m10')
+    spp_out = c3('m9', conv('m10', m10), 1, False)
+    pools = cat_inputs(conv('m8.cv2', spp_out), 4, 'SPP')
+    for j, k in enumerate((5, 9, 13)):
+        mp = g.made_by(pools[j + 1])
+        _need(mp is not None and mp.kind == 'MAX_POOL_2D' and mp.inputs[0] == pools[0] and mp.options['filter_w'] == mp.options['filter_h'] == k and
+              mp.options['stride_w'] == 1 and mp.options['padding'] == 'SAME', mp or g.ops[0], 'SPP: expected a SAME stride-1 %dx%d max pool of the cv1 output' % (k, k))
+    _need(conv('m7', conv('m8.cv1', pools[0]), 3, 2) == x6, g.made_by(pools[0]), 'm7 does not read the map the P4 concatenation takes (m6)')
+    _need(conv('m5', c3('m6', x6, 3, True), 3, 2) == x4, g.made_by(x6), 'm5 does not read the map the P3 concatenation takes (m4)')
+    focus_out = conv('m0.focus', conv('m1', c3('m2', conv('m3', c3('m4', x4, 3, True), 3, 2), 1, True), 3, 2), 3)
+    # ---- Focus: evaluated on an index image
+    probe = np.arange(8 * 8 * 3, dtype=np.float32).reshape(1, 8, 8, 3)
+    ev = _Eval(g)
+    ev.vals[g.inputs[0]] = probe
+    fop = g.made_by(focus_out)
+    _need(fop is not None, g.ops[0], 'the first convolution reads the graph input directly (no Focus slicing)')
+    got = ev.value(focus_out)
+    want = np.concatenate([probe[:, 0::2, 0::2], probe[:, 1::2, 0::2], probe[:, 0::2, 1::2], probe[:, 1::2, 1::2]], axis=3)
+    _need(got.shape == want.shape and np.array_equal(got, want), fop, 'the operators in front of the first convolution are not the Focus slicing (0,0) (1,0) (0,1) (1,1)')
+    # ---- the widths are yolov5s' (the kernels' program is compiled for them)
+    from .. import nets
+    for name, k, cin, cout in nets.yolov5s_convs():
+        _need(name + '/weights' in wd and wd[name + '/weights'].shape == (k, k, cin, cout), g.ops[0],
+              '%s: filter %s (YOLOv5s, width multiple 0.50, has %s)' % (name, wd.get(name + '/weights', np.zeros(0)).shape, (k, k, cin, cout)))
+    _need(no == 5 + nets.YOLO_NC, top, '%d values per row (80 classes are built)' % no)
+    wd['__in_size__'] = size
+    return wd

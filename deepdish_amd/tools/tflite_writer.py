@@ -10,9 +10,10 @@ from .. import nets
 
 TYPE_CODE = {np.dtype(np.float32): 0, np.dtype(np.float16): 1, np.dtype(np.int32): 2, np.dtype(np.uint8): 3, np.dtype(np.int64): 4, np.dtype(np.int8): 9}
 OP_CODE = {'DEQUANTIZE': 6, 'CONCATENATION': 2, 'CONV_2D': 3, 'DEPTHWISE_CONV_2D': 4, 'LOGISTIC': 14, 'RESHAPE': 22, 'CUSTOM': 32, 'MAX_POOL_2D': 17, 'ADD': 0,
-           'MUL': 18, 'FULLY_CONNECTED': 9, 'ELU': 111, 'REVERSE_V2': 105, 'SUM': 74, 'SQRT': 75, 'DIV': 42}
+           'MUL': 18, 'FULLY_CONNECTED': 9, 'ELU': 111, 'REVERSE_V2': 105, 'SUM': 74, 'SQRT': 75, 'DIV': 42, 'PAD': 34, 'TRANSPOSE': 39, 'SUB': 41,
+           'STRIDED_SLICE': 45, 'RESIZE_NEAREST_NEIGHBOR': 97, 'HARD_SWISH': 117}
 OPTIONS_TYPE = {'CONV_2D': 1, 'DEPTHWISE_CONV_2D': 2, 'CONCATENATION': 10, 'RESHAPE': 17, 'MAX_POOL_2D': 5, 'FULLY_CONNECTED': 8, 'ADD': 11, 'MUL': 21,
-                'DIV': 29, 'SUM': 27}
+                'DIV': 29, 'SUM': 27, 'SUB': 28, 'STRIDED_SLICE': 32, 'RESIZE_NEAREST_NEIGHBOR': 74}
 ACT = {'none': 0, 'relu': 1, 'relu6': 3}
 
 
@@ -41,7 +42,7 @@ class GraphWriter:
 
     def _options(self, b, kind, o):
         if kind == 'CONV_2D':
-            return b.table({0: ('i8', 0), 1: ('i32', o['stride']), 2: ('i32', o['stride']), 3: ('i8', ACT[o['act']]), 4: ('i32', 1), 5: ('i32', 1)})
+            return b.table({0: ('i8', 1 if o.get('padding', 'SAME') == 'VALID' else 0), 1: ('i32', o['stride']), 2: ('i32', o['stride']), 3: ('i8', ACT[o['act']]), 4: ('i32', 1), 5: ('i32', 1)})
         if kind == 'DEPTHWISE_CONV_2D':
             return b.table({0: ('i8', 0), 1: ('i32', o['stride']), 2: ('i32', o['stride']), 3: ('i32', 1), 4: ('i8', ACT[o['act']]), 5: ('i32', 1), 6: ('i32', 1)})
         if kind == 'CONCATENATION':
@@ -50,7 +51,11 @@ class GraphWriter:
             return b.table({0: ('offset', b.scalars(o['new_shape'], 'i32'))})
         if kind == 'MAX_POOL_2D':                 # Pool2DOptions: padding (1 = VALID), strides, filter, activation
             return b.table({0: ('i8', 1 if o.get('padding', 'VALID') == 'VALID' else 0), 1: ('i32', o['stride']), 2: ('i32', o['stride']), 3: ('i32', o['k']), 4: ('i32', o['k']), 5: ('i8', 0)})
-        if kind in ('ADD', 'MUL', 'DIV', 'FULLY_CONNECTED'):
+        if kind == 'STRIDED_SLICE':               # StridedSliceOptions: begin_mask, end_mask, ellipsis_mask, new_axis_mask, shrink_axis_mask
+            return b.table({0: ('i32', o.get('begin_mask', 0)), 1: ('i32', o.get('end_mask', 0)), 2: ('i32', 0), 3: ('i32', 0), 4: ('i32', 0)})
+        if kind == 'RESIZE_NEAREST_NEIGHBOR':     # ResizeNearestNeighborOptions: align_corners, half_pixel_centers
+            return b.table({0: ('bool', False), 1: ('bool', False), 2: ('i8', 0)})
+        if kind in ('ADD', 'MUL', 'DIV', 'SUB', 'FULLY_CONNECTED'):
             return b.table({0: ('i8', 0), 1: ('i8', 0)})      # (a second field so that the table is not empty: fused activation NONE)
         if kind == 'SUM':                         # ReducerOptions: keep_dims
             return b.table({0: ('bool', True), 1: ('i8', 0)})
@@ -270,6 +275,188 @@ def write_mars(wd, path, reverse_channels=True, half_weights=False):
 def write_ssd_mobilenet(model, path, anchors=None, post=None):
     """post: overrides of the TFLite_Detection_PostProcess options ({name: value}; None drops the key)."""
     data = ssd_mobilenet_graph(model, anchors, post=post).tobytes()
+    with open(path, 'wb') as f:
+        f.write(data)
+    return len(data)
+
+
+# ------------------------------------------------------------------------------------------- YOLOv5s
+def yolov5s_graph(wd, in_size=640, half_weights=False, activation='silu'):
+    """Named YOLOv5s weights (deepdish_amd/nets.synthetic_yolov5s_weights; batch norms raw or folded) -> GraphWriter of the graph as the
+    YOLOv5 TensorFlow export (models/tf.py of the YOLOv5 repository, which produced the reference's `detectors/yolov5/yolov5s-fp16.tflite`,
+    tools/yolov5.py:59-79 upstream) lays it out: Focus as four STRIDED_SLICEs + CONCATENATION, every Conv as [PAD +] CONV_2D with the batch
+    norm folded + SiLU spelt LOGISTIC + MUL, C3 / Bottleneck / SPP (MAX_POOL_2D 5 / 9 / 13, SAME) / RESIZE_NEAREST_NEIGHBOR / CONCATENATION
+    per detectors/yolov5/yolov5s.yaml:12-48, and Detect as RESHAPE + TRANSPOSE + LOGISTIC + the box arithmetic on slices, normalised by the
+    image size, the three layers concatenated to [1, 25200, 85].  half_weights: filters as float16 constants behind DEQUANTIZE (an fp16 file).
+    activation='hardswish' writes the older export's activation (a file the reader must refuse by name)."""
+    W = GraphWriter('YOLOv5s (float%s), written by deepdish_amd' % ('16 weights' if half_weights else '32'))
+    f32 = np.float32
+    x = W.tensor('input_1', [1, in_size, in_size, 3], f32)
+    W.inputs = [x]
+    cnt = [0]
+
+    def T(shape, name=None):
+        cnt[0] += 1
+        return W.tensor(name or 't%d' % cnt[0], shape, f32)
+
+    def const(name, arr, dtype=f32):
+        a = np.ascontiguousarray(arr, dtype=dtype)
+        return W.tensor(name, list(a.shape), dtype, a)
+
+    def filt(name, w_ohwi):
+        if half_weights:
+            h = const(name + '/weights_f16', w_ohwi, np.float16)
+            f = T(list(w_ohwi.shape), name + '/weights')
+            W.op('DEQUANTIZE', [h], [f])
+            return f
+        return const(name + '/weights', w_ohwi)
+
+    def act(t, shape):
+        out = T(shape)
+        if activation == 'hardswish':
+            W.op('HARD_SWISH', [t], [out])
+            return out
+        sg = T(shape)
+        W.op('LOGISTIC', [t], [sg])
+        W.op('MUL', [t, sg], [out])
+        return out
+
+    def conv_raw(name, src, hw, w_hwio, bias, k, s):
+        """Conv2D as models/tf.py TFConv: stride 1 -> SAME; stride 2 -> ZeroPadding2D(k // 2) + VALID."""
+        h = hw
+        cout = w_hwio.shape[3]
+        pad = 'SAME'
+        if s == 2:
+            padded = T([1, h + 2 * (k // 2), h + 2 * (k // 2), w_hwio.shape[2]])
+            W.op('PAD', [src, const(name + '/paddings', [[0, 0], [k // 2, k // 2], [k // 2, k // 2], [0, 0]], np.int32)], [padded])
+            src, pad = padded, 'VALID'
+            ho = (h + 2 * (k // 2) - k) // 2 + 1
+        else:
+            ho = h
+        out = T([1, ho, ho, cout], name)
+        W.op('CONV_2D', [src, filt(name, np.transpose(w_hwio, (3, 0, 1, 2))), const(name + '/bias', bias)], [out], dict(stride=s, act='none', padding=pad))
+        return out, ho
+
+    def cv(name, src, hw, k=1, s=1):
+        w, b = nets.fold_conv_bn(wd, name)
+        out, ho = conv_raw(name, src, hw, w, b, k, s)
+        return act(out, [1, ho, ho, w.shape[3]]), ho, w.shape[3]
+
+    def c3(name, src, hw, n, shortcut):
+        y, _, c_ = cv(name + '.cv1', src, hw)
+        for i in range(n):
+            h, _, _ = cv('%s.m%d.cv1' % (name, i), y, hw)
+            h, _, _ = cv('%s.m%d.cv2' % (name, i), h, hw, 3)
+            if shortcut:
+                a = T([1, hw, hw, c_])
+                W.op('ADD', [y, h], [a])
+                y = a
+            else:
+                y = h
+        z, _, _ = cv(name + '.cv2', src, hw)
+        cat = T([1, hw, hw, 2 * c_])
+        W.op('CONCATENATION', [y, z], [cat], dict(axis=3))
+        return cv(name + '.cv3', cat, hw)
+
+    def up(src, hw, c):
+        out = T([1, 2 * hw, 2 * hw, c])
+        W.op('RESIZE_NEAREST_NEIGHBOR', [src, const('size%d' % cnt[0], [2 * hw, 2 * hw], np.int32)], [out])
+        return out
+
+    def cat(a, b, hw, c):
+        out = T([1, hw, hw, c])
+        W.op('CONCATENATION', [a, b], [out], dict(axis=3))
+        return out
+
+    # Focus (models/tf.py TFFocus): x[:, ::2, ::2], x[:, 1::2, ::2], x[:, ::2, 1::2], x[:, 1::2, 1::2] along the channels
+    h2 = in_size // 2
+    sl = []
+    for (r0, c0) in ((0, 0), (1, 0), (0, 1), (1, 1)):
+        o = T([1, h2, h2, 3])
+        W.op('STRIDED_SLICE', [x, const('begin%d%d' % (r0, c0), [0, r0, c0, 0], np.int32), const('end%d%d' % (r0, c0), [0, 0, 0, 0], np.int32),
+                               const('strides%d%d' % (r0, c0), [1, 2, 2, 1], np.int32)], [o], dict(begin_mask=0b1001, end_mask=0b1111))
+        sl.append(o)
+    f = T([1, h2, h2, 12])
+    W.op('CONCATENATION', sl, [f], dict(axis=3))
+    t, hw, _ = cv('m0.focus', f, h2, 3)
+    t, hw, _ = cv('m1', t, hw, 3, 2); t, _, _ = c3('m2', t, hw, 1, True)
+    t, hw, _ = cv('m3', t, hw, 3, 2); x4, _, _ = c3('m4', t, hw, 3, True); hw4 = hw
+    t, hw, _ = cv('m5', x4, hw, 3, 2); x6, _, _ = c3('m6', t, hw, 3, True); hw6 = hw
+    t, hw, _ = cv('m7', x6, hw, 3, 2)
+    s1, _, c_ = cv('m8.cv1', t, hw)
+    pools = [s1]
+    for k in (5, 9, 13):
+        o = T([1, hw, hw, c_])
+        W.op('MAX_POOL_2D', [s1], [o], dict(k=k, stride=1, padding='SAME'))
+        pools.append(o)
+    sc = T([1, hw, hw, 4 * c_])
+    W.op('CONCATENATION', pools, [sc], dict(axis=3))
+    t, _, _ = cv('m8.cv2', sc, hw)
+    t, _, _ = c3('m9', t, hw, 1, False)
+    x10, _, c10 = cv('m10', t, hw); hw10 = hw
+    t = cat(up(x10, hw, c10), x6, hw6, c10 + 256)
+    t, _, _ = c3('m13', t, hw6, 1, False)
+    x14, _, c14 = cv('m14', t, hw6)
+    t = cat(up(x14, hw6, c14), x4, hw4, c14 + 128)
+    p3, _, _ = c3('m17', t, hw4, 1, False)
+    t, hw, _ = cv('m18', p3, hw4, 3, 2)
+    p4, _, _ = c3('m20', cat(t, x14, hw6, 256), hw6, 1, False)
+    t, hw, _ = cv('m21', p4, hw6, 3, 2)
+    p5, _, _ = c3('m23', cat(t, x10, hw10, 512), hw10, 1, False)
+    # Detect (models/tf.py TFDetect.call, inference branch)
+    no, na = 5 + nets.YOLO_NC, 3
+    zs, rows = [], 0
+    for i, (p, hwp) in enumerate(((p3, hw4), (p4, hw6), (p5, hw10))):
+        stride = in_size // hwp
+        o, _ = conv_raw('detect%d' % i, p, hwp, wd['detect%d/weights' % i], wd['detect%d/biases' % i], 1, 1)
+        r = T([1, hwp * hwp, na, no])
+        W.op('RESHAPE', [o, const('shape_a%d' % i, [1, hwp * hwp, na, no], np.int32)], [r], dict(new_shape=[1, hwp * hwp, na, no]))
+        tr = T([1, na, hwp * hwp, no])
+        W.op('TRANSPOSE', [r, const('perm%d' % i, [0, 2, 1, 3], np.int32)], [tr])
+        y = T([1, na, hwp * hwp, no])
+        W.op('LOGISTIC', [tr], [y])
+
+        def piece(lo, hi, width):
+            o_ = T([1, na, hwp * hwp, width])
+            W.op('STRIDED_SLICE', [y, const('b%d_%d' % (i, lo), [0, 0, 0, lo], np.int32), const('e%d_%d' % (i, lo), [0, 0, 0, hi], np.int32),
+                                   const('s%d_%d' % (i, lo), [1, 1, 1, 1], np.int32)], [o_], dict(begin_mask=0b0111, end_mask=0b0111 if hi else 0b1111))
+            return o_
+
+        def binop(kind, a, bconst, width, name):
+            o_ = T([1, na, hwp * hwp, width])
+            W.op(kind, [a, bconst], [o_])
+            return o_
+
+        gy, gx = np.meshgrid(np.arange(hwp), np.arange(hwp), indexing='ij')
+        grid = np.stack([gx, gy], axis=-1).reshape(1, 1, hwp * hwp, 2).astype(np.float32)
+        anchors = np.array(nets.YOLO_ANCHORS[i], np.float32).reshape(1, na, 1, 2)
+        xy = piece(0, 2, 2)
+        xy = binop('MUL', xy, const('two%d' % i, [2.0]), 2, 'xy2')
+        xy = binop('SUB', xy, const('half%d' % i, [0.5]), 2, 'xyh')
+        xy = binop('ADD', xy, const('grid%d' % i, grid), 2, 'xyg')
+        xy = binop('MUL', xy, const('stride%d' % i, [float(stride)]), 2, 'xys')
+        xy = binop('DIV', xy, const('imgsz_xy%d' % i, [[float(in_size), float(in_size)]]), 2, 'xyn')
+        wh = piece(2, 4, 2)
+        wh = binop('MUL', wh, const('two_b%d' % i, [2.0]), 2, 'wh2')
+        whs = T([1, na, hwp * hwp, 2])
+        W.op('MUL', [wh, wh], [whs])
+        wh = binop('MUL', whs, const('anchor_grid%d' % i, anchors), 2, 'wha')
+        wh = binop('DIV', wh, const('imgsz_wh%d' % i, [[float(in_size), float(in_size)]]), 2, 'whn')
+        rest = piece(4, 0, no - 4)
+        yc = T([1, na, hwp * hwp, no])
+        W.op('CONCATENATION', [xy, wh, rest], [yc], dict(axis=3))
+        z = T([1, na * hwp * hwp, no])
+        W.op('RESHAPE', [yc, const('shape_b%d' % i, [1, na * hwp * hwp, no], np.int32)], [z], dict(new_shape=[1, na * hwp * hwp, no]))
+        zs.append(z)
+        rows += na * hwp * hwp
+    out = T([1, rows, no], 'Identity')
+    W.op('CONCATENATION', zs, [out], dict(axis=1))
+    W.outputs = [out]
+    return W
+
+
+def write_yolov5s(wd, path, in_size=640, half_weights=False, activation='silu'):
+    data = yolov5s_graph(wd, in_size, half_weights, activation).tobytes()
     with open(path, 'wb') as f:
         f.write(data)
     return len(data)

@@ -28,9 +28,9 @@ def load_named_weights(model_file, synthetic_fn):
             return {k: z[k] for k in z.files}
     hint = ''
     if name.endswith('.tflite'):
-        hint = (' A .tflite file is parsed by deepdish_amd/tools/tflite_reader.py (tensors, buffers, quantisation, operators); only the '
-                'SSD-MobileNet-v1 detector (tools/weights_io.load_ssd_model) and the MARS encoder (load_mars_weights) graphs are mapped onto programs '
-                'so far -- YOLOv5 graphs are not.')
+        hint = (' A .tflite file is parsed by deepdish_amd/tools/tflite_reader.py (tensors, buffers, quantisation, operators); the '
+                'SSD-MobileNet-v1 detector (tools/weights_io.load_ssd_model), the MARS encoder (load_mars_weights) and the YOLOv5s detector '
+                '(load_yolov5_weights) graphs are mapped onto programs; this path was asked for a model kind that takes none of them.')
     elif name.endswith('.pb'):
         hint = ' Frozen TensorFlow graphs (.pb) are read for the MARS encoder only (tools/graphdef.py, tools/generate_detections.py:118-148 upstream).'
     raise FileNotFoundError(
@@ -50,6 +50,17 @@ def load_mars_weights(model_file):
         from . import graphdef
         return graphdef.load_mars(name)[0]                       # '__in_hw__' carries the crop size its placeholder states
     return load_named_weights(model_file, nets.synthetic_mars_weights)
+
+
+def load_yolov5_weights(model_file):
+    """What the YOLOv5 plugins call: a `.tflite` file on disk goes through tools/tflite_reader.load_yolov5s (the reference's
+    `detectors/yolov5/yolov5s-fp16.tflite`, tools/yolov5.py:59-79), anything else through load_named_weights."""
+    from .. import nets
+    name = str(model_file)
+    if name.endswith('.tflite') and os.path.exists(name):
+        from . import tflite_reader
+        return tflite_reader.load_yolov5s(name)
+    return load_named_weights(model_file, nets.synthetic_yolov5s_weights)
 
 
 def load_ssd_model(model_file):

@@ -12,7 +12,7 @@ from .._lib import lib, check
 from ..runtime import default_context, ptr
 from .. import nets
 from ..engine import Net
-from .weights_io import load_named_weights
+from .weights_io import load_named_weights, load_yolov5_weights
 
 
 class YOLOV5:
@@ -35,9 +35,11 @@ class YOLOV5:
         self.num_threads = num_threads
         self.mode = 'hip'
         self.ctx = context or default_context()
-        wd = load_named_weights(model_file, nets.synthetic_yolov5s_weights)
+        if 'int8' in str(model_file) and str(model_file).endswith('.tflite') and os.path.exists(str(model_file)):
+            raise ValueError('%s: the int8 YOLOv5 file (tools/yolov5.py:61,102-104,115-118 upstream) is not built; the float / fp16-weight file is' % model_file)
+        wd = load_yolov5_weights(model_file)                     # <file>.tflite (yolov5.py:68-79), .npz of named arrays, or synthetic[:seed]
         self.weights = wd
-        prog = nets.compile_yolov5s(wd)
+        prog = nets.compile_yolov5s(wd, int(wd.get('__in_size__', 640)))
         self.net = Net(prog, max_batch=1, context=self.ctx)
         self.height = self.width = prog.in_h
         self.anchors = nets.YOLO_ANCHORS

@@ -223,3 +223,27 @@ def test_yolo_heads_reduce_rows_in_their_epilogue(n):
     net.yolo_decode(False)
     net.forward(xd)
     np.testing.assert_array_equal(np.asarray(net.read(), dtype=np.float32).reshape(n, -1, 85), raw)
+
+
+def test_yolov5_plugin_loads_a_tflite_file(tmp_path):
+    """YOLOV5(model_file='.../yolov5s-fp16.tflite') as deepdish.py:482-491 constructs it: the detector written to disk in the interchange
+    format (export-shaped graph, float16 filters behind DEQUANTIZE) gives, bit for bit, the detections of the same weights handed over as
+    named arrays (tools/tflite_reader.load_yolov5s), also through the batched pipeline."""
+    import torch
+    from deepdish_amd import nets
+    from deepdish_amd.tools import tflite_writer
+    from deepdish_amd.tools.yolov5 import YOLOV5
+    from deepdish_amd.pipeline import DEFAULT_YOLO_LABELS
+    from deepdish_amd.synth import Scene
+    wd = nets.synthetic_yolov5s_weights(1234)
+    path = str(tmp_path / 'yolov5s-fp16.tflite')
+    tflite_writer.write_yolov5s(wd, path, half_weights=True)
+    wanted = sorted({l.strip() for l in open(DEFAULT_YOLO_LABELS)})
+    a = YOLOV5(wanted_labels=wanted, model_file=path, label_file=DEFAULT_YOLO_LABELS)
+    b = YOLOV5(wanted_labels=wanted, model_file='synthetic-yolov5s', label_file=DEFAULT_YOLO_LABELS)
+    frame = Scene(seed=3, n_obj=8).frame(0)
+    ra = a.detect_frame_device(torch.from_numpy(frame).cuda(), 480, 640)
+    rb = b.detect_frame_device(torch.from_numpy(frame).cuda(), 480, 640)
+    assert ra[1] == rb[1] and len(ra[1]) > 0
+    np.testing.assert_array_equal(np.asarray(ra[0]), np.asarray(rb[0]))
+    np.testing.assert_array_equal(np.asarray(ra[2]), np.asarray(rb[2]))

@@ -211,3 +211,51 @@ def test_mars_reader_refuses_other_graphs_by_name(tmp_path, golden_dir):
     with pytest.raises(R.UnsupportedModel) as e:
         R.load_mars(p)
     assert '15 convolutions' in str(e.value)
+
+
+def test_yolov5s_round_trip_and_refusals(tmp_path):
+    """nets weights -> export-shaped .tflite (float32 and float16 filters) -> load_yolov5s -> the same compiled program; graphs that
+    compute something else are refused by operator: Hardswish, other anchors in the Detect tail, another Focus order, an int8 input."""
+    from deepdish_amd import nets
+    from deepdish_amd.tools import tflite_writer, tflite_reader
+    from deepdish_amd.tools.weights_io import load_yolov5_weights
+    wd = nets.synthetic_yolov5s_weights(3)
+    want = bytes(nets.compile_yolov5s(wd).blob)
+    path = str(tmp_path / 'yolov5s-fp32.tflite')
+    tflite_writer.write_yolov5s(wd, path)
+    got = load_yolov5_weights(path)                                # what YOLOV5(model_file=...) calls
+    assert got['__in_size__'] == 640 and bytes(nets.compile_yolov5s(got).blob) == want
+    # an fp16 file: the filters are float16 constants behind DEQUANTIZE; the program keeps f16 weights anyway, so the blob is the same
+    path16 = str(tmp_path / 'yolov5s-fp16.tflite')
+    tflite_writer.write_yolov5s(wd, path16, half_weights=True)
+    got16 = load_yolov5_weights(path16)
+    for name, k, cin, cout in nets.yolov5s_convs():
+        np.testing.assert_array_equal(got16[name + '/weights'], got[name + '/weights'].astype(np.float16).astype(np.float32), err_msg=name)
+    assert bytes(nets.compile_yolov5s(got16).blob) == want
+    tflite_writer.write_yolov5s(wd, path, activation='hardswish')
+    with pytest.raises(tflite_reader.UnsupportedModel) as e:
+        tflite_reader.load_yolov5s(path)
+    assert 'HARD_SWISH' in str(e.value) or 'Hardswish' in str(e.value)
+    old = nets.YOLO_ANCHORS
+    try:                                                            # a file whose Detect tail carries other anchors: the numeric check catches it
+        nets.YOLO_ANCHORS = [[12, 13, 16, 30, 33, 23]] + [list(a) for a in old[1:]]
+        tflite_writer.write_yolov5s(wd, path)
+    finally:
+        nets.YOLO_ANCHORS = old
+    with pytest.raises(tflite_reader.UnsupportedModel) as e:
+        tflite_reader.load_yolov5s(path)
+    assert 'detect0' in str(e.value) and 'box decode' in str(e.value)
+    # another slicing order in front of the first convolution
+    g = tflite_writer.yolov5s_graph(wd)
+    cat = next(o for o in g.ops if o['kind'] == 'CONCATENATION')
+    cat['inputs'][1], cat['inputs'][2] = cat['inputs'][2], cat['inputs'][1]
+    open(path, 'wb').write(g.tobytes())
+    with pytest.raises(tflite_reader.UnsupportedModel) as e:
+        tflite_reader.load_yolov5s(path)
+    assert 'Focus' in str(e.value)
+    # a narrower model (the filters of m1 cut): named
+    wd2 = dict(wd)
+    with pytest.raises(Exception):
+        wd2['m1/weights'] = wd['m1/weights'][:, :, :, :32]
+        tflite_writer.write_yolov5s(wd2, path)
+        tflite_reader.load_yolov5s(path)
