@@ -21,3 +21,19 @@ enum { MARS_WS_S1 = 0, MARS_WS_S1_RES = 1, MARS_WS_S2_PROJ = 2 };
 
 // mode: MARS_WS_*; act: ACT_* of nets.hip (0 none, 2 ELU) applied to the main output before the residual; out2: mode 1 only
 int mars_ws128_launch(hipStream_t s, int device, const MarsWsP &P, int mode, int act, bool out2);
+
+// ---- conv3_x: two layers per launch (csrc/mars_pair.hip)
+struct MarsPairP {
+    const _Float16 *in;  int cs_in, coff_in;        // first = true: the block's pre-activation [n][31][15][32]; else [n][16][8][64]
+    const _Float16 *in2; int cs_in2, coff_in2;      // first = true: the raw block input (what the 1x1 stride-2 projection reads)
+    const _Float16 *wa;  int kpad_a; const float *bias_a;       // stage A: 3x3 (stride 2, 32 -> 64 | stride 1, 64 -> 64) + ELU
+    const _Float16 *wp;  int kpad_p; const float *bias_p;       // first = true: the projection [64][kpad_p]
+    const _Float16 *wb;  int kpad_b; const float *bias_b;       // stage B: 3x3 64 -> 64, no activation, + residual
+    const _Float16 *res; int cs_res, coff_res;      // first = false: the residual tensor [n][16][8][64] (first: the projection, kept on chip)
+    _Float16 *out;  int cs_out, coff_out;
+    _Float16 *out2; int cs_out2, coff_out2;         // ELU(scale * v + shift): aff2 = [2][cout_pad] f32
+    const float *aff2; int cout_pad;
+    const _Float16 *zero;
+    int n_img;
+};
+int mars_pair64_launch(hipStream_t s, int device, const MarsPairP &P, bool first);

@@ -31,7 +31,7 @@ enum { OP_INPUT = 1, OP_CONV = 2, OP_DWCONV = 3, OP_MAXPOOL = 4, OP_UPSAMPLE = 5
 enum { ACT_NONE = 0, ACT_RELU6 = 1, ACT_ELU = 2, ACT_SILU = 3, ACT_RELU = 4, ACT_SIGMOID = 5 };
 enum { EPI_F16 = 0, EPI_F32 = 1, EPI_SSD_HEAD = 2, EPI_YOLO = 3 };
 // dd_net_op_launches: 0 = the op's own kernel, 1 = no launch (folded into the next op's), else the fused / special kernel
-enum { OPK_DEFAULT = 0, OPK_FOLDED = 1, OPK_POOL_ROWS = 2, OPK_POOL_ROWS_STEM = 3, OPK_RES_UNIT = 4, OPK_SSD_FRONT = 5, OPK_C64_ROWS = 6, OPK_S2_ROWS = 7, OPK_CONV_WS = 8, OPK_WS_DW = 9, OPK_DWPW_ROWS = 10, OPK_SSD_HEAD_DEC = 11, OPK_RES_PAIR = 12, OPK_YOLO_HEAD_DEC = 13, OPK_MARS_WS = 14, OPK_FOLDED_PREV = 15 };
+enum { OPK_DEFAULT = 0, OPK_FOLDED = 1, OPK_POOL_ROWS = 2, OPK_POOL_ROWS_STEM = 3, OPK_RES_UNIT = 4, OPK_SSD_FRONT = 5, OPK_C64_ROWS = 6, OPK_S2_ROWS = 7, OPK_CONV_WS = 8, OPK_WS_DW = 9, OPK_DWPW_ROWS = 10, OPK_SSD_HEAD_DEC = 11, OPK_RES_PAIR = 12, OPK_YOLO_HEAD_DEC = 13, OPK_MARS_WS = 14, OPK_FOLDED_PREV = 15, OPK_MARS_PAIR = 16 };
 enum { DT_F16 = 0, DT_F32 = 1, DT_U8 = 2 };
 
 constexpr int OP_WORDS = 48;       // int32 words per op record (see deepdish_amd/nets.py)
@@ -4062,6 +4062,57 @@ bool mars_proj_follows(const dd_net *net, int i, const ConvP &P) {   // op i + 1
     const TensorDesc &qs = net->tensors[q[1]], &qd = net->tensors[q[2]];
     return qs.h == 16 && qs.w == 8 && qd.h == 8 && qd.w == 4 && qs.cs % 8 == 0 && qs.coff % 8 == 0 && qd.cs % 8 == 0 && qd.coff % 8 == 0 && qd.dtype == DT_F16;
 }
+// MARS conv3_x blocks as one launch each (csrc/mars_pair.hip), from DD_MARS_PAIR_MIN crops (default 256; the same bits as the layer-by-layer
+// kernels, so a crop's feature does not depend on which ran).  Ops i .. i + n - 1 must be: [3x3 stride-2 32 -> 64 ELU on a 31x15 map; 1x1
+// stride-2 projection of another 31x15 tensor;] or [3x3 64 -> 64 ELU on 16x8;] then 3x3 64 -> 64, no activation, residual = the projection /
+// a 16x8x64 tensor, second output with its affine.  Returns the number of ops (3 or 2) and fills Q, or 0.
+int mars_pair_match(const dd_net *net, int i, int nimg, char *const *bufs, MarsPairP &Q, bool &first) {
+    static const bool off = getenv("DD_MARS_PAIR") && atoi(getenv("DD_MARS_PAIR")) == 0;
+    static const int min_crops = getenv("DD_MARS_PAIR_MIN") ? atoi(getenv("DD_MARS_PAIR_MIN")) : 256;
+    if (off || nimg < min_crops) return 0;
+    auto op = [&](int k) { return net->prog.data() + net->ops_off + (size_t)k * OP_WORDS; };
+    auto W = [&](const int32_t *o, int word) { return net->d_weights + (size_t)(uint32_t)o[word]; };
+    auto conv3 = [&](const int32_t *o, int stride, int cin, int act) {
+        return o[0] == OP_CONV && o[5] == 3 && o[6] == 3 && o[7] == stride && o[10] == cin && o[11] == 64 && o[12] == 64 && o[14] == act && o[15] == EPI_F16 &&
+               o[8] == 1 && o[9] == 1 && o[13] >= 9 * cin && o[1] >= 0 && o[2] >= 0 && !o[29];
+    };
+    auto t16x8 = [&](int t, int c) { const TensorDesc &d = net->tensors[t]; return d.h == 16 && d.w == 8 && d.c == c && d.cs % 8 == 0 && d.coff % 8 == 0 && d.dtype == DT_F16; };
+    auto t31x15 = [&](int t) { const TensorDesc &d = net->tensors[t]; return d.h == 31 && d.w == 15 && d.c == 32 && d.cs % 8 == 0 && d.coff % 8 == 0 && d.dtype == DT_F16; };
+    memset(&Q, 0, sizeof(Q));
+    const int32_t *a = op(i);
+    int nb;                                                       // index of the block's second layer
+    if (i + 2 < net->n_ops && a[30] == 3 && conv3(a, 2, 32, ACT_ELU) && a[3] < 0 && a[4] < 0 && t31x15(a[1]) && t16x8(a[2], 64)) {
+        const int32_t *p = op(i + 1);
+        if (!(p[30] == 4 && p[0] == OP_CONV && p[5] == 1 && p[6] == 1 && p[7] == 2 && p[8] == 0 && p[9] == 0 && p[10] == 32 && p[11] == 64 && p[12] == 64 &&
+              p[14] == ACT_NONE && p[15] == EPI_F16 && p[3] < 0 && p[4] < 0 && p[13] >= 32 && p[1] >= 0 && p[2] >= 0 && t31x15(p[1]) && t16x8(p[2], 64))) return 0;
+        first = true; nb = i + 2;
+        const TensorDesc &ti = net->tensors[a[1]], &tr = net->tensors[p[1]];
+        Q.in = reinterpret_cast<const _Float16 *>(bufs[ti.buf]); Q.cs_in = ti.cs; Q.coff_in = ti.coff;
+        Q.in2 = reinterpret_cast<const _Float16 *>(bufs[tr.buf]); Q.cs_in2 = tr.cs; Q.coff_in2 = tr.coff;
+        Q.wp = reinterpret_cast<const _Float16 *>(W(p, 16)); Q.kpad_p = p[13]; Q.bias_p = reinterpret_cast<const float *>(W(p, 17));
+        const int32_t *b = op(nb);
+        if (b[3] != p[2]) return 0;                               // the second layer adds the projection
+    } else if (i + 1 < net->n_ops && a[30] == 4 && conv3(a, 1, 64, ACT_ELU) && a[3] < 0 && a[4] < 0 && t16x8(a[1], 64) && t16x8(a[2], 64)) {
+        first = false; nb = i + 1;
+        const TensorDesc &ti = net->tensors[a[1]];
+        Q.in = reinterpret_cast<const _Float16 *>(bufs[ti.buf]); Q.cs_in = ti.cs; Q.coff_in = ti.coff;
+        const int32_t *b = op(nb);
+        if (b[3] < 0 || !t16x8(b[3], 64)) return 0;
+        const TensorDesc &tr = net->tensors[b[3]];
+        Q.res = reinterpret_cast<const _Float16 *>(bufs[tr.buf]); Q.cs_res = tr.cs; Q.coff_res = tr.coff;
+    } else return 0;
+    const int32_t *b = op(nb);
+    if (!(conv3(b, 1, 64, ACT_NONE) && b[1] == a[2] && b[3] >= 0 && b[4] >= 0 && b[19] && t16x8(b[2], 64) && t16x8(b[4], 64))) return 0;
+    Q.wa = reinterpret_cast<const _Float16 *>(W(a, 16)); Q.kpad_a = a[13]; Q.bias_a = reinterpret_cast<const float *>(W(a, 17));
+    Q.wb = reinterpret_cast<const _Float16 *>(W(b, 16)); Q.kpad_b = b[13]; Q.bias_b = reinterpret_cast<const float *>(W(b, 17));
+    const TensorDesc &to = net->tensors[b[2]], &t2 = net->tensors[b[4]];
+    Q.out = reinterpret_cast<_Float16 *>(bufs[to.buf]); Q.cs_out = to.cs; Q.coff_out = to.coff;
+    Q.out2 = reinterpret_cast<_Float16 *>(bufs[t2.buf]); Q.cs_out2 = t2.cs; Q.coff_out2 = t2.coff;
+    Q.aff2 = reinterpret_cast<const float *>(W(b, 18)); Q.cout_pad = b[12];
+    Q.zero = net->d_zero; Q.n_img = nimg;
+    return nb - i + 1;
+}
+
 MarsWsP mars_ws_params(const ConvP &P, int nimg) {
     MarsWsP Q;
     memset(&Q, 0, sizeof(Q));
@@ -4507,6 +4558,9 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
     ConvP pw_p;                                                   // pointwise layer whose only reader is the next (depthwise) op
     bool pw_pending = false;
     bool proj_done = false;                                       // the previous op's launch also ran this op (a 1x1 stride-2 projection)
+    MarsPairP pair64;                                             // a conv3_x block whose ops run as one launch at its last op (mars_pair64_k)
+    bool pair64_first = false;
+    int pair_left = 0;
     ConvP pair_a, pair_b;                                         // a whole residual unit held back: it may run with the next unit (res_pair_rows_k)
     bool pair_pending = false;
     int pair_op = -1;
@@ -4567,6 +4621,19 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
             }
             case OP_CONV: {
                 if (proj_done) { proj_done = false; net->op_launch[i] = OPK_FOLDED_PREV; break; }
+                if (pair_left > 0) {                               // inside a conv3_x block that runs as one launch: at its last op
+                    if (--pair_left > 0) { net->op_launch[i] = OPK_FOLDED; break; }
+                    const int rc = mars_pair64_launch(s, net->ctx->device, pair64, pair64_first);
+                    if (rc != DD_OK) return rc;
+                    net->op_launch[i] = OPK_MARS_PAIR;
+                    break;
+                }
+                if (o[30] == 3 || o[30] == 4) {
+                    std::vector<char *> bp(net->bufs.size());
+                    for (size_t b = 0; b < bp.size(); ++b) bp[b] = static_cast<char *>(net->bufs[b]);
+                    const int n_ops = mars_pair_match(net, i, nimg, bp.data(), pair64, pair64_first);
+                    if (n_ops) { pair_left = n_ops - 1; net->op_launch[i] = OPK_FOLDED; break; }
+                }
                 ConvP P;
                 memset(&P, 0, sizeof(P));
                 P.in = reinterpret_cast<const _Float16 *>(base(src)); P.H = ts->h; P.W = ts->w; P.cs_in = ts->cs;

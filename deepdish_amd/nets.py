@@ -46,6 +46,7 @@ class Program:
     STEM_POOL_FUSE = os.environ.get('DD_STEM_POOL_FUSE', '1') != '0'   # MARS conv1_1 folded into conv1_2's launch
     RES_UNIT_FUSE = os.environ.get('DD_RES_UNIT_FUSE', '1') != '0'     # MARS conv2_x: both 3x3 layers of a residual unit in one launch
     RES_PAIR_FUSE = os.environ.get('DD_RES_PAIR_FUSE', '1') != '0'     # ... and the two units of the stage in one launch (res_pair_rows_k)
+    PAIR64_FUSE = os.environ.get('DD_PAIR64_FUSE', '1') != '0'         # MARS conv3_x: both 3x3 layers of a block (and its projection) in one launch (csrc/mars_pair.hip)
     PROJ_FUSE = os.environ.get('DD_PROJ_FUSE', '1') != '0'             # MARS widening blocks: 3x3 stride-2 layer + 1x1 stride-2 projection in one launch
     SSD_FRONT_FUSE = os.environ.get('DD_SSD_FRONT_FUSE', '1') != '0'   # SSD conv0 + MobileNet block 1 in one launch
     PW_DW_FUSE = os.environ.get('DD_PW_DW_FUSE', '1') != '0'           # MobileNet: pointwise layer + the next block's depthwise layer in one launch
@@ -433,6 +434,11 @@ def compile_mars(wd, in_h=64, in_w=32):
         else:
             skip = raw
         nxt = MARS_BLOCKS[i + 1][0] if i + 1 < len(MARS_BLOCKS) else None
+        if Program.PAIR64_FUSE and c == 64 and nxt is not None:
+            # conv3_x: h1 (and the projection) are read by conv "2" only -- with enough crops the block's layers run as ONE launch
+            # (csrc/mars_pair.hip) and neither tensor is written.  Marks the op in front of conv "2"; the widening block's stride-2 layer
+            # already carries the projection marker (3), which chains it to the projection for the buffer lifetimes.
+            P.ops[-1][30] = 4
         s = P.T(h1)
         out = P.tensor(s['h'], s['w'], c)
         if nxt is not None:          # the next block's BN+ELU pre-activation is a second epilogue output (:17-21)

@@ -37,7 +37,12 @@ def test_mars_batch_of_1280_is_crop_independent():
         np.testing.assert_array_equal(net.read()[0, 0, 0, :], full[i])
 
 
-@pytest.mark.parametrize('n', [159, 160, 170, 511, 512, 800, 1023, 1024, 1030, 1600, 2100])
+def net_op_launches_(net):
+    from deepdish_amd.profile import net_op_launches
+    return net_op_launches(net)
+
+
+@pytest.mark.parametrize('n', [159, 160, 170, 255, 256, 257, 511, 512, 800, 1023, 1024, 1030, 1600, 2100])
 def test_mars_first_layers_give_the_same_bits_in_every_launch_shape(n):
     """conv1_1 + conv1_2 + pool: below 160 crops two launches (stem_conv3_k, tiled conv3x3_rw_k<POOL>), from 160 one
     launch of one wave per row range (conv3x3_pool_rows_k<STEM>, 4 / 2 / 1 units per crop by batch size); a program
@@ -68,8 +73,11 @@ def test_mars_first_layers_give_the_same_bits_in_every_launch_shape(n):
     finally:
         nets.Program.STEM_POOL_FUSE, nets.Program.RES_UNIT_FUSE = old
     assert net2.program.ops[0][30] == 0 and not any(op[30] in (1, 2) for op in net2.program.ops)
-    # conv1_1, conv2_1/1, conv2_1/2 (pair), conv2_3/1; 3 = the stride-2 layers of conv3_1 / conv4_1, whose projection may share their launch
-    assert [int(op[30]) for op in net.program.ops if op[30]] == [1, 1, 2, 1, 3, 3]
+    # conv1_1, conv2_1/1, conv2_1/2 (pair), conv2_3/1; 3 = the stride-2 layers of conv3_1 / conv4_1, whose projection may share their launch;
+    # 4 = conv3_1's projection and conv3_3/1: with enough crops a conv3_x block is one launch (mars_pair64_k)
+    assert [int(op[30]) for op in net.program.ops if op[30]] == [1, 1, 2, 1, 3, 4, 4, 3]
+    net.forward(x)
+    assert (16 in [int(c) for c in net_op_launches_(net)]) == (n >= 256)              # 16 = mars_pair64_k
     from deepdish_amd.profile import net_op_launches
     net.forward(x)
     assert (12 in [int(c) for c in net_op_launches(net)]) == (n >= 1024)         # 12 = res_pair_rows_k
