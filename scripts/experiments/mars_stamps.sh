@@ -5,7 +5,7 @@ set -e
 N=${1:-7680}
 OBJ=deepdish_amd/csrc/_obj
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -I include -mllvm -amdgpu-mfma-vgpr-form -DDD_MARS_STAMPS -x hip -c deepdish_amd/csrc/mars_tail.hip -o /tmp/mars_tail_stamps.o
-OBJS=$(ls $OBJ/*.o | grep -v mars_tail)
+OBJS=$(ls $OBJ/*.o | grep -v mars_tail.hip)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o gpurun_out/libdd_stamps.so $OBJS /tmp/mars_tail_stamps.o
 DD_LIB=$PWD/gpurun_out/libdd_stamps.so python3 - <<PY
 import sys, os
