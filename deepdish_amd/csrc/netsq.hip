@@ -1568,6 +1568,7 @@ int netq_run_op(dd_net *net, int i, const int32_t *o, const uint8_t *input, int 
                 if (P.R.lo == 0 && P.R.hi == 255) hipLaunchKernelGGL((q_dwm_k<true>), dim3((unsigned)((n_items + 3) / 4)), dim3(256), 0, s, Q, (int)n_items);
                 else hipLaunchKernelGGL((q_dwm_k<false>), dim3((unsigned)((n_items + 3) / 4)), dim3(256), 0, s, Q, (int)n_items);
                 DD_LAUNCH_CHECK();
+                if (i < (int)net->op_launch.size()) net->op_launch[i] = 17;      // dd_net_op_launches: q_dwm_k ran (a layer table prints the kernel that ran, not the op's default)
                 return DD_OK;
             }
             hipLaunchKernelGGL(q_dw_k, dim3((unsigned)((P.total + 255) / 256)), dim3(256), 0, s, P);

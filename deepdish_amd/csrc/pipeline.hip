@@ -431,8 +431,11 @@ int flush_stage_events(dd_pipeline *p) {
     }
     return DD_OK;
 }
-#define DD_STAGE_BEGIN(k) DD_HIP(hipEventRecord(p->ev_main[2 * (k)], s))
-#define DD_STAGE_END(k) do { DD_HIP(hipEventRecord(p->ev_main[2 * (k) + 1], s)); p->ev_pair[k] = true; } while (0)
+// DD_STAGE_EVENTS=0: no stage events (dd_pipeline_stage_gpu_ms then reports zeros for the GPU stages); fourteen event records and seven
+// reads per step are ~10 us of host time -- noise against a multi-millisecond batched step, a few % of a single stream's 0.45 ms frame
+static const bool g_stage_events = !(getenv("DD_STAGE_EVENTS") && atoi(getenv("DD_STAGE_EVENTS")) == 0);
+#define DD_STAGE_BEGIN(k) do { if (g_stage_events) DD_HIP(hipEventRecord(p->ev_main[2 * (k)], s)); } while (0)
+#define DD_STAGE_END(k) do { if (g_stage_events) { DD_HIP(hipEventRecord(p->ev_main[2 * (k) + 1], s)); p->ev_pair[k] = true; } } while (0)
 #define DD_TIMED_WAIT(expr) do { const double w0_ = now_s(); DD_HIP(expr); p->step_wait += now_s() - w0_; } while (0)
 
 int enqueue_detector(dd_pipeline *p, const uint8_t *frames) {
@@ -443,7 +446,7 @@ int enqueue_detector(dd_pipeline *p, const uint8_t *frames) {
     // upload of these frames)
     DD_HIP(hipEventRecord(p->main_mark, p->ctx->stream));
     DD_HIP(hipStreamWaitEvent(s, p->main_mark, 0));
-    DD_HIP(hipEventRecord(p->ev_det[0], s));
+    if (g_stage_events) DD_HIP(hipEventRecord(p->ev_det[0], s));
     if (p->det_kind == DET_TFLITE) {                           // tflite_object_detector.py:207-211: cv2.resize (INTER_LINEAR) of the RGB frame
         if ((rc = ddk::crop_resize(s, frames, p->H, p->W, p->d_tfl_boxes.p, S, p->det_in, p->det_in_w, p->d_resized.as<uint8_t>())) != DD_OK) return rc;
     } else if ((rc = ddk::resize_lanczos(s, p->ctx->device, frames, p->H, p->W, 3, 1, p->d_resized.as<uint8_t>(), p->det_in,
@@ -469,7 +472,7 @@ int enqueue_detector(dd_pipeline *p, const uint8_t *frames) {
         const size_t head = ((size_t)S * 4 + 63) / 64 * 64;
         DD_HIP(hipMemcpyAsync(p->h_fin.p, yn, (size_t)S * 4, hipMemcpyDeviceToHost, s));
         DD_HIP(hipMemcpyAsync(p->h_fin.as<char>() + head, p->d_pack.p, p->yolo_host_rows * 24, hipMemcpyDeviceToHost, s));
-        DD_HIP(hipEventRecord(p->ev_det[1], s));
+        if (g_stage_events) DD_HIP(hipEventRecord(p->ev_det[1], s));
         DD_HIP(hipEventRecord(p->det_done, s));
         p->det_pending = frames;
         return DD_OK;
@@ -487,7 +490,7 @@ int enqueue_detector(dd_pipeline *p, const uint8_t *frames) {
     if (p->det_kind == DET_TFLITE) {                           // the generic adaptor's tail is a few integer truncations: on the host (step2)
         const size_t dbytes = (size_t)S * MAX_DET * 6 * sizeof(float) + (size_t)S * sizeof(int);
         DD_HIP(hipMemcpyAsync(p->h_fin.p, p->d_det.p, dbytes, hipMemcpyDeviceToHost, s));
-        DD_HIP(hipEventRecord(p->ev_det[1], s));
+        if (g_stage_events) DD_HIP(hipEventRecord(p->ev_det[1], s));
         DD_HIP(hipEventRecord(p->det_done, s));
         p->det_pending = frames;
         return DD_OK;
@@ -498,7 +501,7 @@ int enqueue_detector(dd_pipeline *p, const uint8_t *frames) {
         return rc;                                                                                    // :111-150
     const size_t fbytes = (size_t)S * (MAX_DET * (4 * 8 + 8 + 4) + 4);
     DD_HIP(hipMemcpyAsync(p->h_fin.p, p->d_fin.p, fbytes, hipMemcpyDeviceToHost, s));
-    DD_HIP(hipEventRecord(p->ev_det[1], s));
+    if (g_stage_events) DD_HIP(hipEventRecord(p->ev_det[1], s));
     DD_HIP(hipEventRecord(p->det_done, s));
     p->det_pending = frames;
     return DD_OK;
@@ -616,7 +619,7 @@ int dd_pipeline_step2(dd_pipeline *p, const uint8_t *frames_in, const uint8_t *f
         if (p->det_pending != frames && (rc = enqueue_detector(p, frames)) != DD_OK) return rc;       // not queued ahead: run it now
         DD_TIMED_WAIT(hipEventSynchronize(p->det_done));                                               // round trip 1
         p->det_pending = nullptr;
-        {   // the detector chain of these frames on its stream: resize, forward, post-process, adaptor tail, host copy
+        if (g_stage_events) {   // the detector chain of these frames on its stream: resize, forward, post-process, adaptor tail, host copy
             float ms = 0.f;
             DD_HIP(hipEventElapsedTime(&ms, p->ev_det[0], p->ev_det[1]));
             p->g_det += (double)ms;

@@ -44,8 +44,12 @@ def test_mars_forward_switches_give_the_same_bits():
     """MARS forward at 1280 crops: pair kernel off, residual units unfused, stem unfused, row kernels off."""
     base = _sha('time_forward.py', ['mars', 1280], {})
     for env in ({'DD_RES_PAIR_OFF': '1'}, {'DD_RES_UNIT_UNFUSED': '1'}, {'DD_STEM_UNFUSED': '1'},
-                {'DD_C64_ROWS_OFF': '1', 'DD_S2_ROWS_OFF': '1'}, {'DD_POOL_TILED': '1'}):
+                {'DD_C64_ROWS_OFF': '1', 'DD_S2_ROWS_OFF': '1'}, {'DD_POOL_TILED': '1'},
+                {'DD_MARS_PAIR': '0'},                               # conv3_x layer by layer instead of one launch per block (csrc/mars_pair.hip)
+                {'DD_MARS_PAIR': '0', 'DD_C64_ROWS_OFF': '1', 'DD_S2_ROWS_OFF': '1'}, {'DD_MARS_PAIR_MIN': '2000'}):
         assert _sha('time_forward.py', ['mars', 1280], env) == base, env
+    # conv4_x on the generic kernels (DD_MARS_WS=0) sums its K halves in another order: within the encoder's tolerance, not the same bits
+    assert _sha('time_forward.py', ['mars', 1280], {'DD_MARS_WS': '0'}) != base
 
 
 def test_yolo_and_image_switches_give_the_same_bits():
