@@ -4923,7 +4923,7 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
                 P.out = reinterpret_cast<_Float16 *>(base(dst)); P.cs_out = td->cs; P.coff_out = td->coff;
                 if (o[6] > 1) {                                  // a cascade of o[6] stride-1 pools into consecutive channel slices (nets.py pool_cascade)
                     const size_t lds = (size_t)2 * ts->h * ts->w * 16 * PC_GROUPS;
-                    DD_REQUIRE(P.stride == 1 && P.pad == P.k / 2 && (P.k & 1) && td->h == ts->h && td->w == ts->w && lds <= 64 * 1024 && P.coff_out + o[6] * P.c <= td->cs + td->coff &&
+                    DD_REQUIRE(P.stride == 1 && P.pad == P.k / 2 && (P.k & 1) && td->h == ts->h && td->w == ts->w && lds <= 64 * 1024 && ts->h * ts->w <= 4096 && P.coff_out + o[6] * P.c <= td->cs &&      /* (the kernel's p / W by float reciprocal is exact below 4 096 pixels) */
                                (P.c >> 3) % PC_GROUPS == 0 && (long long)nimg * (P.c >> 3) < (1LL << 31), DD_E_ARG, "dd_net_forward: pool cascade %d: shape", i);
                     hipLaunchKernelGGL(pool_cascade_k, dim3((unsigned)(nimg * ((P.c >> 3) / PC_GROUPS))), dim3(256), lds, s, P, o[6]);
                     DD_LAUNCH_CHECK();

@@ -272,7 +272,8 @@ def load_mars(path):
 
     The file is absent from the reference tree, so the operator pattern is the one a TFLite conversion of tools/freeze_model.py's graph
     gives as far as that can be told without it: every slim.conv2d / fully_connected with a normalizer arrives as CONV_2D /
-    FULLY_CONNECTED with the batch norm in filter and bias, followed by ELU; a block's leading batch norm (create_link, :17-21) as MUL +
+    FULLY_CONNECTED (with or without keep_num_dims: only its weights are read) with the batch norm in filter and bias, followed by ELU; a
+    stride-2 layer's SAME padding may be spelt PAD + VALID CONV_2D (accepted when the zeros are exactly SAME's); a block's leading batch norm (create_link, :17-21) as MUL +
     ADD with constant operands; the skip as ADD of two activations; pool1 as a 3x3 stride-2 VALID MAX_POOL_2D; the projection as a 1x1
     stride-2 CONV_2D; "ball" as MUL + ADD behind fc1's ELU; the unit-length tail (:153-156) in any spelling out of SQUARE / MUL / SUM / ADD /
     SQRT / RSQRT / MAXIMUM / DIV / L2_NORMALIZATION.  A channel reversal in front (REVERSE_V2, or STRIDED_SLICE with a negative stride: the
@@ -294,9 +295,15 @@ def load_mars(path):
             return g.tensors[op.inputs[0]].data.astype(np.float32)
         return None
     convs, affines, pools, fc, flip, pending, n_skip = [], [], 0, None, False, None, 0
+    pads = {}                                                          # output tensor of a PAD -> (its input, [[top, bottom], [left, right]])
     for op in g.ops:
         k = op.kind
         if k in ('CAST', 'DEQUANTIZE', 'RESHAPE', 'SQUEEZE', 'ELU'):
+            continue
+        if k == 'PAD':                                                 # explicit zero padding in front of a VALID convolution (some converters spell SAME this way)
+            pv = const(op.inputs[1])
+            _need(pv is not None and np.asarray(pv).shape == (4, 2) and not np.any(np.asarray(pv)[[0, 3]]), op, 'only constant spatial zero padding is understood')
+            pads[op.outputs[0]] = (op.inputs[0], [[int(v) for v in np.asarray(pv)[1]], [int(v) for v in np.asarray(pv)[2]]])
             continue
         if k == 'REVERSE_V2':
             ax = const(op.inputs[1])
@@ -316,7 +323,17 @@ def load_mars(path):
             o = op.options
             _need(wdata is not None and xi.dtype == np.float32 and wdata.dtype == np.float32, op, 'float32 activations and constant float32 (or float16 behind DEQUANTIZE) filters: a quantised encoder is not built')
             w = type('W', (), dict(data=wdata))
-            _need(o['padding'] == 'SAME' and o['stride_w'] == o['stride_h'] and o['act'] == 'none' and o['dilation_w'] == 1 and o['dilation_h'] == 1, op, 'SAME padding, square stride, no fused activation')
+            _need(o['stride_w'] == o['stride_h'] and o['act'] == 'none' and o['dilation_w'] == 1 and o['dilation_h'] == 1, op, 'square stride, no fused activation')
+            if o['padding'] == 'VALID' and op.inputs[0] in pads:        # PAD + VALID: accepted when the padding is exactly what SAME would add
+                src, pv = pads[op.inputs[0]]
+                xs, kk, st = g.tensors[src].shape, wdata.shape[1], int(o['stride_w'])
+                want = []
+                for d in (1, 2):
+                    tot = max((-(-int(xs[d]) // st) - 1) * st + kk - int(xs[d]), 0)
+                    want.append([tot // 2, tot - tot // 2])
+                _need(pv == want, op, 'explicit padding %s in front of a VALID convolution (TensorFlow SAME for this layer is %s)' % (pv, want))
+            else:
+                _need(o['padding'] == 'SAME', op, 'SAME padding (or PAD + VALID with the same zeros)')
             wt = np.ascontiguousarray(np.transpose(w.data, (1, 2, 3, 0))).astype(np.float32)     # OHWI -> HWIO
             convs.append(dict(op=op, w=wt, b=np.zeros(wt.shape[3], np.float32) if b is None else np.asarray(b, np.float32).reshape(-1), stride=int(o['stride_w'])))
             continue

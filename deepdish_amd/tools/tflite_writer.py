@@ -177,7 +177,7 @@ def ssd_mobilenet_graph(model, anchors=None, post=None):
     return W
 
 
-def mars_graph(wd, reverse_channels=True, half_weights=False):
+def mars_graph(wd, reverse_channels=True, half_weights=False, explicit_pad=False):
     """Named float weights of the MARS encoder (deepdish_amd/nets.synthetic_mars_weights or the arrays of an .npz; batch norms raw or folded)
     -> GraphWriter of the graph as tools/tflite_reader.load_mars documents it: channel reversal, CONV_2D with the batch norm in filter and
     bias + ELU, block batch norms as MUL + ADD, skip ADDs, pool1, FULLY_CONNECTED, "ball", the unit-length tail as MUL / SUM / ADD / SQRT / DIV."""
@@ -205,9 +205,19 @@ def mars_graph(wd, reverse_channels=True, half_weights=False):
             W.op('DEQUANTIZE', [hw_], [fw])
         else:
             fw = const(name + '/weights', np.transpose(w_hwio, (3, 0, 1, 2)))
+        padding = 'SAME'
+        if explicit_pad and stride == 2:                                # the same zeros SAME adds, spelt PAD + VALID (another converter's habit)
+            kk = w_hwio.shape[0]
+            pv = []
+            for d in (h, w_):
+                tot = max((-(-d // stride) - 1) * stride + kk - d, 0)
+                pv.append([tot // 2, tot - tot // 2])
+            padded = T([1, h + sum(pv[0]), w_ + sum(pv[1]), w_hwio.shape[2]])
+            W.op('PAD', [src, const(name + '/paddings', [[0, 0], pv[0], pv[1], [0, 0]], np.int32)], [padded])
+            src, padding = padded, 'VALID'
         ins = [src, fw] + ([const(name + '/bias', bias)] if bias is not None else [-1])
         out = T([1, ho, wo, cout], name)
-        W.op('CONV_2D', ins, [out], dict(stride=stride, act='none'))
+        W.op('CONV_2D', ins, [out], dict(stride=stride, act='none', padding=padding))
         return out, (ho, wo)
 
     def elu(src, shape):
@@ -265,8 +275,8 @@ def mars_graph(wd, reverse_channels=True, half_weights=False):
     return W
 
 
-def write_mars(wd, path, reverse_channels=True, half_weights=False):
-    data = mars_graph(wd, reverse_channels, half_weights).tobytes()
+def write_mars(wd, path, reverse_channels=True, half_weights=False, explicit_pad=False):
+    data = mars_graph(wd, reverse_channels, half_weights, explicit_pad).tobytes()
     with open(path, 'wb') as f:
         f.write(data)
     return len(data)

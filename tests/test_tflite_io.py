@@ -259,3 +259,33 @@ def test_yolov5s_round_trip_and_refusals(tmp_path):
         wd2['m1/weights'] = wd['m1/weights'][:, :, :, :32]
         tflite_writer.write_yolov5s(wd2, path)
         tflite_reader.load_yolov5s(path)
+
+
+def test_mars_reader_accepts_explicit_same_padding(tmp_path):
+    """A stride-2 layer's SAME padding spelt PAD + VALID CONV_2D gives the same weights; other zeros in front of a VALID convolution are refused."""
+    from deepdish_amd import nets
+    from deepdish_amd.tools import tflite_writer, tflite_reader
+    wd = nets.synthetic_mars_weights(11)
+    a, b = str(tmp_path / 'a.tflite'), str(tmp_path / 'b.tflite')
+    tflite_writer.write_mars(wd, a)
+    tflite_writer.write_mars(wd, b, explicit_pad=True)
+    assert sum(o.kind == 'PAD' for o in tflite_reader.read(b).ops) == 4          # conv3_1/1, its projection, conv4_1/1, its projection
+    wa, wb = tflite_reader.load_mars(a), tflite_reader.load_mars(b)
+    assert set(wa) == set(wb)
+    for k in wa:
+        np.testing.assert_array_equal(np.asarray(wa[k]), np.asarray(wb[k]), err_msg=k)
+    # conv4_1/1 reads a 16 x 8 map: SAME adds a row below and a column to the right only; symmetric zeros there are another convolution
+    g = tflite_writer.mars_graph(wd, explicit_pad=True)
+    hit = 0
+    for o in g.ops:
+        if o['kind'] == 'PAD':
+            t = g.tensors[o['inputs'][1]]
+            if np.frombuffer(g.buffers[t['buffer']], np.int32).tolist() == [0, 0, 0, 1, 0, 1, 0, 0]:
+                g.buffers[t['buffer']] = np.array([[0, 0], [1, 1], [1, 1], [0, 0]], np.int32).tobytes()
+                hit += 1
+                break
+    assert hit == 1
+    open(b, 'wb').write(g.tobytes())
+    with pytest.raises(tflite_reader.UnsupportedModel) as e:
+        tflite_reader.load_mars(b)
+    assert 'explicit padding' in str(e.value)
