@@ -9,29 +9,30 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 export DD_BENCH_GEN_WORKERS=1      # every profiled run generates its frames in-process: no generator pool forked from a process the profiler's preloaded library may have initialised the GPU in
 PARTS=${*:-layers trace pmc sq}
-B="python3 $R/bench.py --groups 1 --streams 384 --steps 20 --warmup 5 --no-cpu-baseline"
+S=${DD_PROF_STREAMS:-768}      # streams of the one worker group the passes profile = frames per detector launch of the default bench
+B="python3 $R/bench.py --groups 1 --streams $S --steps 20 --warmup 5 --no-cpu-baseline"
 for part in $PARTS; do
 case $part in
 tests)
     (cd $R && timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/gputests.log 2>&1; echo "rc=$?" >> $O/gputests.log; tail -3 $O/gputests.log) ;;
 layers)
-    for kb in "ssd_i8 384" "ssd_i8_sym 384" "ssd 384" "mars 7680" "yolo 128"; do set -- $kb
+    for kb in "ssd_i8 384" "ssd_i8 768" "ssd 384" "mars 7680" "mars 15360" "yolo 128"; do set -- $kb
         python3 $R/scripts/profile_layers.py $1 $2 > $O/layers_$1_b$2.txt 2>&1; tail -1 $O/layers_$1_b$2.txt; done ;;
 trace)
-    DD_BENCH_NO_LOOKAHEAD=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_g1 -- python3 $R/bench.py --groups 1 --streams 384 --steps 60 --warmup 5 --no-cpu-baseline > $O/bench_groups1_s384.json 2> $O/kt_g1.err
+    DD_BENCH_NO_LOOKAHEAD=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_g1 -- python3 $R/bench.py --groups 1 --streams $S --steps 40 --warmup 5 --no-cpu-baseline > $O/bench_groups1_s$S.json 2> $O/kt_g1.err
     rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_default -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_default_traced.json 2> $O/kt_default.err
     echo trace done ;;
 pmc)
     export DD_BENCH_GEN_WORKERS=1
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $B > $O/pmc_fetch.json 2> $O/pmc_fetch.err
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- $B > $O/pmc_write.json 2> $O/pmc_write.err
-    python3 $R/scripts/summarize_pmc.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic_s384.json ;;
+    python3 $R/scripts/summarize_pmc.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic_s$S.json ;;
 sq)
     export DD_BENCH_GEN_WORKERS=1
     rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC --output-format csv -d $O/pmc_sq -- $B > $O/pmc_sq.json 2> $O/pmc_sq.err
-    python3 $R/scripts/summarize_pmc_sq.py $O/pmc_sq $O/pmc_sq_bench_s384.json "bench.py --groups 1 --streams 384 --steps 20" > $O/pmc_sq_summary.txt
+    python3 $R/scripts/summarize_pmc_sq.py $O/pmc_sq $O/pmc_sq_bench_s$S.json "bench.py --groups 1 --streams $S --steps 20" > $O/pmc_sq_summary.txt
     rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma -- $B > $O/pmc_mfma.json 2> $O/pmc_mfma.err
-    python3 $R/scripts/summarize_pmc_sq.py $O/pmc_mfma $O/pmc_mfma_busy_bench_s384.json "bench.py --groups 1 --streams 384 --steps 20" > $O/pmc_mfma_summary.txt
+    python3 $R/scripts/summarize_pmc_sq.py $O/pmc_mfma $O/pmc_mfma_busy_bench_s$S.json "bench.py --groups 1 --streams $S --steps 20" > $O/pmc_mfma_summary.txt
     head -20 $O/pmc_mfma_summary.txt ;;
 esac
 done
