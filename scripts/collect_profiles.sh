@@ -37,5 +37,7 @@ sq)
 esac
 done
 # keep the merge-back small: the raw counter CSVs are large
-find $O -name '*counter_collection.csv' -size +20M -delete 2>/dev/null
+# (gpurun copies back at most 64 MiB: the raw per-dispatch CSVs are summarised above and dropped)
+find $O -name '*counter_collection.csv' -delete 2>/dev/null
+find $O -name '*kernel_trace.csv' -delete 2>/dev/null
 du -sh $O
