@@ -4570,7 +4570,34 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
         return launch_res_unit(s, pair_a, pair_b, nimg, net->ctx->device);
     };
     auto run_ws = [&](ConvP &P) { return P.cin == 256 ? launch_conv_ws<4>(s, P, net->ctx->device) : launch_conv_ws<8>(s, P, net->ctx->device); };
-    for (int i = 0; i < net->n_ops; ++i) {
+    int first_op = 0;
+    {
+        // uint8 SSD: the first three launches (first layer, MobileNet blocks 1 and 2) over chunks of frames that REUSE the image slots 0 .. chunk - 1
+        // of the two tensors between them, so that 0.72 + 1.44 MB per frame of producer -> consumer traffic can stay in the 256 MB Infinity
+        // Cache instead of going to HBM and back (DD_Q_FRONT_CHUNK=n frames; 0 = off).  Same kernels, same bits: block 2 writes its own
+        // output where the whole-batch launch would.
+        static const int chunk_env = getenv("DD_Q_FRONT_CHUNK") ? atoi(getenv("DD_Q_FRONT_CHUNK")) : 0;
+        auto opw = [&](int k) { return net->prog.data() + net->ops_off + (size_t)k * OP_WORDS; };
+        if (chunk_env > 0 && nimg > chunk_env && net->n_ops > 3 && opw(0)[0] == 16 && opw(1)[0] == 19 && opw(2)[0] == 19 && opw(1)[1] == opw(0)[2] && opw(2)[1] == opw(1)[2]) {
+            const TensorDesc &t2 = net->tensors[opw(2)[2]];
+            const size_t img_out = (size_t)(t2.h + 2) * (t2.w + 2) * t2.cs;          // bordered uint8 layout: bytes per image
+            void *&out_buf = net->bufs[t2.buf];
+            void *const out_base = out_buf;
+            if (net->profile) for (int k = 0; k < 3; ++k) DD_HIP(hipEventRecord(net->events[k], s));
+            for (int c0 = 0; c0 < nimg; c0 += chunk_env) {
+                const int nc = std::min(chunk_env, nimg - c0);
+                out_buf = static_cast<char *>(out_base) + (size_t)c0 * img_out;
+                for (int k = 0; k < 3; ++k) {
+                    int handled = 0;
+                    const int rc = netq_run_op(net, k, opw(k), input + (size_t)c0 * net->in_h * net->in_w * 3, nc, s, &handled);
+                    if (rc != DD_OK || !handled) { out_buf = out_base; return rc != DD_OK ? rc : DD_E_ARG; }
+                }
+            }
+            out_buf = out_base;
+            first_op = 3;
+        }
+    }
+    for (int i = first_op; i < net->n_ops; ++i) {
         if (net->profile) DD_HIP(hipEventRecord(net->events[i], s));
         const int32_t *o = net->prog.data() + net->ops_off + (size_t)i * OP_WORDS;
         const float *of = reinterpret_cast<const float *>(o);
