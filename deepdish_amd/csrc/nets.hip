@@ -57,6 +57,17 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     }
 }
 
+// Pooling maximum of values that are never NaN in a valid network: v_maximum3_f32 / v_maximum_f32 on gfx950 (IEEE-754-2019 maximum).  fmaxf is
+// maxnum, which hipcc implements as canonicalise(a), canonicalise(b), v_max for operands it cannot prove quiet (loop-carried values,
+// results of other maxima): three instructions instead of one in kernels bound by instruction issue.  Same result for non-NaN inputs.
+__device__ __forceinline__ float pool_max(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_elementwise_maximum(a, b);
+#else
+    return a > b ? a : b;
+#endif
+}
+
 struct ConvP {
     const _Float16 *in; int H, W, cs_in, coff_in, cin;
     const _Float16 *w; const float *bias; int kpad;
@@ -1164,8 +1175,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rw_k(const ConvP P, const int 
 // halves 1..3, x = 0 at half 4, x = 32 at 100..102; the pad columns are zeroed once), and a stem fragment gathers its
 // eight k operands with ds_read_u16 from one ring row per lane.  The 64x32x32 f16 tensor between the two layers (131 KB
 // per image written and read back -- what bounds the DMA version) never exists.
-constexpr int PR_SLOTS = 8, PR_SLOT_HALVES = 1024, PR_CROP_PITCH = 104;
-constexpr int pr_wave_halves(bool stem) { return PR_SLOTS * PR_SLOT_HALVES + (stem ? PR_SLOTS * PR_CROP_PITCH : 0); }
+// Round 5 (the kernel is bound by vector-instruction issue, and an MFMA and a vector instruction do not overlap on a SIMD:
+// scripts/experiments/mfma_valu_overlap.hip, profiles/r05_mfma_valu_overlap.txt -- so every vector instruction that goes is time):
+//   * the round loop is unrolled by four: a round consumes two of the eight ring slots, so inside a group of four rounds every slot
+//     index -- of the row ring and of the crop ring -- is a literal and every LDS access is lane base + immediate offset (no address
+//     arithmetic, no scalar bookkeeping per round);
+//   * a row slot is 130 chunks: [64 even][64 odd][2 zero chunks]; the lane of pixel 0 / 31 points its left / right tap at a zero
+//     chunk (the one in front of the slot / behind it: the bank phases of the chunks they replace, a read stays conflict free)
+//     instead of masking what it read;
+//   * the crop ring keeps rows 0..2 twice (rows 8..10), so the three image rows of a window are rows c, c+1, c+2 without a wrap;
+//   * pooling maxima are v_maximum3_f32 (gfx950): the IEEE maxnum form canonicalises loop-carried and pooled operands first
+//     (two extra v_max per maximum); the two differ only on NaN inputs.
+constexpr int PR_SLOTS = 8, PR_SLOT_HALVES = 1040, PR_CROP_PITCH = 104, PR_CROP_ROWS = 11;
+constexpr int pr_wave_halves(bool stem) { return 8 + PR_SLOTS * PR_SLOT_HALVES + (stem ? PR_CROP_ROWS * PR_CROP_PITCH : 0); }
 
 template <int ACT, bool STEM>
 __global__ __launch_bounds__(256, 2) void conv3x3_pool_rows_k(const ConvP P, const int n_units, const int split_dbg) {
@@ -1173,10 +1195,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_pool_rows_k(const ConvP P, con
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
-    _Float16 *ring = lds + (size_t)wave * pr_wave_halves(STEM);
+    _Float16 *ring = lds + (size_t)wave * pr_wave_halves(STEM) + 8;
     _Float16 *crop = ring + PR_SLOTS * PR_SLOT_HALVES;
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    const h8 zero8 = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
 
     h8 wf[9][2];
 #pragma unroll
@@ -1187,19 +1209,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_pool_rows_k(const ConvP P, con
     const f4 bias0 = *reinterpret_cast<const f4 *>(P.bias + fq * 8), bias1 = *reinterpret_cast<const f4 *>(P.bias + fq * 8 + 4);
     h8 ws[2];
     f4 sb0, sb1;
+    // the zero chunks: one in front of slot 0, two behind every slot (never written again: rows fill chunks 0..127 of a slot only)
+    if (lane < 2 * PR_SLOTS) *reinterpret_cast<h8 *>(ring + (lane >> 1) * PR_SLOT_HALVES + 1024 + (lane & 1) * 8) = zero8;
+    if (lane == 2 * PR_SLOTS) *reinterpret_cast<h8 *>(ring - 8) = zero8;
     if constexpr (STEM) {
 #pragma unroll
         for (int a = 0; a < 2; ++a) ws[a] = *reinterpret_cast<const h8 *>(P.dw_w + rw_weight_row(a, fr) * 32 + fq * 8);
         sb0 = *reinterpret_cast<const f4 *>(P.dw_bias + fq * 8); sb1 = *reinterpret_cast<const f4 *>(P.dw_bias + fq * 8 + 4);
-        if (lane < 2 * PR_SLOTS)                                  // pad columns of every ring row, never written again
+        if (lane < 2 * PR_CROP_ROWS)                              // pad columns of every crop-ring row, never written again
             *reinterpret_cast<h4 *>(crop + (lane >> 1) * PR_CROP_PITCH + ((lane & 1) ? 100 : 0)) = h4{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
     }
     const int ph = P.p[0], pw = P.p[1];
     const int H = P.H;
-    // fragment addresses inside a row slot (halves): B = even[fr], C = odd[fr], A = odd[fr-1], D = even[fr+1]
-    const int offB = (fq * 16 + fr) * 8, offC = 512 + offB;
-    const int offA = 512 + (fq * 16 + (fr ? fr - 1 : 0)) * 8, offD = (fq * 16 + (fr < 15 ? fr + 1 : 15)) * 8;
-    const unsigned keepA = fr ? 0xFFFFFFFFu : 0u, keepD = fr < 15 ? 0xFFFFFFFFu : 0u;   // x = -1 / x = 32: the zero padding
+    // fragment addresses inside a row slot (halves): B = even[fr], C = odd[fr], A = odd[fr-1], D = even[fr+1]; x = -1 / x = 32 are the
+    // zero chunk in front of the slot (phase 15, as odd[fr-1] of the other lanes' pattern) / behind it (phase 0)
+    const _Float16 *pB = ring + (fq * 16 + fr) * 8, *pC = pB + 512;
+    const _Float16 *pA = fr ? pC - 8 : ring - 8, *pD = fr < 15 ? pB + 8 : ring + 1024;
     const int act = ACT < 0 ? P.act : ACT;
     const int split = split_dbg & 255;
 #ifdef DD_KERNEL_DBG
@@ -1208,7 +1233,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_pool_rows_k(const ConvP P, con
     constexpr int dbg = 0;                                      // compiled out of the product build: as a run-time value it put ~30 scalar branches
 #endif                                                          // into every round of a kernel that is bound by instruction issue (build with -DDD_KERNEL_DBG)
     const int crow = lane >> 5, cdw = lane & 31;                // image rows: two per step, one dword per lane (24 of 32 live)
-    const int cx = 1 + 6 * fr;                                  // window start (x - 1) of the even pixel x = 2 fr in a ring row
+    // stem fragment gathers: lane group fq < 3 reads eight taps of crop-ring row c + fq, group 3 tap 8 of rows c .. c + 2 and the rest of row c + 2
+    // (c = the ring row of image row y - 1, a literal inside the unrolled loop)
+    const int cx = 1 + 6 * fr;                                  // window start (x - 1) of the even pixel x = 2 fr in a crop-ring row
+    const _Float16 *gPb = crop + (fq < 3 ? fq : 2) * PR_CROP_PITCH + cx;
+    const _Float16 *gA0 = fq == 3 ? crop + cx + 8 : gPb, *gA1 = fq == 3 ? crop + PR_CROP_PITCH + cx + 7 : gPb, *gA2 = fq == 3 ? crop + 2 * PR_CROP_PITCH + cx + 6 : gPb;
+    _Float16 *cW = crop + 4 + cdw * 4;                           // where a lane's four normalised pixels-channels go inside a crop-ring row
 
     // unit = pooled rows [j0, j1) of one image (`split` units per image: few images still fill the chip; a unit's first
     // round only builds the carry, so a split costs one recomputed round per extra unit)
@@ -1217,8 +1247,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_pool_rows_k(const ConvP P, con
         const int j0 = part * ph / split, j1 = (part + 1) * ph / split;
         const _Float16 *img = STEM ? nullptr : P.in + (size_t)n * H * 32 * P.cs_in + P.coff_in + fq * 8;
         const uint8_t *img8 = STEM ? P.src8 + (size_t)n * H * 96 : nullptr;
-        auto fill_row = [&](int y) {                              // wave-uniform y; rows outside the image: zero lines
-            _Float16 *dst = ring + ((y + 1) & (PR_SLOTS - 1)) * PR_SLOT_HALVES;
+        auto fill_row = [&](int y, int slot) {                    // wave-uniform y (slot = (y + 1) & 7); rows outside the image: zero lines
+            _Float16 *dst = ring + slot * PR_SLOT_HALVES;
             const bool ok = (unsigned)y < (unsigned)H;
             const _Float16 *src = img + ((size_t)(ok ? y : 0) * 32 + 2 * fr) * P.cs_in;
             lds_fill16(ok ? src : P.zero, dst);
@@ -1229,33 +1259,33 @@ __global__ __launch_bounds__(256, 2) void conv3x3_pool_rows_k(const ConvP P, con
             const bool ok = (unsigned)r < (unsigned)H && cdw < 24;
             return *reinterpret_cast<const unsigned *>(ok ? img8 + (size_t)r * 96 + cdw * 4 : reinterpret_cast<const uint8_t *>(P.zero));
         };
-        auto put_crop = [&](int r0, unsigned raw) {               // normalise; rows outside the image are the zero padding
+        auto put_crop = [&](int r0, int row_lo, int row_hi, unsigned raw) {   // normalise image rows r0, r0+1 into crop-ring rows row_lo / row_hi = (r + 1) & 7
             const int r = r0 + crow;
-            const bool ok = (unsigned)r < (unsigned)H;
+            const bool ok = (unsigned)r < (unsigned)H;            // rows outside the image are the zero padding
             h4 o;
 #pragma unroll
             for (int q = 0; q < 4; ++q) o[q] = (_Float16)(ok ? ((float)((raw >> (8 * q)) & 255u) - P.in_mean) * P.in_scale : 0.f);
-            if (cdw < 24) *reinterpret_cast<h4 *>(crop + ((r + 1) & (PR_SLOTS - 1)) * PR_CROP_PITCH + 4 + cdw * 4) = o;
+            const int row = crow ? row_hi : row_lo;
+            if (cdw < 24) {
+                *reinterpret_cast<h4 *>(cW + row * PR_CROP_PITCH) = o;
+                if (row < 3) *reinterpret_cast<h4 *>(cW + (row + 8) * PR_CROP_PITCH) = o;     // rows 0..2 a second time behind row 7
+            }
         };
-        auto stem_row = [&](int y) {                              // first-layer row y -> its ring slot (wave-uniform y)
-            _Float16 *dst = ring + ((y + 1) & (PR_SLOTS - 1)) * PR_SLOT_HALVES;
+        auto stem_row = [&](int y, int slot, int c) {             // first-layer row y -> ring slot (y + 1) & 7 (wave-uniform y); c = y & 7
+            _Float16 *dst = ring + slot * PR_SLOT_HALVES;
             if ((unsigned)y >= (unsigned)H) {                     // the second layer's zero padding
-                const h8 z = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
-                *reinterpret_cast<h8 *>(dst + lane * 8) = z;
-                *reinterpret_cast<h8 *>(dst + 512 + lane * 8) = z;
+                *reinterpret_cast<h8 *>(dst + lane * 8) = zero8;
+                *reinterpret_cast<h8 *>(dst + 512 + lane * 8) = zero8;
                 return;
             }
-            // image row y-1+d sits in ring row (y+d) & 7; k slots: group d < 3 = taps 0..7 of filter row d, group 3 = tap 8 of rows 0..2
-            const int L0 = (y & (PR_SLOTS - 1)) * PR_CROP_PITCH + cx, L1 = ((y + 1) & (PR_SLOTS - 1)) * PR_CROP_PITCH + cx,
-                      L2 = ((y + 2) & (PR_SLOTS - 1)) * PR_CROP_PITCH + cx;
-            const int Pb = fq == 0 ? L0 : fq == 1 ? L1 : L2;
-            const int A0 = fq == 3 ? L0 + 8 : Pb, A1 = fq == 3 ? L1 + 7 : Pb, A2 = fq == 3 ? L2 + 6 : Pb;
+            // image row y-1+d sits in crop-ring row c + d; k slots: group d < 3 = taps 0..7 of filter row d, group 3 = tap 8 of rows 0..2
+            const int co = c * PR_CROP_PITCH;
 #pragma unroll
             for (int par = 0; par < 2; ++par) {
                 h8 xf;
-                xf[0] = crop[A0 + 3 * par]; xf[1] = crop[A1 + 1 + 3 * par]; xf[2] = crop[A2 + 2 + 3 * par];
+                xf[0] = gA0[co + 3 * par]; xf[1] = gA1[co + 1 + 3 * par]; xf[2] = gA2[co + 2 + 3 * par];
 #pragma unroll
-                for (int j = 3; j < 8; ++j) xf[j] = crop[Pb + j + 3 * par];
+                for (int j = 3; j < 8; ++j) xf[j] = gPb[co + j + 3 * par];
                 const f4 a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ws[0], xf, sb0, 0, 0, 0);       // onto the bias, as stem_conv3_k
                 const f4 a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ws[1], xf, sb1, 0, 0, 0);
                 h8 o;
@@ -1264,104 +1294,109 @@ __global__ __launch_bounds__(256, 2) void conv3x3_pool_rows_k(const ConvP P, con
                 *reinterpret_cast<h8 *>(dst + par * 512 + (fq * 16 + fr) * 8) = o;
             }
         };
+        const int kbeg = STEM ? j0 - 2 : j0;
         unsigned raw = 0;
         if constexpr (STEM) {
-            put_crop(2 * j0 - 2, load_raw(2 * j0 - 2));
+            put_crop(2 * j0 - 2, (2 * j0 - 1) & 7, (2 * j0) & 7, load_raw(2 * j0 - 2));
             raw = load_raw(2 * j0);
         } else {
-            fill_row(2 * j0 - 1); fill_row(2 * j0); fill_row(2 * j0 + 1); fill_row(2 * j0 + 2);
+            for (int y = 2 * j0 - 1; y <= 2 * j0 + 2; ++y) fill_row(y, (y + 1) & 7);
         }
         f4 carry[2];
         h8 pend;                                                  // pooled row of the previous round, not yet stored
         _Float16 *out_img = static_cast<_Float16 *>(P.out) + (size_t)n * ph * pw * P.cs_out + P.coff_out + fq * 8;
-        for (int k = STEM ? j0 - 2 : j0; k <= j1; ++k) {
-            if constexpr (STEM) {
-                // step k makes first-layer rows 2k+3 and 2k+4 (round k+1's new rows) from image rows 2k+2 .. 2k+5
-                if (k < j1 && !((dbg & 4) && k >= j0)) {
-                    put_crop(2 * k + 4, raw);
-                    raw = load_raw(2 * k + 6);
-                    stem_row(2 * k + 3); stem_row(2 * k + 4);
+        for (int kk = kbeg & ~3; kk <= j1; kk += 4) {
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) {
+                const int k = kk + kq;                            // 2 k = 2 kq (mod 8): every slot index below is a literal
+                if (k < kbeg || k > j1) continue;                 // wave-uniform
+                if constexpr (STEM) {
+                    // step k makes first-layer rows 2k+3 and 2k+4 (round k+1's new rows) from image rows 2k+2 .. 2k+5
+                    if (k < j1 && !((dbg & 4) && k >= j0)) {
+                        put_crop(2 * k + 4, (2 * kq + 5) & 7, (2 * kq + 6) & 7, raw);
+                        raw = load_raw(2 * k + 6);
+                        stem_row(2 * k + 3, (2 * kq + 4) & 7, (2 * kq + 3) & 7);
+                        stem_row(2 * k + 4, (2 * kq + 5) & 7, (2 * kq + 4) & 7);
+                    }
+                    if (k < j0) continue;
+                } else {
+                    if (!(dbg & 4)) { fill_row(2 * k + 3, (2 * kq + 4) & 7); fill_row(2 * k + 4, (2 * kq + 5) & 7); }
+#if defined(__HIP_DEVICE_COMPILE__)
+                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // rows up to 2k+2 have landed (this wave's own DMAs: no barrier)
+#endif
                 }
-                if (k < j0) continue;
-            } else {
-                if (!(dbg & 4)) { fill_row(2 * k + 3); fill_row(2 * k + 4); }
+                if (k >= j0 + 2 && fr < pw) *reinterpret_cast<h8 *>(out_img + (size_t)((k - 2) * pw + fr) * P.cs_out) = pend;
+                f4 acc[2][2][2];                                  // [conv row][parity][channel half], from the bias
+#pragma unroll
+                for (int cr = 0; cr < 2; ++cr)
+#pragma unroll
+                    for (int par = 0; par < 2; ++par) { acc[cr][par][0] = bias0; acc[cr][par][1] = bias1; }
+                h8 X[2][4];
+                auto read_row = [&](int i, h8 (&x)[4]) {
+                    const int so = ((2 * kq + i) & (PR_SLOTS - 1)) * PR_SLOT_HALVES;      // slot of input row 2k-1+i
+                    x[0] = *reinterpret_cast<const h8 *>(pA + so);
+                    x[1] = *reinterpret_cast<const h8 *>(pB + so);
+                    x[2] = *reinterpret_cast<const h8 *>(pC + so);
+                    x[3] = *reinterpret_cast<const h8 *>(pD + so);
+                };
+                read_row(0, X[0]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    // order: wait for row i (requested one row of MFMAs ago), THEN request row i+1, then multiply -- hipcc's wait
+                    // before the first use of row i is lgkmcnt(0), so a request issued ahead of it would be waited for as well
+                    h8 (&x)[4] = X[i & 1];
 #if defined(__HIP_DEVICE_COMPILE__)
-                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // rows up to 2k+2 have landed (this wave's own DMAs: no barrier)
+                    __builtin_amdgcn_sched_barrier(0);
 #endif
-            }
-            if (k >= j0 + 2 && fr < pw) *reinterpret_cast<h8 *>(out_img + (size_t)((k - 2) * pw + fr) * P.cs_out) = pend;
-            f4 acc[2][2][2];                                      // [conv row][parity][channel half], from the bias
-#pragma unroll
-            for (int cr = 0; cr < 2; ++cr)
-#pragma unroll
-                for (int par = 0; par < 2; ++par) { acc[cr][par][0] = bias0; acc[cr][par][1] = bias1; }
-            h8 X[2][4];
-            auto read_row = [&](int i, h8 (&x)[4]) {
-                const _Float16 *rs = ring + ((2 * k + i) & (PR_SLOTS - 1)) * PR_SLOT_HALVES;     // slot of input row 2k-1+i
-                x[0] = *reinterpret_cast<const h8 *>(rs + offA);
-                x[1] = *reinterpret_cast<const h8 *>(rs + offB);
-                x[2] = *reinterpret_cast<const h8 *>(rs + offC);
-                x[3] = *reinterpret_cast<const h8 *>(rs + offD);
-            };
-            read_row(0, X[0]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                // order: wait for row i (requested one row of MFMAs ago), THEN request row i+1, then multiply -- hipcc's wait
-                // before the first use of row i is lgkmcnt(0), so a request issued ahead of it would be waited for as well
-                h8 (&x)[4] = X[i & 1];
-                x[0] = __builtin_bit_cast(h8, __builtin_bit_cast(u4v, x[0]) & keepA);
-                x[3] = __builtin_bit_cast(h8, __builtin_bit_cast(u4v, x[3]) & keepD);
+                    if (i + 1 < 4) read_row(i + 1, X[(i + 1) & 1]);
 #if defined(__HIP_DEVICE_COMPILE__)
-                __builtin_amdgcn_sched_barrier(0);
-#endif
-                if (i + 1 < 4) read_row(i + 1, X[(i + 1) & 1]);
-#if defined(__HIP_DEVICE_COMPILE__)
-                __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_sched_barrier(0);
 #endif
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx)
+                    for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-                    for (int cr = 0; cr < 2; ++cr) {
-                        const int dy = i - cr;                    // filter row of conv row 2k+cr that meets input row 2k-1+i
-                        if (dy < 0 || dy > 2 || (dbg & 1)) continue;
+                        for (int cr = 0; cr < 2; ++cr) {
+                            const int dy = i - cr;                // filter row of conv row 2k+cr that meets input row 2k-1+i
+                            if (dy < 0 || dy > 2 || (dbg & 1)) continue;
 #pragma unroll
-                        for (int par = 0; par < 2; ++par)
+                            for (int par = 0; par < 2; ++par)
 #pragma unroll
-                            for (int a = 0; a < 2; ++a)
-                                acc[cr][par][a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[dy * 3 + dx][a], x[dx + par], acc[cr][par][a], 0, 0, 0);
-                    }
+                                for (int a = 0; a < 2; ++a)
+                                    acc[cr][par][a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[dy * 3 + dx][a], x[dx + par], acc[cr][par][a], 0, 0, 0);
+                        }
 #if defined(__HIP_DEVICE_COMPILE__)
-                __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_sched_barrier(0);
 #endif
-            }
-            if (dbg & 2) { pend = __builtin_bit_cast(h8, acc[0][0][0] + acc[1][1][1] + acc[0][1][0] + acc[1][0][1]); continue; }
-            // horizontal 3-max of each conv row: x = 2fr, 2fr+1 and 2fr+2 (the even fragment of lane fr+1)
-            f4 hm[2][2];
+                }
+                if (dbg & 2) { pend = __builtin_bit_cast(h8, acc[0][0][0] + acc[1][1][1] + acc[0][1][0] + acc[1][0][1]); continue; }
+                // horizontal 3-max of each conv row: x = 2fr, 2fr+1 and 2fr+2 (the even fragment of lane fr+1)
+                f4 hm[2][2];
 #pragma unroll
-            for (int cr = 0; cr < 2; ++cr)
+                for (int cr = 0; cr < 2; ++cr)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float e = acc[cr][0][a][r];
+                            float nx = e;
+#if defined(__HIP_DEVICE_COMPILE__)
+                            // lane 15 of a row gets 0 (bound_ctrl): it is pooled column 15, which does not exist and is never stored
+                            nx = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, e), 0x101 /* row_shl:1 */, 0xf, 0xf, true));
+#endif
+                            hm[cr][a][r] = pool_max(pool_max(e, acc[cr][1][a][r]), nx);
+                        }
+                if (k > j0) {                                     // pooled row k-1 = rows 2k-2, 2k-1 (carried) and 2k
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            pend[a * 4 + r] = (_Float16)apply_act(pool_max(carry[a][r], hm[0][a][r]), act);
+                }
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float e = acc[cr][0][a][r];
-                        float nx = e;
-#if defined(__HIP_DEVICE_COMPILE__)
-                        // lane 15 of a row gets 0 (bound_ctrl): it is pooled column 15, which does not exist and is never stored
-                        nx = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, e), 0x101 /* row_shl:1 */, 0xf, 0xf, true));
-#endif
-                        hm[cr][a][r] = fmaxf(fmaxf(e, acc[cr][1][a][r]), nx);
-                    }
-            if (k > j0) {                                         // pooled row k-1 = rows 2k-2, 2k-1 (carried) and 2k
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        pend[a * 4 + r] = (_Float16)apply_act(fmaxf(carry[a][r], hm[0][a][r]), act);
+                    for (int r = 0; r < 4; ++r) carry[a][r] = pool_max(hm[0][a][r], hm[1][a][r]);
             }
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) carry[a][r] = fmaxf(hm[0][a][r], hm[1][a][r]);
         }
         if (fr < pw) *reinterpret_cast<h8 *>(out_img + (size_t)((j1 - 1) * pw + fr) * P.cs_out) = pend;
     }

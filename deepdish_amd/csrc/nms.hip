@@ -332,6 +332,80 @@ __global__ __launch_bounds__(1024) void nms_lazy_k(const SBox *__restrict__ sort
     if (tid == 0) *out_n = s_nkeep;
 }
 
+
+// The SSD post-process form (max_keep survivors of k candidates, max_keep << k): no sort at all.  Greedy score-ordered NMS is
+// "keep the best live candidate, kill what it suppresses, repeat" -- max_keep rounds of a workgroup-wide arg-max over the live
+// composite keys (order-preserving score bits << 32 | index: equal scores "higher index first", the order of nms_sort_f32_k) and one
+// IoU per live candidate, against 67 K compare-exchanges of the full sort plus 64 x k pair tests of nms_lazy_k's first chunk.  (The
+// model files' nms_score_threshold is 1e-8: practically every one of the 1917 anchors is a candidate, so compacting the candidates
+// first -- this kernel's first form -- left the sort as long as it was.)  A thread keeps PER candidates (keys, boxes, areas) in
+// registers; the boxes are staged in LDS once so that the round's pivot is one broadcast read.  One barrier per round: the
+// per-wave maxima alternate between two LDS rows.  Same f32 expressions as `suppresses` mode 2, the same survivors in the same
+// order as nms_f32_batched returns for keys = (score >= score_thr ? score : -1), up to the first below-threshold row.
+template <int PER>
+__global__ __launch_bounds__(256) void nms_greedy_f32_k(const float *__restrict__ boxes, const float *__restrict__ scores, int k,
+                                                        float score_thr, float iou_thr, int max_keep, int *__restrict__ out_idx,
+                                                        int *__restrict__ out_n) {
+    extern __shared__ __attribute__((aligned(16))) float4 sbox[];         // [k]
+    __shared__ u64 s_part[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    boxes += (size_t)blockIdx.x * k * 4; scores += (size_t)blockIdx.x * k;
+    out_idx += (size_t)blockIdx.x * k; out_n += blockIdx.x;
+    u64 key[PER];
+    float4 bx[PER];
+    float area[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int i = tid + 256 * j;
+        key[j] = 0ull;                                            // 0 = not a candidate / dead (a real key is never 0: only the bits of a NaN map to 0)
+        bx[j] = float4{0.f, 0.f, 0.f, 0.f};
+        if (i < k) {
+            bx[j] = *reinterpret_cast<const float4 *>(boxes + (size_t)i * 4);
+            sbox[i] = bx[j];
+            const float sc = scores[i];
+            if (sc >= score_thr) {                                // NaN: not a candidate (its key was -1 in the full sort as well)
+                const unsigned b = __float_as_uint(sc);
+                const unsigned mkey = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+                key[j] = ((u64)mkey << 32) | (unsigned)i;
+            }
+        }
+        area[j] = (bx[j].z - bx[j].x) * (bx[j].w - bx[j].y);
+    }
+    int n_keep = 0;
+    for (int it = 0; n_keep < max_keep; ++it) {
+        u64 best = key[0];
+#pragma unroll
+        for (int j = 1; j < PER; ++j) best = key[j] > best ? key[j] : best;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const u64 other = __shfl_xor(best, o, 64);
+            best = other > best ? other : best;
+        }
+        if (lane == 0) s_part[it & 1][wave] = best;
+        __syncthreads();                                          // (round 0: also orders the sbox writes above)
+        u64 b = s_part[it & 1][0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) { const u64 o = s_part[it & 1][w]; b = o > b ? o : b; }
+        if (b == 0ull) break;                                     // nothing live any more (uniform)
+        const int idx = (int)(unsigned)b;
+        if (tid == 0) out_idx[n_keep] = idx;
+        ++n_keep;
+        const float4 pv = sbox[idx];
+        const float ia = pv.x, ib = pv.y, ic = pv.z, id = pv.w;
+        const float iarea = (ic - ia) * (id - ib);
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            if (key[j] == b) key[j] = 0ull;                       // the survivor itself
+            if (key[j] != 0ull && iarea > 0.f && area[j] > 0.f) {
+                const float y0 = fmaxf(ia, bx[j].x), x0 = fmaxf(ib, bx[j].y), y1 = fminf(ic, bx[j].z), x1 = fminf(id, bx[j].w);
+                const float inter = fmaxf(y1 - y0, 0.f) * fmaxf(x1 - x0, 0.f);
+                if (inter / (iarea + area[j] - inter) > iou_thr) key[j] = 0ull;
+            }
+        }
+    }
+    if (tid == 0) *out_n = n_keep;
+}
+
 }  // namespace
 
 namespace ddk {
@@ -414,6 +488,23 @@ int nms_f32_batched(hipStream_t s, const float *boxes, const float *keys, int k,
     hipLaunchKernelGGL(nms_mask_k, dim3(words, dd_ceil_div(k, 4), batch), dim3(256), 0, s, sorted, k, words, (double)thr, 2, mask);
     DD_LAUNCH_CHECK();
     hipLaunchKernelGGL(nms_scan_k, dim3(batch), dim3(64), 0, s, mask, sidx, k, words, max_keep, out_idx, out_n);
+    DD_LAUNCH_CHECK();
+    return DD_OK;
+}
+
+// The SSD post-process form: `batch` problems of k <= 4096 boxes each, candidates = scores >= score_thr, at most max_keep
+// (1..64) survivors each; out_idx [batch][k], out_n [batch].  The survivors and their order are those nms_f32_batched returns
+// for keys = (score >= score_thr ? score : -1) up to the first below-threshold row.  No scratch.
+int nms_f32_select_batched(hipStream_t s, const float *boxes, const float *scores, int k, float score_thr, float iou_thr,
+                           int max_keep, int *out_idx, int *out_n, int batch) {
+    DD_REQUIRE(k > 0 && k <= MAXK && batch > 0 && max_keep > 0 && max_keep <= 64, DD_E_ARG,
+               "nms_f32_select_batched: k=%d batch=%d max_keep=%d", k, batch, max_keep);
+    const size_t lds = (size_t)k * sizeof(float4);
+    if (k <= 2048) hipLaunchKernelGGL(nms_greedy_f32_k<8>, dim3(batch), dim3(256), lds, s, boxes, scores, k, score_thr, iou_thr, max_keep, out_idx, out_n);
+    else {
+        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&nms_greedy_f32_k<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MAXK * sizeof(float4))));
+        hipLaunchKernelGGL(nms_greedy_f32_k<16>, dim3(batch), dim3(256), lds, s, boxes, scores, k, score_thr, iou_thr, max_keep, out_idx, out_n);
+    }
     DD_LAUNCH_CHECK();
     return DD_OK;
 }

@@ -14,6 +14,8 @@
 namespace ddk {
 int nms_f32(hipStream_t s, const float *boxes_yxyx, const float *keys, int k, float thr, int max_keep, int *out_idx,
             int *out_n, void *scratch, size_t scratch_bytes);
+int nms_f32_select_batched(hipStream_t s, const float *boxes, const float *scores, int k, float score_thr, float iou_thr,
+                           int max_keep, int *out_idx, int *out_n, int batch);
 int nms_f32_batched(hipStream_t s, const float *boxes, const float *keys, int k, float thr, int max_keep, int *out_idx,
                     int *out_n, void *scratch, size_t scratch_bytes, int batch);
 }
@@ -296,6 +298,12 @@ __global__ void counts_add_k(long long *__restrict__ acc, const long long *__res
 
 namespace ddk {
 
+// DD_NMS_SELECT=0: the op's NMS as a full sort of all anchors + nms_lazy_k (rounds 1-4) instead of nms_greedy_f32_k -- same rows, for A/B runs
+static bool nms_select_on() {
+    static const bool on = [] { const char *e = getenv("DD_NMS_SELECT"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 size_t ssd_post_scratch_bytes(int n_anchors, int batch) {
     const size_t per = (size_t)n_anchors;
     const size_t head = (size_t)batch * per * (4 * 4 + 4 + 4 + 4 + 4) + (size_t)batch * 4 + 512;
@@ -324,8 +332,11 @@ int ssd_postprocess(hipStream_t s, const float *raw, const float *anchors, int n
                        score_thr, d_boxes, d_score, d_cls, d_keys);
     DD_LAUNCH_CHECK();
     int rc;
-    if ((rc = nms_f32_batched(s, d_boxes, d_keys, n_anchors, iou_thr, max_det, d_keep, d_nkeep, d_nms, scratch_bytes - head,
-                              batch)) != DD_OK) return rc;
+    if (nms_select_on())
+        rc = nms_f32_select_batched(s, d_boxes, d_score, n_anchors, score_thr, iou_thr, max_det, d_keep, d_nkeep, batch);
+    else
+        rc = nms_f32_batched(s, d_boxes, d_keys, n_anchors, iou_thr, max_det, d_keep, d_nkeep, d_nms, scratch_bytes - head, batch);
+    if (rc != DD_OK) return rc;
     hipLaunchKernelGGL(ssd_gather_k, dim3(batch), dim3(64), 0, s, d_keep, d_nkeep, d_boxes, d_score, d_cls, score_thr, max_det,
                        n_anchors, boxes, classes, scores, count);
     DD_LAUNCH_CHECK();
@@ -350,8 +361,11 @@ int ssd_postprocess_decoded(hipStream_t s, const float *d_boxes, const float *d_
     int *d_nkeep = d_keep + per;
     const size_t head = ((per * 4 + (size_t)batch * 4) + 255) / 256 * 256;
     int rc;
-    if ((rc = nms_f32_batched(s, d_boxes, d_keys, n_anchors, iou_thr, max_det, d_keep, d_nkeep, p + head, scratch_bytes - head,
-                              batch)) != DD_OK) return rc;
+    if (nms_select_on())
+        rc = nms_f32_select_batched(s, d_boxes, d_score, n_anchors, score_thr, iou_thr, max_det, d_keep, d_nkeep, batch);
+    else
+        rc = nms_f32_batched(s, d_boxes, d_keys, n_anchors, iou_thr, max_det, d_keep, d_nkeep, p + head, scratch_bytes - head, batch);
+    if (rc != DD_OK) return rc;
     hipLaunchKernelGGL(ssd_gather_k, dim3(batch), dim3(64), 0, s, d_keep, d_nkeep, d_boxes, d_score, d_cls, score_thr, max_det,
                        n_anchors, boxes, classes, scores, count);
     DD_LAUNCH_CHECK();

@@ -247,3 +247,25 @@ def test_yolov5_plugin_loads_a_tflite_file(tmp_path):
     assert ra[1] == rb[1] and len(ra[1]) > 0
     np.testing.assert_array_equal(np.asarray(ra[0]), np.asarray(rb[0]))
     np.testing.assert_array_equal(np.asarray(ra[2]), np.asarray(rb[2]))
+
+
+def test_ssd_select_nms_matches_the_oracle_on_crafted_candidates():
+    """csrc/nms.hip nms_greedy_f32_k (no sort: max_detections rounds of a workgroup-wide arg-max over the live candidates + one IoU each) behind
+    dd_ssd_postprocess_decoded against oracle/nets_torch.ssd_postprocess_decoded (NonMaxSuppressionMultiClassFastHelper restated):
+    0 .. 1917 candidates, ties, NaN / degenerate boxes, max_detections 10 .. 64, chains that cross many 64-row chunks.  Bit-exact."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'scripts'))
+    from ssd_post_cases import cases, run_device
+    from oracle import nets_torch
+    cs = cases()
+    got = run_device(cs)
+    crossed = 0
+    for c, (gb, gc, gs, gn) in zip(cs, got):
+        ob, oc, os_, on = nets_torch.ssd_postprocess_decoded(c['boxes'], c['score'], c['cls'], c['max_det'], c['thr'], c['iou'])
+        assert gn == on, (gn, on, c['max_det'], c['thr'])
+        np.testing.assert_array_equal(gb[:on], ob[:on])
+        np.testing.assert_array_equal(gc[:on], oc[:on])
+        np.testing.assert_array_equal(gs[:on], os_[:on])
+        assert not gb[on:].any() and not gs[on:].any()
+        crossed += on < c['max_det'] and (c['score'] >= np.float32(c['thr'])).sum() > 128
+    assert crossed >= 2                                  # some cases end by exhausting several chunks, not by reaching max_detections

@@ -61,3 +61,9 @@ def test_yolo_and_image_switches_give_the_same_bits():
         assert _sha('time_forward.py', ['yolo', 3], env) == base, env
     base = _sha('time_resize.py', [24], {})
     assert _sha('time_resize.py', [24], {'DD_LANCZOS_FUSED': '0'}) == base
+
+
+def test_ssd_post_process_nms_forms_give_the_same_bits():
+    """dd_ssd_postprocess_decoded on the crafted cases of scripts/ssd_post_cases.py: the full sort + nms_lazy_k of rounds 1-4
+    (DD_NMS_SELECT=0) against nms_greedy_f32_k."""
+    assert _sha('ssd_post_cases.py', [], {'DD_NMS_SELECT': '0'}) == _sha('ssd_post_cases.py', [], {})
