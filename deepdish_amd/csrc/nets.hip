@@ -1625,7 +1625,7 @@ __global__ __launch_bounds__(512, 2) void res_pair_rows_k(const ConvP P1A, const
     __builtin_amdgcn_s_barrier();                                 // the rings are zero before the first row arrives
     asm volatile("" ::: "memory");
 #endif
-    if (role == 0 && K > 0) { fill_pre(-1); fill_pre(0); fill_pre(1); fill_pre(2); }
+    if (role == 0 && K > 0) { fill_pre(-1); fill_pre(0); fill_pre(1); fill_pre(2); fill_pre(3); fill_pre(4); }   // rounds 0 and 1
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -1689,7 +1689,9 @@ __global__ __launch_bounds__(512, 2) void res_pair_rows_k(const ConvP P1A, const
         const bool active = role ? (gr >= 0 && gr < GA) : (K > 0 && gr <= GA);   // A's round GA only writes the trailing padding row
         if (grC >= 0) { b_store(); grC = -1; }
         if (active) {
-            if (role == 0) { fill_pre(2 * gr + 3); fill_pre(2 * gr + 4); }
+            // A's input rows arrive TWO rounds ahead (the eight slots hold rows 2gr - 1 .. 2gr + 6: four being read, two landed, two in flight): a
+            // round is ~1.4 us, about one HBM round trip under load -- requested one round ahead, the wait at the end of the round still met them
+            if (role == 0) { fill_pre(2 * gr + 5); fill_pre(2 * gr + 6); }
             // ---- first layer: h1 stream rows 2gr, 2gr + 1 from input rows 2gr - 1 .. 2gr + 2
             {
                 f4 acc[2][2] = {{bA0, bA1}, {bA0, bA1}};
@@ -1742,7 +1744,7 @@ __global__ __launch_bounds__(512, 2) void res_pair_rows_k(const ConvP P1A, const
                         *reinterpret_cast<u4v_t *>(xo2 + ((s + 1) & (RP_X_SLOTS - 1)) * RU_SLOT + offC) = ou2;
                     }
 #if defined(__HIP_DEVICE_COMPILE__)
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next round's input rows have landed
+                    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // the next round's input rows have landed (this round's two requests may still be in flight; an A wave issues nothing else that counts)
 #endif
                 } else {                                            // B keeps its sums: their epilogue opens its NEXT round (see b_store)
 #pragma unroll
