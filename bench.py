@@ -474,6 +474,9 @@ def main():
                 for g in range(G)]
     torch.cuda.synchronize()
 
+    # DD_BENCH_STEP_TIMES=1: when each worker group finished each of its steps (stderr, after the run; a diagnostic, not part of the line)
+    step_times = [[] for _ in range(G)] if os.environ.get('DD_BENCH_STEP_TIMES') else None
+
     def run(g, f0, f1):
         torch.cuda.set_device(local_rank)                    # a fresh thread starts on device 0
         if ings is not None:
@@ -489,6 +492,8 @@ def main():
         for f in range(f0, f1):                                   # blocking C call, releases the GIL; the detector of
             pipes[g].step(dev_frames[g][f], injected[g][f],       # frame f+1 is queued behind this step's own detections
                           dev_frames[g][f + 1] if ahead and f + 1 < f1 else None)
+            if step_times is not None:
+                step_times[g].append(time.perf_counter())
 
     # Worker threads exist and have finished the warm-up before the clock starts: they park on `go`, the main thread
     # synchronises the device (and the ranks), takes t0 and releases them -- no thread start inside the timed region.
@@ -527,6 +532,10 @@ def main():
     dt = time.perf_counter() - t0
     if errors:
         raise errors[0]
+    if step_times is not None and rank == 0:
+        for g in range(G):
+            ts = step_times[g][args.warmup:]
+            print('group %d: ms per timed step: %s' % (g, ' '.join('%.1f' % (1e3 * (b - a)) for a, b in zip([t0] + ts[:-1], ts))), file=sys.stderr)
     stage_ms = pipes[0].stage_ms()
     local_counts = sum(p.counts().sum(axis=0) for p in pipes)
     tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
