@@ -1186,7 +1186,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rw_k(const ConvP P, const int 
 //   * the crop ring keeps rows 0..2 twice (rows 8..10), so the three image rows of a window are rows c, c+1, c+2 without a wrap;
 //   * pooling maxima are v_maximum3_f32 (gfx950): the IEEE maxnum form canonicalises loop-carried and pooled operands first
 //     (two extra v_max per maximum); the two differ only on NaN inputs.
-constexpr int PR_SLOTS = 8, PR_SLOT_HALVES = 1040, PR_CROP_PITCH = 104, PR_CROP_ROWS = 11;
+//   * crop-ring pitch 160 halves = 80 banks = 16 (mod 32): lane group fq reads ring row c + fq, and the 16 lanes of a group sit 3 banks
+//     apart (6 halves per pixel pair), so two groups of a 32-lane half are disjoint only at a row shift of 16 banks; at the tight pitch of
+//     104 halves 39 % of the kernel's LDS cycles were bank conflicts (SQ_LDS_BANK_CONFLICT), all of them these ds_read_u16 gathers.
+constexpr int PR_SLOTS = 8, PR_SLOT_HALVES = 1040, PR_CROP_PITCH = 160, PR_CROP_ROWS = 11;
 constexpr int pr_wave_halves(bool stem) { return 8 + PR_SLOTS * PR_SLOT_HALVES + (stem ? PR_CROP_ROWS * PR_CROP_PITCH : 0); }
 
 template <int ACT, bool STEM>
