@@ -37,6 +37,22 @@ enum { DT_F16 = 0, DT_F32 = 1, DT_U8 = 2 };
 constexpr int OP_WORDS = 48;       // int32 words per op record (see deepdish_amd/nets.py)
 constexpr int TENSOR_WORDS = 8;
 
+// 1 / (1 + exp(-v)) with v_rcp_f32 (1 ulp) instead of the correctly rounded quotient hipcc makes of `1.f / x` (v_div_scale x 2, v_rcp, four
+// v_fma, v_div_fmas, v_div_fixup: eleven instructions per element -- 6 355 such sequences in this file before; every YOLOv5 layer ends in a SiLU
+// and the conv kernels are bound by instruction issue).  The result is stored as f16 (SiLU) or compared at 2e-4 (Detect heads): the last f32
+// bit does not reach either.  Used by SiLU and by both forms of the YOLOv5 head (matrix and fused decode: the same bits between them).
+__device__ __forceinline__ float fast_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
+
+// YOLOv5 Detect box of one row (models/yolo.py Detect.forward as tools/yolov5.py consumes it): columns 0..3 of the decoded row from the four
+// sigmoids; one function with contraction off, called by the matrix epilogue and by the fused decode, so both round alike.
+__device__ __forceinline__ float yolo_box_col(int o, float s, float px, float py, float stride, float aw, float ah, float img_w, float img_h) {
+#pragma clang fp contract(off)
+    if (o == 0) return (s * 2.f - 0.5f + px) * stride / img_w;
+    if (o == 1) return (s * 2.f - 0.5f + py) * stride / img_h;
+    if (o == 2) return (s * 2.f) * (s * 2.f) * aw / img_w;
+    return (s * 2.f) * (s * 2.f) * ah / img_h;
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
         case ACT_RELU6: return __builtin_amdgcn_fmed3f(v, 0.f, 6.f);      // one v_med3_f32 (fmin(fmax()) costs an extra canonicalising v_max)
@@ -50,7 +66,16 @@ __device__ __forceinline__ float apply_act(float v, int act) {
             e = __builtin_amdgcn_fmed3f(e, 0.f, 1.f);
             return __builtin_amdgcn_fmed3f(v, e - 1.f, 3.0e38f);   // (with +inf hipcc rewrites the med3 as a max and canonicalises v first: a fifth instruction)
         }
-        case ACT_SILU: return v / (1.f + __expf(-v));
+        case ACT_SILU: {
+            // The product is pinned in a register: left to itself hipcc folds it into the f16 conversion that follows in SOME kernels
+            // (v_fma_mixlo_f16: one rounding instead of two) or into a residual add -- and two kernels that can run the same layer
+            // (the Focus fold, the row kernels, the tile variants) then differ in 2e-5 of their outputs.  A quotient could not fuse.
+            float r = v * fast_sigmoid(v);
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm("" : "+v"(r));
+#endif
+            return r;
+        }
         case ACT_RELU: return fmaxf(v, 0.f);
         case ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
         default: return v;
@@ -105,12 +130,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvP &P, int m, int co, flo
             if (ch >= P.cout) continue;
             const int no = P.p[0];                     // 5 + classes
             const int an = ch / no, o = ch - an * no;
-            const float s = 1.f / (1.f + __expf(-v[r]));
+            const float s = fast_sigmoid(v[r]);
             float val = s;
-            if (o == 0) val = (s * 2.f - 0.5f + (float)px) * P.f[6] / P.f[7];
-            else if (o == 1) val = (s * 2.f - 0.5f + (float)py) * P.f[6] / (float)P.p[4];
-            else if (o == 2) val = (s * 2.f) * (s * 2.f) * P.f[2 * an] / P.f[7];
-            else if (o == 3) val = (s * 2.f) * (s * 2.f) * P.f[2 * an + 1] / (float)P.p[4];
+            if (o < 4) val = yolo_box_col(o, s, (float)px, (float)py, P.f[6], P.f[2 * an], P.f[2 * an + 1], P.f[7], (float)P.p[4]);
             const size_t row = (size_t)n * P.p[1] + P.p[2] + (size_t)an * hw + p;
             static_cast<float *>(P.out)[row * no + o] = val;
         }
@@ -388,8 +410,9 @@ __device__ __forceinline__ void conv_finish(const ConvP &P, f4 (&acc)[NI][MI], _
             const f4 v = *reinterpret_cast<const f4 *>(ot + pl * OROW + lc) + bias;
             f4 val;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) val[q] = 1.f / (1.f + __expf(-v[q]));
+            for (int q = 0; q < 4; ++q) val[q] = fast_sigmoid(v[q]);
             if (any_box) {
+#pragma clang fp contract(off)                                    // yolo_box_col's operations in its order, un-fused like them
                 const int py = p / P.wo, px = p - py * P.wo;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -515,7 +538,7 @@ __device__ __forceinline__ void yolo_head_finish(const ConvP &P, f4 (&acc)[NI][M
     const int no = P.p[0], C = no - 5;
     const float *row = ot + pl * OROW;
     const float *bias = P.bias + n0;
-    const float sobj = 1.f / (1.f + __expf(-(row[4] + bias[4])));
+    const float sobj = fast_sigmoid(row[4] + bias[4]);
     float best = -__builtin_inff();
     int bi = 0x7fffffff, nan_i = 0x7fffffff;
     const int half = (C + 1) >> 1;                              // lane h scans classes [h * half, min(C, h * half + half)), ascending
@@ -526,7 +549,7 @@ __device__ __forceinline__ void yolo_head_finish(const ConvP &P, f4 (&acc)[NI][M
         for (int q = 0; q < 4; ++q) {
             const int ci = c4 + q - 5;
             if (ci < c_lo || ci >= c_hi) continue;
-            const float pq = (1.f / (1.f + __expf(-v[q]))) * sobj;
+            const float pq = fast_sigmoid(v[q]) * sobj;
             if (pq != pq) nan_i = min(nan_i, ci);
             if (pq > best) { best = pq; bi = ci; }
         }
@@ -545,12 +568,10 @@ __device__ __forceinline__ void yolo_head_finish(const ConvP &P, f4 (&acc)[NI][M
         const f4 rv = *reinterpret_cast<const f4 *>(row) + *reinterpret_cast<const f4 *>(bias);
         float sg[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) sg[q] = 1.f / (1.f + __expf(-rv[q]));
+        for (int q = 0; q < 4; ++q) sg[q] = fast_sigmoid(rv[q]);
         f4 bx;
-        bx[0] = (sg[0] * 2.f - 0.5f + (float)px) * P.f[6] / P.f[7];
-        bx[1] = (sg[1] * 2.f - 0.5f + (float)py) * P.f[6] / (float)P.p[4];
-        bx[2] = (sg[2] * 2.f) * (sg[2] * 2.f) * P.f[2 * an] / P.f[7];
-        bx[3] = (sg[3] * 2.f) * (sg[3] * 2.f) * P.f[2 * an + 1] / (float)P.p[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bx[q] = yolo_box_col(q, sg[q], (float)px, (float)py, P.f[6], P.f[2 * an], P.f[2 * an + 1], P.f[7], (float)P.p[4]);
         *reinterpret_cast<f4 *>(P.dec_boxes + r * 4) = bx;
         const bool has_nan = nan_i != 0x7fffffff;
         P.dec_score[r] = has_nan ? __builtin_nanf("") : best;
