@@ -31,7 +31,7 @@ enum { OP_INPUT = 1, OP_CONV = 2, OP_DWCONV = 3, OP_MAXPOOL = 4, OP_UPSAMPLE = 5
 enum { ACT_NONE = 0, ACT_RELU6 = 1, ACT_ELU = 2, ACT_SILU = 3, ACT_RELU = 4, ACT_SIGMOID = 5 };
 enum { EPI_F16 = 0, EPI_F32 = 1, EPI_SSD_HEAD = 2, EPI_YOLO = 3 };
 // dd_net_op_launches: 0 = the op's own kernel, 1 = no launch (folded into the next op's), else the fused / special kernel
-enum { OPK_DEFAULT = 0, OPK_FOLDED = 1, OPK_POOL_ROWS = 2, OPK_POOL_ROWS_STEM = 3, OPK_RES_UNIT = 4, OPK_SSD_FRONT = 5, OPK_C64_ROWS = 6, OPK_S2_ROWS = 7, OPK_CONV_WS = 8, OPK_WS_DW = 9, OPK_DWPW_ROWS = 10, OPK_SSD_HEAD_DEC = 11, OPK_RES_PAIR = 12, OPK_YOLO_HEAD_DEC = 13, OPK_MARS_WS = 14, OPK_FOLDED_PREV = 15, OPK_MARS_PAIR = 16 };
+enum { OPK_DEFAULT = 0, OPK_FOLDED = 1, OPK_POOL_ROWS = 2, OPK_POOL_ROWS_STEM = 3, OPK_RES_UNIT = 4, OPK_SSD_FRONT = 5, OPK_C64_ROWS = 6, OPK_S2_ROWS = 7, OPK_CONV_WS = 8, OPK_WS_DW = 9, OPK_DWPW_ROWS = 10, OPK_SSD_HEAD_DEC = 11, OPK_RES_PAIR = 12, OPK_YOLO_HEAD_DEC = 13, OPK_MARS_WS = 14, OPK_FOLDED_PREV = 15, OPK_MARS_PAIR = 16, OPK_C64_STRIPS = 18 };   // (17: q_dwm_k, csrc/netsq.hip)
 enum { DT_F16 = 0, DT_F32 = 1, DT_U8 = 2 };
 
 constexpr int OP_WORDS = 48;       // int32 words per op record (see deepdish_amd/nets.py)
@@ -229,7 +229,7 @@ __device__ __forceinline__ Epi8 epi8_load(const ConvP &P, int co) {
 
 // ACT >= 0: the activation is known at compile time (the per-element switch on P.act would otherwise be
 // compiled into a chain of branches around every value).
-// EF (epilogue flavour) 0: no residual, no second output; 1: both; -1: whatever P says.
+// EF (epilogue flavour) 0: no residual, no second output; 1: both; 2: residual only; -1: whatever P says.
 #ifndef DD_EPI_NT
 #define DD_EPI_NT true
 #endif
@@ -239,7 +239,7 @@ __device__ __forceinline__ void conv_epilogue_f16x8(const ConvP &P, const Epi8 &
     // load issued here cannot be moved above the stores of the caller's previous pixel (they may alias), so a loop of
     // epilogues would pay one memory round trip per pixel
     const int act = ACT < 0 ? P.act : ACT;
-    const bool has_res = EF < 0 ? P.res != nullptr : EF == 1, has_out2 = EF < 0 ? P.out2 != nullptr : EF == 1;
+    const bool has_res = EF < 0 ? P.res != nullptr : EF >= 1, has_out2 = EF < 0 ? P.out2 != nullptr : EF == 1;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         v[r] = apply_act(BIAS ? v[r] + E.b0[r] : v[r], act);
@@ -1808,8 +1808,12 @@ __global__ __launch_bounds__(512, 2) void res_pair_rows_k(const ConvP P1A, const
 constexpr int C64_PITCH = 704, C64_SLOTS = 11, C64_RES_SLOTS = 4, C64_LEAD = 3;   // 11: 4 rows being read + up to 7 requested (a group that crosses an image boundary)
 constexpr int c64_wave_halves() { return C64_SLOTS * C64_PITCH + C64_RES_SLOTS * 512; }
 
-template <int ACT, int EF>                                      // EF 0: plain layer; 1: residual input and second output
-__global__ __launch_bounds__(256, 2) void conv3x3_c64_rows_k(const ConvP P, const int n_img) {
+// STRIP: the same kernel on maps wider than 8 pixels (YOLOv5's 3x3 64 -> 64 layers, 80 pixels wide): a work item is an 8-column strip of an
+// image instead of an image -- its two pad slots take the neighbouring strips' pixels (the zero line only at the image's own border), its
+// pixels sit W, not 8, apart in memory; everything else (the row stream with a shared zero row between items, the ring, the counted waits,
+// the summation order) is the 8-wide kernel.  Each strip re-reads two of ten columns (L2 hits: the neighbours run on the same CU or XCD).
+template <int ACT, int EF, bool STRIP = false>                  // EF 0: plain layer; 1: residual input and second output; 2: residual only
+__global__ __launch_bounds__(256, 2) void conv3x3_c64_rows_k(const ConvP P, const int n_img) {          // n_img: work items (images, or strips of images)
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1817,6 +1821,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_rows_k(const ConvP P, cons
     const int j = fr >> 3, x = fr & 7;                            // fragment pixel: row j of the pair, column x
     _Float16 *ring = lds + (size_t)wave * c64_wave_halves(), *resr = ring + C64_SLOTS * C64_PITCH;
     const int H = P.H, S = H + 1, RPI = H / 2;                    // stream rows / rounds per image
+    constexpr int NRES = EF ? 1 : 0;                              // residual DMAs per round
+    (void)NRES;
+    const int NSX = STRIP ? P.W >> 3 : 1;                         // strips per image
 
     const int half = wave & 1;                                    // a wave keeps its channel half for the whole launch: one filter load
     h8 wf[9][2][2];                                               // [tap][k slice][fragment]
@@ -1835,48 +1842,64 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_rows_k(const ConvP P, cons
 
     // per-lane constants of the two row DMAs (chunk c = 16 * c2 + lane -> plane c / 10, pixel slot c % 10)
     int dma_off[2];
-    bool dma_px[2];
+    bool dma_px[2], dma_l[2], dma_r[2];
 #pragma unroll
     for (int c2 = 0; c2 < 2; ++c2) {
         const int c = 16 * c2 + lane, pl = c / 10, sl = c - pl * 10;
         dma_px[c2] = sl >= 1 && sl <= 8;
+        dma_l[c2] = sl == 0; dma_r[c2] = sl == 9;
         dma_off[c2] = (sl - 1) * P.cs_in + pl * 8;
     }
     int dq = 0, dq_slot = 0, dq_k = 0, dq_y = -1;                 // next stream row to request: its ring slot, image, map row
+    int dq_f = n0 / NSX, dq_sx = n0 - dq_f * NSX;                 // STRIP: image and strip of item n0 + dq_k * nstep
     auto issue_row = [&]() {                                      // past the stream / between images: zero lines
         const bool rok = dq < T && dq_y >= 0;
-        const _Float16 *row = P.in + ((size_t)(n0 + dq_k * nstep) * H + (rok ? dq_y : 0)) * 8 * P.cs_in + P.coff_in;
+        const _Float16 *row = STRIP ? P.in + (((size_t)dq_f * H + (rok ? dq_y : 0)) * P.W + dq_sx * 8) * P.cs_in + P.coff_in
+                                    : P.in + ((size_t)(n0 + dq_k * nstep) * H + (rok ? dq_y : 0)) * 8 * P.cs_in + P.coff_in;
         _Float16 *dst = ring + dq_slot * C64_PITCH;
         // two full-wave DMAs: chunks 0..63 and 16..79 (48 chunks twice, with the same bytes).  A DMA under a divergent
         // `if (lane < 16)` is not safe: hipcc threads consecutive such branches and the copies of the wave-wide DMA
         // between them then take M0 from readfirstlane of a per-path value -- one path's lanes land in another row.
 #pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2) lds_fill16(rok && dma_px[c2] ? row + dma_off[c2] : P.zero, dst + 128 * c2);
+        for (int c2 = 0; c2 < 2; ++c2) {
+            const bool ok = rok && (dma_px[c2] || (STRIP && ((dma_l[c2] && dq_sx > 0) || (dma_r[c2] && dq_sx + 1 < NSX))));
+            lds_fill16(ok ? row + dma_off[c2] : P.zero, dst + 128 * c2);
+        }
         ++dq;
         dq_slot = dq_slot + 1 == C64_SLOTS ? 0 : dq_slot + 1;
-        if (++dq_y == H) { dq_y = -1; ++dq_k; }
+        if (++dq_y == H) {
+            dq_y = -1; ++dq_k;
+            if constexpr (STRIP) { const int it = n0 + dq_k * nstep; dq_f = it / NSX; dq_sx = it - dq_f * NSX; }
+        }
     };
     int ga_k = 0, ga_r = 0;                                       // round q + LEAD: image, round inside the image
+    int ga_f = n0 / NSX, ga_sx = n0 - ga_f * NSX;
     const int res_px = lane & 15, res_c = lane >> 4;
     auto issue_group = [&](int qa) {                              // what round qa = q + LEAD needs: rows up to its last, its residual rows
         const int last = ga_k * S + 2 * ga_r + 3;
         while (dq <= last) issue_row();                           // 2 rows, 3 when round qa opens an image (first group: 4)
-        if constexpr (EF == 1) {                                  // residual rows 2 ga_r, 2 ga_r + 1 of image ga_k: [chunk fq][pixel] x 16 B
+        if constexpr (EF != 0) {                                  // residual rows 2 ga_r, 2 ga_r + 1 of image ga_k: [chunk fq][pixel] x 16 B
             const bool ok = qa < Q;
-            const _Float16 *src = P.res + ((size_t)((n0 + ga_k * nstep) * H + 2 * ga_r) * 8 + res_px) * P.cs_res + P.coff_res + half * 32 + res_c * 8;
+            const _Float16 *src = STRIP ? P.res + ((((size_t)ga_f * H + 2 * ga_r + (res_px >> 3)) * P.W + ga_sx * 8 + (res_px & 7))) * P.cs_res + P.coff_res + half * 32 + res_c * 8
+                                        : P.res + ((size_t)((n0 + ga_k * nstep) * H + 2 * ga_r) * 8 + res_px) * P.cs_res + P.coff_res + half * 32 + res_c * 8;
             lds_fill16(ok ? src : P.zero, resr + (qa & (C64_RES_SLOTS - 1)) * 512);
         }
-        if (++ga_r == RPI) { ga_r = 0; ++ga_k; }
+        if (++ga_r == RPI) {
+            ga_r = 0; ++ga_k;
+            if constexpr (STRIP) { const int it = n0 + ga_k * nstep; ga_f = it / NSX; ga_sx = it - ga_f * NSX; }
+        }
     };
     for (int qa = 0; qa < C64_LEAD; ++qa) issue_group(qa);
     int k = 0, r = 0, bslot = 0;                                  // this round: image, round inside it, ring slot of its first row (map row 2r - 1)
+    int k_f = n0 / NSX, k_sx = n0 - k_f * NSX;
     for (int q = 0; q < Q; ++q) {
         issue_group(q + C64_LEAD);
 #if defined(__HIP_DEVICE_COMPILE__)
-        if (q < C64_LEAD) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(C64_LEAD * (4 + EF)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(C64_LEAD * (4 + EF) + C64_LEAD * (1 + EF)) : "memory");
+        if (q < C64_LEAD) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(C64_LEAD * (4 + NRES)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(C64_LEAD * (4 + NRES) + C64_LEAD * (1 + (EF == 1 ? 1 : 0))) : "memory");
 #endif
-        const int m = ((n0 + k * nstep) * H + 2 * r + j) * 8 + x; // this lane's output pixel
+        const int m = STRIP ? ((k_f * H + 2 * r + j) * P.W + k_sx * 8 + x)
+                            : ((n0 + k * nstep) * H + 2 * r + j) * 8 + x; // this lane's output pixel
         f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
         const _Float16 *rowp[3];                                   // this lane's row of filter row dy: stream row first + dy + j
         {
@@ -1918,15 +1941,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_rows_k(const ConvP P, cons
 #endif
         }
         h8 rp;
-        if constexpr (EF == 1) rp = *reinterpret_cast<const h8 *>(resr + (q & (C64_RES_SLOTS - 1)) * 512 + (fq * 16 + fr) * 8);
+        if constexpr (EF != 0) rp = *reinterpret_cast<const h8 *>(resr + (q & (C64_RES_SLOTS - 1)) * 512 + (fq * 16 + fr) * 8);
         float o[8];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { o[i] = acc[0][i]; o[4 + i] = acc[1][i]; }
-        conv_epilogue_f16x8<ACT, true, EF, true, false>(P, E, m, half * 32 + fq * 8, o, EF == 1 ? &rp : nullptr);
+        conv_epilogue_f16x8<ACT, true, EF, true, false>(P, E, m, half * 32 + fq * 8, o, EF != 0 ? &rp : nullptr);
         // next round: two rows on, three across an image boundary
         const int adv = r + 1 == RPI ? 3 : 2;
         bslot += adv; if (bslot >= C64_SLOTS) bslot -= C64_SLOTS;
-        if (++r == RPI) { r = 0; ++k; }
+        if (++r == RPI) {
+            r = 0; ++k;
+            if constexpr (STRIP) { const int it = n0 + k * nstep; k_f = it / NSX; k_sx = it - k_f * NSX; }
+        }
     }
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the look-ahead DMAs past the last round
@@ -3820,6 +3846,35 @@ int launch_conv3x3_s2_rows(hipStream_t s, const ConvP &P, int nimg, int device) 
     return DD_OK;
 }
 
+// YOLOv5's 3x3 64 -> 64 layers (80 x 80 maps, SiLU, with or without the bottleneck's shortcut) as 8-column strips of conv3x3_c64_rows_k
+bool c64_strips_eligible(const ConvP &P, int nimg, int max_batch) {
+    static const bool off = getenv("DD_C64_STRIPS_OFF") && atoi(getenv("DD_C64_STRIPS_OFF")) != 0;
+    static const int min_items = getenv("DD_C64_STRIPS_MIN") ? atoi(getenv("DD_C64_STRIPS_MIN")) : 1024;      // two items per wave slot of the chip
+    return !off && P.kh == 3 && P.kw == 3 && P.stride == 1 && P.pad_t == 1 && P.pad_l == 1 && P.cin == 64 && P.cout == 64 &&
+           P.cout_pad == 64 && P.kpad == 576 && P.epi == EPI_F16 && P.W > 8 && P.W % 8 == 0 && P.wo == P.W && P.H == P.ho && P.H % 2 == 0 &&
+           P.splitk <= 1 && P.act == ACT_SILU && !P.out2 && (!P.res || (P.cs_res % 8 == 0 && P.coff_res % 8 == 0)) &&
+           P.cs_in % 8 == 0 && P.coff_in % 8 == 0 && (long long)nimg * (P.W >> 3) >= min_items &&
+           (long long)dd_ceil_div(max_batch * P.ho * P.wo, 64) >= 256;    // launch_conv would not split K for this engine: same summation order
+}
+
+int launch_conv3x3_c64_strips(hipStream_t s, const ConvP &P, int nimg, int device) {
+    constexpr size_t lds_bytes = (size_t)4 * c64_wave_halves() * sizeof(_Float16);
+    static DevOnce once;
+    const int rc = once.run(device, [&]() -> int {
+        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_c64_rows_k<ACT_SILU, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_c64_rows_k<ACT_SILU, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        return DD_OK;
+    });
+    if (rc != DD_OK) return rc;
+    const long long items = (long long)nimg * (P.W >> 3);
+    DD_REQUIRE(items * P.H * 8 < (1LL << 31), DD_E_CAPACITY, "conv3x3_c64 strips: %lld items exceed 32-bit pixel indexing", items);
+    const int grid = (int)std::min<long long>((items + 1) / 2, 2 * 256);      // a block: two items x two channel halves
+    if (P.res) hipLaunchKernelGGL((conv3x3_c64_rows_k<ACT_SILU, 2, true>), dim3((unsigned)grid), dim3(256), lds_bytes, s, P, (int)items);
+    else hipLaunchKernelGGL((conv3x3_c64_rows_k<ACT_SILU, 0, true>), dim3((unsigned)grid), dim3(256), lds_bytes, s, P, (int)items);
+    DD_LAUNCH_CHECK();
+    return DD_OK;
+}
+
 bool c64_rows_eligible(const ConvP &P, int nimg, int max_batch) {
     static const bool off = getenv("DD_C64_ROWS_OFF") && atoi(getenv("DD_C64_ROWS_OFF")) != 0;
     static const int min_img = getenv("DD_C64_ROWS_MIN") ? atoi(getenv("DD_C64_ROWS_MIN")) : 512;
@@ -4858,6 +4913,9 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
                 } else if (c64_rows_eligible(P, nimg, net->max_batch)) {
                     net->op_launch[i] = OPK_C64_ROWS;
                     rc = launch_conv3x3_c64_rows(s, P, nimg, net->ctx->device);
+                } else if (c64_strips_eligible(P, nimg, net->max_batch)) {
+                    net->op_launch[i] = OPK_C64_STRIPS;
+                    rc = launch_conv3x3_c64_strips(s, P, nimg, net->ctx->device);
                 } else if (ws_eligible(P) && o[30] && i + 1 < net->n_ops && P.act == ACT_RELU6) {
                     pw_p = P; pw_pending = true; net->op_launch[i] = OPK_FOLDED;     // o[30]: only the next (depthwise) op reads this output
                     break;

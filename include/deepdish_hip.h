@@ -266,7 +266,7 @@ int dd_net_profile_read(dd_net *net, float *ms_host, int cap, int *n_ops_host);
  * 2 conv3x3_pool_rows_k, 3 conv3x3_pool_rows_k with the first layer folded in, 4 res_unit_rows_k, 5 ssd_front_k,
  * 6 conv3x3_c64_rows_k, 7 conv3x3_s2_rows_k, 8 conv_ws_k, 9 conv_ws_dw_k, 10 dwpw_rows_k, 11 SSD head with the decode in its
  * epilogue, 12 res_pair_rows_k, 13 YOLOv5 Detect head with the row reduction in its epilogue, 14 mars_ws128_k, 15 none (the op ran
- * inside the previous op's launch), 16 mars_pair64_k, 17 q_dwm_k -- so that a per-kernel time table attributes a fused launch to the kernel that ran. */
+ * inside the previous op's launch), 16 mars_pair64_k, 17 q_dwm_k, 18 conv3x3_c64_rows_k on 8-column strips -- so that a per-kernel time table attributes a fused launch to the kernel that ran. */
 int dd_net_op_launches(dd_net *net, int32_t *codes_host, int cap, int *n_ops_host);
 
 /* TFLite_Detection_PostProcess (inside the reference's .tflite graph, tools/ssd_mobilenet.py:103-109):

@@ -57,7 +57,8 @@ def test_yolo_and_image_switches_give_the_same_bits():
     """YOLOv5s forward at 3 frames with the Focus slicing as its own launch / as a 16-channel tensor; the batched Lanczos
     stretch in two launches; (the crop kernel's two forms are compared through the pipeline tests' golden scenes)."""
     base = _sha('time_forward.py', ['yolo', 3], {})
-    for env in ({'DD_FOCUS_UNFUSED': '1'}, {'DD_YOLO_FOCUS_FUSE': '0'}, {'DD_YOLO_SPP_FUSE': '0'}):
+    for env in ({'DD_FOCUS_UNFUSED': '1'}, {'DD_YOLO_FOCUS_FUSE': '0'}, {'DD_YOLO_SPP_FUSE': '0'},
+                {'DD_C64_STRIPS_MIN': '1'}):                         # the 3x3 64 -> 64 layers as 8-column strips of the weight-stationary row kernel (from 1024 strips by default)
         assert _sha('time_forward.py', ['yolo', 3], env) == base, env
     base = _sha('time_resize.py', [24], {})
     assert _sha('time_resize.py', [24], {'DD_LANCZOS_FUSED': '0'}) == base
