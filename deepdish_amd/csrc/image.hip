@@ -610,6 +610,19 @@ __global__ __launch_bounds__(256) void copy_rgb_k(const uint8_t *__restrict__ sr
     d[0] = s[swap_rb ? 2 : 0]; d[1] = s[1]; d[2] = s[swap_rb ? 0 : 2];
 }
 
+// The same for packed 3-byte pixels with the red / blue swap, four pixels (three dwords) per thread: the byte kernel above issues six
+// single-byte memory instructions per pixel and moved a 640x640 batch at 2.1 TB/s (config 3: 298 us per 256 frames, 2.5 % of a step).
+__global__ __launch_bounds__(256) void copy_swap_rb4_k(const uint32_t *__restrict__ src, int n_quads, uint32_t *__restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_quads) return;
+    const size_t o = ((size_t)blockIdx.y * n_quads + i) * 3;
+    const uint32_t w0 = src[o], w1 = src[o + 1], w2 = src[o + 2];      // p0c0 p0c1 p0c2 p1c0 | p1c1 p1c2 p2c0 p2c1 | p2c2 p3c0 p3c1 p3c2
+    const uint32_t t = __builtin_amdgcn_perm(w1, w0, 0x070c0304u);     // p1c1 p1c0 . p2c1
+    dst[o] = __builtin_amdgcn_perm(w1, w0, 0x05000102u);               // p0c2 p0c1 p0c0 p1c2
+    dst[o + 1] = __builtin_amdgcn_perm(w2, t, 0x03040100u);            // p1c1 p1c0 p2c2 p2c1
+    dst[o + 2] = __builtin_amdgcn_perm(w2, w1, 0x05060702u);           // p2c0 p3c2 p3c1 p3c0
+}
+
 // tools/generate_detections.py:86-116 -- the reference's model-free test encoders.
 // mode 0 (DummyImageEncoder): patches u8 [n][16][8][3] -> mean over the 3 channels -> 128 values - 128
 // -> L2-normalised (e0 when the norm is 0).  mode 1 (ConstantImageEncoder): e0.  One wave per patch.
@@ -959,7 +972,11 @@ int resize_lanczos(hipStream_t s, int device, const uint8_t *src, int H, int W, 
         mid_c = 3;
     } else if (src_c != 3 || swap_rb) {
         uint8_t *o = (h != H) ? tmp : dst;
-        hipLaunchKernelGGL(copy_rgb_k, dim3(dd_ceil_div(H * W, 256), batch), dim3(256), 0, s, src, H * W, src_c, swap_rb, o);
+        if (src_c == 3 && swap_rb && (H * W) % 4 == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(o)) & 3) == 0)
+            hipLaunchKernelGGL(copy_swap_rb4_k, dim3(dd_ceil_div(H * W / 4, 256), batch), dim3(256), 0, s, reinterpret_cast<const uint32_t *>(src),
+                               H * W / 4, reinterpret_cast<uint32_t *>(o));
+        else
+            hipLaunchKernelGGL(copy_rgb_k, dim3(dd_ceil_div(H * W, 256), batch), dim3(256), 0, s, src, H * W, src_c, swap_rb, o);
         DD_LAUNCH_CHECK();
         mid = o;
         mid_c = 3;

@@ -757,7 +757,7 @@ __device__ __forceinline__ void lds_fill16(const _Float16 *g, _Float16 *lds_wave
 // FM (fill mode) 1: 1x1, stride 1, no padding, Cin % 64 == 0 -- the pixel operand is a plain row-major matrix: no
 // tap walk, no bounds tests; 2: up to 3x3 with Cin % 64 == 0 -- a K step lies inside one filter tap, the same one
 // for every lane, so the tap walk is scalar and a lane does one add and a two-bit test per row group; 0: anything
-// else.  (The general per-lane walk costs more issue slots per K step than the MFMAs: 19x19x512 -> 512 went
+// else.  (A scalar walk over tap PAIRS for Cin = 32 -- YOLOv5's 3x3 stride-2 32 -> 64 layer -- changed nothing: 399 -> 407 us at 128 frames.)  (The general per-lane walk costs more issue slots per K step than the MFMAs: 19x19x512 -> 512 went
 // 24.9 -> 21.8 us with FM 1, the MARS 16x8x64 -> 64 layers 28.8 -> 24.5 us with FM 2.)
 template <int WM, int WN, int MI, int NI, int FM = 0, int DEC = 0>       // DEC: one anchor per 96-channel tile, decode in the epilogue (1 SSD head, 2 YOLOv5 Detect)
 __global__ __launch_bounds__(WM *WN * 64, 2) void conv_glds_k(const ConvP P) {

@@ -101,7 +101,8 @@ def test_lanczos_batch_one_launch_vs_pillow(ctx):
     from deepdish_amd.runtime import ptr
     rng = np.random.default_rng(5)
     for (H, W, h, w, n) in ((480, 640, 300, 300, 7), (480, 640, 320, 320, 2), (480, 640, 320, 512, 2),      # the third: one 64-byte window step
-                            (512, 512, 128, 200, 2), (720, 1280, 300, 300, 2)):
+                            (512, 512, 128, 200, 2), (720, 1280, 300, 300, 2),
+                            (640, 640, 640, 640, 3), (33, 35, 33, 35, 2)):      # same size: only the red / blue swap (four pixels per thread; 33 x 35 is not a multiple of four: byte kernel)
         frames = rng.integers(0, 256, (n, H, W, 3), dtype=np.uint8)
         frames[1] = 255
         if n > 3:
