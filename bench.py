@@ -41,7 +41,8 @@ CONFIGS = {
     2: dict(W=640, H=480, model='synthetic-ssd_mobilenet_v1', streams=3072, groups=4,
             workload='SSD-MobileNet-v1 (300x300) + MARS-64x32x3 + deep_sort on synthetic 640x480 BGR frames, '
                      '~20 synthetic detections/frame (BASELINE.json configs[1])'),
-    3: dict(W=640, H=640, model='synthetic-yolov5s-fp16', streams=512, groups=2,
+    # (round 5, same box, 20 steps: 2 x 256 streams 21.9 k frames/s, 3 x 256 22.2 k, 2 x 512 and 4 x 256 22.5 k)
+    3: dict(W=640, H=640, model='synthetic-yolov5s-fp16', streams=1024, groups=4,
             workload='YOLOv5s-f16 (640x640) + HIP NMS / IoU + MARS-64x32x3 + deep_sort on synthetic 640x640 BGR frames, '
                      '~20 synthetic detections/frame (BASELINE.json configs[2])'),
     5: dict(W=1280, H=720, model='synthetic-ssd_mobilenet_v1', streams=1, groups=1,
