@@ -31,7 +31,7 @@ enum { OP_INPUT = 1, OP_CONV = 2, OP_DWCONV = 3, OP_MAXPOOL = 4, OP_UPSAMPLE = 5
 enum { ACT_NONE = 0, ACT_RELU6 = 1, ACT_ELU = 2, ACT_SILU = 3, ACT_RELU = 4, ACT_SIGMOID = 5 };
 enum { EPI_F16 = 0, EPI_F32 = 1, EPI_SSD_HEAD = 2, EPI_YOLO = 3 };
 // dd_net_op_launches: 0 = the op's own kernel, 1 = no launch (folded into the next op's), else the fused / special kernel
-enum { OPK_DEFAULT = 0, OPK_FOLDED = 1, OPK_POOL_ROWS = 2, OPK_POOL_ROWS_STEM = 3, OPK_RES_UNIT = 4, OPK_SSD_FRONT = 5, OPK_C64_ROWS = 6, OPK_S2_ROWS = 7, OPK_CONV_WS = 8, OPK_WS_DW = 9, OPK_DWPW_ROWS = 10, OPK_SSD_HEAD_DEC = 11, OPK_RES_PAIR = 12, OPK_YOLO_HEAD_DEC = 13, OPK_MARS_WS = 14, OPK_FOLDED_PREV = 15, OPK_MARS_PAIR = 16, OPK_C64_STRIPS = 18 };   // (17: q_dwm_k, csrc/netsq.hip)
+enum { OPK_DEFAULT = 0, OPK_FOLDED = 1, OPK_POOL_ROWS = 2, OPK_POOL_ROWS_STEM = 3, OPK_RES_UNIT = 4, OPK_SSD_FRONT = 5, OPK_C64_ROWS = 6, OPK_S2_ROWS = 7, OPK_CONV_WS = 8, OPK_WS_DW = 9, OPK_DWPW_ROWS = 10, OPK_SSD_HEAD_DEC = 11, OPK_RES_PAIR = 12, OPK_YOLO_HEAD_DEC = 13, OPK_MARS_WS = 14, OPK_FOLDED_PREV = 15, OPK_MARS_PAIR = 16, OPK_C64_STRIPS = 18, OPK_Q_FRONT = 19 };   // (17: q_dwm_k, csrc/netsq.hip; 19: q_front_k, csrc/netsq_front.hip)
 enum { DT_F16 = 0, DT_F32 = 1, DT_U8 = 2 };
 
 constexpr int OP_WORDS = 48;       // int32 words per op record (see deepdish_amd/nets.py)
@@ -4694,7 +4694,19 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
         // output where the whole-batch launch would.
         static const int chunk_env = getenv("DD_Q_FRONT_CHUNK") ? atoi(getenv("DD_Q_FRONT_CHUNK")) : 0;
         auto opw = [&](int k) { return net->prog.data() + net->ops_off + (size_t)k * OP_WORDS; };
-        if (chunk_env > 0 && nimg > chunk_env && net->n_ops > 3 && opw(0)[0] == 16 && opw(1)[0] == 19 && opw(2)[0] == 19 && opw(1)[1] == opw(0)[2] && opw(2)[1] == opw(1)[2]) {
+        // uint8 SSD: the same three ops as ONE launch, the two tensors between them in LDS rings (csrc/netsq_front.hip).  DD_Q_FRONT=0: the three
+        // launches; DD_Q_FRONT_MIN: frames per forward from which the row pipeline runs (a few frames spread better as three wide launches).  Read on
+        // every forward: a test flips them between two forwards of one engine.
+        const char *front_env = getenv("DD_Q_FRONT"), *front_min_env = getenv("DD_Q_FRONT_MIN");
+        const int front_min = front_min_env ? atoi(front_min_env) : 24;
+        if (!(front_env && atoi(front_env) == 0) && chunk_env <= 0 && nimg >= front_min && net->n_ops > 3 && opw(0)[0] == 16 && opw(1)[0] == 19 && opw(2)[0] == 19) {
+            if (net->profile) for (int k = 0; k < 3; ++k) DD_HIP(hipEventRecord(net->events[k], s));
+            int ran = 0;
+            const int rc = netq_run_front(net, opw(0), opw(1), opw(2), input, nimg, s, &ran);
+            if (rc != DD_OK) return rc;
+            if (ran) { first_op = 3; net->op_launch[0] = OPK_FOLDED; net->op_launch[1] = OPK_FOLDED; net->op_launch[2] = OPK_Q_FRONT; }
+        }
+        if (first_op == 0 && chunk_env > 0 && nimg > chunk_env && net->n_ops > 3 && opw(0)[0] == 16 && opw(1)[0] == 19 && opw(2)[0] == 19 && opw(1)[1] == opw(0)[2] && opw(2)[1] == opw(1)[2]) {
             const TensorDesc &t2 = net->tensors[opw(2)[2]];
             const size_t img_out = (size_t)(t2.h + 2) * (t2.w + 2) * t2.cs;          // bordered uint8 layout: bytes per image
             void *&out_buf = net->bufs[t2.buf];

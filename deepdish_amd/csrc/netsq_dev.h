@@ -1,0 +1,125 @@
+// Device-side arithmetic shared by the uint8 executors (csrc/netsq.hip, csrc/netsq_front.hip): vector types, the requantisation
+// parameters of one layer and the requantise-and-pack forms.  See the header comment of csrc/netsq.hip for the arithmetic.
+#pragma once
+#include "common.h"
+
+namespace {
+
+typedef int i4v __attribute__((ext_vector_type(4)));
+typedef int i2v __attribute__((ext_vector_type(2)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+typedef short s2v __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(4))) int cint;      // read-only data at a wave-uniform address: s_load
+
+enum { OP_QCONV0 = 16, OP_QCONV = 17, OP_QDW = 18, OP_QDWPW = 19, OP_QSSD_DECODE = 20 };
+enum { QEPI_Q16 = 0, QEPI_ROWS = 1 };
+
+struct QReq {            // requantisation of one layer (per-tensor parameters)
+    int M;               // quantized multiplier, [2^30, 2^31)
+    int e;               // right shift (>= 0)
+    long long C;         // 2^30 + (e ? 2^(30+e) : 0) + (zo << (31 + e))   (ReLU-type layers)
+    int zo, lo, hi;
+    int linear;          // no activation: literal two-step rounding
+};
+
+__device__ __forceinline__ int q_requant(int x, const QReq &R) {
+    if (R.linear) {
+        const long long t = (long long)x * R.M + (1ll << 30);
+        int y = (int)(t >> 31);
+        if (R.e > 0) y = (y + (1 << (R.e - 1)) + (y >> 31)) >> R.e;          // RoundingDivideByPOT: half away from zero
+        y += R.zo;
+        return min(max(y, R.lo), R.hi);
+    }
+    const long long t = (long long)x * R.M + R.C;
+    const int sh = 31 + R.e;
+    const int z = sh >= 32 ? ((int)(t >> 32)) >> (sh - 32) : (int)(t >> 31);
+    return min(max(z, R.lo), R.hi);
+}
+
+__device__ __forceinline__ int q_requant_relu(int x, int M, long long C, int sh32) {      // e >= 1: z = (x M + C) >> (32 + sh32)
+    const long long t = (long long)x * M + C;
+    return ((int)(t >> 32)) >> sh32;
+}
+__device__ __forceinline__ int q_clamp(int z, int lo, int hi) {                           // lo <= hi: one v_med3_i32 (min(max()) is two instructions)
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(z), "s"(lo), "v"(hi));     // one scalar operand per vector instruction (constant bus)
+    return r;
+}
+
+// Four requantised values -> four bytes.  SAT (the layer's clamp is the whole byte range, as ReLU6 at scale 6/255 makes it): saturating
+// packs do clamp and pack in 5 instructions (v_cvt_pk_i16_i32 x2, v_sat_pk_u8_i16 x2, v_perm_b32) instead of 4 v_med3 + 3 v_lshl_or.
+template <bool SAT>
+__device__ __forceinline__ unsigned q_pack4(int z0, int z1, int z2, int z3, int lo, int hi) {
+    if constexpr (SAT) {
+        unsigned p01, p23, q01, q23;
+        asm("v_cvt_pk_i16_i32 %0, %1, %2" : "=v"(p01) : "v"(z0), "v"(z1));
+        asm("v_cvt_pk_i16_i32 %0, %1, %2" : "=v"(p23) : "v"(z2), "v"(z3));
+        asm("v_sat_pk_u8_i16 %0, %1" : "=v"(q01) : "v"(p01));
+        asm("v_sat_pk_u8_i16 %0, %1" : "=v"(q23) : "v"(p23));
+        return __builtin_amdgcn_perm(q23, q01, 0x05040100u);                  // bytes 0, 1 of each
+    } else {
+        return (unsigned)q_clamp(z0, lo, hi) | (unsigned)q_clamp(z1, lo, hi) << 8 | (unsigned)q_clamp(z2, lo, hi) << 16 | (unsigned)q_clamp(z3, lo, hi) << 24;
+    }
+}
+
+// Four accumulators -> four requantised bytes (ReLU-type layers, e >= 1): z = (x M + C) >> (32 + sh), clamped.  SAT: 0 = the layer's own clamp
+// (v_med3), 1 = the clamp is the byte range: saturating packs, 2 = that and sh <= 7: the shift moves behind the first pack, where one
+// v_pk_ashrrev_i16 serves two values -- exact, because the high word saturated to 16 bits still shifts to >= 255 (32767 >> 7) or below 0
+// exactly when the unsaturated one does.  14 -> 12 instructions per four values; these kernels are bound by instruction issue.
+template <int SAT>
+__device__ __forceinline__ unsigned q_requant_pack4(int x0, int x1, int x2, int x3, int M, long long C0, long long C1, long long C2, long long C3, int sh32, int lo, int hi) {
+    if constexpr (SAT == 2) {
+        const int h0 = (int)(((long long)x0 * M + C0) >> 32), h1 = (int)(((long long)x1 * M + C1) >> 32);
+        const int h2 = (int)(((long long)x2 * M + C2) >> 32), h3 = (int)(((long long)x3 * M + C3) >> 32);
+        const unsigned shpk = (unsigned)sh32 | (unsigned)sh32 << 16;
+        unsigned p01, p23, q01, q23;
+        asm("v_cvt_pk_i16_i32 %0, %1, %2" : "=v"(p01) : "v"(h0), "v"(h1));
+        asm("v_cvt_pk_i16_i32 %0, %1, %2" : "=v"(p23) : "v"(h2), "v"(h3));
+        asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(p01) : "s"(shpk), "v"(p01));
+        asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(p23) : "s"(shpk), "v"(p23));
+        asm("v_sat_pk_u8_i16 %0, %1" : "=v"(q01) : "v"(p01));
+        asm("v_sat_pk_u8_i16 %0, %1" : "=v"(q23) : "v"(p23));
+        return __builtin_amdgcn_perm(q23, q01, 0x05040100u);
+    } else {
+        return q_pack4<SAT == 1>(q_requant_relu(x0, M, C0, sh32), q_requant_relu(x1, M, C1, sh32), q_requant_relu(x2, M, C2, sh32), q_requant_relu(x3, M, C3, sh32), lo, hi);
+    }
+}
+
+// The same for a layer without activation (the SSD heads), clamp = the byte range, e >= 1: the literal two roundings
+//     y = (x M + 2^30) >> 31,   z = ((y + 2^(e-1) + (y >> 31)) >> e) + zo  =  (y + [2^(e-1) + (zo << e)] + (y >> 31)) >> e
+// with the bias in the 64-bit addend (C = cbias * M + 2^30 per channel) and the clamp in the saturating packs: 5 instructions per value
+// + 5 per four (q_requant's statement of the same arithmetic: 11 per value).
+__device__ __forceinline__ unsigned q_requant_linear_pack4(int x0, int x1, int x2, int x3, int M, long long C0, long long C1, long long C2, long long C3, int e, int k1) {
+    int z[4];
+    const int x[4] = {x0, x1, x2, x3};
+    const long long C[4] = {C0, C1, C2, C3};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int y = (int)(((long long)x[i] * M + C[i]) >> 31);
+        z[i] = (y + k1 + (y >> 31)) >> e;
+    }
+    unsigned p01, p23, q01, q23;
+    asm("v_cvt_pk_i16_i32 %0, %1, %2" : "=v"(p01) : "v"(z[0]), "v"(z[1]));
+    asm("v_cvt_pk_i16_i32 %0, %1, %2" : "=v"(p23) : "v"(z[2]), "v"(z[3]));
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(q01) : "v"(p01));
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(q23) : "v"(p23));
+    return __builtin_amdgcn_perm(q23, q01, 0x05040100u);
+}
+
+__device__ __forceinline__ int sdot4(int a, int b, int c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_sdot4(a, b, c, false);
+#else
+    return c;
+#endif
+}
+
+inline QReq make_req(const int32_t *o) {
+    QReq R;
+    R.M = o[32]; R.e = o[33];
+    R.zo = o[40]; R.lo = o[36]; R.hi = o[37]; R.linear = o[41];
+    R.C = (1ll << 30) + (R.e > 0 ? (1ll << (30 + R.e)) : 0) + ((long long)R.zo << (31 + R.e));
+    return R;
+}
+
+}  // namespace

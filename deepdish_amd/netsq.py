@@ -164,8 +164,8 @@ def compile_ssd_mobilenet_quant(qm):
         wo, pl = same_pad(d['w'], k, stride)
         return ho, wo, pt, pl
 
-    def info(kernel, flops, nbytes, wbytes):
-        P.info[-1] = dict(kernel=kernel, flops=flops, bytes=nbytes, wbytes=wbytes)
+    def info(kernel, flops, nbytes, wbytes, src_bytes=0):
+        P.info[-1] = dict(kernel=kernel, flops=flops, bytes=nbytes, wbytes=wbytes, src_bytes=src_bytes)     # src_bytes: what the op reads (a folded op's share of its launch: profile.launches_of)
 
     # first layer
     L = Ls['conv0']
@@ -178,7 +178,7 @@ def compile_ssd_mobilenet_quant(qm):
     raw.update({38: 0 if wl is not None else 128 - int(L['w_zp']), 39: int(L['in_zp']), 46: P.add_blob(folded_addends(cb, raw))})
     P._op(OP_QCONV0, dst=x, kh=3, kw=3, stride=L['stride'], pad_t=pt, pad_l=pl, cin=3, cout=32, cout_pad=32,
           w_off=P.add_blob(wp), b_off=P.add_blob(cb), aff_off=P.add_blob(wl) if wl is not None else 0, ho=ho, wo=wo, raw=raw)
-    info('q_conv0_k', 2 * ho * wo * 27 * 32, 3 * size * size + ho * wo * 32, 27 * 32 + 4 * 32)
+    info('q_conv0_k', 2 * ho * wo * 27 * 32, 3 * size * size + ho * wo * 32, 27 * 32 + 4 * 32, 3 * size * size)
 
     def conv(src, name, epi=QEPI_Q16, dst=None, chan_map=None, cout_pad=None, row_bytes=0, base_off=0, cout_store=0):
         L = Ls[name]
@@ -281,7 +281,7 @@ def compile_ssd_mobilenet_quant(qm):
         P._op(OP_QDWPW, src=src, dst=dst, kh=1, kw=1, stride=stride, pad_t=pt, pad_l=pl, cin=cin, cout=cout, cout_pad=cout, kpad=kcpt,
               w_off=P.add_blob(wp), b_off=P.add_blob(cb), aff_off=w_lo, ho=ho, wo=wo,
               p=[P.add_blob(dwa), P.add_blob(dcb), rd[32], rd[33], rd[36], rd[37]], bk=rd[40], raw=raw)
-        info('q_dwpw_k', 2 * ho * wo * cin * (9 + cout), s['h'] * s['w'] * cin + ho * wo * cout, cin * (9 + cout) + 4 * (cin + cout))
+        info('q_dwpw_k', 2 * ho * wo * cin * (9 + cout), s['h'] * s['w'] * cin + ho * wo * cout, cin * (9 + cout) + 4 * (cin + cout), s['h'] * s['w'] * cin)
         return dst
 
     feats = {}

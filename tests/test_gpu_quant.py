@@ -76,6 +76,46 @@ def test_every_layer_is_bit_exact(qnet):
     assert len(np.unique(cls)) > 100 and len(np.unique(box)) > 50          # not a degenerate comparison
 
 
+def test_front_row_pipeline_is_bit_exact(qnet, monkeypatch):
+    """First layer + blocks 1 and 2 as ONE launch (csrc/netsq_front.hip, the default from 24 frames per forward; forced here): block 2's
+    tensor and everything behind it against the oracle, borders included; the two tensors the launch keeps in LDS are not readable; the
+    three-launch form gives the same bytes.  Frame counts that end a workgroup's row range inside a frame and at a frame's edge."""
+    from deepdish_amd import netsq
+    from deepdish_amd.profile import net_op_launches
+    from oracle import nets_quant
+    qm, prog, net = qnet
+    fr = _frames(7, 17)
+    fr[2] = 0
+    fr[5] = 255
+    want_box, want_cls, kept = nets_quant.ssd_quant_forward(qm, fr, keep=['pw2', 'pw3', 'pw13'])
+    monkeypatch.setenv('DD_Q_FRONT_MIN', '1')
+    for n in (7, 1, 2, 3):
+        net.forward(fr[:n])
+        codes = net_op_launches(net)
+        assert list(codes[:3]) == [1, 1, 19], codes[:3]
+        for name in ('pw2', 'pw3', 'pw13'):
+            t = _tensor_of(prog, name)
+            d = prog.tensors[t]
+            raw = net.read(tensor=t)
+            got = netsq.unpack_q16(raw, d['h'], d['w'], d['c'])
+            bad = int((got != kept[name][:n]).sum())
+            assert bad == 0, '%d frames, %s: %d of %d bytes differ' % (n, name, bad, got.size)
+            assert (netsq.borders_q16(raw, d['h'], d['w'], d['c']) == d['zp']).all(), name + ': border overwritten'
+        np.testing.assert_array_equal(net.read(tensor=prog.meta['box_tensor'])[:, :, 0, :], want_box[:n])
+        np.testing.assert_array_equal(net.read(tensor=prog.meta['cls_tensor'])[:, :, 0, :prog.meta['n_classes']], want_cls[:n])
+    with pytest.raises(Exception):
+        net.read(tensor=_tensor_of(prog, 'conv0'))                         # never written by this forward
+    with pytest.raises(Exception):
+        net.read(tensor=_tensor_of(prog, 'pw1'))
+    monkeypatch.setenv('DD_Q_FRONT', '0')
+    net.forward(fr)
+    assert list(net_op_launches(net)[:3]) == [0, 0, 0]
+    np.testing.assert_array_equal(net.read(tensor=prog.meta['box_tensor'])[:, :, 0, :], want_box)
+    np.testing.assert_array_equal(net.read(tensor=prog.meta['cls_tensor'])[:, :, 0, :prog.meta['n_classes']], want_cls)
+    t = _tensor_of(prog, 'pw1')
+    assert net.read(tensor=t).shape[0] == 7
+
+
 def test_results_do_not_depend_on_the_launch(qnet):
     qm, prog, net = qnet
     fr = _frames(5, 3)
@@ -125,6 +165,8 @@ def test_launch_of_many_frames_is_bit_exact(n_frames, symmetric):
     idx = np.arange(n_frames) % 4
     idx[[0, 1, n_frames // 2, n_frames - 1]] = [3, 2, 1, 0]
     net.forward(base[idx])
+    from deepdish_amd.profile import net_op_launches
+    assert list(net_op_launches(net)[:3]) == ([1, 1, 19] if n_frames >= 24 else [0, 0, 0])     # the front end as one launch from 24 frames (csrc/netsq_front.hip)
     box = net.read(tensor=prog.meta['box_tensor'])[:, :, 0, :]
     cls = net.read(tensor=prog.meta['cls_tensor'])[:, :, 0, :prog.meta['n_classes']]
     box_w, cls_w, _ = nets_quant.ssd_quant_forward(qm, base)
