@@ -30,6 +30,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 #include "ssd_dev.h"
 #include "net_priv.h"
@@ -607,12 +608,25 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64, (COUT / (16 * MW)) * 
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) Wr[m][kc] = P.w[((size_t)(wm * MW + m) * KC + kc) * 64 + lane];
     const int mg = (wm * MW) / 4, m0 = (wm * MW) % 4;               // the 64-channel group and the first fragment inside it
-    i4v Wl[HL ? MW : 1][HL ? KC : 1];
+    // Split filter (HL): only a tensor's extreme weights overflow int8, so the lo part is zero in nearly every (fragment, k slice).  wlm = the k
+    // slices in which one of this wave's fragments has a lo part (wave-uniform, fixed for the launch); the lo fragments of the FIRST such slice stay
+    // in registers (16 of them, not 16 per slice), those of any further one are fetched from L2 where they are used -- exact either way.
+    unsigned wlm = 0;
+    int kcl = -1;
+    i4v Wl1[HL ? MW : 1];
     if constexpr (HL) {
 #pragma unroll
-        for (int m = 0; m < MW; ++m)
+        for (int kc = 0; kc < KC; ++kc) {
+            int any = 0;
 #pragma unroll
-            for (int kc = 0; kc < KC; ++kc) Wl[m][kc] = P.w2[((size_t)(wm * MW + m) * KC + kc) * 64 + lane];
+            for (int m = 0; m < MW; ++m) {
+                const i4v w = P.w2[((size_t)(wm * MW + m) * KC + kc) * 64 + lane];
+                any |= w[0] | w[1] | w[2] | w[3];
+            }
+            if (__builtin_amdgcn_ballot_w64(any != 0) != 0ull) { wlm |= 1u << kc; if (kcl < 0) kcl = kc; }
+        }
+#pragma unroll
+        for (int m = 0; m < MW; ++m) Wl1[m] = P.w2[((size_t)(wm * MW + m) * KC + max(kcl, 0)) * 64 + lane];
     }
     long long CP[FOLDP ? MW : 1][4];
     if constexpr (FOLDP) {
@@ -639,23 +653,27 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64, (COUT / (16 * MW)) * 
 #pragma unroll
     for (int ks = 0; ks < 3; ++ks) tap_dx[ks] = (min(4 * ks + fq, 8) % 3) * 16;
     const bool row_up0 = fq == 3, row_up1 = fq >= 2;                // the lane's tap of k step 0 / 1 lies in the later of the step's two rows
-    auto build_a = [&](int cg, i4v (&Ah)[3], i4v (&Al)[3], long long (&Cq)[4]) {
+    // (the hi parts of the wave's planes stay in registers; a lo part -- needed in few k steps of few planes, see the depthwise stage -- is built
+    // from the table word where it is used)
+    auto build_a = [&](int cg, i4v (&Ah)[3], unsigned &lo_w, long long (&Cq)[4], unsigned &lom) {
         const uint2 ab = P.dw_a[cg * 64 + lane];
+        lo_w = ab.y;
+        lom = (unsigned)__builtin_amdgcn_readfirstlane((int)(ab.y >> 24));     // which k steps of this plane have a lo part at all (netsq.pack_dw_mfma)
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) {
-            const unsigned sel = 0x01010101u * (unsigned)ks;
-            const unsigned rh = __builtin_amdgcn_perm(ab.x, ab.x, sel), rl = __builtin_amdgcn_perm(ab.y, ab.y, sel);
+            const unsigned rh = __builtin_amdgcn_perm(ab.x, ab.x, 0x01010101u * (unsigned)ks);
 #pragma unroll
-            for (int d = 0; d < 4; ++d) { Ah[ks][d] = (int)(rh & dmask[d]); Al[ks][d] = (int)(rl & dmask[d]); }
+            for (int d = 0; d < 4; ++d) Ah[ks][d] = (int)(rh & dmask[d]);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) Cq[r] = P.dw_cq[cg * 16 + 4 * fq + r];
     };
-    i4v KAh[KEEP ? CPW : 1][3], KAl[KEEP ? CPW : 1][3];
+    i4v KAh[KEEP ? CPW : 1][3];
     long long KCq[KEEP ? CPW : 1][4];
+    unsigned Klom[KEEP ? CPW : 1] = {}, Klow[KEEP ? CPW : 1] = {};
     if constexpr (KEEP) {
 #pragma unroll
-        for (int ci = 0; ci < CPW; ++ci) build_a((wave * CPW + ci) % C16, KAh[ci], KAl[ci], KCq[ci]);
+        for (int ci = 0; ci < CPW; ++ci) build_a((wave * CPW + ci) % C16, KAh[ci], Klow[ci], KCq[ci], Klom[ci]);
     }
 
     const int t_begin = blockIdx.x * tiles_per_block, t_end = min(n_tiles, t_begin + tiles_per_block);
@@ -701,13 +719,13 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64, (COUT / (16 * MW)) * 
         }
     };
     // ---- depthwise stage: this wave's planes x the four pixel fragments of the tile whose geometry is in buffer gbuf
-    auto dw_planes = [&](int gbuf, int rsb) {
+    auto dw_planes = [&](int gbuf, int rsb) __attribute__((always_inline)) {
         int rs[4] = {0, 0, 0, 0};
         constexpr int FB = QTT > 64 ? 2 : 4;                           // fragments in flight (see below)
         constexpr bool TAP_ONCE = FB == 4;                             // the ring offsets of all four fragments up front (shared by the wave's planes), or per pass
         int tapoff[3][4];                                            // ring offset of this lane's tap of k step ks at its pixel of fragment f (plane 0)
         const int fb = 4 * ((wave * CPW) / C16);                       // the wave's fragment quad (one per wave: see the assertion)
-        auto taps = [&](int f0, int nfr) {
+        auto taps = [&](int f0, int nfr) __attribute__((always_inline)) {
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
                 if (f < f0 || f >= f0 + nfr) continue;
@@ -718,11 +736,16 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64, (COUT / (16 * MW)) * 
             }
         };
         if constexpr (TAP_ONCE) taps(0, 4);
-        auto plane = [&](int unit, int ci) {                         // (ci: a literal after unrolling when KEEP)
+        auto plane = [&](int unit, int ci) __attribute__((always_inline)) {                         // (ci: a literal after unrolling when KEEP)
             const int cg = unit % C16;
             const int pofs = cg * PP;
             uint2 ab = make_uint2(0u, 0u);
             if constexpr (!KEEP) ab = dwa_l[cg * 64 + lane];
+            // Only a tensor's extreme weights overflow int8: most planes have no lo part in most k steps, and those MFMAs (half of the
+            // stage's) are skipped -- a product with zeros, the same bits.
+            unsigned lom;
+            if constexpr (KEEP) lom = Klom[ci];
+            else lom = (unsigned)__builtin_amdgcn_readfirstlane((int)(ab.y >> 24));
             long long Cq[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -742,13 +765,12 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64, (COUT / (16 * MW)) * 
                 for (int f = 0; f < FB; ++f) b[0][f] = *reinterpret_cast<const i4v *>(ring + tapoff[0][f0 + f] + pofs);
 #pragma unroll
                 for (int ks = 0; ks < 3; ++ks) {
-                    i4v Ah, Al;
-                    if constexpr (KEEP) { Ah = KAh[ci][ks]; Al = KAl[ci][ks]; }
+                    i4v Ah;
+                    if constexpr (KEEP) Ah = KAh[ci][ks];
                     else {
-                        const unsigned sel = 0x01010101u * (unsigned)ks;
-                        const unsigned rh = __builtin_amdgcn_perm(ab.x, ab.x, sel), rl = __builtin_amdgcn_perm(ab.y, ab.y, sel);
+                        const unsigned rh = __builtin_amdgcn_perm(ab.x, ab.x, 0x01010101u * (unsigned)ks);
 #pragma unroll
-                        for (int d = 0; d < 4; ++d) { Ah[d] = (int)(rh & dmask[d]); Al[d] = (int)(rl & dmask[d]); }
+                        for (int d = 0; d < 4; ++d) Ah[d] = (int)(rh & dmask[d]);
                     }
                     if (ks < 2) {                                    // the next k step's operands are on their way while this one multiplies
 #pragma unroll
@@ -756,8 +778,16 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64, (COUT / (16 * MW)) * 
                     }
 #pragma unroll
                     for (int f = 0; f < FB; ++f) acc[f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Ah, b[ks & 1][f], acc[f], 0, 0, 0);
+                    if (lom & (1u << ks)) {
+                        i4v Al;
+                        unsigned lo_w;
+                        if constexpr (KEEP) lo_w = Klow[ci]; else lo_w = ab.y;
+                        const unsigned rl = __builtin_amdgcn_perm(lo_w, lo_w, 0x01010101u * (unsigned)ks);
 #pragma unroll
-                    for (int f = 0; f < FB; ++f) acc[f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Al, b[ks & 1][f], acc[f], 0, 0, 0);
+                        for (int d = 0; d < 4; ++d) Al[d] = (int)(rl & dmask[d]);
+#pragma unroll
+                        for (int f = 0; f < FB; ++f) acc[f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Al, b[ks & 1][f], acc[f], 0, 0, 0);
+                    }
                 }
 #pragma unroll
                 for (int f = 0; f < FB; ++f) {
@@ -828,7 +858,7 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64, (COUT / (16 * MW)) * 
         }
     };
     // ---- pointwise stage of this wave's channels / fragments
-    auto matrix = [&](int q0, int q1, int gbuf, int rsb) {
+    auto matrix = [&](int q0, int q1, int gbuf, int rsb) __attribute__((always_inline)) {
         const int nf = (q1 - q0) / 16 + 1;
         // A lone ds_read -> s_waitcnt -> 4 MFMAs per K slice leaves the matrix pipe idle for the LDS latency eight times per fragment
         // (2.2 k cycles per fragment measured, 0.5 k of MFMA): all K slices of a fragment are requested before its first MFMA, and the
@@ -852,12 +882,19 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64, (COUT / (16 * MW)) * 
 #pragma unroll
             for (int k0 = 0; k0 < KC; k0 += KB) {
 #pragma unroll
-                for (int kc = 0; kc < KB; ++kc)
+                for (int kc = 0; kc < KB; ++kc) {
 #pragma unroll
-                    for (int m = 0; m < MW; ++m) {
-                        acc[m] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Wr[m][k0 + kc], b[kc], acc[m], 0, 0, 0);
-                        if constexpr (HL) acc[m] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Wl[m][k0 + kc], b[kc], acc[m], 0, 0, 0);
+                    for (int m = 0; m < MW; ++m) acc[m] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Wr[m][k0 + kc], b[kc], acc[m], 0, 0, 0);
+                    if (HL && ((wlm >> (k0 + kc)) & 1u)) {          // (the lo part of this k slice: zero for most of them)
+                        if (k0 + kc == kcl) {
+#pragma unroll
+                            for (int m = 0; m < MW; ++m) acc[m] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Wl1[m], b[kc], acc[m], 0, 0, 0);
+                        } else {
+#pragma unroll
+                            for (int m = 0; m < MW; ++m) acc[m] = __builtin_amdgcn_mfma_i32_16x16x64_i8(P.w2[((size_t)(wm * MW + m) * KC + (k0 + kc)) * 64 + lane], b[kc], acc[m], 0, 0, 0);
+                        }
                     }
+                }
                 if (k0 + KB < KC) {
 #pragma unroll
                     for (int kc = 0; kc < KB; ++kc) b[kc] = *reinterpret_cast<const i4v *>(bp + (size_t)(k0 + KB + kc) * 4 * QTT * 16);

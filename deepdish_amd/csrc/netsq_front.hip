@@ -15,7 +15,7 @@
 // zero point), opnd1 / opnd2 = the pointwise stages' MFMA operand tiles [k group][pixel][16].  Work per wave and phase is the same for
 // all four waves: a row of 150 pixels is ten 16-pixel fragments, one of 75 is five, and
 //     first layer: wave (row, half) -> five fragments x two channel fragments       depthwise 1: wave (row, plane) -> ten fragments
-//     pointwise 1: wave (row, half) -> five fragments x four channel fragments       depthwise 2: wave = plane -> five fragments
+//     pointwise 1: wave (row, channel-fragment pair) -> ten fragments                 depthwise 2: wave = plane -> five fragments
 //     pointwise 2: wave = channel-fragment pair -> five fragments.
 // Every filter a wave needs stays in its registers for the whole launch (two waves per SIMD, 256 registers each: two workgroups per CU,
 // 72.5 KB of LDS each).  The next tick's frame bytes are requested at the head of phase Y and used at the head of phase X.
@@ -44,6 +44,7 @@ struct QFrontP {
     const uint2 *dwa1; const int *dcb1; const i4v *w1; const int *cb1; int zp1;     // block 1 (zp1: stored zero-point byte of its output)
     const uint2 *dwa2; const int *dcb2; const i4v *w2, *w2l; const int *cb2;        // block 2
     QReq R0, Rd1, Rp1, Rd2, Rp2;
+    unsigned long long *dbg;                                       // DD_Q_STAMPS=1: per wave, cycles spent in each stage (diagnostic launches only)
 };
 
 template <int SAT, bool SPLIT>
@@ -73,33 +74,44 @@ __global__ __launch_bounds__(256, 2) void q_front_k(const QFrontP P, const int r
 #pragma unroll
     for (int ks = 0; ks < 3; ++ks) tap_dx[ks] = (min(4 * ks + fq, 8) % 3) * 16;
     const bool row_up0 = fq == 3, row_up1 = fq >= 2;               // the lane's tap of k step 0 / 1 lies in the later of the step's two rows
-    auto build_a = [&](const uint2 ab, i4v (&Ah)[3], i4v (&Al)[3]) {
+    auto build_a = [&](const unsigned w, i4v (&A)[3]) {               // (the hi parts stay in registers; a lo part, needed in few k steps of few planes, is built where it is used)
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) {
-            const unsigned sel = 0x01010101u * (unsigned)ks;
-            const unsigned rh = __builtin_amdgcn_perm(ab.x, ab.x, sel), rl = __builtin_amdgcn_perm(ab.y, ab.y, sel);
+            const unsigned rh = __builtin_amdgcn_perm(w, w, 0x01010101u * (unsigned)ks);
 #pragma unroll
-            for (int d = 0; d < 4; ++d) { Ah[ks][d] = (int)(rh & dmask[d]); Al[ks][d] = (int)(rl & dmask[d]); }
+            for (int d = 0; d < 4; ++d) A[ks][d] = (int)(rh & dmask[d]);
         }
     };
-    i4v A1h[3], A1l[3], A2h[3], A2l[3];
-    build_a(P.dwa1[wh * 64 + lane], A1h, A1l);                     // depthwise 1: plane wh
-    build_a(P.dwa2[wave * 64 + lane], A2h, A2l);                   // depthwise 2: plane wave
+    i4v A1h[3], A2h[3];
+    const uint2 ab1 = P.dwa1[wh * 64 + lane], ab2 = P.dwa2[wave * 64 + lane];
+    build_a(ab1.x, A1h);                                           // depthwise 1: plane wh
+    build_a(ab2.x, A2h);                                           // depthwise 2: plane wave
+    // Only a tensor's extreme weights overflow int8, so the lo part of a split filter is zero nearly everywhere: which k steps of the wave's
+    // depthwise planes have one at all (netsq.pack_dw_mfma keeps the mask in byte 3 of the lo word), which of its first-layer and pointwise
+    // fragments.  The MFMAs of the others are skipped (wave-uniform branches): a product with zeros, the same bits.
+    const unsigned lom1 = SPLIT ? (unsigned)__builtin_amdgcn_readfirstlane((int)(ab1.y >> 24)) : 0u;
+    const unsigned lom2 = SPLIT ? (unsigned)__builtin_amdgcn_readfirstlane((int)(ab2.y >> 24)) : 0u;
+    auto any_nz = [&](const i4v v) { return __builtin_amdgcn_ballot_w64((v[0] | v[1] | v[2] | v[3]) != 0) != 0ull; };
     const i4v dcb1 = *reinterpret_cast<const i4v *>(P.dcb1 + 16 * wh + 4 * fq);
     const i4v dcb2 = *reinterpret_cast<const i4v *>(P.dcb2 + 16 * wave + 4 * fq);
-    // pointwise 1: all four channel fragments (fragment m's row 4g + r = channel 16 g + 4 m + r); pointwise 2: fragments 2 wave, 2 wave + 1
-    i4v W1[4], cb1[4];
+    // pointwise 1: channel fragments 2 wh, 2 wh + 1 (fragment m's row 4g + r = channel 16 g + 4 m + r); pointwise 2: fragments 2 wave, 2 wave + 1
+    i4v W1[2], cb1[2];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) { W1[m] = P.w1[m * 64 + lane]; cb1[m] = *reinterpret_cast<const i4v *>(P.cb1 + 16 * fq + 4 * m); }
-    i4v W2[2], W2l[2], cb2[2];
+    for (int q = 0; q < 2; ++q) { W1[q] = P.w1[(2 * wh + q) * 64 + lane]; cb1[q] = *reinterpret_cast<const i4v *>(P.cb1 + 16 * fq + 4 * (2 * wh + q)); }
+    i4v W2[2], cb2[2];
+    bool nz2a = false, nz2b = false;                                // (the lo parts of pointwise 2's fragments are fetched where they are used: few waves have one)
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int mm = 2 * wave + q;                                // fragment 4 mg + m holds channels 64 mg + 16 g + 4 m + r
         W2[q] = P.w2[mm * 64 + lane];
-        W2l[q] = i4v{0, 0, 0, 0};
-        if constexpr (SPLIT) W2l[q] = P.w2l[mm * 64 + lane];
+        if constexpr (SPLIT) {
+            const i4v wl = P.w2l[mm * 64 + lane];
+            const bool nz = __builtin_amdgcn_ballot_w64((wl[0] | wl[1] | wl[2] | wl[3]) != 0) != 0ull;
+            if (q == 0) nz2a = nz; else nz2b = nz;
+        }
         cb2[q] = *reinterpret_cast<const i4v *>(P.cb2 + 64 * (mm >> 2) + 16 * fq + 4 * (mm & 3));
     }
+    const bool nz0a = SPLIT && any_nz(wal), nz0b = SPLIT && any_nz(wbl);
     const int M0 = P.R0.M, sh0 = P.R0.e - 1, lo0 = P.R0.lo, hi0 = P.R0.hi;
     const int Md1 = P.Rd1.M, shd1 = P.Rd1.e - 1, lod1 = P.Rd1.lo, hid1 = P.Rd1.hi;
     const int Mp1 = P.Rp1.M, shp1 = P.Rp1.e - 1, lop1 = P.Rp1.lo, hip1 = P.Rp1.hi;
@@ -117,11 +129,15 @@ __global__ __launch_bounds__(256, 2) void q_front_k(const QFrontP P, const int r
     __syncthreads();
 
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(P.src), 0, (int)P.src_bytes, 0x00020000);
+    // (a row's last fragment is partly filled: pixels 144 .. 149 of 150, 64 .. 74 of 75 -- the only lane-dependent store conditions of the kernel)
+    const bool ok6 = wh == 0 || fr < 6;
     const int al_o = 2 * (fr & 1);                                  // byte offset of the lane's window inside its first dword (6 x mod 4)
     unsigned win[5][3];                                             // the lane's three dwords of filter row fq at its pixel of the wave's five fragments
 #pragma unroll
     for (int i = 0; i < 5; ++i) { win[i][0] = 0; win[i][1] = 0; win[i][2] = 0; }
 
+    unsigned long long st[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = P.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+#define F_STAMP(k) do { if (P.dbg) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st[k] += now_ - tprev; tprev = now_; } } while (0)
     int g = g_begin;
     while (g < g_end) {
         const int n = g / F_S2, r_lo = g - n * F_S2, r_hi = min(F_S2 - 1, r_lo + (g_end - g) - 1);
@@ -129,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void q_front_k(const QFrontP P, const int r
         const int y_lo = 2 * r_lo, y_hi = 2 * r_hi + 2;                       // block-1 rows (row 150: padding)
 
         // frame bytes of the first-layer row of tick t1 (range-checked buffer loads: a window past the end of the batch reads zeros)
-        auto prefetch = [&](int t1) {
+        auto prefetch = [&](int t1) __attribute__((always_inline)) {
             const int c = 2 * t1 + 2 + wj;
             if (c < max(c_lo, 0) || c > min(c_hi, F_S1 - 1)) return;
             const int row = min(2 * c + min(fq, 2), F_S0 - 1);
@@ -140,15 +156,9 @@ __global__ __launch_bounds__(256, 2) void q_front_k(const QFrontP P, const int r
 #pragma unroll
                 for (int k = 0; k < 3; ++k) win[i][k] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, a4 + 96 * i + 4 * k, 0, 0);
         };
-        // ---- first layer: row c = 2t + 2 + wj, fragments 5 wh .. 5 wh + 4 -> ring0
-        auto conv0_stage = [&](int t) {
-            const int c = 2 * t + 2 + wj;
-            if (c < c_lo || c > c_hi) return;
-            uint8_t *const dst = ring0 + ((c + 4) & 3) * F_RB0;
-            if (c < 0 || c >= F_S1) {                              // a padding row: this wave's half of the slot
-                for (int i = lane * 16; i < F_RB0 / 2; i += 1024) *reinterpret_cast<u4v *>(dst + wh * (F_RB0 / 2) + i) = z0v;
-                return;
-            }
+        // ---- first layer: row c = 2t + 2 + wj, fragments 5 wh .. 5 wh + 4 -> ring0 (one body per combination of fragments with a lo part)
+        auto conv0_t = [&](auto nza_tag, auto nzb_tag, int c, uint8_t *const dst) __attribute__((always_inline)) {
+            constexpr bool NZA = decltype(nza_tag)::value, NZB = decltype(nzb_tag)::value;
             const bool below = 2 * c + fq >= F_S0 && fq < 3;        // filter row 2 of the last output row lies under the frame
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
@@ -164,41 +174,53 @@ __global__ __launch_bounds__(256, 2) void q_front_k(const QFrontP P, const int r
                 b[0] = (int)(d0 ^ 0x80808080u); b[1] = (int)(d1 ^ 0x80808080u); b[2] = (int)(d2 ^ 0x80808080u); b[3] = 0;
                 i4v acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa, b, cb0a, 0, 0, 0);
                 i4v acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(wb, b, cb0b, 0, 0, 0);
-                if constexpr (SPLIT) {
-                    acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(wal, b, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(wbl, b, acc1, 0, 0, 0);
-                }
+                if constexpr (NZA) acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(wal, b, acc0, 0, 0, 0);
+                if constexpr (NZB) acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(wbl, b, acc1, 0, 0, 0);
                 const unsigned lo = 0x80808080u ^ q_requant_pack4<SAT>(acc0[0], acc0[1], acc0[2], acc0[3], M0, C0, C0, C0, C0, sh0, lo0, hi0);
                 const unsigned hi = 0x80808080u ^ q_requant_pack4<SAT>(acc1[0], acc1[1], acc1[2], acc1[3], M0, C0, C0, C0, C0, sh0, lo0, hi0);
-                if (x < F_S1) *reinterpret_cast<uint2 *>(dst + (fq >> 1) * F_PP + (x + 1) * 16 + (fq & 1) * 8) = make_uint2(lo, hi);
+                if (i < 4 || ok6) *reinterpret_cast<uint2 *>(dst + (fq >> 1) * F_PP + (x + 1) * 16 + (fq & 1) * 8) = make_uint2(lo, hi);
             }
+        };
+        auto conv0_stage = [&](int t) __attribute__((always_inline)) {
+            const int c = 2 * t + 2 + wj;
+            if (c < c_lo || c > c_hi) return;
+            uint8_t *const dst = ring0 + ((c + 4) & 3) * F_RB0;
+            if (c < 0 || c >= F_S1) {                              // a padding row: this wave's half of the slot
+                for (int i = lane * 16; i < F_RB0 / 2; i += 1024) *reinterpret_cast<u4v *>(dst + wh * (F_RB0 / 2) + i) = z0v;
+                return;
+            }
+            if (nz0a) { if (nz0b) conv0_t(std::true_type{}, std::true_type{}, c, dst); else conv0_t(std::true_type{}, std::false_type{}, c, dst); }
+            else { if (nz0b) conv0_t(std::false_type{}, std::true_type{}, c, dst); else conv0_t(std::false_type{}, std::false_type{}, c, dst); }
         };
         // ---- depthwise 3x3 of one plane over NF fragments of one output row: ring rows at s0, s1, s2 (byte offsets of the plane in the three slots),
         //      pixel x of fragment f at column byte XS * (16 f + fr) + col0; the packed bytes go to tile + f * 256 (+ dup)
-        auto dw_run = [&](auto nf_tag, const uint8_t *ring, int s0, int s1, int s2, int lane_col, int frag_pitch, const i4v (&Ah)[3], const i4v (&Al)[3], const i4v cb,
-                          int Md, long long Cd, int shd, int lod, int hid, uint8_t *tile, int dup_off) {
-            constexpr int NF = decltype(nf_tag)::value;
+        auto dw_run_t = [&](auto lom_tag, const uint8_t *ring, int s0, int s1, int s2, int lane_col, int frag_pitch, const i4v (&Ah)[3], const unsigned al_w, const i4v cb,
+                            int Md, long long Cd, int shd, int lod, int hid, uint8_t *tile, int dup_off) __attribute__((always_inline)) {
+            constexpr int NF = 5;
+            constexpr unsigned LOM = decltype(lom_tag)::value;
             const uint8_t *const a0 = ring + (row_up0 ? s1 : s0) + tap_dx[0] + lane_col;
             const uint8_t *const a1 = ring + (row_up1 ? s2 : s1) + tap_dx[1] + lane_col;
             const uint8_t *const a2 = ring + s2 + tap_dx[2] + lane_col;
-            i4v acc[NF], b[2][NF];
+            // the 15 (k step, fragment) operands as one sequence, DW_W of them in flight (a rolling window instead of a second buffer for all five
+            // fragments of the next k step: 24 registers instead of 40 -- the kernel sits at the 256-register line)
+            constexpr int DW_W = 6;
+            i4v acc[NF], b[DW_W];
+            auto opnd_at = [&](int j) { const int ks = j / NF, f = j - ks * NF; return *reinterpret_cast<const i4v *>((ks == 0 ? a0 : ks == 1 ? a1 : a2) + f * frag_pitch); };
 #pragma unroll
-            for (int f = 0; f < NF; ++f) b[0][f] = *reinterpret_cast<const i4v *>(a0 + f * frag_pitch);
+            for (int j = 0; j < DW_W; ++j) b[j] = opnd_at(j);
 #pragma unroll
-            for (int ks = 0; ks < 3; ++ks) {
-                if (ks < 2) {                                        // the next k step's operands are on their way while this one multiplies
+            for (int j = 0; j < 3 * NF; ++j) {
+                const int ks = j / NF, f = j - ks * NF;
+                if (ks == 0) acc[f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Ah[0], b[j % DW_W], cb, 0, 0, 0);
+                else acc[f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Ah[ks], b[j % DW_W], acc[f], 0, 0, 0);
+                if (SPLIT && ((LOM >> ks) & 1u)) {                  // (LOM is a literal, the loop unrolled: no branch is emitted)
+                    const unsigned rl = __builtin_amdgcn_perm(al_w, al_w, 0x01010101u * (unsigned)ks);
+                    i4v Al;
 #pragma unroll
-                    for (int f = 0; f < NF; ++f) b[(ks + 1) & 1][f] = *reinterpret_cast<const i4v *>((ks == 0 ? a1 : a2) + f * frag_pitch);
+                    for (int d = 0; d < 4; ++d) Al[d] = (int)(rl & dmask[d]);
+                    acc[f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Al, b[j % DW_W], acc[f], 0, 0, 0);
                 }
-#pragma unroll
-                for (int f = 0; f < NF; ++f) {
-                    if (ks == 0) acc[f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Ah[0], b[0][f], cb, 0, 0, 0);
-                    else acc[f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Ah[ks], b[ks & 1][f], acc[f], 0, 0, 0);
-                }
-                if constexpr (SPLIT) {
-#pragma unroll
-                    for (int f = 0; f < NF; ++f) acc[f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Al[ks], b[ks & 1][f], acc[f], 0, 0, 0);
-                }
+                if (j + DW_W < 3 * NF) b[j % DW_W] = opnd_at(j + DW_W);
             }
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
@@ -207,28 +229,39 @@ __global__ __launch_bounds__(256, 2) void q_front_k(const QFrontP P, const int r
                 if (dup_off) *reinterpret_cast<unsigned *>(tile + f * 256 + dup_off) = packed;
             }
         };
+        // (one straight-line body per lo mask that occurs in practice: none, one k step, all -- a branch inside the k loop cost more than it saved)
+        auto dw_run = [&](const unsigned lom, const uint8_t *ring, int s0, int s1, int s2, int lane_col, int frag_pitch, const i4v (&Ah)[3], const unsigned al_w, const i4v cb,
+                          int Md, long long Cd, int shd, int lod, int hid, uint8_t *tile, int dup_off) __attribute__((always_inline)) {
+            switch (lom) {
+                case 0: dw_run_t(std::integral_constant<unsigned, 0u>{}, ring, s0, s1, s2, lane_col, frag_pitch, Ah, al_w, cb, Md, Cd, shd, lod, hid, tile, dup_off); break;
+                case 1: dw_run_t(std::integral_constant<unsigned, 1u>{}, ring, s0, s1, s2, lane_col, frag_pitch, Ah, al_w, cb, Md, Cd, shd, lod, hid, tile, dup_off); break;
+                case 2: dw_run_t(std::integral_constant<unsigned, 2u>{}, ring, s0, s1, s2, lane_col, frag_pitch, Ah, al_w, cb, Md, Cd, shd, lod, hid, tile, dup_off); break;
+                case 4: dw_run_t(std::integral_constant<unsigned, 4u>{}, ring, s0, s1, s2, lane_col, frag_pitch, Ah, al_w, cb, Md, Cd, shd, lod, hid, tile, dup_off); break;
+                default: dw_run_t(std::integral_constant<unsigned, 7u>{}, ring, s0, s1, s2, lane_col, frag_pitch, Ah, al_w, cb, Md, Cd, shd, lod, hid, tile, dup_off); break;
+            }
+        };
         // ---- depthwise 1: block-1 row y = 2t + 1 + wj, plane wh, ten fragments: ring0 -> opnd1 (32 channels fill half of the 64-byte k slice: with
         //      the split filter the bytes go to BOTH halves, whose filter halves are the hi and lo parts -- see q_dwpw_k's P.dup)
-        auto dw1_stage = [&](int t) {
+        auto dw1_stage = [&](int t) __attribute__((always_inline)) {
             const int y = 2 * t + 1 + wj;
             if (y < y_lo || y > min(y_hi, F_S1 - 1)) return;
             const int s0 = ((y + 3) & 3) * F_RB0 + wh * F_PP, s1 = ((y + 4) & 3) * F_RB0 + wh * F_PP, s2 = ((y + 5) & 3) * F_RB0 + wh * F_PP;   // first-layer rows y - 1 .. y + 1
             uint8_t *const tile = opnd1 + ((wh * 320 + wj * 160 + fr) * 16 + 4 * fq);
 #pragma unroll
             for (int h = 0; h < 2; ++h)
-                dw_run(std::integral_constant<int, 5>{}, ring0 + h * 5 * 256, s0, s1, s2, fr * 16, 256, A1h, A1l, dcb1, Md1, Cd1, shd1, lod1, hid1, tile + h * 5 * 256, SPLIT ? 2 * 320 * 16 : 0);
+                dw_run(lom1, ring0 + h * 5 * 256, s0, s1, s2, fr * 16, 256, A1h, ab1.y, dcb1, Md1, Cd1, shd1, lod1, hid1, tile + h * 5 * 256, SPLIT ? 2 * 320 * 16 : 0);
         };
         // ---- depthwise 2 (stride 2): block-2 row r = t - 1, plane wave, five fragments: ring1 -> opnd2
-        auto dw2_stage = [&](int t) {
+        auto dw2_stage = [&](int t) __attribute__((always_inline)) {
             const int r = t - 1;
             if (r < r_lo || r > r_hi) return;
             const int y = 2 * r;                                    // block-1 rows y .. y + 2, columns 2 x .. 2 x + 2 (bordered: + 1)
             const int s0 = (y % 3) * F_RB1 + wave * F_PP, s1 = ((y + 1) % 3) * F_RB1 + wave * F_PP, s2 = ((y + 2) % 3) * F_RB1 + wave * F_PP;
             uint8_t *const tile = opnd2 + ((wave * 80 + fr) * 16 + 4 * fq);
-            dw_run(std::integral_constant<int, 5>{}, ring1, s0, s1, s2, fr * 32 + 16, 512, A2h, A2l, dcb2, Md2, Cd2, shd2, lod2, hid2, tile, 0);
+            dw_run(lom2, ring1, s0, s1, s2, fr * 32 + 16, 512, A2h, ab2.y, dcb2, Md2, Cd2, shd2, lod2, hid2, tile, 0);
         };
-        // ---- pointwise 1: block-1 row y = 2t - 1 + wj, fragments 5 wh .. 5 wh + 4, all 64 channels: opnd1 -> ring1
-        auto pw1_stage = [&](int t) {
+        // ---- pointwise 1: block-1 row y = 2t - 1 + wj, ten fragments, channel fragments 2 wh, 2 wh + 1 (bytes 8 wh .. 8 wh + 7 of a pixel's plane slot): opnd1 -> ring1
+        auto pw1_stage = [&](int t) __attribute__((always_inline)) {
             const int y = 2 * t - 1 + wj;
             if (y < y_lo || y > y_hi) return;
             uint8_t *const dst = ring1 + (y % 3) * F_RB1;
@@ -236,26 +269,29 @@ __global__ __launch_bounds__(256, 2) void q_front_k(const QFrontP P, const int r
                 for (int i = lane * 16; i < F_RB1 / 2; i += 1024) *reinterpret_cast<u4v *>(dst + wh * (F_RB1 / 2) + i) = z1v;
                 return;
             }
-            const uint8_t *const bp = opnd1 + (fq * 320 + wj * 160 + 80 * wh + fr) * 16;
-            i4v b[5];
+            const uint8_t *const bp = opnd1 + (fq * 320 + wj * 160 + fr) * 16;
 #pragma unroll
-            for (int i = 0; i < 5; ++i) b[i] = *reinterpret_cast<const i4v *>(bp + i * 256);
+            for (int h = 0; h < 2; ++h) {
+                i4v b[5];
 #pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                u4v o;
+                for (int i = 0; i < 5; ++i) b[i] = *reinterpret_cast<const i4v *>(bp + (5 * h + i) * 256);
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const i4v acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(W1[m], b[i], cb1[m], 0, 0, 0);
-                    o[m] = 0x80808080u ^ q_requant_pack4<SAT>(acc[0], acc[1], acc[2], acc[3], Mp1, Cp1, Cp1, Cp1, Cp1, shp1, lop1, hip1);
+                for (int i = 0; i < 5; ++i) {
+                    const i4v a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(W1[0], b[i], cb1[0], 0, 0, 0);
+                    const i4v a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(W1[1], b[i], cb1[1], 0, 0, 0);
+                    const unsigned o0 = 0x80808080u ^ q_requant_pack4<SAT>(a0[0], a0[1], a0[2], a0[3], Mp1, Cp1, Cp1, Cp1, Cp1, shp1, lop1, hip1);
+                    const unsigned o1 = 0x80808080u ^ q_requant_pack4<SAT>(a1[0], a1[1], a1[2], a1[3], Mp1, Cp1, Cp1, Cp1, Cp1, shp1, lop1, hip1);
+                    const int x = 16 * (5 * h + i) + fr;
+                    if (5 * h + i < 9 || fr < 6) *reinterpret_cast<uint2 *>(dst + fq * F_PP + (x + 1) * 16 + 8 * wh) = make_uint2(o0, o1);
                 }
-                const int x = 80 * wh + 16 * i + fr;
-                if (x < F_S1) *reinterpret_cast<u4v *>(dst + fq * F_PP + (x + 1) * 16) = o;
             }
         };
         // ---- pointwise 2: block-2 row r = t - 2, channel fragments 2 wave, 2 wave + 1, five fragments: opnd2 -> HBM
-        auto pw2_stage = [&](int t) {
-            const int r = t - 2;
-            if (r < r_lo || r > r_hi) return;
+        auto pw2_t = [&](auto nza_tag, auto nzb_tag, int r) __attribute__((always_inline)) {
+            constexpr bool NZA = decltype(nza_tag)::value, NZB = decltype(nzb_tag)::value;
+            i4v W2l[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+            if constexpr (NZA) W2l[0] = P.w2l[(2 * wave) * 64 + lane];
+            if constexpr (NZB) W2l[1] = P.w2l[(2 * wave + 1) * 64 + lane];
             const uint8_t *const bp = opnd2 + (fq * 80 + fr) * 16;
             i4v b[5];
 #pragma unroll
@@ -263,33 +299,47 @@ __global__ __launch_bounds__(256, 2) void q_front_k(const QFrontP P, const int r
             uint8_t *const dst = P.out + ((size_t)((n * (F_S2 + 2) + r + 1) * 8 + 4 * (wave >> 1) + fq) * F_PPO + 8 * (wave & 1));
 #pragma unroll
             for (int f = 0; f < 5; ++f) {
-                unsigned o[2];
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    i4v acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(W2[q], b[f], cb2[q], 0, 0, 0);
-                    if constexpr (SPLIT) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(W2l[q], b[f], acc, 0, 0, 0);
-                    o[q] = 0x80808080u ^ q_requant_pack4<SAT>(acc[0], acc[1], acc[2], acc[3], Mp2, Cp2, Cp2, Cp2, Cp2, shp2, lop2, hip2);
-                }
+                i4v a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(W2[0], b[f], cb2[0], 0, 0, 0);
+                i4v a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(W2[1], b[f], cb2[1], 0, 0, 0);
+                if constexpr (NZA) a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(W2l[0], b[f], a0, 0, 0, 0);
+                if constexpr (NZB) a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(W2l[1], b[f], a1, 0, 0, 0);
+                const unsigned o0 = 0x80808080u ^ q_requant_pack4<SAT>(a0[0], a0[1], a0[2], a0[3], Mp2, Cp2, Cp2, Cp2, Cp2, shp2, lop2, hip2);
+                const unsigned o1 = 0x80808080u ^ q_requant_pack4<SAT>(a1[0], a1[1], a1[2], a1[3], Mp2, Cp2, Cp2, Cp2, Cp2, shp2, lop2, hip2);
                 const int x = 16 * f + fr;
-                if (x < F_S2) *reinterpret_cast<uint2 *>(dst + (x + 1) * 16) = make_uint2(o[0], o[1]);
+                if (f < 4 || fr < 11) *reinterpret_cast<uint2 *>(dst + (x + 1) * 16) = make_uint2(o0, o1);
             }
+        };
+        auto pw2_stage = [&](int t) __attribute__((always_inline)) {
+            const int r = t - 2;
+            if (r < r_lo || r > r_hi) return;
+            if (nz2a) { if (nz2b) pw2_t(std::true_type{}, std::true_type{}, r); else pw2_t(std::true_type{}, std::false_type{}, r); }
+            else { if (nz2b) pw2_t(std::false_type{}, std::true_type{}, r); else pw2_t(std::false_type{}, std::false_type{}, r); }
         };
 
         prefetch(r_lo - 2);
         for (int t = r_lo - 2; t <= r_hi + 2; ++t) {
             conv0_stage(t);
+            F_STAMP(0);
             pw1_stage(t);
+            F_STAMP(1);
             pw2_stage(t);
+            F_STAMP(2);
             __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0): this wave's ring and tile traffic is done
             __builtin_amdgcn_s_barrier();                            // (bare: the output stores and nothing else stay in flight)
+            F_STAMP(3);
             prefetch(t + 1);
             dw1_stage(t);
+            F_STAMP(4);
             dw2_stage(t);
+            F_STAMP(5);
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_s_barrier();
+            F_STAMP(6);
         }
         g += r_hi - r_lo + 1;
     }
+#undef F_STAMP
+    if (P.dbg && lane == 0) for (int k = 0; k < 7; ++k) P.dbg[((size_t)blockIdx.x * 4 + wave) * 8 + k] = st[k];
 }
 
 }  // namespace
@@ -356,8 +406,23 @@ int netq_run_front(dd_net *net, const int32_t *o0, const int32_t *o1, const int3
     const int rows_total = nimg * F_S2;
     const int blocks = std::max(1, std::min(2 * n_cu, rows_total / 15));
     const int rpb = dd_ceil_div(rows_total, blocks);
-    hipLaunchKernelGGL(kern, dim3((unsigned)dd_ceil_div(rows_total, rpb)), dim3(256), F_LDS, s, P, rows_total, rpb);
+    const unsigned grid = (unsigned)dd_ceil_div(rows_total, rpb);
+    static const bool stamps = getenv("DD_Q_STAMPS") && atoi(getenv("DD_Q_STAMPS")) != 0;
+    const size_t n_st = (size_t)grid * 4 * 8;
+    if (stamps) { DD_HIP(hipMalloc(&P.dbg, n_st * 8)); DD_HIP(hipMemsetAsync(P.dbg, 0, n_st * 8, s)); }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), F_LDS, s, P, rows_total, rpb);
     DD_LAUNCH_CHECK();
+    if (stamps) {                                                   // diagnostic: where the waves of this launch spent their cycles
+        std::vector<unsigned long long> h(n_st);
+        DD_HIP(hipStreamSynchronize(s));
+        DD_HIP(hipMemcpy(h.data(), P.dbg, n_st * 8, hipMemcpyDeviceToHost));
+        DD_HIP(hipFree(P.dbg));
+        double sum[7] = {0, 0, 0, 0, 0, 0, 0};
+        for (size_t w = 0; w < n_st / 8; ++w) for (int k = 0; k < 7; ++k) sum[k] += (double)h[w * 8 + k];
+        const double nw = (double)(n_st / 8) * rpb;
+        fprintf(stderr, "q_front_k %u blocks of %d rows: cycles per wave and output row: first layer %.0f  pointwise 1 %.0f  pointwise 2 %.0f  barrier %.0f | depthwise 1 %.0f  depthwise 2 %.0f  barrier %.0f\n",
+                grid, rpb, sum[0] / nw, sum[1] / nw, sum[2] / nw, sum[3] / nw, sum[4] / nw, sum[5] / nw, sum[6] / nw);
+    }
     *ran = 1;
     return DD_OK;
 }

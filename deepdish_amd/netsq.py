@@ -120,7 +120,8 @@ def pack_dw(L):
 def pack_dw_mfma(L):
     """Fused block's depthwise stage on the matrix pipe (csrc/netsq.hip q_dwpw_k): per plane of 16 channels and lane (g, r) the six
     bytes of the lane's diagonal element -- tap 4 ks + g of channel r for k steps ks = 0..2, split hi = clamp(w - zw, -128, 127),
-    lo = (w - zw) - hi -- as uint32 [C / 16][64][2].  None when a weight needs lo = 128 (w - zw = 255)."""
+    lo = (w - zw) - hi -- as uint32 [C / 16][64][2] (byte 3 of the lo word: the plane's mask of k steps whose lo part is not all zero).
+    None when a weight needs lo = 128 (w - zw = 255)."""
     w9 = (L['w'].astype(np.int64) - int(L['w_zp'])).reshape(9, -1)       # [tap][C]
     c = w9.shape[1]
     hi = np.clip(w9, -128, 127)
@@ -134,6 +135,12 @@ def pack_dw_mfma(L):
             if t < 9:
                 tab[:, g * 16:(g + 1) * 16, 0, ks] = (hi[t].reshape(c // 16, 16) & 0xff).astype(np.uint8)
                 tab[:, g * 16:(g + 1) * 16, 1, ks] = (lo[t].reshape(c // 16, 16) & 0xff).astype(np.uint8)
+    # byte 3 of the lo word (every lane of the plane alike): which k steps of this plane have a lo part at all -- only the extreme weights of a
+    # tensor overflow int8, so most planes have none and the kernels skip those MFMAs (bit ks = taps 4 ks .. 4 ks + 3)
+    lo9 = np.zeros((12, c), np.int64)
+    lo9[:9] = lo
+    mask = sum(((lo9[4 * ks:4 * ks + 4].reshape(4, c // 16, 16) != 0).any(axis=(0, 2)).astype(np.uint8) << ks) for ks in range(3))
+    tab[:, :, 1, 3] = mask[:, None]
     cb = L['bias'].astype(np.int64) - (int(L['in_zp']) - 128) * w9.sum(axis=0)
     return tab.reshape(c // 16, 64, 8).view(np.uint32).reshape(c // 16, 64, 2), cb.astype(np.int32)
 
