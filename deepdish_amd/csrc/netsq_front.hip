@@ -98,19 +98,16 @@ __global__ __launch_bounds__(256, 2) void q_front_k(const QFrontP P, const int r
     i4v W1[2], cb1[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) { W1[q] = P.w1[(2 * wh + q) * 64 + lane]; cb1[q] = *reinterpret_cast<const i4v *>(P.cb1 + 16 * fq + 4 * (2 * wh + q)); }
-    i4v W2[2], cb2[2];
-    bool nz2a = false, nz2b = false;                                // (the lo parts of pointwise 2's fragments are fetched where they are used: few waves have one)
+    i4v W2[2], W2l[2], cb2[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int mm = 2 * wave + q;                                // fragment 4 mg + m holds channels 64 mg + 16 g + 4 m + r
         W2[q] = P.w2[mm * 64 + lane];
-        if constexpr (SPLIT) {
-            const i4v wl = P.w2l[mm * 64 + lane];
-            const bool nz = __builtin_amdgcn_ballot_w64((wl[0] | wl[1] | wl[2] | wl[3]) != 0) != 0ull;
-            if (q == 0) nz2a = nz; else nz2b = nz;
-        }
+        W2l[q] = i4v{0, 0, 0, 0};
+        if constexpr (SPLIT) W2l[q] = P.w2l[mm * 64 + lane];
         cb2[q] = *reinterpret_cast<const i4v *>(P.cb2 + 64 * (mm >> 2) + 16 * fq + 4 * (mm & 3));
     }
+    const bool nz2a = SPLIT && any_nz(W2l[0]), nz2b = SPLIT && any_nz(W2l[1]);
     const bool nz0a = SPLIT && any_nz(wal), nz0b = SPLIT && any_nz(wbl);
     const int M0 = P.R0.M, sh0 = P.R0.e - 1, lo0 = P.R0.lo, hi0 = P.R0.hi;
     const int Md1 = P.Rd1.M, shd1 = P.Rd1.e - 1, lod1 = P.Rd1.lo, hid1 = P.Rd1.hi;
@@ -202,8 +199,8 @@ __global__ __launch_bounds__(256, 2) void q_front_k(const QFrontP P, const int r
             const uint8_t *const a1 = ring + (row_up1 ? s2 : s1) + tap_dx[1] + lane_col;
             const uint8_t *const a2 = ring + s2 + tap_dx[2] + lane_col;
             // the 15 (k step, fragment) operands as one sequence, DW_W of them in flight (a rolling window instead of a second buffer for all five
-            // fragments of the next k step: 24 registers instead of 40 -- the kernel sits at the 256-register line)
-            constexpr int DW_W = 6;
+            // fragments of the next k step: 32 registers instead of 40 -- the kernel sits at the 256-register line)
+            constexpr int DW_W = 8;
             i4v acc[NF], b[DW_W];
             auto opnd_at = [&](int j) { const int ks = j / NF, f = j - ks * NF; return *reinterpret_cast<const i4v *>((ks == 0 ? a0 : ks == 1 ? a1 : a2) + f * frag_pitch); };
 #pragma unroll
@@ -289,9 +286,6 @@ __global__ __launch_bounds__(256, 2) void q_front_k(const QFrontP P, const int r
         // ---- pointwise 2: block-2 row r = t - 2, channel fragments 2 wave, 2 wave + 1, five fragments: opnd2 -> HBM
         auto pw2_t = [&](auto nza_tag, auto nzb_tag, int r) __attribute__((always_inline)) {
             constexpr bool NZA = decltype(nza_tag)::value, NZB = decltype(nzb_tag)::value;
-            i4v W2l[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-            if constexpr (NZA) W2l[0] = P.w2l[(2 * wave) * 64 + lane];
-            if constexpr (NZB) W2l[1] = P.w2l[(2 * wave + 1) * 64 + lane];
             const uint8_t *const bp = opnd2 + (fq * 80 + fr) * 16;
             i4v b[5];
 #pragma unroll
