@@ -38,7 +38,9 @@ CONFIGS = {
     # 3 072 streams in 4 worker groups = 768 frames and ~15 000 crops per launch: with the crop-resident encoder kernels of round 5 bigger launches pay
     # (same box, 20 steps: 4 x 384 streams 102.6 / 108.0 k frames/s, 4 x 768 114.7 / 116.2 k, 4 x 1 024 119.4 k); at 768 per launch every stream still
     # advances at 37 frames/s, above camera rate
-    2: dict(W=640, H=480, model='synthetic-ssd_mobilenet_v1', streams=3072, groups=4,
+    # round 6 (the SSD front end as one row pipeline, zero lo parts skipped): one group alone now reaches 95 % of the multi-group figure, and two groups of
+    # 1 536 beat four of 768 (same box, alternating: 135.2 / 135.1 k against 131.5 / 129.0 k; six of 512: 125 k; one of 3 072: 125 k)
+    2: dict(W=640, H=480, model='synthetic-ssd_mobilenet_v1', streams=3072, groups=2,
             workload='SSD-MobileNet-v1 (300x300) + MARS-64x32x3 + deep_sort on synthetic 640x480 BGR frames, '
                      '~20 synthetic detections/frame (BASELINE.json configs[1])'),
     # (round 5, same box, 20 steps: 2 x 256 streams 21.9 k frames/s, 3 x 256 22.2 k, 2 x 512 and 4 x 256 22.5 k)
@@ -80,8 +82,8 @@ def parse():
                          'throughput is reported (what tests/test_bench_launcher.py runs where there is no GPU)')
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
-    if args.streams is None:        # --ingest-host keeps every step's frames in pinned host memory: a smaller default there
-        args.streams = int(os.environ.get('DD_BENCH_STREAMS', '256' if args.ingest_host and args.config == 2 else cfg['streams']))
+    if args.streams is None:        # --ingest-host keeps every step's frames in pinned host memory (0.92 MB per frame): a smaller default there
+        args.streams = int(os.environ.get('DD_BENCH_STREAMS', '1536' if args.ingest_host and args.config == 2 else cfg['streams']))
     if args.groups is None:
         args.groups = int(os.environ.get('DD_BENCH_GROUPS', cfg['groups']))
     return args
@@ -390,6 +392,11 @@ def rehearse(args, rank, world, real_stdout):
                'n_gpus': world, 'steps': 0, 'warmup': 0, 'rehearsal': 'launcher / rendezvous / count reduction only (gloo, CPU): '
                'no frames processed, nothing measured', 'counts_pos_neg_int_del': [int(v) for v in counts.reshape(-1)],
                'host_cores': os.cpu_count(), 'per_rank_host': budgets}
+        if dist.is_initialized():
+            out['rccl_ranks'] = dist.get_world_size()       # (the rehearsal's communicator is gloo: what the field holds in the real run is RCCL's)
+            out['collective_backend'] = 'gloo'
+        if os.environ.get('DD_BENCH_REPORT_ENV'):           # tests: what this rank's environment holds when the collectives come up
+            out['env_of_rank0'] = {k: os.environ.get(k) for k in ('HSA_ENABLE_IPC_MODE_LEGACY', 'MASTER_ADDR', 'MASTER_PORT')}
         os.write(real_stdout, (json.dumps(out) + '\n').encode())
     if dist.is_initialized():
         dist.barrier()
@@ -400,6 +407,10 @@ def main():
     args = parse()
     if args.gpus > 1 and 'RANK' not in os.environ:
         sys.exit(launch_ranks(args))                         # before torch is imported or the GPU is touched
+    if 'RANK' in os.environ:
+        # a rank started by a launcher other than launch_ranks (the driver's `python -m torch.distributed.run ...`): RCCL needs dmabuf IPC
+        # on this host driver, and the variable must be in the environment before torch / the HIP runtime are loaded
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus:
         sys.stderr.write('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks\n' % (args.gpus, world))
@@ -440,12 +451,22 @@ def main():
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         else:
             dist.init_process_group(backend)
+        comm_ranks = dist.get_world_size()                   # what the communicator holds after init (reported as rccl_ranks)
 
     import threading
     from deepdish_amd.multipipe import MultiStreamPipeline
     from deepdish_amd.multistream import reduce_counts
     from deepdish_amd.runtime import Context
     n_frames = args.warmup + args.steps
+    # every step's frames are resident before the timed region (HBM, or pinned host memory + the ring's device slots with --ingest-host):
+    # say so before allocating rather than dying inside an allocation (engines: ~14 MB per stream at these launch sizes)
+    need = n_frames * args.streams * H * W * 3
+    free_b, total_b = torch.cuda.mem_get_info(local_rank)
+    engines = args.streams * 14 * (1 << 20)
+    if need + engines > free_b:
+        sys.stderr.write('bench.py: %d steps x %d streams of %dx%d frames = %.1f GB resident (+ ~%.1f GB of engines), %.1f GB free on the device: '
+                         'lower --steps / --warmup / --streams\n' % (n_frames, args.streams, W, H, need / 1e9, engines / 1e9, free_b / 1e9))
+        sys.exit(2)
     bounds = [round(g * args.streams / G) for g in range(G + 1)]
     ctxs = [Context(local_rank) for _ in range(G)]
     pipes = [MultiStreamPipeline(bounds[g + 1] - bounds[g], model=cfg['model'], input_size=(W, H), context=ctxs[g],
@@ -572,8 +593,17 @@ def main():
                                              'boxes_rejected_by_motion_test': int(sum(p.motion_mask(read=False)[1] for p in pipes)),
                                              'note': 'reference default configuration; not the headline (BASELINE configs disable it)'}
             extra_only = True
+        if dist_on:
+            out['rccl_ranks'] = int(comm_ranks)
+            out['collective_backend'] = backend
         if ings is not None:
             out['frames_start_in'] = 'pinned host memory (PCIe upload inside the timed region; not the headline configuration)'
+            step_bytes = args.streams * H * W * 3                   # per GPU and step, host -> device
+            gbs = step_bytes / (1e6 * out['ms_per_step'])
+            out['pcie'] = {'bytes_per_step': step_bytes, 'achieved': gbs, 'peak': 63.0, 'unit': 'GB/s', 'frac': gbs / 63.0,
+                           'pinned_slots_per_group': n_frames, 'pinned_host_bytes': n_frames * step_bytes,
+                           'bound_frames_per_s': 63.0e9 / (H * W * 3),
+                           'note': 'PCIe Gen5 x16 spec 63 GB/s (MI355X_MICROARCH.md): the most a host can feed one GPU at %dx%d BGR' % (W, H)}
             extra_only = True
         if not extra_only:
             try:

@@ -95,21 +95,22 @@ def profile_nets(run_once, nets_with_batch, reps=20):
 
 
 def pmc_traffic(kernel, streams):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (separate --pmc FETCH_SIZE and
+    """(HBM bytes per launch of `kernel`, where the figure comes from) from the committed rocprofv3 PMC summary (separate --pmc FETCH_SIZE and
     --pmc WRITE_SIZE passes of this same bench; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
     None when no summary exists for this stream count -- bench.py cannot run the profiler on itself."""
     import json, os
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles')
-    path = next((p for p in (os.path.join(root, 'r%02d_pmc_traffic_s%d.json' % (r, streams)) for r in (5, 4, 3, 2, 1)) if os.path.exists(p)), None)
+    path = next((p for p in (os.path.join(root, 'r%02d_pmc_traffic_s%d.json' % (r, streams)) for r in (6, 5, 4, 3, 2, 1)) if os.path.exists(p)), None)
     if path is None:                       # the newest round's summary for this stream count, if one was collected
-        return None
+        return None, None
     keys = [part.replace(',', ', ') for part in kernel.split('+')]
     tot_b = tot_n = 0.0
     for k, v in json.load(open(path)).items():          # a kernel family (all tile shapes of conv_glds_k) is summed
         if any(key in k for key in keys):
             tot_b += (v['hbm_read_bytes_corrected'] + v['hbm_write_bytes']) * v['launches']
             tot_n += v['launches']
-    return tot_b / tot_n if tot_n else None
+    src = 'profiles/%s (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes of `bench.py --groups 1 --streams %d`, committed; not measured in this run)' % (os.path.basename(path), streams)
+    return (tot_b / tot_n, src) if tot_n else (None, None)
 
 
 def dominant_kernel_roofline(pipes, step_group, args, reps=20):
@@ -156,7 +157,8 @@ def dominant_kernel_roofline(pipes, step_group, args, reps=20):
     else:
         achieved = k['bytes'] / sec / 1e9
         out = dict(bound='hbm', achieved=achieved, peak=PEAK_HBM_GBS, unit='GB/s', frac=achieved / PEAK_HBM_GBS)
-    out.update(kernel=name, traffic=pmc_traffic(name, p.S), launches_per_step=k['launches'], avg_launch_us=avg_us,
+    traffic, traffic_source = pmc_traffic(name, p.S)
+    out.update(kernel=name, traffic=traffic, traffic_source=traffic_source, launches_per_step=k['launches'], avg_launch_us=avg_us,
                frames_per_launch=p.S,
                algorithmic_per_launch=dict(flops=k['flops'] / max(k['launches'], 1e-9), bytes=k['bytes'] / max(k['launches'], 1e-9)),
                measured='HIP events on the launch stream, one worker group (%d streams) alone on the GPU' % p.S,

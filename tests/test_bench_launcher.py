@@ -59,3 +59,25 @@ def test_gpus_8_rehearsal_keeps_the_node_within_its_cores():
         assert b['generator_processes'] == max(1, min(16, cores // 16))
         assert b['host_pool_threads'] == max(1, min(12, cores // 8 - b['worker_groups'] - 1))
         assert b['worker_groups'] >= 1
+
+
+def test_ranks_started_by_an_external_launcher():
+    """The driver starts the ranks itself (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...`): bench.py must then NOT spawn again, must put HSA_ENABLE_IPC_MODE_LEGACY=0 into its own
+    environment before torch is imported (RCCL's dmabuf IPC on this host driver), and rank 0 reports the communicator's size."""
+    import socket
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT', 'MASTER_ADDR', 'HSA_ENABLE_IPC_MODE_LEGACY')}
+    env['DD_BENCH_REPORT_ENV'] = '1'
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--rehearse-cpu'],
+                       capture_output=True, text=True, env=env, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith('{')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['rccl_ranks'] == 2 and out['collective_backend'] == 'gloo'
+    assert out['counts_pos_neg_int_del'] == [3, 30, 33, 0]
+    assert out['env_of_rank0']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'

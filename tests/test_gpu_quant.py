@@ -149,9 +149,9 @@ def test_decoded_arrays(qnet):
         net.ssd_decode(None, 0.0, enable=False)
 
 
-@pytest.mark.parametrize('n_frames, symmetric', [(768, False), (384, False), (91, False), (91, True), (23, False)])
+@pytest.mark.parametrize('n_frames, symmetric', [(1536, False), (768, False), (384, False), (91, False), (91, True), (23, False)])
 def test_launch_of_many_frames_is_bit_exact(n_frames, symmetric):
-    """The bench's launch shape (one worker group = 768 frames per forward since round 5, 384 before) and odd ones: picked slots against the integer oracle, every
+    """The bench's launch shape (one worker group = 1 536 frames per forward since round 6, 768 in round 5, 384 before) and odd ones: picked slots against the integer oracle, every
     other slot against the slot that holds the same frame (persistent blocks, tiles that straddle frames, the last tile of a frame).
     91 frames: the register-filter pointwise kernel (from 8 192 pixels per launch) with a partly filled last tile on every map it takes,
     merged predictors included; 23 frames: the same layers on the generic kernel, the 19x19 predictors still merged (8 303 pixels)."""
