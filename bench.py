@@ -502,11 +502,13 @@ def main():
     def run(g, f0, f1):
         torch.cuda.set_device(local_rank)                    # a fresh thread starts on device 0
         if ings is not None:
+            det_streams = [p.detector_stream() for p in pipes]
             ings[g].submit(f0)
             for f in range(f0, f1):
                 if f + 1 < f1:
                     ings[g].submit(f + 1)                         # the next step's upload runs under this step's kernels
-                nxt = ings[g].frames(f + 1) if f + 1 < f1 else None
+                # the next frames are consumed first by their look-ahead detector run: ITS stream waits for their upload, not this step's kernels
+                nxt = ings[g].frames(f + 1, stream=det_streams[g]) if f + 1 < f1 else None
                 pipes[g].step(ings[g].frames(f), injected[g][f], nxt)
                 ings[g].release(f)
             return

@@ -105,6 +105,7 @@ SIGNATURES = {
     'dd_pipeline_tracker': [P, c_int, POINTER(P)],
     'dd_pipeline_stage_seconds': [P, P, POINTER(ctypes.c_longlong)],
     'dd_pipeline_stage_gpu_ms': [P, P, POINTER(ctypes.c_longlong)],
+    'dd_pipeline_detector_stream': [P, POINTER(P)],
     'dd_pipeline_detections': [P, c_int, P, P, P, c_int, POINTER(c_int)],
     'dd_counts_accumulate': [P, P, P, c_int, P],
 }

@@ -96,6 +96,17 @@ static inline hipStream_t dd_pick_stream(dd_ctx *ctx, void *stream) {
 
 static inline int dd_ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// Compute units of a device (cached; 256 on MI355X): what the persistent one-workgroup-per-CU launches size their grids by.
+static inline int dd_cu_count(int device) {
+    static std::atomic<int> cache[64];
+    int n = cache[device & 63].load(std::memory_order_relaxed);
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || n <= 0) n = 256;
+        cache[device & 63].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+
 // XCD-aware block order (MI355X: 8 XCDs, each with a private 4 MiB L2; workgroups are dealt round-robin
 // over them).  Maps the hardware's linear workgroup id to a logical id such that every XCD works on one
 // contiguous 1/8 of the logical range: neighbouring tiles (shared halo rows, shared weight panels) then

@@ -270,7 +270,8 @@ int launch_pair(hipStream_t s, int device, const MarsPairP &P) {
         return DD_OK;
     });
     if (rc != DD_OK) return rc;
-    const int grid = P.n_img < 256 ? P.n_img : 256;
+    const int n_cu = dd_cu_count(device);
+    const int grid = P.n_img < n_cu ? P.n_img : n_cu;             // one workgroup per CU
     hipLaunchKernelGGL((mars_pair64_k<FIRST>), dim3(grid), dim3(512), lds, s, P);
     DD_LAUNCH_CHECK();
     return DD_OK;

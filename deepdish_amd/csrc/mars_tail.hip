@@ -359,7 +359,8 @@ int launch_one(hipStream_t s, int device, const MarsWsP &P) {
         return DD_OK;
     });
     if (rc != DD_OK) return rc;
-    const int grid = P.n_img < 256 ? P.n_img : 256;               // one workgroup per CU, each the whole filter
+    const int n_cu = dd_cu_count(device);
+    const int grid = P.n_img < n_cu ? P.n_img : n_cu;             // one workgroup per CU (the device's count, not a literal), each the whole filter
     hipLaunchKernelGGL((mars_ws128_k<MODE, ACT, OUT2>), dim3(grid), dim3(512), lds, s, P);
     DD_LAUNCH_CHECK();
 #ifdef DD_MARS_STAMPS

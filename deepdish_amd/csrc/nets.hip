@@ -4775,8 +4775,13 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
                 break;
             }
             case OP_CONV: {
-                if (proj_done) { proj_done = false; net->op_launch[i] = OPK_FOLDED_PREV; break; }
+                // (the early exits below skip the held-back launches' flush further down: a program that puts a held residual unit, stem or
+                // pointwise layer directly in front of a folded op is refused instead of silently never writing it)
+#define DD_NO_PENDING() DD_REQUIRE(!unit_pending && !pair_pending && !stem_pending && !pw_pending && !input_pending, DD_E_STATE, \
+                                   "dd_net_forward: op %d is folded into a neighbouring launch while an earlier op's launch is still held back", i)
+                if (proj_done) { DD_NO_PENDING(); proj_done = false; net->op_launch[i] = OPK_FOLDED_PREV; break; }
                 if (pair_left > 0) {                               // inside a conv3_x block that runs as one launch: at its last op
+                    DD_NO_PENDING();
                     if (--pair_left > 0) { net->op_launch[i] = OPK_FOLDED; break; }
                     const int rc = mars_pair64_launch(s, net->ctx->device, pair64, pair64_first);
                     if (rc != DD_OK) return rc;
@@ -4787,8 +4792,9 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
                     std::vector<char *> bp(net->bufs.size());
                     for (size_t b = 0; b < bp.size(); ++b) bp[b] = static_cast<char *>(net->bufs[b]);
                     const int n_ops = mars_pair_match(net, i, nimg, bp.data(), pair64, pair64_first);
-                    if (n_ops) { pair_left = n_ops - 1; net->op_launch[i] = OPK_FOLDED; break; }
+                    if (n_ops) { DD_NO_PENDING(); pair_left = n_ops - 1; net->op_launch[i] = OPK_FOLDED; break; }
                 }
+#undef DD_NO_PENDING
                 ConvP P;
                 memset(&P, 0, sizeof(P));
                 P.in = reinterpret_cast<const _Float16 *>(base(src)); P.H = ts->h; P.W = ts->w; P.cs_in = ts->cs;

@@ -390,13 +390,7 @@ int netq_run_front(dd_net *net, const int32_t *o0, const int32_t *o1, const int3
     });
     if (rc != DD_OK) return rc;
     // a segment costs four ticks beyond its rows: ranges of at least a fifth of a frame, two workgroups per CU
-    static std::atomic<int> n_cu_cache[64];
-    int n_cu = n_cu_cache[net->ctx->device & 63].load(std::memory_order_relaxed);
-    if (n_cu == 0) {
-        DD_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, net->ctx->device));
-        n_cu = std::max(1, n_cu);
-        n_cu_cache[net->ctx->device & 63].store(n_cu, std::memory_order_relaxed);
-    }
+    const int n_cu = dd_cu_count(net->ctx->device);
     const int rows_total = nimg * F_S2;
     const int blocks = std::max(1, std::min(2 * n_cu, rows_total / 15));
     const int rpb = dd_ceil_div(rows_total, blocks);

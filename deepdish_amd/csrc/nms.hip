@@ -501,8 +501,15 @@ int nms_f32_select_batched(hipStream_t s, const float *boxes, const float *score
                "nms_f32_select_batched: k=%d batch=%d max_keep=%d", k, batch, max_keep);
     const size_t lds = (size_t)k * sizeof(float4);
     if (k <= 2048) hipLaunchKernelGGL(nms_greedy_f32_k<8>, dim3(batch), dim3(256), lds, s, boxes, scores, k, score_thr, iou_thr, max_keep, out_idx, out_n);
-    else {
-        DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&nms_greedy_f32_k<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MAXK * sizeof(float4))));
+    else {                                                  // (exercised by the 3 000-box case of scripts/ssd_post_cases.py)
+        static DevOnce once;                                   // a per-device attribute: once per device, not on every launch
+        int dev = 0;
+        DD_HIP(hipGetDevice(&dev));
+        const int rc = once.run(dev, [&]() -> int {
+            DD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&nms_greedy_f32_k<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MAXK * sizeof(float4))));
+            return DD_OK;
+        });
+        if (rc != DD_OK) return rc;
         hipLaunchKernelGGL(nms_greedy_f32_k<16>, dim3(batch), dim3(256), lds, s, boxes, scores, k, score_thr, iou_thr, max_keep, out_idx, out_n);
     }
     DD_LAUNCH_CHECK();

@@ -381,6 +381,12 @@ int dd_pipeline_counts(dd_pipeline *p, int64_t *counts_host) {
     return DD_OK;
 }
 
+int dd_pipeline_detector_stream(dd_pipeline *p, void **stream_out) {
+    DD_REQUIRE(p && stream_out, DD_E_ARG, "dd_pipeline_detector_stream: NULL argument");
+    *stream_out = p->det ? reinterpret_cast<void *>(p->det_stream) : nullptr;
+    return DD_OK;
+}
+
 int dd_pipeline_stage_gpu_ms(dd_pipeline *p, double *out6_host, long long *steps_host) {
     DD_REQUIRE(p && out6_host, DD_E_ARG, "dd_pipeline_stage_gpu_ms: NULL argument");
     DD_DEVICE(p->ctx);

@@ -53,6 +53,17 @@ class MultiStreamPipeline:
             raise ValueError('the multi-stream pipeline batches the SSD-MobileNet, YOLOv5 and generic TFLite detectors (got %s)' % model)
         with open(labels or (DEFAULT_YOLO_LABELS if self.kind == 'yolov5' else DEFAULT_LABELS)) as f:
             self.label_lines = [l.strip() for l in f.readlines()]
+        meta = None
+        if self.kind == 'tflite' and str(model).endswith('.tflite') and os.path.exists(str(model)):
+            # the generic adaptor takes its label list and input normalisation from the model file's metadata (tools/tflite_object_detector.py:117-137
+            # upstream); a file without metadata keeps the label file and the 127.5 / 127.5 defaults (see tools/tflite.py here)
+            from .tools import tflite_reader
+            try:
+                meta = tflite_reader.read_metadata(str(model))
+                self.label_lines = ['???'] + list(meta['labels'])      # (line 0 = the background entry the adaptor's label map skips)
+            except tflite_reader.UnsupportedModel:
+                if labels is None:
+                    raise
         self.det = None
         anchors, n_anchors, n_classes = None, 0, 0
         if run_detector and self.kind == 'yolov5':
@@ -62,7 +73,8 @@ class MultiStreamPipeline:
             n_anchors, n_classes = prog.meta['rows'], prog.meta['n_classes']
         elif run_detector:
             kind, wd = load_ssd_model(model)                        # ('uint8', QModel): the reference's own arithmetic (csrc/netsq.hip)
-            prog = netsq.compile_ssd_mobilenet_quant(wd) if kind == 'uint8' else nets.compile_ssd_mobilenet(wd)
+            prog = (netsq.compile_ssd_mobilenet_quant(wd) if kind == 'uint8' else
+                    nets.compile_ssd_mobilenet(wd, mean=meta['mean'], std=meta['std']) if meta else nets.compile_ssd_mobilenet(wd))
             self.det_dtype = 'u8' if kind == 'uint8' else 'f16'
             self.det = Net(prog, max_batch=self.S, context=self.ctx)
             anchors = np.ascontiguousarray(prog.meta['anchors'], dtype=np.float32)
@@ -147,6 +159,14 @@ class MultiStreamPipeline:
         b, sc, cl, off = injected if injected is not None else (None, None, None, None)
         check(lib().dd_pipeline_step2(self._h, ptr(frames_dev), ptr(frames_next), ptr(b), ptr(sc), ptr(cl), ptr(off)),
               'dd_pipeline_step')
+
+    def detector_stream(self):
+        """The stream the look-ahead detector run is queued on (None without a detector): the consumer to name when acquiring the NEXT
+        step's frames from an ingest ring (`ring.frames(slot, stream=pipe.detector_stream())`), so that their upload is waited for by
+        their own detector run and not by this step's kernels."""
+        h = P()
+        check(lib().dd_pipeline_detector_stream(self._h, ctypes.byref(h)), 'dd_pipeline_detector_stream')
+        return h if h.value else None
 
     def counts(self):
         out = np.zeros((self.S, len(self.wanted), 4), dtype=np.int64)

@@ -530,8 +530,9 @@ def synthetic_ssd_weights(seed=1234):
     return wd
 
 
-def compile_ssd_mobilenet(wd, in_size=300):
-    """u8 RGB [n,300,300,3] -> f32 [n,1917,4+91] raw box encodings + class logits."""
+def compile_ssd_mobilenet(wd, in_size=300, mean=127.5, std=127.5):
+    """u8 RGB [n,300,300,3] -> f32 [n,1917,4+91] raw box encodings + class logits.  mean / std: the input normalisation (x - mean) / std, fused into
+    the first layer (a model file's NormalizationOptions, tools/tflite_object_detector.py:124-131,222-224 upstream; 127.5 / 127.5 without one)."""
     P = Program(in_size, in_size)
     anchors, maps = ssd_anchors(in_size)
     if 'anchors' in wd:                                     # a model file carries its own (the post-process op's third input)
@@ -540,7 +541,7 @@ def compile_ssd_mobilenet(wd, in_size=300):
     n_anchors = len(anchors)
     ld = 4 + SSD_CLASSES
     w, b = fold_conv_bn(wd, 'conv0')
-    x = P.stem(w, b, 2, ACT_RELU6, swap_rb=False, mean=127.5, scale=1.0 / 127.5)
+    x = P.stem(w, b, 2, ACT_RELU6, swap_rb=False, mean=float(mean), scale=1.0 / float(std))
     feats = []
     for i, (c, st) in enumerate(MOBILENET_V1, 1):
         s, t = bn_affine(wd, f'dw{i}/bn')

@@ -217,6 +217,51 @@ def _mars_variable_names():
     return out
 
 
+def _reverses_channels(path, nodes, consts):
+    """Does the graph reverse the channel axis of its input (tools/freeze_model.py:175-177: `image[:, :, ::-1]`)?  That statement freezes to a
+    StridedSlice whose strides constant is [1, .., 1, -1] (or, written with tf.reverse, a ReverseV2 over the last axis).  Every TF1 frozen graph
+    also holds StridedSlice nodes that pick dimensions out of a Shape (strides [1]): the op's presence alone says nothing.  A slice with a
+    negative stride that is NOT this form, or a reversal whose axis / strides are not constants, is refused rather than guessed at."""
+    def const_of(ref):
+        name = ref.split(':')[0].lstrip('^')
+        t = consts.get(name)
+        if t is None and name.endswith('/read'):
+            t = consts.get(name[:-5])
+        return None if t is None else np.asarray(t).reshape(-1)
+    found = False
+    for n in nodes:
+        if n.op == 'StridedSlice' and len(n.inputs) >= 4:
+            st = const_of(n.inputs[3])
+            if st is None:
+                continue                                     # (strides computed at run time: a shape manipulation, not the image slice)
+            if (st < 0).any():
+                if len(st) >= 1 and int(st[-1]) == -1 and all(int(v) == 1 for v in st[:-1]):
+                    found = True
+                else:
+                    raise UnsupportedGraph('%s: StridedSlice %r has strides %s: a reversal other than the channel axis of the crops' % (path, n.name, st.tolist()))
+        elif n.op == 'ReverseV2':
+            ax = const_of(n.inputs[1]) if len(n.inputs) >= 2 else None
+            if ax is None:
+                raise UnsupportedGraph('%s: ReverseV2 %r with an axis that is not a constant' % (path, n.name))
+            if set(int(v) for v in ax) <= {-1, 2, 3}:
+                found = True
+            else:
+                raise UnsupportedGraph('%s: ReverseV2 %r over axis %s: a reversal other than the channel axis of the crops' % (path, n.name, ax.tolist()))
+    return found
+
+
+def _check_arithmetic(path, nodes):
+    """The constants are mapped by name onto nets.compile_mars' fixed arithmetic (tools/freeze_model.py:13-157: scale-less batch norm with
+    epsilon 1e-3, ELU); where the graph states its own, it must state the same."""
+    for n in nodes:
+        if n.op.startswith('FusedBatchNorm'):
+            eps = n.attr.get('epsilon', {}).get('f')
+            if eps is not None and abs(float(eps) - 1e-3) > 1e-7:
+                raise UnsupportedGraph('%s: %s %r has epsilon %g (the encoder is built for slim\'s 1e-3)' % (path, n.op, n.name, eps))
+        elif n.op in ('Relu', 'Relu6', 'LeakyRelu', 'Selu', 'Tanh', 'Sigmoid', 'Swish'):
+            raise UnsupportedGraph('%s: activation %s at %r (the encoder\'s activation is ELU, tools/freeze_model.py:27,57)' % (path, n.op, n.name))
+
+
 def load_mars(path, input_name='images', output_name='features'):
     """-> (named f32 weights for nets.compile_mars, (height, width) of the crops the graph takes)."""
     nodes = read(path)
@@ -249,8 +294,9 @@ def load_mars(path, input_name='images', output_name='features'):
     for name, want in (('conv1_1/weights', (3, 3, 3, 32)), ('conv3_1/projection/weights', (1, 1, 32, 64)), ('conv4_3/2/weights', (3, 3, 128, 128))):
         if wd[name].shape != want:
             raise UnsupportedGraph('%s: %s has shape %s (expected %s)' % (path, name, wd[name].shape, want))
-    # freeze_model.py:175-177,203-205: the graph reverses the channel axis of the BGR crops itself (a StridedSlice inside the map_fn)
-    wd['__swap_rb__'] = any(n.op in ('StridedSlice', 'ReverseV2') for n in nodes)
+    # freeze_model.py:175-177,203-205: the graph reverses the channel axis of the BGR crops itself (`image[:, :, ::-1]` inside the map_fn)
+    wd['__swap_rb__'] = _reverses_channels(path, nodes, consts)
+    _check_arithmetic(path, nodes)
     wd['__in_hw__'] = (h, w)
     return wd, (h, w)
 
@@ -303,8 +349,16 @@ def write_mars(wd, path, in_hw=(128, 64), reverse_channels=True):
     h, w = in_hw
     out = [node('images', 'Placeholder', (), [_attr('dtype', _vi(6, 4)), _attr('shape', _ld(7, _shape_msg([-1, h, w, 3])))])]
     out.append(node('Cast', 'Cast', ('images',), [_attr('SrcT', _vi(6, 4)), _attr('DstT', _vi(6, 1))]))
-    if reverse_channels:
-        out.append(node('map/while/strided_slice', 'StridedSlice', ('Cast',), [_attr('T', _vi(6, 1))]))
+    if reverse_channels:                       # image[:, :, ::-1] of one crop inside the map_fn: begin / end / strides constants, strides [1, 1, -1]
+        for suffix, vals in (('stack', [0, 0, 0]), ('stack_1', [0, 0, 0]), ('stack_2', [1, 1, -1])):
+            out.append(const_node('map/while/strided_slice/' + suffix, np.asarray(vals, dtype=np.int32)))
+        out.append(node('map/while/strided_slice', 'StridedSlice', ('Cast', 'map/while/strided_slice/stack', 'map/while/strided_slice/stack_1',
+                                                                   'map/while/strided_slice/stack_2'), [_attr('T', _vi(6, 1))]))
+    # (what every TF1 frozen graph also holds: a StridedSlice that picks a dimension out of a Shape -- not a reversal)
+    out.append(node('Shape', 'Shape', ('images',), [_attr('T', _vi(6, 4))]))
+    for suffix, vals in (('stack', [0]), ('stack_1', [1]), ('stack_2', [1])):
+        out.append(const_node('strided_slice/' + suffix, np.asarray(vals, dtype=np.int32)))
+    out.append(node('strided_slice', 'StridedSlice', ('Shape', 'strided_slice/stack', 'strided_slice/stack_1', 'strided_slice/stack_2'), [_attr('T', _vi(6, 3))]))
     inv = {v[0]: k for k, v in _mars_variable_names().items()}
     last = 'images'
     for name in sorted(k for k in wd if not k.startswith('__')):

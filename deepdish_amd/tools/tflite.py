@@ -59,17 +59,34 @@ class ObjectDetector:
         post = ssd_post_options(wd)                           # the post-process op's own options (its file's, else the stock export's)
         self.MAX_DET = int(post['max_detections'])
         self._score_thr, self._iou_thr = float(post['nms_score_threshold']), float(post['nms_iou_threshold'])
-        prog = nets.compile_ssd_mobilenet(wd)                 # float model: (x - 127.5) / 127.5 in the input op
-        self._mean = self._std = 127.5                        # tflite_object_detector.py:124-131 defaults
+        # tflite_object_detector.py:117-137: mean / std and the label list come from the model file's own metadata.  A model WITHOUT metadata
+        # (the reference's MetadataDisplayer raises on one) is taken with a label_file and the defaults: an extension for this build's
+        # synthetic / .npz models, never consulted when the file carries metadata (the reference ignores its label_file argument, tflite.py:16-23).
+        import os
+        meta = None
+        if str(model_path).endswith('.tflite') and os.path.exists(str(model_path)):
+            from . import tflite_reader
+            try:
+                meta = tflite_reader.read_metadata(str(model_path))
+            except tflite_reader.UnsupportedModel:
+                if label_file is None:
+                    raise
+        elif label_file is None:
+            raise ValueError('%s: not a .tflite file with metadata, and no label_file given' % model_path)
+        self._mean, self._std = (meta['mean'], meta['std']) if meta else (127.5, 127.5)     # :124-131 (defaults without a NormalizationOptions unit)
+        prog = nets.compile_ssd_mobilenet(wd, mean=self._mean, std=self._std)     # float model: (x - mean) / std in the input op (:222-224)
         self.net = Net(prog, max_batch=1, context=self.ctx)
         self._input_size = prog.in_w, prog.in_h
         self._is_quantized_input = False
         self._anchors = prog.meta['anchors']
         self._anchors_dev = self.ctx.to_device(self._anchors)
         self._n_classes = prog.meta['n_classes']
-        with open(label_file) as f:                           # the metadata label map: class id 0 is the first real class
-            lines = [l.strip() for l in f.readlines()]
-        self._label_list = list(filter(len, lines[1:]))
+        if meta:
+            self._label_list = list(meta['labels'])           # :134-137 the packed label map: class id 0 is its first line
+        else:
+            with open(label_file) as f:                       # (no metadata) a label file in the SSD adaptor's form: line 0 is the background entry
+                lines = [l.strip() for l in f.readlines()]
+            self._label_list = list(filter(len, lines[1:]))
         self._options = options
         c = self.ctx
         self._resized = c.empty((1, prog.in_h, prog.in_w, 3), torch.uint8)

@@ -124,6 +124,44 @@ class UnsupportedModel(ValueError):
     pass
 
 
+def read_metadata(path_or_bytes):
+    """TFLite Model Metadata of a model file, the part tools/tflite_object_detector.py:117-137 upstream takes from
+    `metadata.MetadataDisplayer` (tflite_support, absent here): -> dict(mean, std, labels, label_file).
+      * mean / std: the first values of the input tensor's NormalizationOptions process unit, 127.5 / 127.5 without one (:124-131);
+      * labels: the FIRST packed associated file (the ZIP archive behind the flatbuffer), decoded, empty lines dropped (:134-137).
+    UnsupportedModel where the reference's calls raise: no TFLITE_METADATA buffer, no packed file."""
+    import io
+    import zipfile
+    buf = path_or_bytes if isinstance(path_or_bytes, (bytes, bytearray, memoryview)) else open(path_or_bytes, 'rb').read()
+    name = path_or_bytes if isinstance(path_or_bytes, str) else '<bytes>'
+    m = flatbuf.root(buf, b'TFL3')
+    meta_buf = None
+    buffers = m.tables(4)
+    for e in m.tables(6):                       # Model.metadata: [Metadata {0 name, 1 buffer}]
+        if e.string(0) == 'TFLITE_METADATA' and e.scalar(1, 'u32') < len(buffers):
+            meta_buf = bytes(buffers[e.scalar(1, 'u32')].scalars(0, 'u8'))
+    if not meta_buf:
+        raise UnsupportedModel('%s: the model file carries no TFLITE_METADATA buffer (the generic adaptor takes mean / std and the label list from it, '
+                               'tools/tflite_object_detector.py:117-137 upstream)' % name)
+    root = flatbuf.root(meta_buf, b'M001')
+    mean = std = 127.5
+    subs = root.tables(3)                       # ModelMetadata.subgraph_metadata
+    if subs and subs[0].tables(2):              # SubGraphMetadata.input_tensor_metadata[0].process_units
+        for unit in subs[0].tables(2)[0].tables(4):
+            if unit.scalar(0, 'u8') == 1:       # ProcessUnitOptions.NormalizationOptions {0 mean, 1 std}
+                o = unit.table(1)
+                mean, std = float(o.scalars(0, 'f32')[0]), float(o.scalars(1, 'f32')[0])
+    try:
+        z = zipfile.ZipFile(io.BytesIO(bytes(buf)))
+        names = z.namelist()
+    except zipfile.BadZipFile:
+        names = []
+    if not names:
+        raise UnsupportedModel('%s: no associated file is packed into the model file (the label list is its first packed file)' % name)
+    text = z.read(names[0]).decode()
+    return dict(mean=mean, std=std, labels=list(filter(len, text.splitlines())), label_file=names[0])
+
+
 def _need(cond, op, what):
     if not cond:
         raise UnsupportedModel('operator %s: %s' % (op, what))

@@ -17,10 +17,45 @@ OPTIONS_TYPE = {'CONV_2D': 1, 'DEPTHWISE_CONV_2D': 2, 'CONCATENATION': 10, 'RESH
 ACT = {'none': 0, 'relu': 1, 'relu6': 3}
 
 
+def metadata_bytes(mean, std, label_file):
+    """The metadata flatbuffer (schema tflite_metadata, file identifier M001), the fields the reference reads: ModelMetadata.subgraph_metadata[0]
+    .input_tensor_metadata[0].process_units[] with a NormalizationOptions unit (mean, std: [f32]) and, on the output tensor, the associated
+    label file's name.  Slots: ModelMetadata {0 name, 1 description, 2 version, 3 subgraph_metadata}; SubGraphMetadata {0 name, 2 input_tensor_metadata,
+    3 output_tensor_metadata}; TensorMetadata {0 name, 4 process_units, 6 associated_files}; ProcessUnit {0 options_type (1 = NormalizationOptions),
+    1 options}; NormalizationOptions {0 mean, 1 std}; AssociatedFile {0 name, 2 type (2 = TENSOR_AXIS_LABELS... 3 = TENSOR_VALUE_LABELS)}."""
+    b = flatbuf.Builder()
+    units = []
+    if mean is not None:
+        norm = b.table({0: ('offset', b.scalars([float(v) for v in np.atleast_1d(mean)], 'f32')), 1: ('offset', b.scalars([float(v) for v in np.atleast_1d(std)], 'f32'))})
+        units.append(b.table({0: ('u8', 1), 1: ('offset', norm)}))
+    tin = b.table({0: ('offset', b.string('image')), 4: ('offset', b.offsets(units) if units else 0)})
+    outs = []
+    for k, name in enumerate(('location', 'category', 'score', 'number of detections')):
+        files = 0
+        if k == 1 and label_file is not None:
+            files = b.offsets([b.table({0: ('offset', b.string(label_file)), 2: ('i8', 3)})])
+        outs.append(b.table({0: ('offset', b.string(name)), 6: ('offset', files)}))
+    sub = b.table({0: ('offset', b.string('main')), 2: ('offset', b.offsets([tin])), 3: ('offset', b.offsets(outs))})
+    root = b.table({0: ('offset', b.string('ObjectDetector')), 2: ('offset', b.string('v1')), 3: ('offset', b.offsets([sub]))})
+    return b.finish(root, b'M001')
+
+
+def packed_files(files):
+    """{name: text} -> the ZIP archive the metadata tooling appends to the model file (stored, no compression)."""
+    import io
+    import zipfile
+    bio = io.BytesIO()
+    with zipfile.ZipFile(bio, 'w', zipfile.ZIP_STORED) as z:
+        for name, text in files.items():
+            z.writestr(name, text)
+    return bio.getvalue()
+
+
 class GraphWriter:
     def __init__(self, description='deepdish_amd'):
         self.tensors, self.ops, self.buffers, self.codes = [], [], [b''], []
         self.inputs, self.outputs, self.description = [], [], description
+        self.metadata = None              # dict(mean=[..], std=[..] (None: no NormalizationOptions unit), labels=[..], label_file='labelmap.txt'): see metadata_bytes
 
     def tensor(self, name, shape, dtype, data=None, scale=None, zero_point=None):
         buf = 0
@@ -94,8 +129,21 @@ class GraphWriter:
             c_pos.append(b.table({0: ('i8', min(code, 127)), 1: ('offset', cs), 2: ('i32', 1), 3: ('i32', code)}))
         codes = b.offsets(c_pos)
         desc = b.string(self.description)
-        model = b.table({0: ('u32', 3), 1: ('offset', codes), 2: ('offset', subs), 3: ('offset', desc), 4: ('offset', buffers)})
-        return b.finish(model, b'TFL3')
+        fields = {0: ('u32', 3), 1: ('offset', codes), 2: ('offset', subs), 3: ('offset', desc), 4: ('offset', buffers)}
+        if self.metadata is not None:             # Model.metadata: [Metadata{name, buffer}] -- the buffer (appended last) holds the metadata flatbuffer
+            entry = b.table({0: ('offset', b.string('TFLITE_METADATA')), 1: ('u32', len(self.buffers) - 1)})
+            fields[6] = ('offset', b.offsets([entry]))
+        model = b.table(fields)
+        out = b.finish(model, b'TFL3')
+        if self.metadata is not None and self.metadata.get('labels') is not None:
+            out += packed_files({self.metadata.get('label_file', 'labelmap.txt'): '\n'.join(self.metadata['labels']) + '\n'})
+        return out
+
+    def set_metadata(self, mean=None, std=None, labels=None, label_file='labelmap.txt'):
+        """TFLite Model Metadata as the Task library's tooling writes it (what tools/tflite_object_detector.py:117-137 upstream reads): a
+        `TFLITE_METADATA` buffer -- NormalizationOptions of the input tensor -- and the label file packed behind the flatbuffer as a ZIP archive."""
+        self.metadata = dict(mean=mean, std=std, labels=labels, label_file=label_file)
+        self.buffers.append(metadata_bytes(mean, std, label_file if labels is not None else None))
 
 
 def ssd_mobilenet_graph(model, anchors=None, post=None):
@@ -282,9 +330,13 @@ def write_mars(wd, path, reverse_channels=True, half_weights=False, explicit_pad
     return len(data)
 
 
-def write_ssd_mobilenet(model, path, anchors=None, post=None):
-    """post: overrides of the TFLite_Detection_PostProcess options ({name: value}; None drops the key)."""
-    data = ssd_mobilenet_graph(model, anchors, post=post).tobytes()
+def write_ssd_mobilenet(model, path, anchors=None, post=None, metadata=None):
+    """post: overrides of the TFLite_Detection_PostProcess options ({name: value}; None drops the key).  metadata: dict(mean, std, labels
+    [, label_file]) -> TFLite Model Metadata + the packed label file (GraphWriter.set_metadata), as the generic adaptor's models carry them."""
+    g = ssd_mobilenet_graph(model, anchors, post=post)
+    if metadata is not None:
+        g.set_metadata(**metadata)
+    data = g.tobytes()
     with open(path, 'wb') as f:
         f.write(data)
     return len(data)

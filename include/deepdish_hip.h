@@ -364,6 +364,11 @@ int dd_pipeline_step(dd_pipeline *p, const uint8_t *frames, const double *inj_bo
  * not be handed in here (pass NULL instead).  frames_next == frames is rejected (DD_E_ARG). */
 int dd_pipeline_step2(dd_pipeline *p, const uint8_t *frames, const uint8_t *frames_next, const double *inj_boxes_host,
                       const double *inj_scores_host, const int *inj_cls_host, const int *inj_offsets_host);
+/* The stream the look-ahead detector run of dd_pipeline_step2 is queued on (NULL for a pipeline without a detector).  A caller whose
+ * `frames_next` are still on their way to the device hands it to dd_ingest_acquire as the consumer of THAT slot: the upload of frame
+ * t + 1 is then waited for by the detector run of frame t + 1 alone, not by step t's own kernels -- the reference's capture thread fills
+ * the next frame while the stages work on the current one the same way (deepdish.py:837-878, FreshQueue :192-203). */
+int dd_pipeline_detector_stream(dd_pipeline *p, void **stream_out);
 /* counts_host: int64 [n_streams][n_wanted][4] = poscount, negcount, intcount, delcount */
 /* Background subtraction for every stream of the pipeline (deepdish.py:512,889,920-924,957): ratio =
  * --background-subtraction-ratio (reference default 0.25), ratio < 0 = --disable-background-subtraction (the state

@@ -73,3 +73,53 @@ def test_ingest_ring_feeds_the_pipeline():
         np.testing.assert_array_equal(res[0][0][z][1], res[1][0][z][1])
     np.testing.assert_array_equal(res[0][1], res[1][1])
     assert sum(len(t[0]) for t in res[0][0]) > 0
+
+
+def test_ingest_ring_with_detector_look_ahead():
+    """The bench's --ingest-host loop: the upload of frame t + 1 runs under step t, and the look-ahead detector run of frame t + 1 is the
+    consumer that waits for it (`frames(slot, stream=pipe.detector_stream())`), not step t's own kernels.  The detector's own rows
+    (no injected detections, every label wanted, uint8 model) and the tracks must be those of frames handed over as device tensors."""
+    from deepdish_amd.ingest import FrameIngest
+    from deepdish_amd.multipipe import MultiStreamPipeline
+    from deepdish_amd.pipeline import DEFAULT_LABELS
+    from deepdish_amd.synth import Scene
+    S, F = 3, 7
+    labels = [l.strip() for l in open(DEFAULT_LABELS)][1:]
+    wanted = [l for l in labels if l and l != '???']
+    scenes = [Scene(seed=40 + z, n_obj=6, n_frames=F) for z in range(S)]
+    all_frames = [np.stack([sc.frame(f) for sc in scenes]) for f in range(F)]
+    res = []
+    for mode in ('direct', 'ring'):
+        mp = MultiStreamPipeline(S, model='synthetic-ssd_mobilenet_v1-uint8', wanted_labels=wanted)
+        rows = []
+        if mode == 'direct':
+            dev = [torch.from_numpy(fr).cuda() for fr in all_frames]
+            for f in range(F):
+                mp.step(dev[f], None, dev[f + 1] if f + 1 < F else None)
+                rows.append([mp.detections(z) for z in range(S)])
+        else:
+            ing = FrameIngest(S, (640, 480), slots=F, context=mp.ctx)
+            assert mp.detector_stream() is not None
+            for f in range(F):
+                ing.host(f)[...] = all_frames[f]
+            ing.submit(0)
+            for f in range(F):
+                if f + 1 < F:
+                    ing.submit(f + 1)
+                nxt = ing.frames(f + 1, stream=mp.detector_stream()) if f + 1 < F else None
+                mp.step(ing.frames(f), None, nxt)
+                ing.release(f)
+                rows.append([mp.detections(z) for z in range(S)])
+        res.append((rows, [mp.tracker(z).table() for z in range(S)], mp.counts()))
+    n_rows = 0
+    for f in range(F):
+        for z in range(S):
+            a, b = res[0][0][f][z], res[1][0][f][z]
+            assert list(a[1]) == list(b[1])
+            np.testing.assert_array_equal(np.asarray(a[0], np.float64), np.asarray(b[0], np.float64))
+            np.testing.assert_array_equal(np.asarray(a[2], np.float64), np.asarray(b[2], np.float64))
+            n_rows += len(a[1])
+    assert n_rows > 0                                            # random weights do emit rows with every label wanted
+    for z in range(S):
+        np.testing.assert_array_equal(res[0][1][z][0], res[1][1][z][0])
+    np.testing.assert_array_equal(res[0][2], res[1][2])

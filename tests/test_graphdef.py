@@ -66,3 +66,44 @@ def test_other_graphs_are_refused_by_name(tmp_path):
         G.load_mars(path)
     G.write_mars(nets.synthetic_mars_weights(3), path, in_hw=(64, 32), reverse_channels=False)
     assert G.load_mars(path)[0]['__swap_rb__'] is False
+
+
+def test_channel_reversal_is_detected_specifically(tmp_path):
+    """`__swap_rb__` (the graph reverses the BGR crops itself, tools/freeze_model.py:175-177) follows from a StridedSlice with strides
+    [1, 1, -1] (or a ReverseV2 over the last axis) -- not from the shape-picking StridedSlice every TF1 frozen graph holds; a reversal of
+    another axis and a graph that states other arithmetic (batch-norm epsilon, activation) are refused."""
+    import struct
+    from deepdish_amd import nets
+    from deepdish_amd.tools import graphdef as G
+    wd = nets.synthetic_mars_weights(5)
+    p = str(tmp_path / 'a.pb')
+    G.write_mars(wd, p, in_hw=(64, 32), reverse_channels=True)
+    assert any(n.op == 'StridedSlice' and n.name == 'strided_slice' for n in G.read(p))      # the shape slice is there in both files
+    assert G.load_mars(p)[0]['__swap_rb__'] is True
+    G.write_mars(wd, p, in_hw=(64, 32), reverse_channels=False)
+    assert any(n.op == 'StridedSlice' for n in G.read(p)) and G.load_mars(p)[0]['__swap_rb__'] is False
+    base = open(p, 'rb').read()
+    # tf.reverse(image, [-1]) instead of the slice
+    extra = G.const_node('ReverseV2/axis', np.asarray([-1], np.int32)) + G.node('ReverseV2', 'ReverseV2', ('Cast', 'ReverseV2/axis'), [G._attr('T', G._vi(6, 1))])
+    open(p, 'wb').write(base + extra)
+    assert G.load_mars(p)[0]['__swap_rb__'] is True
+    # a flip of the rows is not the channel reversal
+    extra = G.const_node('flip/stack_2', np.asarray([-1, 1, 1], np.int32)) + G.const_node('flip/stack', np.asarray([0, 0, 0], np.int32)) + \
+        G.node('flip', 'StridedSlice', ('Cast', 'flip/stack', 'flip/stack', 'flip/stack_2'), [G._attr('T', G._vi(6, 1))])
+    open(p, 'wb').write(base + extra)
+    with pytest.raises(G.UnsupportedGraph) as e:
+        G.load_mars(p)
+    assert 'flip' in str(e.value)
+    # other arithmetic than the encoder's
+    eps = G._ld(5, G._ld(1, b'epsilon') + G._ld(2, bytes([0x25]) + struct.pack('<f', 1e-5)))
+    open(p, 'wb').write(base + G.node('conv1_1/conv1_1/bn/FusedBatchNorm', 'FusedBatchNorm', ('Cast',), [eps]))
+    with pytest.raises(G.UnsupportedGraph) as e:
+        G.load_mars(p)
+    assert 'epsilon' in str(e.value)
+    eps = G._ld(5, G._ld(1, b'epsilon') + G._ld(2, bytes([0x25]) + struct.pack('<f', 1e-3)))
+    open(p, 'wb').write(base + G.node('conv1_1/conv1_1/bn/FusedBatchNorm', 'FusedBatchNorm', ('Cast',), [eps]))
+    assert G.load_mars(p)[0]['__swap_rb__'] is False
+    open(p, 'wb').write(base + G.node('conv1_1/Relu', 'Relu', ('Cast',), [G._attr('T', G._vi(6, 1))]))
+    with pytest.raises(G.UnsupportedGraph) as e:
+        G.load_mars(p)
+    assert 'Relu' in str(e.value)

@@ -289,3 +289,50 @@ def test_mars_reader_accepts_explicit_same_padding(tmp_path):
     with pytest.raises(tflite_reader.UnsupportedModel) as e:
         tflite_reader.load_mars(b)
     assert 'explicit padding' in str(e.value)
+
+
+def _float_ssd(seed=7):
+    from deepdish_amd import nets, quantize
+    wd = nets.synthetic_ssd_weights(seed)
+    folded = {}
+    for name, kind, w, b, stride, act in quantize.folded_ssd_layers(wd):
+        folded[name + '/weights'] = w if kind == 'conv' else w[:, :, :, None]
+        folded[name + '/biases'] = b
+    return wd, folded
+
+
+def test_model_metadata_round_trip_and_refusals(tmp_path):
+    """TFLite Model Metadata as tools/tflite_object_detector.py:117-137 upstream reads it: NormalizationOptions mean / std of the input tensor
+    and the label list = the first associated file packed (as a ZIP archive) behind the flatbuffer.  The file stays a model the reader maps;
+    a file without metadata, or with metadata but no packed file, is refused where the reference's MetadataDisplayer calls raise."""
+    import zipfile
+    from deepdish_amd import nets
+    from deepdish_amd.tools import tflite_writer, tflite_reader as R
+    from deepdish_amd.tools.weights_io import load_ssd_model
+    wd, folded = _float_ssd()
+    labels = ['person', 'bicycle', 'car', '', 'motorcycle', 'traffic light']
+    path = str(tmp_path / 'efficientdet-style.tflite')
+    tflite_writer.write_ssd_mobilenet(folded, path, metadata=dict(mean=[127.0], std=[128.0], labels=labels, label_file='labelmap.txt'))
+    m = R.read_metadata(path)
+    assert (m['mean'], m['std'], m['label_file']) == (127.0, 128.0, 'labelmap.txt')
+    assert m['labels'] == ['person', 'bicycle', 'car', 'motorcycle', 'traffic light']      # list(filter(len, ...)), :136
+    assert zipfile.ZipFile(path).namelist() == ['labelmap.txt']                            # the archive a stock zip reader sees
+    kind, wd2 = load_ssd_model(path)                                                       # ... and still the same detector
+    assert kind == 'f32' and bytes(nets.compile_ssd_mobilenet(wd2).blob) == bytes(nets.compile_ssd_mobilenet(wd).blob)
+    assert not (nets.compile_ssd_mobilenet(wd2, mean=127.0, std=128.0).serialize()[0] == nets.compile_ssd_mobilenet(wd2).serialize()[0]).all()   # (the first layer's op words carry them)
+    # no NormalizationOptions unit: the reference's defaults (:124-125)
+    p2 = str(tmp_path / 'no-normalisation.tflite')
+    tflite_writer.write_ssd_mobilenet(folded, p2, metadata=dict(mean=None, std=None, labels=labels))
+    m2 = R.read_metadata(p2)
+    assert (m2['mean'], m2['std']) == (127.5, 127.5) and len(m2['labels']) == 5
+    # no metadata at all / metadata without a packed file
+    p3 = str(tmp_path / 'plain.tflite')
+    tflite_writer.write_ssd_mobilenet(folded, p3)
+    with pytest.raises(R.UnsupportedModel) as e:
+        R.read_metadata(p3)
+    assert 'TFLITE_METADATA' in str(e.value)
+    p4 = str(tmp_path / 'no-labels.tflite')
+    tflite_writer.write_ssd_mobilenet(folded, p4, metadata=dict(mean=[127.5], std=[127.5], labels=None))
+    with pytest.raises(R.UnsupportedModel) as e:
+        R.read_metadata(p4)
+    assert 'packed' in str(e.value)
