@@ -407,6 +407,10 @@ def main():
     args = parse()
     if args.gpus > 1 and 'RANK' not in os.environ:
         sys.exit(launch_ranks(args))                         # before torch is imported or the GPU is touched
+    if args.ingest_host:
+        # two worker groups = six HIP streams (main, detector, copy each); ROCm maps streams onto 4 hardware queues by default and a copy stream
+        # that shares one with another group's kernels waits behind them: 47.9 k frames/s with 4 queues, 54.4-54.7 k with 6 / 8 / 16 (same box)
+        os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
     if 'RANK' in os.environ:
         # a rank started by a launcher other than launch_ranks (the driver's `python -m torch.distributed.run ...`): RCCL needs dmabuf IPC
         # on this host driver, and the variable must be in the environment before torch / the HIP runtime are loaded
@@ -605,7 +609,9 @@ def main():
             out['pcie'] = {'bytes_per_step': step_bytes, 'achieved': gbs, 'peak': 63.0, 'unit': 'GB/s', 'frac': gbs / 63.0,
                            'pinned_slots_per_group': n_frames, 'pinned_host_bytes': n_frames * step_bytes,
                            'bound_frames_per_s': 63.0e9 / (H * W * 3),
-                           'note': 'PCIe Gen5 x16 spec 63 GB/s (MI355X_MICROARCH.md): the most a host can feed one GPU at %dx%d BGR' % (W, H)}
+                           'copy_ceiling_measured': 57.4,
+                           'note': 'PCIe Gen5 x16 spec 63 GB/s (MI355X_MICROARCH.md): the most a host can feed one GPU at %dx%d BGR; copy_ceiling_measured = pinned '
+                                   'host -> device copies alone on an idle GPU of this pool (scripts/experiments/pcie_rates.py, 2 streams x 708 MB, either NUMA node)' % (W, H)}
             extra_only = True
         if not extra_only:
             try:
