@@ -801,7 +801,78 @@ __global__ __launch_bounds__((COUT / (16 * MW)) * WP * 64, (COUT / (16 * MW)) * 
                 }
             }
         };
-        if constexpr (KEEP) {
+#ifndef DD_DW_STREAM
+#define DD_DW_STREAM 1
+#endif
+        if constexpr (TAP_ONCE && DD_DW_STREAM != 0 && !KEEP) {
+            // The wave's planes as ONE stream of (plane, k step, fragment) operands with a rolling window of DW_W of them in flight: the next plane's
+            // first operands (and its table words) are requested before this plane's requantisation starts and carried into the next round of the
+            // loop.  Plane by plane (the form below) every plane began with a cold LDS round trip, and two waves per SIMD did not cover it: 7.6 k
+            // cycles per tile for ~2 k of matrix and ~2 k of vector work per wave (512-channel block).  The loop stays rolled (unrolled, hipcc hoists
+            // every plane's addresses and tables to the top: 200+ bytes of scratch).  The rare lo parts (lom != 0) are added behind the plane's
+            // stream from re-read operands.
+            constexpr int DW_W = 6;
+            static_assert(12 % DW_W == 0, "the window slots of a plane's first operands are those of the next plane's");
+            auto opnd_at = [&](int pofs, int j) __attribute__((always_inline)) {
+                return *reinterpret_cast<const i4v *>(ring + tapoff[j / 4][j % 4] + pofs);
+            };
+            i4v b[DW_W];
+            int cg = (wave * CPW) % C16;
+            uint2 ab = dwa_l[cg * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < DW_W; ++j) b[j] = opnd_at(cg * PP, j);
+#pragma unroll 1
+            for (int ci = 0; ci < CPW; ++ci) {
+                const int pofs = cg * PP;
+                i4v acc[4];
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) {
+                    i4v Ah;
+                    const unsigned rh = __builtin_amdgcn_perm(ab.x, ab.x, 0x01010101u * (unsigned)ks);
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) Ah[d] = (int)(rh & dmask[d]);
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) {
+                        const int j = ks * 4 + f;
+                        if (ks == 0) acc[f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Ah, b[j % DW_W], i4v{0, 0, 0, 0}, 0, 0, 0);
+                        else acc[f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Ah, b[j % DW_W], acc[f], 0, 0, 0);
+                        if (j + DW_W < 12) b[j % DW_W] = opnd_at(pofs, j + DW_W);
+                    }
+                }
+                // the next plane's head (the last round re-requests its own: nobody reads them)
+                const int cgn = (wave * CPW + min(ci + 1, CPW - 1)) % C16;
+                const uint2 abn = dwa_l[cgn * 64 + lane];
+                long long Cq[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Cq[r] = dwq_l[cg * 16 + 4 * fq + r];
+                const unsigned lom = (unsigned)__builtin_amdgcn_readfirstlane((int)(ab.y >> 24));
+                if (lom) {                                           // (few planes: only a tensor's extreme weights overflow int8)
+#pragma unroll
+                    for (int ks = 0; ks < 3; ++ks) {
+                        if (lom & (1u << ks)) {
+                            const unsigned rl = __builtin_amdgcn_perm(ab.y, ab.y, 0x01010101u * (unsigned)ks);
+                            i4v Al;
+#pragma unroll
+                            for (int d = 0; d < 4; ++d) Al[d] = (int)(rl & dmask[d]);
+#pragma unroll
+                            for (int f = 0; f < 4; ++f)
+                                acc[f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Al, *reinterpret_cast<const i4v *>(ring + tapoff[ks][f] + pofs), acc[f], 0, 0, 0);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < DW_W; ++j) b[j] = opnd_at(cgn * PP, j);
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    unsigned packed = q_requant_pack4<SAT>(acc[f][0], acc[f][1], acc[f][2], acc[f][3], Md, Cq[0], Cq[1], Cq[2], Cq[3], shd, lod, hid);
+                    packed ^= 0x80808080u;
+                    if (ROWSUM) rs[f] = sdot4((int)packed, 0x01010101, rs[f]);
+                    *reinterpret_cast<unsigned *>(opnd + ((size_t)cg * QTT + 16 * (fb + f) + fr) * 16 + 4 * fq) = packed;
+                }
+                cg = cgn;
+                ab = abn;
+            }
+        } else if constexpr (KEEP) {
 #pragma unroll
             for (int ci = 0; ci < CPW; ++ci) plane(wave * CPW + ci, ci);
         } else {

@@ -9,14 +9,14 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 export DD_BENCH_GEN_WORKERS=1      # every profiled run generates its frames in-process: no generator pool forked from a process the profiler's preloaded library may have initialised the GPU in
 PARTS=${*:-layers trace pmc sq}
-S=${DD_PROF_STREAMS:-768}      # streams of the one worker group the passes profile = frames per detector launch of the default bench
+S=${DD_PROF_STREAMS:-1536}     # streams of the one worker group the passes profile = frames per detector launch of the default bench (two groups of 1 536 since round 6)
 B="python3 $R/bench.py --groups 1 --streams $S --steps 20 --warmup 5 --no-cpu-baseline"
 for part in $PARTS; do
 case $part in
 tests)
     (cd $R && timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/gputests.log 2>&1; echo "rc=$?" >> $O/gputests.log; tail -3 $O/gputests.log) ;;
 layers)
-    for kb in "ssd_i8 384" "ssd_i8 768" "ssd 384" "mars 7680" "mars 15360" "yolo 128"; do set -- $kb
+    for kb in "ssd_i8 384" "ssd_i8 768" "ssd_i8 1536" "mars 15360" "mars 30720" "yolo 256"; do set -- $kb
         python3 $R/scripts/profile_layers.py $1 $2 > $O/layers_$1_b$2.txt 2>&1; tail -1 $O/layers_$1_b$2.txt; done ;;
 trace)
     DD_BENCH_NO_LOOKAHEAD=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_g1 -- python3 $R/bench.py --groups 1 --streams $S --steps 40 --warmup 5 --no-cpu-baseline > $O/bench_groups1_s$S.json 2> $O/kt_g1.err
