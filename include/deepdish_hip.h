@@ -349,7 +349,9 @@ int dd_pipeline_destroy(dd_pipeline *p);
 int dd_pipeline_detector_adaptor(dd_pipeline *p, int adaptor);
 /* Options of the TFLite_Detection_PostProcess op inside an SSD-type model file, which the reference's interpreter applies as the file
  * states them (tools/ssd_mobilenet.py:100-109: invoke() + the four output tensors of max_detections rows): rows per frame (<= 64),
- * nms_score_threshold, nms_iou_threshold (fast class-agnostic NMS).  Defaults: the stock export's 10 / 1e-8 / 0.6.  Before the first step. */
+ * nms_score_threshold, nms_iou_threshold (fast class-agnostic NMS).  Defaults: the stock export's 10 / 1e-8 / 0.6.  Before the first step.
+ * Above 16 rows the ORDER of equal-score rows of one class is the reference's only up to its NumPy's unstable sort (tools/ssd_mobilenet.py:73
+ * `s.argsort()[::-1]`: stable for <= 16 elements, unspecified beyond) -- INTEGRATION.md, "Ties inside a class". */
 int dd_pipeline_ssd_options(dd_pipeline *p, int max_detections, float nms_score_threshold, float nms_iou_threshold);
 /* frames: device u8 [n_streams][H][W][3] BGR.  inj_*: optional detections that REPLACE the detector's
  * output (it still runs): tlwh f64 rows, scores, class ids; stream s owns rows

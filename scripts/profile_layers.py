@@ -36,9 +36,18 @@ acc /= reps
 tot = 0
 print(f'{kind} batch {batch}: op  kernel  ms  GFLOP  MB  TFLOP/s  GB/s')
 codes = net_op_launches(net)
+pend = None                                              # ops folded into the NEXT op's launch: that launch's row carries their FLOPs, reads the first one's source
 for i, (ms, info, op) in enumerate(zip(acc, prog.info, prog.ops)):
     fl, by = info['flops'] * batch, info['bytes'] * batch + info.get('wbytes', 0)
     tot += ms
+    if codes[i] == OPK_FOLDED:
+        if pend is None:
+            pend = [info['flops'] * batch, info.get('src_bytes', 0) * batch + info.get('wbytes', 0)]
+        else:
+            pend[0] += info['flops'] * batch; pend[1] += info.get('wbytes', 0)
+    elif pend is not None and codes[i] != OPK_FOLDED_PREV:
+        fl, by = fl + pend[0], by - info.get('src_bytes', 0) * batch + pend[1]
+        pend = None
     kname = '(in the next launch)' if codes[i] == OPK_FOLDED else '(in the previous launch)' if codes[i] == OPK_FOLDED_PREV else OPK_NAMES.get(int(codes[i]), info['kernel'])
     print(f'{i:3d} {kname:26s} {ms*1e3:8.1f}us {fl/1e9:8.3f} {by/1e6:8.2f} {fl/ms/1e9 if ms else 0:8.1f} {by/ms/1e6 if ms else 0:8.1f}  k={op[5]}x{op[6]} s={op[7]} cin={op[10]} cout={op[11]} hw={op[26]}x{op[27]}')
 print('total ms', tot, 'GFLOP', sum(i['flops'] for i in prog.info) * batch / 1e9)
