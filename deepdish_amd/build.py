@@ -24,7 +24,7 @@ STRICT_FP = {'kalman.hip', 'cost.hip', 'nms.hip', 'tracker.hip', 'lsap.cpp', 'py
 
 # Per-file code generation flags.  netsq.hip: MFMA results in ordinary VGPRs -- its kernels are bound by vector-instruction issue and every
 # accumulator parked in an AGPR costs a v_accvgpr_read before the requantisation (3144 of them in the file's kernels without the flag).
-EXTRA = ({'netsq.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form'], 'netsq_front.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form'], 'mars_tail.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form'],
+EXTRA = ({'netsq.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form'], 'netsq_front.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form'], 'netsq_mid.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form'], 'mars_tail.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form'],
           'mars_pair.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form']}
          if os.environ.get('DD_NO_VGPR_FORM') != '1' else {})
 

@@ -48,4 +48,6 @@ int netq_run_op(dd_net *net, int op_index, const int32_t *o, const uint8_t *inpu
 // csrc/netsq_front.hip: the first three ops of a uint8 SSD-MobileNet-v1 program (first layer, blocks 1 and 2) as one launch; *ran = 0: not this
 // program / geometry / quantisation -- run the ops one by one
 int netq_run_front(dd_net *net, const int32_t *o0, const int32_t *o1, const int32_t *o2, const uint8_t *input, int nimg, hipStream_t s, int *ran);
+// csrc/netsq_mid.hip: two consecutive block ops (MobileNet blocks 3 and 4 of a uint8 SSD-MobileNet-v1 program) as one launch; *ran = 0: not those
+int netq_run_mid(dd_net *net, const int32_t *o3, const int32_t *o4, int nimg, hipStream_t s, int *ran);
 int netq_prepare(dd_net *net);           // after dd_net_create allocated the buffers: borders of the uint8 tensors

@@ -31,7 +31,7 @@ enum { OP_INPUT = 1, OP_CONV = 2, OP_DWCONV = 3, OP_MAXPOOL = 4, OP_UPSAMPLE = 5
 enum { ACT_NONE = 0, ACT_RELU6 = 1, ACT_ELU = 2, ACT_SILU = 3, ACT_RELU = 4, ACT_SIGMOID = 5 };
 enum { EPI_F16 = 0, EPI_F32 = 1, EPI_SSD_HEAD = 2, EPI_YOLO = 3 };
 // dd_net_op_launches: 0 = the op's own kernel, 1 = no launch (folded into the next op's), else the fused / special kernel
-enum { OPK_DEFAULT = 0, OPK_FOLDED = 1, OPK_POOL_ROWS = 2, OPK_POOL_ROWS_STEM = 3, OPK_RES_UNIT = 4, OPK_SSD_FRONT = 5, OPK_C64_ROWS = 6, OPK_S2_ROWS = 7, OPK_CONV_WS = 8, OPK_WS_DW = 9, OPK_DWPW_ROWS = 10, OPK_SSD_HEAD_DEC = 11, OPK_RES_PAIR = 12, OPK_YOLO_HEAD_DEC = 13, OPK_MARS_WS = 14, OPK_FOLDED_PREV = 15, OPK_MARS_PAIR = 16, OPK_C64_STRIPS = 18, OPK_Q_FRONT = 19 };   // (17: q_dwm_k, csrc/netsq.hip; 19: q_front_k, csrc/netsq_front.hip)
+enum { OPK_DEFAULT = 0, OPK_FOLDED = 1, OPK_POOL_ROWS = 2, OPK_POOL_ROWS_STEM = 3, OPK_RES_UNIT = 4, OPK_SSD_FRONT = 5, OPK_C64_ROWS = 6, OPK_S2_ROWS = 7, OPK_CONV_WS = 8, OPK_WS_DW = 9, OPK_DWPW_ROWS = 10, OPK_SSD_HEAD_DEC = 11, OPK_RES_PAIR = 12, OPK_YOLO_HEAD_DEC = 13, OPK_MARS_WS = 14, OPK_FOLDED_PREV = 15, OPK_MARS_PAIR = 16, OPK_C64_STRIPS = 18, OPK_Q_FRONT = 19, OPK_Q_MID = 20 };   // (17: q_dwm_k, csrc/netsq.hip; 19: q_front_k, csrc/netsq_front.hip; 20: q_mid_k, csrc/netsq_mid.hip)
 enum { DT_F16 = 0, DT_F32 = 1, DT_U8 = 2 };
 
 constexpr int OP_WORDS = 48;       // int32 words per op record (see deepdish_amd/nets.py)
@@ -4687,6 +4687,7 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
     };
     auto run_ws = [&](ConvP &P) { return P.cin == 256 ? launch_conv_ws<4>(s, P, net->ctx->device) : launch_conv_ws<8>(s, P, net->ctx->device); };
     int first_op = 0;
+    bool mid_on = false;
     {
         // uint8 SSD: the first three launches (first layer, MobileNet blocks 1 and 2) over chunks of frames that REUSE the image slots 0 .. chunk - 1
         // of the two tensors between them, so that 0.72 + 1.44 MB per frame of producer -> consumer traffic can stay in the 256 MB Infinity
@@ -4699,6 +4700,10 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
         // every forward: a test flips them between two forwards of one engine.
         const char *front_env = getenv("DD_Q_FRONT"), *front_min_env = getenv("DD_Q_FRONT_MIN");
         const int front_min = front_min_env ? atoi(front_min_env) : 24;
+        {   // blocks 3 + 4 as one launch (csrc/netsq_mid.hip), taken in the op loop below: DD_Q_MID=0 the two launches; same batch threshold
+            const char *mid_env = getenv("DD_Q_MID");
+            mid_on = !(mid_env && atoi(mid_env) == 0) && nimg >= front_min;
+        }
         if (!(front_env && atoi(front_env) == 0) && chunk_env <= 0 && nimg >= front_min && net->n_ops > 3 && opw(0)[0] == 16 && opw(1)[0] == 19 && opw(2)[0] == 19) {
             if (net->profile) for (int k = 0; k < 3; ++k) DD_HIP(hipEventRecord(net->events[k], s));
             int ran = 0;
@@ -4733,6 +4738,14 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
         const TensorDesc *ts = src >= 0 ? &net->tensors[src] : nullptr;
         const TensorDesc *td = dst >= 0 ? &net->tensors[dst] : nullptr;
         DD_REQUIRE(!input_pending || (kind == OP_CONV && i == input_op + 1), DD_E_STATE, "dd_net_forward: input op %d was folded into an op that did not take it", input_op);
+        if (mid_on && kind == 19 && i + 1 < net->n_ops && net->prog[net->ops_off + (size_t)(i + 1) * OP_WORDS] == 19) {   // two uint8 block ops: blocks 3 + 4 as one launch?
+            const int32_t *o4 = net->prog.data() + net->ops_off + (size_t)(i + 1) * OP_WORDS;
+            if (net->profile) DD_HIP(hipEventRecord(net->events[i + 1], s));
+            int ran = 0;
+            const int rc = netq_run_mid(net, o, o4, nimg, s, &ran);
+            if (rc != DD_OK) return rc;
+            if (ran) { net->op_launch[i] = OPK_FOLDED; net->op_launch[i + 1] = OPK_Q_MID; ++i; continue; }
+        }
         if (pair_pending && kind != OP_CONV) { const int rc = flush_pair(); if (rc != DD_OK) return rc; }
         if (pw_pending && kind != OP_DWCONV) {
             pw_pending = false; net->op_launch[i - 1] = OPK_CONV_WS;

@@ -29,7 +29,7 @@ def net_op_times(net):
 
 # dd_net_op_launches codes (include/deepdish_hip.h)
 OPK_FOLDED = 1
-OPK_NAMES = {2: 'conv3x3_pool_rows_k', 3: 'conv3x3_pool_rows_k<STEM>', 4: 'res_unit_rows_k', 5: 'ssd_front_k', 6: 'conv3x3_c64_rows_k', 7: 'conv3x3_s2_rows_k', 8: 'conv_ws_k', 9: 'conv_ws_dw_k', 10: 'dwpw_rows_k', 11: 'conv_glds_k<ssd_head_decode>', 12: 'res_pair_rows_k', 13: 'conv_glds_k<yolo_head_decode>', 14: 'mars_ws128_k', 16: 'mars_pair64_k', 17: 'q_dwm_k', 18: 'conv3x3_c64_rows_k<strips>', 19: 'q_front_k'}
+OPK_NAMES = {2: 'conv3x3_pool_rows_k', 3: 'conv3x3_pool_rows_k<STEM>', 4: 'res_unit_rows_k', 5: 'ssd_front_k', 6: 'conv3x3_c64_rows_k', 7: 'conv3x3_s2_rows_k', 8: 'conv_ws_k', 9: 'conv_ws_dw_k', 10: 'dwpw_rows_k', 11: 'conv_glds_k<ssd_head_decode>', 12: 'res_pair_rows_k', 13: 'conv_glds_k<yolo_head_decode>', 14: 'mars_ws128_k', 16: 'mars_pair64_k', 17: 'q_dwm_k', 18: 'conv3x3_c64_rows_k<strips>', 19: 'q_front_k', 20: 'q_mid_k'}
 OPK_FOLDED_PREV = 15      # the op ran inside the PREVIOUS op's launch (a 1x1 stride-2 projection beside its block's 3x3 stride-2 layer)
 
 

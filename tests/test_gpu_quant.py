@@ -77,7 +77,8 @@ def test_every_layer_is_bit_exact(qnet):
 
 
 def test_front_row_pipeline_is_bit_exact(qnet, monkeypatch):
-    """First layer + blocks 1 and 2 as ONE launch (csrc/netsq_front.hip, the default from 24 frames per forward; forced here): block 2's
+    """First layer + blocks 1 and 2 as ONE launch, blocks 3 and 4 as another (csrc/netsq_front.hip, csrc/netsq_mid.hip: the default from 24
+    frames per forward; forced here): block 2's
     tensor and everything behind it against the oracle, borders included; the two tensors the launch keeps in LDS are not readable; the
     three-launch form gives the same bytes.  Frame counts that end a workgroup's row range inside a frame and at a frame's edge."""
     from deepdish_amd import netsq
@@ -87,13 +88,13 @@ def test_front_row_pipeline_is_bit_exact(qnet, monkeypatch):
     fr = _frames(7, 17)
     fr[2] = 0
     fr[5] = 255
-    want_box, want_cls, kept = nets_quant.ssd_quant_forward(qm, fr, keep=['pw2', 'pw3', 'pw13'])
+    want_box, want_cls, kept = nets_quant.ssd_quant_forward(qm, fr, keep=['pw2', 'pw4', 'pw13'])
     monkeypatch.setenv('DD_Q_FRONT_MIN', '1')
     for n in (7, 1, 2, 3):
         net.forward(fr[:n])
         codes = net_op_launches(net)
-        assert list(codes[:3]) == [1, 1, 19], codes[:3]
-        for name in ('pw2', 'pw3', 'pw13'):
+        assert list(codes[:5]) == [1, 1, 19, 1, 20], codes[:5]          # ... and blocks 3 + 4 as one launch behind it (csrc/netsq_mid.hip)
+        for name in ('pw2', 'pw4', 'pw13'):
             t = _tensor_of(prog, name)
             d = prog.tensors[t]
             raw = net.read(tensor=t)
@@ -107,9 +108,23 @@ def test_front_row_pipeline_is_bit_exact(qnet, monkeypatch):
         net.read(tensor=_tensor_of(prog, 'conv0'))                         # never written by this forward
     with pytest.raises(Exception):
         net.read(tensor=_tensor_of(prog, 'pw1'))
-    monkeypatch.setenv('DD_Q_FRONT', '0')
+    with pytest.raises(Exception):
+        net.read(tensor=_tensor_of(prog, 'pw3'))
+    monkeypatch.setenv('DD_Q_MID', '0')                                    # the front end as one launch, blocks 3 and 4 as two
     net.forward(fr)
-    assert list(net_op_launches(net)[:3]) == [0, 0, 0]
+    assert list(net_op_launches(net)[:5]) == [1, 1, 19, 0, 0]
+    np.testing.assert_array_equal(net.read(tensor=prog.meta['box_tensor'])[:, :, 0, :], want_box)
+    d3 = prog.tensors[_tensor_of(prog, 'pw3')]
+    assert netsq.unpack_q16(net.read(tensor=_tensor_of(prog, 'pw3')), d3['h'], d3['w'], d3['c']).shape[0] == 7
+    monkeypatch.setenv('DD_Q_FRONT', '0')
+    monkeypatch.delenv('DD_Q_MID')                                         # ... and the other way round
+    net.forward(fr)
+    assert list(net_op_launches(net)[:5]) == [0, 0, 0, 1, 20]
+    np.testing.assert_array_equal(net.read(tensor=prog.meta['box_tensor'])[:, :, 0, :], want_box)
+    np.testing.assert_array_equal(net.read(tensor=prog.meta['cls_tensor'])[:, :, 0, :prog.meta['n_classes']], want_cls)
+    monkeypatch.setenv('DD_Q_MID', '0')
+    net.forward(fr)
+    assert list(net_op_launches(net)[:5]) == [0, 0, 0, 0, 0]
     np.testing.assert_array_equal(net.read(tensor=prog.meta['box_tensor'])[:, :, 0, :], want_box)
     np.testing.assert_array_equal(net.read(tensor=prog.meta['cls_tensor'])[:, :, 0, :prog.meta['n_classes']], want_cls)
     t = _tensor_of(prog, 'pw1')
@@ -166,7 +181,7 @@ def test_launch_of_many_frames_is_bit_exact(n_frames, symmetric):
     idx[[0, 1, n_frames // 2, n_frames - 1]] = [3, 2, 1, 0]
     net.forward(base[idx])
     from deepdish_amd.profile import net_op_launches
-    assert list(net_op_launches(net)[:3]) == ([1, 1, 19] if n_frames >= 24 else [0, 0, 0])     # the front end as one launch from 24 frames (csrc/netsq_front.hip)
+    assert list(net_op_launches(net)[:5]) == ([1, 1, 19, 1, 20] if n_frames >= 24 else [0, 0, 0, 0, 0])     # the front end and blocks 3 + 4 as one launch each from 24 frames (csrc/netsq_front.hip, netsq_mid.hip)
     box = net.read(tensor=prog.meta['box_tensor'])[:, :, 0, :]
     cls = net.read(tensor=prog.meta['cls_tensor'])[:, :, 0, :prog.meta['n_classes']]
     box_w, cls_w, _ = nets_quant.ssd_quant_forward(qm, base)
