@@ -131,6 +131,53 @@ def test_front_row_pipeline_is_bit_exact(qnet, monkeypatch):
     assert net.read(tensor=t).shape[0] == 7
 
 
+@pytest.mark.parametrize('variant', ['own_clamp', 'long_shift'])
+def test_row_pipelines_with_other_requantisation_parameters(variant, monkeypatch):
+    """The front end and blocks 3 + 4 (csrc/netsq_front.hip, netsq_mid.hip) pick their requantise-and-pack form from the layers' parameters:
+    byte-range clamps with shifts <= 8 (the synthetic model as it comes: every other test), byte-range clamps with longer shifts
+    ('long_shift': the weight scales of the first nine layers divided by 16, their biases multiplied by 16), and clamps of their own ('own_clamp': zero point 6 and a
+    coarser scale on the tensors between those layers, so lo = 6 and hi = 206).  Same integers as the oracle in each, fused and unfused."""
+    import copy
+    from deepdish_amd import quantize, netsq
+    from deepdish_amd.engine import Net
+    from deepdish_amd.profile import net_op_launches
+    from oracle import nets_quant
+    qm = copy.deepcopy(quantize.synthetic_ssd_quant_model(1234))
+    chain = ['conv0', 'dw1', 'pw1', 'dw2', 'pw2', 'dw3', 'pw3', 'dw4', 'pw4', 'dw5']
+    for a, b in zip(chain[:-1], chain[1:]):
+        La, Lb = qm['layers'][a], qm['layers'][b]
+        if variant == 'own_clamp':
+            La['out_zp'], La['out_scale'] = 6, np.float32(6.0 / 200.0)
+            Lb['in_zp'], Lb['in_scale'] = 6, np.float32(6.0 / 200.0)
+        else:                                                               # (biases scaled up with it, so that the tensors stay lively)
+            La['w_scale'] = np.float32(La['w_scale'] / 16.0)
+            La['bias'] = (La['bias'].astype(np.int64) * 16).astype(np.int32)
+    lo, hi = quantize.activation_range(qm['layers']['pw2'])
+    m, shift = quantize.conv_multiplier(qm['layers']['dw2'])
+    assert ((lo, hi) == (6, 206)) if variant == 'own_clamp' else ((lo, hi) == (0, 255) and -shift > 8)
+    prog = netsq.compile_ssd_mobilenet_quant(qm)
+    net = Net(prog, max_batch=4)
+    fr = _frames(3, 29)
+    want_box, want_cls, kept = nets_quant.ssd_quant_forward(qm, fr, keep=['pw2', 'pw4'])
+    monkeypatch.setenv('DD_Q_FRONT_MIN', '1')
+    for fused in (True, False):
+        if not fused:
+            monkeypatch.setenv('DD_Q_FRONT', '0')
+            monkeypatch.setenv('DD_Q_MID', '0')
+        net.forward(fr)
+        assert list(net_op_launches(net)[:5]) == ([1, 1, 19, 1, 20] if fused else [0, 0, 0, 0, 0])
+        for name in ('pw2', 'pw4'):
+            t = _tensor_of(prog, name)
+            d = prog.tensors[t]
+            raw = net.read(tensor=t)
+            got = netsq.unpack_q16(raw, d['h'], d['w'], d['c'])
+            assert int((got != kept[name]).sum()) == 0, (variant, fused, name)
+            assert (netsq.borders_q16(raw, d['h'], d['w'], d['c']) == d['zp']).all(), name
+        np.testing.assert_array_equal(net.read(tensor=prog.meta['box_tensor'])[:, :, 0, :], want_box)
+        np.testing.assert_array_equal(net.read(tensor=prog.meta['cls_tensor'])[:, :, 0, :prog.meta['n_classes']], want_cls)
+    assert len(np.unique(kept['pw4'])) > 8                                  # not a degenerate comparison
+
+
 def test_results_do_not_depend_on_the_launch(qnet):
     qm, prog, net = qnet
     fr = _frames(5, 3)
