@@ -451,8 +451,7 @@ __global__ __launch_bounds__(256) void q_dwm_k(const QDwmP P, const int n_items)
     const long long C = P.R.C;
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
-        const unsigned packed = 0x80808080u ^ q_pack4<SAT>(q_requant_relu(acc[f][0], M, C, sh), q_requant_relu(acc[f][1], M, C, sh),
-                                                             q_requant_relu(acc[f][2], M, C, sh), q_requant_relu(acc[f][3], M, C, sh), lo, hi);
+        const unsigned packed = 0x80808080u ^ q_requant_pack4<SAT ? 1 : 0>(acc[f][0], acc[f][1], acc[f][2], acc[f][3], M, C, C, C, C, sh, lo, hi);
         if (live[f]) *reinterpret_cast<unsigned *>(dst[f]) = packed;
     }
 }

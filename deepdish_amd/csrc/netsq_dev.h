@@ -46,54 +46,41 @@ __device__ __forceinline__ int q_clamp(int z, int lo, int hi) {                 
     return r;
 }
 
-// Two pairs of 16-bit values -> four bytes, each saturated to 0 .. 255: the second v_sat_pk_u8_i16 in its SDWA form writes its two bytes into the
-// upper half of the first one's result (dst_sel:WORD_1, the lower half preserved) -- no v_perm_b32 to merge the halves.
-__device__ __forceinline__ unsigned q_sat_pk4(unsigned p01, unsigned p23) {
-    unsigned q;
-    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(q) : "v"(p01));
-    asm("v_sat_pk_u8_i16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(q) : "v"(p23));
-    return q;
+// Four requantised values -> four bytes under the layer's own clamp (4 v_med3 + 3 v_lshl_or).
+__device__ __forceinline__ unsigned q_pack4(int z0, int z1, int z2, int z3, int lo, int hi) {
+    return (unsigned)q_clamp(z0, lo, hi) | (unsigned)q_clamp(z1, lo, hi) << 8 | (unsigned)q_clamp(z2, lo, hi) << 16 | (unsigned)q_clamp(z3, lo, hi) << 24;
 }
 
-// Four requantised values -> four bytes.  SAT (the layer's clamp is the whole byte range, as ReLU6 at scale 6/255 makes it): saturating
-// packs do clamp and pack in 5 instructions (v_cvt_pk_i16_i32 x2, v_sat_pk_u8_i16 x2, v_perm_b32) instead of 4 v_med3 + 3 v_lshl_or.
-template <bool SAT>
-__device__ __forceinline__ unsigned q_pack4(int z0, int z1, int z2, int z3, int lo, int hi) {
-    if constexpr (SAT) {
-        unsigned p01, p23;
-        asm("v_cvt_pk_i16_i32 %0, %1, %2" : "=v"(p01) : "v"(z0), "v"(z1));
-        asm("v_cvt_pk_i16_i32 %0, %1, %2" : "=v"(p23) : "v"(z2), "v"(z3));
-        return q_sat_pk4(p01, p23);                  // bytes 0, 1 of each
-    } else {
-        return (unsigned)q_clamp(z0, lo, hi) | (unsigned)q_clamp(z1, lo, hi) << 8 | (unsigned)q_clamp(z2, lo, hi) << 16 | (unsigned)q_clamp(z3, lo, hi) << 24;
-    }
+// Shift right, saturate to 0 .. 255 and pack, two values per instruction (gfx950: v_ashr_pk_u8_i32 D, S0, S1, S2 writes sat_u8(S0 >> S2),
+// sat_u8(S1 >> S2) into the half of D that op_sel[3] names and keeps the other half): four values -> four bytes in TWO instructions, where
+// v_cvt_pk_i16_i32 x2, v_pk_ashrrev_i16 x2, v_sat_pk_u8_i16 x2 were six.  The operands are v_mad_i64_i32 results (ordinary vector results: an
+// MFMA destination read by inline assembly gets no wait states from hipcc, see csrc/image.hip).
+__device__ __forceinline__ unsigned q_ashr_sat_pk4(int h0, int h1, int h2, int h3, int sh) {
+    unsigned r;
+    asm("v_ashr_pk_u8_i32 %0, %1, %2, %3" : "=v"(r) : "v"(h0), "v"(h1), "s"(sh));
+    asm("v_ashr_pk_u8_i32 %0, %1, %2, %3 op_sel:[0,0,0,1]" : "+v"(r) : "v"(h2), "v"(h3), "s"(sh));
+    return r;
 }
 
 // Four accumulators -> four requantised bytes (ReLU-type layers, e >= 1): z = (x M + C) >> (32 + sh), clamped.  SAT: 0 = the layer's own clamp
-// (v_med3), 1 = the clamp is the byte range: saturating packs, 2 = that and sh <= 7: the shift moves behind the first pack, where one
-// v_pk_ashrrev_i16 serves two values -- exact, because the high word saturated to 16 bits still shifts to >= 255 (32767 >> 7) or below 0
-// exactly when the unsaturated one does.  14 -> 11 instructions per four values; these kernels are bound by instruction issue.
+// (v_med3 + shifts), 1 / 2 = the clamp is the byte range (ReLU6 at scale 6/255 makes it): the high words of the four 64-bit sums go through
+// q_ashr_sat_pk4 -- 4 + 2 instructions per four values (round 5: 14, round 6 with packed 16-bit shifts and the SDWA pack: 11); these kernels
+// are bound by instruction issue.
 template <int SAT>
 __device__ __forceinline__ unsigned q_requant_pack4(int x0, int x1, int x2, int x3, int M, long long C0, long long C1, long long C2, long long C3, int sh32, int lo, int hi) {
-    if constexpr (SAT == 2) {
+    if constexpr (SAT >= 1) {
         const int h0 = (int)(((long long)x0 * M + C0) >> 32), h1 = (int)(((long long)x1 * M + C1) >> 32);
         const int h2 = (int)(((long long)x2 * M + C2) >> 32), h3 = (int)(((long long)x3 * M + C3) >> 32);
-        const unsigned shpk = (unsigned)sh32 | (unsigned)sh32 << 16;
-        unsigned p01, p23;
-        asm("v_cvt_pk_i16_i32 %0, %1, %2" : "=v"(p01) : "v"(h0), "v"(h1));
-        asm("v_cvt_pk_i16_i32 %0, %1, %2" : "=v"(p23) : "v"(h2), "v"(h3));
-        asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(p01) : "s"(shpk), "v"(p01));
-        asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(p23) : "s"(shpk), "v"(p23));
-        return q_sat_pk4(p01, p23);
+        return q_ashr_sat_pk4(h0, h1, h2, h3, sh32);
     } else {
-        return q_pack4<SAT == 1>(q_requant_relu(x0, M, C0, sh32), q_requant_relu(x1, M, C1, sh32), q_requant_relu(x2, M, C2, sh32), q_requant_relu(x3, M, C3, sh32), lo, hi);
+        return q_pack4(q_requant_relu(x0, M, C0, sh32), q_requant_relu(x1, M, C1, sh32), q_requant_relu(x2, M, C2, sh32), q_requant_relu(x3, M, C3, sh32), lo, hi);
     }
 }
 
 // The same for a layer without activation (the SSD heads), clamp = the byte range, e >= 1: the literal two roundings
 //     y = (x M + 2^30) >> 31,   z = ((y + 2^(e-1) + (y >> 31)) >> e) + zo  =  (y + [2^(e-1) + (zo << e)] + (y >> 31)) >> e
-// with the bias in the 64-bit addend (C = cbias * M + 2^30 per channel) and the clamp in the saturating packs: 5 instructions per value
-// + 5 per four (q_requant's statement of the same arithmetic: 11 per value).
+// with the bias in the 64-bit addend (C = cbias * M + 2^30 per channel), shift and clamp in v_ashr_pk_u8_i32: 4 instructions per value
+// + 2 per four (q_requant's statement of the same arithmetic: 11 per value).
 __device__ __forceinline__ unsigned q_requant_linear_pack4(int x0, int x1, int x2, int x3, int M, long long C0, long long C1, long long C2, long long C3, int e, int k1) {
     int z[4];
     const int x[4] = {x0, x1, x2, x3};
@@ -101,12 +88,12 @@ __device__ __forceinline__ unsigned q_requant_linear_pack4(int x0, int x1, int x
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int y = (int)(((long long)x[i] * M + C[i]) >> 31);
-        z[i] = (y + k1 + (y >> 31)) >> e;
+        z[i] = y + k1 + (y >> 31);                           // the shift by e: in the pack
     }
-    unsigned p01, p23;
-    asm("v_cvt_pk_i16_i32 %0, %1, %2" : "=v"(p01) : "v"(z[0]), "v"(z[1]));
-    asm("v_cvt_pk_i16_i32 %0, %1, %2" : "=v"(p23) : "v"(z[2]), "v"(z[3]));
-    return q_sat_pk4(p01, p23);
+    unsigned r;                                              // (e may differ between the fragments of a wave's heads: a vector operand)
+    asm("v_ashr_pk_u8_i32 %0, %1, %2, %3" : "=v"(r) : "v"(z[0]), "v"(z[1]), "v"(e));
+    asm("v_ashr_pk_u8_i32 %0, %1, %2, %3 op_sel:[0,0,0,1]" : "+v"(r) : "v"(z[2]), "v"(z[3]), "v"(e));
+    return r;
 }
 
 __device__ __forceinline__ int sdot4(int a, int b, int c) {
