@@ -77,6 +77,27 @@ __device__ __forceinline__ unsigned q_requant_pack4(int x0, int x1, int x2, int 
     }
 }
 
+// The same with the bytes in the form the tensors store (a - 128, the matrix instructions' signed operands) and no XOR behind the pack: the caller's
+// 64-bit addend carries the - 128 (q_signed_c: C - 128 * 2^(32 + sh), exact -- a multiple of the shift's unit) and v_ashr_pk_i8_i32 saturates to
+// -128 .. 127 = clamp(z, 0, 255) - 128.  4 + 2 instructions per four bytes.  SAT = 0 (the layer's own clamp): q_requant_pack4 and the XOR, C unchanged.
+template <int SAT>
+__device__ __forceinline__ long long q_signed_c(long long C, int sh32) {
+    return SAT >= 1 ? C - (128ll << (32 + sh32)) : C;
+}
+template <int SAT>
+__device__ __forceinline__ unsigned q_requant_pack4s(int x0, int x1, int x2, int x3, int M, long long C0, long long C1, long long C2, long long C3, int sh32, int lo, int hi) {
+    if constexpr (SAT >= 1) {
+        const int h0 = (int)(((long long)x0 * M + C0) >> 32), h1 = (int)(((long long)x1 * M + C1) >> 32);
+        const int h2 = (int)(((long long)x2 * M + C2) >> 32), h3 = (int)(((long long)x3 * M + C3) >> 32);
+        unsigned r;
+        asm("v_ashr_pk_i8_i32 %0, %1, %2, %3" : "=v"(r) : "v"(h0), "v"(h1), "s"(sh32));
+        asm("v_ashr_pk_i8_i32 %0, %1, %2, %3 op_sel:[0,0,0,1]" : "+v"(r) : "v"(h2), "v"(h3), "s"(sh32));
+        return r;
+    } else {
+        return 0x80808080u ^ q_requant_pack4<0>(x0, x1, x2, x3, M, C0, C1, C2, C3, sh32, lo, hi);
+    }
+}
+
 // The same for a layer without activation (the SSD heads), clamp = the byte range, e >= 1: the literal two roundings
 //     y = (x M + 2^30) >> 31,   z = ((y + 2^(e-1) + (y >> 31)) >> e) + zo  =  (y + [2^(e-1) + (zo << e)] + (y >> 31)) >> e
 // with the bias in the 64-bit addend (C = cbias * M + 2^30 per channel), shift and clamp in v_ashr_pk_u8_i32: 4 instructions per value

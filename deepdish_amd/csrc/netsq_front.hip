@@ -114,7 +114,8 @@ __global__ __launch_bounds__(256, 2) void q_front_k(const QFrontP P, const int r
     const int Mp1 = P.Rp1.M, shp1 = P.Rp1.e - 1, lop1 = P.Rp1.lo, hip1 = P.Rp1.hi;
     const int Md2 = P.Rd2.M, shd2 = P.Rd2.e - 1, lod2 = P.Rd2.lo, hid2 = P.Rd2.hi;
     const int Mp2 = P.Rp2.M, shp2 = P.Rp2.e - 1, lop2 = P.Rp2.lo, hip2 = P.Rp2.hi;
-    const long long C0 = P.R0.C, Cd1 = P.Rd1.C, Cp1 = P.Rp1.C, Cd2 = P.Rd2.C, Cp2 = P.Rp2.C;
+    // (the stored bytes are a - 128: the addends carry it, see q_requant_pack4s)
+    const long long C0 = q_signed_c<SAT>(P.R0.C, sh0), Cd1 = q_signed_c<SAT>(P.Rd1.C, shd1), Cp1 = q_signed_c<SAT>(P.Rp1.C, shp1), Cd2 = q_signed_c<SAT>(P.Rd2.C, shd2), Cp2 = q_signed_c<SAT>(P.Rp2.C, shp2);
     const unsigned zin4 = (unsigned)P.in_zp * 0x01010101u;
     const u4v z0v = {(unsigned)P.zp0 * 0x01010101u, (unsigned)P.zp0 * 0x01010101u, (unsigned)P.zp0 * 0x01010101u, (unsigned)P.zp0 * 0x01010101u};
     const u4v z1v = {(unsigned)P.zp1 * 0x01010101u, (unsigned)P.zp1 * 0x01010101u, (unsigned)P.zp1 * 0x01010101u, (unsigned)P.zp1 * 0x01010101u};
@@ -173,8 +174,8 @@ __global__ __launch_bounds__(256, 2) void q_front_k(const QFrontP P, const int r
                 i4v acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(wb, b, cb0b, 0, 0, 0);
                 if constexpr (NZA) acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(wal, b, acc0, 0, 0, 0);
                 if constexpr (NZB) acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(wbl, b, acc1, 0, 0, 0);
-                const unsigned lo = 0x80808080u ^ q_requant_pack4<SAT>(acc0[0], acc0[1], acc0[2], acc0[3], M0, C0, C0, C0, C0, sh0, lo0, hi0);
-                const unsigned hi = 0x80808080u ^ q_requant_pack4<SAT>(acc1[0], acc1[1], acc1[2], acc1[3], M0, C0, C0, C0, C0, sh0, lo0, hi0);
+                const unsigned lo = q_requant_pack4s<SAT>(acc0[0], acc0[1], acc0[2], acc0[3], M0, C0, C0, C0, C0, sh0, lo0, hi0);
+                const unsigned hi = q_requant_pack4s<SAT>(acc1[0], acc1[1], acc1[2], acc1[3], M0, C0, C0, C0, C0, sh0, lo0, hi0);
                 if (i < 4 || ok6) *reinterpret_cast<uint2 *>(dst + (fq >> 1) * F_PP + (x + 1) * 16 + (fq & 1) * 8) = make_uint2(lo, hi);
             }
         };
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void q_front_k(const QFrontP P, const int r
             }
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
-                const unsigned packed = 0x80808080u ^ q_requant_pack4<SAT>(acc[f][0], acc[f][1], acc[f][2], acc[f][3], Md, Cd, Cd, Cd, Cd, shd, lod, hid);
+                const unsigned packed = q_requant_pack4s<SAT>(acc[f][0], acc[f][1], acc[f][2], acc[f][3], Md, Cd, Cd, Cd, Cd, shd, lod, hid);
                 *reinterpret_cast<unsigned *>(tile + f * 256) = packed;
                 if (dup_off) *reinterpret_cast<unsigned *>(tile + f * 256 + dup_off) = packed;
             }
@@ -276,8 +277,8 @@ __global__ __launch_bounds__(256, 2) void q_front_k(const QFrontP P, const int r
                 for (int i = 0; i < 5; ++i) {
                     const i4v a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(W1[0], b[i], cb1[0], 0, 0, 0);
                     const i4v a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(W1[1], b[i], cb1[1], 0, 0, 0);
-                    const unsigned o0 = 0x80808080u ^ q_requant_pack4<SAT>(a0[0], a0[1], a0[2], a0[3], Mp1, Cp1, Cp1, Cp1, Cp1, shp1, lop1, hip1);
-                    const unsigned o1 = 0x80808080u ^ q_requant_pack4<SAT>(a1[0], a1[1], a1[2], a1[3], Mp1, Cp1, Cp1, Cp1, Cp1, shp1, lop1, hip1);
+                    const unsigned o0 = q_requant_pack4s<SAT>(a0[0], a0[1], a0[2], a0[3], Mp1, Cp1, Cp1, Cp1, Cp1, shp1, lop1, hip1);
+                    const unsigned o1 = q_requant_pack4s<SAT>(a1[0], a1[1], a1[2], a1[3], Mp1, Cp1, Cp1, Cp1, Cp1, shp1, lop1, hip1);
                     const int x = 16 * (5 * h + i) + fr;
                     if (5 * h + i < 9 || fr < 6) *reinterpret_cast<uint2 *>(dst + fq * F_PP + (x + 1) * 16 + 8 * wh) = make_uint2(o0, o1);
                 }
@@ -297,8 +298,8 @@ __global__ __launch_bounds__(256, 2) void q_front_k(const QFrontP P, const int r
                 i4v a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(W2[1], b[f], cb2[1], 0, 0, 0);
                 if constexpr (NZA) a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(W2l[0], b[f], a0, 0, 0, 0);
                 if constexpr (NZB) a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(W2l[1], b[f], a1, 0, 0, 0);
-                const unsigned o0 = 0x80808080u ^ q_requant_pack4<SAT>(a0[0], a0[1], a0[2], a0[3], Mp2, Cp2, Cp2, Cp2, Cp2, shp2, lop2, hip2);
-                const unsigned o1 = 0x80808080u ^ q_requant_pack4<SAT>(a1[0], a1[1], a1[2], a1[3], Mp2, Cp2, Cp2, Cp2, Cp2, shp2, lop2, hip2);
+                const unsigned o0 = q_requant_pack4s<SAT>(a0[0], a0[1], a0[2], a0[3], Mp2, Cp2, Cp2, Cp2, Cp2, shp2, lop2, hip2);
+                const unsigned o1 = q_requant_pack4s<SAT>(a1[0], a1[1], a1[2], a1[3], Mp2, Cp2, Cp2, Cp2, Cp2, shp2, lop2, hip2);
                 const int x = 16 * f + fr;
                 if (f < 4 || fr < 11) *reinterpret_cast<uint2 *>(dst + (x + 1) * 16) = make_uint2(o0, o1);
             }

@@ -100,7 +100,8 @@ __global__ __launch_bounds__(1024) void q_mid_k(const QMidP P, const int rows_to
     const int Mp3 = P.Rp3.M, shp3 = P.Rp3.e - 1, lop3 = P.Rp3.lo, hip3 = P.Rp3.hi;
     const int Md4 = P.Rd4.M, shd4 = P.Rd4.e - 1, lod4 = P.Rd4.lo, hid4 = P.Rd4.hi;
     const int Mp4 = P.Rp4.M, shp4 = P.Rp4.e - 1, lop4 = P.Rp4.lo, hip4 = P.Rp4.hi;
-    const long long Cd3 = P.Rd3.C, Cp3 = P.Rp3.C, Cd4 = P.Rd4.C, Cp4 = P.Rp4.C;
+    // (the stored bytes are a - 128: the addends carry it, see q_requant_pack4s)
+    const long long Cd3 = q_signed_c<SAT>(P.Rd3.C, shd3), Cp3 = q_signed_c<SAT>(P.Rp3.C, shp3), Cd4 = q_signed_c<SAT>(P.Rd4.C, shd4), Cp4 = q_signed_c<SAT>(P.Rp4.C, shp4);
     const u4v z3v = {(unsigned)P.zp3 * 0x01010101u, (unsigned)P.zp3 * 0x01010101u, (unsigned)P.zp3 * 0x01010101u, (unsigned)P.zp3 * 0x01010101u};
 
     // ring3: every byte the zero point (the border columns keep it: pointwise 3 writes interiors only)
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(1024) void q_mid_k(const QMidP P, const int rows_to
             }
 #pragma unroll
             for (int f = 0; f < NF; ++f)
-                *reinterpret_cast<unsigned *>(tile + f * 256) = 0x80808080u ^ q_requant_pack4<SAT>(acc[f][0], acc[f][1], acc[f][2], acc[f][3], Md, Cd, Cd, Cd, Cd, shd, lod, hid);
+                *reinterpret_cast<unsigned *>(tile + f * 256) = q_requant_pack4s<SAT>(acc[f][0], acc[f][1], acc[f][2], acc[f][3], Md, Cd, Cd, Cd, Cd, shd, lod, hid);
         };
         // ---- depthwise 3: block-3 row y = 2t + wj, plane w8, five fragments: ring_in -> opnd3
         auto dw3_stage = [&](int t) __attribute__((always_inline)) {
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(1024) void q_mid_k(const QMidP P, const int rows_to
             uint8_t *const d4 = dst + (4 * (w8 >> 2) + fq) * M_PP + 4 * (w8 & 3) + (fr + 1) * 16;
 #pragma unroll
             for (int f = 0; f < 5; ++f) {
-                const unsigned o = 0x80808080u ^ q_requant_pack4<SAT>(acc[f][0], acc[f][1], acc[f][2], acc[f][3], Mp3, Cp3, Cp3, Cp3, Cp3, shp3, lop3, hip3);
+                const unsigned o = q_requant_pack4s<SAT>(acc[f][0], acc[f][1], acc[f][2], acc[f][3], Mp3, Cp3, Cp3, Cp3, Cp3, shp3, lop3, hip3);
                 if (f < 4 || fr < 11) *reinterpret_cast<unsigned *>(d4 + f * 256) = o;      // (pixels 64 .. 74 of 75 in the last fragment)
             }
         };
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(1024) void q_mid_k(const QMidP P, const int rows_to
             uint8_t *const dst = P.out + ((size_t)((n * (M_S4 + 2) + r + 1) * 16 + 4 * (wave >> 2) + fq) * M_PPO + 4 * (wave & 3) + (fr + 1) * 16);
 #pragma unroll
             for (int f = 0; f < 3; ++f) {
-                const unsigned o = 0x80808080u ^ q_requant_pack4<SAT>(acc[f][0], acc[f][1], acc[f][2], acc[f][3], Mp4, Cp4, Cp4, Cp4, Cp4, shp4, lop4, hip4);
+                const unsigned o = q_requant_pack4s<SAT>(acc[f][0], acc[f][1], acc[f][2], acc[f][3], Mp4, Cp4, Cp4, Cp4, Cp4, shp4, lop4, hip4);
                 if (f < 2 || fr < 6) *reinterpret_cast<unsigned *>(dst + f * 256) = o;      // (pixels 32 .. 37 of 38 in the last fragment)
             }
         };
