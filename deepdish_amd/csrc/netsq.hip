@@ -53,6 +53,12 @@ struct QConvP {
     int zwc;                                      // 128 - zw
     unsigned hw_magic, wo_magic;                  // floor(2^32 / d) + 1 for ho * wo and wo; hw_magic = 0: not exact for this launch (plain divisions)
     QReq R;
+    // QEPI_ROWS, two predictors on one feature map in one launch (as q_pws_k; the small feature maps and small batches run here): fragments
+    // [n_frag_a, n_mfrag) -- the wave items' groups [groups_a, n_mgroups) -- belong to the second one, with its own requantisation, weight zero
+    // point and destination rows.  A group never holds fragments of both.
+    int n_frag_a, groups_a;                       // 0: one layer
+    uint8_t *out_b; long long img_bytes_b; int row_bytes_b, base_off_b, cout_store_b, zwc_b;
+    QReq Rb;
 };
 
 // One wave item = MQ 16-channel fragments x NPF (2 or 4) 16-pixel fragments; operands straight from L2 / HBM in fragment shape (Q16 is
@@ -92,7 +98,11 @@ __global__ __launch_bounds__(256) void q_conv_k(const QConvP P, const int n_item
     for (int j = 0; j < NPF; ++j) rs[j] = 0;
     const int ksteps = P.kh * P.kw * P.kc_per_tap;
     const int ks_lo = SPLIT > 1 ? wave * (ksteps / SPLIT) : 0, ks_hi = SPLIT > 1 ? ks_lo + ksteps / SPLIT : ksteps;     // this wave's k steps
-    const i4v *wp = P.w + ((size_t)mg * MQ * ksteps) * 64 + lane;
+    // (wave-uniform) the group's first fragment, the end of its predictor's fragments
+    const bool is_b = P.n_frag_a != 0 && mg >= P.groups_a;
+    const int frag0 = is_b ? P.n_frag_a + (mg - P.groups_a) * MQ : mg * MQ;
+    const int frag_end = P.n_frag_a != 0 && !is_b ? P.n_frag_a : P.n_mfrag;
+    const i4v *wp = P.w + ((size_t)frag0 * ksteps) * 64 + lane;
     // k step ks = (tap, 64-channel slice): the operands of step ks + 1 are requested before the MFMAs of step ks are issued (a step's
     // loads followed by its own MFMAs left every step waiting out an L2 round trip: 36 of them in a 3x3 layer with 256 channels)
     auto step_off = [&](int ks, bool &kv) -> size_t {
@@ -110,7 +120,7 @@ __global__ __launch_bounds__(256) void q_conv_k(const QConvP P, const int n_item
             if (!kv) bb[j] = i4v{0, 0, 0, 0};
         }
 #pragma unroll
-        for (int m = 0; m < MQ; ++m) aa[m] = (mg * MQ + m) < P.n_mfrag ? wp[((size_t)m * ksteps + ks) * 64] : i4v{0, 0, 0, 0};
+        for (int m = 0; m < MQ; ++m) aa[m] = frag0 + m < frag_end ? wp[((size_t)m * ksteps + ks) * 64] : i4v{0, 0, 0, 0};
     };
     i4v b0[NPF], a0[MQ], b1[NPF], a1[MQ];
     if constexpr (!PIPE) {                                          // launches with thousands of wave items per CU: the waves cover each other's round trips,
@@ -183,7 +193,7 @@ __global__ __launch_bounds__(256) void q_conv_k(const QConvP P, const int n_item
         for (int j = 0; j < NPF; ++j) {
             rs[j] += __shfl_xor(rs[j], 16, 64);
             rs[j] += __shfl_xor(rs[j], 32, 64);
-            rs[j] *= P.zwc;
+            rs[j] *= is_b ? P.zwc_b : P.zwc;
         }
     }
     if (P.epi == QEPI_Q16) {
@@ -210,18 +220,22 @@ __global__ __launch_bounds__(256) void q_conv_k(const QConvP P, const int n_item
             }
         }
     } else {
+        const QReq R = is_b ? P.Rb : P.R;
+        uint8_t *const out = is_b ? P.out_b : P.out;
+        const long long img_bytes = is_b ? P.img_bytes_b : P.img_bytes_out;
+        const int row_bytes = is_b ? P.row_bytes_b : P.row_bytes, base_off = is_b ? P.base_off_b : P.base_off, cout_store = is_b ? P.cout_store_b : P.cout_store;
 #pragma unroll
         for (int m = 0; m < MQ; ++m) {
-            const int ch = 16 * (mg * MQ + m) + 4 * fq;
-            if (ch >= P.cout_store) continue;
-            const i4v c = *reinterpret_cast<const i4v *>(P.cbias + ch);
+            const int ch = 16 * (frag0 + m - (is_b ? P.n_frag_a : 0)) + 4 * fq;          // the channel inside its predictor
+            if (frag0 + m >= frag_end || ch >= cout_store) continue;
+            const i4v c = *reinterpret_cast<const i4v *>(P.cbias + 16 * (frag0 + m) + 4 * fq);
 #pragma unroll
             for (int j = 0; j < NPF; ++j) {
                 unsigned wv = 0;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) wv |= (unsigned)q_requant(acc[m][j][r] + rs[j] + c[r], P.R) << (8 * r);
+                for (int r = 0; r < 4; ++r) wv |= (unsigned)q_requant(acc[m][j][r] + rs[j] + c[r], R) << (8 * r);
                 if (live[j]) {
-                    uint8_t *dst = P.out + (size_t)qn[j] * P.img_bytes_out + P.base_off + (size_t)(qy[j] * P.wo + qx[j]) * P.row_bytes + ch;
+                    uint8_t *dst = out + (size_t)qn[j] * img_bytes + base_off + (size_t)(qy[j] * P.wo + qx[j]) * row_bytes + ch;
                     *reinterpret_cast<unsigned *>(dst) = wv;
                 }
             }
@@ -1491,7 +1505,7 @@ int netq_run_op(dd_net *net, int i, const int32_t *o, const uint8_t *input, int 
             auto run_generic = [&](QConvP &P) -> int {
                 P.hw_magic = P.wo > 1 && (long long)P.m * (P.ho * P.wo) < (1ll << 32) ? (unsigned)((1ull << 32) / (unsigned)(P.ho * P.wo)) + 1u : 0u;   // (a divisor of 1 has no 32-bit magic)
                 P.wo_magic = (unsigned)((1ull << 32) / (unsigned)P.wo) + 1u;
-                const int n_mgroups = dd_ceil_div(P.n_mfrag, P.mq);
+                const int n_mgroups = P.n_frag_a ? P.groups_a + dd_ceil_div(P.n_mfrag - P.n_frag_a, P.mq) : dd_ceil_div(P.n_mfrag, P.mq);
                 // Pixel fragments per wave item.  Two by default; four (half the weight fetches per MFMA, twice the registers) where the launch has
                 // few wave items anyway and pixels enough -- measured per layer at 384 frames: extras 48 -> 38, 63 -> 39 us, 5x5 class predictor
                 // 23 -> 16 us, but 53 -> 65, 86 -> 95, 68 -> 78 us on the layers with 19 k+ items (b12 / b13 pointwise, 19x19 class predictor).
@@ -1503,7 +1517,7 @@ int netq_run_op(dd_net *net, int i, const int32_t *o, const uint8_t *input, int 
                 (void)items2;
                 const long long n_items = (long long)n_mgroups * dd_ceil_div(P.m, 16 * npf);
                 DD_REQUIRE(n_items < (1ll << 31), DD_E_CAPACITY, "dd_net_forward: uint8 conv %d: %lld wave items", i, n_items);
-                const bool rsum = P.zwc != 0;
+                const bool rsum = P.zwc != 0 || (P.n_frag_a && P.zwc_b != 0);
                 const bool pipe = n_items < 8192;
                 static const int split_env = getenv("DD_Q_SPLITK") ? atoi(getenv("DD_Q_SPLITK")) : 1;
                 const bool split = split_env && P.kh * P.kw == 9 && n_items < 1024;       // (3x3: the k steps divide by the three filter rows; at 1 200 items the split costs: 40 -> 51 us)
@@ -1521,12 +1535,21 @@ int netq_run_op(dd_net *net, int i, const int32_t *o, const uint8_t *input, int 
                 return DD_OK;
             };
             if (n_frag_a == 0) return run_generic(P);
-            // two predictors, small batch: one launch each (the second one's fragments, constants and destination follow the first one's)
+            // two predictors outside q_pws_k's shapes (small feature maps, small batches): one launch, the second one's fragments, constants and
+            // destination rows chosen per wave item (DD_Q_HEADS_ONE=0: one launch each, the form until round 6 -- the same bits)
+            const TensorDesc *tb = &net->tensors[o[4]];
+            static const int heads_one = getenv("DD_Q_HEADS_ONE") ? atoi(getenv("DD_Q_HEADS_ONE")) : 1;
+            if (heads_one) {
+                P.mq = std::min(4, n_frag_a);
+                P.n_frag_a = n_frag_a; P.groups_a = dd_ceil_div(n_frag_a, P.mq);
+                P.out_b = base(o[4]); P.img_bytes_b = (long long)tb->h * tb->w * tb->cs; P.row_bytes_b = o[23]; P.base_off_b = o[24]; P.cout_store_b = o[25];
+                P.zwc_b = o[28]; P.Rb = Rb;
+                return run_generic(P);
+            }
             QConvP P2 = P;
             P.n_mfrag = n_frag_a; P.mq = std::min(4, P.n_mfrag);
             int rc2 = run_generic(P);
             if (rc2 != DD_OK) return rc2;
-            const TensorDesc *tb = &net->tensors[o[4]];
             P2.w = P.w + (size_t)n_frag_a * (P.kh * P.kw * P.kc_per_tap) * 64; P2.cbias = P.cbias + 16 * n_frag_a;
             P2.n_mfrag -= n_frag_a; P2.mq = std::min(4, P2.n_mfrag);
             P2.out = base(o[4]); P2.img_bytes_out = (long long)tb->h * tb->w * tb->cs; P2.row_bytes = o[23]; P2.base_off = o[24]; P2.cout_store = o[25];

@@ -37,6 +37,7 @@ def test_uint8_ssd_forward_switches_give_the_same_bits():
     vector ALU, the front end (first layer + blocks 1 / 2) as three launches instead of the row pipeline."""
     base = _sha('time_forward.py', ['ssd_i8', 96], {})
     for env in ({'DD_Q_PWS': '0'}, {'DD_Q_MERGE_HEADS': '0'}, {'DD_Q_QT128': '0'}, {'DD_Q_SPLITK': '0'}, {'DD_Q_DUP32': '0'}, {'DD_Q_FUSE': '0'}, {'DD_Q_SPLIT_PW': '0'}, {'DD_Q_DW_VALU': '1'}, {'DD_Q_FRONT': '0'}, {'DD_Q_MID': '0'}, {'DD_Q_FRONT': '0', 'DD_Q_MID': '0'},
+                {'DD_Q_HEADS_ONE': '0'},                               # the two predictors of a small feature map as two launches of the generic kernel instead of one
                 {'DD_Q_FRONT_CHUNK': '40'}):                         # first layer + blocks 1 / 2 over chunks of 40 frames that reuse the intermediate image slots (96 = 40 + 40 + 16)
         assert _sha('time_forward.py', ['ssd_i8', 96], env) == base, env
 
