@@ -4182,7 +4182,8 @@ bool mars_proj_follows(const dd_net *net, int i, const ConvP &P) {   // op i + 1
 // kernels, so a crop's feature does not depend on which ran).  Ops i .. i + n - 1 must be: [3x3 stride-2 32 -> 64 ELU on a 31x15 map; 1x1
 // stride-2 projection of another 31x15 tensor;] or [3x3 64 -> 64 ELU on 16x8;] then 3x3 64 -> 64, no activation, residual = the projection /
 // a 16x8x64 tensor, second output with its affine.  Returns the number of ops (3 or 2) and fills Q, or 0.
-int mars_pair_match(const dd_net *net, int i, int nimg, char *const *bufs, MarsPairP &Q, bool &first) {
+int mars_pair_match(const dd_net *net, int i, int nimg, MarsPairP &Q, bool &first) {
+    void *const *bufs = net->bufs.data();
     static const bool off = getenv("DD_MARS_PAIR") && atoi(getenv("DD_MARS_PAIR")) == 0;
     static const int min_crops = getenv("DD_MARS_PAIR_MIN") ? atoi(getenv("DD_MARS_PAIR_MIN")) : 256;
     if (off || nimg < min_crops) return 0;
@@ -4802,9 +4803,7 @@ static int net_run_ops(dd_net *net, const uint8_t *input, int nimg, hipStream_t 
                     break;
                 }
                 if (o[30] == 3 || o[30] == 4) {
-                    std::vector<char *> bp(net->bufs.size());
-                    for (size_t b = 0; b < bp.size(); ++b) bp[b] = static_cast<char *>(net->bufs[b]);
-                    const int n_ops = mars_pair_match(net, i, nimg, bp.data(), pair64, pair64_first);
+                    const int n_ops = mars_pair_match(net, i, nimg, pair64, pair64_first);
                     if (n_ops) { DD_NO_PENDING(); pair_left = n_ops - 1; net->op_launch[i] = OPK_FOLDED; break; }
                 }
 #undef DD_NO_PENDING
