@@ -2,8 +2,7 @@
 // against 2 556 / 2 537 / 2 549 us for the SSD forward of 768 frames, same box (profiles/r06_ab_requant.txt).  It was built into the library as
 // csrc/netsq_b512.hip with `int netq_run_b512(const NetqB512 &, int nimg, hipStream_t, int device, int *ran)` declared in csrc/net_priv.h and called
 // from csrc/netsq.hip's OP_QDWPW case for cin = cout = 512, stride 1.  What it shows: with one barrier per tile, no barrier around the row ring and
-// the two stages of a wave on different tiles, a tile still costs 14-15 k cycles -- the block is at its instruction sum once an i8 MFMA is priced at
-// the 19.7 cycles two waves per SIMD sustain, not waiting for its barriers.
+// the two stages of a wave on different tiles, a tile still costs 14-15 k cycles -- the block is at its instruction sum, not waiting for its barriers.
 //
 // uint8 SSD-MobileNet-v1, the 512 -> 512 MobileNet blocks (7-11: depthwise 3x3 stride 1 + pointwise at 19 x 19): q_dwpw_k's arithmetic and packed
 // operands (csrc/netsq.hip), same bits, ONE barrier per 64-pixel tile instead of two.
