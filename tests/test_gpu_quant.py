@@ -236,6 +236,37 @@ def test_launch_of_many_frames_is_bit_exact(n_frames, symmetric):
         assert (box[z] == box_w[idx[z]]).all() and (cls[z] == cls_w[idx[z]]).all(), 'slot %d (frame %d)' % (z, idx[z])
 
 
+@pytest.mark.parametrize('zero_point_of', ['box', 'cls'])
+def test_merged_predictors_with_mixed_weight_zero_points(zero_point_of):
+    """The class and box predictors of a feature map run as ONE launch -- of q_pws_k from 8 192 pixels per launch, of q_conv_k below (round 6;
+    csrc/netsq.hip) -- and each fragment picks its predictor's requantisation, destination rows and weight zero point.  Here only ONE of the
+    two has a weight zero point other than 128 (so exactly one of them needs the activation row sums): 23 frames put the 19x19 map on q_pws_k
+    and the five smaller maps on q_conv_k; four frames put all six on q_conv_k.  Same integers as the oracle, slot by slot."""
+    import copy
+    from deepdish_amd import quantize, netsq
+    from deepdish_amd.engine import Net
+    from oracle import nets_quant
+    qm = copy.deepcopy(quantize.synthetic_ssd_quant_model(1234))
+    changed = 0
+    for name, L in qm['layers'].items():
+        if name.startswith(zero_point_of) and name[len(zero_point_of):].isdigit():
+            L['w_zp'] = 128
+            changed += 1
+    assert changed == 6
+    prog = netsq.compile_ssd_mobilenet_quant(qm)
+    base = _frames(4, 33)
+    box_w, cls_w, _ = nets_quant.ssd_quant_forward(qm, base)
+    for n_frames in (23, 4):
+        net = Net(prog, max_batch=n_frames)
+        idx = np.arange(n_frames) % 4
+        net.forward(base[idx])
+        box = net.read(tensor=prog.meta['box_tensor'])[:, :, 0, :]
+        cls = net.read(tensor=prog.meta['cls_tensor'])[:, :, 0, :prog.meta['n_classes']]
+        for z in range(n_frames):
+            assert (box[z] == box_w[idx[z]]).all() and (cls[z] == cls_w[idx[z]]).all(), '%d frames, slot %d (frame %d)' % (n_frames, z, idx[z])
+    assert len(np.unique(cls_w)) > 8 and len(np.unique(box_w)) > 8
+
+
 def test_plugin_loads_a_tflite_file(tmp_path):
     """SSD_MOBILENET(model_file='....tflite') as deepdish.py:491-495 constructs it: a uint8 model written to disk in the interchange format
     gives the detections of the same model handed over in memory."""
